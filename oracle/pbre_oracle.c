@@ -1,0 +1,896 @@
+/* pbre_oracle.c -- TEST INFRASTRUCTURE ONLY (see pbre_oracle.h header comment).
+ *
+ * PARITY UNPINNED for physics: restates Bullet3's btMultiBodyDynamicsWorld step
+ * (third-party `pybullet`, unpinned in reference requirements.txt:2; not present in
+ * /root/reference) from its published algorithm.  Call sites restated:
+ *   p.stepSimulation                 panda_push_gym_env.py:236 (+133,140,148), panda_reach_gym_env.py:220
+ *   p.setJointMotorControl2          panda_env.py:74-77 (reset gains), :305-310 (step gains)
+ *   p.getLinkState/getJointStates    panda_env.py:147,187
+ *   p.getBasePositionAndOrientation  world_env.py:114
+ *   p.getEulerFromQuaternion / getQuaternionFromEuler / invertTransform / multiplyTransforms
+ *                                    panda_push_gym_env.py:168-174
+ * Glue restated (pinned by tests/golden): panda_push_gym_env.py:105-360,
+ * panda_reach_gym_env.py:105-313, world_env.py:145-176, utils.py:11-14.
+ *
+ * Formulation: Featherstone articulated-body algorithm in link coordinates
+ * (spatial vectors [angular; linear]), one impulse-response ABA pass per
+ * constraint row (Bullet: calcAccelerationDeltasMultiDof), velocity-level
+ * constraint rows, projected Gauss-Seidel in Bullet's row order, semi-implicit
+ * Euler.  The device path (csrc/) uses a different but mathematically
+ * equivalent formulation (world-frame RNEA + CRBA + explicit inverse), so
+ * agreement between the two is a genuine cross-check.
+ */
+#include "pbre_oracle.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------ small math */
+static void m3_mul(const real* A, const real* B, real* C) {
+    real t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        real s = 0; for (int k = 0; k < 3; k++) s += A[i*3+k] * B[k*3+j];
+        t[i*3+j] = s;
+    }
+    memcpy(C, t, sizeof t);
+}
+static void m3_T(const real* A, real* B) {
+    real t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[i*3+j] = A[j*3+i];
+    memcpy(B, t, sizeof t);
+}
+static void m3_v(const real* A, const real* v, real* o) {
+    real t[3];
+    for (int i = 0; i < 3; i++) t[i] = A[i*3]*v[0] + A[i*3+1]*v[1] + A[i*3+2]*v[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+static void m3T_v(const real* A, const real* v, real* o) {
+    real t[3];
+    for (int i = 0; i < 3; i++) t[i] = A[i]*v[0] + A[3+i]*v[1] + A[6+i]*v[2];
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+}
+static void cross(const real* a, const real* b, real* o) {
+    real t0 = a[1]*b[2] - a[2]*b[1], t1 = a[2]*b[0] - a[0]*b[2], t2 = a[0]*b[1] - a[1]*b[0];
+    o[0] = t0; o[1] = t1; o[2] = t2;
+}
+static real dot3(const real* a, const real* b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+static real norm3(const real* a) { return (real)sqrt((double)dot3(a, a)); }
+static void axis_angle(const real* a, real th, real* R) { /* Rodrigues */
+    real c = (real)cos((double)th), s = (real)sin((double)th), C = 1 - c;
+    R[0] = c + a[0]*a[0]*C;      R[1] = a[0]*a[1]*C - a[2]*s; R[2] = a[0]*a[2]*C + a[1]*s;
+    R[3] = a[1]*a[0]*C + a[2]*s; R[4] = c + a[1]*a[1]*C;      R[5] = a[1]*a[2]*C - a[0]*s;
+    R[6] = a[2]*a[0]*C - a[1]*s; R[7] = a[2]*a[1]*C + a[0]*s; R[8] = c + a[2]*a[2]*C;
+}
+static void quat_to_R(const real* q, real* R) { /* (x,y,z,w), local->world */
+    real x = q[0], y = q[1], z = q[2], w = q[3];
+    R[0] = 1 - 2*(y*y + z*z); R[1] = 2*(x*y - w*z);     R[2] = 2*(x*z + w*y);
+    R[3] = 2*(x*y + w*z);     R[4] = 1 - 2*(x*x + z*z); R[5] = 2*(y*z - w*x);
+    R[6] = 2*(x*z - w*y);     R[7] = 2*(y*z + w*x);     R[8] = 1 - 2*(x*x + y*y);
+}
+static void quat_mul(const real* a, const real* b, real* o) {
+    real t[4];
+    t[0] = a[3]*b[0] + a[0]*b[3] + a[1]*b[2] - a[2]*b[1];
+    t[1] = a[3]*b[1] - a[0]*b[2] + a[1]*b[3] + a[2]*b[0];
+    t[2] = a[3]*b[2] + a[0]*b[1] - a[1]*b[0] + a[2]*b[3];
+    t[3] = a[3]*b[3] - a[0]*b[0] - a[1]*b[1] - a[2]*b[2];
+    memcpy(o, t, sizeof t);
+}
+/* btMatrix3x3::getRotation [EXT-UNVERIFIED, standard Shepperd branches] */
+static void R_to_quat(const real* R, real* q) {
+    real tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        real s = (real)sqrt((double)(tr + 1));
+        q[3] = s * (real)0.5; s = (real)0.5 / s;
+        q[0] = (R[7] - R[5]) * s; q[1] = (R[2] - R[6]) * s; q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = R[0] < R[4] ? (R[4] < R[8] ? 2 : 1) : (R[0] < R[8] ? 2 : 0);
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        real s = (real)sqrt((double)(R[i*3+i] - R[j*3+j] - R[k*3+k] + 1));
+        real t[4];
+        t[i] = s * (real)0.5; s = (real)0.5 / s;
+        t[3] = (R[k*3+j] - R[j*3+k]) * s;
+        t[j] = (R[j*3+i] + R[i*3+j]) * s;
+        t[k] = (R[k*3+i] + R[i*3+k]) * s;
+        memcpy(q, t, sizeof t);
+    }
+}
+/* pybullet.getQuaternionFromEuler / getEulerFromQuaternion [EXT-UNVERIFIED] */
+void orc_quat_from_euler(const real e[3], real q[4]) {
+    double hr = e[0] * 0.5, hp = e[1] * 0.5, hy = e[2] * 0.5;
+    double cr = cos(hr), sr = sin(hr), cp = cos(hp), sp = sin(hp), cy = cos(hy), sy = sin(hy);
+    q[0] = (real)(sr*cp*cy - cr*sp*sy);
+    q[1] = (real)(cr*sp*cy + sr*cp*sy);
+    q[2] = (real)(cr*cp*sy - sr*sp*cy);
+    q[3] = (real)(cr*cp*cy + sr*sp*sy);
+}
+void orc_euler_from_quat(const real q[4], real e[3]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double sqx = x*x, sqy = y*y, sqz = z*z, squ = w*w;
+    double sarg = -2.0 * (x*z - w*y);
+    if (sarg <= -0.99999) { e[0] = 0; e[1] = (real)(-0.5*PI); e[2] = (real)(2*atan2(x, -y)); }
+    else if (sarg >= 0.99999) { e[0] = 0; e[1] = (real)(0.5*PI); e[2] = (real)(2*atan2(-x, y)); }
+    else {
+        e[0] = (real)atan2(2*(y*z + w*x), squ - sqx - sqy + sqz);
+        e[1] = (real)asin(sarg);
+        e[2] = (real)atan2(2*(x*y + w*z), squ + sqx - sqy - sqz);
+    }
+}
+
+/* ------------------------------------------------------------------ model */
+int orc_sizeof_real(void) { return (int)sizeof(real); }
+
+int orc_model_from_table(const double* t, size_t n, orc_model* m) {
+    memset(m, 0, sizeof *m);
+    if (n < 24 || t[0] != 1346523717.0 || t[1] != 1.0) return -1;
+    m->nl = (int)t[2]; m->ndof = (int)t[3]; m->ee_link = (int)t[4]; m->ns = (int)t[5];
+    if (m->nl > ORC_MAXL || m->ndof > ORC_MAXD || m->ns > ORC_MAXS) return -2;
+    if (n < (size_t)(24 + m->nl * 40 + m->ns * 8)) return -3;
+    for (int i = 0; i < 3; i++) m->base_pos[i] = (real)t[6+i];
+    for (int i = 0; i < 9; i++) m->base_R[i] = (real)t[9+i];
+    m->fixed_base = (int)t[18];
+    for (int i = 0; i < m->nl; i++) {
+        const double* r = t + 24 + i * 40;
+        m->parent[i] = (int)r[0]; m->jtype[i] = (int)r[1];
+        for (int k = 0; k < 3; k++) { m->axis[i][k] = (real)r[2+k]; m->Xp[i][k] = (real)r[5+k]; m->com[i][k] = (real)r[18+k]; }
+        for (int k = 0; k < 9; k++) { m->XR[i][k] = (real)r[8+k]; m->inertia[i][k] = (real)r[21+k]; }
+        m->mass[i] = (real)r[17]; m->lower[i] = (real)r[30]; m->upper[i] = (real)r[31];
+        m->damping[i] = (real)r[32]; m->dof[i] = (int)r[33]; m->friction[i] = (real)r[34];
+        if (m->dof[i] >= 0) m->link_of_dof[m->dof[i]] = i;
+    }
+    for (int k = 0; k < m->ns; k++) {
+        const double* s = t + 24 + m->nl * 40 + k * 8;
+        m->s_link[k] = (int)s[0];
+        for (int c = 0; c < 3; c++) m->s_c[k][c] = (real)s[1+c];
+        m->s_r[k] = (real)s[4]; m->s_mu[k] = (real)s[5];
+    }
+    return 0;
+}
+
+void orc_default_params(orc_params* p) {
+    memset(p, 0, sizeof *p);
+    p->dt = 1.0 / 240.0;            /* panda_push_gym_env.py:39 */
+    p->gravity_z = -9.8;            /* :126 */
+    p->solver_iters = 150;          /* :122 */
+    p->erp = 0.2;                   /* Bullet contact/joint ERP default [EXT-UNVERIFIED] */
+    p->linear_slop = 1e-5;          /* [EXT-UNVERIFIED] */
+    p->contact_margin = 1e-3;       /* ~ contact breaking threshold of a 5 cm cube [EXT-UNVERIFIED] */
+    p->lin_damping = 0.04; p->ang_damping = 0.04;   /* btMultiBody defaults [EXT-UNVERIFIED] */
+    p->max_coord_vel = 100.0;       /* btMultiBody::m_maxCoordinateVelocity [EXT-UNVERIFIED] */
+    p->max_motor_impulse = 100000.0 / 240.0;  /* pybullet default force 1e5 * dt [EXT-UNVERIFIED] */
+    p->limit_max_impulse = 100.0;   /* btMultiBodyConstraint default [EXT-UNVERIFIED] */
+    /* pybullet_data/table/table.urdf at (0.85,0,0): top box 1.5 x 1.0 x 0.05 centred z=0.6 */
+    p->table_c[0] = 0.85; p->table_c[1] = 0.0; p->table_c[2] = 0.6;
+    p->table_h[0] = 0.75; p->table_h[1] = 0.5; p->table_h[2] = 0.025;
+    p->table_mu = 0.5; p->ground_z = 0.0;
+    /* cube_small.urdf: 0.05 m box, 0.1 kg, lateral friction 1.0, inertia from shape */
+    p->obj_h[0] = p->obj_h[1] = p->obj_h[2] = 0.025;
+    p->obj_mass = 0.1;
+    p->obj_inertia[0] = p->obj_inertia[1] = p->obj_inertia[2] = 0.1 * (0.05*0.05 + 0.05*0.05) / 12.0;
+    p->obj_mu = 1.0;
+    p->flags = 0;
+}
+
+/* ------------------------------------------------------------------ FK */
+void orc_fk(const orc_model* m, const real* q, real* R, real* p) {
+    for (int i = 0; i < m->nl; i++) {
+        const real* Rp = m->parent[i] < 0 ? m->base_R : R + 9 * m->parent[i];
+        const real* pp = m->parent[i] < 0 ? m->base_pos : p + 3 * m->parent[i];
+        real Rj[9], t[3], tmp[9];
+        real qi = m->dof[i] >= 0 ? q[m->dof[i]] : 0;
+        m3_mul(Rp, m->XR[i], tmp);
+        if (m->jtype[i] == 1) { axis_angle(m->axis[i], qi, Rj); m3_mul(tmp, Rj, R + 9*i); }
+        else memcpy(R + 9*i, tmp, sizeof tmp);
+        m3_v(Rp, m->Xp[i], t);
+        for (int k = 0; k < 3; k++) p[3*i+k] = pp[k] + t[k];
+        if (m->jtype[i] == 2) {
+            real aw[3]; m3_v(R + 9*i, m->axis[i], aw);
+            for (int k = 0; k < 3; k++) p[3*i+k] += aw[k] * qi;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ spatial algebra */
+typedef struct {
+    real E[9], r[3];          /* parent->link rotation, link origin in parent coords */
+    real S[6];                /* joint motion subspace in link coords */
+    real v[6], c[6];          /* spatial velocity, velocity-product acceleration */
+    real I[36];               /* rigid-body spatial inertia at link origin */
+    real IA[36], U[6], d;     /* articulated inertia, IA*S, S.U */
+    real pA[6], u, a[6];
+} lws;
+
+typedef struct {
+    lws L[ORC_MAXL];
+    real Rw[ORC_MAXL][9], pw[ORC_MAXL][3];
+} aba_ws;
+
+static void xm(const lws* L, const real* in, real* out) { /* motion transform parent->link */
+    real t[3], w[3], v[3];
+    cross(L->r, in, t);                       /* r x w */
+    m3_v(L->E, in, w);
+    t[0] = in[3] - t[0]; t[1] = in[4] - t[1]; t[2] = in[5] - t[2];
+    m3_v(L->E, t, v);
+    out[0] = w[0]; out[1] = w[1]; out[2] = w[2]; out[3] = v[0]; out[4] = v[1]; out[5] = v[2];
+}
+static void xf_T(const lws* L, const real* in, real* out) { /* force transform link->parent (X^T) */
+    real n[3], f[3], t[3];
+    m3T_v(L->E, in, n); m3T_v(L->E, in + 3, f);
+    cross(L->r, f, t);
+    out[0] = n[0] + t[0]; out[1] = n[1] + t[1]; out[2] = n[2] + t[2];
+    out[3] = f[0]; out[4] = f[1]; out[5] = f[2];
+}
+static void crm(const real* v, const real* m_, real* o) { /* v x m (motion) */
+    real a[3], b[3], c[3];
+    cross(v, m_, a); cross(v, m_ + 3, b); cross(v + 3, m_, c);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+static void crf(const real* v, const real* f, real* o) { /* v x* f (force) */
+    real a[3], b[3], c[3];
+    cross(v, f, a); cross(v + 3, f + 3, b); cross(v, f + 3, c);
+    o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+static void m6_v(const real* A, const real* v, real* o) {
+    real t[6];
+    for (int i = 0; i < 6; i++) { real s = 0; for (int k = 0; k < 6; k++) s += A[i*6+k] * v[k]; t[i] = s; }
+    memcpy(o, t, sizeof t);
+}
+static void build_X(const lws* L, real* X) { /* 6x6 motion transform */
+    real rx[9] = {0, -L->r[2], L->r[1], L->r[2], 0, -L->r[0], -L->r[1], L->r[0], 0};
+    real Erx[9]; m3_mul(L->E, rx, Erx);
+    memset(X, 0, 36 * sizeof(real));
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        X[i*6+j] = L->E[i*3+j]; X[(i+3)*6+(j+3)] = L->E[i*3+j]; X[(i+3)*6+j] = -Erx[i*3+j];
+    }
+}
+static void spatial_inertia(real mass, const real* com, const real* Ic, real* I) {
+    real cx[9] = {0, -com[2], com[1], com[2], 0, -com[0], -com[1], com[0], 0};
+    real cxT[9], cc[9];
+    m3_T(cx, cxT); m3_mul(cx, cxT, cc);
+    memset(I, 0, 36 * sizeof(real));
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        I[i*6+j] = Ic[i*3+j] + mass * cc[i*3+j];
+        I[i*6+3+j] = mass * cx[i*3+j];
+        I[(i+3)*6+j] = mass * cxT[i*3+j];
+    }
+    I[21] = I[28] = I[35] = mass;
+}
+
+/* configuration-dependent part: transforms, articulated inertias (pass 2 without forces) */
+static void aba_config(const orc_model* m, const real* q, aba_ws* w) {
+    orc_fk(m, q, &w->Rw[0][0], &w->pw[0][0]);
+    for (int i = 0; i < m->nl; i++) {
+        lws* L = &w->L[i];
+        real qi = m->dof[i] >= 0 ? q[m->dof[i]] : 0;
+        real Rloc[9];
+        if (m->jtype[i] == 1) { real Rj[9]; axis_angle(m->axis[i], qi, Rj); m3_mul(m->XR[i], Rj, Rloc); }
+        else memcpy(Rloc, m->XR[i], sizeof Rloc);
+        m3_T(Rloc, L->E);
+        for (int k = 0; k < 3; k++) L->r[k] = m->Xp[i][k];
+        if (m->jtype[i] == 2) { real ap[3]; m3_v(m->XR[i], m->axis[i], ap); for (int k = 0; k < 3; k++) L->r[k] += ap[k] * qi; }
+        memset(L->S, 0, sizeof L->S);
+        if (m->jtype[i] == 1) for (int k = 0; k < 3; k++) L->S[k] = m->axis[i][k];
+        if (m->jtype[i] == 2) for (int k = 0; k < 3; k++) L->S[3+k] = m->axis[i][k];
+        spatial_inertia(m->mass[i], m->com[i], m->inertia[i], L->I);
+        memcpy(L->IA, L->I, sizeof L->IA);
+    }
+    for (int i = m->nl - 1; i >= 0; i--) {
+        lws* L = &w->L[i];
+        real Ia[36];
+        memcpy(Ia, L->IA, sizeof Ia);
+        if (m->jtype[i] != 0) {
+            m6_v(L->IA, L->S, L->U);
+            L->d = 0; for (int k = 0; k < 6; k++) L->d += L->S[k] * L->U[k];
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Ia[a*6+b] -= L->U[a] * L->U[b] / L->d;
+        } else { memset(L->U, 0, sizeof L->U); L->d = 1; }
+        if (m->parent[i] >= 0) {
+            real X[36], T[36];
+            build_X(L, X);
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real s = 0; for (int k = 0; k < 6; k++) s += Ia[a*6+k] * X[k*6+b]; T[a*6+b] = s; }
+            lws* P = &w->L[m->parent[i]];
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real s = 0; for (int k = 0; k < 6; k++) s += X[k*6+a] * T[k*6+b]; P->IA[a*6+b] += s; }
+        }
+    }
+}
+
+/* force-dependent passes.  pA0[i]: bias force per link (link coords) or NULL; abase: base spatial accel */
+static void aba_solve(const orc_model* m, aba_ws* w, const real* tau, int use_vel, const real (*pA0)[6],
+                      const real* abase, real* qdd) {
+    for (int i = 0; i < m->nl; i++) {
+        lws* L = &w->L[i];
+        if (pA0) memcpy(L->pA, pA0[i], sizeof L->pA); else memset(L->pA, 0, sizeof L->pA);
+        if (!use_vel) memset(L->c, 0, sizeof L->c);
+    }
+    for (int i = m->nl - 1; i >= 0; i--) {
+        lws* L = &w->L[i];
+        real pa[6], Iac[6];
+        m6_v(L->IA, L->c, Iac);
+        if (m->jtype[i] != 0) {
+            real Sp = 0; for (int k = 0; k < 6; k++) Sp += L->S[k] * L->pA[k];
+            L->u = tau[m->dof[i]] - Sp;
+            /* Ia c = IA c - U (U.c)/d */
+            real Uc = 0; for (int k = 0; k < 6; k++) Uc += L->U[k] * L->c[k];
+            for (int k = 0; k < 6; k++) pa[k] = L->pA[k] + Iac[k] - L->U[k] * Uc / L->d + L->U[k] * L->u / L->d;
+        } else {
+            for (int k = 0; k < 6; k++) pa[k] = L->pA[k] + Iac[k];
+        }
+        if (m->parent[i] >= 0) {
+            real t[6]; xf_T(L, pa, t);
+            for (int k = 0; k < 6; k++) w->L[m->parent[i]].pA[k] += t[k];
+        }
+    }
+    for (int i = 0; i < m->nl; i++) {
+        lws* L = &w->L[i];
+        real ap[6];
+        if (m->parent[i] >= 0) xm(L, w->L[m->parent[i]].a, ap); else xm(L, abase, ap);
+        for (int k = 0; k < 6; k++) ap[k] += L->c[k];
+        if (m->jtype[i] != 0) {
+            real Ua = 0; for (int k = 0; k < 6; k++) Ua += L->U[k] * ap[k];
+            real qd2 = (L->u - Ua) / L->d;
+            qdd[m->dof[i]] = qd2;
+            for (int k = 0; k < 6; k++) L->a[k] = ap[k] + L->S[k] * qd2;
+        } else memcpy(L->a, ap, sizeof ap);
+    }
+}
+
+/* velocity pass + bias forces: gyroscopic, Bullet's per-link velocity damping
+ * f = m v_c (K + K|v_c|), n = I w (K + K|w|) [EXT-UNVERIFIED: btMultiBody.cpp DAMPING_K1/K2 = m_linearDamping] */
+static void aba_velocity(const orc_model* m, const orc_params* prm, const real* qd, aba_ws* w, real (*pA0)[6]) {
+    for (int i = 0; i < m->nl; i++) {
+        lws* L = &w->L[i];
+        real vp[6] = {0, 0, 0, 0, 0, 0}, vj[6];
+        if (m->parent[i] >= 0) xm(L, w->L[m->parent[i]].v, vp); else { real z[6] = {0,0,0,0,0,0}; xm(L, z, vp); }
+        real qdi = m->dof[i] >= 0 ? qd[m->dof[i]] : 0;
+        for (int k = 0; k < 6; k++) { vj[k] = L->S[k] * qdi; L->v[k] = vp[k] + vj[k]; }
+        crm(L->v, vj, L->c);
+        real Iv[6]; m6_v(L->I, L->v, Iv);
+        crf(L->v, Iv, pA0[i]);
+        /* damping on the COM velocity */
+        real vc[3], t[3];
+        cross(L->v, m->com[i], t);
+        for (int k = 0; k < 3; k++) vc[k] = L->v[3+k] + t[k];
+        real kl = (real)prm->lin_damping, ka = (real)prm->ang_damping;
+        real fl[3], na[3], Iw[3];
+        real sl = m->mass[i] * (kl + kl * norm3(vc));
+        for (int k = 0; k < 3; k++) fl[k] = sl * vc[k];
+        m3_v(m->inertia[i], L->v, Iw);
+        real sa = ka + ka * norm3(L->v);
+        for (int k = 0; k < 3; k++) na[k] = sa * Iw[k];
+        cross(m->com[i], fl, t);
+        for (int k = 0; k < 3; k++) { pA0[i][k] += na[k] + t[k]; pA0[i][3+k] += fl[k]; }
+    }
+}
+
+void orc_forward_dynamics(const orc_model* m, const orc_params* prm, const real* q, const real* qd,
+                          const real* tau_in, real* qdd) {
+    aba_ws* w = (aba_ws*)malloc(sizeof *w);
+    real pA0[ORC_MAXL][6], tau[ORC_MAXD];
+    aba_config(m, q, w);
+    aba_velocity(m, prm, qd, w, pA0);
+    for (int i = 0; i < m->nl; i++) if (m->dof[i] >= 0)
+        tau[m->dof[i]] = (tau_in ? tau_in[m->dof[i]] : 0) - m->damping[i] * qd[m->dof[i]];
+    real gb[3] = {0, 0, (real)(-prm->gravity_z)}, ab[6] = {0, 0, 0, 0, 0, 0};
+    m3T_v(m->base_R, gb, ab + 3);
+    aba_solve(m, w, tau, 1, pA0, ab, qdd);
+    free(w);
+}
+
+void orc_mass_matrix_inverse(const orc_model* m, const orc_params* prm, const real* q, real* Minv) {
+    (void)prm;
+    aba_ws* w = (aba_ws*)malloc(sizeof *w);
+    aba_config(m, q, w);
+    real ab[6] = {0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < m->ndof; j++) {
+        real tau[ORC_MAXD] = {0}, col[ORC_MAXD];
+        tau[j] = 1;
+        aba_solve(m, w, tau, 0, NULL, ab, col);
+        for (int i = 0; i < m->ndof; i++) Minv[i * m->ndof + j] = col[i];
+    }
+    free(w);
+}
+
+/* ------------------------------------------------------------------ collision */
+/* sphere vs oriented box.  Returns signed distance; n = world normal from box to sphere; pb = point on box */
+static real sphere_box(const real* sc, real sr, const real* bc, const real* Rb, const real* h, real* n, real* pb) {
+    real d[3], dl[3], cl[3], nl[3];
+    for (int k = 0; k < 3; k++) d[k] = sc[k] - bc[k];
+    m3T_v(Rb, d, dl);
+    int inside = 1;
+    for (int k = 0; k < 3; k++) {
+        cl[k] = dl[k] < -h[k] ? -h[k] : (dl[k] > h[k] ? h[k] : dl[k]);
+        if (cl[k] != dl[k]) inside = 0;
+    }
+    real dist;
+    real df[3] = {dl[0] - cl[0], dl[1] - cl[1], dl[2] - cl[2]};
+    real len = norm3(df);
+    if (len < (real)1e-9) inside = 1;   /* centre on/inside the surface: use the face-normal branch */
+    if (!inside) {
+        for (int k = 0; k < 3; k++) nl[k] = df[k] / len;
+        dist = len - sr;
+    } else {
+        int ax = 0; real best = h[0] - (real)fabs((double)dl[0]);
+        for (int k = 1; k < 3; k++) { real e = h[k] - (real)fabs((double)dl[k]); if (e < best) { best = e; ax = k; } }
+        nl[0] = nl[1] = nl[2] = 0; nl[ax] = dl[ax] >= 0 ? (real)1 : (real)-1;
+        cl[ax] = nl[ax] * h[ax];
+        dist = -best - sr;
+    }
+    m3_v(Rb, nl, n);
+    real t[3]; m3_v(Rb, cl, t);
+    for (int k = 0; k < 3; k++) pb[k] = bc[k] + t[k];
+    return dist;
+}
+
+/* support height under a world point: table top inside the footprint (unless the point is below the slab), else ground */
+static real support_height(const orc_params* p, const real* x) {
+    real top = (real)(p->table_c[2] + p->table_h[2]);
+    real bot = (real)(p->table_c[2] - p->table_h[2]);
+    int in = fabs((double)x[0] - p->table_c[0]) <= p->table_h[0] && fabs((double)x[1] - p->table_c[1]) <= p->table_h[1];
+    return (in && x[2] > bot) ? top : (real)p->ground_z;
+}
+
+typedef struct { int idx; real dist; real n[3], pA[3], pB[3]; int link; real mu; } cand_t;
+
+/* keep the `cap` smallest-distance candidates with dist < margin, then order by idx */
+static int select_contacts(cand_t* c, int n, int cap, real margin, cand_t* out) {
+    int used[32] = {0}, cnt = 0;
+    for (int s = 0; s < cap; s++) {
+        int best = -1;
+        for (int i = 0; i < n; i++) if (!used[i] && c[i].dist < margin && (best < 0 || c[i].dist < c[best].dist)) best = i;
+        if (best < 0) break;
+        used[best] = 1; cnt++;
+    }
+    int k = 0;
+    for (int i = 0; i < n; i++) if (used[i]) out[k++] = c[i];
+    return cnt;
+}
+
+/* ------------------------------------------------------------------ rows + PGS */
+typedef struct {
+    real jA[ORC_MAXD], bA[ORC_MAXD], jB[6], bB[6];
+    int useA, useB;
+    real rhs, dinv, lo, hi, app, mu;
+    int fidx;
+} row_t;
+
+static real resolve_row(row_t* r, real* dvA, real* dvB, int nd) {
+    /* btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric, cfm = 0 */
+    real delta = r->rhs, dot = 0;
+    if (r->useA) for (int k = 0; k < nd; k++) dot += r->jA[k] * dvA[k];
+    if (r->useB) for (int k = 0; k < 6; k++) dot += r->jB[k] * dvB[k];
+    delta -= dot * r->dinv;
+    real sum = r->app + delta;
+    if (sum < r->lo) { delta = r->lo - r->app; r->app = r->lo; }
+    else if (sum > r->hi) { delta = r->hi - r->app; r->app = r->hi; }
+    else r->app = sum;
+    if (r->useA) for (int k = 0; k < nd; k++) dvA[k] += r->bA[k] * delta;
+    if (r->useB) for (int k = 0; k < 6; k++) dvB[k] += r->bB[k] * delta;
+    return delta;
+}
+
+/* linear-velocity Jacobian row of world point p on link `link` projected on direction dir */
+static void point_jacobian(const orc_model* m, const aba_ws* w, int link, const real* p, const real* dir, real* J) {
+    for (int k = 0; k < m->ndof; k++) J[k] = 0;
+    for (int i = link; i >= 0; i = m->parent[i]) {
+        if (m->jtype[i] == 0) continue;
+        real aw[3]; m3_v(w->Rw[i], m->axis[i], aw);
+        if (m->jtype[i] == 1) {
+            real rr[3] = {p[0] - w->pw[i][0], p[1] - w->pw[i][1], p[2] - w->pw[i][2]}, t[3];
+            cross(aw, rr, t);
+            J[m->dof[i]] = dot3(dir, t);
+        } else J[m->dof[i]] = dot3(dir, aw);
+    }
+}
+
+void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const real* q_des, const real* kp,
+                  const real* kd, orc_step_info* info) {
+    const int nd = m->ndof;
+    const real dt = (real)prm->dt;
+    real* q = st; real* qd = st + 16;
+    real* op = st + 9; real* oq = st + 12; real* ov = st + 16 + 9; real* ow = st + 16 + 12;
+    const int obj_on = !(prm->flags & ORC_F_NO_OBJECT);
+    aba_ws* w = (aba_ws*)malloc(sizeof *w);
+    orc_step_info li; if (!info) info = &li;
+    memset(info, 0, sizeof *info);
+
+    /* 1. kinematics + articulated inertias at q_t */
+    aba_config(m, q, w);
+    real Ro[9]; quat_to_R(oq, Ro);
+
+    /* 2. collision detection at q_t (Bullet: performDiscreteCollisionDetection before the solve) */
+    cand_t sel[ORC_NC]; int nsel = 0, n_ot = 0, n_ro = 0, n_rt = 0;
+    real margin = (real)prm->contact_margin;
+    real oh[3] = {(real)prm->obj_h[0], (real)prm->obj_h[1], (real)prm->obj_h[2]};
+    real sc[ORC_MAXS][3];
+    for (int s = 0; s < m->ns; s++) {
+        real t[3]; m3_v(w->Rw[m->s_link[s]], m->s_c[s], t);
+        for (int k = 0; k < 3; k++) sc[s][k] = w->pw[m->s_link[s]][k] + t[k];
+    }
+    if (obj_on) {
+        cand_t c[8];
+        for (int v = 0; v < 8; v++) {
+            real l[3] = {(v & 1 ? oh[0] : -oh[0]), (v & 2 ? oh[1] : -oh[1]), (v & 4 ? oh[2] : -oh[2])}, x[3];
+            m3_v(Ro, l, x);
+            for (int k = 0; k < 3; k++) x[k] += op[k];
+            real hs = support_height(prm, x);
+            c[v].idx = v; c[v].dist = x[2] - hs; c[v].n[0] = 0; c[v].n[1] = 0; c[v].n[2] = 1;
+            for (int k = 0; k < 3; k++) { c[v].pA[k] = x[k]; c[v].pB[k] = x[k]; }
+            c[v].pB[2] = hs; c[v].link = -1; c[v].mu = (real)(prm->obj_mu * prm->table_mu);
+        }
+        n_ot = select_contacts(c, 8, ORC_NC_OT, margin, sel);
+        cand_t cs[ORC_MAXS];
+        for (int s = 0; s < m->ns; s++) {
+            cs[s].idx = s; cs[s].link = m->s_link[s]; cs[s].mu = (real)(m->s_mu[s] * prm->obj_mu);
+            cs[s].dist = sphere_box(sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
+            for (int k = 0; k < 3; k++) cs[s].pA[k] = cs[s].pB[k] + cs[s].n[k] * cs[s].dist;
+        }
+        n_ro = select_contacts(cs, m->ns, ORC_NC_RO, margin, sel + n_ot);
+    }
+    {
+        cand_t cs[ORC_MAXS];
+        real Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        real tc[3] = {(real)prm->table_c[0], (real)prm->table_c[1], (real)prm->table_c[2]};
+        real th[3] = {(real)prm->table_h[0], (real)prm->table_h[1], (real)prm->table_h[2]};
+        for (int s = 0; s < m->ns; s++) {
+            cs[s].idx = s; cs[s].link = m->s_link[s]; cs[s].mu = (real)(m->s_mu[s] * prm->table_mu);
+            cs[s].dist = sphere_box(sc[s], m->s_r[s], tc, Rt, th, cs[s].n, cs[s].pB);
+            for (int k = 0; k < 3; k++) cs[s].pA[k] = cs[s].pB[k] + cs[s].n[k] * cs[s].dist;
+        }
+        n_rt = select_contacts(cs, m->ns, ORC_NC_RT, margin, sel + n_ot + n_ro);
+    }
+    nsel = n_ot + n_ro + n_rt;
+
+    /* 3. unconstrained accelerations; v* = v + dt a (Bullet: solveExternalForces -> applyDeltaVee) */
+    real pA0[ORC_MAXL][6], tau[ORC_MAXD], qdd[ORC_MAXD], vs[ORC_MAXD], ovs[6];
+    aba_velocity(m, prm, qd, w, pA0);
+    for (int i = 0; i < m->nl; i++) if (m->dof[i] >= 0) tau[m->dof[i]] = -m->damping[i] * qd[m->dof[i]];
+    real gb[3] = {0, 0, (real)(-prm->gravity_z)}, ab[6] = {0, 0, 0, 0, 0, 0};
+    m3T_v(m->base_R, gb, ab + 3);
+    aba_solve(m, w, tau, 1, pA0, ab, qdd);
+    real mcv = (real)prm->max_coord_vel;
+    for (int k = 0; k < nd; k++) {
+        info->qdd[k] = qdd[k];
+        vs[k] = qd[k] + dt * qdd[k];
+        if (vs[k] > mcv) vs[k] = mcv; if (vs[k] < -mcv) vs[k] = -mcv;
+    }
+    real Iinv[9] = {0};
+    if (obj_on) {
+        real Il[3] = {(real)prm->obj_inertia[0], (real)prm->obj_inertia[1], (real)prm->obj_inertia[2]};
+        real RoT[9], D[9] = {1/Il[0], 0, 0, 0, 1/Il[1], 0, 0, 0, 1/Il[2]}, T[9];
+        m3_T(Ro, RoT); m3_mul(Ro, D, T); m3_mul(T, RoT, Iinv);
+        real Dm[9] = {Il[0], 0, 0, 0, Il[1], 0, 0, 0, Il[2]}, Iw[9];
+        m3_mul(Ro, Dm, T); m3_mul(T, RoT, Iw);
+        real kl = (real)prm->lin_damping, ka = (real)prm->ang_damping;
+        real acc[6], Lw[3], gy[3], tq[3];
+        real sl = kl + kl * norm3(ov);
+        acc[0] = -sl * ov[0]; acc[1] = -sl * ov[1]; acc[2] = (real)prm->gravity_z - sl * ov[2];
+        m3_v(Iw, ow, Lw); cross(ow, Lw, gy);
+        real sa = ka + ka * norm3(ow);
+        for (int k = 0; k < 3; k++) tq[k] = -gy[k] - sa * Lw[k];
+        m3_v(Iinv, tq, acc + 3);
+        for (int k = 0; k < 3; k++) { ovs[k] = ov[k] + dt * acc[k]; ovs[3+k] = ow[k] + dt * acc[3+k]; }
+        for (int k = 0; k < 6; k++) { info->obj_acc[k] = acc[k]; if (ovs[k] > mcv) ovs[k] = mcv; if (ovs[k] < -mcv) ovs[k] = -mcv; }
+    } else for (int k = 0; k < 6; k++) ovs[k] = 0;
+
+    /* 4. constraint rows */
+    row_t* nc = (row_t*)calloc(3 * ORC_MAXD, sizeof(row_t)); int n_nc = 0;    /* limits then motors */
+    row_t* rn = (row_t*)calloc(ORC_NC, sizeof(row_t));
+    row_t* rf = (row_t*)calloc(2 * ORC_NC, sizeof(row_t));
+    real zero_ab[6] = {0, 0, 0, 0, 0, 0};
+    int motor_row[ORC_MAXD];
+    /* joint limits: btMultiBodyJointLimitConstraint, created at URDF load before the motors [EXT-UNVERIFIED] */
+    for (int i = 0; i < m->nl; i++) {
+        if (m->dof[i] < 0) continue;
+        int j = m->dof[i];
+        for (int side = 0; side < 2; side++) {
+            real pen = side == 0 ? q[j] - m->lower[i] : m->upper[i] - q[j];
+            if (pen > 0) continue;
+            row_t* r = &nc[n_nc++];
+            real dir = side ? (real)-1 : (real)1;
+            r->useA = 1; r->jA[j] = dir;
+            aba_solve(m, w, r->jA, 0, NULL, zero_ab, r->bA);
+            r->dinv = 1 / (r->jA[j] * r->bA[j]);
+            real rel = dir * vs[j];
+            r->rhs = (-pen * (real)prm->erp / dt - rel) * r->dinv;
+            r->lo = 0; r->hi = (real)prm->limit_max_impulse;
+        }
+    }
+    /* joint motors: btMultiBodyJointMotor (POSITION_CONTROL): target velocity kp*(q_des-q)/dt + (1-kd)*v */
+    for (int i = 0; i < m->nl; i++) {
+        if (m->dof[i] < 0) continue;
+        int j = m->dof[i];
+        motor_row[j] = n_nc;
+        row_t* r = &nc[n_nc++];
+        r->useA = 1; r->jA[j] = 1;
+        aba_solve(m, w, r->jA, 0, NULL, zero_ab, r->bA);
+        r->dinv = 1 / r->bA[j];
+        real verr = kp[j] * (q_des[j] - q[j]) / dt - kd[j] * vs[j];
+        r->rhs = verr * r->dinv;
+        r->lo = -(real)prm->max_motor_impulse; r->hi = (real)prm->max_motor_impulse;
+    }
+    /* contacts: normal row + 2 friction rows (btPlaneSpace1 directions) */
+    for (int c = 0; c < nsel; c++) {
+        cand_t* cc = &sel[c];
+        int type = c < n_ot ? 0 : (c < n_ot + n_ro ? 1 : 2);
+        real t1[3], t2[3]; const real* n = cc->n;
+        if (fabs((double)n[2]) > 0.7071067811865475244) {
+            real a = n[1]*n[1] + n[2]*n[2], k = 1 / (real)sqrt((double)a);
+            t1[0] = 0; t1[1] = -n[2]*k; t1[2] = n[1]*k;
+            t2[0] = a*k; t2[1] = -n[0]*t1[2]; t2[2] = n[0]*t1[1];
+        } else {
+            real a = n[0]*n[0] + n[1]*n[1], k = 1 / (real)sqrt((double)a);
+            t1[0] = -n[1]*k; t1[1] = n[0]*k; t1[2] = 0;
+            t2[0] = -n[2]*t1[1]; t2[1] = n[2]*t1[0]; t2[2] = a*k;
+        }
+        const real* dirs[3] = {n, t1, t2};
+        for (int d = 0; d < 3; d++) {
+            row_t* r = d == 0 ? &rn[c] : &rf[2*c + d - 1];
+            const real* dir = dirs[d];
+            real rel = 0, denom = 0;
+            if (type == 0) {            /* A = object (+dir), B = static */
+                real rr[3] = {cc->pA[0] - op[0], cc->pA[1] - op[1], cc->pA[2] - op[2]}, t[3];
+                cross(rr, dir, t);
+                r->useB = 1;
+                for (int k = 0; k < 3; k++) { r->jB[k] = dir[k]; r->jB[3+k] = t[k]; }
+            } else {                    /* A = robot (+dir), B = object (-dir) or static */
+                r->useA = 1;
+                point_jacobian(m, w, cc->link, cc->pA, dir, r->jA);
+                aba_solve(m, w, r->jA, 0, NULL, zero_ab, r->bA);
+                if (type == 1) {
+                    real rr[3] = {cc->pB[0] - op[0], cc->pB[1] - op[1], cc->pB[2] - op[2]}, t[3];
+                    cross(rr, dir, t);
+                    r->useB = 1;
+                    for (int k = 0; k < 3; k++) { r->jB[k] = -dir[k]; r->jB[3+k] = -t[k]; }
+                }
+            }
+            if (r->useB) {
+                for (int k = 0; k < 3; k++) r->bB[k] = r->jB[k] / (real)prm->obj_mass;
+                m3_v(Iinv, r->jB + 3, r->bB + 3);
+                for (int k = 0; k < 6; k++) { rel += r->jB[k] * ovs[k]; denom += r->jB[k] * r->bB[k]; }
+            }
+            if (r->useA) for (int k = 0; k < nd; k++) { rel += r->jA[k] * vs[k]; denom += r->jA[k] * r->bA[k]; }
+            r->dinv = 1 / denom;
+            r->mu = cc->mu; r->fidx = c;
+            if (d == 0) {
+                /* btMultiBodyConstraintSolver::setupMultiBodyContactConstraint, restitution 0 */
+                real pen = cc->dist + (real)prm->linear_slop;
+                real perr = 0, verr = -rel;
+                if (pen > 0) verr -= pen / dt; else perr = -pen * (real)prm->erp / dt;
+                r->rhs = (perr + verr) * r->dinv; r->lo = 0; r->hi = (real)1e10;
+            } else { r->rhs = -rel * r->dinv; r->lo = -cc->mu; r->hi = cc->mu; }
+        }
+    }
+
+    /* 5. projected Gauss-Seidel, Bullet row order (btMultiBodyConstraintSolver::solveSingleIteration):
+     *    non-contact rows (order alternates with iteration parity), all normals, all frictions */
+    real dvA[ORC_MAXD] = {0}, dvB[6] = {0};
+    for (int it = 0; it < prm->solver_iters; it++) {
+        for (int j = 0; j < n_nc; j++) {
+            int idx = (it & 1) ? j : n_nc - 1 - j;
+            resolve_row(&nc[idx], dvA, dvB, nd);
+        }
+        for (int c = 0; c < nsel; c++) resolve_row(&rn[c], dvA, dvB, nd);
+        for (int f = 0; f < 2 * nsel; f++) {
+            real tot = rn[rf[f].fidx].app;
+            if (tot > 0) { rf[f].lo = -rf[f].mu * tot; rf[f].hi = rf[f].mu * tot; resolve_row(&rf[f], dvA, dvB, nd); }
+        }
+    }
+
+    /* 6. velocity update + position integration (stepPositionsMultiDof) */
+    for (int k = 0; k < nd; k++) {
+        real v = vs[k] + dvA[k];
+        if (v > mcv) v = mcv; if (v < -mcv) v = -mcv;
+        qd[k] = v; q[k] += dt * v;
+        info->motor_impulse[k] = nc[motor_row[k]].app;
+    }
+    if (obj_on) {
+        for (int k = 0; k < 6; k++) { real v = ovs[k] + dvB[k]; if (v > mcv) v = mcv; if (v < -mcv) v = -mcv; st[16 + 9 + k] = v; }
+        for (int k = 0; k < 3; k++) op[k] += dt * ov[k];
+        /* quaternion exponential-map update (btMultiBody pQuatUpdateFun, world-frame omega) [EXT-UNVERIFIED] */
+        real ang = norm3(ow), ax[3];
+        if (ang * dt > (real)(0.5 * PI * 0.5)) ang = (real)(0.5 * PI * 0.5) / dt;
+        real sc_;
+        if (ang < (real)0.001) sc_ = (real)0.5 * dt - dt*dt*dt * (real)0.020833333333 * ang * ang;
+        else sc_ = (real)sin(0.5 * (double)ang * (double)dt) / ang;
+        for (int k = 0; k < 3; k++) ax[k] = ow[k] * sc_;
+        real dq[4] = {ax[0], ax[1], ax[2], (real)cos((double)ang * (double)dt * 0.5)}, nq[4];
+        quat_mul(dq, oq, nq);
+        real nn = (real)sqrt((double)(nq[0]*nq[0] + nq[1]*nq[1] + nq[2]*nq[2] + nq[3]*nq[3]));
+        for (int k = 0; k < 4; k++) oq[k] = nq[k] / nn;
+    }
+    info->ncontacts = nsel;
+    for (int c = 0; c < nsel; c++) {
+        info->type[c] = c < n_ot ? 0 : (c < n_ot + n_ro ? 1 : 2);
+        info->link[c] = sel[c].link; info->idx[c] = sel[c].idx; info->dist[c] = sel[c].dist; info->mu[c] = sel[c].mu;
+        for (int k = 0; k < 3; k++) { info->n[c][k] = sel[c].n[k]; info->pA[c][k] = sel[c].pA[k]; info->pB[c][k] = sel[c].pB[k]; }
+        info->lambda_n[c] = rn[c].app; info->lambda_f1[c] = rf[2*c].app; info->lambda_f2[c] = rf[2*c+1].app;
+    }
+    free(nc); free(rn); free(rf); free(w);
+}
+
+/* ------------------------------------------------------------------ RNG */
+void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 16777216.0); }
+
+/* ------------------------------------------------------------------ task layer */
+void orc_default_task(orc_task* t, int task) {
+    memset(t, 0, sizeof *t);
+    t->task = task; t->max_steps = 1000;
+    t->target_dist_min = task == 0 ? 0.03 : 0.1;   /* panda_reach_gym_env.py:47, panda_push_gym_env.py:52 */
+    t->h_table = 0.625;
+    /* WorldEnv workspace = robot workspace x,y (panda_env.py:37) with z = [h, h+0.3] (world_env.py:72) */
+    t->ws_lim[0][0] = 0.3; t->ws_lim[0][1] = 0.65; t->ws_lim[1][0] = -0.3; t->ws_lim[1][1] = 0.3;
+    t->ws_lim[2][0] = 0.625; t->ws_lim[2][1] = 0.925;
+    const double home[9] = {0.0, -0.54, 0.0, -2.6, -0.30, 2.0, 1.0, 0.02, 0.02};  /* panda_env.py:19-23 */
+    for (int k = 0; k < 9; k++) t->home[k] = home[k];
+    t->act_scale = 0.05;                            /* panda_push_gym_env.py:225 */
+    t->kp_act = 0.5; t->kd_act = 1.0;               /* panda_env.py:308 */
+    t->kp_hold = 0.2; t->kd_hold = 1.0;             /* panda_env.py:76 */
+    t->n_act = 7; t->seed = 1234;
+}
+int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + m->ndof + 6 + 6 + (t->task == 1 ? 3 : 0); }
+
+static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, real* vlin) {
+    real R[ORC_MAXL*9], p[ORC_MAXL*3];
+    orc_fk(m, st, R, p);
+    int e = m->ee_link;
+    real c[3]; m3_v(R + 9*e, m->com[e], c);           /* getLinkState[0] is the link COM frame */
+    for (int k = 0; k < 3; k++) pos[k] = p[3*e+k] + c[k];
+    R_to_quat(R + 9*e, quat);
+    vlin[0] = vlin[1] = vlin[2] = 0;
+    for (int i = e; i >= 0; i = m->parent[i]) {
+        if (m->jtype[i] == 0) continue;
+        real aw[3], t[3]; m3_v(R + 9*i, m->axis[i], aw);
+        real qd = st[16 + m->dof[i]];
+        if (m->jtype[i] == 1) { real rr[3] = {pos[0]-p[3*i], pos[1]-p[3*i+1], pos[2]-p[3*i+2]}; cross(aw, rr, t); }
+        else { t[0] = aw[0]; t[1] = aw[1]; t[2] = aw[2]; }
+        for (int k = 0; k < 3; k++) vlin[k] += t[k] * qd;
+    }
+}
+
+void orc_observation(const orc_model* m, const orc_task* t, const real* st, real* obs) {
+    /* panda_env.py:141-193 + panda_push_gym_env.py:150-187 */
+    real pos[3], quat[4], vl[3], eu[3];
+    ee_state(m, st, pos, quat, vl);
+    orc_euler_from_quat(quat, eu);
+    int o = 0;
+    for (int k = 0; k < 3; k++) obs[o++] = pos[k];
+    for (int k = 0; k < 3; k++) obs[o++] = eu[k];
+    const real vmean[3] = {0, (real)0.01, 0}, vstd[3] = {(real)0.04, (real)0.07, (real)0.03};
+    for (int k = 0; k < 3; k++) obs[o++] = (vl[k] - vmean[k]) / vstd[k];
+    for (int k = 0; k < m->ndof; k++) obs[o++] = st[k];
+    real oe[3];
+    orc_euler_from_quat(st + 12, oe);
+    for (int k = 0; k < 3; k++) obs[o++] = st[9+k];
+    for (int k = 0; k < 3; k++) obs[o++] = oe[k];
+    /* object pose in the hand frame: invertTransform(ee_pos, quatFromEuler(ee_eul)) * (obj_pos, quatFromEuler(obj_eul)) */
+    real qh[4], qo[4], Rh[9], d[3], rel[3], qhi[4], qr[4], er[3];
+    orc_quat_from_euler(eu, qh); orc_quat_from_euler(oe, qo);
+    quat_to_R(qh, Rh);
+    for (int k = 0; k < 3; k++) d[k] = st[9+k] - pos[k];
+    m3T_v(Rh, d, rel);
+    qhi[0] = -qh[0]; qhi[1] = -qh[1]; qhi[2] = -qh[2]; qhi[3] = qh[3];
+    quat_mul(qhi, qo, qr);
+    orc_euler_from_quat(qr, er);
+    for (int k = 0; k < 3; k++) obs[o++] = rel[k];
+    for (int k = 0; k < 3; k++) obs[o++] = er[k];
+    if (t->task == 1) for (int k = 0; k < 3; k++) obs[o++] = st[32+k];
+}
+
+/* reward + termination; pre_increment=1 reproduces the in-loop `_termination()` + counter++ of apply_action
+ * (panda_push_gym_env.py:239-242) before the final `_termination()`/`_compute_reward()` of step (:252-253) */
+void orc_reward_done(const orc_model* m, const orc_task* t, real* st, int pre_increment, real* reward, real* done) {
+    real pos[3], quat[4], vl[3];
+    ee_state(m, st, pos, quat, vl);
+    real d1 = 0, d2 = 0;
+    for (int k = 0; k < 3; k++) { real a = pos[k] - st[9+k], b = st[9+k] - st[32+k]; d1 += a*a; d2 += b*b; }
+    d1 = (real)sqrt((double)d1); d2 = (real)sqrt((double)d2);
+    real dsucc = t->task == 1 ? d2 : d1;
+    int succ = dsucc <= (real)t->target_dist_min;
+    int cnt = (int)st[35], term = (int)st[36];
+    if (pre_increment) {
+        int d0 = succ || term || cnt > t->max_steps;
+        if (succ) term = 1;
+        if (!d0) cnt++;
+    }
+    if (succ) term = 1;
+    *done = (succ || term || cnt > t->max_steps) ? (real)1 : (real)0;
+    if (t->task == 1) { *reward = -d1 - d2; if (d2 <= (real)t->target_dist_min) *reward = (real)1000 + ((real)100 - d2 * 80); }
+    else { *reward = -d1; if (d1 <= (real)t->target_dist_min) *reward = (real)1000 + ((real)100 - d1 * 80); }
+    st[35] = (real)cnt; st[36] = (real)term;
+}
+
+static void hold_targets(const orc_task* t, int nd, real* qdes, real* kp, real* kd) {
+    for (int k = 0; k < nd; k++) { qdes[k] = (real)t->home[k]; kp[k] = (real)t->kp_hold; kd[k] = (real)t->kd_hold; }
+}
+
+void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
+                   real* st, real* obs) {
+    /* reset_simulation (panda_push_gym_env.py:117-148): robot at home, 100 steps, load world, 100 steps, 1 step */
+    const int nd = m->ndof;
+    memset(st, 0, ORC_STATE * sizeof(real));
+    for (int k = 0; k < nd; k++) st[k] = (real)t->home[k];
+    /* WorldEnv._sample_pose (world_env.py:145-176) */
+    real x_min = (real)t->ws_lim[0][0] + (real)0.05, x_max = (real)t->ws_lim[0][1] - (real)0.1;
+    real y_min = (real)t->ws_lim[1][0] + (real)0.05, y_max = (real)t->ws_lim[1][1] - (real)0.05;
+    real px = x_min + (real)0.5 * (x_max - x_min), py = y_min + (real)0.5 * (y_max - y_min);
+    real pz = (real)t->h_table + (real)0.07, yaw = (real)(0.25 * PI);
+    uint32_t r[4];
+    orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 0u, (uint32_t)t->seed, (uint32_t)(t->seed >> 32), r);
+    if (t->obj_pose_rnd_std > 0) {
+        real s = (real)t->obj_pose_rnd_std;
+        px += -s + 2 * s * u01(r[0]);
+        py += -s + 2 * s * u01(r[1]);
+        yaw = (real)(-0.25 * PI) + (real)(0.5 * PI) * u01(r[2]);
+    }
+    px = px < x_min ? x_min : (px > x_max ? x_max : px);
+    py = py < y_min ? y_min : (py > y_max ? y_max : py);
+    real e[3] = {0, 0, yaw};
+    st[9] = px; st[10] = py; st[11] = pz;
+    orc_quat_from_euler(e, st + 12);
+    real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
+    hold_targets(t, nd, qdes, kp, kd);
+    orc_params p1 = *prm; p1.flags |= ORC_F_NO_OBJECT;
+    for (int i = 0; i < 100; i++) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
+    for (int i = 0; i < 101; i++) orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
+    /* sample_tg_pose (panda_push_gym_env.py:333-360) */
+    if (t->task == 1) {
+        real tx_min = (real)t->ws_lim[0][0] + (real)0.07, tx_max = (real)t->ws_lim[0][1] - (real)0.07;
+        real ty_min = (real)t->ws_lim[1][0], ty_max = (real)t->ws_lim[1][1];
+        real tx = st[9] + (real)0.05, ty = st[10] + (real)0.05, tz = st[11];
+        if (t->tg_pose_rnd_std > 0) {
+            orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 1u, (uint32_t)t->seed, (uint32_t)(t->seed >> 32), r);
+            real u1 = (real)((r[0] >> 8) + 1) * (real)(1.0 / 16777216.0), u2 = u01(r[1]);
+            real rad = (real)sqrt(-2.0 * log((double)u1)) * (real)t->tg_pose_rnd_std;
+            tx = st[9] + rad * (real)cos(2 * PI * (double)u2);
+            ty = st[10] + rad * (real)sin(2 * PI * (double)u2);
+        }
+        tx = tx < tx_min ? tx_min : (tx > tx_max ? tx_max : tx);
+        ty = ty < ty_min ? ty_min : (ty > ty_max ? ty_max : ty);
+        st[32] = tx; st[33] = ty; st[34] = tz;
+    }
+    st[35] = 0; st[36] = 0; st[37] = (real)episode;
+    if (obs) orc_observation(m, t, st, obs);
+}
+
+void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, const real* action,
+                  real* obs, real* reward, real* done) {
+    /* step -> apply_action (panda_push_gym_env.py:189-242, joint control) */
+    const int nd = m->ndof;
+    real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
+    hold_targets(t, nd, qdes, kp, kd);
+    for (int k = 0; k < t->n_act; k++) {
+        int li = m->link_of_dof[k];
+        real tgt = st[k] + action[k] * (real)t->act_scale;                 /* :225-230 */
+        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);   /* panda_env.py:303 */
+        qdes[k] = tgt; kp[k] = (real)t->kp_act; kd[k] = (real)t->kd_act;
+    }
+    orc_params p = *prm;
+    if (t->task == 0) p.flags |= 0;   /* reach uses the same world; config 2 sets ORC_F_NO_OBJECT via prm */
+    orc_sim_step(m, &p, st, qdes, kp, kd, NULL);
+    orc_reward_done(m, t, st, 1, reward, done);
+    orc_observation(m, t, st, obs);
+}
+
+void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* t, int n, uint64_t env_id0,
+                     real* states, real* obs) {
+    int od = orc_obs_dim(t, m);
+    for (int e = 0; e < n; e++) orc_env_reset(m, prm, t, env_id0 + (uint64_t)e, 0, states + (size_t)e * ORC_STATE, obs ? obs + (size_t)e * od : NULL);
+}
+void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
+                    const real* actions, real* out) {
+    int od = orc_obs_dim(t, m);
+    for (int e = 0; e < n; e++) {
+        real* o = out + (size_t)e * (od + 2);
+        orc_env_step(m, prm, t, states + (size_t)e * ORC_STATE, actions + (size_t)e * t->n_act, o, o + od, o + od + 1);
+    }
+}

@@ -1,0 +1,134 @@
+/* pbre_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (double precision by default, -DORC_FLOAT for a float build)
+ * of the env.step() hot path of hsp-iit/pybullet-robot-envs for the Panda
+ * reach/push tasks.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (libpbre.so) never does.
+ *
+ * PARITY UNPINNED for the physics: the arithmetic of `p.stepSimulation()`
+ * lives in the third-party PyBullet/Bullet3 C++ extension (reference
+ * requirements.txt:2, unpinned; setup.py:35 hints pybullet==2.5.0), which is not
+ * vendored, not installed, and the reference ships no tests/golden vectors
+ * (SURVEY §8c).  This file restates Bullet's published multibody algorithm
+ * (Featherstone ABA -> constraint rows -> projected Gauss-Seidel -> semi-
+ * implicit Euler) from the call sites in the reference; every Bullet-internal
+ * choice is tagged [EXT-UNVERIFIED] in pbre_oracle.c.  The Python-glue part
+ * (observation layout, reward, termination, sampling) IS pinned: it is checked
+ * against vectors captured from the reference's own classes
+ * (tests/golden/, tools/make_golden.py).
+ */
+#ifndef PBRE_ORACLE_H
+#define PBRE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef ORC_FLOAT
+typedef float real;
+#else
+typedef double real;
+#endif
+
+#define ORC_MAXL 16      /* links (fixed joints kept as 0-DoF links) */
+#define ORC_MAXD 12      /* joint DoF */
+#define ORC_MAXS 16      /* collision spheres */
+#define ORC_NC_OT 4      /* object-table contact slots */
+#define ORC_NC_RO 2      /* robot-object contact slots */
+#define ORC_NC_RT 2      /* robot-table contact slots */
+#define ORC_NC (ORC_NC_OT + ORC_NC_RO + ORC_NC_RT)
+#define ORC_STATE 48     /* floats per env state record (see include/pbre.h) */
+
+typedef struct {
+    int nl, ndof, ee_link, ns, fixed_base;
+    real base_pos[3], base_R[9];
+    int parent[ORC_MAXL], jtype[ORC_MAXL], dof[ORC_MAXL];
+    real axis[ORC_MAXL][3], Xp[ORC_MAXL][3], XR[ORC_MAXL][9];
+    real mass[ORC_MAXL], com[ORC_MAXL][3], inertia[ORC_MAXL][9];
+    real lower[ORC_MAXL], upper[ORC_MAXL], damping[ORC_MAXL], friction[ORC_MAXL];
+    int s_link[ORC_MAXS];
+    real s_c[ORC_MAXS][3], s_r[ORC_MAXS], s_mu[ORC_MAXS];
+    int link_of_dof[ORC_MAXD];
+} orc_model;
+
+/* numeric parameters of the simulated scene + task; mirrors pbre_params in include/pbre.h */
+typedef struct {
+    double dt, gravity_z;
+    int solver_iters;
+    double erp, linear_slop, contact_margin;
+    double lin_damping, ang_damping, max_coord_vel;
+    double max_motor_impulse;      /* force * dt */
+    double limit_max_impulse;
+    double table_c[3], table_h[3]; /* table-top box centre / half extents */
+    double table_mu, ground_z;
+    double obj_h[3], obj_mass, obj_inertia[3], obj_mu;
+    int flags;                     /* ORC_F_* */
+} orc_params;
+
+#define ORC_F_NO_OBJECT 1   /* object frozen and contact-free (reset phase 1; reach config 2) */
+
+typedef struct {
+    int ncontacts;
+    int  type[ORC_NC];      /* 0 obj-table, 1 robot-obj, 2 robot-table */
+    int  link[ORC_NC], idx[ORC_NC];
+    real n[ORC_NC][3], pA[ORC_NC][3], pB[ORC_NC][3], dist[ORC_NC], mu[ORC_NC];
+    real lambda_n[ORC_NC], lambda_f1[ORC_NC], lambda_f2[ORC_NC];
+    real motor_impulse[ORC_MAXD];
+    real qdd[ORC_MAXD];          /* unconstrained joint accelerations (ABA) */
+    real obj_acc[6];
+    real residual;
+} orc_step_info;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int  orc_sizeof_real(void);
+int  orc_model_from_table(const double* tbl, size_t n, orc_model* m);
+void orc_default_params(orc_params* p);
+/* forward kinematics: world rotation (row-major 3x3) and origin of every link frame */
+void orc_fk(const orc_model* m, const real* q, real* R /*[nl][9]*/, real* p /*[nl][3]*/);
+/* joint-space mass matrix by ndof impulse-response ABA passes (tests) and bias accelerations */
+void orc_mass_matrix_inverse(const orc_model* m, const orc_params* prm, const real* q, real* Minv /*[ndof][ndof]*/);
+void orc_forward_dynamics(const orc_model* m, const orc_params* prm, const real* q, const real* qd,
+                          const real* tau, real* qdd);
+/* one stepSimulation(): state record [48], motor targets/gains per DoF */
+void orc_sim_step(const orc_model* m, const orc_params* prm, real* state,
+                  const real* q_des, const real* kp, const real* kd, orc_step_info* info);
+
+/* ---- task layer (reference Python glue restated) ---- */
+typedef struct {
+    int task;             /* 0 reach, 1 push */
+    int max_steps;
+    double target_dist_min;
+    double obj_pose_rnd_std, tg_pose_rnd_std;
+    double ws_lim[3][2];     /* world workspace (object) */
+    double h_table;
+    double home[ORC_MAXD];
+    double act_scale;        /* 0.05 */
+    double kp_act, kd_act, kp_hold, kd_hold;
+    int n_act;               /* controlled joints (7) */
+    uint64_t seed;
+} orc_task;
+
+void orc_default_task(orc_task* t, int task);
+int  orc_obs_dim(const orc_task* t, const orc_model* m);
+void orc_observation(const orc_model* m, const orc_task* t, const real* state, real* obs);
+void orc_reward_done(const orc_model* m, const orc_task* t, real* state, int pre_increment,
+                     real* reward, real* done);
+void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id,
+                   uint32_t episode, real* state, real* obs);
+void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* state,
+                  const real* action, real* obs, real* reward, real* done);
+/* batched convenience loops (tests, cpu_baseline) */
+void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* t, int n, uint64_t env_id0,
+                     real* states, real* obs);
+void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
+                    const real* actions, real* out /*[n][obs_dim+2]*/);
+
+/* counter-based RNG shared (by specification) with the device path */
+void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
+/* Bullet pure-math helpers used by the observation code */
+void orc_quat_from_euler(const real e[3], real q[4]);
+void orc_euler_from_quat(const real q[4], real e[3]);
+#ifdef __cplusplus
+}
+#endif
+#endif
