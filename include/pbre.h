@@ -1,0 +1,135 @@
+/* pbre.h -- C-ABI of libpbre.so, the MI355X batched rollout engine.
+ *
+ * Drop-in boundary.  The reference (hsp-iit/pybullet-robot-envs) has no FFI of its
+ * own: its hot path calls the third-party `pybullet` Python module once per env and
+ * per query.  This ABI is what the reference's Gym classes bind instead (ctypes stub
+ * in INTEGRATION.md); each entry point names the reference call sites it replaces.
+ * `R/` = pybullet_robot_envs/ in the reference tree.
+ *
+ * Conventions: plain C types only; caller owns every buffer it passes; the ctx owns
+ * all device memory.  Every function returns 0 on success or a negative PBRE_E_* code
+ * and never throws; pbre_last_error() gives the message.  A ctx is used by one host
+ * thread at a time and is bound to one GPU (one process per GPU; multi-GPU sharding is
+ * done above this ABI with one ctx per rank and env_id_base = rank * num_envs).
+ *
+ * Per-env state record: 48 floats (three 16-float lane records):
+ *   Q[0..8]  joint positions          Q[9..11]  object position   Q[12..15] object quaternion (x,y,z,w)
+ *   V[0..8]  joint velocities         V[9..11]  object lin. vel.  V[12..14] object ang. vel.  V[15] 0
+ *   X[0..2]  push target              X[3] step counter  X[4] terminated flag  X[5] episode  X[6..15] reserved
+ *
+ * RobotTable (pbre_config.robot_table): float64 array, little endian
+ *   [0] magic 1346523717 ('PBRE')  [1] version 1  [2] n_links  [3] n_dof  [4] ee_link  [5] n_spheres
+ *   [6..8] base position  [9..17] base rotation (row major)  [18] fixed_base  [19..23] reserved
+ *   then n_links records of 40: parent, jtype(0 fixed,1 revolute,2 prismatic), axis[3], origin_xyz[3],
+ *        origin_R[9], mass, com[3], inertia[9] (about COM, link axes), lower, upper, damping,
+ *        dof_index(-1 fixed), lateral_friction, effort, velocity, reserved[3]
+ *   then n_spheres records of 8: link, centre[3], radius, friction, reserved[2]
+ */
+#ifndef PBRE_H
+#define PBRE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBRE_STATE_FLOATS 48
+
+enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
+enum { PBRE_ROBOT_PANDA = 0 };
+enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1 };
+enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
+       PBRE_F_AUTO_RESET = 2 };   /* done envs are re-initialised from the settled snapshot at the next step */
+
+typedef struct pbre_ctx pbre_ctx;
+
+/* Simulation constants.  Defaults (pbre_default_config) are the values the reference
+ * hard-codes or inherits from PyBullet: R/envs/panda_envs/panda_push_gym_env.py:39 (dt),
+ * :122 (150 solver iterations), :126 (gravity); panda_env.py:76,308 (motor gains). */
+typedef struct {
+    double dt, gravity_z;
+    int32_t solver_iters;
+    double erp, linear_slop, contact_margin;
+    double lin_damping, ang_damping, max_coord_vel;
+    double max_motor_impulse, limit_max_impulse;
+    double table_c[3], table_h[3], table_mu, ground_z;
+    double obj_h[3], obj_mass, obj_inertia[3], obj_mu;
+} pbre_physics;
+
+typedef struct {
+    int32_t robot;             /* PBRE_ROBOT_* */
+    int32_t task;              /* PBRE_TASK_* */
+    int32_t num_envs;          /* envs owned by this ctx (this GPU) */
+    int32_t device_id;         /* HIP device ordinal */
+    uint64_t env_id_base;      /* global id of local env 0: RNG streams are keyed by global id, so results do
+                                  not depend on how the batch is sharded */
+    uint64_t seed;
+    int32_t use_ik;            /* must be 0 (joint control, R/__init__.py:62); IK is SURVEY §8f */
+    int32_t num_controlled_joints;   /* 7 */
+    int32_t action_repeat;     /* 1 */
+    int32_t max_steps;         /* 1000 */
+    int32_t flags;             /* PBRE_F_* */
+    double  obj_pose_rnd_std, tg_pose_rnd_std;
+    double  target_dist_min;   /* 0.1 push / 0.03 reach */
+    double  act_scale;         /* 0.05 rad per unit action (panda_push_gym_env.py:225) */
+    double  kp_act, kd_act, kp_hold, kd_hold;
+    double  ws_lim[3][2];      /* world (object) workspace, world_env.py:72 */
+    double  h_table;
+    double  home[16];          /* initial joint positions, panda_env.py:19-23 */
+    pbre_physics phys;
+    const double* robot_table; size_t robot_table_len;   /* number of doubles */
+} pbre_config;
+
+/* Fills *cfg with the reference's defaults for (robot, task); caller then sets num_envs, robot_table, ... */
+int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task);
+
+/* replaces: p.connect + pandaEnv.__init__/reset (R/envs/panda_envs/panda_env.py:25-91: loadURDF, per-joint
+ * POSITION_CONTROL motors) + WorldEnv.__init__/reset (R/envs/world_envs/world_env.py:35-84) for a whole batch */
+int pbre_create(const pbre_config* cfg, pbre_ctx** out);
+void pbre_destroy(pbre_ctx* ctx);
+const char* pbre_last_error(const pbre_ctx* ctx);   /* borrowed; ctx may be NULL for create errors */
+
+int pbre_dims(const pbre_ctx* ctx, int32_t* obs_dim, int32_t* act_dim, int32_t* num_envs);
+
+/* replaces: pandaPushGymEnv.reset -> reset_simulation (panda_push_gym_env.py:105-148: resetSimulation,
+ * robot.reset, 100 x stepSimulation, world.reset incl. WorldEnv._sample_pose (world_env.py:145-176),
+ * 100 + 1 x stepSimulation) + sample_tg_pose (:333-360) + get_extended_observation.
+ * env_mask: NULL = all envs, else num_envs bytes (non-zero = reset that env).
+ * obs_out: NULL or host [num_envs][obs_dim] raw (unscaled) observation, float32. */
+int pbre_reset(pbre_ctx* ctx, const uint8_t* env_mask, float* obs_out);
+
+/* replaces: pandaPushGymEnv.step (panda_push_gym_env.py:244-255) = apply_action (:189-242: action*0.05,
+ * clip to joint limits panda_env.py:303, 7 x setJointMotorControl2 :305-310, p.stepSimulation :236,
+ * _termination :239, counter :242) + get_extended_observation (:150-187) + _termination (:301-316) +
+ * _compute_reward (:318-331), for every env.  actions: host [num_envs][act_dim] float32.
+ * out: host [num_envs][obs_dim+2] float32 = raw observation | reward | done.  Synchronous. */
+int pbre_step(pbre_ctx* ctx, const float* actions, float* out);
+
+/* Same with device-resident buffers (HIP device pointers on ctx's GPU) enqueued on `stream`
+ * (a hipStream_t, NULL = the ctx's own stream); asynchronous.  For device-resident policies
+ * (replaces the stable-baselines DummyVecEnv hop, R/examples/algos/train/.../train_ddpg_reaching.py:96). */
+int pbre_step_device(pbre_ctx* ctx, const float* d_actions, float* d_out, void* stream);
+int pbre_sync(pbre_ctx* ctx);
+
+/* raw simulator state, host [num_envs][PBRE_STATE_FLOATS] float32 (parity tests, checkpoint/restore) */
+int pbre_get_state(pbre_ctx* ctx, float* state);
+int pbre_set_state(pbre_ctx* ctx, const float* state);
+/* recompute the observation of the current state (replaces get_extended_observation, :150-187) */
+int pbre_observe(pbre_ctx* ctx, float* obs_out);
+/* `n` bare physics steps with hold motors (replaces the settle loops `for _ in range(100): p.stepSimulation`,
+ * panda_push_gym_env.py:132-133,139-140); flags: PBRE_F_NO_OBJECT or 0 */
+int pbre_settle(pbre_ctx* ctx, int32_t n, int32_t flags);
+
+/* observation limits used by the Gym Box space / scale_gym_data (create_gym_spaces, :83-103) */
+int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
+
+/* wall-clock of the last pbre_step phases in ms: [0] upload, [1] kernels, [2] download */
+int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
+/* static kernel facts for the bench/roofline report: [0] VGPRs, [1] waves launched per step, [2] envs per wave */
+int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,765 @@
+// pbre_core.hpp -- the env.step() hot path, written once against a "lane backend" L.
+//
+// Mapping: one environment = one 16-lane DPP row of a wavefront; a wave owns
+// 4 consecutive envs.  Lane k of a group owns generalized coordinate k:
+//     lanes 0..8   robot joints (7 arm + 2 fingers)        -- link/joint data of link k
+//     lanes 9..11  object linear velocity x,y,z            lanes 12..14 object angular velocity
+//     lane  15     constant 1 (carries -rhs of a contact row through the row dot product)
+// All solver data lives in VGPRs; cross-lane traffic is DPP (row all-reduce) and
+// ds_bpermute (broadcast/gather inside the row).  No LDS allocation, no scratch.
+//
+// L provides: F (float per lane), I (int per lane), B (predicate per lane) and the ops used
+// below.  Device backend: lanes_device.hpp (F = float).  Host backend (CPU tests only):
+// tests/host_emu/lanes_host.hpp (F = 16 floats).  Control flow is group-uniform by
+// construction; L::any() is only ever used to skip work that is a no-op when false.
+//
+// Replaces, per env (reference file:line):
+//   apply_action          pybullet_robot_envs/envs/panda_envs/panda_push_gym_env.py:189-242
+//   p.setJointMotorControl2  .../panda_env.py:293-310
+//   p.stepSimulation      panda_push_gym_env.py:236  (Bullet multibody step, restated; see oracle/)
+//   get_observation       panda_env.py:141-193; world_env.py:109-126
+//   get_extended_observation / _termination / _compute_reward   panda_push_gym_env.py:150-187, 301-331
+#pragma once
+#include <math.h>
+#include "pbre_tables.hpp"
+
+#ifndef PBRE_HD
+#define PBRE_HD
+#endif
+#ifndef PBRE_UNROLL
+#define PBRE_UNROLL
+#endif
+
+namespace pbre {
+
+template <class L>
+struct Core {
+    using F = typename L::F;
+    using I = typename L::I;
+    using B = typename L::B;
+
+    struct V3 { F x, y, z; };
+    struct Q4 { F x, y, z, w; };
+    struct M3 { F m[9]; };
+    struct Sp { V3 a, l; };            // spatial vector: angular, linear (world frame, about world origin)
+
+    // ---------------------------------------------------------------- small math
+    static PBRE_HD V3 v3(F x, F y, F z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+    static PBRE_HD V3 add(const V3& a, const V3& b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+    static PBRE_HD V3 sub(const V3& a, const V3& b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+    static PBRE_HD V3 scl(const V3& a, F s) { return v3(a.x * s, a.y * s, a.z * s); }
+    static PBRE_HD F dot(const V3& a, const V3& b) { return L::fma(a.x, b.x, L::fma(a.y, b.y, a.z * b.z)); }
+    static PBRE_HD V3 cross(const V3& a, const V3& b) {
+        return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+    }
+    static PBRE_HD F norm(const V3& a) { return L::sqrt(dot(a, a)); }
+    static PBRE_HD V3 mv(const M3& A, const V3& v) {
+        return v3(L::fma(A.m[0], v.x, L::fma(A.m[1], v.y, A.m[2] * v.z)),
+                  L::fma(A.m[3], v.x, L::fma(A.m[4], v.y, A.m[5] * v.z)),
+                  L::fma(A.m[6], v.x, L::fma(A.m[7], v.y, A.m[8] * v.z)));
+    }
+    static PBRE_HD V3 mtv(const M3& A, const V3& v) {
+        return v3(L::fma(A.m[0], v.x, L::fma(A.m[3], v.y, A.m[6] * v.z)),
+                  L::fma(A.m[1], v.x, L::fma(A.m[4], v.y, A.m[7] * v.z)),
+                  L::fma(A.m[2], v.x, L::fma(A.m[5], v.y, A.m[8] * v.z)));
+    }
+    static PBRE_HD M3 mm(const M3& A, const M3& Bm) {
+        M3 C;
+        PBRE_UNROLL for (int i = 0; i < 3; i++)
+            PBRE_UNROLL for (int j = 0; j < 3; j++)
+                C.m[i*3+j] = L::fma(A.m[i*3], Bm.m[j], L::fma(A.m[i*3+1], Bm.m[3+j], A.m[i*3+2] * Bm.m[6+j]));
+        return C;
+    }
+    static PBRE_HD V3 selv(B c, const V3& a, const V3& b) { return v3(L::sel(c, a.x, b.x), L::sel(c, a.y, b.y), L::sel(c, a.z, b.z)); }
+    static PBRE_HD V3 bcastv(const V3& a, int i) { return v3(L::bcast(a.x, i), L::bcast(a.y, i), L::bcast(a.z, i)); }
+    static PBRE_HD V3 bcastvI(const V3& a, I i) { return v3(L::gather(a.x, i), L::gather(a.y, i), L::gather(a.z, i)); }
+    // pick component by lane: x for (lane%3==0 of the triple starting at `base`) ...
+    static PBRE_HD F pick3(const V3& a, I lane, int base) {
+        return L::sel(L::eqi(lane, base), a.x, L::sel(L::eqi(lane, base + 1), a.y, a.z));
+    }
+    static PBRE_HD M3 quat_R(const Q4& q) {
+        M3 R; F x = q.x, y = q.y, z = q.z, w = q.w; F two = L::c(2.f), one = L::c(1.f);
+        R.m[0] = one - two * (y*y + z*z); R.m[1] = two * (x*y - w*z);       R.m[2] = two * (x*z + w*y);
+        R.m[3] = two * (x*y + w*z);       R.m[4] = one - two * (x*x + z*z); R.m[5] = two * (y*z - w*x);
+        R.m[6] = two * (x*z - w*y);       R.m[7] = two * (y*z + w*x);       R.m[8] = one - two * (x*x + y*y);
+        return R;
+    }
+    static PBRE_HD Q4 qmul(const Q4& a, const Q4& b) {
+        Q4 o;
+        o.x = a.w*b.x + a.x*b.w + a.y*b.z - a.z*b.y;
+        o.y = a.w*b.y - a.x*b.z + a.y*b.w + a.z*b.x;
+        o.z = a.w*b.z + a.x*b.y - a.y*b.x + a.z*b.w;
+        o.w = a.w*b.w - a.x*b.x - a.y*b.y - a.z*b.z;
+        return o;
+    }
+    // btMatrix3x3::getRotation (Shepperd); branch-free over the four cases
+    static PBRE_HD Q4 R_quat(const M3& R) {
+        F tr = R.m[0] + R.m[4] + R.m[8], one = L::c(1.f), h = L::c(.5f);
+        // case trace > 0
+        F s0 = L::sqrt(L::max(tr + one, L::c(1e-30f))); F k0 = h / s0;
+        Q4 a; a.w = s0 * h; a.x = (R.m[7] - R.m[5]) * k0; a.y = (R.m[2] - R.m[6]) * k0; a.z = (R.m[3] - R.m[1]) * k0;
+        // case i = 0,1,2 (largest diagonal)
+        Q4 c[3];
+        PBRE_UNROLL for (int i = 0; i < 3; i++) {
+            int j = (i + 1) % 3, k = (i + 2) % 3;
+            F s = L::sqrt(L::max(R.m[i*4] - R.m[j*4] - R.m[k*4] + one, L::c(1e-30f))); F kk = h / s;
+            F t[3]; t[i] = s * h; t[j] = (R.m[j*3+i] + R.m[i*3+j]) * kk; t[k] = (R.m[k*3+i] + R.m[i*3+k]) * kk;
+            c[i].x = t[0]; c[i].y = t[1]; c[i].z = t[2]; c[i].w = (R.m[k*3+j] - R.m[j*3+k]) * kk;
+        }
+        // i = R00 < R11 ? (R11 < R22 ? 2 : 1) : (R00 < R22 ? 2 : 0)
+        B c01 = L::lt(R.m[0], R.m[4]), c12 = L::lt(R.m[4], R.m[8]), c02 = L::lt(R.m[0], R.m[8]);
+        B use2 = L::bor(L::band(c01, c12), L::band(L::bnot(c01), c02));
+        B use1 = L::band(c01, L::bnot(c12));
+        B pos = L::gt(tr, L::c(0.f));
+        Q4 o;
+        o.x = L::sel(pos, a.x, L::sel(use2, c[2].x, L::sel(use1, c[1].x, c[0].x)));
+        o.y = L::sel(pos, a.y, L::sel(use2, c[2].y, L::sel(use1, c[1].y, c[0].y)));
+        o.z = L::sel(pos, a.z, L::sel(use2, c[2].z, L::sel(use1, c[1].z, c[0].z)));
+        o.w = L::sel(pos, a.w, L::sel(use2, c[2].w, L::sel(use1, c[1].w, c[0].w)));
+        return o;
+    }
+    // pybullet getQuaternionFromEuler / getEulerFromQuaternion
+    static PBRE_HD Q4 euler_quat(const V3& e) {
+        F h = L::c(.5f);
+        F cr = L::cos(e.x * h), sr = L::sin(e.x * h), cp = L::cos(e.y * h), sp = L::sin(e.y * h), cy = L::cos(e.z * h), sy = L::sin(e.z * h);
+        Q4 q; q.x = sr*cp*cy - cr*sp*sy; q.y = cr*sp*cy + sr*cp*sy; q.z = cr*cp*sy - sr*sp*cy; q.w = cr*cp*cy + sr*sp*sy;
+        return q;
+    }
+    static PBRE_HD V3 quat_euler(const Q4& q) {
+        F x = q.x, y = q.y, z = q.z, w = q.w, two = L::c(2.f);
+        F sqx = x*x, sqy = y*y, sqz = z*z, squ = w*w;
+        F sarg = L::c(-2.f) * (x*z - w*y);
+        B lo = L::le(sarg, L::c(-0.99999f)), hi = L::ge(sarg, L::c(0.99999f));
+        F roll = L::atan2(two * (y*z + w*x), squ - sqx - sqy + sqz);
+        F pitch = L::asin(L::max(L::min(sarg, L::c(1.f)), L::c(-1.f)));
+        F yaw = L::atan2(two * (x*y + w*z), squ + sqx - sqy - sqz);
+        F hp = L::c(1.57079632679489662f);
+        F ylo = two * L::atan2(x, L::c(0.f) - y), yhi = two * L::atan2(L::c(0.f) - x, y);
+        V3 e;
+        e.x = L::sel(L::bor(lo, hi), L::c(0.f), roll);
+        e.y = L::sel(lo, L::c(0.f) - hp, L::sel(hi, hp, pitch));
+        e.z = L::sel(lo, ylo, L::sel(hi, yhi, yaw));
+        return e;
+    }
+    static PBRE_HD F clampf(F x, F lo, F hi) { return L::min(L::max(x, lo), hi); }
+
+    // ---------------------------------------------------------------- kinematics
+    struct Kin {
+        M3 R; V3 p;          // world pose of this lane's link frame
+        Sp S;                // joint motion axis (world, about world origin)
+    };
+
+    // Forward kinematics of all robot lanes by pointer jumping over the ancestor tables.
+    static PBRE_HD void fk(const Tables& T, F q, Kin& K) {
+        I jt = L::loadI(T.jtype);
+        B rev = L::eqi(jt, 1), pri = L::eqi(jt, 2);
+        V3 ax = v3(L::load(T.axis[0]), L::load(T.axis[1]), L::load(T.axis[2]));
+        M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = L::load(T.R0[k]);
+        V3 p0 = v3(L::load(T.p0[0]), L::load(T.p0[1]), L::load(T.p0[2]));
+        // Rodrigues rotation about the joint axis (identity for non-revolute lanes)
+        F th = L::sel(rev, q, L::c(0.f));
+        F c = L::cos(th), s = L::sin(th), C = L::c(1.f) - c;
+        M3 Rj;
+        Rj.m[0] = c + ax.x*ax.x*C;      Rj.m[1] = ax.x*ax.y*C - ax.z*s; Rj.m[2] = ax.x*ax.z*C + ax.y*s;
+        Rj.m[3] = ax.y*ax.x*C + ax.z*s; Rj.m[4] = c + ax.y*ax.y*C;      Rj.m[5] = ax.y*ax.z*C - ax.x*s;
+        Rj.m[6] = ax.z*ax.x*C - ax.y*s; Rj.m[7] = ax.z*ax.y*C + ax.x*s; Rj.m[8] = c + ax.z*ax.z*C;
+        M3 R = mm(R0, Rj);
+        V3 d = mv(R0, ax);
+        F qs = L::sel(pri, q, L::c(0.f));
+        V3 p = v3(L::fma(d.x, qs, p0.x), L::fma(d.y, qs, p0.y), L::fma(d.z, qs, p0.z));
+        PBRE_UNROLL for (int lev = 0; lev < NLEV; lev++) {
+            I a = L::loadI(T.anc[lev]);
+            B ok = L::gei(a, 0);
+            if (!L::any(ok)) break;
+            I ai = L::maxi(a, 0);
+            M3 Ra; PBRE_UNROLL for (int k = 0; k < 9; k++) Ra.m[k] = L::gather(R.m[k], ai);
+            V3 pa = bcastvI(p, ai);
+            M3 Rn = mm(Ra, R);
+            V3 pn = add(pa, mv(Ra, p));
+            PBRE_UNROLL for (int k = 0; k < 9; k++) R.m[k] = L::sel(ok, Rn.m[k], R.m[k]);
+            p = selv(ok, pn, p);
+        }
+        K.R = R; K.p = p;
+        V3 aw = mv(R, ax);
+        V3 z = v3(L::c(0.f), L::c(0.f), L::c(0.f));
+        K.S.a = selv(rev, aw, z);
+        K.S.l = selv(rev, cross(p, aw), selv(pri, aw, z));
+    }
+
+    // inclusive sum over the ancestor chain (pointer jumping): out_j = sum_{i anc-or-self j} x_i
+    static PBRE_HD Sp chain_sum(const Tables& T, Sp x) {
+        PBRE_UNROLL for (int lev = 0; lev < NLEV; lev++) {
+            I a = L::loadI(T.anc[lev]);
+            B ok = L::gei(a, 0);
+            if (!L::any(ok)) break;
+            I ai = L::maxi(a, 0);
+            V3 ga = bcastvI(x.a, ai), gl = bcastvI(x.l, ai);
+            F zero = L::c(0.f);
+            x.a = add(x.a, selv(ok, ga, v3(zero, zero, zero)));
+            x.l = add(x.l, selv(ok, gl, v3(zero, zero, zero)));
+        }
+        return x;
+    }
+    static PBRE_HD Sp crossm(const Sp& v, const Sp& m) {   // motion cross product v x m
+        Sp o; o.a = cross(v.a, m.a); o.l = add(cross(v.a, m.l), cross(v.l, m.a)); return o;
+    }
+
+    // ---------------------------------------------------------------- collision helpers
+    // sphere vs oriented box; returns signed distance, n = world normal box->sphere, pb = point on box
+    static PBRE_HD F sphere_box(const V3& sc, F sr, const V3& bc, const M3& Rb, const V3& h, V3& n, V3& pb) {
+        V3 dl = mtv(Rb, sub(sc, bc));
+        V3 cl = v3(clampf(dl.x, L::c(0.f) - h.x, h.x), clampf(dl.y, L::c(0.f) - h.y, h.y), clampf(dl.z, L::c(0.f) - h.z, h.z));
+        V3 df = sub(dl, cl);
+        F len = norm(df);
+        B inside = L::lt(len, L::c(1e-9f));
+        F il = L::c(1.f) / L::max(len, L::c(1e-30f));
+        V3 n_out = scl(df, il);
+        // inside branch: nearest face
+        F ex = h.x - L::abs(dl.x), ey = h.y - L::abs(dl.y), ez = h.z - L::abs(dl.z);
+        B ax_y = L::lt(ey, ex);                       // strict '<' scanning x,y,z keeps the first minimum
+        F best = L::sel(ax_y, ey, ex);
+        B ax_z = L::lt(ez, best);
+        best = L::sel(ax_z, ez, best);
+        B is_x = L::band(L::bnot(ax_y), L::bnot(ax_z)), is_y = L::band(ax_y, L::bnot(ax_z));
+        F one = L::c(1.f), zero = L::c(0.f);
+        F sx = L::sel(L::ge(dl.x, zero), one, zero - one), sy = L::sel(L::ge(dl.y, zero), one, zero - one), sz = L::sel(L::ge(dl.z, zero), one, zero - one);
+        V3 n_in = v3(L::sel(is_x, sx, zero), L::sel(is_y, sy, zero), L::sel(ax_z, sz, zero));
+        V3 cl_in = v3(L::sel(is_x, sx * h.x, cl.x), L::sel(is_y, sy * h.y, cl.y), L::sel(ax_z, sz * h.z, cl.z));
+        V3 nl = selv(inside, n_in, n_out);
+        V3 c2 = selv(inside, cl_in, cl);
+        n = mv(Rb, nl);
+        pb = add(bc, mv(Rb, c2));
+        return L::sel(inside, zero - best - sr, len - sr);
+    }
+
+    // Select the `cap` smallest-distance candidates (dist < margin) among lanes with `valid`;
+    // returns the per-lane rank (0..cap-1 in lane order) or -1.  Ties resolve to the lowest lane.
+    static PBRE_HD I select_k(F dist, B valid, F margin, int cap, I lane) {
+        B cand = L::band(valid, L::lt(dist, margin));
+        B chosen = L::bfalse();
+        for (int r = 0; r < cap; r++) {
+            F key = L::sel(L::band(cand, L::bnot(chosen)), dist, L::c(3e38f));
+            F mn = L::vmin(key);
+            B hit = L::band(L::band(cand, L::bnot(chosen)), L::eq(key, mn));
+            hit = L::band(hit, L::lt(mn, L::c(1e38f)));
+            // lowest lane among hits
+            F lk = L::sel(hit, L::itof(lane), L::c(99.f));
+            F lm = L::vmin(lk);
+            chosen = L::bor(chosen, L::band(hit, L::eq(lk, lm)));
+        }
+        // rank = number of chosen lanes below this lane
+        F cf = L::sel(chosen, L::c(1.f), L::c(0.f));
+        F rank = L::c(0.f);
+        PBRE_UNROLL for (int i = 0; i < W; i++) {
+            F ci = L::bcast(cf, i);
+            rank = rank + L::sel(L::lti(L::ci(i), lane), ci, L::c(0.f));
+        }
+        return L::seli(chosen, L::ftoi(rank), L::ci(-1));
+    }
+
+    // ---------------------------------------------------------------- contact slot (group-uniform values)
+    struct Contact {
+        B act; V3 n, pA, pB; F dist, mu; I owner;
+    };
+
+    // fetch the contact whose rank == r from the candidate lanes (all fields become group-uniform)
+    static PBRE_HD Contact fetch(I rank, int r, const V3& n, const V3& pA, const V3& pB, F dist, F mu, I owner, I lane) {
+        B mine = L::eqi(rank, r);
+        F lk = L::sel(mine, L::itof(lane), L::c(99.f));
+        F lm = L::vmin(lk);
+        Contact c;
+        c.act = L::lt(lm, L::c(98.f));
+        I src = L::ftoi(L::min(lm, L::c(15.f)));
+        c.n = bcastvI(n, src); c.pA = bcastvI(pA, src); c.pB = bcastvI(pB, src);
+        c.dist = L::gather(dist, src); c.mu = L::gather(mu, src);
+        c.owner = L::gatherI(owner, src);
+        return c;
+    }
+
+    // ---------------------------------------------------------------- the step
+    // mode bits
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4 };
+
+    struct Rows {             // register-resident solver data
+        F Mi[NJ];             // row of M^-1 (lane k: Minv[k][j])
+        F m_dinv, m_rhs;      // motor row owned by this lane (rhs already multiplied by dinv)
+        F l_j, l_rhs;         // limit row owned by this lane: J' = dir*dinv (0 if inactive), rhs'
+        F l_dir;
+        F m_app[NJ], l_app[NJ];
+        F Jn[NC], Bn[NC], an[NC];
+        F J1[NC], B1[NC], a1[NC];
+        F J2[NC], B2[NC], a2[NC];
+        F mu[NC];
+        B act[NC];
+    };
+
+    static PBRE_HD void row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
+        F t = L::sum(Jp * dv);
+        F s = L::med3(app - t, lo, hi);
+        F d = s - app; app = s;
+        dv = L::fma(d, Bv, dv);
+    }
+    static PBRE_HD void frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
+        F t = L::sum(Jp * dv);
+        F s = L::med3(app - t, L::c(0.f) - lim, lim);
+        s = L::sel(L::gt(lim, L::c(0.f)), s, app);
+        F d = s - app; app = s;
+        dv = L::fma(d, Bv, dv);
+    }
+
+    // One simulation step for one env group.  st: pointer to the env's 48-float record.
+    // act: pointer to this env's action row or nullptr.  out: this env's [obs_dim+2] row or nullptr.
+    static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+        const I lane = L::lane();
+        const F zero = L::c(0.f), one = L::c(1.f);
+        const B robot = L::lti(lane, NJ);
+        const B is_lin = L::band(L::gei(lane, LC), L::lti(lane, LC + 3));
+        const B is_ang = L::band(L::gei(lane, LC + 3), L::lti(lane, LC + 6));
+        const B obj_lane = L::bor(is_lin, is_ang);
+        const bool obj_on = !(flags & 1);
+        const F dt = L::c(P.dt), inv_dt = L::c(P.inv_dt);
+
+        F Qr = L::load(st), Vr = L::load(st + 16), Xr = L::load(st + 32);
+        F q = L::sel(robot, Qr, zero);
+
+        // ---- motor targets (apply_action): q_des = clip(q + 0.05 a, ll, ul) for actuated lanes, else hold at home
+        F lower = L::load(T.lower), upper = L::load(T.upper);
+        F qdes = L::load(T.home), kp = L::load(T.kp_hold), kd = L::load(T.kd_hold);
+        if (mode & M_ACTION) {
+            B al = L::lti(lane, T.n_act);
+            F a = L::loadm(act, al);
+            F tgt = clampf(L::fma(a, L::c(P.act_scale), q), lower, upper);
+            qdes = L::sel(al, tgt, qdes);
+            kp = L::load(T.kp_act); kd = L::load(T.kd_act);
+        }
+
+        // ---- object pose/twist as group-uniform values
+        V3 op = v3(L::bcast(Qr, 9), L::bcast(Qr, 10), L::bcast(Qr, 11));
+        Q4 oq; oq.x = L::bcast(Qr, 12); oq.y = L::bcast(Qr, 13); oq.z = L::bcast(Qr, 14); oq.w = L::bcast(Qr, 15);
+        V3 ov = v3(L::bcast(Vr, 9), L::bcast(Vr, 10), L::bcast(Vr, 11));
+        V3 ow = v3(L::bcast(Vr, 12), L::bcast(Vr, 13), L::bcast(Vr, 14));
+        M3 Ro = quat_R(oq);
+
+        // ---- kinematics at q_t
+        Kin K; fk(T, q, K);
+        F qd = L::sel(robot, Vr, zero);
+
+        // ---- rigid-body quantities of this lane's sub-bodies, velocities, bias forces (world-frame RNEA)
+        Sp Sq; Sq.a = scl(K.S.a, qd); Sq.l = scl(K.S.l, qd);
+        Sp Vs = chain_sum(T, Sq);                         // spatial velocity of this link
+        Sp cj = crossm(Vs, Sq);
+        Sp As = chain_sum(T, cj);                         // velocity-product acceleration
+        As.l.z = As.l.z - L::c(P.gz);                     // gravity as base acceleration
+        F cm = zero; V3 ch = v3(zero, zero, zero); F cI[6] = {zero, zero, zero, zero, zero, zero};   // own spatial inertia about world origin
+        Sp Fo; Fo.a = v3(zero, zero, zero); Fo.l = v3(zero, zero, zero);
+        PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
+            F m = L::load(T.sb_m[b]);
+            V3 cl = v3(L::load(T.sb_c[b][0]), L::load(T.sb_c[b][1]), L::load(T.sb_c[b][2]));
+            V3 c = add(K.p, mv(K.R, cl));
+            // world inertia Iw = R I R^T (symmetric)
+            F Ixx = L::load(T.sb_I[b][0]), Iyy = L::load(T.sb_I[b][1]), Izz = L::load(T.sb_I[b][2]);
+            F Ixy = L::load(T.sb_I[b][3]), Ixz = L::load(T.sb_I[b][4]), Iyz = L::load(T.sb_I[b][5]);
+            M3 Il; Il.m[0] = Ixx; Il.m[1] = Ixy; Il.m[2] = Ixz; Il.m[3] = Ixy; Il.m[4] = Iyy; Il.m[5] = Iyz; Il.m[6] = Ixz; Il.m[7] = Iyz; Il.m[8] = Izz;
+            M3 RI = mm(K.R, Il);
+            M3 Iw;
+            PBRE_UNROLL for (int i = 0; i < 3; i++)
+                PBRE_UNROLL for (int j = 0; j < 3; j++)
+                    Iw.m[i*3+j] = L::fma(RI.m[i*3], K.R.m[j*3], L::fma(RI.m[i*3+1], K.R.m[j*3+1], RI.m[i*3+2] * K.R.m[j*3+2]));
+            // Newton-Euler of the sub-body
+            V3 w = Vs.a;
+            V3 vc = add(Vs.l, cross(w, c));
+            V3 ac = add(add(As.l, cross(As.a, c)), cross(w, vc));
+            F sl = L::fma(L::c(P.kl), norm(vc), L::c(P.kl));           // Bullet velocity damping K1 + K2|v|
+            V3 f = scl(add(ac, scl(vc, sl)), m);
+            V3 Iww = mv(Iw, w);
+            F sa = L::fma(L::c(P.ka), norm(w), L::c(P.ka));
+            V3 nc = add(add(mv(Iw, As.a), cross(w, Iww)), scl(Iww, sa));
+            Fo.a = add(Fo.a, add(nc, cross(c, f)));
+            Fo.l = add(Fo.l, f);
+            // spatial inertia about the world origin: m, h = m c, Io = Iw + m (c.c 1 - c c^T)
+            cm = cm + m;
+            ch = add(ch, scl(c, m));
+            F cc = dot(c, c);
+            cI[0] = cI[0] + L::fma(m, cc - c.x*c.x, Iw.m[0]); cI[1] = cI[1] + L::fma(m, cc - c.y*c.y, Iw.m[4]); cI[2] = cI[2] + L::fma(m, cc - c.z*c.z, Iw.m[8]);
+            cI[3] = cI[3] + L::fma(zero - m, c.x*c.y, Iw.m[1]); cI[4] = cI[4] + L::fma(zero - m, c.x*c.z, Iw.m[2]); cI[5] = cI[5] + L::fma(zero - m, c.y*c.z, Iw.m[5]);
+        }
+        // ---- subtree sums (bias force + composite inertia): broadcast loop with descendant masks
+        I dmask = L::loadI(T.dmask);
+        Sp Fs; Fs.a = v3(zero, zero, zero); Fs.l = v3(zero, zero, zero);
+        F Cm = zero; V3 Ch = v3(zero, zero, zero); F CI[6] = {zero, zero, zero, zero, zero, zero};
+        PBRE_UNROLL for (int i = 0; i < NJ; i++) {
+            B in = L::bit(dmask, i);
+            Fs.a = add(Fs.a, selv(in, bcastv(Fo.a, i), v3(zero, zero, zero)));
+            Fs.l = add(Fs.l, selv(in, bcastv(Fo.l, i), v3(zero, zero, zero)));
+            Cm = Cm + L::sel(in, L::bcast(cm, i), zero);
+            Ch = add(Ch, selv(in, bcastv(ch, i), v3(zero, zero, zero)));
+            PBRE_UNROLL for (int k = 0; k < 6; k++) CI[k] = CI[k] + L::sel(in, L::bcast(cI[k], i), zero);
+        }
+        F tau = zero - (dot(K.S.a, Fs.a) + dot(K.S.l, Fs.l)) - L::load(T.jdamp) * qd;   // -bias - joint damping
+
+        // ---- CRBA: G = Ic S (own), H[row=lane][i]
+        M3 Io; Io.m[0] = CI[0]; Io.m[1] = CI[3]; Io.m[2] = CI[4]; Io.m[3] = CI[3]; Io.m[4] = CI[1]; Io.m[5] = CI[5]; Io.m[6] = CI[4]; Io.m[7] = CI[5]; Io.m[8] = CI[2];
+        Sp G; G.a = add(mv(Io, K.S.a), cross(Ch, K.S.l)); G.l = add(scl(K.S.l, Cm), cross(K.S.a, Ch));
+        I amask = L::loadI(T.amask);
+        Rows R;
+        PBRE_UNROLL for (int i = 0; i < NJ; i++) {
+            V3 Sa = bcastv(K.S.a, i), Sl = bcastv(K.S.l, i), Ga = bcastv(G.a, i), Gl = bcastv(G.l, i);
+            F up = dot(Sa, G.a) + dot(Sl, G.l);            // i is an ancestor-or-self of this lane
+            F dn = dot(K.S.a, Ga) + dot(K.S.l, Gl);        // this lane is an ancestor of i
+            R.Mi[i] = L::sel(L::bit(amask, i), up, L::sel(L::bit(dmask, i), dn, zero));
+        }
+        // unused robot lanes (fewer than 9 DoF): unit diagonal keeps the inverse well defined
+        PBRE_UNROLL for (int i = 0; i < NJ; i++) R.Mi[i] = L::sel(L::band(L::eqi(lane, i), L::eqi(L::loadI(T.jtype), 0)), one, R.Mi[i]);
+
+        // ---- M^-1 by in-place Gauss-Jordan (SPD, no pivoting), one matrix row per lane
+        PBRE_UNROLL for (int c = 0; c < NJ; c++) {
+            F pc = L::bcast(R.Mi[c], c);
+            F inv = one / pc;
+            B isc = L::eqi(lane, c);
+            F f = R.Mi[c];
+            PBRE_UNROLL for (int k = 0; k < NJ; k++) {
+                if (k == c) continue;
+                F rc = L::bcast(R.Mi[k], c) * inv;
+                R.Mi[k] = L::sel(isc, rc, L::fma(zero - f, rc, R.Mi[k]));
+            }
+            R.Mi[c] = L::sel(isc, inv, zero - f * inv);
+        }
+
+        // ---- unconstrained velocities v* (ABA equivalent): qdd = M^-1 tau
+        F qdd = zero;
+        PBRE_UNROLL for (int j = 0; j < NJ; j++) qdd = L::fma(R.Mi[j], L::bcast(tau, j), qdd);
+        const F vmax = L::c(P.vmax);
+        F vstar = clampf(L::fma(dt, qdd, qd), zero - vmax, vmax);
+        // object: gravity, damping, gyroscopic torque
+        M3 Iinv; V3 oI = v3(L::c(P.obj_I[0]), L::c(P.obj_I[1]), L::c(P.obj_I[2]));
+        {
+            M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
+            PBRE_UNROLL for (int i = 0; i < 3; i++)
+                PBRE_UNROLL for (int j = 0; j < 3; j++)
+                    Iinv.m[i*3+j] = L::fma(D.m[i*3], Ro.m[j*3], L::fma(D.m[i*3+1], Ro.m[j*3+1], D.m[i*3+2] * Ro.m[j*3+2]));
+        }
+        F vobj = zero;
+        if (obj_on) {
+            V3 wl = mtv(Ro, ow);
+            V3 Lw = mv(Ro, v3(wl.x * oI.x, wl.y * oI.y, wl.z * oI.z));   // I_w w
+            F sl = L::fma(L::c(P.kl), norm(ov), L::c(P.kl));
+            V3 al = v3(zero - sl * ov.x, zero - sl * ov.y, L::c(P.gz) - sl * ov.z);
+            F sa = L::fma(L::c(P.ka), norm(ow), L::c(P.ka));
+            V3 tq = sub(scl(cross(ow, Lw), zero - one), scl(Lw, sa));
+            V3 aa = mv(Iinv, tq);
+            V3 vl = v3(L::fma(dt, al.x, ov.x), L::fma(dt, al.y, ov.y), L::fma(dt, al.z, ov.z));
+            V3 va = v3(L::fma(dt, aa.x, ow.x), L::fma(dt, aa.y, ow.y), L::fma(dt, aa.z, ow.z));
+            vobj = L::sel(is_lin, pick3(vl, lane, LC), L::sel(is_ang, pick3(va, lane, LC + 3), zero));
+            vobj = clampf(vobj, zero - vmax, vmax);
+        }
+        vstar = L::sel(robot, vstar, vobj);                 // generalized v* of all 15 DoF (lane 15: 0)
+        V3 ovs = v3(L::bcast(vstar, 9), L::bcast(vstar, 10), L::bcast(vstar, 11));
+        V3 ows = v3(L::bcast(vstar, 12), L::bcast(vstar, 13), L::bcast(vstar, 14));
+
+        // ---- collision detection at q_t
+        const F margin = L::c(P.margin);
+        Contact C[NC];
+        {
+            // candidates: sphere lane s vs object / table; vertex lane v (0..7) vs support surface
+            I so = L::loadI(T.s_owner);
+            B sv = L::nei(L::loadI(T.s_valid), 0);
+            M3 Rs; PBRE_UNROLL for (int k = 0; k < 9; k++) Rs.m[k] = L::gather(K.R.m[k], so);
+            V3 ps = bcastvI(K.p, so);
+            V3 sc = add(ps, mv(Rs, v3(L::load(T.s_c[0]), L::load(T.s_c[1]), L::load(T.s_c[2]))));
+            F sr = L::load(T.s_r), smu = L::load(T.s_mu);
+            V3 oh = v3(L::c(P.obj_h[0]), L::c(P.obj_h[1]), L::c(P.obj_h[2]));
+            // object vertices
+            F sgx = L::sel(L::bit(lane, 0), one, zero - one), sgy = L::sel(L::bit(lane, 1), one, zero - one), sgz = L::sel(L::bit(lane, 2), one, zero - one);
+            V3 vx = add(op, mv(Ro, v3(sgx * oh.x, sgy * oh.y, sgz * oh.z)));
+            F top = L::c(P.tab_c[2] + P.tab_h[2]), bot = L::c(P.tab_c[2] - P.tab_h[2]);
+            B infoot = L::band(L::le(L::abs(vx.x - L::c(P.tab_c[0])), L::c(P.tab_h[0])), L::le(L::abs(vx.y - L::c(P.tab_c[1])), L::c(P.tab_h[1])));
+            F hs = L::sel(L::band(infoot, L::gt(vx.z, bot)), top, L::c(P.ground_z));
+            F vd = vx.z - hs;
+            V3 up = v3(zero, zero, one);
+            I none = L::ci(-1);
+            I rk_ot = none, rk_ro = none;
+            V3 n_ro, pB_ro, pA_ro; F d_ro = L::c(1.f);
+            if (obj_on) {
+                rk_ot = select_k(vd, L::lti(lane, 8), margin, NC_OT, lane);
+                d_ro = sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro);
+                pA_ro = add(pB_ro, scl(n_ro, d_ro));
+                rk_ro = select_k(d_ro, sv, margin, NC_RO, lane);
+            } else { n_ro = up; pB_ro = up; pA_ro = up; }
+            V3 n_rt, pB_rt;
+            M3 Idm; PBRE_UNROLL for (int k = 0; k < 9; k++) Idm.m[k] = (k % 4 == 0) ? one : zero;
+            F d_rt = sphere_box(sc, sr, v3(L::c(P.tab_c[0]), L::c(P.tab_c[1]), L::c(P.tab_c[2])), Idm,
+                                v3(L::c(P.tab_h[0]), L::c(P.tab_h[1]), L::c(P.tab_h[2])), n_rt, pB_rt);
+            V3 pA_rt = add(pB_rt, scl(n_rt, d_rt));
+            I rk_rt = select_k(d_rt, sv, margin, NC_RT, lane);
+            V3 vB = v3(vx.x, vx.y, hs);
+            PBRE_UNROLL for (int c = 0; c < NC_OT; c++)
+                C[c] = fetch(rk_ot, c, up, vx, vB, vd, L::c(P.obj_mu * P.tab_mu), L::ci(0), lane);
+            PBRE_UNROLL for (int c = 0; c < NC_RO; c++)
+                C[NC_OT + c] = fetch(rk_ro, c, n_ro, pA_ro, pB_ro, d_ro, smu * L::c(P.obj_mu), so, lane);
+            PBRE_UNROLL for (int c = 0; c < NC_RT; c++)
+                C[NC_OT + NC_RO + c] = fetch(rk_rt, c, n_rt, pA_rt, pB_rt, d_rt, smu * L::c(P.tab_mu), so, lane);
+        }
+
+        // ---- constraint rows
+        // motors (btMultiBodyJointMotor, POSITION_CONTROL): velocity error kp (q_des - q)/dt - kd v*
+        {
+            F dinv = zero;
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) dinv = L::sel(L::eqi(lane, j), one / R.Mi[j], dinv);
+            B live = L::band(robot, L::nei(L::loadI(T.jtype), 0));
+            R.m_dinv = L::sel(live, dinv, zero);
+            R.m_rhs = L::sel(live, (kp * (qdes - q) * inv_dt - kd * vstar) * dinv, zero);
+            // joint limits (btMultiBodyJointLimitConstraint): row exists only while violated
+            F pl = q - lower, pu = upper - q;
+            B lo_v = L::band(live, L::le(pl, zero)), up_v = L::band(live, L::band(L::bnot(lo_v), L::le(pu, zero)));
+            F dir = L::sel(lo_v, one, L::sel(up_v, zero - one, zero));
+            F pen = L::sel(lo_v, pl, pu);
+            R.l_dir = dir;
+            R.l_j = dir * dinv;                            // J' = dir * dinv (dir^2 = 1 so dinv is unchanged)
+            R.l_rhs = L::sel(L::bor(lo_v, up_v), (zero - pen * L::c(P.erp) * inv_dt - dir * vstar) * dinv, zero);
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) { R.m_app[j] = zero; R.l_app[j] = zero; }
+        }
+        const B any_limit = L::ne(R.l_dir, zero);
+        // contacts
+        const F inv_m = L::c(1.f / P.obj_m);
+        PBRE_UNROLL for (int c = 0; c < NC; c++) {
+            const int type = c < NC_OT ? 0 : (c < NC_OT + NC_RO ? 1 : 2);
+            Contact& cc = C[c];
+            R.act[c] = cc.act; R.mu[c] = L::sel(cc.act, cc.mu, zero);
+            R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
+            if (!L::any(cc.act)) { R.Jn[c] = zero; R.Bn[c] = zero; R.J1[c] = zero; R.B1[c] = zero; R.J2[c] = zero; R.B2[c] = zero; continue; }
+            // btPlaneSpace1
+            V3 n = cc.n, t1, t2;
+            {
+                B big = L::gt(L::abs(n.z), L::c(0.70710678118654752f));
+                F a1 = n.y*n.y + n.z*n.z, k1 = one / L::sqrt(L::max(a1, L::c(1e-30f)));
+                V3 p1 = v3(zero, zero - n.z * k1, n.y * k1);
+                V3 q1 = v3(a1 * k1, zero - n.x * p1.z, n.x * p1.y);
+                F a2 = n.x*n.x + n.y*n.y, k2 = one / L::sqrt(L::max(a2, L::c(1e-30f)));
+                V3 p2 = v3(zero - n.y * k2, n.x * k2, zero);
+                V3 q2 = v3(zero - n.z * p2.y, n.z * p2.x, a2 * k2);
+                t1 = selv(big, p1, p2); t2 = selv(big, q1, q2);
+            }
+            B onchain = L::band(robot, L::biti(L::gatherI(amask, cc.owner), lane));   // this joint moves the contact link
+            V3 rO = sub(type == 0 ? cc.pA : cc.pB, op);
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                const V3& dir = d == 0 ? n : (d == 1 ? t1 : t2);
+                F J = zero;
+                if (type != 0) {
+                    F jr = dot(dir, add(K.S.l, cross(K.S.a, cc.pA)));
+                    J = L::sel(onchain, jr, zero);
+                }
+                if (type != 2) {
+                    V3 ra = cross(rO, dir);
+                    F jo = L::sel(is_lin, pick3(dir, lane, LC), L::sel(is_ang, pick3(ra, lane, LC + 3), zero));
+                    J = J + (type == 0 ? jo : zero - jo);
+                }
+                J = L::sel(cc.act, J, zero);
+                // B = M^-1 J^T
+                F Bv = zero;
+                if (type != 0) {
+                    F Br = zero;
+                    PBRE_UNROLL for (int j = 0; j < NJ; j++) Br = L::fma(R.Mi[j], L::bcast(J, j), Br);
+                    Bv = L::sel(robot, Br, zero);
+                }
+                if (type != 2) {
+                    V3 Ja = v3(L::bcast(J, LC + 3), L::bcast(J, LC + 4), L::bcast(J, LC + 5));
+                    V3 Ba = mv(Iinv, Ja);
+                    Bv = Bv + L::sel(is_lin, J * inv_m, L::sel(is_ang, pick3(Ba, lane, LC + 3), zero));
+                }
+                F denom = L::sum(J * Bv);
+                F rel = L::sum(J * vstar);
+                F dinv = L::sel(cc.act, one / L::sel(cc.act, denom, one), zero);
+                F rhs;
+                if (d == 0) {   // setupMultiBodyContactConstraint, restitution 0
+                    F pen = cc.dist + L::c(P.slop);
+                    B sep = L::gt(pen, zero);
+                    F perr = L::sel(sep, zero, zero - pen * L::c(P.erp) * inv_dt);
+                    F verr = L::sel(sep, zero - rel - pen * inv_dt, zero - rel);
+                    rhs = (perr + verr) * dinv;
+                } else rhs = (zero - rel) * dinv;
+                F Jp = L::sel(L::eqi(lane, L1), zero - rhs, J * dinv);
+                Jp = L::sel(cc.act, Jp, zero);
+                if (d == 0) { R.Jn[c] = Jp; R.Bn[c] = Bv; } else if (d == 1) { R.J1[c] = Jp; R.B1[c] = Bv; } else { R.J2[c] = Jp; R.B2[c] = Bv; }
+            }
+        }
+
+        // ---- projected Gauss-Seidel (Bullet order: non-contact rows alternate direction, normals, frictions)
+        F dv = L::sel(L::eqi(lane, L1), one, zero);
+        const F mlim = L::c(P.motor_imp), llim = L::c(P.limit_imp), big = L::c(1e10f);
+        auto motor = [&](int j) {
+            F x = L::sel(L::eqi(lane, j), L::fma(R.m_dinv, dv, zero - R.m_rhs), zero);
+            F t = L::sum(x);
+            F s = L::med3(R.m_app[j] - t, zero - mlim, mlim);
+            F d = s - R.m_app[j]; R.m_app[j] = s;
+            dv = L::fma(d, R.Mi[j], dv);
+        };
+        auto limit = [&](int j) {
+            F x = L::sel(L::eqi(lane, j), L::fma(R.l_j, dv, zero - R.l_rhs), zero);
+            F t = L::sum(x);
+            F s = L::med3(R.l_app[j] - t, zero, llim);
+            F d = s - R.l_app[j]; R.l_app[j] = s;
+            dv = L::fma(d * L::bcast(R.l_dir, j), R.Mi[j], dv);
+        };
+        auto contacts = [&]() {
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) row(R.Jn[c], R.Bn[c], R.an[c], zero, big, dv);
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) {
+                F lim = R.mu[c] * R.an[c];
+                frow(R.J1[c], R.B1[c], R.a1[c], lim, dv);
+                frow(R.J2[c], R.B2[c], R.a2[c], lim, dv);
+            }
+        };
+        const bool has_limit = L::any(any_limit);
+        for (int it = 0; it < P.iters; it += 2) {
+            // even iteration: reversed non-contact order
+            PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+            if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) limit(j); }
+            contacts();
+            if (it + 1 >= P.iters) break;
+            // odd iteration: forward order
+            if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) limit(j); }
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+            contacts();
+        }
+
+        // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
+        F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
+        B dyn = obj_on ? L::bor(robot, obj_lane) : robot;
+        F Vn = L::sel(dyn, vnew, Vr);
+        B posl = obj_on ? L::lti(lane, LC + 3) : robot;
+        F Qn = L::sel(posl, L::fma(dt, vnew, Qr), Qr);
+        if (obj_on) {
+            V3 wn = v3(L::bcast(vnew, 12), L::bcast(vnew, 13), L::bcast(vnew, 14));
+            F ang = norm(wn);
+            F cap = L::c(0.78539816339744831f) * inv_dt;
+            ang = L::sel(L::gt(ang * dt, L::c(0.78539816339744831f)), cap, ang);
+            F small = L::c(0.5f) * dt - dt * dt * dt * L::c(0.020833333333f) * ang * ang;
+            F sc_ = L::sel(L::lt(ang, L::c(0.001f)), small, L::sin(L::c(0.5f) * ang * dt) / L::max(ang, L::c(1e-30f)));
+            Q4 dq; dq.x = wn.x * sc_; dq.y = wn.y * sc_; dq.z = wn.z * sc_; dq.w = L::cos(ang * dt * L::c(0.5f));
+            Q4 nq = qmul(dq, oq);
+            F in = one / L::sqrt(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
+            F qc = L::sel(L::eqi(lane, 12), nq.x, L::sel(L::eqi(lane, 13), nq.y, L::sel(L::eqi(lane, 14), nq.z, nq.w)));
+            Qn = L::sel(L::gei(lane, 12), qc * in, Qn);
+        }
+        L::store(st, Qn); L::store(st + 16, Vn);
+
+        if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode);
+    }
+
+    // Observation / reward / termination of the current state (Qn, Vn, Xr = the three state records).
+    static PBRE_HD void observe(const Tables& T, const Params& P, float* st, F Qn, F Vn, F Xr, float* out, int mode) {
+        const I lane = L::lane();
+        const F zero = L::c(0.f), one = L::c(1.f);
+        const B robot = L::lti(lane, NJ);
+        F q = L::sel(robot, Qn, zero), qd = L::sel(robot, Vn, zero);
+        Kin K; fk(T, q, K);
+        Sp Sq; Sq.a = scl(K.S.a, qd); Sq.l = scl(K.S.l, qd);
+        Sp Vs = chain_sum(T, Sq);
+        const int eo = T.ee_owner;
+        M3 Re; PBRE_UNROLL for (int k = 0; k < 9; k++) Re.m[k] = L::bcast(K.R.m[k], eo);
+        V3 pe = bcastv(K.p, eo);
+        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = L::c(T.ee_R[k]);
+        M3 Ree = mm(Re, Eo);
+        V3 ee = add(pe, mv(Re, v3(L::c(T.ee_p[0]), L::c(T.ee_p[1]), L::c(T.ee_p[2]))));
+        V3 vee = add(bcastv(Vs.l, eo), cross(bcastv(Vs.a, eo), ee));
+        V3 eul = quat_euler(R_quat(Ree));
+        V3 op = v3(L::bcast(Qn, 9), L::bcast(Qn, 10), L::bcast(Qn, 11));
+        Q4 oq; oq.x = L::bcast(Qn, 12); oq.y = L::bcast(Qn, 13); oq.z = L::bcast(Qn, 14); oq.w = L::bcast(Qn, 15);
+        V3 oe = quat_euler(oq);
+        // object pose in the hand frame via the Euler round trip the reference performs (panda_push_gym_env.py:168-174)
+        Q4 qh = euler_quat(eul), qo = euler_quat(oe);
+        V3 rel = mtv(quat_R(qh), sub(op, ee));
+        Q4 qhi; qhi.x = zero - qh.x; qhi.y = zero - qh.y; qhi.z = zero - qh.z; qhi.w = qh.w;
+        V3 er = quat_euler(qmul(qhi, qo));
+        V3 tg = v3(L::bcast(Xr, 0), L::bcast(Xr, 1), L::bcast(Xr, 2));
+        V3 vn = v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
+
+        F reward = zero, done = zero;
+        if (mode & M_TASK) {
+            // _termination + counter (panda_push_gym_env.py:239-242, 301-316) and _compute_reward (:318-331)
+            F d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
+            F dsucc = P.task == 1 ? d2 : d1;
+            B succ = L::le(dsucc, L::c(P.dist_min));
+            F cnt = L::bcast(Xr, 3), term = L::bcast(Xr, 4);
+            F mx = L::c((float)P.max_steps);
+            B d0 = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
+            cnt = L::sel(d0, cnt, cnt + one);
+            term = L::sel(succ, one, term);
+            B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
+            done = L::sel(dn, one, zero);
+            F base = P.task == 1 ? zero - d1 - d2 : zero - d1;
+            reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
+            F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, Xr));
+            L::store(st + 32, Xn);
+        }
+        if (out) {
+            // row-major [obs | reward | done]; obs layout SURVEY Appendix C
+            const int nd = T.ndof;
+            const int od = 9 + nd + 12 + (P.task == 1 ? 3 : 0);
+            F head = L::sel(L::eqi(lane, 0), ee.x, L::sel(L::eqi(lane, 1), ee.y, L::sel(L::eqi(lane, 2), ee.z,
+                     L::sel(L::eqi(lane, 3), eul.x, L::sel(L::eqi(lane, 4), eul.y, L::sel(L::eqi(lane, 5), eul.z,
+                     L::sel(L::eqi(lane, 6), vn.x, L::sel(L::eqi(lane, 7), vn.y, vn.z))))))));
+            L::storem(out, head, L::lti(lane, 9));
+            L::storem(out + 9, q, L::lti(lane, nd));
+            float* o2 = out + 9 + nd;
+            F tail = L::sel(L::eqi(lane, 0), op.x, L::sel(L::eqi(lane, 1), op.y, L::sel(L::eqi(lane, 2), op.z,
+                     L::sel(L::eqi(lane, 3), oe.x, L::sel(L::eqi(lane, 4), oe.y, L::sel(L::eqi(lane, 5), oe.z,
+                     L::sel(L::eqi(lane, 6), rel.x, L::sel(L::eqi(lane, 7), rel.y, L::sel(L::eqi(lane, 8), rel.z,
+                     L::sel(L::eqi(lane, 9), er.x, L::sel(L::eqi(lane, 10), er.y, L::sel(L::eqi(lane, 11), er.z,
+                     L::sel(L::eqi(lane, 12), tg.x, L::sel(L::eqi(lane, 13), tg.y, tg.z))))))))))))));
+            L::storem(o2, tail, L::lti(lane, P.task == 1 ? 15 : 12));
+            F rd = L::sel(L::eqi(lane, 0), reward, done);
+            L::storem(out + od, rd, L::lti(lane, 2));
+        }
+    }
+
+    // ---------------------------------------------------------------- reset (initial state before the settle steps)
+    static PBRE_HD void philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
+        for (int r = 0; r < 10; r++) {
+            unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+            unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    }
+    static PBRE_HD float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+    static PBRE_HD float clamps(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+    // robot.reset + WorldEnv._sample_pose (reference panda_env.py:51-79, world_env.py:145-176): scalar, one call per env
+    static PBRE_HD void init_state(const Tables& T, const Params& P, unsigned long long env_id, unsigned episode, float* st) {
+        for (int k = 0; k < STATE; k++) st[k] = 0.f;
+        for (int k = 0; k < T.ndof; k++) st[k] = T.home[k];
+        const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
+        const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;
+        float px = x_min + 0.5f * (x_max - x_min), py = y_min + 0.5f * (y_max - y_min);
+        const float pz = P.h_table + 0.07f;
+        float yaw = 0.78539816339744831f;
+        if (P.obj_std > 0.f) {
+            unsigned r[4];
+            philox((unsigned)env_id, (unsigned)(env_id >> 32), episode, 0u, P.seed_lo, P.seed_hi, r);
+            px += -P.obj_std + 2.f * P.obj_std * u01(r[0]);
+            py += -P.obj_std + 2.f * P.obj_std * u01(r[1]);
+            yaw = -0.78539816339744831f + 1.57079632679489662f * u01(r[2]);
+        }
+        st[9] = clamps(px, x_min, x_max); st[10] = clamps(py, y_min, y_max); st[11] = pz;
+        st[12] = 0.f; st[13] = 0.f; st[14] = sinf(0.5f * yaw); st[15] = cosf(0.5f * yaw);
+        st[37] = (float)episode;
+    }
+    // sample_tg_pose (reference panda_push_gym_env.py:333-360) on the settled object position
+    static PBRE_HD void sample_target(const Params& P, unsigned long long env_id, unsigned episode, float* st) {
+        if (P.task != 1) return;
+        const float tx_min = P.ws[0][0] + 0.07f, tx_max = P.ws[0][1] - 0.07f;
+        float tx = st[9] + 0.05f, ty = st[10] + 0.05f;
+        if (P.tg_std > 0.f) {
+            unsigned r[4];
+            philox((unsigned)env_id, (unsigned)(env_id >> 32), episode, 1u, P.seed_lo, P.seed_hi, r);
+            const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(r[1]);
+            const float rad = sqrtf(-2.f * logf(u1)) * P.tg_std;
+            tx = st[9] + rad * cosf(6.28318530717958648f * u2);
+            ty = st[10] + rad * sinf(6.28318530717958648f * u2);
+        }
+        st[32] = clamps(tx, tx_min, tx_max); st[33] = clamps(ty, P.ws[1][0], P.ws[1][1]); st[34] = st[11];
+        st[35] = 0.f; st[36] = 0.f;
+    }
+};
+
+}  // namespace pbre

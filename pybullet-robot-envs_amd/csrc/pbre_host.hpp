@@ -1,0 +1,97 @@
+// pbre_host.hpp -- host-side pieces of the C-ABI that do not depend on HIP: default
+// configuration, pbre_config -> Tables/Params, observation limits.  Shared by
+// pbre_capi.hip (product) and tests/host_emu (lane emulation, tests only).
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <string>
+#include "../../include/pbre.h"
+#include "pbre_tables.hpp"
+
+namespace pbre {
+
+inline void default_physics(pbre_physics& p) {
+    std::memset(&p, 0, sizeof p);
+    p.dt = 1.0 / 240.0;                 // reference panda_push_gym_env.py:39
+    p.gravity_z = -9.8;                 // :126
+    p.solver_iters = 150;               // :122
+    p.erp = 0.2; p.linear_slop = 1e-5; p.contact_margin = 1e-3;   // Bullet defaults [EXT-UNVERIFIED], DESIGN.md
+    p.lin_damping = 0.04; p.ang_damping = 0.04; p.max_coord_vel = 100.0;
+    p.max_motor_impulse = 100000.0 / 240.0;   // pybullet default force 1e5 N * dt
+    p.limit_max_impulse = 100.0;
+    p.table_c[0] = 0.85; p.table_c[1] = 0.0; p.table_c[2] = 0.6;   // table.urdf top slab at world_env.py:65 base pos
+    p.table_h[0] = 0.75; p.table_h[1] = 0.5; p.table_h[2] = 0.025;
+    p.table_mu = 0.5; p.ground_z = 0.0;
+    p.obj_h[0] = p.obj_h[1] = p.obj_h[2] = 0.025;                 // cube_small.urdf
+    p.obj_mass = 0.1;
+    p.obj_inertia[0] = p.obj_inertia[1] = p.obj_inertia[2] = 0.1 * (0.05 * 0.05 + 0.05 * 0.05) / 12.0;
+    p.obj_mu = 1.0;
+}
+
+inline int default_config(pbre_config* c, int robot, int task) {
+    if (!c || robot != PBRE_ROBOT_PANDA || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH)) return PBRE_E_ARG;
+    std::memset(c, 0, sizeof *c);
+    c->robot = robot; c->task = task; c->num_envs = 1; c->device_id = 0; c->seed = 1234;
+    c->use_ik = 0; c->num_controlled_joints = 7; c->action_repeat = 1; c->max_steps = 1000;
+    c->target_dist_min = task == PBRE_TASK_PUSH ? 0.1 : 0.03;   // panda_push_gym_env.py:52, panda_reach_gym_env.py:47
+    c->act_scale = 0.05;                                        // panda_push_gym_env.py:225
+    c->kp_act = 0.5; c->kd_act = 1.0;                           // panda_env.py:308
+    c->kp_hold = 0.2; c->kd_hold = 1.0;                         // panda_env.py:76
+    c->h_table = 0.625;                                         // world_env.py:68-69
+    c->ws_lim[0][0] = 0.3; c->ws_lim[0][1] = 0.65;              // panda_env.py:37 (x,y); world_env.py:72 (z)
+    c->ws_lim[1][0] = -0.3; c->ws_lim[1][1] = 0.3;
+    c->ws_lim[2][0] = 0.625; c->ws_lim[2][1] = 0.925;
+    const double home[9] = {0.0, -0.54, 0.0, -2.6, -0.30, 2.0, 1.0, 0.02, 0.02};   // panda_env.py:19-23
+    for (int k = 0; k < 9; k++) c->home[k] = home[k];
+    default_physics(c->phys);
+    return PBRE_OK;
+}
+
+inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
+    if (c.num_envs <= 0) return "num_envs must be positive";
+    if (c.use_ik) return "use_IK=1 is not implemented by this engine (joint control only, SURVEY 8f)";
+    if (c.action_repeat != 1) return "action_repeat != 1 is not implemented";
+    if (c.num_controlled_joints < 1 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
+    const double gains[4] = {c.kp_act, c.kd_act, c.kp_hold, c.kd_hold};
+    std::string e = build_tables(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, T);
+    if (!e.empty()) return e;
+    const pbre_physics& p = c.phys;
+    if (p.solver_iters <= 0 || p.dt <= 0) return "bad physics parameters";
+    std::memset(&P, 0, sizeof P);
+    P.dt = (float)p.dt; P.inv_dt = (float)(1.0 / p.dt); P.gz = (float)p.gravity_z; P.iters = p.solver_iters;
+    P.erp = (float)p.erp; P.slop = (float)p.linear_slop; P.margin = (float)p.contact_margin;
+    P.kl = (float)p.lin_damping; P.ka = (float)p.ang_damping; P.vmax = (float)p.max_coord_vel;
+    P.motor_imp = (float)p.max_motor_impulse; P.limit_imp = (float)p.limit_max_impulse;
+    for (int k = 0; k < 3; k++) { P.tab_c[k] = (float)p.table_c[k]; P.tab_h[k] = (float)p.table_h[k]; P.obj_h[k] = (float)p.obj_h[k]; P.obj_I[k] = (float)p.obj_inertia[k]; }
+    P.tab_mu = (float)p.table_mu; P.ground_z = (float)p.ground_z; P.obj_m = (float)p.obj_mass; P.obj_mu = (float)p.obj_mu;
+    P.task = c.task; P.max_steps = c.max_steps; P.flags = c.flags;
+    P.dist_min = (float)c.target_dist_min; P.act_scale = (float)c.act_scale;
+    P.obj_std = (float)c.obj_pose_rnd_std; P.tg_std = (float)c.tg_pose_rnd_std;
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 2; b++) P.ws[a][b] = (float)c.ws_lim[a][b];
+    P.h_table = (float)c.h_table;
+    P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
+    P.env_id_base = c.env_id_base;
+    return "";
+}
+
+inline int obs_dim_of(const Tables& T, const Params& P) { return 9 + T.ndof + 12 + (P.task == PBRE_TASK_PUSH ? 3 : 0); }
+
+// Observation limits exactly as the reference assembles them (panda_env.py:141-193 limits list,
+// panda_push_gym_env.py:73-75 / panda_reach_gym_env.py:68-70 z-min, :177-185 extras).
+inline void obs_limits(const pbre_config& c, const Tables& T, float* lo, float* hi) {
+    const double PI = 3.14159265358979323846;
+    int o = 0;
+    auto put = [&](double a, double b) { lo[o] = (float)a; hi[o] = (float)b; o++; };
+    const double zmin = c.task == PBRE_TASK_PUSH ? c.h_table - 0.2 : c.h_table;
+    put(0.3, 0.65); put(-0.3, 0.3); put(zmin, 1.5);                 // robot workspace (panda_env.py:37)
+    for (int k = 0; k < 3; k++) put(-PI, PI);
+    for (int k = 0; k < 3; k++) put(-1, 1);
+    for (int k = 0; k < T.ndof; k++) put(T.lower[k], T.upper[k]);
+    for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
+    for (int k = 0; k < 3; k++) put(-PI, PI);
+    for (int k = 0; k < 3; k++) put(-0.5, 0.5);
+    for (int k = 0; k < 3; k++) put(0, 2 * PI);
+    if (c.task == PBRE_TASK_PUSH) for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
+}
+
+}  // namespace pbre

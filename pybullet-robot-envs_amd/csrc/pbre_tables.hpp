@@ -1,0 +1,175 @@
+// pbre_tables.hpp -- host side: RobotTable (include/pbre.h) -> per-lane tables of the
+// 16-lane env group (DESIGN.md "Lane layout").  Plain C++17, no HIP, so the same code
+// feeds the device kernels (pbre_capi.hip) and the host lane emulation used by the CPU
+// tests (tests/host_emu).
+//
+// What PyBullet does at `loadURDF` (reference panda_env.py:53-56) -- build a multibody,
+// keep fixed joints as 0-DoF links -- is flattened here: every movable link becomes a
+// lane; links behind fixed joints become "sub-bodies" of the nearest movable ancestor
+// (mass, COM and inertia are kept separately per sub-body because Bullet's velocity
+// damping is applied per link and is not additive).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace pbre {
+
+constexpr int W = 16;        // lanes per env
+constexpr int NJ = 9;        // robot DoF lanes 0..8
+constexpr int LC = 9;        // object lanes: 9..11 linear, 12..14 angular
+constexpr int L1 = 15;       // constant-one lane (carries -rhs of contact rows)
+constexpr int NSUB = 3;      // rigid sub-bodies per lane
+constexpr int NLEV = 4;      // pointer-jumping levels (chains up to 16 deep)
+constexpr int NC_OT = 4, NC_RO = 2, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;
+constexpr int STATE = 48;
+
+struct Tables {
+    int   anc[NLEV][W];          // 2^l-th movable ancestor lane, -1 past the root
+    int   amask[W];              // bit i: lane i is an ancestor-or-self of this lane
+    int   dmask[W];              // bit i: lane i is in the subtree of this lane (incl. self)
+    int   jtype[W];              // 0 none, 1 revolute, 2 prismatic
+    float axis[3][W];
+    float R0[9][W], p0[3][W];    // joint frame w.r.t. parent movable link frame at q = 0 (root: world)
+    float sb_m[NSUB][W], sb_c[NSUB][3][W], sb_I[NSUB][6][W];   // xx yy zz xy xz yz, link axes, about sub-body COM
+    float lower[W], upper[W], jdamp[W], home[W];
+    float kp_hold[W], kd_hold[W], kp_act[W], kd_act[W];
+    int   s_owner[W], s_valid[W];
+    float s_c[3][W], s_r[W], s_mu[W];
+    int   ee_owner;
+    float ee_R[9], ee_p[3];      // EE (link COM frame) in the owner lane's link frame
+    int   ndof, n_act, nspheres;
+};
+
+struct Params {                  // float copies of pbre_physics + task constants used on device
+    float dt, inv_dt, gz;
+    int   iters;
+    float erp, slop, margin, kl, ka, vmax, motor_imp, limit_imp;
+    float tab_c[3], tab_h[3], tab_mu, ground_z;
+    float obj_h[3], obj_m, obj_I[3], obj_mu;
+    int   task, max_steps, flags;
+    float dist_min, act_scale;
+    float obj_std, tg_std, ws[3][2], h_table;
+    unsigned seed_lo, seed_hi;
+    unsigned long long env_id_base;
+};
+
+namespace detail {
+struct Xf { double R[9]; double p[3]; };
+inline Xf ident() { Xf x{}; x.R[0] = x.R[4] = x.R[8] = 1; return x; }
+inline Xf mul(const Xf& a, const Xf& b) {
+    Xf o{};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += a.R[i*3+k] * b.R[k*3+j]; o.R[i*3+j] = s; }
+        o.p[i] = a.p[i] + a.R[i*3] * b.p[0] + a.R[i*3+1] * b.p[1] + a.R[i*3+2] * b.p[2];
+    }
+    return o;
+}
+}  // namespace detail
+
+// Returns "" on success, else an error message.
+inline std::string build_tables(const double* t, size_t n, const double* home, const double* gains /*kp_act,kd_act,kp_hold,kd_hold*/,
+                                int n_act, Tables& T) {
+    using namespace detail;
+    std::memset(&T, 0, sizeof T);
+    if (!t || n < 24 || t[0] != 1346523717.0 || t[1] != 1.0) return "robot_table: bad magic/version";
+    const int nl = (int)t[2], ndof = (int)t[3], ee = (int)t[4], ns = (int)t[5];
+    if (n < (size_t)(24 + nl * 40 + ns * 8)) return "robot_table: truncated";
+    if (ndof > NJ) return "robot_table: more than 9 DoF (this kernel maps one DoF per lane of a 16-lane group)";
+    if (ns > W) return "robot_table: more than 16 collision spheres";
+    if ((int)t[18] != 1) return "robot_table: floating-base robots are not supported by this kernel";
+    if (ee < 0 || ee >= nl) return "robot_table: ee_link out of range";
+    auto L = [&](int i) { return t + 24 + i * 40; };
+    std::vector<int> lane_of(nl, -1), owner(nl, -1);
+    std::vector<Xf> to_owner(nl);          // link frame expressed in its owner's (movable link) frame; owner == -1: in world
+    Xf base = ident();
+    for (int k = 0; k < 3; k++) base.p[k] = t[6 + k];
+    for (int k = 0; k < 9; k++) base.R[k] = t[9 + k];
+    int nsub[W] = {0};
+    for (int l = 0; l < W; l++) { for (int v = 0; v < NLEV; v++) T.anc[v][l] = -1; T.s_owner[l] = 0; }
+    for (int i = 0; i < nl; i++) {
+        const double* r = L(i);
+        const int par = (int)r[0], jt = (int)r[1], dof = (int)r[33];
+        if (par >= i) return "robot_table: links must be in topological order";
+        Xf X = ident();
+        for (int k = 0; k < 3; k++) X.p[k] = r[5 + k];
+        for (int k = 0; k < 9; k++) X.R[k] = r[8 + k];
+        // frame of the parent link expressed in the parent's owner frame (or world)
+        Xf P = par < 0 ? base : to_owner[par];
+        int pown = par < 0 ? -1 : owner[par];
+        Xf J = mul(P, X);                   // this joint frame in pown's frame (q = 0)
+        if (jt != 0) {
+            if (dof < 0 || dof >= NJ) return "robot_table: bad dof index";
+            const int ln = dof;
+            lane_of[i] = ln; owner[i] = i; to_owner[i] = ident();
+            T.jtype[ln] = jt;
+            for (int k = 0; k < 3; k++) { T.axis[k][ln] = (float)r[2 + k]; T.p0[k][ln] = (float)J.p[k]; }
+            for (int k = 0; k < 9; k++) T.R0[k][ln] = (float)J.R[k];
+            T.anc[0][ln] = pown < 0 ? -1 : lane_of[pown];
+            T.lower[ln] = (float)r[30]; T.upper[ln] = (float)r[31]; T.jdamp[ln] = (float)r[32];
+        } else {
+            owner[i] = pown; to_owner[i] = J;
+        }
+        // rigid sub-body
+        const double mass = r[17];
+        bool has_inertia = false;
+        for (int k = 0; k < 9; k++) has_inertia = has_inertia || r[21 + k] != 0.0;
+        if (owner[i] >= 0 && (mass > 0 || has_inertia)) {
+            const int ln = lane_of[owner[i]];
+            // A massless link keeps its rotational inertia (PyBullet keeps <inertia> with URDF_USE_INERTIA_FROM_FILE,
+            // reference panda_env.py:53; e.g. panda_link8).  It moves rigidly with the lane, and every term it enters
+            // is linear in the tensor, so it is folded exactly into the lane's first sub-body.
+            const bool fold = mass <= 0 && nsub[ln] > 0;
+            if (!fold && nsub[ln] >= NSUB) return "robot_table: too many fixed-attached bodies on one movable link";
+            const int b = fold ? 0 : nsub[ln]++;
+            const Xf& F = to_owner[i];
+            double c[3], I[9], RI[9], Io[9];
+            for (int a = 0; a < 3; a++) c[a] = F.p[a] + F.R[a*3] * r[18] + F.R[a*3+1] * r[19] + F.R[a*3+2] * r[20];
+            for (int k = 0; k < 9; k++) I[k] = r[21 + k];
+            for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) { double s = 0; for (int k = 0; k < 3; k++) s += F.R[a*3+k] * I[k*3+bb]; RI[a*3+bb] = s; }
+            for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) { double s = 0; for (int k = 0; k < 3; k++) s += RI[a*3+k] * F.R[bb*3+k]; Io[a*3+bb] = s; }
+            if (!fold) {
+                T.sb_m[b][ln] = (float)mass;
+                for (int a = 0; a < 3; a++) T.sb_c[b][a][ln] = (float)c[a];
+            }
+            T.sb_I[b][0][ln] += (float)Io[0]; T.sb_I[b][1][ln] += (float)Io[4]; T.sb_I[b][2][ln] += (float)Io[8];
+            T.sb_I[b][3][ln] += (float)Io[1]; T.sb_I[b][4][ln] += (float)Io[2]; T.sb_I[b][5][ln] += (float)Io[5];
+        }
+    }
+    // ancestor tables
+    for (int v = 1; v < NLEV; v++) for (int l = 0; l < NJ; l++) { int a = T.anc[v-1][l]; T.anc[v][l] = a < 0 ? -1 : T.anc[v-1][a]; }
+    for (int l = 0; l < NJ; l++) { if (!T.jtype[l]) continue; for (int a = l; a >= 0; a = T.anc[0][a]) T.amask[l] |= 1 << a; }
+    for (int l = 0; l < NJ; l++) for (int i = 0; i < NJ; i++) if (T.jtype[i] && (T.amask[i] >> l & 1)) T.dmask[l] |= 1 << i;
+    for (int l = 0; l < NJ; l++) if (T.jtype[l] && T.anc[NLEV-1][l] >= 0 && T.anc[0][T.anc[NLEV-1][l]] >= 0) return "robot_table: chain deeper than 16";
+    for (int l = 0; l < ndof; l++) {
+        T.home[l] = (float)home[l];
+        const bool act = l < n_act;
+        T.kp_act[l] = (float)(act ? gains[0] : gains[2]); T.kd_act[l] = (float)(act ? gains[1] : gains[3]);
+        T.kp_hold[l] = (float)gains[2]; T.kd_hold[l] = (float)gains[3];
+    }
+    // end effector: getLinkState()[0] is the link COM frame (reference panda_env.py:147,155)
+    {
+        const double* r = L(ee);
+        if (owner[ee] < 0) return "robot_table: end effector is fixed to the base";
+        T.ee_owner = lane_of[owner[ee]];
+        const Xf& F = to_owner[ee];
+        for (int k = 0; k < 9; k++) T.ee_R[k] = (float)F.R[k];
+        for (int a = 0; a < 3; a++) T.ee_p[a] = (float)(F.p[a] + F.R[a*3] * r[18] + F.R[a*3+1] * r[19] + F.R[a*3+2] * r[20]);
+    }
+    for (int s = 0; s < ns; s++) {
+        const double* r = t + 24 + nl * 40 + s * 8;
+        const int li = (int)r[0];
+        if (li < 0 || li >= nl || owner[li] < 0) return "robot_table: sphere on a base-fixed link";
+        const Xf& F = to_owner[li];
+        T.s_owner[s] = lane_of[owner[li]]; T.s_valid[s] = 1;
+        for (int a = 0; a < 3; a++) T.s_c[a][s] = (float)(F.p[a] + F.R[a*3] * r[1] + F.R[a*3+1] * r[2] + F.R[a*3+2] * r[3]);
+        T.s_r[s] = (float)r[4]; T.s_mu[s] = (float)r[5];
+    }
+    T.ndof = ndof; T.n_act = n_act; T.nspheres = ns;
+    return "";
+}
+
+}  // namespace pbre

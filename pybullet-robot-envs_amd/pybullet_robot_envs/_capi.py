@@ -1,0 +1,177 @@
+"""Thin ctypes binding of libpbre.so (C-ABI in include/pbre.h).
+
+This is the only place the Python package touches native code.  The library is the
+HIP engine built in-tree by `__graft_entry__.build()` (csrc/build.sh); there is NO CPU
+fallback: if the shared object is missing or no GPU is usable, loading/creating fails
+loudly with RuntimeError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")
+
+STATE_FLOATS = 48
+ROBOT_PANDA = 0
+TASK_REACH, TASK_PUSH = 0, 1
+F_NO_OBJECT, F_AUTO_RESET = 1, 2
+
+
+class Physics(C.Structure):
+    _fields_ = [("dt", C.c_double), ("gravity_z", C.c_double), ("solver_iters", C.c_int32),
+                ("erp", C.c_double), ("linear_slop", C.c_double), ("contact_margin", C.c_double),
+                ("lin_damping", C.c_double), ("ang_damping", C.c_double), ("max_coord_vel", C.c_double),
+                ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
+                ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
+                ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("robot", C.c_int32), ("task", C.c_int32), ("num_envs", C.c_int32), ("device_id", C.c_int32),
+                ("env_id_base", C.c_uint64), ("seed", C.c_uint64),
+                ("use_ik", C.c_int32), ("num_controlled_joints", C.c_int32), ("action_repeat", C.c_int32),
+                ("max_steps", C.c_int32), ("flags", C.c_int32),
+                ("obj_pose_rnd_std", C.c_double), ("tg_pose_rnd_std", C.c_double),
+                ("target_dist_min", C.c_double), ("act_scale", C.c_double),
+                ("kp_act", C.c_double), ("kd_act", C.c_double), ("kp_hold", C.c_double), ("kd_hold", C.c_double),
+                ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 16),
+                ("phys", Physics),
+                ("robot_table", C.c_void_p), ("robot_table_len", C.c_size_t)]
+
+
+_LIB = None
+
+
+def load(path=None):
+    """Load libpbre.so (once).  Raises RuntimeError when the HIP extension has not been built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError("libpbre.so not found at %s -- build the HIP engine first "
+                           "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    lib.pbre_last_error.restype = C.c_char_p
+    lib.pbre_last_error.argtypes = [C.c_void_p]
+    lib.pbre_destroy.restype = None
+    for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
+                 "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
+                 "pbre_timing", "pbre_kernel_info"):
+        getattr(lib, name).restype = C.c_int
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One pbre_ctx: `num_envs` environments on one GPU."""
+
+    def __init__(self, robot_table, task=TASK_PUSH, num_envs=1, lib=None, **overrides):
+        self.lib = lib or load()
+        self.cfg = Config()
+        rc = self.lib.pbre_default_config(C.byref(self.cfg), C.c_int32(ROBOT_PANDA), C.c_int32(task))
+        if rc != 0:
+            raise RuntimeError("pbre_default_config failed: %d" % rc)
+        self.cfg.num_envs = int(num_envs)
+        phys = overrides.pop("phys", None)
+        for k, v in overrides.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError("unknown pbre_config field %r" % k)
+            setattr(self.cfg, k, v)
+        if phys:
+            for k, v in phys.items():
+                if not hasattr(self.cfg.phys, k):
+                    raise TypeError("unknown pbre_physics field %r" % k)
+                setattr(self.cfg.phys, k, v)
+        self._table = np.ascontiguousarray(robot_table, dtype=np.float64)
+        self.cfg.robot_table = self._table.ctypes.data
+        self.cfg.robot_table_len = self._table.size
+        self._ctx = C.c_void_p()
+        rc = self.lib.pbre_create(C.byref(self.cfg), C.byref(self._ctx))
+        if rc != 0:
+            raise RuntimeError("pbre_create failed (%d): %s" % (rc, self.lib.pbre_last_error(None).decode()))
+        od, ad, n = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self.lib.pbre_dims(self._ctx, C.byref(od), C.byref(ad), C.byref(n)))
+        self.obs_dim, self.act_dim, self.num_envs = od.value, ad.value, n.value
+        self._out = np.zeros((self.num_envs, self.obs_dim + 2), np.float32)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libpbre error %d: %s" % (rc, self.lib.pbre_last_error(self._ctx).decode()))
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.pbre_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def obs_limits(self):
+        lo = np.zeros(self.obs_dim, np.float32)
+        hi = np.zeros(self.obs_dim, np.float32)
+        self._chk(self.lib.pbre_obs_limits(self._ctx, _fp(lo), _fp(hi)))
+        return lo, hi
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.num_envs, self.obs_dim), np.float32)
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(mask, dtype=np.uint8)
+            assert m.shape == (self.num_envs,)
+        self._chk(self.lib.pbre_reset(self._ctx, _fp(m) if m is not None else None, _fp(obs)))
+        return obs
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, self.act_dim):
+            raise ValueError("actions must have shape (%d, %d), got %r" % (self.num_envs, self.act_dim, a.shape))
+        self._chk(self.lib.pbre_step(self._ctx, _fp(a), _fp(self._out)))
+        o = self._out
+        return o[:, :self.obs_dim].copy(), o[:, self.obs_dim].copy(), o[:, self.obs_dim + 1].copy()
+
+    def step_device(self, d_actions_ptr, d_out_ptr, stream=None):
+        self._chk(self.lib.pbre_step_device(self._ctx, C.c_void_p(d_actions_ptr), C.c_void_p(d_out_ptr),
+                                            C.c_void_p(stream or 0)))
+
+    def sync(self):
+        self._chk(self.lib.pbre_sync(self._ctx))
+
+    def get_state(self):
+        s = np.zeros((self.num_envs, STATE_FLOATS), np.float32)
+        self._chk(self.lib.pbre_get_state(self._ctx, _fp(s)))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        assert s.shape == (self.num_envs, STATE_FLOATS)
+        self._chk(self.lib.pbre_set_state(self._ctx, _fp(s)))
+
+    def observe(self):
+        obs = np.zeros((self.num_envs, self.obs_dim), np.float32)
+        self._chk(self.lib.pbre_observe(self._ctx, _fp(obs)))
+        return obs
+
+    def settle(self, n, flags=0):
+        self._chk(self.lib.pbre_settle(self._ctx, C.c_int32(n), C.c_int32(flags)))
+
+    def timing(self):
+        ms = (C.c_double * 3)()
+        self._chk(self.lib.pbre_timing(self._ctx, ms, C.c_int32(3)))
+        return list(ms)
+
+    def kernel_info(self):
+        info = (C.c_int32 * 3)()
+        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(3)))
+        return list(info)

@@ -1,0 +1,107 @@
+// emu_capi.cpp -- TEST INFRASTRUCTURE.  Builds libpbre_emu.so: the same C-ABI symbols as
+// libpbre.so (include/pbre.h), but the lane-generic step (csrc/pbre_core.hpp) runs through the
+// CPU lane emulation (lanes_host.hpp) over host memory.  Purpose: check the device algorithm
+// against the oracle in the GPU-less dev container (pytest -m "not gpu").  The product never
+// loads this library; it is neither shipped nor a fallback.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+#include "lanes_host.hpp"
+#include "../../pybullet-robot-envs_amd/csrc/pbre_host.hpp"
+#include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
+
+using namespace pbre;
+using CoreH = Core<pbre_emu::HostLanes>;
+
+struct pbre_ctx {
+    pbre_config cfg;
+    Tables T; Params P;
+    int n, obs_dim, act_dim;
+    std::vector<float> state;
+    std::vector<unsigned> episode;
+    std::string err;
+};
+static std::string g_err;
+
+extern "C" {
+
+int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return default_config(cfg, robot, task); }
+
+int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
+    if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
+    pbre_ctx* c = new pbre_ctx();
+    c->cfg = *cfg;
+    std::string e = make_tables(*cfg, c->T, c->P);
+    if (!e.empty()) { g_err = e; delete c; return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG); }
+    c->cfg.robot_table = nullptr;
+    c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
+    c->state.assign((size_t)c->n * STATE, 0.f);
+    c->episode.assign(c->n, 0u);
+    *out = c;
+    return PBRE_OK;
+}
+void pbre_destroy(pbre_ctx* c) { delete c; }
+const char* pbre_last_error(const pbre_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
+    if (!c) return PBRE_E_ARG;
+    if (od) *od = c->obs_dim; if (ad) *ad = c->act_dim; if (n) *n = c->n;
+    return PBRE_OK;
+}
+
+static void settle(pbre_ctx* c, int e, int n, int flags) {
+    for (int i = 0; i < n; i++) CoreH::step(c->T, c->P, &c->state[(size_t)e * STATE], nullptr, nullptr, 0, flags);
+}
+
+int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
+    if (!c) return PBRE_E_ARG;
+    for (int e = 0; e < c->n; e++) {
+        float* st = &c->state[(size_t)e * STATE];
+        if (!mask || mask[e]) {
+            unsigned long long id = c->P.env_id_base + (unsigned long long)e;
+            unsigned ep = c->episode[e]++;
+            CoreH::init_state(c->T, c->P, id, ep, st);
+            settle(c, e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
+            settle(c, e, 101, c->cfg.flags & PBRE_F_NO_OBJECT);        // world loaded: 100 + 1 steps (:136-148)
+            CoreH::sample_target(c->P, id, ep, st);
+        }
+    }
+    if (obs) return pbre_observe(c, obs);
+    return PBRE_OK;
+}
+
+int pbre_step(pbre_ctx* c, const float* actions, float* out) {
+    if (!c || !actions || !out) return PBRE_E_ARG;
+    const int ow = c->obs_dim + 2;
+    for (int e = 0; e < c->n; e++)
+        CoreH::step(c->T, c->P, &c->state[(size_t)e * STATE], actions + (size_t)e * c->act_dim, out + (size_t)e * ow,
+                    CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & PBRE_F_NO_OBJECT);
+    return PBRE_OK;
+}
+int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }
+int pbre_sync(pbre_ctx*) { return PBRE_OK; }
+
+int pbre_get_state(pbre_ctx* c, float* s) { if (!c || !s) return PBRE_E_ARG; std::memcpy(s, c->state.data(), c->state.size() * 4); return PBRE_OK; }
+int pbre_set_state(pbre_ctx* c, const float* s) { if (!c || !s) return PBRE_E_ARG; std::memcpy(c->state.data(), s, c->state.size() * 4); return PBRE_OK; }
+
+int pbre_observe(pbre_ctx* c, float* obs) {
+    if (!c || !obs) return PBRE_E_ARG;
+    std::vector<float> row(c->obs_dim + 2);
+    for (int e = 0; e < c->n; e++) {
+        float* st = &c->state[(size_t)e * STATE];
+        auto Q = pbre_emu::HostLanes::load(st), V = pbre_emu::HostLanes::load(st + 16), X = pbre_emu::HostLanes::load(st + 32);
+        CoreH::observe(c->T, c->P, st, Q, V, X, row.data(), CoreH::M_OBS);
+        std::memcpy(obs + (size_t)e * c->obs_dim, row.data(), c->obs_dim * 4);
+    }
+    return PBRE_OK;
+}
+int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
+    if (!c || n < 0) return PBRE_E_ARG;
+    for (int e = 0; e < c->n; e++) settle(c, e, n, flags & PBRE_F_NO_OBJECT);
+    return PBRE_OK;
+}
+int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; obs_limits(c->cfg, c->T, lo, hi); return PBRE_OK; }
+int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
+int pbre_kernel_info(const pbre_ctx*, int32_t* info, int32_t n) { for (int i = 0; i < n; i++) info[i] = 0; return PBRE_OK; }
+
+}  // extern "C"
