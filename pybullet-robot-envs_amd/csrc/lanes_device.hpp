@@ -1,0 +1,86 @@
+// lanes_device.hpp -- gfx950 (CDNA4) lane backend for pbre_core.hpp.
+//
+// One env = one 16-lane DPP row; a wave64 carries 4 envs.  Row all-reduces are 4 DPP
+// steps (quad_perm xor1, quad_perm xor2, row_half_mirror, row_mirror) that the compiler
+// folds into v_add_f32_dpp; broadcasts/gathers inside a row are ds_bpermute_b32 (LDS
+// crossbar, no LDS memory).  Nothing here touches another row, so a wave never needs a
+// barrier and a workgroup never needs LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pbre {
+
+struct DevLanes {
+    using F = float; using I = int; using B = bool;
+    static __device__ __forceinline__ F c(float x) { return x; }
+    static __device__ __forceinline__ I ci(int x) { return x; }
+    static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 15u); }
+    static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 15u]; }
+    static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 15u]; }
+    static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 15u] : 0.f; }
+    static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 15u] = x; }
+    static __device__ __forceinline__ void storem(float* p, F x, B m) { if (m) p[threadIdx.x & 15u] = x; }
+    static __device__ __forceinline__ F abs(F x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ F sqrt(F x) { return sqrtf(x); }
+    static __device__ __forceinline__ F sin(F x) { return sinf(x); }
+    static __device__ __forceinline__ F cos(F x) { return cosf(x); }
+    static __device__ __forceinline__ F asin(F x) { return asinf(x); }
+    static __device__ __forceinline__ F atan2(F a, F b) { return atan2f(a, b); }
+    static __device__ __forceinline__ F fma(F a, F b, F c_) { return __builtin_fmaf(a, b, c_); }
+    static __device__ __forceinline__ F min(F a, F b) { return __builtin_fminf(a, b); }
+    static __device__ __forceinline__ F max(F a, F b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ F med3(F x, F lo, F hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+    static __device__ __forceinline__ B lt(F a, F b) { return a < b; }
+    static __device__ __forceinline__ B le(F a, F b) { return a <= b; }
+    static __device__ __forceinline__ B gt(F a, F b) { return a > b; }
+    static __device__ __forceinline__ B ge(F a, F b) { return a >= b; }
+    static __device__ __forceinline__ B eq(F a, F b) { return a == b; }
+    static __device__ __forceinline__ B ne(F a, F b) { return a != b; }
+    static __device__ __forceinline__ B eqi(I a, I b) { return a == b; }
+    static __device__ __forceinline__ B nei(I a, I b) { return a != b; }
+    static __device__ __forceinline__ B lti(I a, I b) { return a < b; }
+    static __device__ __forceinline__ B gei(I a, I b) { return a >= b; }
+    static __device__ __forceinline__ B band(B a, B b) { return a & b; }
+    static __device__ __forceinline__ B bor(B a, B b) { return a | b; }
+    static __device__ __forceinline__ B bnot(B a) { return !a; }
+    static __device__ __forceinline__ B bfalse() { return false; }
+    static __device__ __forceinline__ bool any(B a) { return __any((int)a) != 0; }   // wave-uniform
+    static __device__ __forceinline__ F sel(B m, F a, F b) { return m ? a : b; }
+    static __device__ __forceinline__ I seli(B m, I a, I b) { return m ? a : b; }
+    static __device__ __forceinline__ B bit(I m, int k) { return (m >> k) & 1; }
+    static __device__ __forceinline__ B biti(I m, I k) { return (m >> k) & 1; }
+    static __device__ __forceinline__ I maxi(I a, int b) { return a > b ? a : b; }
+    static __device__ __forceinline__ F itof(I a) { return (float)a; }
+    static __device__ __forceinline__ I ftoi(F a) { return (int)a; }
+
+    // ---- cross-lane, confined to the 16-lane row
+    static __device__ __forceinline__ int row_base() { return (int)(threadIdx.x & 48u); }
+    static __device__ __forceinline__ F gather(F a, I idx) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((row_base() | (idx & 15)) << 2, __float_as_int(a)));
+    }
+    static __device__ __forceinline__ I gatherI(I a, I idx) {
+        return __builtin_amdgcn_ds_bpermute((row_base() | (idx & 15)) << 2, a);
+    }
+    static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
+
+    template <int CTRL>
+    static __device__ __forceinline__ F dpp(F x) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+    }
+    static __device__ __forceinline__ F sum(F x) {
+        x += dpp<0xB1>(x);     // quad_perm [1,0,3,2]
+        x += dpp<0x4E>(x);     // quad_perm [2,3,0,1]
+        x += dpp<0x141>(x);    // row_half_mirror
+        x += dpp<0x140>(x);    // row_mirror
+        return x;
+    }
+    static __device__ __forceinline__ F vmin(F x) {
+        x = __builtin_fminf(x, dpp<0xB1>(x));
+        x = __builtin_fminf(x, dpp<0x4E>(x));
+        x = __builtin_fminf(x, dpp<0x141>(x));
+        x = __builtin_fminf(x, dpp<0x140>(x));
+        return x;
+    }
+};
+
+}  // namespace pbre

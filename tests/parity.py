@@ -1,0 +1,63 @@
+"""Shared parity checks: run an engine (HIP library on the GPU, or the host lane emulation on
+CPU) against the oracle on the same seeded inputs.  Tolerances are stated per quantity."""
+import numpy as np
+
+import orc
+import scenarios
+
+# float tolerances: device arithmetic is fp32, oracle fp64.  `rel` is |a-b| / (1 + |b|).
+TOL_STATE = 2e-4      # one step from identical states, all state entries
+TOL_OBS = 2e-3        # raw observation (EE velocity entries are divided by 0.03..0.07)
+TOL_REWARD = 1e-4
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
+
+
+def make_pair(Engine, lib, table, n, task=1, obj_std=0.05, tg_std=0.2, **kw):
+    eng = Engine(table, task=task, num_envs=n, lib=lib, obj_pose_rnd_std=obj_std, tg_pose_rnd_std=tg_std, **kw)
+    ora = orc.Oracle(table, task=task)
+    ora.task.obj_pose_rnd_std = obj_std
+    ora.task.tg_pose_rnd_std = tg_std
+    return eng, ora
+
+
+def check_reset(eng, ora, n):
+    obs = eng.reset()
+    st_o, obs_o = ora.batch_reset(n)
+    st_e = eng.get_state()
+    assert rel(st_e, st_o).max() < TOL_STATE, rel(st_e, st_o).max()
+    assert rel(obs, obs_o).max() < TOL_OBS
+    return st_o
+
+
+def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_obs=TOL_OBS):
+    """From identical fp32 states, one step each; re-synchronised every step."""
+    st = np.asarray(states, np.float64)
+    n = st.shape[0]
+    worst = {"state": 0.0, "obs": 0.0, "reward": 0.0}
+    for _ in range(steps):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        se = eng.get_state()
+        so, out = ora.batch_step(s32.astype(np.float64), a)
+        worst["state"] = max(worst["state"], rel(se, so).max())
+        worst["obs"] = max(worst["obs"], rel(ob, out[:, :-2]).max())
+        # reward/done: a success threshold can flip on an fp32 rounding; compare away from the threshold
+        flip = dn != out[:, -1]
+        assert flip.sum() <= max(1, n // 100), "done flags differ in %d envs" % flip.sum()
+        worst["reward"] = max(worst["reward"], rel(rw[~flip], out[~flip, -2]).max())
+        st = so
+    assert worst["state"] < tol_state, worst
+    assert worst["obs"] < tol_obs, worst
+    assert worst["reward"] < TOL_REWARD, worst
+    return worst
+
+
+def contact_states(ora, panda, base, rng, n_table=8, n_obj=8):
+    return np.concatenate([
+        scenarios.table_contact_states(ora, panda["model"], panda["spheres"], base, n_table, rng),
+        scenarios.object_contact_states(ora, panda["model"], panda["spheres"], base, n_obj, rng)])

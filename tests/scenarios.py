@@ -59,3 +59,36 @@ def object_contact_states(oracle, model, spheres, base, n, rng, pen=0.002, vel=0
         s[25:31] = rng.normal(0, vel * 0.5, 6)
         out.append(s)
     return np.array(out)
+
+
+def ik_position(oracle, target, q0=None, iters=200):
+    """Damped least-squares IK on the arm joints for the EE position (test helper only)."""
+    q = (HOME if q0 is None else q0).copy()
+    ee = oracle.model.ee_link
+    lo, hi = joint_limits(oracle)
+    for _ in range(iters):
+        R, p = oracle.fk(q)
+        e = np.asarray(target) - p[ee]
+        if np.linalg.norm(e) < 1e-5:
+            break
+        J = np.zeros((3, 7))
+        for j in range(7):
+            dq = q.copy(); dq[j] += 1e-6
+            J[:, j] = (oracle.fk(dq)[1][ee] - p[ee]) / 1e-6
+        q[:7] += J.T @ np.linalg.solve(J @ J.T + 1e-4 * np.eye(3), e) * 0.5
+        q = np.clip(q, lo, hi)
+    return q
+
+
+def push_actions(oracle, state, steps_approach=120, steps_push=160):
+    """Open-loop action sequence: move the hand behind the cube (-x side), then sweep +x through it."""
+    obj = np.asarray(state[9:12], dtype=float)
+    q_pre = ik_position(oracle, obj + [-0.10, 0.0, 0.035])
+    q_end = ik_position(oracle, obj + [0.08, 0.0, 0.035], q0=q_pre)
+    return q_pre, q_end, steps_approach, steps_push
+
+
+def track(q, q_goal, amax=1.0):
+    """Action that moves the arm joints toward q_goal (0.05 rad per unit action, position gain 0.5 ->
+    0.025 rad/step at |a| = 1); amax limits the speed."""
+    return np.clip((q_goal[:7] - q[:7]) / 0.05 * 2.0, -amax, amax)

@@ -1,0 +1,77 @@
+"""Device algorithm (csrc/pbre_core.hpp) executed through the CPU lane emulation vs the oracle.
+CPU only; the same checks run against the HIP library in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import parity
+from pybullet_robot_envs import _capi
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_reset_and_steps(panda, emu_lib, task):
+    n = 6
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], n, task=task)
+    st = parity.check_reset(eng, ora, n)
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(0), steps=4)
+
+
+def test_contact_rich_states(panda, emu_lib):
+    eng0, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    rng = np.random.default_rng(1)
+    S = parity.contact_states(ora, panda, base[0], rng, 6, 6)
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], len(S))
+    # stiff motor-vs-contact conflicts amplify fp32 rounding: the oracle's own fp32 build is 1.5e-4 away
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3)
+
+
+def test_joint_limit_rows(panda, emu_lib):
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 4)
+    st, _ = ora.batch_reset(4)
+    st[0, 3] = 0.02       # joint 4 above its upper limit 0.0
+    st[1, 5] = -0.12      # joint 6 below its lower limit -0.0873
+    st[2, 7] = 0.045      # finger beyond 0.04
+    st[3, 1] = -1.9       # joint 2 below -1.8326
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(2), steps=2)
+
+
+def test_free_running_rollout(panda, emu_lib):
+    n = 4
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], n)
+    st = parity.check_reset(eng, ora, n)
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(st, a)
+    assert parity.rel(eng.get_state(), st).max() < 2e-3
+    assert parity.rel(ob, out[:, :-2]).max() < 1e-2
+
+
+def test_sharding_invariance(panda, emu_lib):
+    # RNG streams are keyed by the global env id: two shards of 3 == one batch of 6, bit for bit
+    kw = dict(task=1, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=emu_lib)
+    full = _capi.Engine(panda["table"], num_envs=6, **kw)
+    a = _capi.Engine(panda["table"], num_envs=3, env_id_base=0, **kw)
+    b = _capi.Engine(panda["table"], num_envs=3, env_id_base=3, **kw)
+    of, oa, ob = full.reset(), a.reset(), b.reset()
+    assert np.array_equal(of, np.concatenate([oa, ob]))
+    act = np.random.default_rng(4).uniform(-1, 1, (6, 7)).astype(np.float32)
+    rf = full.step(act); ra = a.step(act[:3]); rb = b.step(act[3:])
+    for x, y, z in zip(rf, ra, rb):
+        assert np.array_equal(x, np.concatenate([y, z]))
+
+
+def test_masked_reset(panda, emu_lib):
+    eng = _capi.Engine(panda["table"], task=1, num_envs=4, lib=emu_lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    eng.reset()
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        eng.step(rng.uniform(-1, 1, (4, 7)).astype(np.float32))
+    before = eng.get_state()
+    eng.reset(mask=[0, 1, 0, 1])
+    after = eng.get_state()
+    assert np.array_equal(before[[0, 2]], after[[0, 2]])           # untouched envs
+    assert after[1, 35] == 0 and after[3, 35] == 0                 # counters cleared
+    assert after[1, 37] == 1 and after[3, 37] == 1                 # second episode -> new object pose
+    assert not np.allclose(after[1, 9:11], before[1, 9:11])

@@ -1,0 +1,129 @@
+"""Parity tests proper: the HIP engine (libpbre.so, through the C-ABI) vs the CPU oracle on a real
+MI355X.  Same checks as test_emu_parity.py plus full-size property tests."""
+import numpy as np
+import pytest
+
+import parity
+from pybullet_robot_envs import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_reset_and_steps(panda, hip_lib, task):
+    n = 50                                   # not a multiple of 16: exercises the padding rows
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], n, task=task)
+    st = parity.check_reset(eng, ora, n)
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(0), steps=6)
+
+
+def test_contact_rich_states(panda, hip_lib):
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    rng = np.random.default_rng(1)
+    S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], len(S))
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3)
+
+
+def test_joint_limit_rows(panda, hip_lib):
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 4)
+    st, _ = ora.batch_reset(4)
+    st[0, 3] = 0.02
+    st[1, 5] = -0.12
+    st[2, 7] = 0.045
+    st[3, 1] = -1.9
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(2), steps=2)
+
+
+def test_free_running_rollout(panda, hip_lib):
+    n = 32
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], n)
+    st = parity.check_reset(eng, ora, n)
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(st, a)
+    assert parity.rel(eng.get_state(), st).max() < 2e-3
+    assert parity.rel(ob, out[:, :-2]).max() < 1e-2
+
+
+def test_matches_host_lane_emulation(panda, hip_lib, emu_lib):
+    # same algorithm, same fp32 arithmetic order: GPU vs CPU lane emulation agree to a few ulp
+    n = 20
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    g = _capi.Engine(panda["table"], lib=hip_lib, **kw)
+    e = _capi.Engine(panda["table"], lib=emu_lib, **kw)
+    og, oe = g.reset(), e.reset()
+    assert np.abs(og - oe).max() < 1e-4
+    e.set_state(g.get_state())
+    a = np.random.default_rng(6).uniform(-1, 1, (n, 7)).astype(np.float32)
+    rg, re_ = g.step(a), e.step(a)
+    assert np.abs(g.get_state() - e.get_state()).max() < 1e-4
+    assert np.abs(rg[0] - re_[0]).max() < 1e-3
+
+
+def test_sharding_invariance(panda, hip_lib):
+    kw = dict(task=1, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib)
+    full = _capi.Engine(panda["table"], num_envs=96, **kw)
+    a = _capi.Engine(panda["table"], num_envs=48, env_id_base=0, **kw)
+    b = _capi.Engine(panda["table"], num_envs=48, env_id_base=48, **kw)
+    of, oa, ob = full.reset(), a.reset(), b.reset()
+    assert np.array_equal(of, np.concatenate([oa, ob]))
+    act = np.random.default_rng(4).uniform(-1, 1, (96, 7)).astype(np.float32)
+    for _ in range(3):
+        rf = full.step(act); ra = a.step(act[:48]); rb = b.step(act[48:])
+        for x, y, z in zip(rf, ra, rb):
+            assert np.array_equal(x, np.concatenate([y, z]))
+
+
+def test_masked_reset(panda, hip_lib):
+    n = 40
+    eng = _capi.Engine(panda["table"], task=1, num_envs=n, lib=hip_lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    first = eng.reset()
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        eng.step(rng.uniform(-1, 1, (n, 7)).astype(np.float32))
+    before = eng.get_state()
+    mask = np.zeros(n, np.uint8); mask[[1, 7, 33]] = 1
+    eng.reset(mask=mask)
+    after = eng.get_state()
+    keep = mask == 0
+    assert np.array_equal(before[keep], after[keep])
+    assert (after[mask == 1, 35] == 0).all() and (after[mask == 1, 37] == 1).all()
+    # a full reset of a fresh engine reproduces episode 0 exactly (deterministic streams)
+    eng2 = _capi.Engine(panda["table"], task=1, num_envs=n, lib=hip_lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    assert np.array_equal(first, eng2.reset())
+
+
+def test_full_size_properties(panda, hip_lib):
+    """BASELINE config 3 size (32768 envs): size-independent properties."""
+    n = 32768
+    eng = _capi.Engine(panda["table"], task=1, num_envs=n, lib=hip_lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    obs = eng.reset()
+    st0 = eng.get_state()
+    assert np.isfinite(st0).all() and np.isfinite(obs).all()
+    assert np.abs(st0[:, 11] - 0.650).max() < 1e-3                       # every cube rests on the table (K3)
+    assert np.abs(st0[:, 9] - 0.45).max() <= 0.05 + 1e-6                 # object x,y noise U(+-0.05)
+    assert np.abs(st0[:, 10]).max() <= 0.05 + 1e-6
+    assert 0.37 - 1e-6 <= st0[:, 32].min() and st0[:, 32].max() <= 0.58 + 1e-6   # target clip range (K6)
+    assert st0[:, 32].std() > 0.05
+    rng = np.random.default_rng(7)
+    a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    ob, rw, dn = eng.step(a)
+    st1 = eng.get_state()
+    assert np.isfinite(st1).all() and np.isfinite(ob).all() and np.isfinite(rw).all()
+    # K2 motor law in free space: dq = 0.5 * (clip(q + 0.05 a) - q)
+    assert np.abs((st1[:, :7] - st0[:, :7]) - 0.025 * a).max() < 2e-5
+    assert np.abs(st1[:, 7:9] - 0.02).max() < 1e-5
+    # identical inputs -> identical outputs (replicated envs), no cross-env leakage
+    eng.set_state(np.repeat(st0[:1], n, 0))
+    ob2, rw2, dn2 = eng.step(np.repeat(a[:1], n, 0))
+    assert (ob2 == ob2[0]).all() and (rw2 == rw2[0]).all()
+    for _ in range(20):
+        ob, rw, dn = eng.step(rng.uniform(-1, 1, (n, 7)).astype(np.float32))
+    st = eng.get_state()
+    assert np.isfinite(st).all()
+    assert (st[:, 11] > 0.62).all()                                       # nothing fell through the table
+    assert np.abs(np.linalg.norm(st[:, 12:16], axis=1) - 1).max() < 1e-5  # unit quaternions

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, rocprof kernel-trace stats.  Logs -> gpurun_out/
+# usage: tools/gpu_round.sh <tag> [bench args...]
+TAG=${1:-r01}; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+echo "== rocminfo" ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee gpurun_out/pytest_gpu_$TAG.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke_$TAG.log
+echo "== bench"
+timeout 900 python bench.py "$@" 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
+echo "== rocprof"
+ROOTDIR=$(pwd)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $ROOTDIR/gpurun_out/rocprof_$TAG.log 2>&1)
+tail -3 gpurun_out/rocprof_$TAG.log
+find gpurun_out/prof_$TAG -name "*stats*" | head; 
+f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
