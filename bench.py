@@ -113,7 +113,11 @@ def main():
     pool = [torch.rand((n_local, eng.act_dim), device=dev, generator=gen) * 2 - 1 for _ in range(8)]
     out = torch.zeros((n_local, ow), device=dev, dtype=torch.float32)
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated non-null stream: the kernel, the HIP timing events and the RCCL gather all run on it
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
 
     def one_step(k, ev=None):
         a = pool[k % len(pool)]

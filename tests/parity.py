@@ -32,7 +32,22 @@ def check_reset(eng, ora, n):
     return st_o
 
 
-def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_obs=TOL_OBS):
+def ambiguous_envs(ora, s64, a, delta=3e-6):
+    """Envs whose result depends on a contact candidate lying within `delta` of the contact margin: the
+    contact set is a discontinuous function of the state there, so fp32 and fp64 may legitimately pick
+    different sets.  Detected by re-running the oracle with the margin nudged either way."""
+    m0 = ora.params.contact_margin
+    base, _ = ora.batch_step(s64, a)
+    bad = np.zeros(len(s64), bool)
+    for m in (m0 + delta, m0 - delta):
+        ora.params.contact_margin = m
+        alt, _ = ora.batch_step(s64, a)
+        bad |= np.abs(alt - base).max(axis=1) > 1e-9
+    ora.params.contact_margin = m0
+    return bad
+
+
+def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_obs=TOL_OBS, skip_ambiguous=False):
     """From identical fp32 states, one step each; re-synchronised every step."""
     st = np.asarray(states, np.float64)
     n = st.shape[0]
@@ -44,13 +59,17 @@ def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_
         ob, rw, dn = eng.step(a)
         se = eng.get_state()
         so, out = ora.batch_step(s32.astype(np.float64), a)
+        if skip_ambiguous:
+            ok = ~ambiguous_envs(ora, s32.astype(np.float64), a)
+            assert ok.mean() > 0.8, "too many threshold-ambiguous states"
+            se, so, ob, rw, dn, out = se[ok], so[ok], ob[ok], rw[ok], dn[ok], out[ok]
         worst["state"] = max(worst["state"], rel(se, so).max())
         worst["obs"] = max(worst["obs"], rel(ob, out[:, :-2]).max())
         # reward/done: a success threshold can flip on an fp32 rounding; compare away from the threshold
         flip = dn != out[:, -1]
         assert flip.sum() <= max(1, n // 100), "done flags differ in %d envs" % flip.sum()
         worst["reward"] = max(worst["reward"], rel(rw[~flip], out[~flip, -2]).max())
-        st = so
+        st = so if not skip_ambiguous else None
     assert worst["state"] < tol_state, worst
     assert worst["obs"] < tol_obs, worst
     assert worst["reward"] < TOL_REWARD, worst

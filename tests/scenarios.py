@@ -24,7 +24,7 @@ def table_contact_states(oracle, model, spheres, base, n, rng, vel=0.5):
     while len(out) < n:
         q = HOME + rng.normal(0, 0.5, 9)
         q[7:] = rng.uniform(0.0, 0.04, 2)
-        q = np.clip(q, lo, hi)
+        q = np.clip(q, lo + 1e-3, hi - 1e-3)     # stay off the exact limit: fp32 rounding of the limit would flip the limit row
         ds = [c[2] - r - 0.625 for c, r in sphere_centres(oracle, model, spheres, q)
               if 0.1 < c[0] < 1.6 and abs(c[1]) < 0.5]
         if ds and -0.004 < min(ds) < 0.0008:
@@ -42,7 +42,7 @@ def object_contact_states(oracle, model, spheres, base, n, rng, pen=0.002, vel=0
     for _ in range(n):
         q = HOME + rng.normal(0, 0.3, 9)
         q[7:] = 0.02
-        q = np.clip(q, lo, hi)
+        q = np.clip(q, lo + 1e-3, hi - 1e-3)
         c, r = sphere_centres(oracle, model, spheres, q)[rng.integers(0, 7)]
         d = rng.normal(size=3)
         d /= np.linalg.norm(d)

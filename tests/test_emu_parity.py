@@ -19,10 +19,10 @@ def test_contact_rich_states(panda, emu_lib):
     eng0, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 1)
     base, _ = ora.batch_reset(1)
     rng = np.random.default_rng(1)
-    S = parity.contact_states(ora, panda, base[0], rng, 6, 6)
+    S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
     eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], len(S))
     # stiff motor-vs-contact conflicts amplify fp32 rounding: the oracle's own fp32 build is 1.5e-4 away
-    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3)
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
 
 
 def test_joint_limit_rows(panda, emu_lib):

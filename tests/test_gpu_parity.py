@@ -23,7 +23,7 @@ def test_contact_rich_states(panda, hip_lib):
     rng = np.random.default_rng(1)
     S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
     eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], len(S))
-    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3)
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
 
 
 def test_joint_limit_rows(panda, hip_lib):
