@@ -38,7 +38,8 @@ extern "C" {
 
 enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
 enum { PBRE_ROBOT_PANDA = 0 };
-enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1 };
+enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
+       PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
        PBRE_F_AUTO_RESET = 2 };   /* done envs are re-initialised from the settled snapshot at the next step */
 

@@ -737,7 +737,7 @@ void orc_default_task(orc_task* t, int task) {
     t->kp_hold = 0.2; t->kd_hold = 1.0;             /* panda_env.py:76 */
     t->n_act = 7; t->seed = 1234;
 }
-int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + m->ndof + 6 + 6 + (t->task == 1 ? 3 : 0); }
+int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + m->ndof + 6 + 6 + (t->task >= 1 ? 3 : 0); }
 
 static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, real* vlin) {
     real R[ORC_MAXL*9], p[ORC_MAXL*3];
@@ -783,7 +783,7 @@ void orc_observation(const orc_model* m, const orc_task* t, const real* st, real
     orc_euler_from_quat(qr, er);
     for (int k = 0; k < 3; k++) obs[o++] = rel[k];
     for (int k = 0; k < 3; k++) obs[o++] = er[k];
-    if (t->task == 1) for (int k = 0; k < 3; k++) obs[o++] = st[32+k];
+    if (t->task >= 1) for (int k = 0; k < 3; k++) obs[o++] = st[32+k];
 }
 
 /* reward + termination; pre_increment=1 reproduces the in-loop `_termination()` + counter++ of apply_action
@@ -794,9 +794,18 @@ void orc_reward_done(const orc_model* m, const orc_task* t, real* st, int pre_in
     real d1 = 0, d2 = 0;
     for (int k = 0; k < 3; k++) { real a = pos[k] - st[9+k], b = st[9+k] - st[32+k]; d1 += a*a; d2 += b*b; }
     d1 = (real)sqrt((double)d1); d2 = (real)sqrt((double)d2);
-    real dsucc = t->task == 1 ? d2 : d1;
+    real dsucc = t->task >= 1 ? d2 : d1;
     int succ = dsucc <= (real)t->target_dist_min;
     int cnt = (int)st[35], term = (int)st[36];
+    if (t->task == 2) {
+        /* pandaPushGymGoalEnv (panda_push_gym_goal_env.py:89-122): _termination() is only the step budget (so the
+         * in-loop check of apply_action never sees success), done = budget or success, reward = -(d > thr) */
+        if (pre_increment && !(cnt > t->max_steps)) cnt++;
+        *done = (cnt > t->max_steps || succ) ? (real)1 : (real)0;
+        *reward = succ ? (real)0 : (real)-1;
+        st[35] = (real)cnt;
+        return;
+    }
     if (pre_increment) {
         int d0 = succ || term || cnt > t->max_steps;
         if (succ) term = 1;
@@ -843,7 +852,7 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
     for (int i = 0; i < 100; i++) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
     for (int i = 0; i < 101; i++) orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
     /* sample_tg_pose (panda_push_gym_env.py:333-360) */
-    if (t->task == 1) {
+    if (t->task >= 1) {
         real tx_min = (real)t->ws_lim[0][0] + (real)0.07, tx_max = (real)t->ws_lim[0][1] - (real)0.07;
         real ty_min = (real)t->ws_lim[1][0], ty_max = (real)t->ws_lim[1][1];
         real tx = st[9] + (real)0.05, ty = st[10] + (real)0.05, tz = st[11];

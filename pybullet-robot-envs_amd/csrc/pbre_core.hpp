@@ -677,24 +677,32 @@ struct Core {
         if (mode & M_TASK) {
             // _termination + counter (panda_push_gym_env.py:239-242, 301-316) and _compute_reward (:318-331)
             F d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
-            F dsucc = P.task == 1 ? d2 : d1;
+            F dsucc = P.task >= 1 ? d2 : d1;
             B succ = L::le(dsucc, L::c(P.dist_min));
             F cnt = L::bcast(Xr, 3), term = L::bcast(Xr, 4);
             F mx = L::c((float)P.max_steps);
-            B d0 = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
-            cnt = L::sel(d0, cnt, cnt + one);
-            term = L::sel(succ, one, term);
-            B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
-            done = L::sel(dn, one, zero);
-            F base = P.task == 1 ? zero - d1 - d2 : zero - d1;
-            reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
+            if (P.task == 2) {
+                // goal env (panda_push_gym_goal_env.py:89-122): _termination is only the step budget, success does
+                // not latch; done = budget or success; sparse reward -(d > threshold)
+                cnt = L::sel(L::gt(cnt, mx), cnt, cnt + one);
+                done = L::sel(L::bor(succ, L::gt(cnt, mx)), one, zero);
+                reward = L::sel(succ, zero, zero - one);
+            } else {
+                B d0 = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
+                cnt = L::sel(d0, cnt, cnt + one);
+                term = L::sel(succ, one, term);
+                B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
+                done = L::sel(dn, one, zero);
+                F base = P.task == 1 ? zero - d1 - d2 : zero - d1;
+                reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
+            }
             F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, Xr));
             L::store(st + 32, Xn);
         }
         if (out) {
             // row-major [obs | reward | done]; obs layout SURVEY Appendix C
             const int nd = T.ndof;
-            const int od = 9 + nd + 12 + (P.task == 1 ? 3 : 0);
+            const int od = 9 + nd + 12 + (P.task >= 1 ? 3 : 0);
             F head = L::sel(L::eqi(lane, 0), ee.x, L::sel(L::eqi(lane, 1), ee.y, L::sel(L::eqi(lane, 2), ee.z,
                      L::sel(L::eqi(lane, 3), eul.x, L::sel(L::eqi(lane, 4), eul.y, L::sel(L::eqi(lane, 5), eul.z,
                      L::sel(L::eqi(lane, 6), vn.x, L::sel(L::eqi(lane, 7), vn.y, vn.z))))))));
@@ -706,7 +714,7 @@ struct Core {
                      L::sel(L::eqi(lane, 6), rel.x, L::sel(L::eqi(lane, 7), rel.y, L::sel(L::eqi(lane, 8), rel.z,
                      L::sel(L::eqi(lane, 9), er.x, L::sel(L::eqi(lane, 10), er.y, L::sel(L::eqi(lane, 11), er.z,
                      L::sel(L::eqi(lane, 12), tg.x, L::sel(L::eqi(lane, 13), tg.y, tg.z))))))))))))));
-            L::storem(o2, tail, L::lti(lane, P.task == 1 ? 15 : 12));
+            L::storem(o2, tail, L::lti(lane, P.task >= 1 ? 15 : 12));
             F rd = L::sel(L::eqi(lane, 0), reward, done);
             L::storem(out + od, rd, L::lti(lane, 2));
         }
@@ -746,7 +754,7 @@ struct Core {
     }
     // sample_tg_pose (reference panda_push_gym_env.py:333-360) on the settled object position
     static PBRE_HD void sample_target(const Params& P, unsigned long long env_id, unsigned episode, float* st) {
-        if (P.task != 1) return;
+        if (P.task < 1) return;
         const float tx_min = P.ws[0][0] + 0.07f, tx_max = P.ws[0][1] - 0.07f;
         float tx = st[9] + 0.05f, ty = st[10] + 0.05f;
         if (P.tg_std > 0.f) {

@@ -29,11 +29,11 @@ inline void default_physics(pbre_physics& p) {
 }
 
 inline int default_config(pbre_config* c, int robot, int task) {
-    if (!c || robot != PBRE_ROBOT_PANDA || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH)) return PBRE_E_ARG;
+    if (!c || robot != PBRE_ROBOT_PANDA || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
     std::memset(c, 0, sizeof *c);
     c->robot = robot; c->task = task; c->num_envs = 1; c->device_id = 0; c->seed = 1234;
     c->use_ik = 0; c->num_controlled_joints = 7; c->action_repeat = 1; c->max_steps = 1000;
-    c->target_dist_min = task == PBRE_TASK_PUSH ? 0.1 : 0.03;   // panda_push_gym_env.py:52, panda_reach_gym_env.py:47
+    c->target_dist_min = task == PBRE_TASK_REACH ? 0.03 : 0.1;   // panda_push_gym_env.py:52, panda_reach_gym_env.py:47
     c->act_scale = 0.05;                                        // panda_push_gym_env.py:225
     c->kp_act = 0.5; c->kd_act = 1.0;                           // panda_env.py:308
     c->kp_hold = 0.2; c->kd_hold = 1.0;                         // panda_env.py:76
@@ -74,7 +74,7 @@ inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
     return "";
 }
 
-inline int obs_dim_of(const Tables& T, const Params& P) { return 9 + T.ndof + 12 + (P.task == PBRE_TASK_PUSH ? 3 : 0); }
+inline int obs_dim_of(const Tables& T, const Params& P) { return 9 + T.ndof + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0); }
 
 // Observation limits exactly as the reference assembles them (panda_env.py:141-193 limits list,
 // panda_push_gym_env.py:73-75 / panda_reach_gym_env.py:68-70 z-min, :177-185 extras).
@@ -82,7 +82,7 @@ inline void obs_limits(const pbre_config& c, const Tables& T, float* lo, float* 
     const double PI = 3.14159265358979323846;
     int o = 0;
     auto put = [&](double a, double b) { lo[o] = (float)a; hi[o] = (float)b; o++; };
-    const double zmin = c.task == PBRE_TASK_PUSH ? c.h_table - 0.2 : c.h_table;
+    const double zmin = c.task != PBRE_TASK_REACH ? c.h_table - 0.2 : c.h_table;
     put(0.3, 0.65); put(-0.3, 0.3); put(zmin, 1.5);                 // robot workspace (panda_env.py:37)
     for (int k = 0; k < 3; k++) put(-PI, PI);
     for (int k = 0; k < 3; k++) put(-1, 1);
@@ -91,7 +91,7 @@ inline void obs_limits(const pbre_config& c, const Tables& T, float* lo, float* 
     for (int k = 0; k < 3; k++) put(-PI, PI);
     for (int k = 0; k < 3; k++) put(-0.5, 0.5);
     for (int k = 0; k < 3; k++) put(0, 2 * PI);
-    if (c.task == PBRE_TASK_PUSH) for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
+    if (c.task != PBRE_TASK_REACH) for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
 }
 
 }  // namespace pbre

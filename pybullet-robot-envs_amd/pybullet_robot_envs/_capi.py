@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")
 
 STATE_FLOATS = 48
 ROBOT_PANDA = 0
-TASK_REACH, TASK_PUSH = 0, 1
+TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
 F_NO_OBJECT, F_AUTO_RESET = 1, 2
 
 

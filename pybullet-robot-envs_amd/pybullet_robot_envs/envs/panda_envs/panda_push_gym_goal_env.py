@@ -1,0 +1,77 @@
+"""pandaPushGymGoalEnv (reference pybullet_robot_envs/envs/panda_envs/panda_push_gym_goal_env.py):
+dict observation for HER, sparse reward -(d > threshold), done = step budget or success."""
+import numpy as np
+
+from pybullet_robot_envs import _capi
+from pybullet_robot_envs._gym import GoalEnv, spaces
+from pybullet_robot_envs.envs.panda_envs.panda_push_gym_env import pandaPushGymEnv
+from pybullet_robot_envs.envs.world_envs.world_env import get_objects_list
+from pybullet_robot_envs.envs.utils import goal_distance, scale_gym_data
+
+
+class pandaPushGymGoalEnv(GoalEnv, pandaPushGymEnv):
+    _TASK = _capi.TASK_PUSH_GOAL
+
+    def __init__(self,
+                 numControlledJoints=7,
+                 use_IK=0,
+                 action_repeat=1,
+                 obj_name=get_objects_list()[1],
+                 renders=False,
+                 max_steps=1000,
+                 obj_pose_rnd_std=0, tg_pose_rnd_std=0.2,
+                 includeVelObs=True,
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, _lib=None):
+        pandaPushGymEnv.__init__(self, numControlledJoints, use_IK, action_repeat, obj_name, renders, max_steps,
+                                 obj_pose_rnd_std, tg_pose_rnd_std, includeVelObs,
+                                 num_envs=num_envs, device_id=device_id, env_id_base=env_id_base, seed=seed, _lib=_lib)
+
+    def create_gym_spaces(self):
+        box, action_space = pandaPushGymEnv.create_gym_spaces(self)
+        observation_space = spaces.Dict(dict(
+            desired_goal=spaces.Box(-10, 10, shape=(3,), dtype='float32'),
+            achieved_goal=spaces.Box(-10, 10, shape=(3,), dtype='float32'),
+            observation=box,
+        ))
+        return observation_space, action_space
+
+    def _goal_dict(self, raw):
+        raw = raw.astype(np.float64)
+        obs = {'observation': scale_gym_data(self.observation_space['observation'], raw),
+               'achieved_goal': raw[:, 18:21].copy(),      # object position (world_observation[:3])
+               'desired_goal': raw[:, 30:33].copy()}       # target pose
+        if self.num_envs == 1:
+            obs = dict((k, v[0]) for k, v in obs.items())
+        return obs
+
+    def get_goal_observation(self):
+        raw = self._engine.observe().astype(np.float64)
+        d = {'observation': raw, 'achieved_goal': raw[:, 18:21].copy(), 'desired_goal': raw[:, 30:33].copy()}
+        if self.num_envs == 1:
+            d = dict((k, v[0]) for k, v in d.items())
+        return d
+
+    def reset(self, mask=None):
+        return self._goal_dict(self._engine.reset(mask))
+
+    def step(self, action):
+        raw, reward, done = self._raw_step(action)
+        obs = self._goal_dict(raw)
+        succ = self._is_success(obs['achieved_goal'], obs['desired_goal'])
+        info = {'is_success': succ}
+        if self.num_envs == 1:
+            return obs, np.float32(reward[0]), bool(done[0]), info
+        return obs, reward.astype(np.float32), done.astype(bool), info
+
+    def _termination(self):
+        st = self._engine.get_state()
+        return self._squeeze((st[:, 35] > self._max_steps).astype(np.float32))
+
+    def _is_success(self, achieved_goal, goal):
+        d = goal_distance(np.asarray(achieved_goal)[..., :3], np.asarray(goal)[..., :3])
+        return d <= self._target_dist_min
+
+    def compute_reward(self, achieved_goal, goal, info):
+        # vectorised over any leading batch dimensions (HER relabelling)
+        d = goal_distance(np.asarray(achieved_goal)[..., :3], np.asarray(goal)[..., :3])
+        return -(d > self._target_dist_min).astype(np.float32)

@@ -127,3 +127,31 @@ def test_full_size_properties(panda, hip_lib):
     assert np.isfinite(st).all()
     assert (st[:, 11] > 0.62).all()                                       # nothing fell through the table
     assert np.abs(np.linalg.norm(st[:, 12:16], axis=1) - 1).max() < 1e-5  # unit quaternions
+
+
+def test_reference_golden_outputs(hip_lib):
+    """Outputs of the reference's own classes (tests/golden, captured over the oracle's physics) reproduced by the
+    HIP engine through the drop-in classes, step by step from the reference's states."""
+    import os
+    from pybullet_robot_envs.envs import pandaPushGymEnv, pandaReachGymEnv, pandaPushGymGoalEnv
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "panda_glue.npz"))
+    for cls, tag, kw in [(pandaPushGymEnv, "pushA", {}), (pandaPushGymEnv, "pushB", {"max_steps": 6}),
+                         (pandaReachGymEnv, "reachC", {"max_steps": 5}),
+                         (pandaPushGymGoalEnv, "goalD", {"max_steps": 4, "tg_pose_rnd_std": 0.0})]:
+        env = cls(**kw)
+        goal = tag.startswith("goal")
+        o = env.reset()
+        o = o["observation"] if goal else o
+        if tag != "goalD":
+            assert np.abs(o - G[tag + "_reset_obs"]).max() < 2e-3
+        for k in range(len(G[tag + "_actions"])):
+            s = np.zeros((1, 48), np.float32)
+            s[0] = G[tag + "_pre_state"][k]
+            env._engine.set_state(s)
+            ob, r, d, info = env.step(G[tag + "_actions"][k])
+            ob = ob["observation"] if goal else ob
+            assert np.abs(ob - G[tag + "_obs"][k]).max() < 5e-3
+            assert abs(float(r) - G[tag + "_reward"][k]) < 1e-3 * max(1, abs(G[tag + "_reward"][k]))
+            assert float(d) == G[tag + "_done"][k]
+            assert int(env._env_step_counter) == G[tag + "_counter"][k]
+        env.close()

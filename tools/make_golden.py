@@ -1,0 +1,140 @@
+#!/usr/bin/env python
+"""Capture golden vectors from the REFERENCE's own Python classes (dev container only).
+
+The reference Gym envs (/root/reference/pybullet_robot_envs/envs/panda_envs/*.py, utils.py) are imported
+unmodified and executed with stub `pybullet` / `gym` modules (tools/ref_stubs): PyBullet's physics is replaced
+by the CPU oracle, so what is captured -- and pinned -- is the reference's *glue* arithmetic: observation
+order and limits, float32-limit scaling, reward, termination and step-counter logic, object/target start
+poses.  Output: tests/golden/panda_glue.npz (data only).  Usage: python tools/make_golden.py [/root/reference]"""
+import importlib.util
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orc  # noqa: E402  (adds the engine package to sys.path; the reference path is put in front below)
+
+sys.path.insert(0, os.path.join(ROOT, "tools", "ref_stubs"))
+spec = importlib.util.spec_from_file_location("pbre_gymshim", os.path.join(ROOT, "pybullet-robot-envs_amd", "pybullet_robot_envs", "_gym.py"))
+shim = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(shim)
+assert not shim.HAVE_GYM
+gym = types.ModuleType("gym")
+gym.Env, gym.GoalEnv, gym.spaces = shim.Env, shim.GoalEnv, shim.spaces
+gym_spaces = types.ModuleType("gym.spaces"); gym_spaces.Box, gym_spaces.Dict = shim.Box, shim.Dict
+gym_utils = types.ModuleType("gym.utils"); gym_seeding = types.ModuleType("gym.utils.seeding")
+gym_seeding.np_random = shim.seeding.np_random; gym_utils.seeding = gym_seeding
+gym_envs = types.ModuleType("gym.envs"); gym_reg = types.ModuleType("gym.envs.registration")
+gym_reg.register = lambda **k: None; gym_envs.registration = gym_reg
+gym_envs.registry = types.SimpleNamespace(all=lambda: [])
+gym.utils, gym.envs = gym_utils, gym_envs
+for n, m in [("gym", gym), ("gym.spaces", gym_spaces), ("gym.utils", gym_utils), ("gym.utils.seeding", gym_seeding),
+             ("gym.envs", gym_envs), ("gym.envs.registration", gym_reg)]:
+    sys.modules[n] = m
+for n in ("matplotlib", "matplotlib.pyplot", "pandas"):
+    try:
+        __import__(n)
+    except Exception:
+        sys.modules[n] = types.ModuleType(n)
+
+assert "pybullet_robot_envs" not in sys.modules
+sys.path.insert(0, REF)
+time.sleep = lambda s: None                      # reference sleeps 1/240 s per step (panda_push_gym_env.py:237)
+import builtins  # noqa: E402
+_print = builtins.print
+builtins.print = lambda *a, **k: None            # the reference prints on import / on success
+import pybullet as p  # noqa: E402  (stub)
+from pybullet_robot_envs.envs.panda_envs.panda_push_gym_env import pandaPushGymEnv  # noqa: E402
+from pybullet_robot_envs.envs.panda_envs.panda_reach_gym_env import pandaReachGymEnv  # noqa: E402
+from pybullet_robot_envs.envs.panda_envs.panda_push_gym_goal_env import pandaPushGymGoalEnv  # noqa: E402
+from pybullet_robot_envs.envs import utils as ref_utils  # noqa: E402
+builtins.print = _print
+import pybullet_robot_envs  # noqa: E402
+assert pybullet_robot_envs.__file__.startswith(REF), pybullet_robot_envs.__file__
+
+out = {}
+rng = np.random.default_rng(2024)
+
+
+def rollout(env, tag, actions, goal=False, set_target=None):
+    builtins.print = lambda *a, **k: None
+    o0 = env.reset()
+    if set_target is not None:
+        env._target_pose = tuple(set_target)
+        p.W.state[32:35] = set_target
+    else:
+        p.W.state[32:35] = getattr(env, "_target_pose", (0, 0, 0))
+    out[tag + "_reset_state"] = p.W.state.copy()
+    out[tag + "_reset_obs"] = np.asarray(o0["observation"] if goal else o0, dtype=np.float64)
+    pre, obs, rew, done, cnt, succ, raw = [], [], [], [], [], [], []
+    for a in actions:
+        s = p.W.state.copy()
+        s[35] = env._env_step_counter
+        s[36] = float(bool(env.terminated))
+        pre.append(s)
+        o, r, d, info = env.step(a.copy())
+        obs.append(np.asarray(o["observation"] if goal else o, dtype=np.float64))
+        raw.append(np.asarray(env.get_extended_observation()[0], dtype=np.float64))
+        rew.append(float(r)); done.append(float(d)); cnt.append(env._env_step_counter)
+        succ.append(float(info.get("is_success", False)))
+    builtins.print = _print
+    out[tag + "_actions"] = np.array(actions, dtype=np.float64)
+    out[tag + "_pre_state"] = np.array(pre)
+    out[tag + "_obs"] = np.array(obs); out[tag + "_raw_obs"] = np.array(raw)
+    out[tag + "_reward"] = np.array(rew); out[tag + "_done"] = np.array(done)
+    out[tag + "_counter"] = np.array(cnt); out[tag + "_success"] = np.array(succ)
+
+
+def spaces_of(env, tag, goal=False):
+    box = env.observation_space["observation"] if goal else env.observation_space
+    out[tag + "_obs_low"] = box.low; out[tag + "_obs_high"] = box.high
+    out[tag + "_act_low"] = env.action_space.low; out[tag + "_act_high"] = env.action_space.high
+
+
+# A: registered defaults (tg std 0): first step succeeds (quirk E-1 / K4)
+envA = pandaPushGymEnv()
+spaces_of(envA, "push")
+rollout(envA, "pushA", rng.uniform(-1, 1, (4, 7)))
+# B: far target, short budget: reward shaping + counter/max_steps edge
+envB = pandaPushGymEnv(max_steps=6)
+rollout(envB, "pushB", rng.uniform(-1, 1, (10, 7)), set_target=(0.58, 0.25, 0.64999))
+# C: reach
+envC = pandaReachGymEnv(max_steps=5)
+spaces_of(envC, "reach")
+rollout(envC, "reachC", rng.uniform(-1, 1, (9, 7)))
+# D: goal env (dict obs, sparse reward)
+np.random.seed(7)
+envD = pandaPushGymGoalEnv(max_steps=4, tg_pose_rnd_std=0.0)
+spaces_of(envD, "goal", goal=True)
+rollout(envD, "goalD", rng.uniform(-1, 1, (8, 7)), goal=True, set_target=(0.55, -0.2, 0.64999))
+rollout(envD, "goalE", rng.uniform(-1, 1, (3, 7)), goal=True)        # default target: inside the success radius
+
+# utils goldens
+box = envA.observation_space
+x = rng.uniform(-1, 1, (6, 33)) * (box.high - box.low) * 0.6 + 0.5 * (box.high + box.low)
+out["utils_x"] = x
+out["utils_scaled"] = np.array([ref_utils.scale_gym_data(box, xi) for xi in x])
+out["utils_unscaled"] = np.array([ref_utils.unscale_gym_data(box, si) for si in out["utils_scaled"]])
+a = rng.normal(size=(5, 3)); b = rng.normal(size=(5, 3))
+out["utils_a"], out["utils_b"] = a, b
+out["utils_dist"] = ref_utils.goal_distance(a, b)
+out["k5_scale"] = ref_utils.scale_gym_data(types.SimpleNamespace(low=np.array([0.3, -0.3, 0.425], np.float32),
+                                                                high=np.array([0.65, 0.3, 1.5], np.float32), shape=(3,)),
+                                           np.array([0.45, 0.0, 0.695]))
+# start poses (K6)
+out["obj_init_pose"] = np.array(envA._world._obj_init_pose, dtype=np.float64)
+out["h_table"] = np.float64(envA._world.get_table_height())
+
+dst = os.path.join(ROOT, "tests", "golden", "panda_glue.npz")
+np.savez_compressed(dst, **out)
+print("wrote", dst, "with", len(out), "arrays;", os.path.getsize(dst), "bytes")
+print("pushA reward/done:", out["pushA_reward"], out["pushA_done"])
+print("pushB done:", out["pushB_done"], "counter", out["pushB_counter"])
+print("reachC done:", out["reachC_done"], "goalD done", out["goalD_done"], out["goalD_reward"], "goalE", out["goalE_done"], out["goalE_reward"])
