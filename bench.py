@@ -103,8 +103,11 @@ def main():
     assert args.envs % world == 0
     n_local = args.envs // world
     tbl, _ = panda_table()
-    eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=n_local, device_id=local_rank,
-                       env_id_base=rank * n_local, seed=1234, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    from pybullet_robot_envs.sharding import ShardedEngine
+    sh = ShardedEngine(tbl, args.envs, task=_capi.TASK_PUSH, device_id=local_rank, seed=1234,
+                       obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    eng = sh.engine
+    assert (sh.n_local, sh.env_id_base) == (n_local, rank * n_local)
     ow = eng.obs_dim + 2
     eng.reset()
 
@@ -127,7 +130,7 @@ def main():
         if ev is not None:
             ev[1].record()
         if world > 1:
-            dist.gather(out, gathered, dst=0)
+            dist.gather(out, gathered, dst=0)       # the one collective of the data path (RCCL over xGMI)
 
     for k in range(args.warmup):
         one_step(k)

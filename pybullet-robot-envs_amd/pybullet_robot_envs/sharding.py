@@ -1,0 +1,70 @@
+"""Multi-GPU sharding of the env batch: one process per GPU (torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm), env i lives on rank i // (N / G).  Envs are independent, so the data path has no collective
+except the single gather per step that returns the stacked [obs | reward | done] rows to rank 0.
+RNG streams are keyed by the global env id (pbre_config.env_id_base), so results are bitwise independent of G."""
+import os
+
+import numpy as np
+
+from pybullet_robot_envs import _capi
+
+
+def shard_range(total_envs, rank, world):
+    if total_envs % world != 0:
+        raise ValueError("total_envs (%d) must be divisible by the number of ranks (%d)" % (total_envs, world))
+    n = total_envs // world
+    return rank * n, n
+
+
+class ShardedEngine(object):
+    """The local shard of a `total_envs`-wide batch plus the per-step gather."""
+
+    def __init__(self, robot_table, total_envs, task=_capi.TASK_PUSH, lib=None, device_id=None, **cfg):
+        import torch.distributed as dist
+        self.dist = dist
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.total_envs = int(total_envs)
+        base, n = shard_range(self.total_envs, self.rank, self.world)
+        if device_id is None:
+            device_id = int(os.environ.get("LOCAL_RANK", "0"))
+        self.engine = _capi.Engine(robot_table, task=task, num_envs=n, lib=lib, device_id=device_id,
+                                   env_id_base=base, **cfg)
+        self.n_local, self.env_id_base = n, base
+        self.obs_dim, self.act_dim = self.engine.obs_dim, self.engine.act_dim
+        self._gather_list = None
+
+    # ---- host-buffer path (numpy in, numpy out on rank 0) ----
+    def _gather_np(self, local):
+        import torch
+        if not self.distributed:
+            return local
+        t = torch.from_numpy(np.ascontiguousarray(local))
+        if self.dist.get_backend() == "nccl":
+            t = t.cuda()
+        outs = [torch.empty_like(t) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(t, outs, dst=0)
+        if self.rank != 0:
+            return None
+        return torch.cat(outs, 0).cpu().numpy()
+
+    def reset(self):
+        return self._gather_np(self.engine.reset())
+
+    def step(self, actions_local):
+        """actions_local: [n_local, act_dim] for this rank's envs.  Returns (obs, reward, done) stacked over all ranks
+        on rank 0, None elsewhere."""
+        obs, rew, done = self.engine.step(actions_local)
+        out = self._gather_np(np.concatenate([obs, rew[:, None], done[:, None]], 1))
+        if out is None:
+            return None
+        return out[:, :self.obs_dim], out[:, self.obs_dim], out[:, self.obs_dim + 1]
+
+    # ---- device-resident path (torch CUDA tensors; one RCCL gather per step) ----
+    def step_device(self, actions, out, gathered=None, stream=0):
+        """actions [n_local, act_dim] and out [n_local, obs_dim + 2]: CUDA float32 tensors on this rank's GPU;
+        gathered: list of `world` tensors like `out` on rank 0 (None elsewhere).  Asynchronous on `stream`."""
+        self.engine.step_device(actions.data_ptr(), out.data_ptr(), stream)
+        if self.distributed:
+            self.dist.gather(out, gathered if self.rank == 0 else None, dst=0)
