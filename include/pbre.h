@@ -41,7 +41,8 @@ enum { PBRE_ROBOT_PANDA = 0 };
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
-       PBRE_F_AUTO_RESET = 2 };   /* done envs are re-initialised from the settled snapshot at the next step */
+       PBRE_F_AUTO_RESET = 2,     /* done envs are re-initialised from the settled snapshot at the next step */
+       PBRE_F_FORCE_GENERAL = 4 };/* step every env with the general 16-lane row kernel (disable the lane-per-env fast path) */
 
 typedef struct pbre_ctx pbre_ctx;
 
@@ -127,7 +128,8 @@ int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
 
 /* wall-clock of the last pbre_step phases in ms: [0] upload, [1] kernels, [2] download */
 int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
-/* static kernel facts for the bench/roofline report: [0] VGPRs, [1] waves launched per step, [2] envs per wave */
+/* kernel facts for the bench/roofline report: [0] VGPRs of the fast kernel, [1] VGPRs of the general kernel,
+ * [2] fast path enabled, [3] envs stepped by the fast path in the most recent step, [4] envs stepped by the general kernel */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

@@ -9,6 +9,7 @@
 // reuse to be XCD-aware about, and every block is independent (no barriers, no atomics).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -18,27 +19,51 @@
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
+#include "pbre_fast.hpp"
 
 using namespace pbre;
 using CoreD = Core<DevLanes>;
+using FastD = Fast<TopoPanda>;
 
 constexpr int EPB = 16;              // envs per block
 constexpr int TPB = EPB * W;         // 256 threads
 
 // ------------------------------------------------------------------ kernels
-// MODE: CoreD::M_* bits.  n = real env count; state has ceil16(n) records.  actions/out rows of the
-// padding envs are redirected to env n-1 / a scratch row so the user buffers can be exactly [n][...].
+// General row kernel.  MODE: CoreD::M_* bits.  n = real env count; state has ceil16(n) + 16 records (the last 16 are
+// valid dummy records for the padding rows of a partially filled block).  With list == nullptr the kernel steps envs
+// [0, n); otherwise it steps the *count envs named in list (those the fast path declined); the grid is sized for the
+// worst case and surplus blocks exit immediately.  actions/out rows of padding rows are redirected to env 0 / a scratch row.
 template <int MODE>
 __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                               const float* __restrict__ actions, float* __restrict__ out,
-                                              float* __restrict__ scratch_row, int n, int act_dim, int ow, int flags) {
-    const int env = blockIdx.x * EPB + (threadIdx.x >> 4);
+                                              float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags,
+                                              const int* __restrict__ list, const int* __restrict__ count) {
+    const int row = threadIdx.x >> 4;
+    const int total = list ? *count : n;
+    const int i = blockIdx.x * EPB + row;
+    if ((int)blockIdx.x * EPB >= total) return;          // block-uniform: blocks beyond the list exit at once
+    const bool real = i < total;
+    const int env = real ? (list ? list[i] : i) : dummy_base + row;
     float* st = state + (size_t)env * STATE;
     const float* a = nullptr;
     float* o = nullptr;
-    if (MODE & CoreD::M_ACTION) a = actions + (size_t)(env < n ? env : n - 1) * act_dim;
-    if (MODE & CoreD::M_OBS) o = env < n ? out + (size_t)env * ow : scratch_row;
+    if (MODE & CoreD::M_ACTION) a = actions + (size_t)(real ? env : 0) * act_dim;
+    if (MODE & CoreD::M_OBS) o = real ? out + (size_t)env * ow : scratch_row;
     CoreD::step(*T, P, st, a, o, MODE, flags);
+}
+
+// Lane-per-env fast path: one thread = one env.  Envs it cannot handle (robot contact or limit row) are appended to
+// `list` for the general kernel.
+constexpr int FTPB = 64;
+template <int MODE>
+__global__ __launch_bounds__(FTPB) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out,
+                                               int n, int act_dim, int ow, int flags, int* __restrict__ list, int* __restrict__ count) {
+    const int env = blockIdx.x * FTPB + threadIdx.x;
+    if (env >= n) return;
+    const bool ok = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                                (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+    if (!ok) list[atomicAdd(count, 1)] = env;
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -77,6 +102,9 @@ struct pbre_ctx {
     Tables* dT = nullptr;
     float *d_state = nullptr, *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr, *d_tmp = nullptr;
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
+    int *d_list = nullptr, *d_count = nullptr;     // envs declined by the fast path in the current step
+    bool fast_ok = false;
+    int grid_general = 0;
     std::vector<unsigned> episode;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -98,9 +126,19 @@ static int ceil16(int n) { return (n + EPB - 1) / EPB * EPB; }
 
 template <int MODE>
 static hipError_t launch_step(pbre_ctx* c, float* state, int n, const float* act, float* out, int flags, hipStream_t s) {
-    const int blocks = ceil16(n) / EPB;
-    hipLaunchKernelGGL(k_step<MODE>, dim3(blocks), dim3(TPB), 0, s, c->dT, c->P, state, act, out, c->d_scratch, n,
-                       c->act_dim, c->ow, flags);
+    const int dummy = ceil16(n);          // first of the 16 dummy records behind this buffer's real records
+    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
+        hipError_t e = hipMemsetAsync(c->d_count, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fast<MODE>, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, state, act, out, n,
+                           c->act_dim, c->ow, flags, c->d_list, c->d_count);
+        const int blocks = (n + EPB - 1) / EPB;
+        hipLaunchKernelGGL(k_step<MODE>, dim3(blocks), dim3(TPB), 0, s, c->dT, c->P, state, act, out, c->d_scratch, n, dummy,
+                           c->act_dim, c->ow, flags, c->d_list, c->d_count);
+    } else {
+        hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, state, act, out, c->d_scratch, n, dummy,
+                           c->act_dim, c->ow, flags, (const int*)nullptr, (const int*)nullptr);
+    }
     return hipGetLastError();
 }
 
@@ -113,7 +151,7 @@ void pbre_destroy(pbre_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : {(void*)c->dT, (void*)c->d_state, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch,
-                    (void*)c->d_tmp, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx})
+                    (void*)c->d_tmp, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_list, (void*)c->d_count})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -147,7 +185,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
     CK(hipMalloc(&c->dT, sizeof(Tables)));
     CK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
-    const size_t sb = (size_t)c->npad * STATE * sizeof(float);
+    const size_t sb = (size_t)(c->npad + EPB) * STATE * sizeof(float);     // + 16 dummy records for padding rows
     CK(hipMalloc(&c->d_state, sb)); CK(hipMemset(c->d_state, 0, sb));
     CK(hipMalloc(&c->d_tmp, sb));
     CK(hipMalloc(&c->d_act, (size_t)c->npad * c->act_dim * sizeof(float)));
@@ -156,15 +194,28 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(hipMalloc(&c->d_ids, (size_t)c->npad * sizeof(unsigned long long)));
     CK(hipMalloc(&c->d_ep, (size_t)c->npad * sizeof(unsigned)));
     CK(hipMalloc(&c->d_idx, (size_t)c->npad * sizeof(int)));
+    CK(hipMalloc(&c->d_list, (size_t)c->npad * sizeof(int)));
+    CK(hipMalloc(&c->d_count, sizeof(int)));
+    CK(hipMemset(c->d_count, 0, sizeof(int)));
+    c->fast_ok = topo_matches<TopoPanda>(c->T);
+    { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, c->device)); c->grid_general = pr.multiProcessorCount * 2; }
 #undef CK
-    // padding records must hold a valid state: initialise every record to the un-settled reset pose
+    // padding and dummy records must hold a valid state: initialise every record of both buffers to the un-settled reset pose
     {
-        std::vector<unsigned long long> ids(c->npad); std::vector<unsigned> ep(c->npad, 0u);
-        for (int i = 0; i < c->npad; i++) ids[i] = c->P.env_id_base + (unsigned long long)(i < c->n ? i : c->n - 1);
-        if (hipMemcpy(c->d_ids, ids.data(), ids.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(c->d_ep, ep.data(), ep.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { g_err = "hipMemcpy failed"; pbre_destroy(c); return PBRE_E_DEVICE; }
-        hipLaunchKernelGGL(k_init, dim3((c->npad + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->d_state, c->d_ids, c->d_ep, c->npad);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { g_err = "k_init failed"; pbre_destroy(c); return PBRE_E_DEVICE; }
+        const int tot = c->npad + EPB;
+        std::vector<unsigned long long> ids(tot, c->P.env_id_base); std::vector<unsigned> ep(tot, 0u);
+        unsigned long long* d_i = nullptr; unsigned* d_e = nullptr;
+        bool ok = hipMalloc(&d_i, tot * 8) == hipSuccess && hipMalloc(&d_e, tot * 4) == hipSuccess &&
+                  hipMemcpy(d_i, ids.data(), tot * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(d_e, ep.data(), tot * 4, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->d_state, d_i, d_e, tot);
+            hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->d_tmp, d_i, d_e, tot);
+            ok = hipStreamSynchronize(c->stream) == hipSuccess;
+        }
+        if (d_i) (void)hipFree(d_i);
+        if (d_e) (void)hipFree(d_e);
+        if (!ok) { g_err = "initialising the state records failed"; pbre_destroy(c); return PBRE_E_DEVICE; }
     }
     *out = c;
     return PBRE_OK;
@@ -293,10 +344,13 @@ int pbre_timing(const pbre_ctx* c, double* ms, int32_t n) {
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
     hipFuncAttributes fa;
-    int regs = -1;
-    if (hipFuncGetAttributes(&fa, (const void*)k_step<CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK>) == hipSuccess) regs = fa.numRegs;
-    const int v[3] = {regs, c->npad / 4, 4};
-    for (int i = 0; i < n; i++) info[i] = i < 3 ? v[i] : 0;
+    int rf = -1, rg = -1;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast<FastD::M_ACTION | FastD::M_OBS | FastD::M_TASK>) == hipSuccess) rf = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_step<CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK>) == hipSuccess) rg = fa.numRegs;
+    int last = 0;       // envs the fast path declined in the most recent step (reads the device counter)
+    if (c->d_count) { (void)hipSetDevice(c->device); (void)hipMemcpy(&last, c->d_count, sizeof(int), hipMemcpyDeviceToHost); }
+    const int v[5] = {c->fast_ok ? rf : -1, rg, c->fast_ok ? 1 : 0, c->n - last, last};
+    for (int i = 0; i < n; i++) info[i] = i < 5 ? v[i] : 0;
     return PBRE_OK;
 }
 

@@ -1,0 +1,517 @@
+// pbre_fast.hpp -- lane-per-env fast path of the step (one thread = one env, everything in VGPRs).
+//
+// Handles the common case exactly: no robot collision sphere within the contact margin of the
+// object or the table and no joint at/beyond a limit, i.e. the only constraint rows are the 9 joint
+// motors and up to 4 object-table contacts (normal +z => Bullet's btPlaneSpace1 friction directions are
+// the constants (0,-1,0) and (1,0,0), so the object rows are sparse).  Such an env needs ~850
+// instructions per env-step instead of ~17000 in the 16-lane row kernel (pbre_core.hpp), because nothing
+// is computed redundantly across lanes and no cross-lane reduction is needed.  Any other env is
+// reported back (return value false, state untouched) and is stepped by the general row kernel.
+//
+// Same mathematics as pbre_core.hpp (world-frame RNEA + CRBA + explicit M^-1, Bullet row order:
+// motors in alternating direction, normals, frictions), same reference call sites.  The kinematic
+// topology is a compile-time template argument so every array index folds and all link data stay in
+// registers; the numeric model constants are read from `Tables` with wave-uniform addresses (scalar
+// loads).  Plain C++: compiled for the device in pbre_capi.hip and for the host in tests/host_emu.
+#pragma once
+#include <math.h>
+#include "pbre_tables.hpp"
+
+#ifndef PBRE_HD
+#define PBRE_HD
+#endif
+#ifndef PBRE_UNROLL
+#define PBRE_UNROLL
+#endif
+
+namespace pbre {
+
+// Franka Panda as flattened by build_tables(): 7-revolute chain, two prismatic fingers on lane 6,
+// lane 6 carries 3 rigid sub-bodies (link7, hand, grasptarget).
+struct TopoPanda {
+    static constexpr int ND = 9;
+    static constexpr int parent(int j) { return j == 0 ? -1 : (j <= 6 ? j - 1 : 6); }
+    static constexpr int jtype(int j) { return j <= 6 ? 1 : 2; }
+    static constexpr int nsub(int j) { return j == 6 ? 3 : 1; }
+    static constexpr bool is_anc(int i, int j) {   // i ancestor-or-self of j
+        return i == j || (j >= 0 && parent(j) >= 0 && is_anc(i, parent(j)));
+    }
+};
+
+template <class Topo>
+inline bool topo_matches(const Tables& T) {
+    if (T.ndof != Topo::ND) return false;
+    for (int j = 0; j < Topo::ND; j++) {
+        if (T.anc[0][j] != Topo::parent(j) || T.jtype[j] != Topo::jtype(j)) return false;
+        for (int b = 0; b < NSUB; b++) if ((T.sb_m[b][j] != 0.f || T.sb_I[b][0][j] != 0.f) != (b < Topo::nsub(j))) return false;
+        if (T.jdamp[j] != 0.f) return false;   // the fast path folds joint damping out
+    }
+    return true;
+}
+
+template <class Topo>
+struct Fast {
+    static constexpr int ND = Topo::ND;
+    struct V3 { float x, y, z; };
+    static PBRE_HD V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+    static PBRE_HD V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+    static PBRE_HD V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+    static PBRE_HD V3 scl(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+    static PBRE_HD float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+    static PBRE_HD V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+    static PBRE_HD float norm(V3 a) { return sqrtf(dot(a, a)); }
+    struct M3 { float m[9]; };
+    static PBRE_HD V3 mv(const M3& A, V3 v) {
+        return v3(fmaf(A.m[0], v.x, fmaf(A.m[1], v.y, A.m[2] * v.z)), fmaf(A.m[3], v.x, fmaf(A.m[4], v.y, A.m[5] * v.z)),
+                  fmaf(A.m[6], v.x, fmaf(A.m[7], v.y, A.m[8] * v.z)));
+    }
+    static PBRE_HD V3 mtv(const M3& A, V3 v) {
+        return v3(fmaf(A.m[0], v.x, fmaf(A.m[3], v.y, A.m[6] * v.z)), fmaf(A.m[1], v.x, fmaf(A.m[4], v.y, A.m[7] * v.z)),
+                  fmaf(A.m[2], v.x, fmaf(A.m[5], v.y, A.m[8] * v.z)));
+    }
+    static PBRE_HD M3 mm(const M3& A, const M3& B) {
+        M3 C;
+        PBRE_UNROLL for (int i = 0; i < 3; i++)
+            PBRE_UNROLL for (int j = 0; j < 3; j++)
+                C.m[i*3+j] = fmaf(A.m[i*3], B.m[j], fmaf(A.m[i*3+1], B.m[3+j], A.m[i*3+2] * B.m[6+j]));
+        return C;
+    }
+    static PBRE_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+    static PBRE_HD float med3(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+    static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+    struct Q4 { float x, y, z, w; };
+    static PBRE_HD M3 quat_R(Q4 q) {
+        M3 R; float x = q.x, y = q.y, z = q.z, w = q.w;
+        R.m[0] = 1.f - 2.f * (y*y + z*z); R.m[1] = 2.f * (x*y - w*z);       R.m[2] = 2.f * (x*z + w*y);
+        R.m[3] = 2.f * (x*y + w*z);       R.m[4] = 1.f - 2.f * (x*x + z*z); R.m[5] = 2.f * (y*z - w*x);
+        R.m[6] = 2.f * (x*z - w*y);       R.m[7] = 2.f * (y*z + w*x);       R.m[8] = 1.f - 2.f * (x*x + y*y);
+        return R;
+    }
+    static PBRE_HD Q4 qmul(Q4 a, Q4 b) {
+        Q4 o;
+        o.x = a.w*b.x + a.x*b.w + a.y*b.z - a.z*b.y; o.y = a.w*b.y - a.x*b.z + a.y*b.w + a.z*b.x;
+        o.z = a.w*b.z + a.x*b.y - a.y*b.x + a.z*b.w; o.w = a.w*b.w - a.x*b.x - a.y*b.y - a.z*b.z;
+        return o;
+    }
+    static PBRE_HD Q4 R_quat(const M3& R) {   // btMatrix3x3::getRotation
+        float tr = R.m[0] + R.m[4] + R.m[8];
+        Q4 q;
+        if (tr > 0.f) {
+            float s = sqrtf(tr + 1.f); q.w = s * .5f; s = .5f / s;
+            q.x = (R.m[7] - R.m[5]) * s; q.y = (R.m[2] - R.m[6]) * s; q.z = (R.m[3] - R.m[1]) * s;
+        } else {
+            // branch-free over the three cases (kept in registers)
+            Q4 c[3];
+            PBRE_UNROLL for (int i = 0; i < 3; i++) {
+                const int j = (i + 1) % 3, k = (i + 2) % 3;
+                float s = sqrtf(fmaxf(R.m[i*4] - R.m[j*4] - R.m[k*4] + 1.f, 1e-30f)), kk = .5f / s;
+                float t[3]; t[i] = s * .5f; t[j] = (R.m[j*3+i] + R.m[i*3+j]) * kk; t[k] = (R.m[k*3+i] + R.m[i*3+k]) * kk;
+                c[i].x = t[0]; c[i].y = t[1]; c[i].z = t[2]; c[i].w = (R.m[k*3+j] - R.m[j*3+k]) * kk;
+            }
+            const bool c01 = R.m[0] < R.m[4], c12 = R.m[4] < R.m[8], c02 = R.m[0] < R.m[8];
+            const bool use2 = (c01 && c12) || (!c01 && c02), use1 = c01 && !c12;
+            q = use2 ? c[2] : (use1 ? c[1] : c[0]);
+        }
+        return q;
+    }
+    static PBRE_HD Q4 euler_quat(V3 e) {
+        float cr = cosf(e.x * .5f), sr = sinf(e.x * .5f), cp = cosf(e.y * .5f), sp = sinf(e.y * .5f), cy = cosf(e.z * .5f), sy = sinf(e.z * .5f);
+        Q4 q; q.x = sr*cp*cy - cr*sp*sy; q.y = cr*sp*cy + sr*cp*sy; q.z = cr*cp*sy - sr*sp*cy; q.w = cr*cp*cy + sr*sp*sy;
+        return q;
+    }
+    static PBRE_HD V3 quat_euler(Q4 q) {
+        float x = q.x, y = q.y, z = q.z, w = q.w;
+        float sarg = -2.f * (x*z - w*y);
+        V3 e;
+        if (sarg <= -0.99999f) { e.x = 0.f; e.y = -1.57079632679489662f; e.z = 2.f * atan2f(x, -y); }
+        else if (sarg >= 0.99999f) { e.x = 0.f; e.y = 1.57079632679489662f; e.z = 2.f * atan2f(-x, y); }
+        else {
+            e.x = atan2f(2.f * (y*z + w*x), w*w - x*x - y*y + z*z);
+            e.y = asinf(fmaxf(fminf(sarg, 1.f), -1.f));
+            e.z = atan2f(2.f * (x*y + w*z), w*w + x*x - y*y - z*z);
+        }
+        return e;
+    }
+
+    struct Kin { M3 R[ND]; V3 p[ND]; V3 Sa[ND], Sl[ND]; };   // link frames, joint axes (world, about world origin)
+
+    static PBRE_HD void fk(const Tables& T, const float* q, Kin& K) {
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
+            M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
+            V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
+            M3 Rl; V3 pl;
+            if (Topo::jtype(j) == 1) {
+                float c = cosf(q[j]), s = sinf(q[j]), C = 1.f - c;
+                M3 Rj;
+                Rj.m[0] = c + ax.x*ax.x*C;      Rj.m[1] = ax.x*ax.y*C - ax.z*s; Rj.m[2] = ax.x*ax.z*C + ax.y*s;
+                Rj.m[3] = ax.y*ax.x*C + ax.z*s; Rj.m[4] = c + ax.y*ax.y*C;      Rj.m[5] = ax.y*ax.z*C - ax.x*s;
+                Rj.m[6] = ax.z*ax.x*C - ax.y*s; Rj.m[7] = ax.z*ax.y*C + ax.x*s; Rj.m[8] = c + ax.z*ax.z*C;
+                Rl = mm(R0, Rj); pl = p0;
+            } else {
+                Rl = R0; V3 d = mv(R0, ax); pl = v3(fmaf(d.x, q[j], p0.x), fmaf(d.y, q[j], p0.y), fmaf(d.z, q[j], p0.z));
+            }
+            if (Topo::parent(j) < 0) { K.R[j] = Rl; K.p[j] = pl; }
+            else { const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j); K.R[j] = mm(K.R[pj], Rl); K.p[j] = add(K.p[pj], mv(K.R[pj], pl)); }
+            V3 aw = mv(K.R[j], ax);
+            if (Topo::jtype(j) == 1) { K.Sa[j] = aw; K.Sl[j] = cross(K.p[j], aw); }
+            else { K.Sa[j] = v3(0.f, 0.f, 0.f); K.Sl[j] = aw; }
+        }
+    }
+
+    // minimum signed distance of any robot collision sphere to the box (c, R, h)
+    static PBRE_HD float sphere_box_dist(V3 sc, float sr, V3 bc, const M3& Rb, V3 h) {
+        V3 dl = mtv(Rb, sub(sc, bc));
+        V3 cl = v3(clampf(dl.x, -h.x, h.x), clampf(dl.y, -h.y, h.y), clampf(dl.z, -h.z, h.z));
+        V3 df = sub(dl, cl);
+        float len = norm(df);
+        float best = fminf(fminf(h.x - fabsf(dl.x), h.y - fabsf(dl.y)), h.z - fabsf(dl.z));
+        return len < 1e-9f ? -best - sr : len - sr;
+    }
+
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4 };
+
+    // Returns true if the env was stepped; false if it needs the general kernel (state untouched).
+    static PBRE_HD bool step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+        const bool obj_on = !(flags & 1);
+        const float dt = P.dt, inv_dt = P.inv_dt;
+        float q[ND], qd[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+        // ---- eligibility 1: no joint at/over a limit (limit rows exist only while violated)
+        bool simple = true;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) simple = simple && (q[j] - T.lower[j] > 0.f) && (T.upper[j] - q[j] > 0.f);
+        if (!simple) return false;
+        V3 op = v3(st[9], st[10], st[11]);
+        Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+        V3 ov = v3(st[25], st[26], st[27]), ow = v3(st[28], st[29], st[30]);
+        M3 Ro = quat_R(oq);
+
+        Kin K; fk(T, q, K);
+        // ---- eligibility 2: no robot sphere within the contact margin of object or table
+        {
+            const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
+            const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
+            M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+            float dmin = 1e30f;
+            for (int s = 0; s < T.nspheres; s++) {
+                // owner link is a runtime table entry: fetch its frame with a select chain (stays in registers)
+                const int o = T.s_owner[s];
+                M3 Rs = K.R[0]; V3 ps = K.p[0];
+                PBRE_UNROLL for (int j = 1; j < ND; j++) if (o == j) { Rs = K.R[j]; ps = K.p[j]; }
+                V3 sc = add(ps, mv(Rs, v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
+                if (obj_on) dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], op, Ro, oh));
+                dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], tc, Id, th));
+            }
+            if (dmin < P.margin) return false;
+        }
+
+        // ---- motor targets (apply_action)
+        float qdes[ND], kp[ND], kd[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            qdes[j] = T.home[j]; kp[j] = T.kp_hold[j]; kd[j] = T.kd_hold[j];
+            if (mode & M_ACTION) {
+                kp[j] = T.kp_act[j]; kd[j] = T.kd_act[j];
+                if (j < T.n_act) qdes[j] = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
+            }
+        }
+
+        // ---- velocities, bias forces (world-frame RNEA), composite inertias, CRBA
+        V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            V3 sa = scl(K.Sa[j], qd[j]), sl = scl(K.Sl[j], qd[j]);
+            const int pj = Topo::parent(j);
+            if (pj < 0) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj < 0 ? 0 : pj], sa); Vl[j] = add(Vl[pj < 0 ? 0 : pj], sl); }
+            V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
+            if (pj < 0) { Aa[j] = ca; Al[j] = v3(cl.x, cl.y, cl.z - P.gz); }
+            else { Aa[j] = add(Aa[pj < 0 ? 0 : pj], ca); Al[j] = add(Al[pj < 0 ? 0 : pj], cl); }
+        }
+        V3 Fa[ND], Fl[ND];            // (subtree) spatial force about the world origin
+        float Cm[ND]; V3 Ch[ND]; float CI[ND][6];   // (composite) spatial inertia about the world origin
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
+            PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
+            PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
+                if (b >= Topo::nsub(j)) continue;
+                const float m = T.sb_m[b][j];
+                V3 c = add(K.p[j], mv(K.R[j], v3(T.sb_c[b][0][j], T.sb_c[b][1][j], T.sb_c[b][2][j])));
+                M3 Il; Il.m[0] = T.sb_I[b][0][j]; Il.m[1] = T.sb_I[b][3][j]; Il.m[2] = T.sb_I[b][4][j];
+                Il.m[3] = Il.m[1]; Il.m[4] = T.sb_I[b][1][j]; Il.m[5] = T.sb_I[b][5][j]; Il.m[6] = Il.m[2]; Il.m[7] = Il.m[5]; Il.m[8] = T.sb_I[b][2][j];
+                M3 RI = mm(K.R[j], Il), Iw;
+                PBRE_UNROLL for (int a = 0; a < 3; a++)
+                    PBRE_UNROLL for (int bb = 0; bb < 3; bb++)
+                        Iw.m[a*3+bb] = fmaf(RI.m[a*3], K.R[j].m[bb*3], fmaf(RI.m[a*3+1], K.R[j].m[bb*3+1], RI.m[a*3+2] * K.R[j].m[bb*3+2]));
+                V3 w = Va[j];
+                V3 vc = add(Vl[j], cross(w, c));
+                V3 ac = add(add(Al[j], cross(Aa[j], c)), cross(w, vc));
+                float sl_ = fmaf(P.kl, norm(vc), P.kl);
+                V3 f = scl(add(ac, scl(vc, sl_)), m);
+                V3 Iww = mv(Iw, w);
+                float sa_ = fmaf(P.ka, norm(w), P.ka);
+                V3 nc = add(add(mv(Iw, Aa[j]), cross(w, Iww)), scl(Iww, sa_));
+                Fa[j] = add(Fa[j], add(nc, cross(c, f))); Fl[j] = add(Fl[j], f);
+                Cm[j] += m; Ch[j] = add(Ch[j], scl(c, m));
+                const float cc = dot(c, c);
+                CI[j][0] += fmaf(m, cc - c.x*c.x, Iw.m[0]); CI[j][1] += fmaf(m, cc - c.y*c.y, Iw.m[4]); CI[j][2] += fmaf(m, cc - c.z*c.z, Iw.m[8]);
+                CI[j][3] += fmaf(-m, c.x*c.y, Iw.m[1]); CI[j][4] += fmaf(-m, c.x*c.z, Iw.m[2]); CI[j][5] += fmaf(-m, c.y*c.z, Iw.m[5]);
+            }
+        }
+        float Mi[ND * (ND + 1) / 2];       // symmetric storage, becomes M^-1
+        float tau[ND];
+        PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) {
+            // children have larger indices and were already accumulated into j
+            tau[j] = -(dot(K.Sa[j], Fa[j]) + dot(K.Sl[j], Fl[j]));
+            M3 Io; Io.m[0] = CI[j][0]; Io.m[1] = CI[j][3]; Io.m[2] = CI[j][4]; Io.m[3] = CI[j][3]; Io.m[4] = CI[j][1]; Io.m[5] = CI[j][5];
+            Io.m[6] = CI[j][4]; Io.m[7] = CI[j][5]; Io.m[8] = CI[j][2];
+            V3 Ga = add(mv(Io, K.Sa[j]), cross(Ch[j], K.Sl[j]));
+            V3 Gl = add(scl(K.Sl[j], Cm[j]), cross(K.Sa[j], Ch[j]));
+            PBRE_UNROLL for (int i = 0; i < ND; i++) {
+                if (i > j) { if (!Topo::is_anc(j, i)) Mi[sym(i, j)] = 0.f; continue; }   // unrelated branches (the two fingers)
+                if (Topo::is_anc(i, j)) Mi[sym(j, i)] = dot(K.Sa[i], Ga) + dot(K.Sl[i], Gl);
+                else Mi[sym(j, i)] = 0.f;
+            }
+            const int pj = Topo::parent(j);
+            if (pj >= 0) {
+                const int pp = pj < 0 ? 0 : pj;
+                Fa[pp] = add(Fa[pp], Fa[j]); Fl[pp] = add(Fl[pp], Fl[j]);
+                Cm[pp] += Cm[j]; Ch[pp] = add(Ch[pp], Ch[j]);
+                PBRE_UNROLL for (int k = 0; k < 6; k++) CI[pp][k] += CI[j][k];
+            }
+        }
+        // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), exact Gauss-Jordan arithmetic on the triangle
+        PBRE_UNROLL for (int k = 0; k < ND; k++) {
+            const float p = 1.f / Mi[sym(k, k)];
+            float b[ND];
+            PBRE_UNROLL for (int i = 0; i < ND; i++) b[i] = Mi[sym(i, k)];
+            PBRE_UNROLL for (int i = 0; i < ND; i++) {
+                if (i == k) continue;
+                const float bp = b[i] * p;
+                PBRE_UNROLL for (int j = 0; j <= i; j++) { if (j == k) continue; Mi[sym(i, j)] = fmaf(-bp, b[j], Mi[sym(i, j)]); }
+                Mi[sym(i, k)] = bp;
+            }
+            Mi[sym(k, k)] = -p;
+        }
+        PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) Mi[i] = -Mi[i];
+
+        // ---- unconstrained velocities
+        const float vmax = P.vmax;
+        float vs[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            float a = 0.f;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
+            vs[j] = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
+        }
+        // motor rows (btMultiBodyJointMotor): dinv = 1/Minv_jj, rhs = (kp (q_des-q)/dt - kd v*) dinv
+        float m_dinv[ND], m_rhs[ND], m_app[ND], dvR[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            m_dinv[j] = 1.f / Mi[sym(j, j)];
+            m_rhs[j] = (kp[j] * (qdes[j] - q[j]) * inv_dt - kd[j] * vs[j]) * m_dinv[j];
+            m_app[j] = 0.f; dvR[j] = 0.f;
+        }
+
+        // ---- object: unconstrained velocity, object-table contacts
+        V3 oI = v3(P.obj_I[0], P.obj_I[1], P.obj_I[2]);
+        M3 Iinv;
+        {
+            M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
+            PBRE_UNROLL for (int i = 0; i < 3; i++)
+                PBRE_UNROLL for (int j = 0; j < 3; j++)
+                    Iinv.m[i*3+j] = fmaf(D.m[i*3], Ro.m[j*3], fmaf(D.m[i*3+1], Ro.m[j*3+1], D.m[i*3+2] * Ro.m[j*3+2]));
+        }
+        V3 ovs = ov, ows = ow;
+        constexpr int NK = NC_OT;
+        float c_rx[NK], c_ry[NK], c_rz[NK], c_mu[NK];
+        bool c_act[NK];
+        // rows: 0 normal, 1 friction (0,-1,0), 2 friction (1,0,0); per row: B_ang(3), dinv, rhs', accumulated impulse
+        float r_bx[NK][3], r_by[NK][3], r_bz[NK][3], r_dinv[NK][3], r_rhs[NK][3], r_app[NK][3];
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            c_act[c] = false; c_rx[c] = c_ry[c] = c_rz[c] = c_mu[c] = 0.f;
+            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_bx[c][d] = r_by[c][d] = r_bz[c][d] = r_dinv[c][d] = r_rhs[c][d] = r_app[c][d] = 0.f; }
+        }
+        const float inv_m = 1.f / P.obj_m;
+        if (obj_on) {
+            V3 wl = mtv(Ro, ow);
+            V3 Lw = mv(Ro, v3(wl.x * oI.x, wl.y * oI.y, wl.z * oI.z));
+            float sl_ = fmaf(P.kl, norm(ov), P.kl);
+            V3 al = v3(-sl_ * ov.x, -sl_ * ov.y, P.gz - sl_ * ov.z);
+            float sa_ = fmaf(P.ka, norm(ow), P.ka);
+            V3 tq = sub(scl(cross(ow, Lw), -1.f), scl(Lw, sa_));
+            V3 aa = mv(Iinv, tq);
+            ovs = v3(clampf(fmaf(dt, al.x, ov.x), -vmax, vmax), clampf(fmaf(dt, al.y, ov.y), -vmax, vmax), clampf(fmaf(dt, al.z, ov.z), -vmax, vmax));
+            ows = v3(clampf(fmaf(dt, aa.x, ow.x), -vmax, vmax), clampf(fmaf(dt, aa.y, ow.y), -vmax, vmax), clampf(fmaf(dt, aa.z, ow.z), -vmax, vmax));
+            // vertices vs support surface; keep the NC_OT smallest distances < margin, ordered by vertex index
+            float vd[8]; V3 vr[8];
+            const float top = P.tab_c[2] + P.tab_h[2], bot = P.tab_c[2] - P.tab_h[2];
+            PBRE_UNROLL for (int v = 0; v < 8; v++) {
+                V3 l = v3((v & 1) ? P.obj_h[0] : -P.obj_h[0], (v & 2) ? P.obj_h[1] : -P.obj_h[1], (v & 4) ? P.obj_h[2] : -P.obj_h[2]);
+                vr[v] = mv(Ro, l);
+                V3 x = add(op, vr[v]);
+                const bool in = fabsf(x.x - P.tab_c[0]) <= P.tab_h[0] && fabsf(x.y - P.tab_c[1]) <= P.tab_h[1];
+                const float hs = (in && x.z > bot) ? top : P.ground_z;
+                vd[v] = x.z - hs;
+            }
+            int rank[8]; bool chosen[8];
+            PBRE_UNROLL for (int v = 0; v < 8; v++) {
+                int r = 0;
+                PBRE_UNROLL for (int u = 0; u < 8; u++) {
+                    if (u == v) continue;
+                    const bool before = vd[u] < vd[v] || (vd[u] == vd[v] && u < v);
+                    r += (vd[u] < P.margin && before) ? 1 : 0;
+                }
+                chosen[v] = vd[v] < P.margin && r < NK;
+                rank[v] = r;
+            }
+            (void)rank;
+            int slot = 0;
+            const float mu = P.obj_mu * P.tab_mu;
+            PBRE_UNROLL for (int v = 0; v < 8; v++) {
+                if (chosen[v]) {
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) if (slot == c) {
+                        c_act[c] = true; c_rx[c] = vr[v].x; c_ry[c] = vr[v].y; c_rz[c] = vr[v].z; c_mu[c] = mu;
+                        r_rhs[c][0] = vd[v];     // distance parked here until the row setup below
+                    }
+                    slot++;
+                }
+            }
+            PBRE_UNROLL for (int c = 0; c < NK; c++) {
+                if (!c_act[c]) continue;
+                const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c], dist = r_rhs[c][0];
+                // J = [dir ; r x dir] for dir = +z, -y, +x
+                const V3 Ja[3] = {v3(ry, -rx, 0.f), v3(rz, 0.f, -rx), v3(0.f, rz, -ry)};
+                const float vl[3] = {ovs.z, -ovs.y, ovs.x};
+                PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                    V3 Ba = mv(Iinv, Ja[d]);
+                    const float denom = inv_m + dot(Ja[d], Ba);
+                    const float dinv = 1.f / denom;
+                    const float rel = vl[d] + dot(Ja[d], ows);
+                    float rhs;
+                    if (d == 0) {
+                        const float pen = dist + P.slop;
+                        rhs = pen > 0.f ? (-rel - pen * inv_dt) * dinv : (-pen * P.erp * inv_dt - rel) * dinv;
+                    } else rhs = -rel * dinv;
+                    r_bx[c][d] = Ba.x; r_by[c][d] = Ba.y; r_bz[c][d] = Ba.z; r_dinv[c][d] = dinv; r_rhs[c][d] = rhs; r_app[c][d] = 0.f;
+                }
+            }
+        }
+
+        // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
+        float dlx = 0.f, dly = 0.f, dlz = 0.f, dax = 0.f, day = 0.f, daz = 0.f;   // object delta-velocity
+        const float mlim = P.motor_imp;
+        auto motor = [&](int j) {
+            const float t = fmaf(m_dinv[j], dvR[j], -m_rhs[j]);
+            const float s = med3(m_app[j] - t, -mlim, mlim);
+            const float d = s - m_app[j]; m_app[j] = s;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) dvR[k] = fmaf(d, Mi[sym(k, j)], dvR[k]);
+        };
+        auto orow = [&](int c, int d) {
+            const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
+            float jv;
+            if (d == 0) jv = dlz + ry * dax - rx * day;
+            else if (d == 1) jv = -dly + rz * dax - rx * daz;
+            else jv = dlx + rz * day - ry * daz;
+            const float t = fmaf(jv, r_dinv[c][d], -r_rhs[c][d]);
+            float lo, hi;
+            if (d == 0) { lo = 0.f; hi = 1e10f; } else { hi = c_mu[c] * r_app[c][0]; lo = -hi; }
+            float s = med3(r_app[c][d] - t, lo, hi);
+            if (d != 0) s = hi > 0.f ? s : r_app[c][d];
+            const float dd = s - r_app[c][d]; r_app[c][d] = s;
+            const float dm = dd * inv_m;
+            if (d == 0) dlz += dm; else if (d == 1) dly -= dm; else dlx += dm;
+            dax = fmaf(dd, r_bx[c][d], dax); day = fmaf(dd, r_by[c][d], day); daz = fmaf(dd, r_bz[c][d], daz);
+        };
+        auto contacts = [&]() {
+            PBRE_UNROLL for (int c = 0; c < NK; c++) if (c_act[c]) orow(c, 0);
+            PBRE_UNROLL for (int c = 0; c < NK; c++) if (c_act[c]) { orow(c, 1); orow(c, 2); }
+        };
+        for (int it = 0; it < P.iters; it += 2) {
+            PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
+            contacts();
+            if (it + 1 >= P.iters) break;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
+            contacts();
+        }
+
+        // ---- integrate
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            const float v = clampf(vs[j] + dvR[j], -vmax, vmax);
+            qd[j] = v; q[j] = fmaf(dt, v, q[j]);
+            st[j] = q[j]; st[16 + j] = v;
+        }
+        if (obj_on) {
+            ov = v3(clampf(ovs.x + dlx, -vmax, vmax), clampf(ovs.y + dly, -vmax, vmax), clampf(ovs.z + dlz, -vmax, vmax));
+            ow = v3(clampf(ows.x + dax, -vmax, vmax), clampf(ows.y + day, -vmax, vmax), clampf(ows.z + daz, -vmax, vmax));
+            op = v3(fmaf(dt, ov.x, op.x), fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
+            float ang = norm(ow);
+            if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * inv_dt;
+            const float sc_ = ang < 0.001f ? 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang : sinf(0.5f * ang * dt) / ang;
+            Q4 dq; dq.x = ow.x * sc_; dq.y = ow.y * sc_; dq.z = ow.z * sc_; dq.w = cosf(ang * dt * 0.5f);
+            Q4 nq = qmul(dq, oq);
+            const float in = 1.f / sqrtf(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
+            oq.x = nq.x * in; oq.y = nq.y * in; oq.z = nq.z * in; oq.w = nq.w * in;
+            st[9] = op.x; st[10] = op.y; st[11] = op.z; st[12] = oq.x; st[13] = oq.y; st[14] = oq.z; st[15] = oq.w;
+            st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
+        }
+        if (mode & (M_OBS | M_TASK)) observe(T, P, st, q, qd, op, oq, out, mode);
+        return true;
+    }
+
+    static PBRE_HD void observe(const Tables& T, const Params& P, float* st, const float* q, const float* qd, V3 op, Q4 oq,
+                                float* out, int mode) {
+        Kin K; fk(T, q, K);
+        // EE owner is a runtime table entry: walk the chain up to it with compile-time indices
+        V3 Va = v3(0.f, 0.f, 0.f), Vl = v3(0.f, 0.f, 0.f);
+        M3 Re = K.R[0]; V3 pe = K.p[0];
+        const int eo = T.ee_owner;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            // is j an ancestor-or-self of eo?  (compile-time tree, runtime eo)
+            bool anc = false;
+            PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && eo == e) anc = true;
+            if (anc) { Va = add(Va, scl(K.Sa[j], qd[j])); Vl = add(Vl, scl(K.Sl[j], qd[j])); }
+            if (eo == j) { Re = K.R[j]; pe = K.p[j]; }
+        }
+        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
+        M3 Ree = mm(Re, Eo);
+        V3 ee = add(pe, mv(Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
+        V3 vee = add(Vl, cross(Va, ee));
+        V3 eul = quat_euler(R_quat(Ree));
+        V3 oe = quat_euler(oq);
+        Q4 qh = euler_quat(eul), qo = euler_quat(oe);
+        V3 rel = mtv(quat_R(qh), sub(op, ee));
+        Q4 qhi; qhi.x = -qh.x; qhi.y = -qh.y; qhi.z = -qh.z; qhi.w = qh.w;
+        V3 er = quat_euler(qmul(qhi, qo));
+        V3 tg = v3(st[32], st[33], st[34]);
+        float reward = 0.f, done = 0.f;
+        if (mode & M_TASK) {
+            const float d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
+            const float dsucc = P.task >= 1 ? d2 : d1;
+            const bool succ = dsucc <= P.dist_min;
+            float cnt = st[35], term = st[36];
+            const float mx = (float)P.max_steps;
+            if (P.task == 2) {
+                cnt = cnt > mx ? cnt : cnt + 1.f;
+                done = (succ || cnt > mx) ? 1.f : 0.f;
+                reward = succ ? 0.f : -1.f;
+            } else {
+                const bool d0 = succ || term != 0.f || cnt > mx;
+                cnt = d0 ? cnt : cnt + 1.f;
+                term = succ ? 1.f : term;
+                done = (succ || term != 0.f || cnt > mx) ? 1.f : 0.f;
+                const float base = P.task == 1 ? -d1 - d2 : -d1;
+                reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
+            }
+            st[35] = cnt; st[36] = term;
+        }
+        if (out) {
+            int o = 0;
+            out[o++] = ee.x; out[o++] = ee.y; out[o++] = ee.z; out[o++] = eul.x; out[o++] = eul.y; out[o++] = eul.z;
+            out[o++] = vee.x / 0.04f; out[o++] = (vee.y - 0.01f) / 0.07f; out[o++] = vee.z / 0.03f;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) out[o++] = q[j];
+            out[o++] = op.x; out[o++] = op.y; out[o++] = op.z; out[o++] = oe.x; out[o++] = oe.y; out[o++] = oe.z;
+            out[o++] = rel.x; out[o++] = rel.y; out[o++] = rel.z; out[o++] = er.x; out[o++] = er.y; out[o++] = er.z;
+            if (P.task >= 1) { out[o++] = tg.x; out[o++] = tg.y; out[o++] = tg.z; }
+            out[o++] = reward; out[o++] = done;
+        }
+    }
+};
+
+}  // namespace pbre

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")
 STATE_FLOATS = 48
 ROBOT_PANDA = 0
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
-F_NO_OBJECT, F_AUTO_RESET = 1, 2
+F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL = 1, 2, 4
 
 
 class Physics(C.Structure):
@@ -172,6 +172,6 @@ class Engine:
         return list(ms)
 
     def kernel_info(self):
-        info = (C.c_int32 * 3)()
-        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(3)))
+        info = (C.c_int32 * 5)()
+        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(5)))
         return list(info)

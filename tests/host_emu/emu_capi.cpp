@@ -10,9 +10,11 @@
 #include "lanes_host.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_host.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
+#include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
 
 using namespace pbre;
 using CoreH = Core<pbre_emu::HostLanes>;
+using FastH = Fast<TopoPanda>;
 
 struct pbre_ctx {
     pbre_config cfg;
@@ -21,7 +23,15 @@ struct pbre_ctx {
     std::vector<float> state;
     std::vector<unsigned> episode;
     std::string err;
+    bool fast_ok = false;
+    long n_fast = 0, n_general = 0;
 };
+// same dispatch as the device: lane-per-env fast path first, general row kernel for the envs it declines
+static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags) {
+    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL) && FastH::step(c->T, c->P, st, act, out, mode, flags)) { c->n_fast++; return; }
+    c->n_general++;
+    CoreH::step(c->T, c->P, st, act, out, mode, flags);
+}
 static std::string g_err;
 
 extern "C" {
@@ -38,6 +48,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
     c->state.assign((size_t)c->n * STATE, 0.f);
     c->episode.assign(c->n, 0u);
+    c->fast_ok = topo_matches<TopoPanda>(c->T);
     *out = c;
     return PBRE_OK;
 }
@@ -50,7 +61,7 @@ int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
 }
 
 static void settle(pbre_ctx* c, int e, int n, int flags) {
-    for (int i = 0; i < n; i++) CoreH::step(c->T, c->P, &c->state[(size_t)e * STATE], nullptr, nullptr, 0, flags);
+    for (int i = 0; i < n; i++) step_env(c, &c->state[(size_t)e * STATE], nullptr, nullptr, 0, flags);
 }
 
 int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
@@ -74,8 +85,8 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
     const int ow = c->obs_dim + 2;
     for (int e = 0; e < c->n; e++)
-        CoreH::step(c->T, c->P, &c->state[(size_t)e * STATE], actions + (size_t)e * c->act_dim, out + (size_t)e * ow,
-                    CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & PBRE_F_NO_OBJECT);
+        step_env(c, &c->state[(size_t)e * STATE], actions + (size_t)e * c->act_dim, out + (size_t)e * ow,
+                 CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & PBRE_F_NO_OBJECT);
     return PBRE_OK;
 }
 int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }
@@ -102,6 +113,10 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
 }
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; obs_limits(c->cfg, c->T, lo, hi); return PBRE_OK; }
 int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
-int pbre_kernel_info(const pbre_ctx*, int32_t* info, int32_t n) { for (int i = 0; i < n; i++) info[i] = 0; return PBRE_OK; }
+int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
+    const long v[5] = {0, 0, 0, c->n_fast, c->n_general};
+    for (int i = 0; i < n; i++) info[i] = i < 5 ? (int32_t)v[i] : 0;
+    return PBRE_OK;
+}
 
 }  // extern "C"
