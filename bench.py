@@ -23,7 +23,10 @@ sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALG_BYTES_PER_ENV_STEP = 444.0      # read 172 B + write 272 B (Panda push, joint control)
-ALG_FLOP_PER_ENV_STEP = 0.4e6       # SURVEY 8(d) estimate, 150 PGS iterations
+# FLOPs actually required per env-step by the sparse formulation the fast kernel uses: per PGS iteration
+# 9 motor rows x 23 + 4 normal rows x 18 + 8 friction rows x 20 = 439 flop, x150, + ~8 k for kinematics/dynamics/obs.
+# (SURVEY 8(d)'s 0.4 MFLOP assumed 33 dense rows of 70 flop; the dense figure is what the general row kernel does.)
+ALG_FLOP_PER_ENV_STEP = 150 * 439 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 
@@ -173,11 +176,12 @@ def main():
                        "outputs_finite": finite},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_step<7>", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
+                         "kernel": "k_fast<7> (+ k_step<7> for envs with robot contacts)", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU/dependency bound (AI ~900 FLOP/B >> 25 FLOP/B machine balance); "
                                  "HBM fraction is small by construction, see valu"},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
-                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs": info[0]},
+                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs_fast": info[0], "vgprs_general": info[1],
+                     "envs_on_general_path_last_step": info[4]},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -16,6 +16,9 @@
 
 #define PBRE_HD __device__ __forceinline__
 #define PBRE_UNROLL _Pragma("unroll")
+#define PBRE_ANY(x) (__any((int)(x)) != 0)
+#define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
+#define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -55,8 +58,11 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
 // Lane-per-env fast path: one thread = one env.  Envs it cannot handle (robot contact or limit row) are appended to
 // `list` for the general kernel.
 constexpr int FTPB = 64;
+#ifndef PBRE_FAST_WAVES
+#define PBRE_FAST_WAVES 2      // waves per SIMD the fast kernel is register-limited to (tuned on MI355X)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(FTPB) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out,
                                                int n, int act_dim, int ow, int flags, int* __restrict__ list, int* __restrict__ count) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
@@ -197,7 +203,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(hipMalloc(&c->d_list, (size_t)c->npad * sizeof(int)));
     CK(hipMalloc(&c->d_count, sizeof(int)));
     CK(hipMemset(c->d_count, 0, sizeof(int)));
-    c->fast_ok = topo_matches<TopoPanda>(c->T);
+    c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, c->device)); c->grid_general = pr.multiProcessorCount * 2; }
 #undef CK
     // padding and dummy records must hold a valid state: initialise every record of both buffers to the un-settled reset pose

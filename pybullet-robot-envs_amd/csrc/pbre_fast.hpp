@@ -23,6 +23,15 @@
 #ifndef PBRE_UNROLL
 #define PBRE_UNROLL
 #endif
+#ifndef PBRE_REG_BARRIER    // compiler-only memory barrier (device build); nothing on the host
+#define PBRE_REG_BARRIER() do {} while (0)
+#endif
+#ifndef PBRE_LAUNDER        // hide a (uniform) pointer's provenance from the optimiser (device build)
+#define PBRE_LAUNDER(p) do {} while (0)
+#endif
+#ifndef PBRE_ANY            // wave-uniform "any lane" on the device; identity on the host (one env per call)
+#define PBRE_ANY(x) (x)
+#endif
 
 namespace pbre {
 
@@ -37,6 +46,11 @@ struct TopoPanda {
         return i == j || (j >= 0 && parent(j) >= 0 && is_anc(i, parent(j)));
     }
 };
+
+// fast path preconditions that are uniform over the batch (checked once on the host)
+inline bool fast_scene_ok(const Params& P) {
+    return P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2];   // isotropic object inertia (a cube)
+}
 
 template <class Topo>
 inline bool topo_matches(const Tables& T) {
@@ -184,152 +198,157 @@ struct Fast {
         if (!simple) return false;
         V3 op = v3(st[9], st[10], st[11]);
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-        V3 ov = v3(st[25], st[26], st[27]), ow = v3(st[28], st[29], st[30]);
         M3 Ro = quat_R(oq);
 
-        Kin K; fk(T, q, K);
-        // ---- eligibility 2: no robot sphere within the contact margin of object or table
+        // ---- one forward sweep over the links: FK, joint axes, velocities, velocity-product accelerations,
+        //      collision-sphere distances, per-link bias force and spatial inertia (world frame, about the world origin)
+        V3 Sa[ND], Sl[ND];
+        V3 Fa[ND], Fl[ND];
+        float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
+        float dmin = 1e30f;
         {
+            M3 R[ND]; V3 p[ND]; V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
             const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
             const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
             M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
-            float dmin = 1e30f;
-            for (int s = 0; s < T.nspheres; s++) {
-                // owner link is a runtime table entry: fetch its frame with a select chain (stays in registers)
-                const int o = T.s_owner[s];
-                M3 Rs = K.R[0]; V3 ps = K.p[0];
-                PBRE_UNROLL for (int j = 1; j < ND; j++) if (o == j) { Rs = K.R[j]; ps = K.p[j]; }
-                V3 sc = add(ps, mv(Rs, v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
-                if (obj_on) dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], op, Ro, oh));
-                dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], tc, Id, th));
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+                const bool root = Topo::parent(j) < 0;
+                V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
+                M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
+                V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
+                M3 Rl; V3 pl;
+                if (Topo::jtype(j) == 1) {
+                    float c = cosf(q[j]), sn = sinf(q[j]), C = 1.f - c;
+                    M3 Rj;
+                    Rj.m[0] = c + ax.x*ax.x*C;       Rj.m[1] = ax.x*ax.y*C - ax.z*sn; Rj.m[2] = ax.x*ax.z*C + ax.y*sn;
+                    Rj.m[3] = ax.y*ax.x*C + ax.z*sn; Rj.m[4] = c + ax.y*ax.y*C;       Rj.m[5] = ax.y*ax.z*C - ax.x*sn;
+                    Rj.m[6] = ax.z*ax.x*C - ax.y*sn; Rj.m[7] = ax.z*ax.y*C + ax.x*sn; Rj.m[8] = c + ax.z*ax.z*C;
+                    Rl = mm(R0, Rj); pl = p0;
+                } else {
+                    Rl = R0; V3 d = mv(R0, ax); pl = v3(fmaf(d.x, q[j], p0.x), fmaf(d.y, q[j], p0.y), fmaf(d.z, q[j], p0.z));
+                }
+                if (root) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+                V3 aw = mv(R[j], ax);
+                if (Topo::jtype(j) == 1) { Sa[j] = aw; Sl[j] = cross(p[j], aw); } else { Sa[j] = v3(0.f, 0.f, 0.f); Sl[j] = aw; }
+                V3 sa = scl(Sa[j], qd[j]), sl = scl(Sl[j], qd[j]);
+                if (root) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj], sa); Vl[j] = add(Vl[pj], sl); }
+                V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
+                if (root) { Aa[j] = ca; Al[j] = v3(cl.x, cl.y, cl.z - P.gz); } else { Aa[j] = add(Aa[pj], ca); Al[j] = add(Al[pj], cl); }
+                // eligibility 2: robot spheres owned by this link vs object / table
+                for (int s = 0; s < T.nspheres; s++) {
+                    if (T.s_owner[s] != j) continue;
+                    V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
+                    if (obj_on) dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], op, Ro, oh));
+                    dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], tc, Id, th));
+                }
+                Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
+                PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
+                PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
+                    if (b >= Topo::nsub(j)) continue;
+                    const float m = T.sb_m[b][j];
+                    V3 c = add(p[j], mv(R[j], v3(T.sb_c[b][0][j], T.sb_c[b][1][j], T.sb_c[b][2][j])));
+                    M3 Il; Il.m[0] = T.sb_I[b][0][j]; Il.m[1] = T.sb_I[b][3][j]; Il.m[2] = T.sb_I[b][4][j];
+                    Il.m[3] = Il.m[1]; Il.m[4] = T.sb_I[b][1][j]; Il.m[5] = T.sb_I[b][5][j]; Il.m[6] = Il.m[2]; Il.m[7] = Il.m[5]; Il.m[8] = T.sb_I[b][2][j];
+                    M3 RI = mm(R[j], Il), Iw;
+                    PBRE_UNROLL for (int a = 0; a < 3; a++)
+                        PBRE_UNROLL for (int bb = 0; bb < 3; bb++)
+                            Iw.m[a*3+bb] = fmaf(RI.m[a*3], R[j].m[bb*3], fmaf(RI.m[a*3+1], R[j].m[bb*3+1], RI.m[a*3+2] * R[j].m[bb*3+2]));
+                    V3 w = Va[j];
+                    V3 vc = add(Vl[j], cross(w, c));
+                    V3 ac = add(add(Al[j], cross(Aa[j], c)), cross(w, vc));
+                    float sl_ = fmaf(P.kl, norm(vc), P.kl);
+                    V3 f = scl(add(ac, scl(vc, sl_)), m);
+                    V3 Iww = mv(Iw, w);
+                    float sa_ = fmaf(P.ka, norm(w), P.ka);
+                    V3 nc = add(add(mv(Iw, Aa[j]), cross(w, Iww)), scl(Iww, sa_));
+                    Fa[j] = add(Fa[j], add(nc, cross(c, f))); Fl[j] = add(Fl[j], f);
+                    Cm[j] += m; Ch[j] = add(Ch[j], scl(c, m));
+                    const float cc = dot(c, c);
+                    CI[j][0] += fmaf(m, cc - c.x*c.x, Iw.m[0]); CI[j][1] += fmaf(m, cc - c.y*c.y, Iw.m[4]); CI[j][2] += fmaf(m, cc - c.z*c.z, Iw.m[8]);
+                    CI[j][3] += fmaf(-m, c.x*c.y, Iw.m[1]); CI[j][4] += fmaf(-m, c.x*c.z, Iw.m[2]); CI[j][5] += fmaf(-m, c.y*c.z, Iw.m[5]);
+                }
             }
-            if (dmin < P.margin) return false;
         }
+        if (dmin < P.margin) return false;
 
-        // ---- motor targets (apply_action)
-        float qdes[ND], kp[ND], kd[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            qdes[j] = T.home[j]; kp[j] = T.kp_hold[j]; kd[j] = T.kd_hold[j];
-            if (mode & M_ACTION) {
-                kp[j] = T.kp_act[j]; kd[j] = T.kd_act[j];
-                if (j < T.n_act) qdes[j] = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
-            }
-        }
-
-        // ---- velocities, bias forces (world-frame RNEA), composite inertias, CRBA
-        V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            V3 sa = scl(K.Sa[j], qd[j]), sl = scl(K.Sl[j], qd[j]);
-            const int pj = Topo::parent(j);
-            if (pj < 0) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj < 0 ? 0 : pj], sa); Vl[j] = add(Vl[pj < 0 ? 0 : pj], sl); }
-            V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
-            if (pj < 0) { Aa[j] = ca; Al[j] = v3(cl.x, cl.y, cl.z - P.gz); }
-            else { Aa[j] = add(Aa[pj < 0 ? 0 : pj], ca); Al[j] = add(Al[pj < 0 ? 0 : pj], cl); }
-        }
-        V3 Fa[ND], Fl[ND];            // (subtree) spatial force about the world origin
-        float Cm[ND]; V3 Ch[ND]; float CI[ND][6];   // (composite) spatial inertia about the world origin
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
-            PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
-            PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
-                if (b >= Topo::nsub(j)) continue;
-                const float m = T.sb_m[b][j];
-                V3 c = add(K.p[j], mv(K.R[j], v3(T.sb_c[b][0][j], T.sb_c[b][1][j], T.sb_c[b][2][j])));
-                M3 Il; Il.m[0] = T.sb_I[b][0][j]; Il.m[1] = T.sb_I[b][3][j]; Il.m[2] = T.sb_I[b][4][j];
-                Il.m[3] = Il.m[1]; Il.m[4] = T.sb_I[b][1][j]; Il.m[5] = T.sb_I[b][5][j]; Il.m[6] = Il.m[2]; Il.m[7] = Il.m[5]; Il.m[8] = T.sb_I[b][2][j];
-                M3 RI = mm(K.R[j], Il), Iw;
-                PBRE_UNROLL for (int a = 0; a < 3; a++)
-                    PBRE_UNROLL for (int bb = 0; bb < 3; bb++)
-                        Iw.m[a*3+bb] = fmaf(RI.m[a*3], K.R[j].m[bb*3], fmaf(RI.m[a*3+1], K.R[j].m[bb*3+1], RI.m[a*3+2] * K.R[j].m[bb*3+2]));
-                V3 w = Va[j];
-                V3 vc = add(Vl[j], cross(w, c));
-                V3 ac = add(add(Al[j], cross(Aa[j], c)), cross(w, vc));
-                float sl_ = fmaf(P.kl, norm(vc), P.kl);
-                V3 f = scl(add(ac, scl(vc, sl_)), m);
-                V3 Iww = mv(Iw, w);
-                float sa_ = fmaf(P.ka, norm(w), P.ka);
-                V3 nc = add(add(mv(Iw, Aa[j]), cross(w, Iww)), scl(Iww, sa_));
-                Fa[j] = add(Fa[j], add(nc, cross(c, f))); Fl[j] = add(Fl[j], f);
-                Cm[j] += m; Ch[j] = add(Ch[j], scl(c, m));
-                const float cc = dot(c, c);
-                CI[j][0] += fmaf(m, cc - c.x*c.x, Iw.m[0]); CI[j][1] += fmaf(m, cc - c.y*c.y, Iw.m[4]); CI[j][2] += fmaf(m, cc - c.z*c.z, Iw.m[8]);
-                CI[j][3] += fmaf(-m, c.x*c.y, Iw.m[1]); CI[j][4] += fmaf(-m, c.x*c.z, Iw.m[2]); CI[j][5] += fmaf(-m, c.y*c.z, Iw.m[5]);
-            }
-        }
+        // ---- backward sweep: subtree forces -> bias torques, composite inertias -> mass matrix (CRBA)
         float Mi[ND * (ND + 1) / 2];       // symmetric storage, becomes M^-1
         float tau[ND];
         PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) {
-            // children have larger indices and were already accumulated into j
-            tau[j] = -(dot(K.Sa[j], Fa[j]) + dot(K.Sl[j], Fl[j]));
+            tau[j] = -(dot(Sa[j], Fa[j]) + dot(Sl[j], Fl[j]));
             M3 Io; Io.m[0] = CI[j][0]; Io.m[1] = CI[j][3]; Io.m[2] = CI[j][4]; Io.m[3] = CI[j][3]; Io.m[4] = CI[j][1]; Io.m[5] = CI[j][5];
             Io.m[6] = CI[j][4]; Io.m[7] = CI[j][5]; Io.m[8] = CI[j][2];
-            V3 Ga = add(mv(Io, K.Sa[j]), cross(Ch[j], K.Sl[j]));
-            V3 Gl = add(scl(K.Sl[j], Cm[j]), cross(K.Sa[j], Ch[j]));
+            V3 Ga = add(mv(Io, Sa[j]), cross(Ch[j], Sl[j]));
+            V3 Gl = add(scl(Sl[j], Cm[j]), cross(Sa[j], Ch[j]));
             PBRE_UNROLL for (int i = 0; i < ND; i++) {
                 if (i > j) { if (!Topo::is_anc(j, i)) Mi[sym(i, j)] = 0.f; continue; }   // unrelated branches (the two fingers)
-                if (Topo::is_anc(i, j)) Mi[sym(j, i)] = dot(K.Sa[i], Ga) + dot(K.Sl[i], Gl);
+                if (Topo::is_anc(i, j)) Mi[sym(j, i)] = dot(Sa[i], Ga) + dot(Sl[i], Gl);
                 else Mi[sym(j, i)] = 0.f;
             }
-            const int pj = Topo::parent(j);
-            if (pj >= 0) {
-                const int pp = pj < 0 ? 0 : pj;
+            if (Topo::parent(j) >= 0) {
+                const int pp = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
                 Fa[pp] = add(Fa[pp], Fa[j]); Fl[pp] = add(Fl[pp], Fl[j]);
                 Cm[pp] += Cm[j]; Ch[pp] = add(Ch[pp], Ch[j]);
                 PBRE_UNROLL for (int k = 0; k < 6; k++) CI[pp][k] += CI[j][k];
             }
         }
-        // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), exact Gauss-Jordan arithmetic on the triangle
+        // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle
         PBRE_UNROLL for (int k = 0; k < ND; k++) {
-            const float p = 1.f / Mi[sym(k, k)];
+            const float pv = 1.f / Mi[sym(k, k)];
             float b[ND];
             PBRE_UNROLL for (int i = 0; i < ND; i++) b[i] = Mi[sym(i, k)];
             PBRE_UNROLL for (int i = 0; i < ND; i++) {
                 if (i == k) continue;
-                const float bp = b[i] * p;
+                const float bp = b[i] * pv;
                 PBRE_UNROLL for (int j = 0; j <= i; j++) { if (j == k) continue; Mi[sym(i, j)] = fmaf(-bp, b[j], Mi[sym(i, j)]); }
                 Mi[sym(i, k)] = bp;
             }
-            Mi[sym(k, k)] = -p;
+            Mi[sym(k, k)] = -pv;
         }
         PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) Mi[i] = -Mi[i];
 
-        // ---- unconstrained velocities
+        // ---- unconstrained joint velocities w = v*; motor rows (btMultiBodyJointMotor) written against the running
+        //      velocity w = v* + dv:  t = dinv*w - rhs2 with rhs2 = (kp (q_des - q)/dt + (1 - kd) v*) dinv
         const float vmax = P.vmax;
-        float vs[ND];
+        float w[ND], m_dinv[ND], m_rhs[ND], m_app[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
-            vs[j] = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
-        }
-        // motor rows (btMultiBodyJointMotor): dinv = 1/Minv_jj, rhs = (kp (q_des-q)/dt - kd v*) dinv
-        float m_dinv[ND], m_rhs[ND], m_app[ND], dvR[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            w[j] = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
+            float qdes = T.home[j], kp = T.kp_hold[j], kd = T.kd_hold[j];
+            if (mode & M_ACTION) {
+                kp = T.kp_act[j]; kd = T.kd_act[j];
+                if (j < T.n_act) qdes = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
+            }
             m_dinv[j] = 1.f / Mi[sym(j, j)];
-            m_rhs[j] = (kp[j] * (qdes[j] - q[j]) * inv_dt - kd[j] * vs[j]) * m_dinv[j];
-            m_app[j] = 0.f; dvR[j] = 0.f;
+            m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * w[j]) * m_dinv[j];
+            m_app[j] = 0.f;
         }
 
-        // ---- object: unconstrained velocity, object-table contacts
-        V3 oI = v3(P.obj_I[0], P.obj_I[1], P.obj_I[2]);
-        M3 Iinv;
-        {
-            M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
-            PBRE_UNROLL for (int i = 0; i < 3; i++)
-                PBRE_UNROLL for (int j = 0; j < 3; j++)
-                    Iinv.m[i*3+j] = fmaf(D.m[i*3], Ro.m[j*3], fmaf(D.m[i*3+1], Ro.m[j*3+1], D.m[i*3+2] * Ro.m[j*3+2]));
-        }
-        V3 ovs = ov, ows = ow;
+        // ---- object: unconstrained velocity, object-table contacts (normal +z, friction directions -y and +x)
+        V3 ov = v3(st[25], st[26], st[27]), ow = v3(st[28], st[29], st[30]);
         constexpr int NK = NC_OT;
-        float c_rx[NK], c_ry[NK], c_rz[NK], c_mu[NK];
+        float c_rx[NK], c_ry[NK], c_rz[NK];
         bool c_act[NK];
-        // rows: 0 normal, 1 friction (0,-1,0), 2 friction (1,0,0); per row: B_ang(3), dinv, rhs', accumulated impulse
-        float r_bx[NK][3], r_by[NK][3], r_bz[NK][3], r_dinv[NK][3], r_rhs[NK][3], r_app[NK][3];
+        // per row: 1/(J M^-1 J^T) and the accumulated impulse; the normal row also carries its positional rhs.  The object's
+        // inertia is isotropic (checked at create time, fast_eligible()), so M^-1 J^T = [dir/m ; (r x dir)/I] needs no storage.
+        float r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
-            c_act[c] = false; c_rx[c] = c_ry[c] = c_rz[c] = c_mu[c] = 0.f;
-            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_bx[c][d] = r_by[c][d] = r_bz[c][d] = r_dinv[c][d] = r_rhs[c][d] = r_app[c][d] = 0.f; }
+            c_act[c] = false; c_rx[c] = c_ry[c] = c_rz[c] = 0.f; r_rhs[c] = 0.f;
+            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = r_app[c][d] = 0.f; }
         }
-        const float inv_m = 1.f / P.obj_m;
+        const float inv_m = 1.f / P.obj_m, inv_I = 1.f / P.obj_I[0];
+        const float mu = P.obj_mu * P.tab_mu;
         if (obj_on) {
+            V3 oI = v3(P.obj_I[0], P.obj_I[1], P.obj_I[2]);
+            M3 Iinv;
+            {
+                M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
+                PBRE_UNROLL for (int i = 0; i < 3; i++)
+                    PBRE_UNROLL for (int j = 0; j < 3; j++)
+                        Iinv.m[i*3+j] = fmaf(D.m[i*3], Ro.m[j*3], fmaf(D.m[i*3+1], Ro.m[j*3+1], D.m[i*3+2] * Ro.m[j*3+2]));
+            }
             V3 wl = mtv(Ro, ow);
             V3 Lw = mv(Ro, v3(wl.x * oI.x, wl.y * oI.y, wl.z * oI.z));
             float sl_ = fmaf(P.kl, norm(ov), P.kl);
@@ -337,8 +356,8 @@ struct Fast {
             float sa_ = fmaf(P.ka, norm(ow), P.ka);
             V3 tq = sub(scl(cross(ow, Lw), -1.f), scl(Lw, sa_));
             V3 aa = mv(Iinv, tq);
-            ovs = v3(clampf(fmaf(dt, al.x, ov.x), -vmax, vmax), clampf(fmaf(dt, al.y, ov.y), -vmax, vmax), clampf(fmaf(dt, al.z, ov.z), -vmax, vmax));
-            ows = v3(clampf(fmaf(dt, aa.x, ow.x), -vmax, vmax), clampf(fmaf(dt, aa.y, ow.y), -vmax, vmax), clampf(fmaf(dt, aa.z, ow.z), -vmax, vmax));
+            ov = v3(clampf(fmaf(dt, al.x, ov.x), -vmax, vmax), clampf(fmaf(dt, al.y, ov.y), -vmax, vmax), clampf(fmaf(dt, al.z, ov.z), -vmax, vmax));
+            ow = v3(clampf(fmaf(dt, aa.x, ow.x), -vmax, vmax), clampf(fmaf(dt, aa.y, ow.y), -vmax, vmax), clampf(fmaf(dt, aa.z, ow.z), -vmax, vmax));
             // vertices vs support surface; keep the NC_OT smallest distances < margin, ordered by vertex index
             float vd[8]; V3 vr[8];
             const float top = P.tab_c[2] + P.tab_h[2], bot = P.tab_c[2] - P.tab_h[2];
@@ -350,7 +369,8 @@ struct Fast {
                 const float hs = (in && x.z > bot) ? top : P.ground_z;
                 vd[v] = x.z - hs;
             }
-            int rank[8]; bool chosen[8];
+            int slot = 0;
+            float c_dist[NK] = {0.f, 0.f, 0.f, 0.f};
             PBRE_UNROLL for (int v = 0; v < 8; v++) {
                 int r = 0;
                 PBRE_UNROLL for (int u = 0; u < 8; u++) {
@@ -358,70 +378,57 @@ struct Fast {
                     const bool before = vd[u] < vd[v] || (vd[u] == vd[v] && u < v);
                     r += (vd[u] < P.margin && before) ? 1 : 0;
                 }
-                chosen[v] = vd[v] < P.margin && r < NK;
-                rank[v] = r;
-            }
-            (void)rank;
-            int slot = 0;
-            const float mu = P.obj_mu * P.tab_mu;
-            PBRE_UNROLL for (int v = 0; v < 8; v++) {
-                if (chosen[v]) {
+                if (vd[v] < P.margin && r < NK) {
                     PBRE_UNROLL for (int c = 0; c < NK; c++) if (slot == c) {
-                        c_act[c] = true; c_rx[c] = vr[v].x; c_ry[c] = vr[v].y; c_rz[c] = vr[v].z; c_mu[c] = mu;
-                        r_rhs[c][0] = vd[v];     // distance parked here until the row setup below
+                        c_act[c] = true; c_rx[c] = vr[v].x; c_ry[c] = vr[v].y; c_rz[c] = vr[v].z; c_dist[c] = vd[v];
                     }
                     slot++;
                 }
             }
             PBRE_UNROLL for (int c = 0; c < NK; c++) {
-                if (!c_act[c]) continue;
-                const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c], dist = r_rhs[c][0];
-                // J = [dir ; r x dir] for dir = +z, -y, +x
-                const V3 Ja[3] = {v3(ry, -rx, 0.f), v3(rz, 0.f, -rx), v3(0.f, rz, -ry)};
-                const float vl[3] = {ovs.z, -ovs.y, ovs.x};
-                PBRE_UNROLL for (int d = 0; d < 3; d++) {
-                    V3 Ba = mv(Iinv, Ja[d]);
-                    const float denom = inv_m + dot(Ja[d], Ba);
-                    const float dinv = 1.f / denom;
-                    const float rel = vl[d] + dot(Ja[d], ows);
-                    float rhs;
-                    if (d == 0) {
-                        const float pen = dist + P.slop;
-                        rhs = pen > 0.f ? (-rel - pen * inv_dt) * dinv : (-pen * P.erp * inv_dt - rel) * dinv;
-                    } else rhs = -rel * dinv;
-                    r_bx[c][d] = Ba.x; r_by[c][d] = Ba.y; r_bz[c][d] = Ba.z; r_dinv[c][d] = dinv; r_rhs[c][d] = rhs; r_app[c][d] = 0.f;
-                }
+                const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
+                const V3 Ja[3] = {v3(ry, -rx, 0.f), v3(rz, 0.f, -rx), v3(0.f, rz, -ry)};   // r x dir for dir = +z, -y, +x
+                PBRE_UNROLL for (int d = 0; d < 3; d++)
+                    r_dinv[c][d] = c_act[c] ? 1.f / fmaf(dot(Ja[d], Ja[d]), inv_I, inv_m) : 0.f;
+                // setupMultiBodyContactConstraint, restitution 0: only the positional part remains in the rhs because the
+                // row is evaluated against the running velocity
+                const float pen = c_dist[c] + P.slop;
+                r_rhs[c] = c_act[c] ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * r_dinv[c][0] : 0.f;
             }
         }
 
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
-        float dlx = 0.f, dly = 0.f, dlz = 0.f, dax = 0.f, day = 0.f, daz = 0.f;   // object delta-velocity
         const float mlim = P.motor_imp;
         auto motor = [&](int j) {
-            const float t = fmaf(m_dinv[j], dvR[j], -m_rhs[j]);
+            const float t = fmaf(m_dinv[j], w[j], -m_rhs[j]);
             const float s = med3(m_app[j] - t, -mlim, mlim);
             const float d = s - m_app[j]; m_app[j] = s;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) dvR[k] = fmaf(d, Mi[sym(k, j)], dvR[k]);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, Mi[sym(k, j)], w[k]);
         };
         auto orow = [&](int c, int d) {
             const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
             float jv;
-            if (d == 0) jv = dlz + ry * dax - rx * day;
-            else if (d == 1) jv = -dly + rz * dax - rx * daz;
-            else jv = dlx + rz * day - ry * daz;
-            const float t = fmaf(jv, r_dinv[c][d], -r_rhs[c][d]);
-            float lo, hi;
-            if (d == 0) { lo = 0.f; hi = 1e10f; } else { hi = c_mu[c] * r_app[c][0]; lo = -hi; }
-            float s = med3(r_app[c][d] - t, lo, hi);
-            if (d != 0) s = hi > 0.f ? s : r_app[c][d];
+            if (d == 0) jv = ov.z + ry * ow.x - rx * ow.y;
+            else if (d == 1) jv = -ov.y + rz * ow.x - rx * ow.z;
+            else jv = ov.x + rz * ow.y - ry * ow.z;
+            float s;
+            if (d == 0) s = med3(r_app[c][0] - fmaf(jv, r_dinv[c][0], -r_rhs[c]), 0.f, 1e10f);
+            else {
+                const float hi = mu * r_app[c][0];
+                s = med3(r_app[c][d] - jv * r_dinv[c][d], -hi, hi);
+                s = hi > 0.f ? s : r_app[c][d];
+            }
             const float dd = s - r_app[c][d]; r_app[c][d] = s;
-            const float dm = dd * inv_m;
-            if (d == 0) dlz += dm; else if (d == 1) dly -= dm; else dlx += dm;
-            dax = fmaf(dd, r_bx[c][d], dax); day = fmaf(dd, r_by[c][d], day); daz = fmaf(dd, r_bz[c][d], daz);
+            const float dm = dd * inv_m, di = dd * inv_I;
+            if (d == 0) { ov.z += dm; ow.x = fmaf(di, ry, ow.x); ow.y = fmaf(-di, rx, ow.y); }
+            else if (d == 1) { ov.y -= dm; ow.x = fmaf(di, rz, ow.x); ow.z = fmaf(-di, rx, ow.z); }
+            else { ov.x += dm; ow.y = fmaf(di, rz, ow.y); ow.z = fmaf(-di, ry, ow.z); }
         };
+        bool any_c[NK];
+        PBRE_UNROLL for (int c = 0; c < NK; c++) any_c[c] = PBRE_ANY(c_act[c]);    // wave-uniform; inactive slots are exact no-ops
         auto contacts = [&]() {
-            PBRE_UNROLL for (int c = 0; c < NK; c++) if (c_act[c]) orow(c, 0);
-            PBRE_UNROLL for (int c = 0; c < NK; c++) if (c_act[c]) { orow(c, 1); orow(c, 2); }
+            PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) orow(c, 0);
+            PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
         };
         for (int it = 0; it < P.iters; it += 2) {
             PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
@@ -431,15 +438,19 @@ struct Fast {
             contacts();
         }
 
-        // ---- integrate
+        // ---- integrate.  Positions are re-read from the state record (still the old values) rather than kept in
+        //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
+        PBRE_REG_BARRIER();
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            const float v = clampf(vs[j] + dvR[j], -vmax, vmax);
-            qd[j] = v; q[j] = fmaf(dt, v, q[j]);
+            const float v = clampf(w[j], -vmax, vmax);
+            qd[j] = v; q[j] = fmaf(dt, v, st[j]);
             st[j] = q[j]; st[16 + j] = v;
         }
         if (obj_on) {
-            ov = v3(clampf(ovs.x + dlx, -vmax, vmax), clampf(ovs.y + dly, -vmax, vmax), clampf(ovs.z + dlz, -vmax, vmax));
-            ow = v3(clampf(ows.x + dax, -vmax, vmax), clampf(ows.y + day, -vmax, vmax), clampf(ows.z + daz, -vmax, vmax));
+            op = v3(st[9], st[10], st[11]);
+            oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+            ov = v3(clampf(ov.x, -vmax, vmax), clampf(ov.y, -vmax, vmax), clampf(ov.z, -vmax, vmax));
+            ow = v3(clampf(ow.x, -vmax, vmax), clampf(ow.y, -vmax, vmax), clampf(ow.z, -vmax, vmax));
             op = v3(fmaf(dt, ov.x, op.x), fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
             float ang = norm(ow);
             if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * inv_dt;
@@ -451,7 +462,12 @@ struct Fast {
             st[9] = op.x; st[10] = op.y; st[11] = op.z; st[12] = oq.x; st[13] = oq.y; st[14] = oq.z; st[15] = oq.w;
             st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
         }
-        if (mode & (M_OBS | M_TASK)) observe(T, P, st, q, qd, op, oq, out, mode);
+        if (mode & (M_OBS | M_TASK)) {
+            // re-read the model constants after the solver loop instead of keeping ~130 of them live across it
+            const Tables* T2 = &T;
+            PBRE_LAUNDER(T2);
+            observe(*T2, P, st, q, qd, op, oq, out, mode);
+        }
         return true;
     }
 

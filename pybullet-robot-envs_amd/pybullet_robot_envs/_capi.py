@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")
+LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")   # PBRE_LIB: build-variant A/B runs
 
 STATE_FLOATS = 48
 ROBOT_PANDA = 0

@@ -48,7 +48,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
     c->state.assign((size_t)c->n * STATE, 0.f);
     c->episode.assign(c->n, 0u);
-    c->fast_ok = topo_matches<TopoPanda>(c->T);
+    c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     *out = c;
     return PBRE_OK;
 }
