@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs", type=int, default=131072, help="total envs over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--steady-preroll", type=int, default=300,
+                    help="untimed steps before the extra mid-episode measurement (0 disables it)")
     args = ap.parse_args()
 
     import numpy as np
@@ -156,6 +158,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
     finite = bool(torch.isfinite(out).all())
+    complex_after = eng.kernel_info()[5]
+
+    # extra, reported separately: the same K steps measured mid-episode (after an untimed pre-roll), when a few per cent
+    # of the envs have robot contacts / joints at a limit and take the heavier k_fast_rc kernel
+    steady = None
+    if args.steady_preroll > 0:
+        for k in range(args.steady_preroll):
+            one_step(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            one_step(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        e2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        steady = {"preroll_steps": args.steady_preroll, "value": args.envs * args.steps / float(e2[0]), "unit": "env-steps/s",
+                  "ms_per_step": float(e2[0]) / args.steps * 1e3, "complex_env_frac_rank0": eng.kernel_info()[5] / n_local}
 
     if rank == 0:
         value = args.envs * args.steps / elapsed
@@ -173,15 +199,16 @@ def main():
                                    % (args.envs, n_local),
                        "envs_total": args.envs, "envs_per_gpu": n_local, "parallelism": "dp%d" % world,
                        "collective": "rccl gather to rank 0 per step" if world > 1 else "none",
-                       "outputs_finite": finite},
+                       "outputs_finite": finite, "start_state": "fresh reset() of every env (reference reset_simulation)",
+                       "complex_env_frac_after_timed_steps_rank0": complex_after / n_local},
+            "steady_state": steady,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_fast<7> (+ k_step<7> for envs with robot contacts)", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
+                         "kernel": "k_fast<7> (+ k_fast_rc<7> for envs with robot contacts / limit rows, concurrently)", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU/dependency bound (AI ~900 FLOP/B >> 25 FLOP/B machine balance); "
                                  "HBM fraction is small by construction, see valu"},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
-                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs_fast": info[0], "vgprs_general": info[1],
-                     "envs_on_general_path_last_step": info[4]},
+                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
         if not args.no_cpu_baseline and world == 1:
             try:

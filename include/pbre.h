@@ -129,7 +129,8 @@ int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
 /* wall-clock of the last pbre_step phases in ms: [0] upload, [1] kernels, [2] download */
 int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
 /* kernel facts for the bench/roofline report: [0] VGPRs of the fast kernel, [1] VGPRs of the general kernel,
- * [2] fast path enabled, [3] envs stepped by the fast path in the most recent step, [4] envs stepped by the general kernel */
+ * [2] fast path enabled, [3..5] envs stepped in the most recent step by the fast kernel / the general row kernel / the
+ * lane-per-env robot-contact kernel, [6] VGPRs of the robot-contact kernel */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

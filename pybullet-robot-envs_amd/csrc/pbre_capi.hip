@@ -1,15 +1,21 @@
 // pbre_capi.hip -- libpbre.so: HIP kernels (gfx950) + the C-ABI of include/pbre.h.
 //
-// Kernels.  k_step<MODE> instantiates the lane-generic step (pbre_core.hpp) with the
-// device lane backend: block = 256 threads = 4 waves = 16 envs, one env per 16-lane DPP
-// row, no LDS, no scratch.  State lives in HBM as one 192-byte record per env (three
-// 64-byte lane records), so a wave's loads/stores are 256 contiguous bytes per record.
-// Grid = ceil(num_envs/16) blocks; the block index -> env mapping is linear, so the 8 XCDs
-// (block b runs on XCD b%8) each stream disjoint 3 KB slices -- there is no inter-block
-// reuse to be XCD-aware about, and every block is independent (no barriers, no atomics).
+// Three stepping kernels:
+//   k_fast     lane-per-env (one thread = one env, 64 envs per wave), everything in VGPRs, 2 waves/SIMD.  Steps the
+//              "simple" envs (class 0: no robot contact, no joint-limit row): 9 motor rows + <= 4 object-table contacts.
+//   k_fast_rc  lane-per-env with dense robot-contact rows and limit rows (class 1), whole register file (1 wave/SIMD),
+//              launched over the compacted list of complex envs, concurrently with k_fast on a second stream.
+//   k_step     general 16-lane-row kernel (pbre_core.hpp): one env per DPP row, 4 envs per wave.  Any robot the
+//              RobotTable describes (<= 9 DoF); used when the table does not match the compiled-in Panda topology
+//              or when PBRE_F_FORCE_GENERAL is set (validation).
+// Every lane-per-env kernel ends by classifying the state it produced and appends complex envs to the list the next
+// step's k_fast_rc consumes, so there is no classification pre-pass on the hot path.
+//
+// State lives in HBM as one 192-byte record per env (three 64-byte lane records).  No kernel uses LDS or barriers; blocks
+// are independent, so the block -> XCD mapping is irrelevant (there is no inter-block reuse to be XCD-aware about).
 #include <hip/hip_runtime.h>
-#include <cstdio>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -28,25 +34,25 @@ using namespace pbre;
 using CoreD = Core<DevLanes>;
 using FastD = Fast<TopoPanda>;
 
-constexpr int EPB = 16;              // envs per block
+constexpr int EPB = 16;              // envs per block of the row kernel
 constexpr int TPB = EPB * W;         // 256 threads
+constexpr int FTPB = 64;             // lane-per-env kernels: one wave per block
+#ifndef PBRE_FAST_WAVES
+#define PBRE_FAST_WAVES 2            // waves per SIMD k_fast is register-limited to (A/B on MI355X: 1 -> 404, 2 -> 495, 3 -> 325 M env-steps/s)
+#endif
+constexpr int MODE_STEP = CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK;
 
 // ------------------------------------------------------------------ kernels
-// General row kernel.  MODE: CoreD::M_* bits.  n = real env count; state has ceil16(n) + 16 records (the last 16 are
-// valid dummy records for the padding rows of a partially filled block).  With list == nullptr the kernel steps envs
-// [0, n); otherwise it steps the *count envs named in list (those the fast path declined); the grid is sized for the
-// worst case and surplus blocks exit immediately.  actions/out rows of padding rows are redirected to env 0 / a scratch row.
+// General row kernel.  n = real env count; state has ceil16(n) + 16 records (the last 16 are valid dummy records for the
+// padding rows of a partially filled block); actions/out rows of padding rows are redirected to env 0 / a scratch row.
 template <int MODE>
 __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                               const float* __restrict__ actions, float* __restrict__ out,
-                                              float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags,
-                                              const int* __restrict__ list, const int* __restrict__ count) {
+                                              float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags) {
     const int row = threadIdx.x >> 4;
-    const int total = list ? *count : n;
     const int i = blockIdx.x * EPB + row;
-    if ((int)blockIdx.x * EPB >= total) return;          // block-uniform: blocks beyond the list exit at once
-    const bool real = i < total;
-    const int env = real ? (list ? list[i] : i) : dummy_base + row;
+    const bool real = i < n;
+    const int env = real ? i : dummy_base + row;
     float* st = state + (size_t)env * STATE;
     const float* a = nullptr;
     float* o = nullptr;
@@ -55,21 +61,44 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     CoreD::step(*T, P, st, a, o, MODE, flags);
 }
 
-// Lane-per-env fast path: one thread = one env.  Envs it cannot handle (robot contact or limit row) are appended to
-// `list` for the general kernel.
-constexpr int FTPB = 64;
-#ifndef PBRE_FAST_WAVES
-#define PBRE_FAST_WAVES 2      // waves per SIMD the fast kernel is register-limited to (tuned on MI355X)
-#endif
+__device__ __forceinline__ void publish_class(int env, int c, signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
+    cls[env] = (signed char)c;
+    if (c) next_list[atomicAdd(next_count, 1)] = env;
+}
+
+// Simple envs: every env of the batch in natural order (coalesced), lanes of complex envs idle.
 template <int MODE>
 __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                               const float* __restrict__ actions, float* __restrict__ out,
-                                               int n, int act_dim, int ow, int flags, int* __restrict__ list, int* __restrict__ count) {
+                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
+    const int env = blockIdx.x * FTPB + threadIdx.x;
+    if (env >= n || cls[env] != 0) return;
+    const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+    publish_class(env, c, cls, next_list, next_count);
+}
+
+// Complex envs (robot contacts and/or limit rows), compacted: thread i steps env cur_list[i].  The grid is sized for the
+// worst case; surplus blocks exit at once.
+template <int MODE>
+__global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
+                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
+    const int i = blockIdx.x * FTPB + threadIdx.x;
+    if (i >= *cur_count) return;
+    const int env = cur_list[i];
+    const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                                 (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+    publish_class(env, c, cls, next_list, next_count);
+}
+
+// Class of every env's current state (after reset / set_state / a change of the NO_OBJECT flag).
+__global__ __launch_bounds__(FTPB) void k_classify(const Tables* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
+                                                   signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n) return;
-    const bool ok = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
-    if (!ok) list[atomicAdd(count, 1)] = env;
+    publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count);
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -91,29 +120,36 @@ __global__ void k_target(const Params P, float* __restrict__ state, const unsign
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) CoreD::sample_target(P, ids[i], ep[i], state + (size_t)i * STATE);
 }
-// dst[idx[i]] <- src[i] (scatter) or dst[i] <- src[idx[i]] (gather), 48 floats per record
-__global__ void k_move(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt, int scatter) {
+// dst[idx[i]] <- src[i], 48 floats per record
+__global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t / STATE, k = t % STATE;
-    if (i >= cnt) return;
-    if (scatter) dst[(size_t)idx[i] * STATE + k] = src[(size_t)i * STATE + k];
-    else dst[(size_t)i * STATE + k] = src[(size_t)idx[i] * STATE + k];
+    if (i < cnt) dst[(size_t)idx[i] * STATE + k] = src[(size_t)i * STATE + k];
 }
 
 // ------------------------------------------------------------------ context
+struct EnvBuf {                       // a batch of state records with its class bookkeeping
+    float* state = nullptr;           // cap + 16 records
+    signed char* cls = nullptr;       // class per env
+    int* list[2] = {nullptr, nullptr};
+    int* count = nullptr;             // 2 ints
+    int cur = 0;                      // list[cur]/count[cur]: complex envs of the current state
+    int cap = 0;
+};
+
 struct pbre_ctx {
     pbre_config cfg;
     Tables T; Params P;
     int n = 0, npad = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0;
     Tables* dT = nullptr;
-    float *d_state = nullptr, *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr, *d_tmp = nullptr;
+    EnvBuf main, tmp;
+    float *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
-    int *d_list = nullptr, *d_count = nullptr;     // envs declined by the fast path in the current step
     bool fast_ok = false;
-    int grid_general = 0;
     std::vector<unsigned> episode;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double ms[3] = {0, 0, 0};
     std::string err;
 };
@@ -129,23 +165,56 @@ static std::string g_err;
     } while (0)
 
 static int ceil16(int n) { return (n + EPB - 1) / EPB * EPB; }
+static bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL); }
 
-template <int MODE>
-static hipError_t launch_step(pbre_ctx* c, float* state, int n, const float* act, float* out, int flags, hipStream_t s) {
-    const int dummy = ceil16(n);          // first of the 16 dummy records behind this buffer's real records
-    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
-        hipError_t e = hipMemsetAsync(c->d_count, 0, sizeof(int), s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fast<MODE>, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, state, act, out, n,
-                           c->act_dim, c->ow, flags, c->d_list, c->d_count);
-        const int blocks = (n + EPB - 1) / EPB;
-        hipLaunchKernelGGL(k_step<MODE>, dim3(blocks), dim3(TPB), 0, s, c->dT, c->P, state, act, out, c->d_scratch, n, dummy,
-                           c->act_dim, c->ow, flags, c->d_list, c->d_count);
-    } else {
-        hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, state, act, out, c->d_scratch, n, dummy,
-                           c->act_dim, c->ow, flags, (const int*)nullptr, (const int*)nullptr);
-    }
+static hipError_t alloc_buf(EnvBuf& b, int cap) {
+    b.cap = cap;
+    hipError_t e;
+    if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.cls, (size_t)cap)) != hipSuccess) return e;
+    if ((e = hipMemset(b.cls, 0, (size_t)cap)) != hipSuccess) return e;
+    for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)cap * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.count, 2 * sizeof(int))) != hipSuccess) return e;
+    return hipMemset(b.count, 0, 2 * sizeof(int));
+}
+static void free_buf(EnvBuf& b) {
+    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
+}
+
+// (re)build class array and current list of the first n envs of b
+static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t s) {
+    if (!lane_per_env(c)) return hipSuccess;
+    hipError_t e = hipMemsetAsync(b.count + b.cur, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls, b.list[b.cur], b.count + b.cur);
     return hipGetLastError();
+}
+
+// one batched step of the first n envs of b on stream s
+template <int MODE>
+static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
+    if (!lane_per_env(c)) {
+        hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
+                           c->act_dim, c->ow, flags);
+        return hipGetLastError();
+    }
+    const int cur = b.cur, nxt = cur ^ 1;
+    const int blocks = (n + FTPB - 1) / FTPB;
+    hipError_t e;
+    if ((e = hipMemsetAsync(b.count + nxt, 0, sizeof(int), s)) != hipSuccess) return e;
+    // fork: the complex envs run on the side stream, concurrently with the simple ones
+    if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+                       b.list[cur], b.count + cur, b.cls, b.list[nxt], b.count + nxt);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                       b.cls, b.list[nxt], b.count + nxt);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;      // join
+    b.cur = nxt;
+    return hipSuccess;
 }
 
 extern "C" {
@@ -156,11 +225,15 @@ void pbre_destroy(pbre_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (void* p : {(void*)c->dT, (void*)c->d_state, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch,
-                    (void*)c->d_tmp, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_list, (void*)c->d_count})
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    free_buf(c->main); free_buf(c->tmp);
+    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
 }
 
@@ -178,6 +251,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->n = cfg->num_envs; c->npad = ceil16(c->n); c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
     c->ow = c->obs_dim + 2; c->device = cfg->device_id;
     c->episode.assign(c->n, 0u);
+    c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -188,41 +262,33 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_err = std::string(#call) + ": " + hipGetErrorString(e_); pbre_destroy(c); return PBRE_E_DEVICE; } } while (0)
     CK(hipSetDevice(c->device));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
+    CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     CK(hipMalloc(&c->dT, sizeof(Tables)));
     CK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
-    const size_t sb = (size_t)(c->npad + EPB) * STATE * sizeof(float);     // + 16 dummy records for padding rows
-    CK(hipMalloc(&c->d_state, sb)); CK(hipMemset(c->d_state, 0, sb));
-    CK(hipMalloc(&c->d_tmp, sb));
+    CK(alloc_buf(c->main, c->npad));
+    CK(alloc_buf(c->tmp, c->npad));
     CK(hipMalloc(&c->d_act, (size_t)c->npad * c->act_dim * sizeof(float)));
     CK(hipMalloc(&c->d_out, (size_t)c->npad * c->ow * sizeof(float)));
     CK(hipMalloc(&c->d_scratch, 64 * sizeof(float)));
-    CK(hipMalloc(&c->d_ids, (size_t)c->npad * sizeof(unsigned long long)));
-    CK(hipMalloc(&c->d_ep, (size_t)c->npad * sizeof(unsigned)));
+    CK(hipMalloc(&c->d_ids, (size_t)(c->npad + EPB) * sizeof(unsigned long long)));
+    CK(hipMalloc(&c->d_ep, (size_t)(c->npad + EPB) * sizeof(unsigned)));
     CK(hipMalloc(&c->d_idx, (size_t)c->npad * sizeof(int)));
-    CK(hipMalloc(&c->d_list, (size_t)c->npad * sizeof(int)));
-    CK(hipMalloc(&c->d_count, sizeof(int)));
-    CK(hipMemset(c->d_count, 0, sizeof(int)));
-    c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
-    { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, c->device)); c->grid_general = pr.multiProcessorCount * 2; }
-#undef CK
-    // padding and dummy records must hold a valid state: initialise every record of both buffers to the un-settled reset pose
+    // every record of both buffers (incl. padding and dummy records) must hold a valid state: the un-settled reset pose
     {
         const int tot = c->npad + EPB;
         std::vector<unsigned long long> ids(tot, c->P.env_id_base); std::vector<unsigned> ep(tot, 0u);
-        unsigned long long* d_i = nullptr; unsigned* d_e = nullptr;
-        bool ok = hipMalloc(&d_i, tot * 8) == hipSuccess && hipMalloc(&d_e, tot * 4) == hipSuccess &&
-                  hipMemcpy(d_i, ids.data(), tot * 8, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMemcpy(d_e, ep.data(), tot * 4, hipMemcpyHostToDevice) == hipSuccess;
-        if (ok) {
-            hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->d_state, d_i, d_e, tot);
-            hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->d_tmp, d_i, d_e, tot);
-            ok = hipStreamSynchronize(c->stream) == hipSuccess;
-        }
-        if (d_i) (void)hipFree(d_i);
-        if (d_e) (void)hipFree(d_e);
-        if (!ok) { g_err = "initialising the state records failed"; pbre_destroy(c); return PBRE_E_DEVICE; }
+        CK(hipMemcpy(c->d_ids, ids.data(), (size_t)tot * 8, hipMemcpyHostToDevice));
+        CK(hipMemcpy(c->d_ep, ep.data(), (size_t)tot * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->main.state, c->d_ids, c->d_ep, tot);
+        hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->tmp.state, c->d_ids, c->d_ep, tot);
+        CK(hipGetLastError());
+        CK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));
+        CK(hipStreamSynchronize(c->stream));
     }
+#undef CK
     *out = c;
     return PBRE_OK;
 }
@@ -241,13 +307,14 @@ int pbre_sync(pbre_ctx* c) {
     if (!c) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->side));
     return PBRE_OK;
 }
 
 int pbre_observe(pbre_ctx* c, float* obs) {
     if (!c || !obs) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->d_state, c->d_out, c->d_scratch, c->n, c->ow);
+    hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->main.state, c->d_out, c->d_scratch, c->n, c->ow);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy2DAsync(obs, (size_t)c->obs_dim * 4, c->d_out, (size_t)c->ow * 4, (size_t)c->obs_dim * 4, c->n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -257,7 +324,10 @@ int pbre_observe(pbre_ctx* c, float* obs) {
 int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     if (!c || n < 0) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    for (int i = 0; i < n; i++) HIPCHK(launch_step<0>(c, c->d_state, c->n, nullptr, nullptr, flags & PBRE_F_NO_OBJECT, c->stream));
+    const int f = flags & PBRE_F_NO_OBJECT, f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
+    if (f != f0) HIPCHK(classify(c, c->main, c->n, f, c->stream));           // classes depend on whether the object is present
+    for (int i = 0; i < n; i++) HIPCHK(launch_step<0>(c, c->main, c->n, nullptr, nullptr, f, c->stream));
+    if (f != f0) HIPCHK(classify(c, c->main, c->n, f0, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PBRE_OK;
 }
@@ -281,17 +351,22 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
         HIPCHK(hipMemcpyAsync(c->d_ep, ep.data(), (size_t)cpad * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_idx, idx.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));          // host vectors go out of scope below
-        float* work = (cnt == c->n) ? c->d_state : c->d_tmp;   // a partial reset settles a compacted copy
-        hipLaunchKernelGGL(k_init, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, work, c->d_ids, c->d_ep, cpad);
+        const bool full = cnt == c->n;
+        EnvBuf& work = full ? c->main : c->tmp;           // a partial reset settles a compacted copy
+        const int f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
+        hipLaunchKernelGGL(k_init, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, work.state, c->d_ids, c->d_ep, cpad);
         HIPCHK(hipGetLastError());
         // reset_simulation (panda_push_gym_env.py:117-148): 100 steps robot alone, then world loaded: 100 + 1 steps
+        HIPCHK(classify(c, work, cnt, PBRE_F_NO_OBJECT, c->stream));
         for (int i = 0; i < 100; i++) HIPCHK(launch_step<0>(c, work, cnt, nullptr, nullptr, PBRE_F_NO_OBJECT, c->stream));
-        for (int i = 0; i < 101; i++) HIPCHK(launch_step<0>(c, work, cnt, nullptr, nullptr, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));
-        hipLaunchKernelGGL(k_target, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->P, work, c->d_ids, c->d_ep, cpad);
+        if (!f0) HIPCHK(classify(c, work, cnt, 0, c->stream));
+        for (int i = 0; i < 101; i++) HIPCHK(launch_step<0>(c, work, cnt, nullptr, nullptr, f0, c->stream));
+        hipLaunchKernelGGL(k_target, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->P, work.state, c->d_ids, c->d_ep, cpad);
         HIPCHK(hipGetLastError());
-        if (work != c->d_state) {
-            hipLaunchKernelGGL(k_move, dim3((cnt * STATE + 255) / 256), dim3(256), 0, c->stream, c->d_state, work, c->d_idx, cnt, 1);
+        if (!full) {
+            hipLaunchKernelGGL(k_scatter, dim3((cnt * STATE + 255) / 256), dim3(256), 0, c->stream, c->main.state, work.state, c->d_idx, cnt);
             HIPCHK(hipGetLastError());
+            HIPCHK(classify(c, c->main, c->n, f0, c->stream));
         }
         HIPCHK(hipStreamSynchronize(c->stream));
     }
@@ -303,7 +378,7 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK((launch_step<CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK>(c, c->d_state, c->n, d_actions, d_out, c->cfg.flags & PBRE_F_NO_OBJECT, s)));
+    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, d_actions, d_out, c->cfg.flags & PBRE_F_NO_OBJECT, s)));
     return PBRE_OK;
 }
 
@@ -313,7 +388,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    HIPCHK((launch_step<CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK>(c, c->d_state, c->n, c->d_act, c->d_out, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream)));
+    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, c->d_act, c->d_out, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream)));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
@@ -326,14 +401,16 @@ int pbre_get_state(pbre_ctx* c, float* s) {
     if (!c || !s) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(s, c->d_state, (size_t)c->n * STATE * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s, c->main.state, (size_t)c->n * STATE * 4, hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
 int pbre_set_state(pbre_ctx* c, const float* s) {
     if (!c || !s) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(c->d_state, s, (size_t)c->n * STATE * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->main.state, s, (size_t)c->n * STATE * 4, hipMemcpyHostToDevice));
+    HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return PBRE_OK;
 }
 
@@ -350,13 +427,15 @@ int pbre_timing(const pbre_ctx* c, double* ms, int32_t n) {
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
     hipFuncAttributes fa;
-    int rf = -1, rg = -1;
-    if (hipFuncGetAttributes(&fa, (const void*)k_fast<FastD::M_ACTION | FastD::M_OBS | FastD::M_TASK>) == hipSuccess) rf = fa.numRegs;
-    if (hipFuncGetAttributes(&fa, (const void*)k_step<CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK>) == hipSuccess) rg = fa.numRegs;
-    int last = 0;       // envs the fast path declined in the most recent step (reads the device counter)
-    if (c->d_count) { (void)hipSetDevice(c->device); (void)hipMemcpy(&last, c->d_count, sizeof(int), hipMemcpyDeviceToHost); }
-    const int v[5] = {c->fast_ok ? rf : -1, rg, c->fast_ok ? 1 : 0, c->n - last, last};
-    for (int i = 0; i < n; i++) info[i] = i < 5 ? v[i] : 0;
+    int rf = -1, rg = -1, rr = -1;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP>) == hipSuccess) rf = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
+    int complex_now = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
+    const bool lpe = lane_per_env(c);
+    if (lpe) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipMemcpy(&complex_now, c->main.count + c->main.cur, sizeof(int), hipMemcpyDeviceToHost); }
+    const int v[7] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1};
+    for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
     return PBRE_OK;
 }
 

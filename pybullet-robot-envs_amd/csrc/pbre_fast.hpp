@@ -1,12 +1,13 @@
 // pbre_fast.hpp -- lane-per-env fast path of the step (one thread = one env, everything in VGPRs).
 //
-// Handles the common case exactly: no robot collision sphere within the contact margin of the
+// step_t<false> handles the common case exactly: no robot collision sphere within the contact margin of the
 // object or the table and no joint at/beyond a limit, i.e. the only constraint rows are the 9 joint
 // motors and up to 4 object-table contacts (normal +z => Bullet's btPlaneSpace1 friction directions are
 // the constants (0,-1,0) and (1,0,0), so the object rows are sparse).  Such an env needs ~850
 // instructions per env-step instead of ~17000 in the 16-lane row kernel (pbre_core.hpp), because nothing
-// is computed redundantly across lanes and no cross-lane reduction is needed.  Any other env is
-// reported back (return value false, state untouched) and is stepped by the general row kernel.
+// is computed redundantly across lanes and no cross-lane reduction is needed.  step_t<true> adds the robot-contact
+// and joint-limit rows for the remaining envs (dense rows, whole register file).  Which variant an env needs is
+// decided by classify() on the state it is in.
 //
 // Same mathematics as pbre_core.hpp (world-frame RNEA + CRBA + explicit M^-1, Bullet row order:
 // motors in alternating direction, normals, frictions), same reference call sites.  The kinematic
@@ -186,16 +187,54 @@ struct Fast {
 
     enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4 };
 
-    // Returns true if the env was stepped; false if it needs the general kernel (state untouched).
-    static PBRE_HD bool step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+    // full sphere-vs-box test: signed distance, world normal box->sphere, point on the box
+    static PBRE_HD float sphere_box(V3 sc, float sr, V3 bc, const M3& Rb, V3 h, V3& n, V3& pb) {
+        V3 dl = mtv(Rb, sub(sc, bc));
+        V3 cl = v3(clampf(dl.x, -h.x, h.x), clampf(dl.y, -h.y, h.y), clampf(dl.z, -h.z, h.z));
+        V3 df = sub(dl, cl);
+        const float len = norm(df);
+        const bool inside = len < 1e-9f;
+        const float il = 1.f / fmaxf(len, 1e-30f);
+        const float ex = h.x - fabsf(dl.x), ey = h.y - fabsf(dl.y), ez = h.z - fabsf(dl.z);
+        const bool ax_y = ey < ex; float best = ax_y ? ey : ex;
+        const bool ax_z = ez < best; best = ax_z ? ez : best;
+        const bool is_x = !ax_y && !ax_z, is_y = ax_y && !ax_z;
+        const float sx = dl.x >= 0.f ? 1.f : -1.f, sy = dl.y >= 0.f ? 1.f : -1.f, sz = dl.z >= 0.f ? 1.f : -1.f;
+        V3 nl = inside ? v3(is_x ? sx : 0.f, is_y ? sy : 0.f, ax_z ? sz : 0.f) : scl(df, il);
+        V3 c2 = inside ? v3(is_x ? sx * h.x : cl.x, is_y ? sy * h.y : cl.y, ax_z ? sz * h.z : cl.z) : cl;
+        n = mv(Rb, nl); pb = add(bc, mv(Rb, c2));
+        return inside ? -best - sr : len - sr;
+    }
+    struct Cand { float dist; int idx; V3 n, pA, pB; float mu; int owner; };
+    static PBRE_HD bool better(const Cand& x, const Cand& y) { return x.dist < y.dist || (x.dist == y.dist && x.idx < y.idx); }
+    // keep the two best (smallest distance, ties -> lowest sphere index) candidates below the margin
+    static PBRE_HD void keep2(const Cand& c, float margin, Cand& a, Cand& b) {
+        if (c.dist < margin) {
+            if (better(c, a)) { b = a; a = c; } else if (better(c, b)) b = c;
+        }
+    }
+
+    // Env classes.  Every stepping kernel finishes by classifying the NEW state (it has the kinematics at hand), so the
+    // next step can launch the right kernel for every env without a pre-pass:
+    //   0  simple : no robot collision sphere within the contact margin of object/table, no joint at a limit
+    //               -> step_t<false> (fast path: motors + object-table contacts only)
+    //   1  complex: robot contacts and/or active joint-limit rows -> step_t<true> (adds dense 9-DoF contact rows and the
+    //               limit rows; needs the whole register file, launched only over the list of complex envs)
+    // Both variants return the class of the state they produced.
+    static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+        return step_t<false>(T, P, st, act, out, mode, flags);
+    }
+    static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+        return step_t<true>(T, P, st, act, out, mode, flags);
+    }
+    template <bool RC>
+    static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+        constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
+        static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
         const float dt = P.dt, inv_dt = P.inv_dt;
         float q[ND], qd[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
-        // ---- eligibility 1: no joint at/over a limit (limit rows exist only while violated)
-        bool simple = true;
-        PBRE_UNROLL for (int j = 0; j < ND; j++) simple = simple && (q[j] - T.lower[j] > 0.f) && (T.upper[j] - q[j] > 0.f);
-        if (!simple) return false;
         V3 op = v3(st[9], st[10], st[11]);
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
         M3 Ro = quat_R(oq);
@@ -205,7 +244,11 @@ struct Fast {
         V3 Sa[ND], Sl[ND];
         V3 Fa[ND], Fl[ND];
         float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
-        float dmin = 1e30f;
+        Cand k1[2], k2[2];       // [0] robot-object, [1] robot-table: best and second best
+        PBRE_UNROLL for (int g = 0; g < 2; g++) {
+            k1[g].dist = k2[g].dist = 3e38f; k1[g].idx = k2[g].idx = 99; k1[g].mu = k2[g].mu = 0.f; k1[g].owner = k2[g].owner = 0;
+            k1[g].n = k2[g].n = k1[g].pA = k2[g].pA = k1[g].pB = k2[g].pB = v3(0.f, 0.f, 0.f);
+        }
         {
             M3 R[ND]; V3 p[ND]; V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
             const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
@@ -235,12 +278,21 @@ struct Fast {
                 if (root) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj], sa); Vl[j] = add(Vl[pj], sl); }
                 V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
                 if (root) { Aa[j] = ca; Al[j] = v3(cl.x, cl.y, cl.z - P.gz); } else { Aa[j] = add(Aa[pj], ca); Al[j] = add(Al[pj], cl); }
-                // eligibility 2: robot spheres owned by this link vs object / table
-                for (int s = 0; s < T.nspheres; s++) {
+                // robot collision spheres owned by this link vs object / table (the simple class has none in range)
+                if (RC) for (int s = 0; s < T.nspheres; s++) {
                     if (T.s_owner[s] != j) continue;
                     V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
-                    if (obj_on) dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], op, Ro, oh));
-                    dmin = fminf(dmin, sphere_box_dist(sc, T.s_r[s], tc, Id, th));
+                    {
+                        Cand c; c.idx = s; c.owner = j;
+                        if (obj_on) {
+                            c.dist = sphere_box(sc, T.s_r[s], op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
+                            c.mu = T.s_mu[s] * P.obj_mu;
+                            keep2(c, P.margin, k1[0], k2[0]);
+                        }
+                        c.dist = sphere_box(sc, T.s_r[s], tc, Id, th, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
+                        c.mu = T.s_mu[s] * P.tab_mu;
+                        keep2(c, P.margin, k1[1], k2[1]);
+                    }
                 }
                 Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
                 PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
@@ -270,7 +322,6 @@ struct Fast {
                 }
             }
         }
-        if (dmin < P.margin) return false;
 
         // ---- backward sweep: subtree forces -> bias torques, composite inertias -> mass matrix (CRBA)
         float Mi[ND * (ND + 1) / 2];       // symmetric storage, becomes M^-1
@@ -324,6 +375,24 @@ struct Fast {
             m_dinv[j] = 1.f / Mi[sym(j, j)];
             m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * w[j]) * m_dinv[j];
             m_app[j] = 0.f;
+        }
+
+        // joint-limit rows (btMultiBodyJointLimitConstraint; complex class only): a row exists while the joint is at/over
+        // the limit; J = dir e_j, positional rhs -pen*erp/dt, impulse in [0, limit_imp]
+        float l_dir[ND], l_rhs[ND], l_app[ND];
+        bool any_lim = false;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { l_dir[j] = 0.f; l_rhs[j] = 0.f; l_app[j] = 0.f; }
+        if (RC) {
+            bool lim = false;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                const float pl = q[j] - T.lower[j], pu = T.upper[j] - q[j];
+                const bool lo_v = pl <= 0.f, up_v = !lo_v && pu <= 0.f;
+                l_dir[j] = lo_v ? 1.f : (up_v ? -1.f : 0.f);
+                const float pen = lo_v ? pl : pu;
+                l_rhs[j] = (lo_v || up_v) ? (-pen * P.erp * inv_dt) * m_dinv[j] : 0.f;
+                lim = lim || lo_v || up_v;
+            }
+            any_lim = PBRE_ANY(lim);
         }
 
         // ---- object: unconstrained velocity, object-table contacts (normal +z, friction directions -y and +x)
@@ -397,12 +466,70 @@ struct Fast {
             }
         }
 
+        // ---- robot contacts (RC): dense rows J_r (9 joint DoF) [+ object part for robot-object], B_r = M^-1 J_r^T
+        float rc_J[NR][3][ND], rc_B[NR][3][ND], rc_dinv[NR][3], rc_app[NR][3], rc_rhs[NR], rc_mu[NR];
+        V3 rc_dir[NC_RO][3], rc_rxd[NC_RO][3];
+        bool rc_act[NR];
+        PBRE_UNROLL for (int c = 0; c < NR; c++) rc_act[c] = false;
+        if (RC) {
+            PBRE_UNROLL for (int c = 0; c < NR; c++) {
+                const int g = c < NC_RO ? 0 : 1, k = c < NC_RO ? c : c - NC_RO;
+                // slot order = sphere index order among the (at most two) selected candidates
+                const bool two = k2[g].dist < 3e38f;
+                const bool swap = two && k2[g].idx < k1[g].idx;
+                const Cand cc = (k == 0) ? (swap ? k2[g] : k1[g]) : (swap ? k1[g] : k2[g]);
+                rc_act[c] = cc.dist < 3e38f;
+                rc_mu[c] = rc_act[c] ? cc.mu : 0.f;
+                const V3 n = cc.n;
+                V3 t1, t2;     // btPlaneSpace1
+                if (fabsf(n.z) > 0.70710678118654752f) {
+                    const float a = n.y*n.y + n.z*n.z, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                    t1 = v3(0.f, -n.z * kk, n.y * kk); t2 = v3(a * kk, -n.x * t1.z, n.x * t1.y);
+                } else {
+                    const float a = n.x*n.x + n.y*n.y, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                    t1 = v3(-n.y * kk, n.x * kk, 0.f); t2 = v3(-n.z * t1.y, n.z * t1.x, a * kk);
+                }
+                const V3 rB = sub(cc.pB, op);
+                PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                    const V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                        bool onchain = false;      // joint j moves the contact link (compile-time tree, per-lane owner)
+                        PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
+                        rc_J[c][d][j] = (rc_act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                    }
+                    float denom = 0.f;
+                    PBRE_UNROLL for (int kx = 0; kx < ND; kx++) {
+                        float b = 0.f;
+                        PBRE_UNROLL for (int j = 0; j < ND; j++) b = fmaf(Mi[sym(kx, j)], rc_J[c][d][j], b);
+                        rc_B[c][d][kx] = b; denom = fmaf(rc_J[c][d][kx], b, denom);
+                    }
+                    if (c < NC_RO) {
+                        const int co = c < NC_RO ? c : 0;
+                        const V3 rxd = cross(rB, dir);
+                        rc_dir[co][d] = rc_act[c] ? dir : v3(0.f, 0.f, 0.f); rc_rxd[co][d] = rc_act[c] ? rxd : v3(0.f, 0.f, 0.f);
+                        denom += fmaf(dot(rxd, rxd), inv_I, inv_m);
+                    }
+                    rc_dinv[c][d] = rc_act[c] ? 1.f / denom : 0.f;
+                    rc_app[c][d] = 0.f;
+                }
+                const float pen = cc.dist + P.slop;
+                rc_rhs[c] = rc_act[c] ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * rc_dinv[c][0] : 0.f;
+            }
+        }
+
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
         const float mlim = P.motor_imp;
         auto motor = [&](int j) {
             const float t = fmaf(m_dinv[j], w[j], -m_rhs[j]);
             const float s = med3(m_app[j] - t, -mlim, mlim);
             const float d = s - m_app[j]; m_app[j] = s;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, Mi[sym(k, j)], w[k]);
+        };
+        const float llim = P.limit_imp;
+        auto limit = [&](int j) {
+            const float t = fmaf(m_dinv[j] * l_dir[j], w[j], -l_rhs[j]);
+            const float s = med3(l_app[j] - t, 0.f, llim);
+            const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
             PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, Mi[sym(k, j)], w[k]);
         };
         auto orow = [&](int c, int d) {
@@ -424,16 +551,41 @@ struct Fast {
             else if (d == 1) { ov.y -= dm; ow.x = fmaf(di, rz, ow.x); ow.z = fmaf(-di, rx, ow.z); }
             else { ov.x += dm; ow.y = fmaf(di, rz, ow.y); ow.z = fmaf(-di, ry, ow.z); }
         };
-        bool any_c[NK];
+        auto rrow = [&](int c, int d) {       // robot contact row (RC only)
+            float jv = 0.f;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(rc_J[c][d][j], w[j], jv);
+            if (c < NC_RO) { const int co = c < NC_RO ? c : 0; jv -= dot(rc_dir[co][d], ov) + dot(rc_rxd[co][d], ow); }
+            float s;
+            if (d == 0) s = med3(rc_app[c][0] - fmaf(jv, rc_dinv[c][0], -rc_rhs[c]), 0.f, 1e10f);
+            else {
+                const float hi = rc_mu[c] * rc_app[c][0];
+                s = med3(rc_app[c][d] - jv * rc_dinv[c][d], -hi, hi);
+                s = hi > 0.f ? s : rc_app[c][d];
+            }
+            const float dd = s - rc_app[c][d]; rc_app[c][d] = s;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(dd, rc_B[c][d][k], w[k]);
+            if (c < NC_RO) {
+                const int co = c < NC_RO ? c : 0;
+                const float dm = -dd * inv_m, di = -dd * inv_I;
+                ov.x = fmaf(dm, rc_dir[co][d].x, ov.x); ov.y = fmaf(dm, rc_dir[co][d].y, ov.y); ov.z = fmaf(dm, rc_dir[co][d].z, ov.z);
+                ow.x = fmaf(di, rc_rxd[co][d].x, ow.x); ow.y = fmaf(di, rc_rxd[co][d].y, ow.y); ow.z = fmaf(di, rc_rxd[co][d].z, ow.z);
+            }
+        };
+        bool any_c[NK], any_r[NR];
         PBRE_UNROLL for (int c = 0; c < NK; c++) any_c[c] = PBRE_ANY(c_act[c]);    // wave-uniform; inactive slots are exact no-ops
-        auto contacts = [&]() {
+        PBRE_UNROLL for (int c = 0; c < NR; c++) any_r[c] = RC && PBRE_ANY(rc_act[c]);
+        auto contacts = [&]() {      // Bullet: all normals (object-table, robot-object, robot-table), then all frictions
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) orow(c, 0);
+            if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) rrow(c, 0); }
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
+            if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) { rrow(c, 1); rrow(c, 2); } }
         };
         for (int it = 0; it < P.iters; it += 2) {
             PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
+            if (RC && any_lim) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) limit(j); }
             contacts();
             if (it + 1 >= P.iters) break;
+            if (RC && any_lim) { PBRE_UNROLL for (int j = 0; j < ND; j++) limit(j); }
             PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
             contacts();
         }
@@ -462,18 +614,49 @@ struct Fast {
             st[9] = op.x; st[10] = op.y; st[11] = op.z; st[12] = oq.x; st[13] = oq.y; st[14] = oq.z; st[15] = oq.w;
             st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
         }
-        if (mode & (M_OBS | M_TASK)) {
-            // re-read the model constants after the solver loop instead of keeping ~130 of them live across it
-            const Tables* T2 = &T;
-            PBRE_LAUNDER(T2);
-            observe(*T2, P, st, q, qd, op, oq, out, mode);
-        }
-        return true;
+        // observation / reward / termination of the new state, and its class for the next step.  The model constants
+        // are re-read after the solver loop instead of keeping ~130 of them live across it.
+        const Tables* T2 = &T;
+        PBRE_LAUNDER(T2);
+        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags);
     }
 
-    static PBRE_HD void observe(const Tables& T, const Params& P, float* st, const float* q, const float* qd, V3 op, Q4 oq,
-                                float* out, int mode) {
+    // class of a state: 1 if any joint is at/over a limit or any robot collision sphere is within the contact margin of the
+    // object or the table (same arithmetic as the contact candidates of step_t<true>)
+    static PBRE_HD int classify(const Tables& T, const Params& P, const Kin& K, const float* q, V3 op, Q4 oq, int flags) {
+        const bool obj_on = !(flags & 1);
+        bool complex_ = false;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) complex_ = complex_ || (q[j] - T.lower[j] <= 0.f) || (T.upper[j] - q[j] <= 0.f);
+        const M3 Ro = quat_R(oq);
+        const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
+        const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
+        M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+        float dmin = 1e30f;
+        for (int s = 0; s < T.nspheres; s++) {
+            const int o = T.s_owner[s];
+            M3 Rs = K.R[0]; V3 ps = K.p[0];
+            PBRE_UNROLL for (int j = 1; j < ND; j++) if (o == j) { Rs = K.R[j]; ps = K.p[j]; }
+            V3 sc = add(ps, mv(Rs, v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
+            V3 n, pb;
+            if (obj_on) dmin = fminf(dmin, sphere_box(sc, T.s_r[s], op, Ro, oh, n, pb));
+            dmin = fminf(dmin, sphere_box(sc, T.s_r[s], tc, Id, th, n, pb));
+        }
+        return (complex_ || dmin < P.margin) ? 1 : 0;
+    }
+    // class of the state stored in `st` (after reset / set_state)
+    static PBRE_HD int classify_state(const Tables& T, const Params& P, const float* st, int flags) {
+        float q[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
         Kin K; fk(T, q, K);
+        Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+        return classify(T, P, K, q, v3(st[9], st[10], st[11]), oq, flags);
+    }
+
+    static PBRE_HD int finish(const Tables& T, const Params& P, float* st, const float* q, const float* qd, V3 op, Q4 oq,
+                              float* out, int mode, int flags) {
+        Kin K; fk(T, q, K);
+        const int cls = classify(T, P, K, q, op, oq, flags);
+        if (!(mode & (M_OBS | M_TASK))) return cls;
         // EE owner is a runtime table entry: walk the chain up to it with compile-time indices
         V3 Va = v3(0.f, 0.f, 0.f), Vl = v3(0.f, 0.f, 0.f);
         M3 Re = K.R[0]; V3 pe = K.p[0];
@@ -527,6 +710,7 @@ struct Fast {
             if (P.task >= 1) { out[o++] = tg.x; out[o++] = tg.y; out[o++] = tg.z; }
             out[o++] = reward; out[o++] = done;
         }
+        return cls;
     }
 };
 

@@ -172,6 +172,6 @@ class Engine:
         return list(ms)
 
     def kernel_info(self):
-        info = (C.c_int32 * 5)()
-        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(5)))
+        info = (C.c_int32 * 7)()
+        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(7)))
         return list(info)

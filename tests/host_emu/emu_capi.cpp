@@ -24,11 +24,16 @@ struct pbre_ctx {
     std::vector<unsigned> episode;
     std::string err;
     bool fast_ok = false;
-    long n_fast = 0, n_general = 0;
+    long n_fast = 0, n_rc = 0, n_general = 0;
 };
 // same dispatch as the device: lane-per-env fast path first, general row kernel for the envs it declines
 static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags) {
-    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL) && FastH::step(c->T, c->P, st, act, out, mode, flags)) { c->n_fast++; return; }
+    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
+        // same dispatch as the device; the class is recomputed here instead of being carried from the previous step
+        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags); }
+        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags); }
+        return;
+    }
     c->n_general++;
     CoreH::step(c->T, c->P, st, act, out, mode, flags);
 }
@@ -114,8 +119,8 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; obs_limits(c->cfg, c->T, lo, hi); return PBRE_OK; }
 int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
-    const long v[5] = {0, 0, 0, c->n_fast, c->n_general};
-    for (int i = 0; i < n; i++) info[i] = i < 5 ? (int32_t)v[i] : 0;
+    const long v[7] = {0, 0, 0, c->n_fast, c->n_general, c->n_rc, 0};
+    for (int i = 0; i < n; i++) info[i] = i < 7 ? (int32_t)v[i] : 0;
     return PBRE_OK;
 }
 
