@@ -61,44 +61,55 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     CoreD::step(*T, P, st, a, o, MODE, flags);
 }
 
-__device__ __forceinline__ void publish_class(int env, int c, signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
+// Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
+// k_fast_rc are homogeneous.  lists: [NB][cap] ints, counts: [NB] ints.
+constexpr int NB = FastD::NCLASS - 1;
+__device__ __forceinline__ void publish_class(int env, int c, signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
     cls[env] = (signed char)c;
-    if (c) next_list[atomicAdd(next_count, 1)] = env;
+    if (c) next_list[(size_t)(c - 1) * cap + atomicAdd(next_count + (c - 1), 1)] = env;
 }
 
 // Simple envs: every env of the batch in natural order (coalesced), lanes of complex envs idle.
 template <int MODE>
 __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
+                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n || cls[env] != 0) return;
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                               (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
-    publish_class(env, c, cls, next_list, next_count);
+    publish_class(env, c, cls, next_list, next_count, cap);
 }
 
-// Complex envs (robot contacts and/or limit rows), compacted: thread i steps env cur_list[i].  The grid is sized for the
-// worst case; surplus blocks exit at once.
+// Complex envs (robot contacts and/or limit rows), compacted per class.  Persistent blocks (the host does not know the
+// list lengths): work item w = (bucket, 64-env chunk); block b takes items b, b + gridDim.x, ...  The grid is one block
+// per SIMD (the kernel needs a whole SIMD's register file), blocks without work exit at once.
 template <int MODE>
 __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
-    const int i = blockIdx.x * FTPB + threadIdx.x;
-    if (i >= *cur_count) return;
-    const int env = cur_list[i];
-    const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                 (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
-    publish_class(env, c, cls, next_list, next_count);
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
+    int chunks[NB], total = 0;
+    PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; }
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        int b = 0, k = w;
+        PBRE_UNROLL for (int j = 0; j < NB - 1; j++) if (b == j && k >= chunks[j]) { k -= chunks[j]; b = j + 1; }
+        const int i = k * FTPB + threadIdx.x;
+        if (i < cur_count[b]) {
+            const int env = cur_list[(size_t)b * cap + i];
+            const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+            publish_class(env, c, cls, next_list, next_count, cap);
+        }
+    }
 }
 
 // Class of every env's current state (after reset / set_state / a change of the NO_OBJECT flag).
 __global__ __launch_bounds__(FTPB) void k_classify(const Tables* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
-                                                   signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count) {
+                                                   signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count, int cap) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n) return;
-    publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count);
+    publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count, cap);
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -131,9 +142,9 @@ __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src
 struct EnvBuf {                       // a batch of state records with its class bookkeeping
     float* state = nullptr;           // cap + 16 records
     signed char* cls = nullptr;       // class per env
-    int* list[2] = {nullptr, nullptr};
-    int* count = nullptr;             // 2 ints
-    int cur = 0;                      // list[cur]/count[cur]: complex envs of the current state
+    int* list[2] = {nullptr, nullptr};  // each [NB][cap]
+    int* count = nullptr;             // [2][NB]
+    int cur = 0;                      // list[cur] / count + cur*NB: complex envs of the current state, per class
     int cap = 0;
 };
 
@@ -146,6 +157,7 @@ struct pbre_ctx {
     float *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
+    int n_simd = 1024;
     std::vector<unsigned> episode;
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -173,9 +185,9 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMalloc(&b.cls, (size_t)cap)) != hipSuccess) return e;
     if ((e = hipMemset(b.cls, 0, (size_t)cap)) != hipSuccess) return e;
-    for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)cap * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&b.count, 2 * sizeof(int))) != hipSuccess) return e;
-    return hipMemset(b.count, 0, 2 * sizeof(int));
+    for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.count, 2 * NB * sizeof(int))) != hipSuccess) return e;
+    return hipMemset(b.count, 0, 2 * NB * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
     for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
@@ -184,9 +196,9 @@ static void free_buf(EnvBuf& b) {
 // (re)build class array and current list of the first n envs of b
 static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t s) {
     if (!lane_per_env(c)) return hipSuccess;
-    hipError_t e = hipMemsetAsync(b.count + b.cur, 0, sizeof(int), s);
+    hipError_t e = hipMemsetAsync(b.count + b.cur * NB, 0, NB * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls, b.list[b.cur], b.count + b.cur);
+    hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls, b.list[b.cur], b.count + b.cur * NB, b.cap);
     return hipGetLastError();
 }
 
@@ -201,18 +213,19 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     const int cur = b.cur, nxt = cur ^ 1;
     const int blocks = (n + FTPB - 1) / FTPB;
     hipError_t e;
-    if ((e = hipMemsetAsync(b.count + nxt, 0, sizeof(int), s)) != hipSuccess) return e;
-    // fork: the complex envs run on the side stream, concurrently with the simple ones
+    if ((e = hipMemsetAsync(b.count + nxt * NB, 0, NB * sizeof(int), s)) != hipSuccess) return e;
+    // fork/join: k_fast_rc (few waves, whole register file each) is enqueued first on the caller's stream so that its waves
+    // claim their SIMDs before k_fast floods the chip from the side stream; both run concurrently and append to list[nxt]
     if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
-                       b.list[cur], b.count + cur, b.cls, b.list[nxt], b.count + nxt);
+    hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+                       b.list[cur], b.count + cur * NB, b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                       b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                       b.cls, b.list[nxt], b.count + nxt);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;      // join
+    if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
     b.cur = nxt;
     return hipSuccess;
 }
@@ -261,6 +274,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (c->device < 0 || c->device >= ndev) { g_err = "device_id out of range"; delete c; return PBRE_E_ARG; }
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_err = std::string(#call) + ": " + hipGetErrorString(e_); pbre_destroy(c); return PBRE_E_DEVICE; } } while (0)
     CK(hipSetDevice(c->device));
+    { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, c->device)); c->n_simd = std::max(1, pr.multiProcessorCount * 4); }
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
@@ -433,7 +447,12 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
     int complex_now = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
     const bool lpe = lane_per_env(c);
-    if (lpe) { (void)hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipMemcpy(&complex_now, c->main.count + c->main.cur, sizeof(int), hipMemcpyDeviceToHost); }
+    if (lpe) {
+        int cnt[NB] = {0};
+        (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
+        (void)hipMemcpy(cnt, c->main.count + c->main.cur * NB, NB * sizeof(int), hipMemcpyDeviceToHost);
+        for (int k = 0; k < NB; k++) complex_now += cnt[k];
+    }
     const int v[7] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1};
     for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
     return PBRE_OK;

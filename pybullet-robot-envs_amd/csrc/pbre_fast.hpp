@@ -621,53 +621,90 @@ struct Fast {
         return finish(*T2, P, st, q, qd, op, oq, out, mode, flags);
     }
 
-    // class of a state: 1 if any joint is at/over a limit or any robot collision sphere is within the contact margin of the
-    // object or the table (same arithmetic as the contact candidates of step_t<true>)
-    static PBRE_HD int classify(const Tables& T, const Params& P, const Kin& K, const float* q, V3 op, Q4 oq, int flags) {
+    // Class of a state (same distance arithmetic as the contact candidates of step_t<true>):
+    //   0 simple; 1 limit rows only; 2 one robot-table contact; 3 two robot-table contacts; 4 one robot-object contact;
+    //   5 any other combination.
+    // Classes 1..5 are all stepped by step_t<true>; they exist so that a wave of the compacted complex list is homogeneous
+    // and the wave-uniform "any lane uses this row slot" tests skip the row slots nobody in the wave needs.
+#ifndef PBRE_NCLASS
+#define PBRE_NCLASS 2        // 2: all complex envs share one list (best at <= 131072 envs/GPU on MI355X: 308 vs 282 M env-steps/s
+#endif                       //    mid-episode); 6: one list per class above (pays off only when k_fast_rc is throughput-bound)
+    static constexpr int NCLASS = PBRE_NCLASS;
+    static_assert(NCLASS == 2 || NCLASS == 6, "supported class layouts");
+    struct Tail { int cls; M3 Re; V3 pe, Va, Vl; };   // class + end-effector owner frame and spatial velocity
+
+    // One streaming sweep over the links (a link's frame is dropped as soon as its children are done): kinematics, the
+    // class of the state, and -- when qd is given -- the frame and spatial velocity of the end-effector's owner link.
+    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags) {
         const bool obj_on = !(flags & 1);
-        bool complex_ = false;
-        PBRE_UNROLL for (int j = 0; j < ND; j++) complex_ = complex_ || (q[j] - T.lower[j] <= 0.f) || (T.upper[j] - q[j] <= 0.f);
+        Tail t;
+        bool lim = false;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) lim = lim || (q[j] - T.lower[j] <= 0.f) || (T.upper[j] - q[j] <= 0.f);
         const M3 Ro = quat_R(oq);
         const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
         const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
         M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
-        float dmin = 1e30f;
-        for (int s = 0; s < T.nspheres; s++) {
-            const int o = T.s_owner[s];
-            M3 Rs = K.R[0]; V3 ps = K.p[0];
-            PBRE_UNROLL for (int j = 1; j < ND; j++) if (o == j) { Rs = K.R[j]; ps = K.p[j]; }
-            V3 sc = add(ps, mv(Rs, v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
-            V3 n, pb;
-            if (obj_on) dmin = fminf(dmin, sphere_box(sc, T.s_r[s], op, Ro, oh, n, pb));
-            dmin = fminf(dmin, sphere_box(sc, T.s_r[s], tc, Id, th, n, pb));
+        int nO = 0, nT = 0;
+        const int eo = T.ee_owner;
+        t.Va = v3(0.f, 0.f, 0.f); t.Vl = v3(0.f, 0.f, 0.f); t.pe = v3(0.f, 0.f, 0.f);
+        PBRE_UNROLL for (int k = 0; k < 9; k++) t.Re.m[k] = 0.f;
+        M3 R[ND]; V3 p[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+            V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
+            M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
+            V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
+            M3 Rl; V3 pl;
+            if (Topo::jtype(j) == 1) {
+                float c = cosf(q[j]), sn = sinf(q[j]), C = 1.f - c;
+                M3 Rj;
+                Rj.m[0] = c + ax.x*ax.x*C;       Rj.m[1] = ax.x*ax.y*C - ax.z*sn; Rj.m[2] = ax.x*ax.z*C + ax.y*sn;
+                Rj.m[3] = ax.y*ax.x*C + ax.z*sn; Rj.m[4] = c + ax.y*ax.y*C;       Rj.m[5] = ax.y*ax.z*C - ax.x*sn;
+                Rj.m[6] = ax.z*ax.x*C - ax.y*sn; Rj.m[7] = ax.z*ax.y*C + ax.x*sn; Rj.m[8] = c + ax.z*ax.z*C;
+                Rl = mm(R0, Rj); pl = p0;
+            } else {
+                Rl = R0; V3 d = mv(R0, ax); pl = v3(fmaf(d.x, q[j], p0.x), fmaf(d.y, q[j], p0.y), fmaf(d.z, q[j], p0.z));
+            }
+            if (Topo::parent(j) < 0) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+            for (int s = 0; s < T.nspheres; s++) {
+                if (T.s_owner[s] != j) continue;
+                V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
+                if (obj_on && sphere_box_dist(sc, T.s_r[s], op, Ro, oh) < P.margin) nO++;
+                if (sphere_box_dist(sc, T.s_r[s], tc, Id, th) < P.margin) nT++;
+            }
+            if (qd) {
+                bool anc = false;      // is j an ancestor-or-self of the EE owner?  (compile-time tree, uniform runtime owner)
+                PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && eo == e) anc = true;
+                if (anc) {
+                    V3 aw = mv(R[j], ax);
+                    if (Topo::jtype(j) == 1) { t.Va = add(t.Va, scl(aw, qd[j])); t.Vl = add(t.Vl, scl(cross(p[j], aw), qd[j])); }
+                    else t.Vl = add(t.Vl, scl(aw, qd[j]));
+                }
+                if (eo == j) { t.Re = R[j]; t.pe = p[j]; }
+            }
         }
-        return (complex_ || dmin < P.margin) ? 1 : 0;
+        if (nO == 0 && nT == 0) t.cls = lim ? 1 : 0;
+        else if (NCLASS == 2) t.cls = 1;
+        else if (!lim && nO == 0) t.cls = nT == 1 ? 2 : 3;
+        else if (!lim && nT == 0 && nO == 1) t.cls = 4;
+        else t.cls = 5;
+        return t;
     }
     // class of the state stored in `st` (after reset / set_state)
     static PBRE_HD int classify_state(const Tables& T, const Params& P, const float* st, int flags) {
         float q[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
-        Kin K; fk(T, q, K);
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-        return classify(T, P, K, q, v3(st[9], st[10], st[11]), oq, flags);
+        return sweep(T, P, q, nullptr, v3(st[9], st[10], st[11]), oq, flags).cls;
     }
 
     static PBRE_HD int finish(const Tables& T, const Params& P, float* st, const float* q, const float* qd, V3 op, Q4 oq,
                               float* out, int mode, int flags) {
-        Kin K; fk(T, q, K);
-        const int cls = classify(T, P, K, q, op, oq, flags);
-        if (!(mode & (M_OBS | M_TASK))) return cls;
-        // EE owner is a runtime table entry: walk the chain up to it with compile-time indices
-        V3 Va = v3(0.f, 0.f, 0.f), Vl = v3(0.f, 0.f, 0.f);
-        M3 Re = K.R[0]; V3 pe = K.p[0];
-        const int eo = T.ee_owner;
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            // is j an ancestor-or-self of eo?  (compile-time tree, runtime eo)
-            bool anc = false;
-            PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && eo == e) anc = true;
-            if (anc) { Va = add(Va, scl(K.Sa[j], qd[j])); Vl = add(Vl, scl(K.Sl[j], qd[j])); }
-            if (eo == j) { Re = K.R[j]; pe = K.p[j]; }
-        }
+        const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
+        const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
+        const int cls = tl.cls;
+        if (!want_obs) return cls;
+        const M3 Re = tl.Re; const V3 pe = tl.pe, Va = tl.Va, Vl = tl.Vl;
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
         M3 Ree = mm(Re, Eo);
         V3 ee = add(pe, mv(Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
