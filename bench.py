@@ -189,6 +189,15 @@ def main():
         ach_gbs = ALG_BYTES_PER_ENV_STEP * n_local / kern_s / 1e9
         ach_tf = ALG_FLOP_PER_ENV_STEP * n_local / kern_s / 1e12
         info = eng.kernel_info()
+        # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
+        # calibrated in profiles/r01_pmc_hbm.json); counters cannot be read from inside this process, so the committed
+        # per-env figure of the profiled run is scaled to this launch's env count.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["k_fast<7>"]
+            traffic = pmc["hbm_bytes_per_env_step"] * n_local
+        except Exception:
+            pass
         res = {
             "metric": "env-steps/sec (whole node), Panda-push 128k envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,7 +212,7 @@ def main():
                        "complex_env_frac_after_timed_steps_rank0": complex_after / n_local},
             "steady_state": steady,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_fast<7> (+ k_fast_rc<7> for envs with robot contacts / limit rows, concurrently)", "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU/dependency bound (AI ~900 FLOP/B >> 25 FLOP/B machine balance); "
                                  "HBM fraction is small by construction, see valu"},
