@@ -126,7 +126,9 @@ int pbre_settle(pbre_ctx* ctx, int32_t n, int32_t flags);
 /* observation limits used by the Gym Box space / scale_gym_data (create_gym_spaces, :83-103) */
 int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
 
-/* wall-clock of the last pbre_step phases in ms: [0] upload, [1] kernels, [2] download */
+/* ms of the last pbre_step phases: [0] upload, [1] kernels, [2] download; [3] mean duration of the dominant kernel
+ * (k_fast, or k_step on the general path) over the most recent <= 64 steps of any kind, from HIP events recorded on the
+ * stream that kernel runs on (synchronises the device) */
 int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
 /* kernel facts for the bench/roofline report: [0] VGPRs of the fast kernel, [1] VGPRs of the general kernel,
  * [2] fast path enabled, [3..5] envs stepped in the most recent step by the fast kernel / the general row kernel / the

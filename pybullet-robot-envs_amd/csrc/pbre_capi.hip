@@ -162,6 +162,9 @@ struct pbre_ctx {
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING steps,
+    hipEvent_t ev_k[KRING][2] = {};            // recorded on the stream that kernel runs on
+    long k_steps = 0;
     double ms[3] = {0, 0, 0};
     std::string err;
 };
@@ -206,8 +209,12 @@ static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t
 template <int MODE>
 static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
     if (!lane_per_env(c)) {
+        hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
+        (void)hipEventRecord(ek[0], s);
         hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
                            c->act_dim, c->ow, flags);
+        (void)hipEventRecord(ek[1], s);
+        c->k_steps++;
         return hipGetLastError();
     }
     const int cur = b.cur, nxt = cur ^ 1;
@@ -221,9 +228,13 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                        b.list[cur], b.count + cur * NB, b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
+    (void)hipEventRecord(ek[0], c->side);
     hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                        b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    (void)hipEventRecord(ek[1], c->side);
+    c->k_steps++;
     if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
     b.cur = nxt;
@@ -245,6 +256,7 @@ void pbre_destroy(pbre_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (auto& pr : c->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
@@ -280,6 +292,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (auto& pr : c->ev_k) for (auto& ev : pr) CK(hipEventCreate(&ev));
     CK(hipMalloc(&c->dT, sizeof(Tables)));
     CK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
     CK(alloc_buf(c->main, c->npad));
@@ -435,7 +448,20 @@ int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) {
 }
 int pbre_timing(const pbre_ctx* c, double* ms, int32_t n) {
     if (!c || !ms) return PBRE_E_ARG;
-    for (int i = 0; i < n; i++) ms[i] = i < 3 ? c->ms[i] : 0.0;
+    double kd = 0.0;
+    if (n > 3 && c->k_steps > 0) {      // mean over the last min(k_steps, KRING) steps
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        const long cnt = std::min<long>(c->k_steps, pbre_ctx::KRING);
+        int ok = 0;
+        for (long i = 0; i < cnt; i++) {
+            float t = 0.f;
+            hipEvent_t* ek = const_cast<pbre_ctx*>(c)->ev_k[(c->k_steps - 1 - i) % pbre_ctx::KRING];
+            if (hipEventElapsedTime(&t, ek[0], ek[1]) == hipSuccess) { kd += t; ok++; }
+        }
+        kd = ok ? kd / ok : 0.0;
+    }
+    for (int i = 0; i < n; i++) ms[i] = i < 3 ? c->ms[i] : (i == 3 ? kd : 0.0);
     return PBRE_OK;
 }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {

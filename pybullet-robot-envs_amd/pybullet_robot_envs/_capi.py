@@ -167,8 +167,8 @@ class Engine:
         self._chk(self.lib.pbre_settle(self._ctx, C.c_int32(n), C.c_int32(flags)))
 
     def timing(self):
-        ms = (C.c_double * 3)()
-        self._chk(self.lib.pbre_timing(self._ctx, ms, C.c_int32(3)))
+        ms = (C.c_double * 4)()
+        self._chk(self.lib.pbre_timing(self._ctx, ms, C.c_int32(4)))
         return list(ms)
 
     def kernel_info(self):
