@@ -77,7 +77,7 @@ __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n || cls[env] != 0) return;
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
     publish_class(env, c, cls, next_list, next_count, cap);
 }
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
         if (i < cur_count[b]) {
             const int env = cur_list[(size_t)b * cap + i];
             const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags);
+                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
             publish_class(env, c, cls, next_list, next_count, cap);
         }
     }
@@ -131,6 +131,11 @@ __global__ void k_target(const Params P, float* __restrict__ state, const unsign
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) CoreD::sample_target(P, ids[i], ep[i], state + (size_t)i * STATE);
 }
+// episode number of the next reset of env idx[i]: one more than the episode stored in its record (-1 = never reset)
+__global__ void k_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, int cpad, unsigned* __restrict__ ep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cpad) ep[i] = (unsigned)((int)state[(size_t)idx[i < cnt ? i : cnt - 1] * STATE + 37] + 1);
+}
 // dst[idx[i]] <- src[i], 48 floats per record
 __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,7 +163,6 @@ struct pbre_ctx {
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
     int n_simd = 1024;
-    std::vector<unsigned> episode;
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -275,8 +279,11 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->cfg.robot_table = nullptr;
     c->n = cfg->num_envs; c->npad = ceil16(c->n); c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
     c->ow = c->obs_dim + 2; c->device = cfg->device_id;
-    c->episode.assign(c->n, 0u);
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
+    if ((cfg->flags & PBRE_F_AUTO_RESET) && !lane_per_env(c)) {
+        g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel (needs the lane-per-env kernels: Panda topology, cube object, no PBRE_F_FORCE_GENERAL)";
+        delete c; return PBRE_E_UNSUPPORTED;
+    }
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -306,7 +313,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     // every record of both buffers (incl. padding and dummy records) must hold a valid state: the un-settled reset pose
     {
         const int tot = c->npad + EPB;
-        std::vector<unsigned long long> ids(tot, c->P.env_id_base); std::vector<unsigned> ep(tot, 0u);
+        std::vector<unsigned long long> ids(tot, c->P.env_id_base); std::vector<unsigned> ep(tot, 0xFFFFFFFFu);   // episode -1
         CK(hipMemcpy(c->d_ids, ids.data(), (size_t)tot * 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(c->d_ep, ep.data(), (size_t)tot * 4, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_init, dim3((tot + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->main.state, c->d_ids, c->d_ep, tot);
@@ -367,16 +374,13 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
     const int cnt = (int)idx.size();
     if (cnt > 0) {
         const int cpad = ceil16(cnt);
-        std::vector<unsigned long long> ids(cpad); std::vector<unsigned> ep(cpad);
-        for (int i = 0; i < cpad; i++) {
-            const int e = idx[i < cnt ? i : cnt - 1];
-            ids[i] = c->P.env_id_base + (unsigned long long)e;
-            ep[i] = c->episode[e];
-        }
-        for (int i = 0; i < cnt; i++) c->episode[idx[i]]++;
+        std::vector<unsigned long long> ids(cpad);
+        for (int i = 0; i < cpad; i++) ids[i] = c->P.env_id_base + (unsigned long long)idx[i < cnt ? i : cnt - 1];
         HIPCHK(hipMemcpyAsync(c->d_ids, ids.data(), (size_t)cpad * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->d_ep, ep.data(), (size_t)cpad * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_idx, idx.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
+        // episode numbers live in the state records (the device advances them on auto-reset)
+        hipLaunchKernelGGL(k_next_episode, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->main.state, c->d_idx, cnt, cpad, c->d_ep);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(c->stream));          // host vectors go out of scope below
         const bool full = cnt == c->n;
         EnvBuf& work = full ? c->main : c->tmp;           // a partial reset settles a compacted copy
@@ -396,6 +400,12 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             HIPCHK(classify(c, c->main, c->n, f0, c->stream));
         }
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (full) {   // snapshot for PBRE_F_AUTO_RESET: settled robot pose and object height (identical in every env)
+            float rec[STATE];
+            HIPCHK(hipMemcpy(rec, c->main.state, sizeof rec, hipMemcpyDeviceToHost));
+            for (int k = 0; k < NJ; k++) c->P.rst_q[k] = rec[k];
+            c->P.rst_objz = rec[11];
+        }
     }
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
@@ -405,7 +415,7 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, d_actions, d_out, c->cfg.flags & PBRE_F_NO_OBJECT, s)));
+    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, d_actions, d_out, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET), s)));
     return PBRE_OK;
 }
 
@@ -415,7 +425,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, c->d_act, c->d_out, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream)));
+    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, c->d_act, c->d_out, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET), c->stream)));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));

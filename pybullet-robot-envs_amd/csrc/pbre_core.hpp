@@ -750,7 +750,7 @@ struct Core {
         }
         st[9] = clamps(px, x_min, x_max); st[10] = clamps(py, y_min, y_max); st[11] = pz;
         st[12] = 0.f; st[13] = 0.f; st[14] = sinf(0.5f * yaw); st[15] = cosf(0.5f * yaw);
-        st[37] = (float)episode;
+        st[37] = (float)(int)episode;     // 0xFFFFFFFF marks a record that was never reset (episode -1)
     }
     // sample_tg_pose (reference panda_push_gym_env.py:333-360) on the settled object position
     static PBRE_HD void sample_target(const Params& P, unsigned long long env_id, unsigned episode, float* st) {

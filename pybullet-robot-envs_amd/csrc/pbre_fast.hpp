@@ -221,14 +221,17 @@ struct Fast {
     //   1  complex: robot contacts and/or active joint-limit rows -> step_t<true> (adds dense 9-DoF contact rows and the
     //               limit rows; needs the whole register file, launched only over the list of complex envs)
     // Both variants return the class of the state they produced.
-    static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
-        return step_t<false>(T, P, st, act, out, mode, flags);
+    static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                            unsigned long long env_id = 0) {
+        return step_t<false>(T, P, st, act, out, mode, flags, env_id);
     }
-    static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
-        return step_t<true>(T, P, st, act, out, mode, flags);
+    static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                               unsigned long long env_id = 0) {
+        return step_t<true>(T, P, st, act, out, mode, flags, env_id);
     }
     template <bool RC>
-    static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+    static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                              unsigned long long env_id) {
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
@@ -618,7 +621,7 @@ struct Fast {
         // are re-read after the solver loop instead of keeping ~130 of them live across it.
         const Tables* T2 = &T;
         PBRE_LAUNDER(T2);
-        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags);
+        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id);
     }
 
     // Class of a state (same distance arithmetic as the contact candidates of step_t<true>):
@@ -698,54 +701,107 @@ struct Fast {
         return sweep(T, P, q, nullptr, v3(st[9], st[10], st[11]), oq, flags).cls;
     }
 
-    static PBRE_HD int finish(const Tables& T, const Params& P, float* st, const float* q, const float* qd, V3 op, Q4 oq,
-                              float* out, int mode, int flags) {
-        const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
-        const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
-        const int cls = tl.cls;
-        if (!want_obs) return cls;
-        const M3 Re = tl.Re; const V3 pe = tl.pe, Va = tl.Va, Vl = tl.Vl;
-        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
-        M3 Ree = mm(Re, Eo);
-        V3 ee = add(pe, mv(Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
-        V3 vee = add(Vl, cross(Va, ee));
-        V3 eul = quat_euler(R_quat(Ree));
-        V3 oe = quat_euler(oq);
-        Q4 qh = euler_quat(eul), qo = euler_quat(oe);
-        V3 rel = mtv(quat_R(qh), sub(op, ee));
-        Q4 qhi; qhi.x = -qh.x; qhi.y = -qh.y; qhi.z = -qh.z; qhi.w = qh.w;
-        V3 er = quat_euler(qmul(qhi, qo));
-        V3 tg = v3(st[32], st[33], st[34]);
-        float reward = 0.f, done = 0.f;
-        if (mode & M_TASK) {
-            const float d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
-            const float dsucc = P.task >= 1 ? d2 : d1;
-            const bool succ = dsucc <= P.dist_min;
-            float cnt = st[35], term = st[36];
-            const float mx = (float)P.max_steps;
-            if (P.task == 2) {
-                cnt = cnt > mx ? cnt : cnt + 1.f;
-                done = (succ || cnt > mx) ? 1.f : 0.f;
-                reward = succ ? 0.f : -1.f;
-            } else {
-                const bool d0 = succ || term != 0.f || cnt > mx;
-                cnt = d0 ? cnt : cnt + 1.f;
-                term = succ ? 1.f : term;
-                done = (succ || term != 0.f || cnt > mx) ? 1.f : 0.f;
-                const float base = P.task == 1 ? -d1 - d2 : -d1;
-                reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
-            }
-            st[35] = cnt; st[36] = term;
+    // counter-based sampling shared with pbre_core.hpp / the oracle (Philox4x32-10 keyed by seed, counter = global env id,
+    // episode, stream)
+    static PBRE_HD void philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
+        for (int r = 0; r < 10; r++) {
+            unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+            unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3; k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
         }
-        if (out) {
-            int o = 0;
-            out[o++] = ee.x; out[o++] = ee.y; out[o++] = ee.z; out[o++] = eul.x; out[o++] = eul.y; out[o++] = eul.z;
-            out[o++] = vee.x / 0.04f; out[o++] = (vee.y - 0.01f) / 0.07f; out[o++] = vee.z / 0.03f;
-            PBRE_UNROLL for (int j = 0; j < ND; j++) out[o++] = q[j];
-            out[o++] = op.x; out[o++] = op.y; out[o++] = op.z; out[o++] = oe.x; out[o++] = oe.y; out[o++] = oe.z;
-            out[o++] = rel.x; out[o++] = rel.y; out[o++] = rel.z; out[o++] = er.x; out[o++] = er.y; out[o++] = er.z;
-            if (P.task >= 1) { out[o++] = tg.x; out[o++] = tg.y; out[o++] = tg.z; }
-            out[o++] = reward; out[o++] = done;
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    }
+    static PBRE_HD float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+    // Observation / reward / termination of the new state and its class.  With PBRE_F_AUTO_RESET a finished env is
+    // re-initialised right here (snapshot reset): the transition's reward and done flag are returned
+    // together with the first observation of the next episode.
+    static PBRE_HD int finish(const Tables& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
+                              float* out, int mode, int flags, unsigned long long env_id) {
+        const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
+        float reward = 0.f, done = 0.f;
+        int cls = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
+            cls = tl.cls;
+            if (!want_obs) return cls;
+            const M3 Re = tl.Re; const V3 pe = tl.pe, Va = tl.Va, Vl = tl.Vl;
+            M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
+            M3 Ree = mm(Re, Eo);
+            V3 ee = add(pe, mv(Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
+            V3 vee = add(Vl, cross(Va, ee));
+            V3 eul = quat_euler(R_quat(Ree));
+            V3 oe = quat_euler(oq);
+            Q4 qh = euler_quat(eul), qo = euler_quat(oe);
+            V3 rel = mtv(quat_R(qh), sub(op, ee));
+            Q4 qhi; qhi.x = -qh.x; qhi.y = -qh.y; qhi.z = -qh.z; qhi.w = qh.w;
+            V3 er = quat_euler(qmul(qhi, qo));
+            V3 tg = v3(st[32], st[33], st[34]);
+            if (pass == 0 && (mode & M_TASK)) {
+                const float d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
+                const float dsucc = P.task >= 1 ? d2 : d1;
+                const bool succ = dsucc <= P.dist_min;
+                float cnt = st[35], term = st[36];
+                const float mx = (float)P.max_steps;
+                if (P.task == 2) {
+                    cnt = cnt > mx ? cnt : cnt + 1.f;
+                    done = (succ || cnt > mx) ? 1.f : 0.f;
+                    reward = succ ? 0.f : -1.f;
+                } else {
+                    const bool d0 = succ || term != 0.f || cnt > mx;
+                    cnt = d0 ? cnt : cnt + 1.f;
+                    term = succ ? 1.f : term;
+                    done = (succ || term != 0.f || cnt > mx) ? 1.f : 0.f;
+                    const float base = P.task == 1 ? -d1 - d2 : -d1;
+                    reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
+                }
+                st[35] = cnt; st[36] = term;
+            }
+            const bool again = pass == 0 && (flags & 2) && (mode & M_TASK) && done != 0.f;
+            if (out && !again) {
+                int o = 0;
+                out[o++] = ee.x; out[o++] = ee.y; out[o++] = ee.z; out[o++] = eul.x; out[o++] = eul.y; out[o++] = eul.z;
+                out[o++] = vee.x / 0.04f; out[o++] = (vee.y - 0.01f) / 0.07f; out[o++] = vee.z / 0.03f;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) out[o++] = q[j];
+                out[o++] = op.x; out[o++] = op.y; out[o++] = op.z; out[o++] = oe.x; out[o++] = oe.y; out[o++] = oe.z;
+                out[o++] = rel.x; out[o++] = rel.y; out[o++] = rel.z; out[o++] = er.x; out[o++] = er.y; out[o++] = er.z;
+                if (P.task >= 1) { out[o++] = tg.x; out[o++] = tg.y; out[o++] = tg.z; }
+                out[o++] = reward; out[o++] = done;
+            }
+            if (!again) break;
+            // ---- snapshot reset: the settled state of reset_simulation (panda_push_gym_env.py:117-148) is invariant under
+            // the sampled object x, y, yaw (flat table, vertical drop), so the next episode starts from the settled robot
+            // state and object height recorded at the last full reset, with freshly sampled pose and target
+            // (WorldEnv._sample_pose, world_env.py:145-176; sample_tg_pose, panda_push_gym_env.py:333-360).
+            const unsigned ep = (unsigned)(int)st[37] + 1u;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = P.rst_q[j]; qd[j] = 0.f; st[j] = q[j]; st[16 + j] = 0.f; }
+            const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
+            const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;
+            float px = x_min + 0.5f * (x_max - x_min), py = y_min + 0.5f * (y_max - y_min), yaw = 0.78539816339744831f;
+            unsigned r[4];
+            if (P.obj_std > 0.f) {
+                philox((unsigned)env_id, (unsigned)(env_id >> 32), ep, 0u, P.seed_lo, P.seed_hi, r);
+                px += -P.obj_std + 2.f * P.obj_std * u01(r[0]);
+                py += -P.obj_std + 2.f * P.obj_std * u01(r[1]);
+                yaw = -0.78539816339744831f + 1.57079632679489662f * u01(r[2]);
+            }
+            op = v3(clampf(px, x_min, x_max), clampf(py, y_min, y_max), P.rst_objz);
+            oq.x = 0.f; oq.y = 0.f; oq.z = sinf(0.5f * yaw); oq.w = cosf(0.5f * yaw);
+            st[9] = op.x; st[10] = op.y; st[11] = op.z; st[12] = oq.x; st[13] = oq.y; st[14] = oq.z; st[15] = oq.w;
+            PBRE_UNROLL for (int k = 25; k < 31; k++) st[k] = 0.f;
+            if (P.task >= 1) {
+                const float tx_min = P.ws[0][0] + 0.07f, tx_max = P.ws[0][1] - 0.07f;
+                float tx = op.x + 0.05f, ty = op.y + 0.05f;
+                if (P.tg_std > 0.f) {
+                    philox((unsigned)env_id, (unsigned)(env_id >> 32), ep, 1u, P.seed_lo, P.seed_hi, r);
+                    const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(r[1]);
+                    const float rad = sqrtf(-2.f * logf(u1)) * P.tg_std;
+                    tx = op.x + rad * cosf(6.28318530717958648f * u2);
+                    ty = op.y + rad * sinf(6.28318530717958648f * u2);
+                }
+                st[32] = clampf(tx, tx_min, tx_max); st[33] = clampf(ty, P.ws[1][0], P.ws[1][1]); st[34] = op.z;
+            }
+            st[35] = 0.f; st[36] = 0.f; st[37] = (float)(int)ep;
         }
         return cls;
     }

@@ -71,6 +71,8 @@ inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
     P.h_table = (float)c.h_table;
     P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
     P.env_id_base = c.env_id_base;
+    for (int k = 0; k < NJ; k++) P.rst_q[k] = T.home[k];
+    P.rst_objz = (float)(c.h_table + p.obj_h[2]);      // refined from the settled state after the first full reset
     return "";
 }
 

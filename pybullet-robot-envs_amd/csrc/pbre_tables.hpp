@@ -55,6 +55,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     float obj_std, tg_std, ws[3][2], h_table;
     unsigned seed_lo, seed_hi;
     unsigned long long env_id_base;
+    float rst_q[NJ], rst_objz;    // settled robot pose / object height recorded at the last full reset (snapshot auto-reset)
 };
 
 namespace detail {

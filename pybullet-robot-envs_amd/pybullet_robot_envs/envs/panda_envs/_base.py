@@ -3,7 +3,9 @@
 Each public class keeps the reference constructor signature and Gym surface
 (reset() -> obs, step(a) -> (obs, reward, done, info), render(), seed(), observation_space,
 action_space, _robot, _world, _env_step_counter, terminated) and adds optional trailing kwargs
-`num_envs=1, device_id=0, env_id_base=0, seed=1234`.  With num_envs == 1 the return shapes are the
+`num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False` (auto_reset: a finished env is re-initialised
+inside the step that finished it -- the step returns that transition's reward/done with the first observation of the
+next episode, Isaac-Gym style -- using the snapshot reset of DESIGN.md section 5).  With num_envs == 1 the return shapes are the
 reference's ((obs_dim,) float64, 0-d reward, 0-d float32 done, {}); with num_envs = N everything is
 stacked [N, ...].  All per-step work is one fused HIP kernel behind the C-ABI (include/pbre.h)."""
 import numpy as np
@@ -21,7 +23,7 @@ class PandaTaskBase(Env):
     _TASK = _capi.TASK_PUSH
 
     def _setup(self, numControlledJoints, use_IK, action_repeat, obj_name, renders, max_steps, obj_pose_rnd_std,
-               tg_pose_rnd_std, includeVelObs, target_dist_min, num_envs, device_id, env_id_base, seed, _lib):
+               tg_pose_rnd_std, includeVelObs, target_dist_min, num_envs, device_id, env_id_base, seed, _lib, auto_reset=False):
         self._timeStep = 1. / 240.
         self.action_dim = []
         self._use_IK = use_IK
@@ -34,6 +36,7 @@ class PandaTaskBase(Env):
         self._obj_pose_rnd_std = obj_pose_rnd_std
         self.includeVelObs = includeVelObs
         self.num_envs = int(num_envs)
+        self._auto_reset = bool(auto_reset)
         if action_repeat != 1:
             raise NotImplementedError("action_repeat != 1 is not implemented by the batched engine")
 
@@ -70,7 +73,8 @@ class PandaTaskBase(Env):
         overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed,
                          num_controlled_joints=self._robot.get_action_dim(), max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
-                         target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()))
+                         target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),
+                         flags=_capi.F_AUTO_RESET if self._auto_reset else 0)
         c.engine = _capi.Engine(self._robot.robot_table, task=self._TASK, num_envs=c.num_envs, lib=c.lib, **overrides)
         for a in range(3):
             for b in range(2):

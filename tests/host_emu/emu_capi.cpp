@@ -21,17 +21,16 @@ struct pbre_ctx {
     Tables T; Params P;
     int n, obs_dim, act_dim;
     std::vector<float> state;
-    std::vector<unsigned> episode;
     std::string err;
     bool fast_ok = false;
     long n_fast = 0, n_rc = 0, n_general = 0;
 };
 // same dispatch as the device: lane-per-env fast path first, general row kernel for the envs it declines
-static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags) {
+static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0) {
     if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
         // same dispatch as the device; the class is recomputed here instead of being carried from the previous step
-        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags); }
-        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags); }
+        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags, env_id); }
+        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags, env_id); }
         return;
     }
     c->n_general++;
@@ -52,8 +51,9 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->cfg.robot_table = nullptr;
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
     c->state.assign((size_t)c->n * STATE, 0.f);
-    c->episode.assign(c->n, 0u);
+    for (int e = 0; e < c->n; e++) c->state[(size_t)e * STATE + 37] = -1.f;      // never reset
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
+    if ((cfg->flags & PBRE_F_AUTO_RESET) && (!c->fast_ok || (cfg->flags & PBRE_F_FORCE_GENERAL))) { g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel"; delete c; return PBRE_E_UNSUPPORTED; }
     *out = c;
     return PBRE_OK;
 }
@@ -75,13 +75,14 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
         float* st = &c->state[(size_t)e * STATE];
         if (!mask || mask[e]) {
             unsigned long long id = c->P.env_id_base + (unsigned long long)e;
-            unsigned ep = c->episode[e]++;
+            unsigned ep = (unsigned)((int)st[37] + 1);      // episode numbers live in the state records
             CoreH::init_state(c->T, c->P, id, ep, st);
             settle(c, e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
             settle(c, e, 101, c->cfg.flags & PBRE_F_NO_OBJECT);        // world loaded: 100 + 1 steps (:136-148)
             CoreH::sample_target(c->P, id, ep, st);
         }
     }
+    if (!mask) { for (int k = 0; k < NJ; k++) c->P.rst_q[k] = c->state[k]; c->P.rst_objz = c->state[11]; }
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -91,7 +92,8 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     const int ow = c->obs_dim + 2;
     for (int e = 0; e < c->n; e++)
         step_env(c, &c->state[(size_t)e * STATE], actions + (size_t)e * c->act_dim, out + (size_t)e * ow,
-                 CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & PBRE_F_NO_OBJECT);
+                 CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET),
+                 c->P.env_id_base + (unsigned long long)e);
     return PBRE_OK;
 }
 int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }

@@ -80,3 +80,37 @@ def contact_states(ora, panda, base, rng, n_table=8, n_obj=8):
     return np.concatenate([
         scenarios.table_contact_states(ora, panda["model"], panda["spheres"], base, n_table, rng),
         scenarios.object_contact_states(ora, panda["model"], panda["spheres"], base, n_obj, rng)])
+
+
+def check_auto_reset(Engine, lib, table, n=12, max_steps=4):
+    """PBRE_F_AUTO_RESET: when an env finishes, the same step re-initialises it (snapshot reset).  The state it lands in
+    must equal -- up to the settle transients the snapshot skips -- what an explicit masked pbre_reset produces for the
+    same episode number, and the step returns the terminal transition's reward/done with the fresh observation."""
+    F_AUTO = 2
+    kw = dict(task=1, num_envs=n, lib=lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, max_steps=max_steps)
+    auto = Engine(table, flags=F_AUTO, **kw)
+    ref = Engine(table, **kw)
+    o_a, o_r = auto.reset(), ref.reset()
+    assert np.array_equal(o_a, o_r)
+    rng = np.random.default_rng(9)
+    finished = np.zeros(n, bool)
+    for t in range(max_steps + 3):
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ob_a, rw_a, dn_a = auto.step(a)
+        ob_r, rw_r, dn_r = ref.step(a)
+        assert np.array_equal(dn_a, dn_r) and np.allclose(rw_a, rw_r, atol=1e-5)      # the transition itself is unchanged
+        d = dn_r != 0
+        assert np.allclose(ob_a[~d], ob_r[~d], atol=1e-5)
+        if d.any():
+            ref.reset(mask=d.astype(np.uint8))                                        # explicit reset of the same envs
+            sa, sr = auto.get_state(), ref.get_state()
+            assert np.array_equal(sa[d, 37], sr[d, 37]) and (sa[d, 35] == 0).all() and (sa[d, 36] == 0).all()
+            assert np.abs(sa[d][:, :16] - sr[d][:, :16]).max() < 2e-5                # same sampled pose, settled height
+            assert np.abs(sa[d][:, 16:31]).max() < 1e-6 and np.abs(sr[d][:, 16:31]).max() < 1e-3
+            assert np.abs(sa[d][:, 32:35] - sr[d][:, 32:35]).max() < 2e-5            # same sampled target
+            assert np.abs(ob_a[d] - ref.observe()[d]).max() < 1e-3                    # returned obs = first obs of the new episode
+            ref.set_state(sa)                                                         # continue from identical states
+            finished |= d
+    assert finished.all()
+    ep = auto.get_state()[:, 37]
+    assert (ep >= 1).all()

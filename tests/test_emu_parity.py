@@ -75,3 +75,20 @@ def test_masked_reset(panda, emu_lib):
     assert after[1, 35] == 0 and after[3, 35] == 0                 # counters cleared
     assert after[1, 37] == 1 and after[3, 37] == 1                 # second episode -> new object pose
     assert not np.allclose(after[1, 9:11], before[1, 9:11])
+
+
+def test_auto_reset(panda, emu_lib):
+    parity.check_auto_reset(_capi.Engine, emu_lib, panda["table"], n=6, max_steps=3)
+
+
+def test_auto_reset_env_class(emu_lib):
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    env = pandaPushGymEnv(_lib=emu_lib, num_envs=3, max_steps=2, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, auto_reset=True)
+    env.reset()
+    dones = []
+    for _ in range(8):
+        o, r, d, _ = env.step(np.zeros((3, 7)))
+        dones.append(d.copy())
+    dones = np.array(dones)
+    assert dones.sum(axis=0).min() >= 2          # every env finished (and was restarted) more than once
+    assert (env._env_step_counter <= 3).all()

@@ -155,3 +155,30 @@ def test_reference_golden_outputs(hip_lib):
             assert float(d) == G[tag + "_done"][k]
             assert int(env._env_step_counter) == G[tag + "_counter"][k]
         env.close()
+
+
+def test_auto_reset(panda, hip_lib):
+    parity.check_auto_reset(_capi.Engine, hip_lib, panda["table"], n=200, max_steps=4)
+
+
+def test_lane_per_env_kernels_match_row_kernel(panda, hip_lib):
+    """k_fast / k_fast_rc (lane-per-env) against the general 16-lane row kernel (PBRE_F_FORCE_GENERAL) on the same states,
+    including contact-rich and limit-violating ones."""
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    rng = np.random.default_rng(12)
+    S = parity.contact_states(ora, panda, base[0], rng, 40, 40).astype(np.float32)
+    S[3, 3] = 0.02; S[5, 5] = -0.12          # joint-limit rows
+    n = len(S)
+    a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    kw = dict(task=1, num_envs=n, lib=hip_lib)
+    f = _capi.Engine(panda["table"], **kw)
+    g = _capi.Engine(panda["table"], flags=_capi.F_FORCE_GENERAL, **kw)
+    f.set_state(S); g.set_state(S)
+    info = f.kernel_info()
+    assert info[2] == 1 and info[5] >= 40                      # fast path enabled, most of these states are "complex"
+    rf, rg = f.step(a), g.step(a)
+    amb = parity.ambiguous_envs(ora, S.astype(np.float64), a)
+    ok = ~amb
+    assert parity.rel(f.get_state()[ok], g.get_state()[ok].astype(np.float64)).max() < 1e-3
+    assert parity.rel(rf[0][ok], rg[0][ok].astype(np.float64)).max() < 5e-3
