@@ -123,6 +123,12 @@ int pbre_observe(pbre_ctx* ctx, float* obs_out);
  * panda_push_gym_env.py:132-133,139-140); flags: PBRE_F_NO_OBJECT or 0 */
 int pbre_settle(pbre_ctx* ctx, int32_t n, int32_t flags);
 
+/* replace the physics constants of every env of the batch (replaces p.changeDynamics in change_physics_params,
+ * R/envs/panda_envs/panda_push_gym_env.py:362-368: object mass / friction / link damping -- domain randomisation between
+ * episodes; batch-uniform).  The object must stay a cube (isotropic inertia) for the lane-per-env kernels. */
+int pbre_set_physics(pbre_ctx* ctx, const pbre_physics* phys);
+int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
+
 /* observation limits used by the Gym Box space / scale_gym_data (create_gym_spaces, :83-103) */
 int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
 

@@ -54,13 +54,21 @@ def load(path=None):
     if not os.path.exists(p):
         raise RuntimeError("libpbre.so not found at %s -- build the HIP engine first "
                            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % p)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's).  If libpbre.so
+    # pulled in the system copy first and torch loaded its bundled copy afterwards, the second runtime would find no
+    # device.  Importing torch first (when it is installed) makes libpbre.so bind to the runtime torch uses, which is also
+    # what sharing streams and device pointers with torch tensors requires.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     lib.pbre_last_error.restype = C.c_char_p
     lib.pbre_last_error.argtypes = [C.c_void_p]
     lib.pbre_destroy.restype = None
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
-                 "pbre_timing", "pbre_kernel_info"):
+                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -165,6 +173,24 @@ class Engine:
 
     def settle(self, n, flags=0):
         self._chk(self.lib.pbre_settle(self._ctx, C.c_int32(n), C.c_int32(flags)))
+
+    def get_physics(self):
+        ph = Physics()
+        self._chk(self.lib.pbre_get_physics(self._ctx, C.byref(ph)))
+        return ph
+
+    def set_physics(self, **fields):
+        """Update batch-uniform physics constants, e.g. set_physics(obj_mass=0.2, obj_mu=0.8, lin_damping=0.1)."""
+        ph = self.get_physics()
+        for k, v in fields.items():
+            if not hasattr(ph, k):
+                raise TypeError("unknown pbre_physics field %r" % k)
+            if isinstance(v, (list, tuple)):
+                for i, x in enumerate(v):
+                    getattr(ph, k)[i] = x
+            else:
+                setattr(ph, k, v)
+        self._chk(self.lib.pbre_set_physics(self._ctx, C.byref(ph)))
 
     def timing(self):
         ms = (C.c_double * 4)()

@@ -147,6 +147,28 @@ class PandaTaskBase(Env):
             return scaled_obs[0], np.array(np.float64(reward[0])), np.array(np.float32(done[0])), {}
         return scaled_obs, reward.astype(np.float64), done.astype(np.float32), {}
 
+    # ------------------------------------------------------------------ device-resident API (torch tensors, no host hop)
+    def step_tensor(self, actions):
+        """Batched step with device-resident data (replaces the DummyVecEnv hop of the reference's training scripts,
+        train_ddpg_reaching.py:96): `actions` is a CUDA float32 tensor [num_envs, act_dim] on this env's GPU; returns
+        (scaled_obs [N, obs_dim], reward [N], done [N]) CUDA float32 tensors.  Asynchronous on torch's current stream;
+        observation scaling (scale_gym_data with the float32 Box limits) runs on the device in float32."""
+        import torch
+        a = actions.contiguous()
+        assert a.is_cuda and a.dtype == torch.float32 and tuple(a.shape) == (self.num_envs, self._engine.act_dim)
+        if getattr(self, "_t_out", None) is None or self._t_out.device != a.device:
+            self._t_out = torch.empty((self.num_envs, self._engine.obs_dim + 2), device=a.device, dtype=torch.float32)
+            box = self.observation_space["observation"] if hasattr(self.observation_space, "spaces") else self.observation_space
+            self._t_low = torch.as_tensor(box.low, device=a.device)
+            self._t_inv = 1.0 / (torch.as_tensor(box.high, device=a.device) - self._t_low)
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        self._engine.step_device(a.data_ptr(), self._t_out.data_ptr(), stream or None)
+        if not stream:
+            self._engine.sync()          # the null stream maps to the engine's own stream: order it before torch ops
+        od = self._engine.obs_dim
+        obs = 2.0 * ((self._t_out[:, :od] - self._t_low) * self._t_inv) - 1.0
+        return obs, self._t_out[:, od], self._t_out[:, od + 1]
+
     def seed(self, seed=None):
         self.np_random, seed = seeding.np_random(seed)
         self._world.seed(seed)

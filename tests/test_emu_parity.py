@@ -92,3 +92,19 @@ def test_auto_reset_env_class(emu_lib):
     dones = np.array(dones)
     assert dones.sum(axis=0).min() >= 2          # every env finished (and was restarted) more than once
     assert (env._env_step_counter <= 3).all()
+
+
+def test_set_physics_matches_oracle(panda, emu_lib):
+    # change_physics_params: heavier, slipperier cube and stronger damping -> still matches the oracle with the same constants
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 4)
+    st = parity.check_reset(eng, ora, 4)
+    eng.set_physics(obj_mass=0.25, obj_mu=0.6, lin_damping=0.1, obj_inertia=[0.25 * 0.005 / 12] * 3)
+    ora.params.obj_mass = 0.25; ora.params.obj_mu = 0.6; ora.params.lin_damping = 0.1
+    for k in range(3):
+        ora.params.obj_inertia[k] = 0.25 * 0.005 / 12
+    ph = eng.get_physics()
+    assert ph.obj_mass == 0.25 and ph.obj_mu == 0.6 and ph.solver_iters == 150
+    st[:, 25:28] = [0.3, -0.2, 0.0]            # sliding cube: friction and damping matter
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(5), steps=3)
+    with pytest.raises(RuntimeError, match="isotropic"):
+        eng.set_physics(obj_inertia=[1e-4, 2e-4, 1e-4])

@@ -182,3 +182,43 @@ def test_lane_per_env_kernels_match_row_kernel(panda, hip_lib):
     ok = ~amb
     assert parity.rel(f.get_state()[ok], g.get_state()[ok].astype(np.float64)).max() < 1e-3
     assert parity.rel(rf[0][ok], rg[0][ok].astype(np.float64)).max() < 5e-3
+
+
+def test_env_classes_and_tensor_api(hip_lib):
+    import torch
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    n = 256
+    env = pandaPushGymEnv(num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    ref = pandaPushGymEnv(num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    o0 = env.reset(); ref.reset()
+    assert o0.shape == (n, 33) and o0.dtype == np.float64
+    a = np.random.default_rng(1).uniform(-1, 1, (n, 7)).astype(np.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        obs_t, rew_t, done_t = env.step_tensor(torch.as_tensor(a, device="cuda"))
+        torch.cuda.synchronize()
+    obs_h, rew_h, done_h, _ = ref.step(a)
+    assert np.abs(obs_t.cpu().numpy() - obs_h).max() < 1e-4          # float32 scaling on device vs float64 on host
+    assert np.allclose(rew_t.cpu().numpy(), rew_h, atol=1e-5) and np.array_equal(done_t.cpu().numpy(), done_h)
+    env.change_physics_params(0.2, 0.7, 0.05, 0.05)
+    assert env._engine.get_physics().obj_mass == 0.2
+    env.close(); ref.close()
+
+
+def test_config2_reach_without_object(panda, hip_lib):
+    """BASELINE config 2: Panda reach, 4096 envs, object frozen and contact-free (free-space dynamics only)."""
+    n = 4096
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], n, task=0, obj_std=0.05, tg_std=0.0, flags=_capi.F_NO_OBJECT)
+    import orc as _orc
+    ora.params.flags = _orc.F_NO_OBJECT
+    eng.reset()
+    st0 = eng.get_state()
+    sub = np.arange(0, n, 64)
+    rng = np.random.default_rng(8)
+    a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    ob, rw, dn = eng.step(a)
+    st1 = eng.get_state()
+    so, out = ora.batch_step(st0[sub].astype(np.float64), a[sub])
+    assert parity.rel(st1[sub], so).max() < parity.TOL_STATE and parity.rel(ob[sub], out[:, :-2]).max() < parity.TOL_OBS
+    assert np.array_equal(st1[:, 9:16], st0[:, 9:16])                           # the object did not move
+    assert np.abs((st1[:, :7] - st0[:, :7]) - 0.025 * a).max() < 2e-5          # K2 motor law
