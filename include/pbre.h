@@ -67,7 +67,9 @@ typedef struct {
     uint64_t env_id_base;      /* global id of local env 0: RNG streams are keyed by global id, so results do
                                   not depend on how the batch is sharded */
     uint64_t seed;
-    int32_t use_ik;            /* must be 0 (joint control, R/__init__.py:62); IK is SURVEY §8f */
+    int32_t use_ik;            /* 0: joint control (R/__init__.py:62).  1: Cartesian control through inverse kinematics with
+                                  control_orientation=1 / Euler angles (pandaEnv defaults): act_dim = 6
+                                  (dx,dy,dz,droll,dpitch,dyaw), R/envs/panda_envs/panda_push_gym_env.py:197-222 */
     int32_t num_controlled_joints;   /* 7 */
     int32_t action_repeat;     /* 1 */
     int32_t max_steps;         /* 1000 */
@@ -80,6 +82,10 @@ typedef struct {
     double  h_table;
     double  home[16];          /* initial joint positions, panda_env.py:19-23 */
     pbre_physics phys;
+    /* use_ik = 1: damped-least-squares IK (replaces p.calculateInverseKinematics, panda_env.py:269-272) */
+    double  ik_damping, ik_residual; int32_t ik_max_iters;   /* 0.1 [EXT-UNVERIFIED], 1e-3, 100 */
+    double  home_hand_pose[6];  /* panda_env.py:85-88 */
+    double  robot_ws[3][2];     /* robot workspace used to clip the hand pose (panda_env.py:37, z-min set by the task env) */
     const double* robot_table; size_t robot_table_len;   /* number of doubles */
 } pbre_config;
 

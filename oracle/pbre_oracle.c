@@ -721,6 +721,60 @@ void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
 }
 static real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 16777216.0); }
 
+
+/* ------------------------------------------------------------------ inverse kinematics
+ * PyBullet's calculateInverseKinematics(maxNumIterations=100, residualThreshold=1e-3) (panda_env.py:269-272) iterates a
+ * damped-least-squares update of the end-effector pose from the current joint angles [EXT-UNVERIFIED: Bullet's BussIK
+ * "DLS with orientation"; the damping value and the exact stopping rule are restated, not verified].  Here:
+ *   e = [p_target - p_ee ; axis-angle(R_target R_ee^T)],  dq = J^T (J J^T + lambda^2 I)^-1 e,  stop when |e_pos| < threshold.
+ * Only joints on the chain to the end effector move; the others (fingers) keep their current value.  Returns iterations. */
+static void euler_to_R(const real* e, real* R) { real q[4]; orc_quat_from_euler(e, q); quat_to_R(q, R); }
+int orc_ik(const orc_model* m, const orc_task* t, const real* q_start, const real* pos, const real* euler, real* q) {
+    const int nd = m->ndof, ee = m->ee_link;
+    real Rt[9]; euler_to_R(euler, Rt);
+    for (int k = 0; k < nd; k++) q[k] = q_start[k];
+    real R[ORC_MAXL*9], p[ORC_MAXL*3];
+    int it = 0;
+    for (; it < t->ik_max_iters; it++) {
+        orc_fk(m, q, R, p);
+        real pe[3], c[3]; m3_v(R + 9*ee, m->com[ee], c);
+        for (int k = 0; k < 3; k++) pe[k] = p[3*ee+k] + c[k];
+        real e[6];
+        for (int k = 0; k < 3; k++) e[k] = pos[k] - pe[k];
+        if (norm3(e) < (real)t->ik_residual) break;
+        /* orientation error as a world-frame rotation vector */
+        real ReT[9], Rerr[9]; m3_T(R + 9*ee, ReT); m3_mul(Rt, ReT, Rerr);
+        real sx = Rerr[7] - Rerr[5], sy = Rerr[2] - Rerr[6], sz = Rerr[3] - Rerr[1];
+        real s2 = (real)sqrt((double)(sx*sx + sy*sy + sz*sz)) * (real)0.5;          /* sin(angle) */
+        real c2 = (Rerr[0] + Rerr[4] + Rerr[8] - 1) * (real)0.5;                     /* cos(angle) */
+        real ang = (real)atan2((double)s2, (double)c2);
+        real f = s2 > (real)1e-9 ? ang / (2 * s2) : (real)0.5;
+        e[3] = f * sx; e[4] = f * sy; e[5] = f * sz;
+        /* Jacobian columns of the joints on the chain */
+        real J[6][ORC_MAXD]; memset(J, 0, sizeof J);
+        for (int i = ee; i >= 0; i = m->parent[i]) {
+            if (m->jtype[i] == 0) continue;
+            real aw[3], tt[3]; m3_v(R + 9*i, m->axis[i], aw);
+            const int d = m->dof[i];
+            if (m->jtype[i] == 1) { real rr[3] = {pe[0]-p[3*i], pe[1]-p[3*i+1], pe[2]-p[3*i+2]}; cross(aw, rr, tt); for (int k = 0; k < 3; k++) { J[k][d] = tt[k]; J[3+k][d] = aw[k]; } }
+            else for (int k = 0; k < 3; k++) J[k][d] = aw[k];
+        }
+        /* A = J J^T + lambda^2 I ; solve A y = e by Cholesky ; dq = J^T y */
+        real A[6][6], L[6][6], y[6];
+        const real l2 = (real)(t->ik_damping * t->ik_damping);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { real sum = a == b ? l2 : 0; for (int d = 0; d < nd; d++) sum += J[a][d] * J[b][d]; A[a][b] = sum; }
+        memset(L, 0, sizeof L);
+        for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
+            real sum = A[a][b]; for (int k = 0; k < b; k++) sum -= L[a][k] * L[b][k];
+            L[a][b] = a == b ? (real)sqrt((double)sum) : sum / L[b][b];
+        }
+        for (int a = 0; a < 6; a++) { real sum = e[a]; for (int k = 0; k < a; k++) sum -= L[a][k] * y[k]; y[a] = sum / L[a][a]; }
+        for (int a = 5; a >= 0; a--) { real sum = y[a]; for (int k = a + 1; k < 6; k++) sum -= L[k][a] * y[k]; y[a] = sum / L[a][a]; }
+        for (int d = 0; d < nd; d++) { real sum = 0; for (int a = 0; a < 6; a++) sum += J[a][d] * y[a]; q[d] += sum; }
+    }
+    return it;
+}
+
 /* ------------------------------------------------------------------ task layer */
 void orc_default_task(orc_task* t, int task) {
     memset(t, 0, sizeof *t);
@@ -736,6 +790,11 @@ void orc_default_task(orc_task* t, int task) {
     t->kp_act = 0.5; t->kd_act = 1.0;               /* panda_env.py:308 */
     t->kp_hold = 0.2; t->kd_hold = 1.0;             /* panda_env.py:76 */
     t->n_act = 7; t->seed = 1234;
+    t->use_ik = 0; t->ik_damping = 0.1; t->ik_residual = 1e-3; t->ik_max_iters = 100;   /* panda_env.py:269-272; damping [EXT-UNVERIFIED] */
+    const double hh[6] = {0.2, 0.0, 0.8, PI, 0.0, 0.0};                                /* panda_env.py:85-88 */
+    for (int k = 0; k < 6; k++) t->home_hand_pose[k] = hh[k];
+    t->robot_ws[0][0] = 0.3; t->robot_ws[0][1] = 0.65; t->robot_ws[1][0] = -0.3; t->robot_ws[1][1] = 0.3;   /* panda_env.py:37 */
+    t->robot_ws[2][0] = task == 0 ? 0.625 : 0.425; t->robot_ws[2][1] = 1.5;            /* z-min: panda_reach_gym_env.py:69 / panda_push_gym_env.py:74 */
 }
 int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + m->ndof + 6 + 6 + (t->task >= 1 ? 3 : 0); }
 
@@ -849,6 +908,15 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
     real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
     hold_targets(t, nd, qdes, kp, kd);
     orc_params p1 = *prm; p1.flags |= ORC_F_NO_OBJECT;
+    if (t->use_ik) {
+        /* pandaEnv.reset with use_IK (panda_env.py:83-91): apply_action(home_hand_pose) -> IK once from the joint home
+         * pose, motors (all DoF, kp 0.2) hold that solution for the whole settle; one extra stepSimulation */
+        real hp[6]; for (int k = 0; k < 6; k++) hp[k] = (real)t->home_hand_pose[k];
+        hp[2] = hp[2] < (real)t->robot_ws[2][0] ? (real)t->robot_ws[2][0] : (hp[2] > (real)t->robot_ws[2][1] ? (real)t->robot_ws[2][1] : hp[2]);
+        orc_ik(m, t, st, hp, hp + 3, qdes);
+        for (int k = 0; k < 6; k++) st[38 + k] = (real)t->home_hand_pose[k];
+        orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
+    }
     for (int i = 0; i < 100; i++) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
     for (int i = 0; i < 101; i++) orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
     /* sample_tg_pose (panda_push_gym_env.py:333-360) */
@@ -877,6 +945,15 @@ void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, 
     const int nd = m->ndof;
     real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
     hold_targets(t, nd, qdes, kp, kd);
+    if (t->use_ik) {
+        /* apply_action, IK branch (panda_push_gym_env.py:197-222, panda_env.py:229-291) */
+        real hp[6];
+        for (int k = 0; k < 3; k++) hp[k] = st[38 + k] + action[k] * (real)0.005;
+        for (int k = 3; k < 6; k++) { hp[k] = st[38 + k] + action[k] * (real)0.01; hp[k] = hp[k] < (real)-PI ? (real)-PI : (hp[k] > (real)PI ? (real)PI : hp[k]); }
+        for (int k = 0; k < 3; k++) hp[k] = hp[k] < (real)t->robot_ws[k][0] ? (real)t->robot_ws[k][0] : (hp[k] > (real)t->robot_ws[k][1] ? (real)t->robot_ws[k][1] : hp[k]);
+        for (int k = 0; k < 6; k++) st[38 + k] = hp[k];
+        orc_ik(m, t, st, hp, hp + 3, qdes);
+    } else
     for (int k = 0; k < t->n_act; k++) {
         int li = m->link_of_dof[k];
         real tgt = st[k] + action[k] * (real)t->act_scale;                 /* :225-230 */

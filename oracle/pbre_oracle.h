@@ -104,8 +104,12 @@ typedef struct {
     double home[ORC_MAXD];
     double act_scale;        /* 0.05 */
     double kp_act, kd_act, kp_hold, kd_hold;
-    int n_act;               /* controlled joints (7) */
+    int n_act;               /* controlled joints (7); 6 in IK mode (dx,dy,dz,droll,dpitch,dyaw) */
     uint64_t seed;
+    int use_ik;              /* 1: Cartesian control through inverse kinematics (use_IK=1) */
+    double ik_damping, ik_residual; int ik_max_iters;
+    double home_hand_pose[6];
+    double robot_ws[3][2];   /* robot workspace used to clip the hand pose */
 } orc_task;
 
 void orc_default_task(orc_task* t, int task);
@@ -123,6 +127,8 @@ void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* 
 void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
                     const real* actions, real* out /*[n][obs_dim+2]*/);
 
+/* damped-least-squares IK of the end effector (restates p.calculateInverseKinematics call sites panda_env.py:269-272) */
+int  orc_ik(const orc_model* m, const orc_task* t, const real* q_start, const real* pos, const real* euler, real* q_out);
 /* counter-based RNG shared (by specification) with the device path */
 void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
 /* Bullet pure-math helpers used by the observation code */

@@ -41,6 +41,8 @@ constexpr int FTPB = 64;             // lane-per-env kernels: one wave per block
 #define PBRE_FAST_WAVES 2            // waves per SIMD k_fast is register-limited to (A/B on MI355X: 1 -> 404, 2 -> 495, 3 -> 325 M env-steps/s)
 #endif
 constexpr int MODE_STEP = CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK;
+constexpr int MODE_STEP_IK = CoreD::M_TGT | CoreD::M_OBS | CoreD::M_TASK;      // use_IK = 1: targets from k_ik
+constexpr int MODE_SETTLE_IK = CoreD::M_TGT;
 
 // ------------------------------------------------------------------ kernels
 // General row kernel.  n = real env count; state has ceil16(n) + 16 records (the last 16 are valid dummy records for the
@@ -48,7 +50,8 @@ constexpr int MODE_STEP = CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK;
 template <int MODE>
 __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                               const float* __restrict__ actions, float* __restrict__ out,
-                                              float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags) {
+                                              float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags,
+                                              const float* __restrict__ tgt) {
     const int row = threadIdx.x >> 4;
     const int i = blockIdx.x * EPB + row;
     const bool real = i < n;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     float* o = nullptr;
     if (MODE & CoreD::M_ACTION) a = actions + (size_t)(real ? env : 0) * act_dim;
     if (MODE & CoreD::M_OBS) o = real ? out + (size_t)env * ow : scratch_row;
-    CoreD::step(*T, P, st, a, o, MODE, flags);
+    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
 }
 
 // Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
@@ -73,11 +76,13 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 template <int MODE>
 __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
+                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                               const float* __restrict__ tgt) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n || cls[env] != 0) return;
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
+                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
     publish_class(env, c, cls, next_list, next_count, cap);
 }
 
@@ -88,7 +93,8 @@ template <int MODE>
 __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                                  const float* __restrict__ tgt) {
     int chunks[NB], total = 0;
     PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; }
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -98,10 +104,20 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
         if (i < cur_count[b]) {
             const int env = cur_list[(size_t)b * cap + i];
             const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
+                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                                         (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
             publish_class(env, c, cls, next_list, next_count, cap);
         }
     }
+}
+
+// use_IK = 1: hand-pose update + inverse kinematics -> joint targets (one thread per env).  RESET: targets of the home hand pose.
+template <bool RESET>
+__global__ __launch_bounds__(FTPB) void k_ik(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                             const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
+    const int env = blockIdx.x * FTPB + threadIdx.x;
+    if (env >= n) return;
+    FastD::ik_targets(*T, P, state + (size_t)env * STATE, RESET ? nullptr : actions + (size_t)env * act_dim, tgt + (size_t)env * NJ, RESET);
 }
 
 // Class of every env's current state (after reset / set_state / a change of the NO_OBJECT flag).
@@ -147,6 +163,7 @@ __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src
 struct EnvBuf {                       // a batch of state records with its class bookkeeping
     float* state = nullptr;           // cap + 16 records
     signed char* cls = nullptr;       // class per env
+    float* tgt = nullptr;             // [cap + 16][NJ] joint targets of the IK mode
     int* list[2] = {nullptr, nullptr};  // each [NB][cap]
     int* count = nullptr;             // [2][NB]
     int cur = 0;                      // list[cur] / count + cur*NB: complex envs of the current state, per class
@@ -191,13 +208,15 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     hipError_t e;
     if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMalloc(&b.cls, (size_t)cap)) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.tgt, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMemset(b.tgt, 0, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.cls, 0, (size_t)cap)) != hipSuccess) return e;
     for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc(&b.count, 2 * NB * sizeof(int))) != hipSuccess) return e;
     return hipMemset(b.count, 0, 2 * NB * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
-    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
 }
 
 // (re)build class array and current list of the first n envs of b
@@ -216,7 +235,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
         (void)hipEventRecord(ek[0], s);
         hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
-                           c->act_dim, c->ow, flags);
+                           c->act_dim, c->ow, flags, b.tgt);
         (void)hipEventRecord(ek[1], s);
         c->k_steps++;
         return hipGetLastError();
@@ -230,12 +249,12 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
-                       b.list[cur], b.count + cur * NB, b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
+                       b.list[cur], b.count + cur * NB, b.cls, b.list[nxt], b.count + nxt * NB, b.cap, b.tgt);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
     (void)hipEventRecord(ek[0], c->side);
     hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                       b.cls, b.list[nxt], b.count + nxt * NB, b.cap);
+                       b.cls, b.list[nxt], b.count + nxt * NB, b.cap, b.tgt);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     (void)hipEventRecord(ek[1], c->side);
     c->k_steps++;
@@ -243,6 +262,23 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
     b.cur = nxt;
     return hipSuccess;
+}
+
+// settle steps (hold motors; IK mode: hold the IK targets)
+static hipError_t settle_steps(pbre_ctx* c, EnvBuf& b, int n, int count, int flags, hipStream_t s) {
+    for (int i = 0; i < count; i++) {
+        hipError_t e = c->P.use_ik ? launch_step<MODE_SETTLE_IK>(c, b, n, nullptr, nullptr, flags, s) : launch_step<0>(c, b, n, nullptr, nullptr, flags, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+static hipError_t full_step(pbre_ctx* c, const float* d_act, float* d_out, hipStream_t s) {
+    const int flags = c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
+    if (!c->P.use_ik) return launch_step<MODE_STEP>(c, c->main, c->n, d_act, d_out, flags, s);
+    hipLaunchKernelGGL(k_ik<false>, dim3((c->n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, c->main.state, d_act, c->main.tgt, c->n, c->act_dim);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_step<MODE_STEP_IK>(c, c->main, c->n, nullptr, d_out, flags, s);
 }
 
 extern "C" {
@@ -277,7 +313,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
         return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG);
     }
     c->cfg.robot_table = nullptr;
-    c->n = cfg->num_envs; c->npad = ceil16(c->n); c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
+    c->n = cfg->num_envs; c->npad = ceil16(c->n); c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg);
     c->ow = c->obs_dim + 2; c->device = cfg->device_id;
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     if ((cfg->flags & PBRE_F_AUTO_RESET) && !lane_per_env(c)) {
@@ -360,7 +396,7 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     HIPCHK(hipSetDevice(c->device));
     const int f = flags & PBRE_F_NO_OBJECT, f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
     if (f != f0) HIPCHK(classify(c, c->main, c->n, f, c->stream));           // classes depend on whether the object is present
-    for (int i = 0; i < n; i++) HIPCHK(launch_step<0>(c, c->main, c->n, nullptr, nullptr, f, c->stream));
+    HIPCHK(settle_steps(c, c->main, c->n, n, f, c->stream));
     if (f != f0) HIPCHK(classify(c, c->main, c->n, f0, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PBRE_OK;
@@ -389,9 +425,14 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
         HIPCHK(hipGetLastError());
         // reset_simulation (panda_push_gym_env.py:117-148): 100 steps robot alone, then world loaded: 100 + 1 steps
         HIPCHK(classify(c, work, cnt, PBRE_F_NO_OBJECT, c->stream));
-        for (int i = 0; i < 100; i++) HIPCHK(launch_step<0>(c, work, cnt, nullptr, nullptr, PBRE_F_NO_OBJECT, c->stream));
+        if (c->P.use_ik) {     // pandaEnv.reset with use_IK (panda_env.py:83-91): IK targets of the home hand pose + one step
+            hipLaunchKernelGGL(k_ik<true>, dim3((cnt + FTPB - 1) / FTPB), dim3(FTPB), 0, c->stream, c->dT, c->P, work.state, (const float*)nullptr, work.tgt, cnt, c->act_dim);
+            HIPCHK(hipGetLastError());
+            HIPCHK(settle_steps(c, work, cnt, 1, PBRE_F_NO_OBJECT, c->stream));
+        }
+        HIPCHK(settle_steps(c, work, cnt, 100, PBRE_F_NO_OBJECT, c->stream));
         if (!f0) HIPCHK(classify(c, work, cnt, 0, c->stream));
-        for (int i = 0; i < 101; i++) HIPCHK(launch_step<0>(c, work, cnt, nullptr, nullptr, f0, c->stream));
+        HIPCHK(settle_steps(c, work, cnt, 101, f0, c->stream));
         hipLaunchKernelGGL(k_target, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->P, work.state, c->d_ids, c->d_ep, cpad);
         HIPCHK(hipGetLastError());
         if (!full) {
@@ -415,7 +456,7 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, d_actions, d_out, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET), s)));
+    HIPCHK(full_step(c, d_actions, d_out, s));
     return PBRE_OK;
 }
 
@@ -425,7 +466,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    HIPCHK((launch_step<MODE_STEP>(c, c->main, c->n, c->d_act, c->d_out, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET), c->stream)));
+    HIPCHK(full_step(c, c->d_act, c->d_out, c->stream));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));

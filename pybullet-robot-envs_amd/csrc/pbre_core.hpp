@@ -278,7 +278,7 @@ struct Core {
 
     // ---------------------------------------------------------------- the step
     // mode bits
-    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4 };
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8 };
 
     struct Rows {             // register-resident solver data
         F Mi[NJ];             // row of M^-1 (lane k: Minv[k][j])
@@ -309,7 +309,8 @@ struct Core {
 
     // One simulation step for one env group.  st: pointer to the env's 48-float record.
     // act: pointer to this env's action row or nullptr.  out: this env's [obs_dim+2] row or nullptr.
-    static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags) {
+    static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                             const float* tgt = nullptr) {
         const I lane = L::lane();
         const F zero = L::c(0.f), one = L::c(1.f);
         const B robot = L::lti(lane, NJ);
@@ -325,6 +326,7 @@ struct Core {
         // ---- motor targets (apply_action): q_des = clip(q + 0.05 a, ll, ul) for actuated lanes, else hold at home
         F lower = L::load(T.lower), upper = L::load(T.upper);
         F qdes = L::load(T.home), kp = L::load(T.kp_hold), kd = L::load(T.kd_hold);
+        if (mode & M_TGT) qdes = L::loadm(tgt, robot);     // IK mode: targets from the IK buffer, hold gains
         if (mode & M_ACTION) {
             B al = L::lti(lane, T.n_act);
             F a = L::loadm(act, al);

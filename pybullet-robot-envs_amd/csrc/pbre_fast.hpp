@@ -185,7 +185,7 @@ struct Fast {
         return len < 1e-9f ? -best - sr : len - sr;
     }
 
-    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4 };
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8 };   // M_TGT: motor targets come from the IK target buffer
 
     // full sphere-vs-box test: signed distance, world normal box->sphere, point on the box
     static PBRE_HD float sphere_box(V3 sc, float sr, V3 bc, const M3& Rb, V3 h, V3& n, V3& pb) {
@@ -222,16 +222,16 @@ struct Fast {
     //               limit rows; needs the whole register file, launched only over the list of complex envs)
     // Both variants return the class of the state they produced.
     static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                            unsigned long long env_id = 0) {
-        return step_t<false>(T, P, st, act, out, mode, flags, env_id);
+                            unsigned long long env_id = 0, const float* tgt = nullptr) {
+        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
     static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                               unsigned long long env_id = 0) {
-        return step_t<true>(T, P, st, act, out, mode, flags, env_id);
+                               unsigned long long env_id = 0, const float* tgt = nullptr) {
+        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
     template <bool RC>
     static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                              unsigned long long env_id) {
+                              unsigned long long env_id, const float* tgt) {
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
@@ -371,6 +371,7 @@ struct Fast {
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
             w[j] = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
             float qdes = T.home[j], kp = T.kp_hold[j], kd = T.kd_hold[j];
+            if (mode & M_TGT) qdes = tgt[j];          // IK mode: all joints track the IK solution with the hold gains (panda_env.py:276-282)
             if (mode & M_ACTION) {
                 kp = T.kp_act[j]; kd = T.kd_act[j];
                 if (j < T.n_act) qdes = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
@@ -701,6 +702,106 @@ struct Fast {
         return sweep(T, P, q, nullptr, v3(st[9], st[10], st[11]), oq, flags).cls;
     }
 
+    // ---------------------------------------------------------------- inverse kinematics (use_IK = 1)
+    // Damped-least-squares IK of the end effector from the current joint angles (replaces p.calculateInverseKinematics,
+    // reference panda_env.py:269-272: maxNumIterations=100, residualThreshold=1e-3); same algorithm as oracle/orc_ik:
+    // e = [p_t - p_ee ; rotvec(R_t R_ee^T)], dq = J^T (J J^T + lambda^2 I)^-1 e on the joints of the EE chain, until |e_pos| < res.
+    static PBRE_HD void ik_solve(const Tables& T, const Params& P, const float* q0, V3 pos, V3 eul, float* q) {
+        const M3 Rt = quat_R(euler_quat(eul));
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = q0[j];
+        const int eo = T.ee_owner;
+        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
+        bool done = false;
+        for (int it = 0; it < P.ik_iters; it++) {
+            if (!PBRE_ANY(!done)) break;
+            M3 R[ND]; V3 p[ND], aw[ND];
+            M3 Re = Eo; V3 po = v3(0.f, 0.f, 0.f);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+                V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
+                M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
+                V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
+                M3 Rl; V3 pl;
+                if (Topo::jtype(j) == 1) {
+                    float c = cosf(q[j]), sn = sinf(q[j]), C = 1.f - c;
+                    M3 Rj;
+                    Rj.m[0] = c + ax.x*ax.x*C;       Rj.m[1] = ax.x*ax.y*C - ax.z*sn; Rj.m[2] = ax.x*ax.z*C + ax.y*sn;
+                    Rj.m[3] = ax.y*ax.x*C + ax.z*sn; Rj.m[4] = c + ax.y*ax.y*C;       Rj.m[5] = ax.y*ax.z*C - ax.x*sn;
+                    Rj.m[6] = ax.z*ax.x*C - ax.y*sn; Rj.m[7] = ax.z*ax.y*C + ax.x*sn; Rj.m[8] = c + ax.z*ax.z*C;
+                    Rl = mm(R0, Rj); pl = p0;
+                } else {
+                    Rl = R0; V3 d = mv(R0, ax); pl = v3(fmaf(d.x, q[j], p0.x), fmaf(d.y, q[j], p0.y), fmaf(d.z, q[j], p0.z));
+                }
+                if (Topo::parent(j) < 0) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+                aw[j] = mv(R[j], ax);
+                if (eo == j) { Re = R[j]; po = p[j]; }
+            }
+            const V3 pe = add(po, mv(Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
+            const M3 Ree = mm(Re, Eo);
+            float e[6];
+            e[0] = pos.x - pe.x; e[1] = pos.y - pe.y; e[2] = pos.z - pe.z;
+            done = done || sqrtf(e[0]*e[0] + e[1]*e[1] + e[2]*e[2]) < P.ik_res;
+            // rotation vector of R_t R_ee^T
+            M3 Rerr;
+            PBRE_UNROLL for (int a = 0; a < 3; a++)
+                PBRE_UNROLL for (int b = 0; b < 3; b++)
+                    Rerr.m[a*3+b] = fmaf(Rt.m[a*3], Ree.m[b*3], fmaf(Rt.m[a*3+1], Ree.m[b*3+1], Rt.m[a*3+2] * Ree.m[b*3+2]));
+            const float sx = Rerr.m[7] - Rerr.m[5], sy = Rerr.m[2] - Rerr.m[6], sz = Rerr.m[3] - Rerr.m[1];
+            const float s2 = 0.5f * sqrtf(sx*sx + sy*sy + sz*sz), c2 = 0.5f * (Rerr.m[0] + Rerr.m[4] + Rerr.m[8] - 1.f);
+            const float f = s2 > 1e-9f ? atan2f(s2, c2) / (2.f * s2) : 0.5f;
+            e[3] = f * sx; e[4] = f * sy; e[5] = f * sz;
+            // Jacobian columns (joints on the EE chain), A = J J^T + lambda^2 I
+            float J[6][ND];
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                bool anc = false;
+                PBRE_UNROLL for (int k = 0; k < ND; k++) if (Topo::is_anc(j, k) && eo == k) anc = true;
+                V3 jl, ja;
+                if (Topo::jtype(j) == 1) { jl = cross(aw[j], sub(pe, p[j])); ja = aw[j]; } else { jl = aw[j]; ja = v3(0.f, 0.f, 0.f); }
+                J[0][j] = anc ? jl.x : 0.f; J[1][j] = anc ? jl.y : 0.f; J[2][j] = anc ? jl.z : 0.f;
+                J[3][j] = anc ? ja.x : 0.f; J[4][j] = anc ? ja.y : 0.f; J[5][j] = anc ? ja.z : 0.f;
+            }
+            float A[6][6];
+            PBRE_UNROLL for (int a = 0; a < 6; a++)
+                PBRE_UNROLL for (int b = 0; b <= a; b++) {
+                    float sum = a == b ? P.ik_l2 : 0.f;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) sum = fmaf(J[a][j], J[b][j], sum);
+                    A[a][b] = sum;
+                }
+            // in-place Cholesky (lower), forward/back substitution
+            float y[6];
+            PBRE_UNROLL for (int a = 0; a < 6; a++)
+                PBRE_UNROLL for (int b = 0; b <= a; b++) {
+                    float sum = A[a][b];
+                    PBRE_UNROLL for (int k = 0; k < b; k++) sum = fmaf(-A[a][k], A[b][k], sum);
+                    A[a][b] = a == b ? sqrtf(sum) : sum / A[b][b];
+                }
+            PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum / A[a][a]; }
+            PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum / A[a][a]; }
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                float dq = 0.f;
+                PBRE_UNROLL for (int a = 0; a < 6; a++) dq = fmaf(J[a][j], y[a], dq);
+                q[j] = done ? q[j] : q[j] + dq;
+            }
+        }
+    }
+    // apply_action, IK branch (panda_push_gym_env.py:197-222 + panda_env.py:229-291): accumulate the scaled Cartesian action into
+    // the hand pose, clip it to the rotation limits and the robot workspace, solve IK, store the joint targets.
+    // reset = true: pandaEnv.reset with use_IK (panda_env.py:83-91): targets of the home hand pose.
+    static PBRE_HD void ik_targets(const Tables& T, const Params& P, float* st, const float* act, float* tgt, bool reset) {
+        float hp[6];
+        const float PI_ = 3.14159265358979323846f;
+        if (reset) { PBRE_UNROLL for (int k = 0; k < 6; k++) hp[k] = P.home_hand[k]; }
+        else {
+            PBRE_UNROLL for (int k = 0; k < 3; k++) hp[k] = clampf(fmaf(act[k], 0.005f, st[38 + k]), P.rws[k][0], P.rws[k][1]);
+            PBRE_UNROLL for (int k = 3; k < 6; k++) hp[k] = clampf(fmaf(act[k], 0.01f, st[38 + k]), -PI_, PI_);
+        }
+        PBRE_UNROLL for (int k = 0; k < 6; k++) st[38 + k] = hp[k];
+        float q0[ND], q[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q0[j] = st[j];
+        ik_solve(T, P, q0, v3(hp[0], hp[1], clampf(hp[2], P.rws[2][0], P.rws[2][1])), v3(hp[3], hp[4], hp[5]), q);
+        PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = q[j];
+    }
+
     // counter-based sampling shared with pbre_core.hpp / the oracle (Philox4x32-10 keyed by seed, counter = global env id,
     // episode, stream)
     static PBRE_HD void philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned o[4]) {
@@ -802,6 +903,7 @@ struct Fast {
                 st[32] = clampf(tx, tx_min, tx_max); st[33] = clampf(ty, P.ws[1][0], P.ws[1][1]); st[34] = op.z;
             }
             st[35] = 0.f; st[36] = 0.f; st[37] = (float)(int)ep;
+            if (P.use_ik) { PBRE_UNROLL for (int k = 0; k < 6; k++) st[38 + k] = P.home_hand[k]; }
         }
         return cls;
     }

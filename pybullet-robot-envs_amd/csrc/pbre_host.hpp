@@ -44,14 +44,19 @@ inline int default_config(pbre_config* c, int robot, int task) {
     const double home[9] = {0.0, -0.54, 0.0, -2.6, -0.30, 2.0, 1.0, 0.02, 0.02};   // panda_env.py:19-23
     for (int k = 0; k < 9; k++) c->home[k] = home[k];
     default_physics(c->phys);
+    c->ik_damping = 0.1; c->ik_residual = 1e-3; c->ik_max_iters = 100;              // panda_env.py:269-272
+    const double hh[6] = {0.2, 0.0, 0.8, 3.14159265358979323846, 0.0, 0.0};        // panda_env.py:85-88
+    for (int k = 0; k < 6; k++) c->home_hand_pose[k] = hh[k];
+    c->robot_ws[0][0] = 0.3; c->robot_ws[0][1] = 0.65; c->robot_ws[1][0] = -0.3; c->robot_ws[1][1] = 0.3;   // panda_env.py:37
+    c->robot_ws[2][0] = task == PBRE_TASK_REACH ? c->h_table : c->h_table - 0.2; c->robot_ws[2][1] = 1.5;   // panda_reach_gym_env.py:69 / panda_push_gym_env.py:74
     return PBRE_OK;
 }
 
 inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
     if (c.num_envs <= 0) return "num_envs must be positive";
-    if (c.use_ik) return "use_IK=1 is not implemented by this engine (joint control only, SURVEY 8f)";
     if (c.action_repeat != 1) return "action_repeat != 1 is not implemented";
     if (c.num_controlled_joints < 1 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
+    if (c.use_ik && (c.ik_max_iters <= 0 || c.ik_damping <= 0)) return "bad IK parameters";
     const double gains[4] = {c.kp_act, c.kd_act, c.kp_hold, c.kd_hold};
     std::string e = build_tables(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, T);
     if (!e.empty()) return e;
@@ -71,11 +76,15 @@ inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
     P.h_table = (float)c.h_table;
     P.seed_lo = (unsigned)c.seed; P.seed_hi = (unsigned)(c.seed >> 32);
     P.env_id_base = c.env_id_base;
+    P.use_ik = c.use_ik ? 1 : 0; P.ik_iters = c.ik_max_iters; P.ik_l2 = (float)(c.ik_damping * c.ik_damping); P.ik_res = (float)c.ik_residual;
+    for (int k = 0; k < 6; k++) P.home_hand[k] = (float)c.home_hand_pose[k];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 2; b++) P.rws[a][b] = (float)c.robot_ws[a][b];
     for (int k = 0; k < NJ; k++) P.rst_q[k] = T.home[k];
     P.rst_objz = (float)(c.h_table + p.obj_h[2]);      // refined from the settled state after the first full reset
     return "";
 }
 
+inline int act_dim_of(const pbre_config& c) { return c.use_ik ? 6 : c.num_controlled_joints; }
 inline int obs_dim_of(const Tables& T, const Params& P) { return 9 + T.ndof + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0); }
 
 // Observation limits exactly as the reference assembles them (panda_env.py:141-193 limits list,

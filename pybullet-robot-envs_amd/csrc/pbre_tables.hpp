@@ -56,6 +56,8 @@ struct Params {                  // float copies of pbre_physics + task constant
     unsigned seed_lo, seed_hi;
     unsigned long long env_id_base;
     float rst_q[NJ], rst_objz;    // settled robot pose / object height recorded at the last full reset (snapshot auto-reset)
+    int   use_ik, ik_iters;       // Cartesian control (use_IK=1): damped-least-squares IK
+    float ik_l2, ik_res, home_hand[6], rws[3][2];   // lambda^2, position residual, home hand pose, robot workspace
 };
 
 namespace detail {

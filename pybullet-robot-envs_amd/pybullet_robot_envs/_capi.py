@@ -39,6 +39,8 @@ class Config(C.Structure):
                 ("kp_act", C.c_double), ("kd_act", C.c_double), ("kp_hold", C.c_double), ("kd_hold", C.c_double),
                 ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 16),
                 ("phys", Physics),
+                ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("ik_max_iters", C.c_int32),
+                ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
                 ("robot_table", C.c_void_p), ("robot_table_len", C.c_size_t)]
 
 

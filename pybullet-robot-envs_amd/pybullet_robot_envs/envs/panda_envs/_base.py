@@ -71,14 +71,17 @@ class PandaTaskBase(Env):
         ws = self._world.get_workspace()
         cfg = _capi.Config()
         overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed,
-                         num_controlled_joints=self._robot.get_action_dim(), max_steps=int(self._max_steps),
+                         num_controlled_joints=self._robot.joint_action_space, max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
                          target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),
-                         flags=_capi.F_AUTO_RESET if self._auto_reset else 0)
+                         flags=_capi.F_AUTO_RESET if self._auto_reset else 0, use_ik=1 if self._use_IK else 0)
         c.engine = _capi.Engine(self._robot.robot_table, task=self._TASK, num_envs=c.num_envs, lib=c.lib, **overrides)
+        rws = self._robot.get_workspace()
         for a in range(3):
             for b in range(2):
                 assert abs(c.engine.cfg.ws_lim[a][b] - ws[a][b]) < 1e-12, "workspace differs from the engine default"
+                assert abs(c.engine.cfg.robot_ws[a][b] - rws[a][b]) < 1e-12, "robot workspace differs from the engine default"
+        assert c.engine.act_dim == self._robot.get_action_dim()
         self._engine = c.engine
 
     def close(self):
@@ -188,6 +191,11 @@ class PandaTaskBase(Env):
     @property
     def terminated(self):
         return self._squeeze(self._engine.get_state()[:, 36].astype(np.int64))
+
+    @property
+    def _hand_pose(self):
+        """Commanded hand pose (x, y, z, roll, pitch, yaw) of the IK mode (panda_push_gym_env.py:142-143, 197-222)."""
+        return self._squeeze(self._engine.get_state()[:, 38:44].astype(np.float64))
 
     @property
     def _target_pose(self):

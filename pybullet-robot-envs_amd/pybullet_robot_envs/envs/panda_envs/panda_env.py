@@ -45,9 +45,8 @@ class pandaEnv:
         self._joint_name_to_ids = {}
         self.robot_id = 0
 
-        if use_IK:
-            raise NotImplementedError("use_IK=1 (Cartesian control through inverse kinematics) is not implemented by "
-                                      "the batched engine yet; the Panda ids are registered with use_IK=0")
+        if use_IK and not control_orientation:
+            raise NotImplementedError("use_IK=1 with control_orientation=0 is not implemented (the task envs use the default 1)")
         if control_eu_or_quat != 0:
             raise NotImplementedError("control_eu_or_quat=1 (quaternion observations) is not implemented")
         if not includeVelObs:
@@ -65,6 +64,13 @@ class pandaEnv:
                 assert link["joint_name"] in self.initial_positions.keys()
                 self._joint_name_to_ids[link["joint_name"]] = i
         self.ll, self.ul, self.jr, self.rs = self.get_joint_ranges()
+
+        if self._use_IK:
+            # panda_env.py:83-91; the IK solve + first stepSimulation happen inside the engine's reset (pbre_reset)
+            self._home_hand_pose = [0.2, 0.0, 0.8,
+                                    min(m.pi, max(-m.pi, m.pi)),
+                                    min(m.pi, max(-m.pi, 0)),
+                                    min(m.pi, max(-m.pi, 0))]
 
     def get_joint_ranges(self):
         lower_limits, upper_limits, joint_ranges, rest_poses = [], [], [], []

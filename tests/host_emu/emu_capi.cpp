@@ -20,21 +20,21 @@ struct pbre_ctx {
     pbre_config cfg;
     Tables T; Params P;
     int n, obs_dim, act_dim;
-    std::vector<float> state;
+    std::vector<float> state, tgt;
     std::string err;
     bool fast_ok = false;
     long n_fast = 0, n_rc = 0, n_general = 0;
 };
 // same dispatch as the device: lane-per-env fast path first, general row kernel for the envs it declines
-static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0) {
+static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tgt = nullptr) {
     if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
         // same dispatch as the device; the class is recomputed here instead of being carried from the previous step
-        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags, env_id); }
-        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags, env_id); }
+        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags, env_id, tgt); }
+        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags, env_id, tgt); }
         return;
     }
     c->n_general++;
-    CoreH::step(c->T, c->P, st, act, out, mode, flags);
+    CoreH::step(c->T, c->P, st, act, out, mode, flags, tgt);
 }
 static std::string g_err;
 
@@ -49,8 +49,9 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     std::string e = make_tables(*cfg, c->T, c->P);
     if (!e.empty()) { g_err = e; delete c; return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG); }
     c->cfg.robot_table = nullptr;
-    c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = cfg->num_controlled_joints;
+    c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg);
     c->state.assign((size_t)c->n * STATE, 0.f);
+    c->tgt.assign((size_t)c->n * NJ, 0.f);
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * STATE + 37] = -1.f;      // never reset
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     if ((cfg->flags & PBRE_F_AUTO_RESET) && (!c->fast_ok || (cfg->flags & PBRE_F_FORCE_GENERAL))) { g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel"; delete c; return PBRE_E_UNSUPPORTED; }
@@ -66,7 +67,8 @@ int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
 }
 
 static void settle(pbre_ctx* c, int e, int n, int flags) {
-    for (int i = 0; i < n; i++) step_env(c, &c->state[(size_t)e * STATE], nullptr, nullptr, 0, flags);
+    const int mode = c->P.use_ik ? CoreH::M_TGT : 0;
+    for (int i = 0; i < n; i++) step_env(c, &c->state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &c->tgt[(size_t)e * NJ]);
 }
 
 int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
@@ -77,6 +79,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             unsigned long long id = c->P.env_id_base + (unsigned long long)e;
             unsigned ep = (unsigned)((int)st[37] + 1);      // episode numbers live in the state records
             CoreH::init_state(c->T, c->P, id, ep, st);
+            if (c->P.use_ik) { FastH::ik_targets(c->T, c->P, st, nullptr, &c->tgt[(size_t)e * NJ], true); settle(c, e, 1, PBRE_F_NO_OBJECT); }
             settle(c, e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
             settle(c, e, 101, c->cfg.flags & PBRE_F_NO_OBJECT);        // world loaded: 100 + 1 steps (:136-148)
             CoreH::sample_target(c->P, id, ep, st);
@@ -90,10 +93,16 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
 int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
     const int ow = c->obs_dim + 2;
-    for (int e = 0; e < c->n; e++)
-        step_env(c, &c->state[(size_t)e * STATE], actions + (size_t)e * c->act_dim, out + (size_t)e * ow,
-                 CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET),
-                 c->P.env_id_base + (unsigned long long)e);
+    for (int e = 0; e < c->n; e++) {
+        float* st = &c->state[(size_t)e * STATE];
+        const int fl = c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
+        if (c->P.use_ik) {
+            FastH::ik_targets(c->T, c->P, st, actions + (size_t)e * c->act_dim, &c->tgt[(size_t)e * NJ], false);
+            step_env(c, st, nullptr, out + (size_t)e * ow, CoreH::M_TGT | CoreH::M_OBS | CoreH::M_TASK, fl, c->P.env_id_base + (unsigned long long)e, &c->tgt[(size_t)e * NJ]);
+        } else
+            step_env(c, st, actions + (size_t)e * c->act_dim, out + (size_t)e * ow, CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, fl,
+                     c->P.env_id_base + (unsigned long long)e);
+    }
     return PBRE_OK;
 }
 int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }

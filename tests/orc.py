@@ -49,7 +49,9 @@ class Task(C.Structure):
                 ("obj_pose_rnd_std", C.c_double), ("tg_pose_rnd_std", C.c_double),
                 ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * MAXD),
                 ("act_scale", C.c_double), ("kp_act", C.c_double), ("kd_act", C.c_double),
-                ("kp_hold", C.c_double), ("kd_hold", C.c_double), ("n_act", C.c_int), ("seed", C.c_uint64)]
+                ("kp_hold", C.c_double), ("kd_hold", C.c_double), ("n_act", C.c_int), ("seed", C.c_uint64),
+                ("use_ik", C.c_int), ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("ik_max_iters", C.c_int),
+                ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3)]
 
 
 F_NO_OBJECT = 1
@@ -141,6 +143,17 @@ class Oracle:
         self.lib.orc_batch_reset(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_int(n),
                                  C.c_uint64(env_id0), self._p(st), self._p(obs))
         return st, obs
+
+    def ik(self, q_start, pos, euler):
+        q0 = self._a(q_start)
+        out = np.zeros(self.ndof, self.np_real)
+        self.lib.orc_ik.restype = C.c_int
+        it = self.lib.orc_ik(C.byref(self.model), C.byref(self.task), self._p(q0), self._p(self._a(pos)), self._p(self._a(euler)), self._p(out))
+        return out, it
+
+    def set_ik_mode(self, on=True):
+        self.task.use_ik = 1 if on else 0
+        self.task.n_act = 6 if on else 7
 
     def batch_step(self, states, actions):
         st = self._a(states).copy()

@@ -20,6 +20,8 @@ def make_pair(Engine, lib, table, n, task=1, obj_std=0.05, tg_std=0.2, **kw):
     ora = orc.Oracle(table, task=task)
     ora.task.obj_pose_rnd_std = obj_std
     ora.task.tg_pose_rnd_std = tg_std
+    if kw.get("use_ik"):
+        ora.set_ik_mode(True)
     return eng, ora
 
 
@@ -114,3 +116,40 @@ def check_auto_reset(Engine, lib, table, n=12, max_steps=4):
     assert finished.all()
     ep = auto.get_state()[:, 37]
     assert (ep >= 1).all()
+
+
+def check_ik_mode(Engine, lib, table, task, flags=0):
+    """use_IK=1 against the oracle: reset (IK solve + extra step), single steps, hand-pose clipping."""
+    n = 4
+    eng, ora = make_pair(Engine, lib, table, n, task=task, use_ik=1, flags=flags)
+    assert eng.act_dim == 6
+    obs = eng.reset()
+    st_o, obs_o = ora.batch_reset(n)
+    st_e = eng.get_state()
+    assert np.abs(st_e[:, 38:44] - [0.2, 0, 0.8, np.pi, 0, 0]).max() < 1e-6          # _home_hand_pose (panda_env.py:85-88)
+    assert rel(st_e[:, :44], st_o[:, :44]).max() < 5e-4 and rel(obs, obs_o).max() < 5e-3
+    assert np.abs(obs_o[:, :3] - [0.2, 0.0, 0.8]).max() < 2e-3                           # the arm reached the home hand pose
+    # single steps from identical states (IK may stop one iteration apart in fp32/fp64 -> looser tolerance than joint mode)
+    rng = np.random.default_rng(4)
+    st = st_o
+    for k in range(6):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        so, out = ora.batch_step(s32.astype(np.float64), a)
+        se = eng.get_state()
+        assert np.abs(se[:, 38:44] - so[:, 38:44]).max() < 1e-6                          # hand pose glue: exact up to fp32
+        assert rel(se[:, :35], so[:, :35]).max() < 1e-3
+        assert rel(ob, out[:, :-2]).max() < 2e-2
+        st = so
+    # workspace clipping of the hand pose: x starts at 0.2 < 0.3 and is clipped on the first step (panda_push_gym_env.py:214-218)
+    assert abs(so[0, 38] - 0.3) < 0.03
+    # masked reset keeps the unmasked envs and re-solves the home pose for the masked ones
+    eng.set_state(so.astype(np.float32))
+    mask = np.array([1, 0, 0, 1], np.uint8)
+    eng.reset(mask)
+    s2 = eng.get_state()
+    assert np.abs(s2[1:3, :44] - so[1:3, :44].astype(np.float32)).max() == 0
+    assert np.abs(s2[[0, 3], 38:44] - [0.2, 0, 0.8, np.pi, 0, 0]).max() < 1e-6 and (s2[[0, 3], 37] == 1).all()
+    return eng

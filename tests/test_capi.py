@@ -48,7 +48,7 @@ def test_bad_arguments_are_rejected(panda, emu_lib):
     with pytest.raises(RuntimeError, match="robot_table"):
         _capi.Engine(np.zeros(10), lib=emu_lib)
     with pytest.raises(RuntimeError, match="not implemented"):
-        _capi.Engine(panda["table"], lib=emu_lib, use_ik=1)
+        _capi.Engine(panda["table"], lib=emu_lib, action_repeat=2)
     eng = _capi.Engine(panda["table"], lib=emu_lib, num_envs=2)
     with pytest.raises(ValueError):
         eng.step(np.zeros((3, 7), np.float32))

@@ -108,3 +108,9 @@ def test_set_physics_matches_oracle(panda, emu_lib):
     parity.check_single_steps(eng, ora, st, np.random.default_rng(5), steps=3)
     with pytest.raises(RuntimeError, match="isotropic"):
         eng.set_physics(obj_inertia=[1e-4, 2e-4, 1e-4])
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_ik_mode(panda, emu_lib, task):
+    """use_IK=1: Cartesian actions -> hand-pose accumulation/clipping -> damped-least-squares IK -> joint targets."""
+    parity.check_ik_mode(_capi.Engine, emu_lib, panda["table"], task)

@@ -12,13 +12,15 @@ from pybullet_robot_envs.envs import pandaPushGymEnv, pandaReachGymEnv, pandaPus
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "panda_glue.npz"))
 
-CASES = [("pushA", 1, 1000), ("pushB", 1, 6), ("reachC", 0, 5), ("goalD", 2, 4), ("goalE", 2, 4)]
+CASES = [("pushA", 1, 1000), ("pushB", 1, 6), ("reachC", 0, 5), ("goalD", 2, 4), ("goalE", 2, 4), ("ikF", 1, 1000)]
 
 
 @pytest.mark.parametrize("tag,task,max_steps", CASES)
 def test_oracle_glue_reproduces_reference(panda, tag, task, max_steps):
     o = orc.Oracle(panda["table"], task=task)
     o.task.max_steps = max_steps
+    if tag.startswith("ik"):
+        o.set_ik_mode()
     pre, act = G[tag + "_pre_state"], G[tag + "_actions"]
     for k in range(len(act)):
         st, out = o.batch_step(pre[k:k + 1], act[k:k + 1])
@@ -29,6 +31,8 @@ def test_oracle_glue_reproduces_reference(panda, tag, task, max_steps):
         assert st[0, 35] == G[tag + "_counter"][k]
         if k + 1 < len(act):                                               # the physics under the reference classes was the oracle
             assert np.abs(st[0, :31] - G[tag + "_pre_state"][k + 1][:31]).max() < 1e-12
+            if tag.startswith("ik"):                                       # commanded hand pose: accumulate, scale, clip
+                assert np.abs(st[0, 38:44] - G[tag + "_pre_state"][k + 1][38:44]).max() < 1e-12
 
 
 def test_reset_start_poses(panda):
@@ -37,6 +41,10 @@ def test_reset_start_poses(panda):
     assert np.abs(st[0, :35] - G["pushA_reset_state"][:35]).max() < 1e-12   # K3/K6: settled cube, default target
     assert np.allclose(G["obj_init_pose"], [0.45, 0.0, 0.695, 0, 0, 0.3826834323650898, 0.9238795325112867], atol=1e-15)
     assert G["h_table"] == 0.625
+    o.set_ik_mode()
+    st, obs = o.batch_reset(1)
+    assert np.abs(st[0, :31] - G["ikF_reset_state"][:31]).max() < 1e-12     # IK-mode reset: one IK solve + one extra step
+    assert np.abs(st[0, 38:44] - G["ikF_reset_state"][38:44]).max() < 1e-12
 
 
 @pytest.mark.parametrize("cls,tag", [(pandaPushGymEnv, "push"), (pandaReachGymEnv, "reach"), (pandaPushGymGoalEnv, "goal")])
@@ -48,6 +56,11 @@ def test_spaces_bit_identical(emu_lib, cls, tag):
     assert env.action_space.low.tobytes() == G[tag + "_act_low"].tobytes()
     assert env.action_space.high.tobytes() == G[tag + "_act_high"].tobytes()
     assert env.action_space.shape == (7,)
+    if tag == "push":
+        env = cls(_lib=emu_lib, use_IK=1)
+        assert env.observation_space.low.tobytes() == G["ik_obs_low"].tobytes()
+        assert env.observation_space.high.tobytes() == G["ik_obs_high"].tobytes()
+        assert env.action_space.low.tobytes() == G["ik_act_low"].tobytes() and env.action_space.shape == (6,)
 
 
 def test_utils_bit_identical(emu_lib):
@@ -63,7 +76,8 @@ def test_utils_bit_identical(emu_lib):
 
 @pytest.mark.parametrize("cls,tag,kw", [
     (pandaPushGymEnv, "pushA", {}), (pandaPushGymEnv, "pushB", {"max_steps": 6}),
-    (pandaReachGymEnv, "reachC", {"max_steps": 5}), (pandaPushGymGoalEnv, "goalD", {"max_steps": 4, "tg_pose_rnd_std": 0.0})])
+    (pandaReachGymEnv, "reachC", {"max_steps": 5}), (pandaPushGymGoalEnv, "goalD", {"max_steps": 4, "tg_pose_rnd_std": 0.0}),
+    (pandaPushGymEnv, "ikF", {"use_IK": 1})])
 def test_env_classes_match_reference_outputs(emu_lib, cls, tag, kw):
     """The drop-in classes (fp32 device algorithm, run through the CPU lane emulation here) return what the
     reference classes returned: scaled obs, reward, done -- step by step from the reference's own states."""

@@ -222,3 +222,11 @@ def test_config2_reach_without_object(panda, hip_lib):
     assert parity.rel(st1[sub], so).max() < parity.TOL_STATE and parity.rel(ob[sub], out[:, :-2]).max() < parity.TOL_OBS
     assert np.array_equal(st1[:, 9:16], st0[:, 9:16])                           # the object did not move
     assert np.abs((st1[:, :7] - st0[:, :7]) - 0.025 * a).max() < 2e-5          # K2 motor law
+
+
+@pytest.mark.parametrize("task,flags", [(1, 0), (0, 0), (1, _capi.F_FORCE_GENERAL)])
+def test_ik_mode(panda, hip_lib, task, flags):
+    """use_IK=1 (k_ik + target-mode step kernels) against the oracle, lane-per-env and row kernels."""
+    eng = parity.check_ik_mode(_capi.Engine, hip_lib, panda["table"], task, flags=flags)
+    info = eng.kernel_info()
+    assert (info[2] == 1) == (flags == 0)

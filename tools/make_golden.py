@@ -72,12 +72,16 @@ def rollout(env, tag, actions, goal=False, set_target=None):
     else:
         p.W.state[32:35] = getattr(env, "_target_pose", (0, 0, 0))
     out[tag + "_reset_state"] = p.W.state.copy()
+    if getattr(env, "_use_IK", 0):
+        out[tag + "_reset_state"][38:44] = env._hand_pose
     out[tag + "_reset_obs"] = np.asarray(o0["observation"] if goal else o0, dtype=np.float64)
     pre, obs, rew, done, cnt, succ, raw = [], [], [], [], [], [], []
     for a in actions:
         s = p.W.state.copy()
         s[35] = env._env_step_counter
         s[36] = float(bool(env.terminated))
+        if getattr(env, "_use_IK", 0):
+            s[38:44] = env._hand_pose
         pre.append(s)
         o, r, d, info = env.step(a.copy())
         obs.append(np.asarray(o["observation"] if goal else o, dtype=np.float64))
@@ -115,6 +119,14 @@ envD = pandaPushGymGoalEnv(max_steps=4, tg_pose_rnd_std=0.0)
 spaces_of(envD, "goal", goal=True)
 rollout(envD, "goalD", rng.uniform(-1, 1, (8, 7)), goal=True, set_target=(0.55, -0.2, 0.64999))
 rollout(envD, "goalE", rng.uniform(-1, 1, (3, 7)), goal=True)        # default target: inside the success radius
+
+# F: Cartesian control through IK (use_IK=1): hand-pose accumulation, scales, workspace/rotation clipping, action dim 6
+envF = pandaPushGymEnv(use_IK=1, max_steps=1000)
+spaces_of(envF, "ik")
+actF = rng.uniform(-1, 1, (12, 6))
+actF[3:6, 2] = -1.0          # drive z down
+actF[6:9, 0] = -1.0          # drive x below the workspace limit
+rollout(envF, "ikF", actF, set_target=(0.58, 0.25, 0.64999))
 
 # utils goldens
 box = envA.observation_space

@@ -147,6 +147,20 @@ def setJointMotorControl2(body, i, mode, targetPosition=0.0, positionGain=0.1, v
     W.kd[d] = velocityGain
 
 
+def setJointMotorControlArray(bodyUniqueId, jointIndices, controlMode, targetPositions=None, positionGains=None,
+                              velocityGains=None, physicsClientId=0, **k):
+    for i, t, kp_, kd_ in zip(list(jointIndices), targetPositions, positionGains, velocityGains):
+        setJointMotorControl2(bodyUniqueId, i, controlMode, targetPosition=t, positionGain=kp_, velocityGain=kd_)
+
+
+def calculateInverseKinematics(body, ee, pos, orn, maxNumIterations=20, residualThreshold=1e-4, physicsClientId=0, **k):
+    o = W.oracle
+    o.task.ik_max_iters = maxNumIterations
+    o.task.ik_residual = residualThreshold
+    q, _ = o.ik(W.state[:9], pos, getEulerFromQuaternion(orn))
+    return tuple(q)
+
+
 def stepSimulation(physicsClientId=0):
     o = W.oracle
     o.params.flags = 0 if W.has_object else orc.F_NO_OBJECT
