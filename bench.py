@@ -1,13 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/sec of the batched Panda-push step() hot path on MI355X.
 
-Workload (BASELINE.json `metric`, SURVEY 8d config 4): pandaPushGymEnv, joint control,
-131072 envs in total sharded evenly over the N GPUs of one node (strong scaling: total fixed),
+Workload (BASELINE.json `metric`, SURVEY 8d configs 3/4): pandaPushGymEnv, joint control,
 obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, 150 PGS iterations, dt=1/240, actions U(-1,1).
-A "step" = one batched env.step() of every env: pbre_step_device (actions and outputs resident
-in HBM) and, for N>1, one RCCL gather of the stacked [obs|reward|done] rows to rank 0.
+N=1 runs the 131072-env batch the metric is quoted on.  Envs are independent, so the batch shards
+with no data dependence between ranks: for N>1 every GPU keeps a 131072-env shard (weak scaling,
+131072*N envs in total) and, per step, one RCCL gather returns the stacked [obs|reward|done] rows
+to rank 0, overlapped with the next step's kernels (double-buffered output).  The literal config 4
+(131072 envs in TOTAL over N GPUs, same gather) is measured in the same run and reported under
+"strong_scaling_128k_total".
+A "step" = one batched env.step() of every env: pbre_step_device, actions and outputs resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs TOTAL]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs PER_GPU]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -79,10 +83,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--envs", type=int, default=131072, help="total envs over all GPUs")
+    ap.add_argument("--envs", type=int, default=131072, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--steady-preroll", type=int, default=300,
                     help="untimed steps before the extra mid-episode measurement (0 disables it)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the extra fixed-total measurement at N>1")
     args = ap.parse_args()
 
     import numpy as np
@@ -90,74 +95,114 @@ def main():
     import torch.distributed as dist
     from pybullet_robot_envs import _capi
     from pybullet_robot_envs.model.table import panda_table
+    from pybullet_robot_envs.sharding import ShardedEngine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # test hooks (single-GPU box): PBRE_BENCH_ONE_DEVICE=1 puts every rank on GPU 0, PBRE_BENCH_BACKEND=gloo stages the
+    # gather through host memory.  The driver's runs use neither.
+    if os.environ.get("PBRE_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("PBRE_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    assert args.envs % world == 0
-    n_local = args.envs // world
     tbl, _ = panda_table()
-    from pybullet_robot_envs.sharding import ShardedEngine
-    sh = ShardedEngine(tbl, args.envs, task=_capi.TASK_PUSH, device_id=local_rank, seed=1234,
-                       obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
-    eng = sh.engine
-    assert (sh.n_local, sh.env_id_base) == (n_local, rank * n_local)
-    ow = eng.obs_dim + 2
-    eng.reset()
-
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    pool = [torch.rand((n_local, eng.act_dim), device=dev, generator=gen) * 2 - 1 for _ in range(8)]
-    out = torch.zeros((n_local, ow), device=dev, dtype=torch.float32)
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
-    # a dedicated non-null stream: the kernel, the HIP timing events and the RCCL gather all run on it
+    # a dedicated non-null stream: the kernels and the HIP timing events run on it; RCCL orders itself after it
     side = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
     stream = side.cuda_stream
     assert stream != 0
 
-    def one_step(k, ev=None):
-        a = pool[k % len(pool)]
-        if ev is not None:
-            ev[0].record()
-        eng.step_device(a.data_ptr(), out.data_ptr(), stream)
-        if ev is not None:
-            ev[1].record()
+    def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            dist.gather(out, gathered, dst=0)       # the one collective of the data path (RCCL over xGMI)
+            dist.barrier()
+            torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        t = torch.tensor(x, device=dev, dtype=torch.float64)
+        if world > 1:
+            if backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                tc = t.cpu()
+                dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+                t = tc
+        return [float(v) for v in t]
+
+    class Job(object):
+        """One sharded batch: engine, resident action pool, double-buffered output rows, pipelined gather."""
+
+        def __init__(self, total_envs):
+            self.sh = ShardedEngine(tbl, total_envs, task=_capi.TASK_PUSH, device_id=local_rank, seed=1234,
+                                    obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+            self.eng = eng = self.sh.engine
+            self.n_local = n = self.sh.n_local
+            assert self.sh.env_id_base == rank * n
+            eng.reset()
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(1234 + rank)
+            self.pool = [torch.rand((n, eng.act_dim), device=dev, generator=gen) * 2 - 1 for _ in range(8)]
+            self.out = [torch.zeros((n, eng.obs_dim + 2), device=dev, dtype=torch.float32) for _ in range(2)]
+            self.gathered = [torch.zeros_like(self.out[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+            self.pending = [None, None]
+            self.k = 0
+
+        def step(self, ev=None):
+            b = self.k & 1
+            if self.pending[b] is not None:            # the gather that read this buffer two steps ago
+                self.pending[b].wait()
+                self.pending[b] = None
+            if ev is not None:
+                ev[0].record()
+            self.eng.step_device(self.pool[self.k % len(self.pool)].data_ptr(), self.out[b].data_ptr(), stream)
+            if ev is not None:
+                ev[1].record()
+            if world > 1:                              # the one collective of the data path (RCCL over xGMI)
+                if backend == "nccl":
+                    self.pending[b] = dist.gather(self.out[b], self.gathered, dst=0, async_op=True)
+                else:
+                    side.synchronize()
+                    h = self.out[b].cpu()
+                    dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
+            self.k += 1
+
+        def drain(self):
+            for b in range(2):
+                if self.pending[b] is not None:
+                    self.pending[b].wait()
+                    self.pending[b] = None
+
+        def timed(self, steps, events=False):
+            barrier()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
+            t0 = time.perf_counter()
+            for k in range(steps):
+                self.step(evs[k] if events else None)
+            self.drain()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            pair = float(np.mean([a.elapsed_time(b) for a, b in evs])) if events else 0.0
+            return max_over_ranks([elapsed, pair])
+
+    job = Job(args.envs * world)
+    eng, n_local, total = job.eng, job.n_local, args.envs * world
     for k in range(args.warmup):
-        one_step(k)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(k, evs[k])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))     # whole launch pair (fork/join incl.), HIP events on the caller's stream
-    t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, pair_ms = float(t[0]), float(t[1])
-    finite = bool(torch.isfinite(out).all())
+        job.step()
+    elapsed, pair_ms = job.timed(args.steps, events=True)   # pair_ms: whole launch pair (fork/join incl.), HIP events on the caller's stream
+    finite = bool(torch.isfinite(job.out[0]).all() and torch.isfinite(job.out[1]).all())
     complex_after = eng.kernel_info()[5]
     # duration of the dominant kernel (k_fast) alone: mean over the last <= 64 timed steps of the HIP event pairs the library
     # records around that kernel on the stream it is launched on (pbre_timing[3])
@@ -168,30 +213,32 @@ def main():
     steady = None
     if args.steady_preroll > 0:
         for k in range(args.steady_preroll):
-            one_step(k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            one_step(k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-        e2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
-        steady = {"preroll_steps": args.steady_preroll, "value": args.envs * args.steps / float(e2[0]), "unit": "env-steps/s",
-                  "ms_per_step": float(e2[0]) / args.steps * 1e3, "complex_env_frac_rank0": eng.kernel_info()[5] / n_local}
+            job.step()
+        e2 = job.timed(args.steps)[0]
+        steady = {"preroll_steps": args.steady_preroll, "value": total * args.steps / e2, "unit": "env-steps/s",
+                  "ms_per_step": e2 / args.steps * 1e3, "complex_env_frac_rank0": eng.kernel_info()[5] / n_local}
+    info = eng.kernel_info()
+    del job
+
+    # extra at N>1: BASELINE config 4 taken literally -- 131072 envs in TOTAL over the N GPUs (strong scaling), same gather
+    strong = None
+    if world > 1 and not args.no_strong:
+        try:
+            j2 = Job(131072)
+            for k in range(args.warmup):
+                j2.step()
+            e3 = j2.timed(args.steps)[0]
+            strong = {"envs_total": 131072, "envs_per_gpu": j2.n_local, "value": 131072 * args.steps / e3, "unit": "env-steps/s",
+                      "ms_per_step": e3 / args.steps * 1e3}
+            del j2
+        except Exception as e:   # informative only
+            strong = {"error": repr(e)}
 
     if rank == 0:
-        value = args.envs * args.steps / elapsed
+        value = total * args.steps / elapsed
         kern_s = kern_ms * 1e-3
         ach_gbs = ALG_BYTES_PER_ENV_STEP * n_local / kern_s / 1e9
         ach_tf = ALG_FLOP_PER_ENV_STEP * n_local / kern_s / 1e12
-        info = eng.kernel_info()
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
         # calibrated in profiles/r01_pmc_hbm.json); counters cannot be read from inside this process, so the committed
         # per-env figure of the profiled run is scaled to this launch's env count.
@@ -204,16 +251,18 @@ def main():
         res = {
             "metric": "env-steps/sec (whole node), Panda-push 128k envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pandaPushGymEnv joint-control step, %d envs total (%d per GPU), 150 PGS iters, "
+            "config": {"workload": "pandaPushGymEnv joint-control step, %d envs per GPU (%d in total), 150 PGS iters, "
                                    "dt 1/240, obj_pose_rnd_std 0.05, tg_pose_rnd_std 0.2, actions U(-1,1) resident in HBM"
-                                   % (args.envs, n_local),
-                       "envs_total": args.envs, "envs_per_gpu": n_local, "parallelism": "dp%d" % world,
-                       "collective": "rccl gather to rank 0 per step" if world > 1 else "none",
+                                   % (n_local, total),
+                       "envs_total": total, "envs_per_gpu": n_local, "parallelism": "dp%d" % world,
+                       "collective": "rccl gather of [obs|reward|done] rows to rank 0 per step, overlapped with the next step"
+                                     if world > 1 else "none",
                        "outputs_finite": finite, "start_state": "fresh reset() of every env (reference reset_simulation)",
                        "complex_env_frac_after_timed_steps_rank0": complex_after / n_local},
             "steady_state": steady,
+            "strong_scaling_128k_total": strong,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": pair_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
