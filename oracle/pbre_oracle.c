@@ -120,6 +120,12 @@ void orc_euler_from_quat(const real q[4], real e[3]) {
 
 /* ------------------------------------------------------------------ model */
 int orc_sizeof_real(void) { return (int)sizeof(real); }
+/* state record layout (pbre_oracle.h) */
+static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : 64; }
+int orc_state_floats(const orc_model* m) { return 2 * lay_w(m) + 16; }
+#define OQ(m) ((m)->ndof)                 /* object position (then quaternion) inside Q */
+#define OV(m) (lay_w(m))                  /* V record */
+#define OX(m) (2 * lay_w(m))              /* X record */
 
 int orc_model_from_table(const double* t, size_t n, orc_model* m) {
     memset(m, 0, sizeof *m);
@@ -486,8 +492,8 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
                   const real* kd, orc_step_info* info) {
     const int nd = m->ndof;
     const real dt = (real)prm->dt;
-    real* q = st; real* qd = st + 16;
-    real* op = st + 9; real* oq = st + 12; real* ov = st + 16 + 9; real* ow = st + 16 + 12;
+    real* q = st; real* qd = st + OV(m);
+    real* op = st + OQ(m); real* oq = op + 3; real* ov = qd + nd; real* ow = ov + 3;
     const int obj_on = !(prm->flags & ORC_F_NO_OBJECT);
     aba_ws* w = (aba_ws*)malloc(sizeof *w);
     orc_step_info li; if (!info) info = &li;
@@ -684,7 +690,7 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
         info->motor_impulse[k] = nc[motor_row[k]].app;
     }
     if (obj_on) {
-        for (int k = 0; k < 6; k++) { real v = ovs[k] + dvB[k]; if (v > mcv) v = mcv; if (v < -mcv) v = -mcv; st[16 + 9 + k] = v; }
+        for (int k = 0; k < 6; k++) { real v = ovs[k] + dvB[k]; if (v > mcv) v = mcv; if (v < -mcv) v = -mcv; ov[k] = v; }
         for (int k = 0; k < 3; k++) op[k] += dt * ov[k];
         /* quaternion exponential-map update (btMultiBody pQuatUpdateFun, world-frame omega) [EXT-UNVERIFIED] */
         real ang = norm3(ow), ax[3];
@@ -723,24 +729,31 @@ static real u01(uint32_t x) { return (real)(x >> 8) * (real)(1.0 / 16777216.0); 
 
 
 /* ------------------------------------------------------------------ inverse kinematics
- * PyBullet's calculateInverseKinematics(maxNumIterations=100, residualThreshold=1e-3) (panda_env.py:269-272) iterates a
- * damped-least-squares update of the end-effector pose from the current joint angles [EXT-UNVERIFIED: Bullet's BussIK
- * "DLS with orientation"; the damping value and the exact stopping rule are restated, not verified].  Here:
- *   e = [p_target - p_ee ; axis-angle(R_target R_ee^T)],  dq = J^T (J J^T + lambda^2 I)^-1 e,  stop when |e_pos| < threshold.
- * Only joints on the chain to the end effector move; the others (fingers) keep their current value.  Returns iterations. */
+ * PyBullet's calculateInverseKinematics(maxNumIterations=100, residualThreshold=1e-3) (panda_env.py:269-272,
+ * icub_env.py:307-312) iterates a damped-least-squares update of the end-effector link pose from the current joint
+ * angles [EXT-UNVERIFIED: Bullet's BussIK "DLS with orientation"; the damping value and the exact stopping rule are
+ * restated, not verified].  Here:
+ *   e = [p_target - p_link ; axis-angle(R_target R_link^T)],  dq = J^T (J J^T + lambda^2 I)^-1 e,  stop when |e_pos| < threshold.
+ * The target is given for the hand COM frame and moved to the link frame with the constant ik_link_offset
+ * (icub_env.py:252-258, 300-305; zero for the Panda whose end-effector link has no COM offset).  Only joints on the
+ * chain to the end effector move (on the iCub those are exactly the controlled torso + arm joints, whose joint
+ * damping the reference sets to 0.1; the blocked joints get 100 and are overwritten with their rest pose anyway,
+ * icub_env.py:171, 316-317); the others keep their current value.  Returns iterations. */
 static void euler_to_R(const real* e, real* R) { real q[4]; orc_quat_from_euler(e, q); quat_to_R(q, R); }
 int orc_ik(const orc_model* m, const orc_task* t, const real* q_start, const real* pos, const real* euler, real* q) {
     const int nd = m->ndof, ee = m->ee_link;
     real Rt[9]; euler_to_R(euler, Rt);
+    real off[3] = {(real)t->ik_link_offset[0], (real)t->ik_link_offset[1], (real)t->ik_link_offset[2]}, tp[3];
+    m3_v(Rt, off, tp);
+    for (int k = 0; k < 3; k++) tp[k] += pos[k];
     for (int k = 0; k < nd; k++) q[k] = q_start[k];
     real R[ORC_MAXL*9], p[ORC_MAXL*3];
     int it = 0;
     for (; it < t->ik_max_iters; it++) {
         orc_fk(m, q, R, p);
-        real pe[3], c[3]; m3_v(R + 9*ee, m->com[ee], c);
-        for (int k = 0; k < 3; k++) pe[k] = p[3*ee+k] + c[k];
+        const real* pe = p + 3*ee;
         real e[6];
-        for (int k = 0; k < 3; k++) e[k] = pos[k] - pe[k];
+        for (int k = 0; k < 3; k++) e[k] = tp[k] - pe[k];
         if (norm3(e) < (real)t->ik_residual) break;
         /* orientation error as a world-frame rotation vector */
         real ReT[9], Rerr[9]; m3_T(R + 9*ee, ReT); m3_mul(Rt, ReT, Rerr);
@@ -795,9 +808,40 @@ void orc_default_task(orc_task* t, int task) {
     for (int k = 0; k < 6; k++) t->home_hand_pose[k] = hh[k];
     t->robot_ws[0][0] = 0.3; t->robot_ws[0][1] = 0.65; t->robot_ws[1][0] = -0.3; t->robot_ws[1][1] = 0.3;   /* panda_env.py:37 */
     t->robot_ws[2][0] = task == 0 ? 0.625 : 0.425; t->robot_ws[2][1] = 1.5;            /* z-min: panda_reach_gym_env.py:69 / panda_push_gym_env.py:74 */
+    t->robot = 0; t->n_joints_ctrl = 7;
+    for (int k = 0; k < ORC_MAXACT; k++) t->act_dof[k] = k < 7 ? k : -1;
+    t->control_orientation = 1; t->ik_pos_scale = 0.005; t->ik_rot_scale = 0.01;       /* panda_push_gym_env.py:200-203 */
+    for (int k = 0; k < 3; k++) { t->eu_lim[k][0] = -PI; t->eu_lim[k][1] = PI; }        /* panda_env.py:38 */
 }
-int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + m->ndof + 6 + 6 + (t->task >= 1 ? 3 : 0); }
 
+/* iCub variants: icub_env.py:52-82 (workspace, Euler limits, home hand pose per arm), icub_reach_gym_env.py:27-35,
+ * icub_push_gym_env.py:27-37 (thresholds 0.03, max_steps 2000, reward_type 1) */
+void orc_task_icub(orc_task* t, int task, int right_arm, int use_ik, int control_orientation, const int* ctrl_dof,
+                   const double* home, int ndof) {
+    orc_default_task(t, task);
+    t->robot = 1; t->max_steps = 2000; t->target_dist_min = 0.03;
+    t->ws_lim[0][0] = 0.1; t->ws_lim[0][1] = 0.45; t->ws_lim[1][0] = -0.3; t->ws_lim[1][1] = 0.3;
+    t->ws_lim[2][0] = t->h_table; t->ws_lim[2][1] = t->h_table + 0.3;
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) t->robot_ws[a][b] = t->ws_lim[a][b];
+    t->robot_ws[2][0] = t->h_table; t->robot_ws[2][1] = 1.0;            /* icub_reach_gym_env.py:78-80 */
+    for (int k = 0; k < ORC_MAXD; k++) t->home[k] = k < ndof ? home[k] : 0.0;
+    t->n_joints_ctrl = 10;
+    for (int k = 0; k < ORC_MAXACT; k++) t->act_dof[k] = k < 10 ? ctrl_dof[k] : -1;
+    t->use_ik = use_ik; t->control_orientation = control_orientation;
+    t->n_act = use_ik ? (control_orientation ? 6 : 3) : 10;
+    t->ik_pos_scale = control_orientation ? 0.01 : 0.005; t->ik_rot_scale = 0.02;   /* icub_reach_gym_env.py:206-212 */
+    const double hl[6] = {0.3, 0.26, 0.8, 0, 0, 0}, hr[6] = {0.3, -0.26, 0.8, 0, 0, PI};
+    for (int k = 0; k < 6; k++) t->home_hand_pose[k] = right_arm ? hr[k] : hl[k];
+    for (int k = 0; k < 3; k++) { t->eu_lim[k][0] = -PI / 2; t->eu_lim[k][1] = PI / 2; }
+    if (right_arm) { t->eu_lim[2][0] = PI / 2; t->eu_lim[2][1] = 1.5 * PI; }
+    const double ol[3] = {-0.064768, -0.00563, -0.02266}, orr[3] = {0.064668, -0.0056, -0.022681};   /* icub_env.py:252-258 */
+    for (int k = 0; k < 3; k++) t->ik_link_offset[k] = right_arm ? orr[k] : ol[k];
+    t->reward_type = 1;
+}
+static int n_obs_joints(const orc_task* t, const orc_model* m) { return t->robot == 1 ? t->n_joints_ctrl : m->ndof; }
+int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + n_obs_joints(t, m) + 6 + 6 + (t->task >= 1 ? 3 : 0); }
+
+/* end-effector state as p.getLinkState(computeLinkVelocity=1) reports it: COM frame position, orientation, linear velocity */
 static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, real* vlin) {
     real R[ORC_MAXL*9], p[ORC_MAXL*3];
     orc_fk(m, st, R, p);
@@ -809,7 +853,7 @@ static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, 
     for (int i = e; i >= 0; i = m->parent[i]) {
         if (m->jtype[i] == 0) continue;
         real aw[3], t[3]; m3_v(R + 9*i, m->axis[i], aw);
-        real qd = st[16 + m->dof[i]];
+        real qd = st[OV(m) + m->dof[i]];
         if (m->jtype[i] == 1) { real rr[3] = {pos[0]-p[3*i], pos[1]-p[3*i+1], pos[2]-p[3*i+2]}; cross(aw, rr, t); }
         else { t[0] = aw[0]; t[1] = aw[1]; t[2] = aw[2]; }
         for (int k = 0; k < 3; k++) vlin[k] += t[k] * qd;
@@ -817,52 +861,61 @@ static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, 
 }
 
 void orc_observation(const orc_model* m, const orc_task* t, const real* st, real* obs) {
-    /* panda_env.py:141-193 + panda_push_gym_env.py:150-187 */
+    /* panda_env.py:141-193 + panda_push_gym_env.py:150-187; icub_env.py:202-249 + icub_reach_gym_env.py:150-180 */
     real pos[3], quat[4], vl[3], eu[3];
+    const real* ob = st + OQ(m);
     ee_state(m, st, pos, quat, vl);
     orc_euler_from_quat(quat, eu);
     int o = 0;
     for (int k = 0; k < 3; k++) obs[o++] = pos[k];
     for (int k = 0; k < 3; k++) obs[o++] = eu[k];
-    const real vmean[3] = {0, (real)0.01, 0}, vstd[3] = {(real)0.04, (real)0.07, (real)0.03};
-    for (int k = 0; k < 3; k++) obs[o++] = (vl[k] - vmean[k]) / vstd[k];
-    for (int k = 0; k < m->ndof; k++) obs[o++] = st[k];
+    if (t->robot == 1) {                                   /* iCub: raw velocity, controlled joints only */
+        for (int k = 0; k < 3; k++) obs[o++] = vl[k];
+        for (int k = 0; k < t->n_joints_ctrl; k++) obs[o++] = st[t->act_dof[k]];
+    } else {
+        const real vmean[3] = {0, (real)0.01, 0}, vstd[3] = {(real)0.04, (real)0.07, (real)0.03};
+        for (int k = 0; k < 3; k++) obs[o++] = (vl[k] - vmean[k]) / vstd[k];
+        for (int k = 0; k < m->ndof; k++) obs[o++] = st[k];
+    }
     real oe[3];
-    orc_euler_from_quat(st + 12, oe);
-    for (int k = 0; k < 3; k++) obs[o++] = st[9+k];
+    orc_euler_from_quat(ob + 3, oe);
+    for (int k = 0; k < 3; k++) obs[o++] = ob[k];
     for (int k = 0; k < 3; k++) obs[o++] = oe[k];
     /* object pose in the hand frame: invertTransform(ee_pos, quatFromEuler(ee_eul)) * (obj_pos, quatFromEuler(obj_eul)) */
     real qh[4], qo[4], Rh[9], d[3], rel[3], qhi[4], qr[4], er[3];
     orc_quat_from_euler(eu, qh); orc_quat_from_euler(oe, qo);
     quat_to_R(qh, Rh);
-    for (int k = 0; k < 3; k++) d[k] = st[9+k] - pos[k];
+    for (int k = 0; k < 3; k++) d[k] = ob[k] - pos[k];
     m3T_v(Rh, d, rel);
     qhi[0] = -qh[0]; qhi[1] = -qh[1]; qhi[2] = -qh[2]; qhi[3] = qh[3];
     quat_mul(qhi, qo, qr);
     orc_euler_from_quat(qr, er);
     for (int k = 0; k < 3; k++) obs[o++] = rel[k];
     for (int k = 0; k < 3; k++) obs[o++] = er[k];
-    if (t->task >= 1) for (int k = 0; k < 3; k++) obs[o++] = st[32+k];
+    if (t->task >= 1) for (int k = 0; k < 3; k++) obs[o++] = st[OX(m)+k];
 }
 
 /* reward + termination; pre_increment=1 reproduces the in-loop `_termination()` + counter++ of apply_action
  * (panda_push_gym_env.py:239-242) before the final `_termination()`/`_compute_reward()` of step (:252-253) */
 void orc_reward_done(const orc_model* m, const orc_task* t, real* st, int pre_increment, real* reward, real* done) {
     real pos[3], quat[4], vl[3];
+    real* X = st + OX(m); const real* ob = st + OQ(m);
     ee_state(m, st, pos, quat, vl);
     real d1 = 0, d2 = 0;
-    for (int k = 0; k < 3; k++) { real a = pos[k] - st[9+k], b = st[9+k] - st[32+k]; d1 += a*a; d2 += b*b; }
+    for (int k = 0; k < 3; k++) { real a = pos[k] - ob[k], b = ob[k] - X[k]; d1 += a*a; d2 += b*b; }
     d1 = (real)sqrt((double)d1); d2 = (real)sqrt((double)d2);
     real dsucc = t->task >= 1 ? d2 : d1;
-    int succ = dsucc <= (real)t->target_dist_min;
-    int cnt = (int)st[35], term = (int)st[36];
+    const real thr = (real)t->target_dist_min;
+    int succ = dsucc <= thr;
+    int cnt = (int)X[3], term = (int)X[4];
     if (t->task == 2) {
-        /* pandaPushGymGoalEnv (panda_push_gym_goal_env.py:89-122): _termination() is only the step budget (so the
-         * in-loop check of apply_action never sees success), done = budget or success, reward = -(d > thr) */
+        /* pandaPushGymGoalEnv / iCubPushGymGoalEnv (panda_push_gym_goal_env.py:89-122, icub_push_gym_goal_env.py:103-139):
+         * _termination() is only the step budget (so the in-loop check of apply_action never sees success),
+         * done = budget or success, reward = -(d > thr) */
         if (pre_increment && !(cnt > t->max_steps)) cnt++;
         *done = (cnt > t->max_steps || succ) ? (real)1 : (real)0;
         *reward = succ ? (real)0 : (real)-1;
-        st[35] = (real)cnt;
+        X[3] = (real)cnt;
         return;
     }
     if (pre_increment) {
@@ -872,20 +925,43 @@ void orc_reward_done(const orc_model* m, const orc_task* t, real* st, int pre_in
     }
     if (succ) term = 1;
     *done = (succ || term || cnt > t->max_steps) ? (real)1 : (real)0;
-    if (t->task == 1) { *reward = -d1 - d2; if (d2 <= (real)t->target_dist_min) *reward = (real)1000 + ((real)100 - d2 * 80); }
-    else { *reward = -d1; if (d1 <= (real)t->target_dist_min) *reward = (real)1000 + ((real)100 - d1 * 80); }
-    st[35] = (real)cnt; st[36] = (real)term;
+    if (t->robot == 1) {
+        if (t->task == 0) {                               /* icub_reach_gym_env.py:318-330: the bonus is ADDED */
+            *reward = -d1; if (d1 <= thr) *reward += (real)1000 + ((real)100 - d1 * 80);
+        } else if (t->reward_type == 0) {                 /* icub_push_gym_env.py:353-356 */
+            *reward = -d1 - d2; if (d2 <= thr) *reward += (real)1000;
+        } else {                                          /* :359-371, distances normalised by their values at reset */
+            const real rew1 = (real)0.125, rew2 = (real)0.25;
+            *reward = rew1 * (1 - d1 / X[12]);
+            if (!(d1 > (real)0.1)) *reward += rew2 * (1 - d2 / X[13]);
+            if (d2 <= thr) *reward += (real)1000;
+        }
+    }
+    else if (t->task == 1) { *reward = -d1 - d2; if (d2 <= thr) *reward = (real)1000 + ((real)100 - d2 * 80); }
+    else { *reward = -d1; if (d1 <= thr) *reward = (real)1000 + ((real)100 - d1 * 80); }
+    X[3] = (real)cnt; X[4] = (real)term;
 }
 
 static void hold_targets(const orc_task* t, int nd, real* qdes, real* kp, real* kd) {
     for (int k = 0; k < nd; k++) { qdes[k] = (real)t->home[k]; kp[k] = (real)t->kp_hold; kd[k] = (real)t->kd_hold; }
 }
+static real clampr(real x, double lo, double hi) { return x < (real)lo ? (real)lo : (x > (real)hi ? (real)hi : x); }
+/* joint targets of the IK branch: chain joints from the IK solution; iCub: every other joint at its rest pose
+ * (icub_env.py:316-317); Panda: the IK returns the current finger positions */
+static void ik_targets(const orc_model* m, const orc_task* t, const real* st, const real* hp, real* qdes) {
+    real sol[ORC_MAXD];
+    orc_ik(m, t, st, hp, hp + 3, sol);
+    if (t->robot == 1) { for (int k = 0; k < t->n_joints_ctrl; k++) qdes[t->act_dof[k]] = sol[t->act_dof[k]]; }
+    else for (int k = 0; k < m->ndof; k++) qdes[k] = sol[k];
+}
 
 void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
                    real* st, real* obs) {
-    /* reset_simulation (panda_push_gym_env.py:117-148): robot at home, 100 steps, load world, 100 steps, 1 step */
+    /* reset_simulation (panda_push_gym_env.py:117-148, icub_reach_gym_env.py:121-148): robot at home, 100 steps,
+     * load world, 100 steps, 1 step */
     const int nd = m->ndof;
-    memset(st, 0, ORC_STATE * sizeof(real));
+    real* X = st + OX(m); real* ob = st + OQ(m);
+    memset(st, 0, (size_t)orc_state_floats(m) * sizeof(real));
     for (int k = 0; k < nd; k++) st[k] = (real)t->home[k];
     /* WorldEnv._sample_pose (world_env.py:145-176) */
     real x_min = (real)t->ws_lim[0][0] + (real)0.05, x_max = (real)t->ws_lim[0][1] - (real)0.1;
@@ -903,80 +979,90 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
     px = px < x_min ? x_min : (px > x_max ? x_max : px);
     py = py < y_min ? y_min : (py > y_max ? y_max : py);
     real e[3] = {0, 0, yaw};
-    st[9] = px; st[10] = py; st[11] = pz;
-    orc_quat_from_euler(e, st + 12);
+    ob[0] = px; ob[1] = py; ob[2] = pz;
+    orc_quat_from_euler(e, ob + 3);
     real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
     hold_targets(t, nd, qdes, kp, kd);
     orc_params p1 = *prm; p1.flags |= ORC_F_NO_OBJECT;
     if (t->use_ik) {
-        /* pandaEnv.reset with use_IK (panda_env.py:83-91): apply_action(home_hand_pose) -> IK once from the joint home
-         * pose, motors (all DoF, kp 0.2) hold that solution for the whole settle; one extra stepSimulation */
+        /* robot.reset with use_IK (panda_env.py:83-91, icub_env.py:147-148): apply_action(home_hand_pose) -> IK once from
+         * the joint home pose, motors (all DoF, kp 0.2) hold that solution for the whole settle */
         real hp[6]; for (int k = 0; k < 6; k++) hp[k] = (real)t->home_hand_pose[k];
-        hp[2] = hp[2] < (real)t->robot_ws[2][0] ? (real)t->robot_ws[2][0] : (hp[2] > (real)t->robot_ws[2][1] ? (real)t->robot_ws[2][1] : hp[2]);
-        orc_ik(m, t, st, hp, hp + 3, qdes);
-        for (int k = 0; k < 6; k++) st[38 + k] = (real)t->home_hand_pose[k];
-        orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
+        for (int k = t->robot == 1 ? 0 : 2; k < 3; k++) hp[k] = clampr(hp[k], t->robot_ws[k][0], t->robot_ws[k][1]);
+        ik_targets(m, t, st, hp, qdes);
+        for (int k = 0; k < 6; k++) X[6 + k] = (real)t->home_hand_pose[k];
     }
+    /* one extra stepSimulation at the end of robot.reset: Panda only in IK mode (panda_env.py:91), iCub always (icub_env.py:151) */
+    if (t->use_ik || t->robot == 1) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
     for (int i = 0; i < 100; i++) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
     for (int i = 0; i < 101; i++) orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
-    /* sample_tg_pose (panda_push_gym_env.py:333-360) */
+    /* sample_tg_pose (panda_push_gym_env.py:333-360, icub_push_gym_env.py:375-401) */
     if (t->task >= 1) {
         real tx_min = (real)t->ws_lim[0][0] + (real)0.07, tx_max = (real)t->ws_lim[0][1] - (real)0.07;
         real ty_min = (real)t->ws_lim[1][0], ty_max = (real)t->ws_lim[1][1];
-        real tx = st[9] + (real)0.05, ty = st[10] + (real)0.05, tz = st[11];
+        real tx = ob[0] + (real)0.05, ty = ob[1] + (real)0.05, tz = ob[2];
         if (t->tg_pose_rnd_std > 0) {
             orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 1u, (uint32_t)t->seed, (uint32_t)(t->seed >> 32), r);
             real u1 = (real)((r[0] >> 8) + 1) * (real)(1.0 / 16777216.0), u2 = u01(r[1]);
             real rad = (real)sqrt(-2.0 * log((double)u1)) * (real)t->tg_pose_rnd_std;
-            tx = st[9] + rad * (real)cos(2 * PI * (double)u2);
-            ty = st[10] + rad * (real)sin(2 * PI * (double)u2);
+            tx = ob[0] + rad * (real)cos(2 * PI * (double)u2);
+            ty = ob[1] + rad * (real)sin(2 * PI * (double)u2);
         }
         tx = tx < tx_min ? tx_min : (tx > tx_max ? tx_max : tx);
         ty = ty < ty_min ? ty_min : (ty > ty_max ? ty_max : ty);
-        st[32] = tx; st[33] = ty; st[34] = tz;
+        X[0] = tx; X[1] = ty; X[2] = tz;
     }
-    st[35] = 0; st[36] = 0; st[37] = (real)episode;
+    X[3] = 0; X[4] = 0; X[5] = (real)episode;
+    if (t->robot == 1 && t->task >= 1) {
+        /* iCubPushGymEnv.reset (icub_push_gym_env.py:124-127): distances the normalised reward divides by */
+        real pos[3], quat[4], vl[3], d1 = 0, d2 = 0;
+        ee_state(m, st, pos, quat, vl);
+        for (int k = 0; k < 3; k++) { real a = pos[k] - ob[k], b = ob[k] - X[k]; d1 += a*a; d2 += b*b; }
+        X[12] = (real)sqrt((double)d1); X[13] = (real)sqrt((double)d2);
+    }
     if (obs) orc_observation(m, t, st, obs);
 }
 
 void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, const real* action,
                   real* obs, real* reward, real* done) {
-    /* step -> apply_action (panda_push_gym_env.py:189-242, joint control) */
+    /* step -> apply_action (panda_push_gym_env.py:189-242; icub_reach_gym_env.py:182-246) */
     const int nd = m->ndof;
+    real* X = st + OX(m);
     real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
     hold_targets(t, nd, qdes, kp, kd);
     if (t->use_ik) {
-        /* apply_action, IK branch (panda_push_gym_env.py:197-222, panda_env.py:229-291) */
+        /* IK branch (panda_push_gym_env.py:197-222, panda_env.py:229-291; icub_reach_gym_env.py:204-230, icub_env.py:262-330):
+         * accumulate the scaled action on the commanded hand pose, clip rotation and workspace, solve IK */
         real hp[6];
-        for (int k = 0; k < 3; k++) hp[k] = st[38 + k] + action[k] * (real)0.005;
-        for (int k = 3; k < 6; k++) { hp[k] = st[38 + k] + action[k] * (real)0.01; hp[k] = hp[k] < (real)-PI ? (real)-PI : (hp[k] > (real)PI ? (real)PI : hp[k]); }
-        for (int k = 0; k < 3; k++) hp[k] = hp[k] < (real)t->robot_ws[k][0] ? (real)t->robot_ws[k][0] : (hp[k] > (real)t->robot_ws[k][1] ? (real)t->robot_ws[k][1] : hp[k]);
-        for (int k = 0; k < 6; k++) st[38 + k] = hp[k];
-        orc_ik(m, t, st, hp, hp + 3, qdes);
+        for (int k = 0; k < 6; k++) hp[k] = X[6 + k];
+        for (int k = 0; k < 3; k++) hp[k] += action[k] * (real)t->ik_pos_scale;
+        if (t->control_orientation)
+            for (int k = 3; k < 6; k++) hp[k] = clampr(hp[k] + action[k] * (real)t->ik_rot_scale, t->eu_lim[k-3][0], t->eu_lim[k-3][1]);
+        for (int k = 0; k < 3; k++) hp[k] = clampr(hp[k], t->robot_ws[k][0], t->robot_ws[k][1]);
+        for (int k = 0; k < 6; k++) X[6 + k] = hp[k];
+        ik_targets(m, t, st, hp, qdes);
     } else
     for (int k = 0; k < t->n_act; k++) {
-        int li = m->link_of_dof[k];
-        real tgt = st[k] + action[k] * (real)t->act_scale;                 /* :225-230 */
-        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);   /* panda_env.py:303 */
-        qdes[k] = tgt; kp[k] = (real)t->kp_act; kd[k] = (real)t->kd_act;
+        const int d = t->act_dof[k], li = m->link_of_dof[d];
+        real tgt = st[d] + action[k] * (real)t->act_scale;                 /* :225-230 */
+        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);   /* panda_env.py:303, icub_env.py:347 */
+        qdes[d] = tgt; kp[d] = (real)t->kp_act; kd[d] = (real)t->kd_act;
     }
-    orc_params p = *prm;
-    if (t->task == 0) p.flags |= 0;   /* reach uses the same world; config 2 sets ORC_F_NO_OBJECT via prm */
-    orc_sim_step(m, &p, st, qdes, kp, kd, NULL);
+    orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
     orc_reward_done(m, t, st, 1, reward, done);
     orc_observation(m, t, st, obs);
 }
 
 void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* t, int n, uint64_t env_id0,
                      real* states, real* obs) {
-    int od = orc_obs_dim(t, m);
-    for (int e = 0; e < n; e++) orc_env_reset(m, prm, t, env_id0 + (uint64_t)e, 0, states + (size_t)e * ORC_STATE, obs ? obs + (size_t)e * od : NULL);
+    const int od = orc_obs_dim(t, m), sf = orc_state_floats(m);
+    for (int e = 0; e < n; e++) orc_env_reset(m, prm, t, env_id0 + (uint64_t)e, 0, states + (size_t)e * sf, obs ? obs + (size_t)e * od : NULL);
 }
 void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
                     const real* actions, real* out) {
-    int od = orc_obs_dim(t, m);
+    const int od = orc_obs_dim(t, m), sf = orc_state_floats(m);
     for (int e = 0; e < n; e++) {
         real* o = out + (size_t)e * (od + 2);
-        orc_env_step(m, prm, t, states + (size_t)e * ORC_STATE, actions + (size_t)e * t->n_act, o, o + od, o + od + 1);
+        orc_env_step(m, prm, t, states + (size_t)e * sf, actions + (size_t)e * t->n_act, o, o + od, o + od + 1);
     }
 }

@@ -28,14 +28,19 @@ typedef float real;
 typedef double real;
 #endif
 
-#define ORC_MAXL 16      /* links (fixed joints kept as 0-DoF links) */
-#define ORC_MAXD 12      /* joint DoF */
+#define ORC_MAXL 48      /* links (fixed joints kept as 0-DoF links) */
+#define ORC_MAXD 40      /* joint DoF */
 #define ORC_MAXS 16      /* collision spheres */
 #define ORC_NC_OT 4      /* object-table contact slots */
 #define ORC_NC_RO 2      /* robot-object contact slots */
 #define ORC_NC_RT 2      /* robot-table contact slots */
 #define ORC_NC (ORC_NC_OT + ORC_NC_RO + ORC_NC_RT)
-#define ORC_STATE 48     /* floats per env state record (see include/pbre.h) */
+#define ORC_STATE 48     /* floats per env state record of a <= 9-DoF robot (see include/pbre.h) */
+#define ORC_MAXACT 16    /* controlled joints */
+/* State record layout (include/pbre.h): three lane records Q | V | X.  Q and V are W floats wide (W = 16 for robots
+ * with <= 9 DoF, 64 otherwise), X is 16:  Q[0..nd) q, Q[nd..nd+3) object position, Q[nd+3..nd+7) object quaternion;
+ * V[0..nd) qd, V[nd..nd+6) object twist;  X[0..2] target, X[3] counter, X[4] terminated, X[5] episode,
+ * X[6..11] commanded hand pose, X[12] initial hand-object distance, X[13] initial object-target distance. */
 
 typedef struct {
     int nl, ndof, ee_link, ns, fixed_base;
@@ -110,10 +115,21 @@ typedef struct {
     double ik_damping, ik_residual; int ik_max_iters;
     double home_hand_pose[6];
     double robot_ws[3][2];   /* robot workspace used to clip the hand pose */
+    int robot;               /* 0 Panda, 1 iCub: observation / reward / reset variants of the iCub envs */
+    int act_dof[ORC_MAXACT]; /* DoF index of controlled joint k (k < n_joints_ctrl) */
+    int n_joints_ctrl;       /* joints driven in joint mode and reported in the observation (Panda: 7 driven, all 9 observed) */
+    int control_orientation; /* IK mode: 1 = 6-D action (pose), 0 = 3-D action (position, home orientation kept) */
+    double ik_pos_scale, ik_rot_scale;
+    double eu_lim[3][2];
+    double ik_link_offset[3];/* hand COM frame -> link frame (icub_env.py:252-258) */
+    int reward_type;         /* iCub push: 0 / 1 (icub_push_gym_env.py:353-373) */
 } orc_task;
 
 void orc_default_task(orc_task* t, int task);
 int  orc_obs_dim(const orc_task* t, const orc_model* m);
+int  orc_state_floats(const orc_model* m);
+/* set the iCub variants (robot=1): control_arm 0 left / 1 right, controlled DoF list, home pose per DoF */
+void orc_task_icub(orc_task* t, int task, int right_arm, int use_ik, int control_orientation, const int* ctrl_dof, const double* home, int ndof);
 void orc_observation(const orc_model* m, const orc_task* t, const real* state, real* obs);
 void orc_reward_done(const orc_model* m, const orc_task* t, real* state, int pre_increment,
                      real* reward, real* done);

@@ -10,7 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
 
-MAXL, MAXD, MAXS = 16, 12, 16
+MAXL, MAXD, MAXS, MAXACT = 48, 40, 16, 16
 NC = 8
 STATE = 48
 
@@ -51,7 +51,10 @@ class Task(C.Structure):
                 ("act_scale", C.c_double), ("kp_act", C.c_double), ("kd_act", C.c_double),
                 ("kp_hold", C.c_double), ("kd_hold", C.c_double), ("n_act", C.c_int), ("seed", C.c_uint64),
                 ("use_ik", C.c_int), ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("ik_max_iters", C.c_int),
-                ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3)]
+                ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
+                ("robot", C.c_int), ("act_dof", C.c_int * MAXACT), ("n_joints_ctrl", C.c_int), ("control_orientation", C.c_int),
+                ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double), ("eu_lim", C.c_double * 2 * 3),
+                ("ik_link_offset", C.c_double * 3), ("reward_type", C.c_int)]
 
 
 F_NO_OBJECT = 1
@@ -83,6 +86,14 @@ class Oracle:
         self.lib.orc_default_task(C.byref(self.task), task)
         self.nl, self.ndof = self.model.nl, self.model.ndof
         self.lib.orc_obs_dim.restype = C.c_int
+        self.state_floats = self.lib.orc_state_floats(C.byref(self.model))
+
+    def set_icub(self, info, task, control_arm="l", use_ik=1, control_orientation=0):
+        """iCub task variants (reference icub_*_gym_env.py); info = model.table.icub_info()."""
+        ctrl = (C.c_int * 10)(*info["controlled"])
+        home = (C.c_double * self.ndof)(*info["home"])
+        self.lib.orc_task_icub(C.byref(self.task), C.c_int(task), C.c_int(1 if control_arm == "r" else 0), C.c_int(use_ik),
+                               C.c_int(control_orientation), ctrl, home, C.c_int(self.ndof))
 
     def _a(self, x):
         return np.ascontiguousarray(x, dtype=self.np_real)
@@ -138,7 +149,7 @@ class Oracle:
         return st, r.value, d.value
 
     def batch_reset(self, n, env_id0=0):
-        st = np.zeros((n, STATE), self.np_real)
+        st = np.zeros((n, self.state_floats), self.np_real)
         obs = np.zeros((n, self.obs_dim), self.np_real)
         self.lib.orc_batch_reset(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_int(n),
                                  C.c_uint64(env_id0), self._p(st), self._p(obs))
@@ -168,6 +179,14 @@ class Oracle:
         out = (C.c_uint32 * 4)()
         self.lib.orc_philox4x32(*[C.c_uint32(x) for x in c], *[C.c_uint32(x) for x in k], out)
         return list(out)
+
+
+def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, **kw):
+    from pybullet_robot_envs.model.table import icub_table
+    tbl, model, info = icub_table(control_arm)
+    o = Oracle(tbl, task=task, **kw)
+    o.set_icub(info, task, control_arm, use_ik, control_orientation)
+    return o, tbl, info
 
 
 def panda_oracle(**kw):

@@ -19,3 +19,10 @@ m = urdf.parse_urdf(src, base_position=(0.0, 0.0, 0.625))
 dst = os.path.join(ROOT, "pybullet-robot-envs_amd/pybullet_robot_envs/robot_data/franka_panda/panda_model.json")
 table.save_model_json(m, dst)
 print("wrote", dst, "links:", [l["name"] for l in m["links"]])
+
+from pybullet_robot_envs.model import sdf  # noqa: E402
+src = os.path.join(ref, "pybullet_robot_envs/robot_data/iCub/icub_model.sdf")
+m = sdf.parse_sdf(src)
+dst = os.path.join(ROOT, "pybullet-robot-envs_amd/pybullet_robot_envs/robot_data/iCub/icub_model.json")
+table.save_model_json(m, dst)
+print("wrote", dst, "links:", len(m["links"]), "dof:", sum(1 for l in m["links"] if l["jtype"]))

@@ -63,25 +63,39 @@ out = {}
 rng = np.random.default_rng(2024)
 
 
+def _extras(env, s):
+    """task fields of the state record (X block) that live in the reference's Python objects"""
+    ox = p.W.ox
+    s[ox + 3] = env._env_step_counter
+    s[ox + 4] = float(bool(env.terminated))
+    if getattr(env, "_use_IK", 0):
+        hp = list(env._hand_pose)
+        if len(hp) < 6:                       # iCub, control_orientation=0: the commanded pose shrinks to the position
+            hp = hp + list(env._robot._home_hand_pose[3:6])
+        s[ox + 6:ox + 12] = hp
+    if hasattr(env, "_init_dist_hand_obj"):
+        s[ox + 12], s[ox + 13] = env._init_dist_hand_obj, env._max_dist_obj_tg
+    return s
+
+
 def rollout(env, tag, actions, goal=False, set_target=None):
     builtins.print = lambda *a, **k: None
     o0 = env.reset()
+    ox = p.W.ox
+    tg_attr = "_tg_pose" if hasattr(env, "_tg_pose") else "_target_pose"
     if set_target is not None:
-        env._target_pose = tuple(set_target)
-        p.W.state[32:35] = set_target
+        setattr(env, tg_attr, tuple(set_target))
+        p.W.state[ox:ox + 3] = set_target
+        if hasattr(env, "_max_dist_obj_tg"):
+            env._max_dist_obj_tg = float(np.linalg.norm(np.array(env._world.get_observation()[0][:3]) - np.array(set_target)))
     else:
-        p.W.state[32:35] = getattr(env, "_target_pose", (0, 0, 0))
-    out[tag + "_reset_state"] = p.W.state.copy()
-    if getattr(env, "_use_IK", 0):
-        out[tag + "_reset_state"][38:44] = env._hand_pose
+        p.W.state[ox:ox + 3] = getattr(env, tg_attr, (0, 0, 0))
+    out[tag + "_reset_state"] = _extras(env, p.W.state.copy())
+    out[tag + "_reset_state"][ox + 3:ox + 5] = 0
     out[tag + "_reset_obs"] = np.asarray(o0["observation"] if goal else o0, dtype=np.float64)
     pre, obs, rew, done, cnt, succ, raw = [], [], [], [], [], [], []
     for a in actions:
-        s = p.W.state.copy()
-        s[35] = env._env_step_counter
-        s[36] = float(bool(env.terminated))
-        if getattr(env, "_use_IK", 0):
-            s[38:44] = env._hand_pose
+        s = _extras(env, p.W.state.copy())
         pre.append(s)
         o, r, d, info = env.step(a.copy())
         obs.append(np.asarray(o["observation"] if goal else o, dtype=np.float64))
@@ -150,3 +164,45 @@ print("wrote", dst, "with", len(out), "arrays;", os.path.getsize(dst), "bytes")
 print("pushA reward/done:", out["pushA_reward"], out["pushA_done"])
 print("pushB done:", out["pushB_done"], "counter", out["pushB_counter"])
 print("reachC done:", out["reachC_done"], "goalD done", out["goalD_done"], out["goalD_reward"], "goalE", out["goalE_done"], out["goalE_reward"])
+
+# ---------------------------------------------------------------------------------------------- iCub
+builtins.print = lambda *a, **k: None
+from pybullet_robot_envs.envs.icub_envs.icub_reach_gym_env import iCubReachGymEnv  # noqa: E402
+from pybullet_robot_envs.envs.icub_envs.icub_push_gym_env import iCubPushGymEnv  # noqa: E402
+from pybullet_robot_envs.envs.icub_envs.icub_push_gym_goal_env import iCubPushGymGoalEnv  # noqa: E402
+builtins.print = _print
+out = {}
+rng = np.random.default_rng(77)
+# G: iCubReach-v0 kwargs (R/__init__.py:7-17): IK position control of the left hand, action dim 3
+envG = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, max_steps=5)
+spaces_of(envG, "reach")
+actG = rng.uniform(-1, 1, (9, 3)); actG[2:5, 2] = -1.0
+rollout(envG, "reachG", actG)
+# H: iCubPush-v0 kwargs: reward_type 0
+envH = iCubPushGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0, max_steps=1000, reward_type=0)
+spaces_of(envH, "push")
+rollout(envH, "pushH", rng.uniform(-1, 1, (5, 3)), set_target=(0.33, 0.2, 0.64999))
+# I: normalised reward (default reward_type=1), right arm, orientation control: action dim 6, Euler limits of the right arm
+envI = iCubPushGymEnv(use_IK=1, control_arm='r', control_orientation=1, max_steps=6, reward_type=1)
+spaces_of(envI, "pushr")
+actI = rng.uniform(-1, 1, (10, 6)); actI[3:7, 5] = -1.0
+rollout(envI, "pushI", actI, set_target=(0.33, -0.2, 0.64999))
+# J: joint control (use_IK=0): action dim 10 = torso + left arm
+envJ = iCubPushGymEnv(use_IK=0, control_arm='l', max_steps=1000, reward_type=1)
+spaces_of(envJ, "pushj")
+rollout(envJ, "pushJ", rng.uniform(-1, 1, (6, 10)), set_target=(0.33, 0.2, 0.64999))
+# K: goal env (iCubPushGoal-v0 kwargs: right arm, orientation control)
+envK = iCubPushGymGoalEnv(use_IK=1, control_arm='r', control_orientation=1, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0, max_steps=4)
+spaces_of(envK, "goal", goal=True)
+rollout(envK, "goalK", rng.uniform(-1, 1, (8, 6)), goal=True, set_target=(0.33, -0.2, 0.64999))
+rollout(envK, "goalL", rng.uniform(-1, 1, (3, 6)), goal=True)
+out["joints_to_control_l"] = np.array(envJ._robot._joints_to_control)
+out["joints_to_control_r"] = np.array(envI._robot._joints_to_control)
+out["end_eff_idx"] = np.array([envJ._robot.end_eff_idx, envI._robot.end_eff_idx])
+out["home_hand_pose_l"] = np.array(envG._robot._home_hand_pose, dtype=np.float64)
+out["home_hand_pose_r"] = np.array(envI._robot._home_hand_pose, dtype=np.float64)
+dst = os.path.join(ROOT, "tests", "golden", "icub_glue.npz")
+np.savez_compressed(dst, **out)
+print("wrote", dst, "with", len(out), "arrays;", os.path.getsize(dst), "bytes")
+print("reachG done", out["reachG_done"], out["reachG_counter"], "pushH rew", out["pushH_reward"], "pushI rew", out["pushI_reward"], out["pushI_done"])
+print("goalK", out["goalK_done"], out["goalK_reward"], "goalL", out["goalL_done"], out["goalL_success"])

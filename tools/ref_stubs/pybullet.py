@@ -25,7 +25,23 @@ def _load(name, rel):
 
 
 _urdf = _load("pbre_model_urdf", "model/urdf.py")
+sys.modules.setdefault("pybullet_robot_envs_model_urdf_for_stub", _urdf)
 _table = _load("pbre_model_table", "model/table.py")
+
+
+def _load_sdf():
+    # model/sdf.py imports `pybullet_robot_envs.model.urdf`; while capturing, that package name is the reference's, so
+    # the two helpers it needs are injected instead
+    src = open(os.path.join(ROOT, "pybullet-robot-envs_amd", "pybullet_robot_envs", "model", "sdf.py")).read()
+    src = src.replace("from pybullet_robot_envs.model.urdf import rpy_to_matrix, JOINT_FIXED, JOINT_REVOLUTE, JOINT_PRISMATIC", "")
+    mod = type(sys)("pbre_model_sdf")
+    mod.rpy_to_matrix = _urdf.rpy_to_matrix
+    mod.JOINT_FIXED, mod.JOINT_REVOLUTE, mod.JOINT_PRISMATIC = _urdf.JOINT_FIXED, _urdf.JOINT_REVOLUTE, _urdf.JOINT_PRISMATIC
+    exec(compile(src, "sdf.py", "exec"), mod.__dict__)
+    return mod
+
+
+_sdf = _load_sdf()
 
 DIRECT, GUI, SHARED_MEMORY = 2, 1, 3
 POSITION_CONTROL, VELOCITY_CONTROL, TORQUE_CONTROL = 2, 0, 1
@@ -47,13 +63,21 @@ class _World(object):
         self.next_id = 0
         self.oracle = None
         self.model = None
-        self.state = np.zeros(48)
-        self.state[15] = 1.0
+        self.set_layout(9)
         self.has_object = False
-        self.q_des = np.zeros(9)
-        self.kp = np.zeros(9)
-        self.kd = np.ones(9)
         self.steps = 0
+        self.control_arm = "l"
+
+    def set_layout(self, nd):
+        """state record layout of the oracle (oracle/pbre_oracle.h): Q | V | X"""
+        self.nd = nd
+        self.w = 16 if nd <= 9 else 64
+        self.ov, self.ox = self.w, 2 * self.w
+        self.state = np.zeros(2 * self.w + 16)
+        self.state[nd + 6] = 1.0
+        self.q_des = np.zeros(nd)
+        self.kp = np.zeros(nd)
+        self.kd = np.ones(nd)
 
 
 W = _World()
@@ -97,8 +121,7 @@ def loadURDF(path, basePosition=(0, 0, 0), baseOrientation=(0, 0, 0, 1), useFixe
         tbl = _table.build_table(model, _table.PANDA_SPHERES, ee_link=names.index("panda_grasptarget"))
         W.oracle = orc.Oracle(tbl, task=1)
         W.model = model
-        W.state[:9] = 0
-        W.state[16:25] = 0
+        W.set_layout(9)
         W.bodies[bid] = "robot"
         W.dof_of_joint = {}
         d = 0
@@ -112,13 +135,60 @@ def loadURDF(path, basePosition=(0, 0, 0), baseOrientation=(0, 0, 0, 1), useFixe
         assert tuple(basePosition) == (0.85, 0.0, 0.0)
         W.bodies[bid] = "table"
     else:
-        assert name == "cube_small.urdf", name
+        # duck_vhacd (iCub reach default, icub_reach_gym_env.py:32) is a pybullet_data mesh that is not available: the
+        # cube stands in for it (the reach task only consumes the object's settled pose)
+        assert name in ("cube_small.urdf", "duck_vhacd.urdf"), name
         W.bodies[bid] = "object"
-        W.state[9:12] = basePosition
-        W.state[12:16] = baseOrientation
-        W.state[25:31] = 0
+        nd = W.nd
+        W.state[nd:nd + 3] = basePosition
+        W.state[nd + 3:nd + 7] = baseOrientation
+        W.state[W.ov + nd:W.ov + nd + 6] = 0
         W.has_object = True
     return bid
+
+
+def loadSDF(path, physicsClientId=0, **k):
+    assert os.path.basename(path) == "icub_model.sdf", path
+    bid = W.next_id
+    W.next_id += 1
+    raw = _sdf.parse_sdf(path)
+    model = _table.pin_base(raw)
+    W.raw_base = (np.asarray(raw["base_position"]) + np.asarray(raw["base_R"]) @ np.asarray(raw["base"]["com"]),
+                  _R_to_quat(np.asarray(raw["base_R"])))
+    W.model = model
+    W.icub_info = {a: _table.icub_info(model, a) for a in ("l", "r")}
+    W.set_layout(32)
+    W.bodies[bid] = "robot"
+    W.dof_of_joint = {}
+    d = 0
+    for i, l in enumerate(model["links"]):
+        if l["jtype"] != 0:
+            W.dof_of_joint[i] = d
+            d += 1
+    W.oracle = None            # built lazily: the end-effector link (control arm) is only known at the first getLinkState / IK
+    return (bid,)
+
+
+def _icub_oracle(ee_link):
+    names = [l["name"] for l in W.model["links"]]
+    arm = names[ee_link][0]
+    if W.oracle is None or W.control_arm != arm or W.oracle.model.ee_link != ee_link:
+        info = W.icub_info[arm]
+        assert info["ee_link"] == ee_link
+        tbl = _table.build_table(W.model, _table.icub_spheres(W.model), ee_link=ee_link)
+        W.oracle = orc.Oracle(tbl, task=1)
+        W.oracle.set_icub(info, 1, arm, 1, 1)
+        W.control_arm = arm
+    return W.oracle
+
+
+def createConstraint(*a, **k):
+    # the fixed base constraint (icub_env.py:97-103) is idealised as a fixed base at its rest pose (model/table.py pin_base)
+    return 0
+
+
+def removeBody(*a, **k):
+    pass
 
 
 def getNumJoints(body, physicsClientId=0):
@@ -135,12 +205,12 @@ def getJointInfo(body, i, physicsClientId=0):
 def resetJointState(body, i, value, physicsClientId=0):
     d = W.dof_of_joint[i]
     W.state[d] = value
-    W.state[16 + d] = 0.0
+    W.state[W.ov + d] = 0.0
 
 
 def setJointMotorControl2(body, i, mode, targetPosition=0.0, positionGain=0.1, velocityGain=1.0, force=None,
                           maxVelocity=None, physicsClientId=0, **k):
-    assert mode == POSITION_CONTROL and force is None and maxVelocity is None
+    assert mode == POSITION_CONTROL and force is None and (maxVelocity is None or maxVelocity == -1)
     d = W.dof_of_joint[i]
     W.q_des[d] = targetPosition
     W.kp[d] = positionGain
@@ -153,16 +223,22 @@ def setJointMotorControlArray(bodyUniqueId, jointIndices, controlMode, targetPos
         setJointMotorControl2(bodyUniqueId, i, controlMode, targetPosition=t, positionGain=kp_, velocityGain=kd_)
 
 
-def calculateInverseKinematics(body, ee, pos, orn, maxNumIterations=20, residualThreshold=1e-4, physicsClientId=0, **k):
-    o = W.oracle
+def calculateInverseKinematics(body, ee, pos, orn, maxNumIterations=20, residualThreshold=1e-4, physicsClientId=0,
+                               jointDamping=None, **k):
+    o = W.oracle if W.nd == 9 else _icub_oracle(ee)
     o.task.ik_max_iters = maxNumIterations
     o.task.ik_residual = residualThreshold
-    q, _ = o.ik(W.state[:9], pos, getEulerFromQuaternion(orn))
+    off = np.array(o.task.ik_link_offset[:])
+    o.task.ik_link_offset[:] = [0.0, 0.0, 0.0]          # the caller already passes the LINK pose (icub_env.py:300-305)
+    q, _ = o.ik(W.state[:W.nd], pos, getEulerFromQuaternion(orn))
+    o.task.ik_link_offset[:] = list(off)
     return tuple(q)
 
 
 def stepSimulation(physicsClientId=0):
     o = W.oracle
+    if o is None:
+        o = _icub_oracle(W.icub_info["l"]["ee_link"])
     o.params.flags = 0 if W.has_object else orc.F_NO_OBJECT
     W.state, _ = o.sim_step(W.state, W.q_des, W.kp, W.kd)
     W.steps += 1
@@ -188,9 +264,9 @@ def _R_to_quat(R):
 
 
 def getLinkState(body, link, computeLinkVelocity=0, computeForwardKinematics=0, physicsClientId=0):
-    o = W.oracle
+    o = W.oracle if W.nd == 9 else _icub_oracle(link)
     m = o.model
-    R, p = o.fk(W.state[:9])
+    R, p = o.fk(W.state[:W.nd])
     com = p[link] + R[link] @ np.array(m.com[link])
     quat = _R_to_quat(R[link])
     v = np.zeros(3)
@@ -199,7 +275,7 @@ def getLinkState(body, link, computeLinkVelocity=0, computeForwardKinematics=0, 
     while k >= 0:
         if m.jtype[k] != 0:
             aw = R[k] @ np.array(m.axis[k])
-            qd = W.state[16 + m.dof[k]]
+            qd = W.state[W.ov + m.dof[k]]
             if m.jtype[k] == 1:
                 v += np.cross(aw, com - p[k]) * qd
                 w += aw * qd
@@ -210,7 +286,7 @@ def getLinkState(body, link, computeLinkVelocity=0, computeForwardKinematics=0, 
 
 
 def getJointStates(body, ids, physicsClientId=0):
-    return [(W.state[W.dof_of_joint[i]], W.state[16 + W.dof_of_joint[i]], (0,) * 6, 0.0) for i in ids]
+    return [(W.state[W.dof_of_joint[i]], W.state[W.ov + W.dof_of_joint[i]], (0,) * 6, 0.0) for i in ids]
 
 
 def getJointState(body, i, physicsClientId=0):
@@ -219,7 +295,9 @@ def getJointState(body, i, physicsClientId=0):
 
 def getBasePositionAndOrientation(body, physicsClientId=0):
     if W.bodies.get(body) == "object":
-        return tuple(W.state[9:12]), tuple(W.state[12:16])
+        return tuple(W.state[W.nd:W.nd + 3]), tuple(W.state[W.nd + 3:W.nd + 7])
+    if W.nd != 9:
+        return tuple(W.raw_base[0]), tuple(W.raw_base[1])
     return (0.0, 0.0, 0.625), (0, 0, 0, 1)
 
 
