@@ -12,10 +12,12 @@
  * thread at a time and is bound to one GPU (one process per GPU; multi-GPU sharding is
  * done above this ABI with one ctx per rank and env_id_base = rank * num_envs).
  *
- * Per-env state record: 48 floats (three 16-float lane records):
- *   Q[0..8]  joint positions          Q[9..11]  object position   Q[12..15] object quaternion (x,y,z,w)
- *   V[0..8]  joint velocities         V[9..11]  object lin. vel.  V[12..14] object ang. vel.  V[15] 0
- *   X[0..2]  push target              X[3] step counter  X[4] terminated flag  X[5] episode  X[6..15] reserved
+ * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
+ * (Panda: 48 floats), W = 64 otherwise (iCub: 144 floats); nd = number of DoF:
+ *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
+ *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
+ *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
+ *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14..15] reserved
  *
  * RobotTable (pbre_config.robot_table): float64 array, little endian
  *   [0] magic 1346523717 ('PBRE')  [1] version 1  [2] n_links  [3] n_dof  [4] ee_link  [5] n_spheres
@@ -34,10 +36,11 @@
 extern "C" {
 #endif
 
-#define PBRE_STATE_FLOATS 48
+#define PBRE_STATE_FLOATS 48       /* Panda; see pbre_state_floats() */
 
 enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
-enum { PBRE_ROBOT_PANDA = 0 };
+enum { PBRE_ROBOT_PANDA = 0,
+       PBRE_ROBOT_ICUB = 1 };     /* icub_model.sdf, 32 DoF: observation / reward / reset variants of R/envs/icub_envs */
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
@@ -67,10 +70,10 @@ typedef struct {
     uint64_t env_id_base;      /* global id of local env 0: RNG streams are keyed by global id, so results do
                                   not depend on how the batch is sharded */
     uint64_t seed;
-    int32_t use_ik;            /* 0: joint control (R/__init__.py:62).  1: Cartesian control through inverse kinematics with
-                                  control_orientation=1 / Euler angles (pandaEnv defaults): act_dim = 6
-                                  (dx,dy,dz,droll,dpitch,dyaw), R/envs/panda_envs/panda_push_gym_env.py:197-222 */
-    int32_t num_controlled_joints;   /* 7 */
+    int32_t use_ik;            /* 0: joint control (R/__init__.py:62).  1: Cartesian control through inverse kinematics, Euler
+                                  angles: act_dim = 6 (dx,dy,dz,droll,dpitch,dyaw) with control_orientation=1
+                                  (R/envs/panda_envs/panda_push_gym_env.py:197-222), 3 (dx,dy,dz) with 0 (iCub ids) */
+    int32_t num_controlled_joints;   /* joints driven by the action in joint mode: 7 Panda, 10 iCub (torso + arm) */
     int32_t action_repeat;     /* 1 */
     int32_t max_steps;         /* 1000 */
     int32_t flags;             /* PBRE_F_* */
@@ -80,12 +83,19 @@ typedef struct {
     double  kp_act, kd_act, kp_hold, kd_hold;
     double  ws_lim[3][2];      /* world (object) workspace, world_env.py:72 */
     double  h_table;
-    double  home[16];          /* initial joint positions, panda_env.py:19-23 */
+    double  home[40];          /* initial joint positions per DoF, panda_env.py:19-23 / icub_env.py:19-41 */
     pbre_physics phys;
     /* use_ik = 1: damped-least-squares IK (replaces p.calculateInverseKinematics, panda_env.py:269-272) */
     double  ik_damping, ik_residual; int32_t ik_max_iters;   /* 0.1 [EXT-UNVERIFIED], 1e-3, 100 */
     double  home_hand_pose[6];  /* panda_env.py:85-88 */
     double  robot_ws[3][2];     /* robot workspace used to clip the hand pose (panda_env.py:37, z-min set by the task env) */
+    int32_t control_orientation;/* IK mode: 1 = the action carries droll,dpitch,dyaw; 0 = home orientation is kept (icub_env.py:281-283) */
+    int32_t reward_type;        /* iCub push: 0 / 1 (icub_push_gym_env.py:353-373) */
+    int32_t num_joints_ctrl;    /* controlled joints = observed joints of the iCub (10); Panda: = num_controlled_joints */
+    int32_t act_dof[16];        /* DoF index of controlled joint k, in the reference's _joints_to_control order (icub_env.py:127-138) */
+    double  ik_pos_scale, ik_rot_scale;   /* hand-pose increment per unit action (panda_push_gym_env.py:200-203; icub_reach_gym_env.py:206-212) */
+    double  eu_lim[3][2];       /* Euler limits of the commanded hand orientation (panda_env.py:38, icub_env.py:63-74) */
+    double  ik_link_offset[3];  /* hand COM frame -> hand link frame (icub_env.py:252-258); 0 for the Panda */
     const double* robot_table; size_t robot_table_len;   /* number of doubles */
 } pbre_config;
 
@@ -99,6 +109,8 @@ void pbre_destroy(pbre_ctx* ctx);
 const char* pbre_last_error(const pbre_ctx* ctx);   /* borrowed; ctx may be NULL for create errors */
 
 int pbre_dims(const pbre_ctx* ctx, int32_t* obs_dim, int32_t* act_dim, int32_t* num_envs);
+/* floats per env state record (48 Panda, 144 iCub) */
+int pbre_state_floats(const pbre_ctx* ctx);
 
 /* replaces: pandaPushGymEnv.reset -> reset_simulation (panda_push_gym_env.py:105-148: resetSimulation,
  * robot.reset, 100 x stepSimulation, world.reset incl. WorldEnv._sample_pose (world_env.py:145-176),
@@ -120,7 +132,7 @@ int pbre_step(pbre_ctx* ctx, const float* actions, float* out);
 int pbre_step_device(pbre_ctx* ctx, const float* d_actions, float* d_out, void* stream);
 int pbre_sync(pbre_ctx* ctx);
 
-/* raw simulator state, host [num_envs][PBRE_STATE_FLOATS] float32 (parity tests, checkpoint/restore) */
+/* raw simulator state, host [num_envs][pbre_state_floats()] float32 (parity tests, checkpoint/restore) */
 int pbre_get_state(pbre_ctx* ctx, float* state);
 int pbre_set_state(pbre_ctx* ctx, const float* state);
 /* recompute the observation of the current state (replaces get_extended_observation, :150-187) */

@@ -18,6 +18,9 @@ struct DevLanes {
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 15u]; }
     static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 15u]; }
     static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 15u] : 0.f; }
+    static __device__ __forceinline__ F loadu(const float* p) { return *p; }                       // group-uniform address
+    static __device__ __forceinline__ F loadx(const float* p, I idx, B m) { return m ? p[idx] : 0.f; }
+    static __device__ __forceinline__ void storex(float* p, I idx, F x, B m) { if (m) p[idx] = x; }
     static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 15u] = x; }
     static __device__ __forceinline__ void storem(float* p, F x, B m) { if (m) p[threadIdx.x & 15u] = x; }
     static __device__ __forceinline__ F abs(F x) { return __builtin_fabsf(x); }

@@ -1,12 +1,12 @@
 // pbre_core.hpp -- the env.step() hot path, written once against a "lane backend" L.
 //
-// Mapping: one environment = one 16-lane DPP row of a wavefront; a wave owns
-// 4 consecutive envs.  Lane k of a group owns generalized coordinate k:
-//     lanes 0..8   robot joints (7 arm + 2 fingers)        -- link/joint data of link k
-//     lanes 9..11  object linear velocity x,y,z            lanes 12..14 object angular velocity
-//     lane  15     constant 1 (carries -rhs of a contact row through the row dot product)
-// All solver data lives in VGPRs; cross-lane traffic is DPP (row all-reduce) and
-// ds_bpermute (broadcast/gather inside the row).  No LDS allocation, no scratch.
+// Mapping: one environment = one lane group of shape S (pbre_tables.hpp): a 16-lane DPP row for the
+// Panda (4 envs per wave), a whole 64-lane wave for the iCub.  Lane k of a group owns generalized coordinate k:
+//     lanes 0..NJ-1     robot joints                         -- link/joint data of link k
+//     lanes LC..LC+2    object linear velocity x,y,z         lanes LC+3..LC+5 object angular velocity
+//     lane  L1          constant 1 (carries -rhs of a contact row through the row dot product)
+// All solver data lives in VGPRs; cross-lane traffic is DPP (all-reduce) and ds_bpermute / v_readlane
+// (broadcast/gather inside the group).  No LDS allocation, no scratch.
 //
 // L provides: F (float per lane), I (int per lane), B (predicate per lane) and the ops used
 // below.  Device backend: lanes_device.hpp (F = float).  Host backend (CPU tests only):
@@ -32,11 +32,13 @@
 
 namespace pbre {
 
-template <class L>
+template <class L, class SH = Shape16>
 struct Core {
     using F = typename L::F;
     using I = typename L::I;
     using B = typename L::B;
+    using Tables = TablesT<SH>;
+    static constexpr int W = SH::W, NJ = SH::NJ, LC = SH::LC, L1 = SH::L1, NSUB = SH::NSUB, NLEV = SH::NLEV, STATE = SH::STATE;
 
     struct V3 { F x, y, z; };
     struct Q4 { F x, y, z, w; };
@@ -269,7 +271,7 @@ struct Core {
         F lm = L::vmin(lk);
         Contact c;
         c.act = L::lt(lm, L::c(98.f));
-        I src = L::ftoi(L::min(lm, L::c(15.f)));
+        I src = L::ftoi(L::min(lm, L::c((float)(W - 1))));
         c.n = bcastvI(n, src); c.pA = bcastvI(pA, src); c.pB = bcastvI(pB, src);
         c.dist = L::gather(dist, src); c.mu = L::gather(mu, src);
         c.owner = L::gatherI(owner, src);
@@ -278,14 +280,14 @@ struct Core {
 
     // ---------------------------------------------------------------- the step
     // mode bits
-    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8 };
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8, M_INITD = 16 };
 
     struct Rows {             // register-resident solver data
         F Mi[NJ];             // row of M^-1 (lane k: Minv[k][j])
         F m_dinv, m_rhs;      // motor row owned by this lane (rhs already multiplied by dinv)
         F l_j, l_rhs;         // limit row owned by this lane: J' = dir*dinv (0 if inactive), rhs'
         F l_dir;
-        F m_app[NJ], l_app[NJ];
+        F m_app, l_app;       // applied impulse of the motor / limit row this lane owns
         F Jn[NC], Bn[NC], an[NC];
         F J1[NC], B1[NC], a1[NC];
         F J2[NC], B2[NC], a2[NC];
@@ -320,7 +322,7 @@ struct Core {
         const bool obj_on = !(flags & 1);
         const F dt = L::c(P.dt), inv_dt = L::c(P.inv_dt);
 
-        F Qr = L::load(st), Vr = L::load(st + 16), Xr = L::load(st + 32);
+        F Qr = L::load(st), Vr = L::load(st + W), Xr = L::loadm(st + 2 * W, L::lti(lane, 16));
         F q = L::sel(robot, Qr, zero);
 
         // ---- motor targets (apply_action): q_des = clip(q + 0.05 a, ll, ul) for actuated lanes, else hold at home
@@ -328,18 +330,19 @@ struct Core {
         F qdes = L::load(T.home), kp = L::load(T.kp_hold), kd = L::load(T.kd_hold);
         if (mode & M_TGT) qdes = L::loadm(tgt, robot);     // IK mode: targets from the IK buffer, hold gains
         if (mode & M_ACTION) {
-            B al = L::lti(lane, T.n_act);
-            F a = L::loadm(act, al);
+            I ai = L::loadI(T.act_idx);
+            B al = L::gei(ai, 0);
+            F a = L::loadx(act, ai, al);
             F tgt = clampf(L::fma(a, L::c(P.act_scale), q), lower, upper);
             qdes = L::sel(al, tgt, qdes);
             kp = L::load(T.kp_act); kd = L::load(T.kd_act);
         }
 
         // ---- object pose/twist as group-uniform values
-        V3 op = v3(L::bcast(Qr, 9), L::bcast(Qr, 10), L::bcast(Qr, 11));
-        Q4 oq; oq.x = L::bcast(Qr, 12); oq.y = L::bcast(Qr, 13); oq.z = L::bcast(Qr, 14); oq.w = L::bcast(Qr, 15);
-        V3 ov = v3(L::bcast(Vr, 9), L::bcast(Vr, 10), L::bcast(Vr, 11));
-        V3 ow = v3(L::bcast(Vr, 12), L::bcast(Vr, 13), L::bcast(Vr, 14));
+        V3 op = v3(L::bcast(Qr, LC), L::bcast(Qr, LC + 1), L::bcast(Qr, LC + 2));
+        Q4 oq; oq.x = L::bcast(Qr, LC + 3); oq.y = L::bcast(Qr, LC + 4); oq.z = L::bcast(Qr, LC + 5); oq.w = L::bcast(Qr, LC + 6);
+        V3 ov = v3(L::bcast(Vr, LC), L::bcast(Vr, LC + 1), L::bcast(Vr, LC + 2));
+        V3 ow = v3(L::bcast(Vr, LC + 3), L::bcast(Vr, LC + 4), L::bcast(Vr, LC + 5));
         M3 Ro = quat_R(oq);
 
         // ---- kinematics at q_t
@@ -455,8 +458,6 @@ struct Core {
             vobj = clampf(vobj, zero - vmax, vmax);
         }
         vstar = L::sel(robot, vstar, vobj);                 // generalized v* of all 15 DoF (lane 15: 0)
-        V3 ovs = v3(L::bcast(vstar, 9), L::bcast(vstar, 10), L::bcast(vstar, 11));
-        V3 ows = v3(L::bcast(vstar, 12), L::bcast(vstar, 13), L::bcast(vstar, 14));
 
         // ---- collision detection at q_t
         const F margin = L::c(P.margin);
@@ -518,7 +519,7 @@ struct Core {
             R.l_dir = dir;
             R.l_j = dir * dinv;                            // J' = dir * dinv (dir^2 = 1 so dinv is unchanged)
             R.l_rhs = L::sel(L::bor(lo_v, up_v), (zero - pen * L::c(P.erp) * inv_dt - dir * vstar) * dinv, zero);
-            PBRE_UNROLL for (int j = 0; j < NJ; j++) { R.m_app[j] = zero; R.l_app[j] = zero; }
+            R.m_app = zero; R.l_app = zero;
         }
         const B any_limit = L::ne(R.l_dir, zero);
         // contacts
@@ -588,19 +589,21 @@ struct Core {
         // ---- projected Gauss-Seidel (Bullet order: non-contact rows alternate direction, normals, frictions)
         F dv = L::sel(L::eqi(lane, L1), one, zero);
         const F mlim = L::c(P.motor_imp), llim = L::c(P.limit_imp), big = L::c(1e10f);
+        // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
+        // applied (Gauss-Seidel order is kept by the sequence of calls)
         auto motor = [&](int j) {
-            F x = L::sel(L::eqi(lane, j), L::fma(R.m_dinv, dv, zero - R.m_rhs), zero);
-            F t = L::sum(x);
-            F s = L::med3(R.m_app[j] - t, zero - mlim, mlim);
-            F d = s - R.m_app[j]; R.m_app[j] = s;
-            dv = L::fma(d, R.Mi[j], dv);
+            F t = L::fma(R.m_dinv, dv, zero - R.m_rhs);
+            F s = L::med3(R.m_app - t, zero - mlim, mlim);
+            F d = s - R.m_app;
+            R.m_app = L::sel(L::eqi(lane, j), s, R.m_app);
+            dv = L::fma(L::bcast(d, j), R.Mi[j], dv);
         };
         auto limit = [&](int j) {
-            F x = L::sel(L::eqi(lane, j), L::fma(R.l_j, dv, zero - R.l_rhs), zero);
-            F t = L::sum(x);
-            F s = L::med3(R.l_app[j] - t, zero, llim);
-            F d = s - R.l_app[j]; R.l_app[j] = s;
-            dv = L::fma(d * L::bcast(R.l_dir, j), R.Mi[j], dv);
+            F t = L::fma(R.l_j, dv, zero - R.l_rhs);
+            F s = L::med3(R.l_app - t, zero, llim);
+            F d = s - R.l_app;
+            R.l_app = L::sel(L::eqi(lane, j), s, R.l_app);
+            dv = L::fma(L::bcast(d * R.l_dir, j), R.Mi[j], dv);
         };
         auto contacts = [&]() {
             PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) row(R.Jn[c], R.Bn[c], R.an[c], zero, big, dv);
@@ -630,7 +633,7 @@ struct Core {
         B posl = obj_on ? L::lti(lane, LC + 3) : robot;
         F Qn = L::sel(posl, L::fma(dt, vnew, Qr), Qr);
         if (obj_on) {
-            V3 wn = v3(L::bcast(vnew, 12), L::bcast(vnew, 13), L::bcast(vnew, 14));
+            V3 wn = v3(L::bcast(vnew, LC + 3), L::bcast(vnew, LC + 4), L::bcast(vnew, LC + 5));
             F ang = norm(wn);
             F cap = L::c(0.78539816339744831f) * inv_dt;
             ang = L::sel(L::gt(ang * dt, L::c(0.78539816339744831f)), cap, ang);
@@ -639,10 +642,10 @@ struct Core {
             Q4 dq; dq.x = wn.x * sc_; dq.y = wn.y * sc_; dq.z = wn.z * sc_; dq.w = L::cos(ang * dt * L::c(0.5f));
             Q4 nq = qmul(dq, oq);
             F in = one / L::sqrt(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
-            F qc = L::sel(L::eqi(lane, 12), nq.x, L::sel(L::eqi(lane, 13), nq.y, L::sel(L::eqi(lane, 14), nq.z, nq.w)));
-            Qn = L::sel(L::gei(lane, 12), qc * in, Qn);
+            F qc = L::sel(L::eqi(lane, LC + 3), nq.x, L::sel(L::eqi(lane, LC + 4), nq.y, L::sel(L::eqi(lane, LC + 5), nq.z, nq.w)));
+            Qn = L::sel(L::band(L::gei(lane, LC + 3), L::lti(lane, LC + 7)), qc * in, Qn);
         }
-        L::store(st, Qn); L::store(st + 16, Vn);
+        L::store(st, Qn); L::store(st + W, Vn);
 
         if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode);
     }
@@ -664,8 +667,8 @@ struct Core {
         V3 ee = add(pe, mv(Re, v3(L::c(T.ee_p[0]), L::c(T.ee_p[1]), L::c(T.ee_p[2]))));
         V3 vee = add(bcastv(Vs.l, eo), cross(bcastv(Vs.a, eo), ee));
         V3 eul = quat_euler(R_quat(Ree));
-        V3 op = v3(L::bcast(Qn, 9), L::bcast(Qn, 10), L::bcast(Qn, 11));
-        Q4 oq; oq.x = L::bcast(Qn, 12); oq.y = L::bcast(Qn, 13); oq.z = L::bcast(Qn, 14); oq.w = L::bcast(Qn, 15);
+        V3 op = v3(L::bcast(Qn, LC), L::bcast(Qn, LC + 1), L::bcast(Qn, LC + 2));
+        Q4 oq; oq.x = L::bcast(Qn, LC + 3); oq.y = L::bcast(Qn, LC + 4); oq.z = L::bcast(Qn, LC + 5); oq.w = L::bcast(Qn, LC + 6);
         V3 oe = quat_euler(oq);
         // object pose in the hand frame via the Euler round trip the reference performs (panda_push_gym_env.py:168-174)
         Q4 qh = euler_quat(eul), qo = euler_quat(oe);
@@ -673,9 +676,16 @@ struct Core {
         Q4 qhi; qhi.x = zero - qh.x; qhi.y = zero - qh.y; qhi.z = zero - qh.z; qhi.w = qh.w;
         V3 er = quat_euler(qmul(qhi, qo));
         V3 tg = v3(L::bcast(Xr, 0), L::bcast(Xr, 1), L::bcast(Xr, 2));
-        V3 vn = v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
+        // Panda: normalised EE velocity (panda_env.py:174-178); iCub: raw (icub_env.py:233-236)
+        V3 vn = P.robot == 1 ? vee : v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
 
         F reward = zero, done = zero;
+        if (mode & M_INITD) {
+            // iCubPushGymEnv.reset (icub_push_gym_env.py:124-127): distances the normalised reward divides by
+            F d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
+            F Xn = L::sel(L::eqi(lane, 12), d1, L::sel(L::eqi(lane, 13), d2, Xr));
+            L::storem(st + 2 * W, Xn, L::lti(lane, 16));
+        }
         if (mode & M_TASK) {
             // _termination + counter (panda_push_gym_env.py:239-242, 301-316) and _compute_reward (:318-331)
             F d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
@@ -696,20 +706,32 @@ struct Core {
                 B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
                 done = L::sel(dn, one, zero);
                 F base = P.task == 1 ? zero - d1 - d2 : zero - d1;
+                if (P.robot == 1) {
+                    // iCub (icub_reach_gym_env.py:318-330: the bonus is added; icub_push_gym_env.py:346-373: reward types 0 / 1)
+                    if (P.task == 0) reward = base + L::sel(succ, L::c(1000.f) + (L::c(100.f) - d1 * L::c(80.f)), zero);
+                    else {
+                        if (P.reward_type != 0) {
+                            F r1 = L::c(0.125f) * (one - d1 / L::bcast(Xr, 12));
+                            F r2 = L::c(0.25f) * (one - d2 / L::bcast(Xr, 13));
+                            base = r1 + L::sel(L::gt(d1, L::c(0.1f)), zero, r2);
+                        }
+                        reward = base + L::sel(succ, L::c(1000.f), zero);
+                    }
+                } else
                 reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
             }
             F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, Xr));
-            L::store(st + 32, Xn);
+            L::storem(st + 2 * W, Xn, L::lti(lane, 16));
         }
         if (out) {
             // row-major [obs | reward | done]; obs layout SURVEY Appendix C
-            const int nd = T.ndof;
+            const int nd = T.n_obs_j;
             const int od = 9 + nd + 12 + (P.task >= 1 ? 3 : 0);
             F head = L::sel(L::eqi(lane, 0), ee.x, L::sel(L::eqi(lane, 1), ee.y, L::sel(L::eqi(lane, 2), ee.z,
                      L::sel(L::eqi(lane, 3), eul.x, L::sel(L::eqi(lane, 4), eul.y, L::sel(L::eqi(lane, 5), eul.z,
                      L::sel(L::eqi(lane, 6), vn.x, L::sel(L::eqi(lane, 7), vn.y, vn.z))))))));
             L::storem(out, head, L::lti(lane, 9));
-            L::storem(out + 9, q, L::lti(lane, nd));
+            { I oi = L::loadI(T.obs_idx); L::storex(out + 9, oi, q, L::gei(oi, 0)); }
             float* o2 = out + 9 + nd;
             F tail = L::sel(L::eqi(lane, 0), op.x, L::sel(L::eqi(lane, 1), op.y, L::sel(L::eqi(lane, 2), op.z,
                      L::sel(L::eqi(lane, 3), oe.x, L::sel(L::eqi(lane, 4), oe.y, L::sel(L::eqi(lane, 5), oe.z,
@@ -720,6 +742,100 @@ struct Core {
             F rd = L::sel(L::eqi(lane, 0), reward, done);
             L::storem(out + od, rd, L::lti(lane, 2));
         }
+    }
+
+    // ---------------------------------------------------------------- Cartesian control (use_IK = 1)
+    // apply_action, IK branch (icub_reach_gym_env.py:204-230 + icub_env.py:262-330; panda_push_gym_env.py:197-222 +
+    // panda_env.py:229-291): accumulate the scaled action on the commanded hand pose (X[6..11]), clip rotation and
+    // workspace, then damped-least-squares IK from the current joint angles (restated in oracle/pbre_oracle.c orc_ik:
+    // dq = J^T (J J^T + lambda^2 I)^-1 e over the joints of the chain to the end effector, <= ik_iters iterations, stop
+    // when the position error < ik_res).  Lane k owns Jacobian column k; the 6x6 normal matrix is 21 group all-reduces.
+    // reset: targets of the home hand pose (robot.reset, icub_env.py:147-148).  Writes tgt[0..NJ) and X[6..11].
+    static PBRE_HD void ik_targets(const Tables& T, const Params& P, float* st, const float* act, float* tgt, bool reset) {
+        const I lane = L::lane();
+        const F zero = L::c(0.f), one = L::c(1.f);
+        const B robot = L::lti(lane, NJ);
+        F Qr = L::load(st), Xr = L::loadm(st + 2 * W, L::lti(lane, 16));
+        F q = L::sel(robot, Qr, zero);
+        const F q0 = q;
+        V3 pos, eul;
+        if (reset) {
+            pos = v3(L::c(P.home_hand[0]), L::c(P.home_hand[1]), L::c(P.home_hand[2]));
+            eul = v3(L::c(P.home_hand[3]), L::c(P.home_hand[4]), L::c(P.home_hand[5]));
+        } else {
+            const F ps = L::c(P.ik_ps), rs = L::c(P.ik_rs);
+            pos = v3(L::fma(L::loadu(act), ps, L::bcast(Xr, 6)), L::fma(L::loadu(act + 1), ps, L::bcast(Xr, 7)), L::fma(L::loadu(act + 2), ps, L::bcast(Xr, 8)));
+            eul = v3(L::bcast(Xr, 9), L::bcast(Xr, 10), L::bcast(Xr, 11));
+            if (P.ctrl_ori) {
+                eul.x = clampf(L::fma(L::loadu(act + 3), rs, eul.x), L::c(P.eu_lim[0][0]), L::c(P.eu_lim[0][1]));
+                eul.y = clampf(L::fma(L::loadu(act + 4), rs, eul.y), L::c(P.eu_lim[1][0]), L::c(P.eu_lim[1][1]));
+                eul.z = clampf(L::fma(L::loadu(act + 5), rs, eul.z), L::c(P.eu_lim[2][0]), L::c(P.eu_lim[2][1]));
+            }
+        }
+        V3 cp = pos;                      // the pose handed to the IK; at reset the stored pose stays the unclipped home pose
+        if (!reset || P.robot == 1) {     // pandaEnv.apply_action clips z only (panda_env.py:243-247); the task env / iCub clip x, y, z
+            cp.x = clampf(cp.x, L::c(P.rws[0][0]), L::c(P.rws[0][1]));
+            cp.y = clampf(cp.y, L::c(P.rws[1][0]), L::c(P.rws[1][1]));
+        }
+        cp.z = clampf(cp.z, L::c(P.rws[2][0]), L::c(P.rws[2][1]));
+        if (!reset) pos = cp;
+        {
+            F Xn = L::sel(L::eqi(lane, 6), pos.x, L::sel(L::eqi(lane, 7), pos.y, L::sel(L::eqi(lane, 8), pos.z,
+                   L::sel(L::eqi(lane, 9), eul.x, L::sel(L::eqi(lane, 10), eul.y, eul.z)))));
+            L::storem(st + 2 * W, Xn, L::band(L::gei(lane, 6), L::lti(lane, 12)));
+        }
+        const M3 Rt = quat_R(euler_quat(eul));
+        const V3 tp = add(cp, mv(Rt, v3(L::c(P.ik_off[0]), L::c(P.ik_off[1]), L::c(P.ik_off[2]))));
+        const B chain = L::band(robot, L::biti(L::ci(T.ee_chain), lane));
+        const int eo = T.ee_owner;
+        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = L::c(T.ee_R[k]);
+        const F l2 = L::c(P.ik_l2);
+        for (int it = 0; it < P.ik_iters; it++) {
+            Kin K; fk(T, q, K);
+            M3 Re; PBRE_UNROLL for (int k = 0; k < 9; k++) Re.m[k] = L::bcast(K.R.m[k], eo);
+            const V3 pe = add(bcastv(K.p, eo), mv(Re, v3(L::c(T.ee_lp[0]), L::c(T.ee_lp[1]), L::c(T.ee_lp[2]))));
+            F e[6];
+            { V3 d = sub(tp, pe); e[0] = d.x; e[1] = d.y; e[2] = d.z; }
+            const B go = L::ge(L::sqrt(L::fma(e[0], e[0], L::fma(e[1], e[1], e[2] * e[2]))), L::c(P.ik_res));
+            if (!L::any(go)) break;
+            {   // orientation error as a world-frame rotation vector: axis-angle of Rt (Re Eo)^T
+                const M3 Ree = mm(Re, Eo);
+                M3 Rr;
+                PBRE_UNROLL for (int i = 0; i < 3; i++)
+                    PBRE_UNROLL for (int j = 0; j < 3; j++)
+                        Rr.m[i*3+j] = L::fma(Rt.m[i*3], Ree.m[j*3], L::fma(Rt.m[i*3+1], Ree.m[j*3+1], Rt.m[i*3+2] * Ree.m[j*3+2]));
+                F sx = Rr.m[7] - Rr.m[5], sy = Rr.m[2] - Rr.m[6], sz = Rr.m[3] - Rr.m[1];
+                F s2 = L::sqrt(L::fma(sx, sx, L::fma(sy, sy, sz * sz))) * L::c(0.5f);
+                F c2 = (Rr.m[0] + Rr.m[4] + Rr.m[8] - one) * L::c(0.5f);
+                F ang = L::atan2(s2, c2);
+                F f = L::sel(L::gt(s2, L::c(1e-9f)), ang / (L::c(2.f) * L::max(s2, L::c(1e-30f))), L::c(0.5f));
+                e[3] = f * sx; e[4] = f * sy; e[5] = f * sz;
+            }
+            F J[6];
+            {
+                V3 jl = add(K.S.l, cross(K.S.a, pe));
+                J[0] = L::sel(chain, jl.x, zero); J[1] = L::sel(chain, jl.y, zero); J[2] = L::sel(chain, jl.z, zero);
+                J[3] = L::sel(chain, K.S.a.x, zero); J[4] = L::sel(chain, K.S.a.y, zero); J[5] = L::sel(chain, K.S.a.z, zero);
+            }
+            // A = J J^T + lambda^2 I (symmetric), Cholesky A = G G^T, solve A y = e
+            F G[6][6], y[6];
+            PBRE_UNROLL for (int a = 0; a < 6; a++)
+                PBRE_UNROLL for (int b = 0; b <= a; b++) {
+                    F sum = L::sum(J[a] * J[b]);
+                    if (a == b) sum = sum + l2;
+                    PBRE_UNROLL for (int k = 0; k < b; k++) sum = sum - G[a][k] * G[b][k];
+                    G[a][b] = a == b ? L::sqrt(sum) : sum / G[b][b];
+                }
+            PBRE_UNROLL for (int a = 0; a < 6; a++) { F sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = sum - G[a][k] * y[k]; y[a] = sum / G[a][a]; }
+            PBRE_UNROLL for (int a = 5; a >= 0; a--) { F sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = sum - G[k][a] * y[k]; y[a] = sum / G[a][a]; }
+            F dq = zero;
+            PBRE_UNROLL for (int a = 0; a < 6; a++) dq = L::fma(J[a], y[a], dq);
+            q = L::sel(L::band(go, chain), q + dq, q);
+        }
+        // joints off the chain: the iCub sends them to their rest pose (icub_env.py:316-317), PyBullet returns the Panda's
+        // current finger positions
+        F qdes = L::sel(chain, q, P.robot == 1 ? L::load(T.home) : q0);
+        L::storem(tgt, qdes, robot);
     }
 
     // ---------------------------------------------------------------- reset (initial state before the settle steps)
@@ -736,6 +852,8 @@ struct Core {
 
     // robot.reset + WorldEnv._sample_pose (reference panda_env.py:51-79, world_env.py:145-176): scalar, one call per env
     static PBRE_HD void init_state(const Tables& T, const Params& P, unsigned long long env_id, unsigned episode, float* st) {
+        float* ob = st + LC;                       // object position (3) + quaternion (4) inside the Q record
+        float* X = st + 2 * W;
         for (int k = 0; k < STATE; k++) st[k] = 0.f;
         for (int k = 0; k < T.ndof; k++) st[k] = T.home[k];
         const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
@@ -750,25 +868,28 @@ struct Core {
             py += -P.obj_std + 2.f * P.obj_std * u01(r[1]);
             yaw = -0.78539816339744831f + 1.57079632679489662f * u01(r[2]);
         }
-        st[9] = clamps(px, x_min, x_max); st[10] = clamps(py, y_min, y_max); st[11] = pz;
-        st[12] = 0.f; st[13] = 0.f; st[14] = sinf(0.5f * yaw); st[15] = cosf(0.5f * yaw);
-        st[37] = (float)(int)episode;     // 0xFFFFFFFF marks a record that was never reset (episode -1)
+        ob[0] = clamps(px, x_min, x_max); ob[1] = clamps(py, y_min, y_max); ob[2] = pz;
+        ob[3] = 0.f; ob[4] = 0.f; ob[5] = sinf(0.5f * yaw); ob[6] = cosf(0.5f * yaw);
+        X[5] = (float)(int)episode;       // 0xFFFFFFFF marks a record that was never reset (episode -1)
+        if (P.use_ik) for (int k = 0; k < 6; k++) X[6 + k] = P.home_hand[k];
     }
     // sample_tg_pose (reference panda_push_gym_env.py:333-360) on the settled object position
     static PBRE_HD void sample_target(const Params& P, unsigned long long env_id, unsigned episode, float* st) {
         if (P.task < 1) return;
+        const float* ob = st + LC;
+        float* X = st + 2 * W;
         const float tx_min = P.ws[0][0] + 0.07f, tx_max = P.ws[0][1] - 0.07f;
-        float tx = st[9] + 0.05f, ty = st[10] + 0.05f;
+        float tx = ob[0] + 0.05f, ty = ob[1] + 0.05f;
         if (P.tg_std > 0.f) {
             unsigned r[4];
             philox((unsigned)env_id, (unsigned)(env_id >> 32), episode, 1u, P.seed_lo, P.seed_hi, r);
             const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(r[1]);
             const float rad = sqrtf(-2.f * logf(u1)) * P.tg_std;
-            tx = st[9] + rad * cosf(6.28318530717958648f * u2);
-            ty = st[10] + rad * sinf(6.28318530717958648f * u2);
+            tx = ob[0] + rad * cosf(6.28318530717958648f * u2);
+            ty = ob[1] + rad * sinf(6.28318530717958648f * u2);
         }
-        st[32] = clamps(tx, tx_min, tx_max); st[33] = clamps(ty, P.ws[1][0], P.ws[1][1]); st[34] = st[11];
-        st[35] = 0.f; st[36] = 0.f;
+        X[0] = clamps(tx, tx_min, tx_max); X[1] = clamps(ty, P.ws[1][0], P.ws[1][1]); X[2] = ob[2];
+        X[3] = 0.f; X[4] = 0.f;
     }
 };
 

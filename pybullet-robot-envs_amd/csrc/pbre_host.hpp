@@ -29,7 +29,7 @@ inline void default_physics(pbre_physics& p) {
 }
 
 inline int default_config(pbre_config* c, int robot, int task) {
-    if (!c || robot != PBRE_ROBOT_PANDA || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
+    if (!c || (robot != PBRE_ROBOT_PANDA && robot != PBRE_ROBOT_ICUB) || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
     std::memset(c, 0, sizeof *c);
     c->robot = robot; c->task = task; c->num_envs = 1; c->device_id = 0; c->seed = 1234;
     c->use_ik = 0; c->num_controlled_joints = 7; c->action_repeat = 1; c->max_steps = 1000;
@@ -49,16 +49,53 @@ inline int default_config(pbre_config* c, int robot, int task) {
     for (int k = 0; k < 6; k++) c->home_hand_pose[k] = hh[k];
     c->robot_ws[0][0] = 0.3; c->robot_ws[0][1] = 0.65; c->robot_ws[1][0] = -0.3; c->robot_ws[1][1] = 0.3;   // panda_env.py:37
     c->robot_ws[2][0] = task == PBRE_TASK_REACH ? c->h_table : c->h_table - 0.2; c->robot_ws[2][1] = 1.5;   // panda_reach_gym_env.py:69 / panda_push_gym_env.py:74
+    const double PI = 3.14159265358979323846;
+    c->control_orientation = 1; c->reward_type = 1; c->num_joints_ctrl = 7;
+    for (int k = 0; k < 16; k++) c->act_dof[k] = k < 7 ? k : -1;
+    c->ik_pos_scale = 0.005; c->ik_rot_scale = 0.01;                                // panda_push_gym_env.py:200-203
+    for (int k = 0; k < 3; k++) { c->eu_lim[k][0] = -PI; c->eu_lim[k][1] = PI; }     // panda_env.py:38
+    if (robot == PBRE_ROBOT_ICUB) {
+        // iCub*GymEnv defaults, left arm (icub_env.py:52-82, icub_reach_gym_env.py:27-51, icub_push_gym_env.py:27-57);
+        // the right arm differs in home_hand_pose, eu_lim[2], ik_link_offset and act_dof, which the caller sets
+        c->use_ik = 1; c->control_orientation = 0; c->max_steps = 2000; c->target_dist_min = 0.03;
+        c->num_controlled_joints = 10; c->num_joints_ctrl = 10;
+        for (int k = 0; k < 16; k++) c->act_dof[k] = k < 10 ? 12 + k : -1;           // torso 12..14, left arm 15..21 in icub_model.sdf traversal order
+        for (int k = 0; k < 40; k++) c->home[k] = 0.0;
+        c->home[15] = -0.51; c->home[16] = 0.7; c->home[18] = 1.22;                  // l_shoulder_pitch, l_shoulder_roll, l_elbow
+        c->home[25] = -0.51; c->home[26] = 0.7; c->home[28] = 1.22;                  // right arm
+        c->home[22] = 0.008;                                                        // neck_pitch
+        c->ws_lim[0][0] = 0.1; c->ws_lim[0][1] = 0.45;                              // icub_env.py:62
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) c->robot_ws[a][b] = c->ws_lim[a][b];
+        c->robot_ws[2][0] = c->h_table; c->robot_ws[2][1] = 1.0;                    // icub_reach_gym_env.py:78-80
+        const double hl[6] = {0.3, 0.26, 0.8, 0.0, 0.0, 0.0};                       // icub_env.py:67
+        for (int k = 0; k < 6; k++) c->home_hand_pose[k] = hl[k];
+        for (int k = 0; k < 3; k++) { c->eu_lim[k][0] = -PI / 2; c->eu_lim[k][1] = PI / 2; }
+        c->ik_pos_scale = 0.005; c->ik_rot_scale = 0.02;                            // 0.01 / 0.02 with control_orientation=1
+        c->ik_link_offset[0] = -0.064768; c->ik_link_offset[1] = -0.00563; c->ik_link_offset[2] = -0.02266;   // icub_env.py:256
+    }
     return PBRE_OK;
 }
 
-inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
+// number of DoF the RobotTable declares (0 if it is not a table): selects the lane shape
+inline int table_ndof(const pbre_config& c) {
+    return (c.robot_table && c.robot_table_len >= 24 && c.robot_table[0] == 1346523717.0) ? (int)c.robot_table[3] : 0;
+}
+
+template <class S>
+inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
+    constexpr int NJ = S::NJ;
     if (c.num_envs <= 0) return "num_envs must be positive";
     if (c.action_repeat != 1) return "action_repeat != 1 is not implemented";
-    if (c.num_controlled_joints < 1 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
+    if (c.num_controlled_joints < 1 || c.num_controlled_joints > 16 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
+    int act_dof[16], n_ctrl = c.num_joints_ctrl;
+    for (int k = 0; k < 16; k++) act_dof[k] = c.act_dof[k];
+    if (c.robot == PBRE_ROBOT_PANDA) { n_ctrl = c.num_controlled_joints; for (int k = 0; k < 16; k++) act_dof[k] = k; }   // panda_env.py:293-310: the first n joints
+    if (n_ctrl < c.num_controlled_joints || n_ctrl > 16) return "num_joints_ctrl out of range";
     if (c.use_ik && (c.ik_max_iters <= 0 || c.ik_damping <= 0)) return "bad IK parameters";
+    if (c.robot != PBRE_ROBOT_PANDA && c.robot != PBRE_ROBOT_ICUB) return "unknown robot";
     const double gains[4] = {c.kp_act, c.kd_act, c.kp_hold, c.kd_hold};
-    std::string e = build_tables(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, T);
+    std::string e = build_tables<S>(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, act_dof, n_ctrl,
+                                    c.robot == PBRE_ROBOT_PANDA, T);
     if (!e.empty()) return e;
     const pbre_physics& p = c.phys;
     if (p.solver_iters <= 0 || p.dt <= 0) return "bad physics parameters";
@@ -79,25 +116,38 @@ inline std::string make_tables(const pbre_config& c, Tables& T, Params& P) {
     P.use_ik = c.use_ik ? 1 : 0; P.ik_iters = c.ik_max_iters; P.ik_l2 = (float)(c.ik_damping * c.ik_damping); P.ik_res = (float)c.ik_residual;
     for (int k = 0; k < 6; k++) P.home_hand[k] = (float)c.home_hand_pose[k];
     for (int a = 0; a < 3; a++) for (int b = 0; b < 2; b++) P.rws[a][b] = (float)c.robot_ws[a][b];
+    P.robot = c.robot; P.reward_type = c.reward_type; P.ctrl_ori = c.control_orientation ? 1 : 0;
+    P.ik_ps = (float)c.ik_pos_scale; P.ik_rs = (float)c.ik_rot_scale;
+    for (int a = 0; a < 3; a++) { P.ik_off[a] = (float)c.ik_link_offset[a]; for (int b = 0; b < 2; b++) P.eu_lim[a][b] = (float)c.eu_lim[a][b]; }
     for (int k = 0; k < NJ; k++) P.rst_q[k] = T.home[k];
     P.rst_objz = (float)(c.h_table + p.obj_h[2]);      // refined from the settled state after the first full reset
     return "";
 }
 
-inline int act_dim_of(const pbre_config& c) { return c.use_ik ? 6 : c.num_controlled_joints; }
-inline int obs_dim_of(const Tables& T, const Params& P) { return 9 + T.ndof + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0); }
+inline int act_dim_of(const pbre_config& c) { return c.use_ik ? (c.control_orientation ? 6 : 3) : c.num_controlled_joints; }
+template <class S>
+inline int obs_dim_of(const TablesT<S>& T, const Params& P) { return 9 + T.n_obs_j + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0); }
 
 // Observation limits exactly as the reference assembles them (panda_env.py:141-193 limits list,
 // panda_push_gym_env.py:73-75 / panda_reach_gym_env.py:68-70 z-min, :177-185 extras).
-inline void obs_limits(const pbre_config& c, const Tables& T, float* lo, float* hi) {
+// iCub: icub_env.py:202-249 (workspace, Euler limits of the arm, +-1 velocity, limits of the controlled joints).
+template <class S>
+inline void obs_limits(const pbre_config& c, const TablesT<S>& T, float* lo, float* hi) {
     const double PI = 3.14159265358979323846;
     int o = 0;
     auto put = [&](double a, double b) { lo[o] = (float)a; hi[o] = (float)b; o++; };
+    if (c.robot == PBRE_ROBOT_ICUB) {
+        for (int k = 0; k < 3; k++) put(c.robot_ws[k][0], c.robot_ws[k][1]);
+        for (int k = 0; k < 3; k++) put(c.eu_lim[k][0], c.eu_lim[k][1]);
+        for (int k = 0; k < 3; k++) put(-1, 1);
+        for (int k = 0; k < c.num_joints_ctrl; k++) put(T.lower[c.act_dof[k]], T.upper[c.act_dof[k]]);
+    } else {
     const double zmin = c.task != PBRE_TASK_REACH ? c.h_table - 0.2 : c.h_table;
     put(0.3, 0.65); put(-0.3, 0.3); put(zmin, 1.5);                 // robot workspace (panda_env.py:37)
     for (int k = 0; k < 3; k++) put(-PI, PI);
     for (int k = 0; k < 3; k++) put(-1, 1);
     for (int k = 0; k < T.ndof; k++) put(T.lower[k], T.upper[k]);
+    }
     for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
     for (int k = 0; k < 3; k++) put(-PI, PI);
     for (int k = 0; k < 3; k++) put(-0.5, 0.5);

@@ -1,5 +1,6 @@
 // pbre_tables.hpp -- host side: RobotTable (include/pbre.h) -> per-lane tables of the
-// 16-lane env group (DESIGN.md "Lane layout").  Plain C++17, no HIP, so the same code
+// env group (DESIGN.md "Lane layout"): 16 lanes for robots with <= 9 DoF (Panda), a whole
+// 64-lane wave for robots with <= 32 DoF (iCub).  Plain C++17, no HIP, so the same code
 // feeds the device kernels (pbre_capi.hip) and the host lane emulation used by the CPU
 // tests (tests/host_emu).
 //
@@ -18,16 +19,32 @@
 
 namespace pbre {
 
-constexpr int W = 16;        // lanes per env
-constexpr int NJ = 9;        // robot DoF lanes 0..8
-constexpr int LC = 9;        // object lanes: 9..11 linear, 12..14 angular
-constexpr int L1 = 15;       // constant-one lane (carries -rhs of contact rows)
-constexpr int NSUB = 3;      // rigid sub-bodies per lane
-constexpr int NLEV = 4;      // pointer-jumping levels (chains up to 16 deep)
-constexpr int NC_OT = 4, NC_RO = 2, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;
-constexpr int STATE = 48;
+// Lane layout of one env group.  Lanes 0..NJ-1 own the robot DoF, lanes LC..LC+2 / LC+3..LC+5 the object's linear /
+// angular velocity (Q record: LC..LC+2 position, LC+3..LC+6 quaternion), lane L1 is the constant-one lane that carries
+// -rhs of a contact row through the row dot product.  State record = Q[W] | V[W] | X[16] floats.
+template <int W_, int NJ_, int NSUB_, int NLEV_>
+struct ShapeT {
+    static constexpr int W = W_;          // lanes per env
+    static constexpr int NJ = NJ_;        // robot DoF lanes
+    static constexpr int LC = NJ_;        // first object lane
+    static constexpr int L1 = NJ_ + 6;    // constant-one lane
+    static constexpr int NSUB = NSUB_;    // rigid sub-bodies per lane
+    static constexpr int NLEV = NLEV_;    // pointer-jumping levels (chains up to 2^NLEV deep)
+    static constexpr int STATE = 2 * W_ + 16;
+    static_assert(NJ_ + 7 <= W_ && NJ_ <= 32, "lane budget");
+};
+using Shape16 = ShapeT<16, 9, 3, 4>;      // Panda (<= 9 DoF): one env per 16-lane DPP row, 4 envs per wave
+using Shape64 = ShapeT<64, 32, 2, 4>;     // iCub (<= 32 DoF): one env per wave
 
-struct Tables {
+// the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
+constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;
+constexpr int NC_OT = 4, NC_RO = 2, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;
+constexpr int STATE = Shape16::STATE;
+constexpr int MAXJ = 32;     // DoF bound of any shape
+
+template <class S>
+struct TablesT {
+    static constexpr int W = S::W, NJ = S::NJ, NSUB = S::NSUB, NLEV = S::NLEV;
     int   anc[NLEV][W];          // 2^l-th movable ancestor lane, -1 past the root
     int   amask[W];              // bit i: lane i is an ancestor-or-self of this lane
     int   dmask[W];              // bit i: lane i is in the subtree of this lane (incl. self)
@@ -39,10 +56,15 @@ struct Tables {
     float kp_hold[W], kd_hold[W], kp_act[W], kd_act[W];
     int   s_owner[W], s_valid[W];
     float s_c[3][W], s_r[W], s_mu[W];
+    int   act_idx[W];            // index of this lane's joint in the action vector (joint control), -1 if not driven
+    int   obs_idx[W];            // slot of this lane's joint among the observed joint positions, -1 if not observed
     int   ee_owner;
     float ee_R[9], ee_p[3];      // EE (link COM frame) in the owner lane's link frame
-    int   ndof, n_act, nspheres;
+    float ee_lp[3];              // EE link frame origin in the owner lane's link frame (IK target frame)
+    int   ee_chain;              // bit l: lane l is on the chain base -> end effector (joints the IK moves)
+    int   ndof, n_act, n_obs_j, nspheres;
 };
+using Tables = TablesT<Shape16>;
 
 struct Params {                  // float copies of pbre_physics + task constants used on device
     float dt, inv_dt, gz;
@@ -55,9 +77,11 @@ struct Params {                  // float copies of pbre_physics + task constant
     float obj_std, tg_std, ws[3][2], h_table;
     unsigned seed_lo, seed_hi;
     unsigned long long env_id_base;
-    float rst_q[NJ], rst_objz;    // settled robot pose / object height recorded at the last full reset (snapshot auto-reset)
+    float rst_q[MAXJ], rst_objz;  // settled robot pose / object height recorded at the last full reset (snapshot auto-reset)
     int   use_ik, ik_iters;       // Cartesian control (use_IK=1): damped-least-squares IK
     float ik_l2, ik_res, home_hand[6], rws[3][2];   // lambda^2, position residual, home hand pose, robot workspace
+    int   robot, reward_type, ctrl_ori;             // PBRE_ROBOT_*; iCub push reward variant; IK mode: orientation part of the action
+    float ik_ps, ik_rs, eu_lim[3][2], ik_off[3];    // action scales, Euler limits, hand COM frame -> link frame offset
 };
 
 namespace detail {
@@ -74,15 +98,19 @@ inline Xf mul(const Xf& a, const Xf& b) {
 }  // namespace detail
 
 // Returns "" on success, else an error message.
+// act_dof: DoF index of controlled joint k (k < n_ctrl); n_act of them are driven by the action in joint mode;
+// observe_all: the observation reports every DoF (Panda) instead of the controlled joints (iCub).
+template <class S>
 inline std::string build_tables(const double* t, size_t n, const double* home, const double* gains /*kp_act,kd_act,kp_hold,kd_hold*/,
-                                int n_act, Tables& T) {
+                                int n_act, const int* act_dof, int n_ctrl, bool observe_all, TablesT<S>& T) {
     using namespace detail;
+    constexpr int W = S::W, NJ = S::NJ, NSUB = S::NSUB, NLEV = S::NLEV;
     std::memset(&T, 0, sizeof T);
     if (!t || n < 24 || t[0] != 1346523717.0 || t[1] != 1.0) return "robot_table: bad magic/version";
     const int nl = (int)t[2], ndof = (int)t[3], ee = (int)t[4], ns = (int)t[5];
     if (n < (size_t)(24 + nl * 40 + ns * 8)) return "robot_table: truncated";
-    if (ndof > NJ) return "robot_table: more than 9 DoF (this kernel maps one DoF per lane of a 16-lane group)";
-    if (ns > W) return "robot_table: more than 16 collision spheres";
+    if (ndof > NJ) return "robot_table: more DoF than robot lanes of this kernel shape";
+    if (ns > 16) return "robot_table: more than 16 collision spheres";
     if ((int)t[18] != 1) return "robot_table: floating-base robots are not supported by this kernel";
     if (ee < 0 || ee >= nl) return "robot_table: ee_link out of range";
     auto L = [&](int i) { return t + 24 + i * 40; };
@@ -144,12 +172,26 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
     }
     // ancestor tables
     for (int v = 1; v < NLEV; v++) for (int l = 0; l < NJ; l++) { int a = T.anc[v-1][l]; T.anc[v][l] = a < 0 ? -1 : T.anc[v-1][a]; }
-    for (int l = 0; l < NJ; l++) { if (!T.jtype[l]) continue; for (int a = l; a >= 0; a = T.anc[0][a]) T.amask[l] |= 1 << a; }
-    for (int l = 0; l < NJ; l++) for (int i = 0; i < NJ; i++) if (T.jtype[i] && (T.amask[i] >> l & 1)) T.dmask[l] |= 1 << i;
-    for (int l = 0; l < NJ; l++) if (T.jtype[l] && T.anc[NLEV-1][l] >= 0 && T.anc[0][T.anc[NLEV-1][l]] >= 0) return "robot_table: chain deeper than 16";
+    for (int l = 0; l < NJ; l++) { if (!T.jtype[l]) continue; for (int a = l; a >= 0; a = T.anc[0][a]) T.amask[l] |= (int)(1u << a); }
+    for (int l = 0; l < NJ; l++) for (int i = 0; i < NJ; i++) if (T.jtype[i] && ((unsigned)T.amask[i] >> l & 1u)) T.dmask[l] |= (int)(1u << i);
+    for (int l = 0; l < NJ; l++) {           // NLEV doubling steps accumulate over self + (2^NLEV - 1) ancestors
+        int depth = 0;
+        for (int a = T.anc[0][l]; a >= 0; a = T.anc[0][a]) depth++;
+        if (T.jtype[l] && depth > (1 << NLEV) - 1) return "robot_table: chain deeper than the pointer-jumping levels cover";
+    }
+    for (int l = 0; l < W; l++) { T.act_idx[l] = -1; T.obs_idx[l] = -1; }
+    if (n_act > n_ctrl) return "more action joints than controlled joints";
+    for (int k = 0; k < n_ctrl; k++) {
+        const int d = act_dof[k];
+        if (d < 0 || d >= ndof || T.obs_idx[d] >= 0) return "act_dof: bad or repeated DoF index";
+        if (k < n_act) T.act_idx[d] = k;
+        T.obs_idx[d] = k;
+    }
+    T.n_obs_j = n_ctrl;
+    if (observe_all) { for (int l = 0; l < ndof; l++) T.obs_idx[l] = l; T.n_obs_j = ndof; }
     for (int l = 0; l < ndof; l++) {
         T.home[l] = (float)home[l];
-        const bool act = l < n_act;
+        const bool act = T.act_idx[l] >= 0;
         T.kp_act[l] = (float)(act ? gains[0] : gains[2]); T.kd_act[l] = (float)(act ? gains[1] : gains[3]);
         T.kp_hold[l] = (float)gains[2]; T.kd_hold[l] = (float)gains[3];
     }
@@ -161,6 +203,8 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         const Xf& F = to_owner[ee];
         for (int k = 0; k < 9; k++) T.ee_R[k] = (float)F.R[k];
         for (int a = 0; a < 3; a++) T.ee_p[a] = (float)(F.p[a] + F.R[a*3] * r[18] + F.R[a*3+1] * r[19] + F.R[a*3+2] * r[20]);
+        for (int a = 0; a < 3; a++) T.ee_lp[a] = (float)F.p[a];
+        T.ee_chain = T.amask[T.ee_owner];
     }
     for (int s = 0; s < ns; s++) {
         const double* r = t + 24 + nl * 40 + s * 8;

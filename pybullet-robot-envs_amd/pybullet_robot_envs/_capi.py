@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")   # PBRE_LIB: build-variant A/B runs
 
 STATE_FLOATS = 48
-ROBOT_PANDA = 0
+ROBOT_PANDA, ROBOT_ICUB = 0, 1
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
 F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL = 1, 2, 4
 
@@ -37,10 +37,13 @@ class Config(C.Structure):
                 ("obj_pose_rnd_std", C.c_double), ("tg_pose_rnd_std", C.c_double),
                 ("target_dist_min", C.c_double), ("act_scale", C.c_double),
                 ("kp_act", C.c_double), ("kd_act", C.c_double), ("kp_hold", C.c_double), ("kd_hold", C.c_double),
-                ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 16),
+                ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 40),
                 ("phys", Physics),
                 ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("ik_max_iters", C.c_int32),
                 ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
+                ("control_orientation", C.c_int32), ("reward_type", C.c_int32), ("num_joints_ctrl", C.c_int32),
+                ("act_dof", C.c_int32 * 16), ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double),
+                ("eu_lim", C.c_double * 2 * 3), ("ik_link_offset", C.c_double * 3),
                 ("robot_table", C.c_void_p), ("robot_table_len", C.c_size_t)]
 
 
@@ -70,7 +73,7 @@ def load(path=None):
     lib.pbre_destroy.restype = None
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
-                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics"):
+                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -84,10 +87,10 @@ def _fp(a):
 class Engine:
     """One pbre_ctx: `num_envs` environments on one GPU."""
 
-    def __init__(self, robot_table, task=TASK_PUSH, num_envs=1, lib=None, **overrides):
+    def __init__(self, robot_table, task=TASK_PUSH, num_envs=1, lib=None, robot=ROBOT_PANDA, **overrides):
         self.lib = lib or load()
         self.cfg = Config()
-        rc = self.lib.pbre_default_config(C.byref(self.cfg), C.c_int32(ROBOT_PANDA), C.c_int32(task))
+        rc = self.lib.pbre_default_config(C.byref(self.cfg), C.c_int32(robot), C.c_int32(task))
         if rc != 0:
             raise RuntimeError("pbre_default_config failed: %d" % rc)
         self.cfg.num_envs = int(num_envs)
@@ -95,7 +98,18 @@ class Engine:
         for k, v in overrides.items():
             if not hasattr(self.cfg, k):
                 raise TypeError("unknown pbre_config field %r" % k)
-            setattr(self.cfg, k, v)
+            if isinstance(v, (list, tuple, np.ndarray)):          # array fields: home, act_dof, eu_lim, ...
+                arr = getattr(self.cfg, k)
+                flat = np.asarray(v).reshape(-1)
+                if len(arr) and hasattr(arr[0], "__len__"):
+                    cols = len(arr[0])
+                    for i, x in enumerate(flat):
+                        arr[i // cols][i % cols] = x
+                else:
+                    for i, x in enumerate(flat):
+                        arr[i] = x
+            else:
+                setattr(self.cfg, k, v)
         if phys:
             for k, v in phys.items():
                 if not hasattr(self.cfg.phys, k):
@@ -111,6 +125,7 @@ class Engine:
         od, ad, n = C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(self.lib.pbre_dims(self._ctx, C.byref(od), C.byref(ad), C.byref(n)))
         self.obs_dim, self.act_dim, self.num_envs = od.value, ad.value, n.value
+        self.state_floats = int(self.lib.pbre_state_floats(self._ctx))
         self._out = np.zeros((self.num_envs, self.obs_dim + 2), np.float32)
 
     def _chk(self, rc):
@@ -159,13 +174,13 @@ class Engine:
         self._chk(self.lib.pbre_sync(self._ctx))
 
     def get_state(self):
-        s = np.zeros((self.num_envs, STATE_FLOATS), np.float32)
+        s = np.zeros((self.num_envs, self.state_floats), np.float32)
         self._chk(self.lib.pbre_get_state(self._ctx, _fp(s)))
         return s
 
     def set_state(self, s):
         s = np.ascontiguousarray(s, dtype=np.float32)
-        assert s.shape == (self.num_envs, STATE_FLOATS)
+        assert s.shape == (self.num_envs, self.state_floats)
         self._chk(self.lib.pbre_set_state(self._ctx, _fp(s)))
 
     def observe(self):

@@ -12,31 +12,119 @@
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
 
+#include <type_traits>
+
 using namespace pbre;
-using CoreH = Core<pbre_emu::HostLanes>;
 using FastH = Fast<TopoPanda>;
 
-struct pbre_ctx {
+struct pbre_ctx {                       // shape-independent part + the virtual interface of the shape-specific part
     pbre_config cfg;
-    Tables T; Params P;
-    int n, obs_dim, act_dim;
+    Params P;
+    int n = 0, obs_dim = 0, act_dim = 0, sf = 0, nj = 0;
     std::vector<float> state, tgt;
     std::string err;
     bool fast_ok = false;
     long n_fast = 0, n_rc = 0, n_general = 0;
+    virtual ~pbre_ctx() {}
+    virtual void reset(const uint8_t* mask) = 0;
+    virtual void step(const float* actions, float* out) = 0;
+    virtual void observe(float* obs) = 0;
+    virtual void settle_all(int n, int flags) = 0;
+    virtual void limits(float* lo, float* hi) = 0;
 };
-// same dispatch as the device: lane-per-env fast path first, general row kernel for the envs it declines
-static void step_env(pbre_ctx* c, float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tgt = nullptr) {
-    if (c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL)) {
-        // same dispatch as the device; the class is recomputed here instead of being carried from the previous step
-        if (FastH::classify_state(c->T, c->P, st, flags) == 0) { c->n_fast++; FastH::step(c->T, c->P, st, act, out, mode, flags, env_id, tgt); }
-        else { c->n_rc++; FastH::step_rc(c->T, c->P, st, act, out, mode, flags, env_id, tgt); }
-        return;
+
+template <class S>
+struct Emu : pbre_ctx {
+    using L = pbre_emu::HostLanesT<S::W>;
+    using CoreH = Core<L, S>;
+    static constexpr bool PANDA = std::is_same<S, Shape16>::value;
+    static constexpr int STATE = S::STATE, NJ = S::NJ, W = S::W;
+    TablesT<S> T;
+
+    // same dispatch as the device: lane-per-env fast path first (Panda), general lane-group kernel otherwise
+    void step_env(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tg = nullptr) {
+        if constexpr (PANDA) {
+            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
+                // the class is recomputed here instead of being carried from the previous step
+                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
+                else { n_rc++; FastH::step_rc(T, P, st, act, out, mode, flags, env_id, tg); }
+                return;
+            }
+        }
+        n_general++;
+        CoreH::step(T, P, st, act, out, mode, flags, tg);
     }
-    c->n_general++;
-    CoreH::step(c->T, c->P, st, act, out, mode, flags, tgt);
-}
+    void ik(float* st, const float* act, float* tg, bool rst) {
+        if constexpr (PANDA) FastH::ik_targets(T, P, st, act, tg, rst);
+        else CoreH::ik_targets(T, P, st, act, tg, rst);
+    }
+    void settle(int e, int cnt, int flags) {
+        const int mode = P.use_ik ? CoreH::M_TGT : 0;
+        for (int i = 0; i < cnt; i++) step_env(&state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &tgt[(size_t)e * NJ]);
+    }
+    void settle_all(int cnt, int flags) override { for (int e = 0; e < n; e++) settle(e, cnt, flags); }
+    void reset(const uint8_t* mask) override {
+        for (int e = 0; e < n; e++) {
+            float* st = &state[(size_t)e * STATE];
+            if (mask && !mask[e]) continue;
+            unsigned long long id = P.env_id_base + (unsigned long long)e;
+            unsigned ep = (unsigned)((int)st[2 * W + 5] + 1);      // episode numbers live in the state records
+            CoreH::init_state(T, P, id, ep, st);
+            if (P.use_ik) ik(st, nullptr, &tgt[(size_t)e * NJ], true);
+            // one extra stepSimulation at the end of robot.reset: Panda in IK mode (panda_env.py:91), iCub always (icub_env.py:151)
+            if (P.use_ik || P.robot == PBRE_ROBOT_ICUB) settle(e, 1, PBRE_F_NO_OBJECT);
+            settle(e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
+            settle(e, 101, cfg.flags & PBRE_F_NO_OBJECT);           // world loaded: 100 + 1 steps (:136-148)
+            CoreH::sample_target(P, id, ep, st);
+            if (P.robot == PBRE_ROBOT_ICUB && P.task >= 1) {
+                auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
+                CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
+            }
+        }
+        if (!mask) { for (int k = 0; k < NJ; k++) P.rst_q[k] = state[k]; P.rst_objz = state[S::LC + 2]; }
+    }
+    void step(const float* actions, float* out) override {
+        const int ow = obs_dim + 2;
+        for (int e = 0; e < n; e++) {
+            float* st = &state[(size_t)e * STATE];
+            const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
+            const unsigned long long id = P.env_id_base + (unsigned long long)e;
+            if (P.use_ik) {
+                ik(st, actions + (size_t)e * act_dim, &tgt[(size_t)e * NJ], false);
+                step_env(st, nullptr, out + (size_t)e * ow, CoreH::M_TGT | CoreH::M_OBS | CoreH::M_TASK, fl, id, &tgt[(size_t)e * NJ]);
+            } else
+                step_env(st, actions + (size_t)e * act_dim, out + (size_t)e * ow, CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, fl, id);
+        }
+    }
+    void observe(float* obs) override {
+        std::vector<float> row(obs_dim + 2);
+        for (int e = 0; e < n; e++) {
+            float* st = &state[(size_t)e * STATE];
+            auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
+            CoreH::observe(T, P, st, Q, V, X, row.data(), CoreH::M_OBS);
+            std::memcpy(obs + (size_t)e * obs_dim, row.data(), obs_dim * 4);
+        }
+    }
+    void limits(float* lo, float* hi) override { obs_limits(cfg, T, lo, hi); }
+};
 static std::string g_err;
+
+template <class S>
+static int create(const pbre_config* cfg, pbre_ctx** out) {
+    Emu<S>* c = new Emu<S>();
+    c->cfg = *cfg;
+    std::string e = make_tables<S>(*cfg, c->T, c->P);
+    if (!e.empty()) { g_err = e; delete c; return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG); }
+    c->cfg.robot_table = nullptr;
+    c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg); c->sf = S::STATE; c->nj = S::NJ;
+    c->state.assign((size_t)c->n * S::STATE, 0.f);
+    c->tgt.assign((size_t)c->n * S::NJ, 0.f);
+    for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
+    if constexpr (std::is_same<S, Shape16>::value) c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
+    if ((cfg->flags & PBRE_F_AUTO_RESET) && (!c->fast_ok || (cfg->flags & PBRE_F_FORCE_GENERAL))) { g_err = "PBRE_F_AUTO_RESET is not implemented by the general lane-group kernel"; delete c; return PBRE_E_UNSUPPORTED; }
+    *out = c;
+    return PBRE_OK;
+}
 
 extern "C" {
 
@@ -44,19 +132,7 @@ int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return 
 
 int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
-    pbre_ctx* c = new pbre_ctx();
-    c->cfg = *cfg;
-    std::string e = make_tables(*cfg, c->T, c->P);
-    if (!e.empty()) { g_err = e; delete c; return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG); }
-    c->cfg.robot_table = nullptr;
-    c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg);
-    c->state.assign((size_t)c->n * STATE, 0.f);
-    c->tgt.assign((size_t)c->n * NJ, 0.f);
-    for (int e = 0; e < c->n; e++) c->state[(size_t)e * STATE + 37] = -1.f;      // never reset
-    c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
-    if ((cfg->flags & PBRE_F_AUTO_RESET) && (!c->fast_ok || (cfg->flags & PBRE_F_FORCE_GENERAL))) { g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel"; delete c; return PBRE_E_UNSUPPORTED; }
-    *out = c;
-    return PBRE_OK;
+    return table_ndof(*cfg) > Shape16::NJ ? create<Shape64>(cfg, out) : create<Shape16>(cfg, out);
 }
 void pbre_destroy(pbre_ctx* c) { delete c; }
 const char* pbre_last_error(const pbre_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
@@ -65,44 +141,17 @@ int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
     if (od) *od = c->obs_dim; if (ad) *ad = c->act_dim; if (n) *n = c->n;
     return PBRE_OK;
 }
-
-static void settle(pbre_ctx* c, int e, int n, int flags) {
-    const int mode = c->P.use_ik ? CoreH::M_TGT : 0;
-    for (int i = 0; i < n; i++) step_env(c, &c->state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &c->tgt[(size_t)e * NJ]);
-}
+int pbre_state_floats(const pbre_ctx* c) { return c ? c->sf : PBRE_E_ARG; }
 
 int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
     if (!c) return PBRE_E_ARG;
-    for (int e = 0; e < c->n; e++) {
-        float* st = &c->state[(size_t)e * STATE];
-        if (!mask || mask[e]) {
-            unsigned long long id = c->P.env_id_base + (unsigned long long)e;
-            unsigned ep = (unsigned)((int)st[37] + 1);      // episode numbers live in the state records
-            CoreH::init_state(c->T, c->P, id, ep, st);
-            if (c->P.use_ik) { FastH::ik_targets(c->T, c->P, st, nullptr, &c->tgt[(size_t)e * NJ], true); settle(c, e, 1, PBRE_F_NO_OBJECT); }
-            settle(c, e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
-            settle(c, e, 101, c->cfg.flags & PBRE_F_NO_OBJECT);        // world loaded: 100 + 1 steps (:136-148)
-            CoreH::sample_target(c->P, id, ep, st);
-        }
-    }
-    if (!mask) { for (int k = 0; k < NJ; k++) c->P.rst_q[k] = c->state[k]; c->P.rst_objz = c->state[11]; }
-    if (obs) return pbre_observe(c, obs);
+    c->reset(mask);
+    if (obs) c->observe(obs);
     return PBRE_OK;
 }
-
 int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
-    const int ow = c->obs_dim + 2;
-    for (int e = 0; e < c->n; e++) {
-        float* st = &c->state[(size_t)e * STATE];
-        const int fl = c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
-        if (c->P.use_ik) {
-            FastH::ik_targets(c->T, c->P, st, actions + (size_t)e * c->act_dim, &c->tgt[(size_t)e * NJ], false);
-            step_env(c, st, nullptr, out + (size_t)e * ow, CoreH::M_TGT | CoreH::M_OBS | CoreH::M_TASK, fl, c->P.env_id_base + (unsigned long long)e, &c->tgt[(size_t)e * NJ]);
-        } else
-            step_env(c, st, actions + (size_t)e * c->act_dim, out + (size_t)e * ow, CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, fl,
-                     c->P.env_id_base + (unsigned long long)e);
-    }
+    c->step(actions, out);
     return PBRE_OK;
 }
 int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }
@@ -113,18 +162,12 @@ int pbre_set_state(pbre_ctx* c, const float* s) { if (!c || !s) return PBRE_E_AR
 
 int pbre_observe(pbre_ctx* c, float* obs) {
     if (!c || !obs) return PBRE_E_ARG;
-    std::vector<float> row(c->obs_dim + 2);
-    for (int e = 0; e < c->n; e++) {
-        float* st = &c->state[(size_t)e * STATE];
-        auto Q = pbre_emu::HostLanes::load(st), V = pbre_emu::HostLanes::load(st + 16), X = pbre_emu::HostLanes::load(st + 32);
-        CoreH::observe(c->T, c->P, st, Q, V, X, row.data(), CoreH::M_OBS);
-        std::memcpy(obs + (size_t)e * c->obs_dim, row.data(), c->obs_dim * 4);
-    }
+    c->observe(obs);
     return PBRE_OK;
 }
 int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     if (!c || n < 0) return PBRE_E_ARG;
-    for (int e = 0; e < c->n; e++) settle(c, e, n, flags & PBRE_F_NO_OBJECT);
+    c->settle_all(n, flags & PBRE_F_NO_OBJECT);
     return PBRE_OK;
 }
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
@@ -151,7 +194,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;
 }
-int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; obs_limits(c->cfg, c->T, lo, hi); return PBRE_OK; }
+int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; const_cast<pbre_ctx*>(c)->limits(lo, hi); return PBRE_OK; }
 int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     const long v[7] = {0, 0, 0, c->n_fast, c->n_general, c->n_rc, 0};

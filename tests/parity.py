@@ -153,3 +153,56 @@ def check_ik_mode(Engine, lib, table, task, flags=0):
     assert np.abs(s2[1:3, :44] - so[1:3, :44].astype(np.float32)).max() == 0
     assert np.abs(s2[[0, 3], 38:44] - [0.2, 0, 0.8, np.pi, 0, 0]).max() < 1e-6 and (s2[[0, 3], 37] == 1).all()
     return eng
+
+
+# ---------------------------------------------------------------------------------------------- iCub
+def icub_overrides(info, control_arm="l", use_ik=1, control_orientation=0, reward_type=1):
+    """pbre_config fields that differ from pbre_default_config(PBRE_ROBOT_ICUB) (left arm, IK, position only)."""
+    ov = dict(use_ik=use_ik, control_orientation=control_orientation, reward_type=reward_type,
+              act_dof=list(info["controlled"]) + [-1] * 6, home=list(info["home"]) + [0.0] * (40 - len(info["home"])),
+              ik_pos_scale=0.01 if control_orientation else 0.005)
+    if control_arm == "r":
+        ov.update(home_hand_pose=[0.3, -0.26, 0.8, 0.0, 0.0, np.pi],
+                  eu_lim=[-np.pi / 2, np.pi / 2, -np.pi / 2, np.pi / 2, np.pi / 2, 1.5 * np.pi],
+                  ik_link_offset=[0.064668, -0.0056, -0.022681])
+    return ov
+
+
+def make_icub_pair(Engine, lib, n, task=0, control_arm="l", use_ik=1, control_orientation=0, reward_type=1, obj_std=0.0, tg_std=0.0, **kw):
+    from pybullet_robot_envs import _capi
+    ora, tbl, info = orc.icub_oracle(control_arm, task=task, use_ik=use_ik, control_orientation=control_orientation)
+    ora.task.reward_type = reward_type
+    ora.task.obj_pose_rnd_std = obj_std
+    ora.task.tg_pose_rnd_std = tg_std
+    ov = icub_overrides(info, control_arm, use_ik, control_orientation, reward_type)
+    ov.update(kw)
+    eng = Engine(tbl, task=task, num_envs=n, lib=lib, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=obj_std, tg_pose_rnd_std=tg_std, **ov)
+    return eng, ora, info
+
+
+def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, reward_type=1, n=2, steps=4, seed=3):
+    """iCub lane-group kernel (one env per 64-lane wave) against the oracle: reset, then single steps from identical states."""
+    eng, ora, info = make_icub_pair(Engine, lib, n, task, control_arm, use_ik, control_orientation, reward_type, obj_std=0.05, tg_std=0.2)
+    assert eng.state_floats == ora.state_floats == 144 and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim
+    obs = eng.reset()
+    st_o, obs_o = ora.batch_reset(n)
+    st_e = eng.get_state()
+    assert rel(st_e[:, :128], st_o[:, :128]).max() < 2e-3, rel(st_e[:, :128], st_o[:, :128]).max()
+    assert np.abs(st_e[:, 128:] - st_o[:, 128:]).max() < 2e-3
+    assert rel(obs, obs_o).max() < 1e-2
+    rng = np.random.default_rng(seed)
+    st = st_o
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        so, out = ora.batch_step(s32.astype(np.float64), a)
+        se = eng.get_state()
+        assert np.abs(se[:, 128 + 6:128 + 12] - so[:, 128 + 6:128 + 12]).max() < 1e-6      # commanded hand pose
+        assert rel(se[:, :128], so[:, :128]).max() < 2e-3, (k, rel(se[:, :128], so[:, :128]).max())
+        assert rel(ob, out[:, :-2]).max() < 2e-2, (k, rel(ob, out[:, :-2]).max())
+        assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
+        assert (dn == out[:, -1]).all()
+        st = so
+    return eng
