@@ -86,4 +86,46 @@ struct DevLanes {
     }
 };
 
+// One env = one whole wave64 (iCub, <= 32 DoF).  Broadcasts of a compile-time lane are v_readlane_b32 (the value becomes
+// an SGPR operand), gathers are ds_bpermute_b32 over the wave, all-reduces are the 16-lane DPP butterfly followed by
+// row_bcast15 / row_bcast31 and a v_readlane of lane 63 (summation order (r3 + r2) + (r1 + r0), mirrored by the host
+// emulation so that CPU tests and device agree bit for bit).
+struct DevLanes64 : DevLanes {
+    static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }
+    static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 63u]; }
+    static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 63u]; }
+    static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 63u] : 0.f; }
+    static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 63u] = x; }
+    static __device__ __forceinline__ void storem(float* p, F x, B m) { if (m) p[threadIdx.x & 63u] = x; }
+    static __device__ __forceinline__ F gather(F a, I idx) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((idx & 63) << 2, __float_as_int(a)));
+    }
+    static __device__ __forceinline__ I gatherI(I a, I idx) { return __builtin_amdgcn_ds_bpermute((idx & 63) << 2, a); }
+    static __device__ __forceinline__ F bcast(F a, int k) {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), __builtin_amdgcn_readfirstlane(k)));
+    }
+    template <int CTRL, int ROWS>
+    static __device__ __forceinline__ F dppr(F x) {      // rows outside ROWS receive 0
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWS, 0xF, false));
+    }
+    static __device__ __forceinline__ F sum(F x) {
+        x += dpp<0xB1>(x);
+        x += dpp<0x4E>(x);
+        x += dpp<0x141>(x);
+        x += dpp<0x140>(x);              // every lane: sum of its 16-lane row
+        x += dppr<0x142, 0xA>(x);        // row_bcast15 into rows 1, 3: r1 + r0, r3 + r2
+        x += dppr<0x143, 0xC>(x);        // row_bcast31 into rows 2, 3: lane 63 = (r3 + r2) + (r1 + r0)
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    }
+    static __device__ __forceinline__ F vmin(F x) {
+        x = __builtin_fminf(x, dpp<0xB1>(x));
+        x = __builtin_fminf(x, dpp<0x4E>(x));
+        x = __builtin_fminf(x, dpp<0x141>(x));
+        x = __builtin_fminf(x, dpp<0x140>(x));
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+        const float c_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+        return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c_, d));
+    }
+};
+
 }  // namespace pbre

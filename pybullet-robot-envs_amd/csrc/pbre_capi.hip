@@ -29,6 +29,7 @@
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
 #include "pbre_fast.hpp"
+#include "pbre_wide.hpp"
 
 using namespace pbre;
 using CoreD = Core<DevLanes>;
@@ -171,6 +172,7 @@ struct EnvBuf {                       // a batch of state records with its class
 };
 
 struct pbre_ctx {
+    WideEngine* wide = nullptr;        // robots with more than 9 DoF (iCub): every entry point forwards to the 64-lane engine
     pbre_config cfg;
     Tables T; Params P;
     int n = 0, npad = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0;
@@ -287,6 +289,7 @@ int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return 
 
 void pbre_destroy(pbre_ctx* c) {
     if (!c) return;
+    if (c->wide) { wide_destroy(c->wide); delete c; return; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
@@ -306,8 +309,14 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
     *out = nullptr;
     pbre_ctx* c = new pbre_ctx();
+    if (table_ndof(*cfg) > NJ) {
+        const int rc = wide_create(cfg, &c->wide, g_err);
+        if (rc != PBRE_OK) { delete c; return rc; }
+        *out = c;
+        return PBRE_OK;
+    }
     c->cfg = *cfg;
-    std::string e = make_tables(*cfg, c->T, c->P);
+    std::string e = make_tables<Shape16>(*cfg, c->T, c->P);
     if (!e.empty()) {
         g_err = e; delete c;
         return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG);
@@ -363,18 +372,27 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     return PBRE_OK;
 }
 
-const char* pbre_last_error(const pbre_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+const char* pbre_last_error(const pbre_ctx* c) { return c ? (c->wide ? wide_error(c->wide) : c->err.c_str()) : g_err.c_str(); }
 
 int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
     if (!c) return PBRE_E_ARG;
+    if (c->wide) { wide_dims(c->wide, od, ad, n, nullptr); return PBRE_OK; }
     if (od) *od = c->obs_dim;
     if (ad) *ad = c->act_dim;
     if (n) *n = c->n;
     return PBRE_OK;
 }
 
+int pbre_state_floats(const pbre_ctx* c) {
+    if (!c) return PBRE_E_ARG;
+    int32_t sf = STATE;
+    if (c->wide) wide_dims(c->wide, nullptr, nullptr, nullptr, &sf);
+    return sf;
+}
+
 int pbre_sync(pbre_ctx* c) {
     if (!c) return PBRE_E_ARG;
+    if (c->wide) return wide_sync(c->wide);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipStreamSynchronize(c->side));
@@ -383,6 +401,7 @@ int pbre_sync(pbre_ctx* c) {
 
 int pbre_observe(pbre_ctx* c, float* obs) {
     if (!c || !obs) return PBRE_E_ARG;
+    if (c->wide) return wide_observe(c->wide, obs);
     HIPCHK(hipSetDevice(c->device));
     hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->main.state, c->d_out, c->d_scratch, c->n, c->ow);
     HIPCHK(hipGetLastError());
@@ -393,6 +412,7 @@ int pbre_observe(pbre_ctx* c, float* obs) {
 
 int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     if (!c || n < 0) return PBRE_E_ARG;
+    if (c->wide) return wide_settle(c->wide, n, flags);
     HIPCHK(hipSetDevice(c->device));
     const int f = flags & PBRE_F_NO_OBJECT, f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
     if (f != f0) HIPCHK(classify(c, c->main, c->n, f, c->stream));           // classes depend on whether the object is present
@@ -404,6 +424,7 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
 
 int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
     if (!c) return PBRE_E_ARG;
+    if (c->wide) return wide_reset(c->wide, mask, obs);
     HIPCHK(hipSetDevice(c->device));
     std::vector<int> idx;
     for (int e = 0; e < c->n; e++) if (!mask || mask[e]) idx.push_back(e);
@@ -454,6 +475,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
 
 int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* stream) {
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
+    if (c->wide) return wide_step_device(c->wide, d_actions, d_out, stream);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     HIPCHK(full_step(c, d_actions, d_out, s));
@@ -462,6 +484,7 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
 
 int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
+    if (c->wide) return wide_step(c->wide, actions, out);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
@@ -477,6 +500,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
 
 int pbre_get_state(pbre_ctx* c, float* s) {
     if (!c || !s) return PBRE_E_ARG;
+    if (c->wide) return wide_get_state(c->wide, s);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(s, c->main.state, (size_t)c->n * STATE * 4, hipMemcpyDeviceToHost));
@@ -484,6 +508,7 @@ int pbre_get_state(pbre_ctx* c, float* s) {
 }
 int pbre_set_state(pbre_ctx* c, const float* s) {
     if (!c || !s) return PBRE_E_ARG;
+    if (c->wide) return wide_set_state(c->wide, s);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(c->main.state, s, (size_t)c->n * STATE * 4, hipMemcpyHostToDevice));
@@ -494,11 +519,13 @@ int pbre_set_state(pbre_ctx* c, const float* s) {
 
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
+    if (c->wide) return wide_get_physics(c->wide, phys);
     *phys = c->cfg.phys;
     return PBRE_OK;
 }
 int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
+    if (c->wide) return wide_set_physics(c->wide, phys);
     pbre_config cfg = c->cfg;
     cfg.phys = *phys;
     Params P2 = c->P;
@@ -523,11 +550,13 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
 
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) {
     if (!c || !lo || !hi) return PBRE_E_ARG;
+    if (c->wide) return wide_obs_limits(c->wide, lo, hi);
     obs_limits(c->cfg, c->T, lo, hi);
     return PBRE_OK;
 }
 int pbre_timing(const pbre_ctx* c, double* ms, int32_t n) {
     if (!c || !ms) return PBRE_E_ARG;
+    if (c->wide) return wide_timing(c->wide, ms, n);
     double kd = 0.0;
     if (n > 3 && c->k_steps > 0) {      // mean over the last min(k_steps, KRING) steps
         (void)hipSetDevice(c->device);
@@ -546,6 +575,7 @@ int pbre_timing(const pbre_ctx* c, double* ms, int32_t n) {
 }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
+    if (c->wide) return wide_kernel_info(c->wide, info, n);
     hipFuncAttributes fa;
     int rf = -1, rg = -1, rr = -1;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP>) == hipSuccess) rf = fa.numRegs;

@@ -76,6 +76,18 @@ inline int default_config(pbre_config* c, int robot, int task) {
     return PBRE_OK;
 }
 
+// pbre_physics -> the device parameter block (the robot tables do not depend on pbre_physics); false on bad values
+inline bool apply_physics(const pbre_physics& p, Params& P2) {
+    if (p.solver_iters <= 0 || p.dt <= 0 || p.obj_mass <= 0) return false;
+    P2.dt = (float)p.dt; P2.inv_dt = (float)(1.0 / p.dt); P2.gz = (float)p.gravity_z; P2.iters = p.solver_iters;
+    P2.erp = (float)p.erp; P2.slop = (float)p.linear_slop; P2.margin = (float)p.contact_margin;
+    P2.kl = (float)p.lin_damping; P2.ka = (float)p.ang_damping; P2.vmax = (float)p.max_coord_vel;
+    P2.motor_imp = (float)p.max_motor_impulse; P2.limit_imp = (float)p.limit_max_impulse;
+    for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
+    P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
+    return true;
+}
+
 // number of DoF the RobotTable declares (0 if it is not a table): selects the lane shape
 inline int table_ndof(const pbre_config& c) {
     return (c.robot_table && c.robot_table_len >= 24 && c.robot_table[0] == 1346523717.0) ? (int)c.robot_table[3] : 0;

@@ -14,9 +14,10 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture(scope="session", autouse=True)
 def built():
-    """Oracle + host-emulation libraries (CPU only; the HIP library is built by __graft_entry__.build())."""
+    """Oracle + host-emulation libraries (CPU only; the HIP library is built by __graft_entry__.build()).  Session-wide and
+    first: the `make` subprocesses must be forked before any test initialises the HIP runtime in this process."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host_emu")])
     return True
@@ -36,7 +37,7 @@ def emu_lib(built):
 
 
 @pytest.fixture(scope="session")
-def hip_lib():
+def hip_lib(built):
     from pybullet_robot_envs import _capi
     if not os.path.exists(_capi.LIB_PATH):
         subprocess.check_call(["bash", os.path.join(ROOT, "pybullet-robot-envs_amd", "csrc", "build.sh")])
