@@ -126,6 +126,10 @@ class Engine:
         self._chk(self.lib.pbre_dims(self._ctx, C.byref(od), C.byref(ad), C.byref(n)))
         self.obs_dim, self.act_dim, self.num_envs = od.value, ad.value, n.value
         self.state_floats = int(self.lib.pbre_state_floats(self._ctx))
+        # state record layout (include/pbre.h): Q[W] | V[W] | X[16]; object pose at Q[ndof..ndof+7)
+        self.ndof = int(self._table[3])
+        self.v_off = (self.state_floats - 16) // 2
+        self.x_off = self.state_floats - 16
         self._out = np.zeros((self.num_envs, self.obs_dim + 2), np.float32)
 
     def _chk(self, rc):

@@ -1,6 +1,184 @@
-"""iCubEnv / iCubHandsEnv placeholders (reference icub_env.py, icub_env_with_hands.py); see icub_reach_gym_env.py."""
+"""iCubEnv -- robot side of the scene (reference pybullet_robot_envs/envs/icub_envs/icub_env.py).
+
+Keeps the reference constructor signature and the attributes / methods the task envs use.  The SDF is parsed once by the
+engine's own model compiler (model/sdf.py -> robot_data/iCub/icub_model.json) and handed to libpbre as a flat RobotTable;
+the floating base pinned by `p.createConstraint(JOINT_FIXED)` (icub_env.py:97-103) is a fixed base at the constraint's
+rest pose (model/table.py pin_base).  All per-step work (IK, motors, dynamics, observation) runs on the GPU, one env per
+wavefront (csrc/pbre_wide.hip)."""
+import math as m
+
+import numpy as np
+
+from pybullet_robot_envs import _client
+from pybullet_robot_envs._gym import seeding
+from pybullet_robot_envs.model.table import icub_table, ICUB_HOME
 
 
-class iCubEnv(object):
+class iCubEnv:
+
+    initial_positions = dict(ICUB_HOME)
+
+    joint_groups = {'l_leg': ['l_knee', 'l_ankle_pitch', 'l_hip_pitch'],
+                    'r_leg': ['r_knee', 'r_ankle_pitch', 'r_hip_pitch'],
+                    'head': ['neck_pitch', 'neck_roll', 'neck_yaw'],
+                    'torso': ['torso_pitch', 'torso_roll', 'torso_yaw'],
+                    'l_arm': ['l_shoulder_pitch', 'l_shoulder_roll', 'l_shoulder_yaw',
+                              'l_elbow', 'l_wrist_pitch', 'l_wrist_prosup', 'l_wrist_yaw'],
+                    'r_arm': ['r_shoulder_pitch', 'r_shoulder_roll', 'r_shoulder_yaw',
+                              'r_elbow', 'r_wrist_pitch', 'r_wrist_prosup', 'r_wrist_yaw'],
+                    }
+
     def __init__(self, physicsClientId, use_IK=0, control_arm='l', control_orientation=1, control_eu_or_quat=0):
-        raise NotImplementedError("iCubEnv is not implemented by the MI355X engine yet (DESIGN.md 'Out of scope')")
+
+        self._physics_client_id = physicsClientId
+        self._client = _client.get(physicsClientId)
+        self._client.robot = self
+        self._use_IK = use_IK
+        self._control_orientation = control_orientation
+        self._control_eu_or_quat = control_eu_or_quat
+        self._control_arm = control_arm if control_arm == 'r' or control_arm == 'l' else 'l'  # left arm by default
+
+        self.end_eff_idx = []
+
+        self._workspace_lim = [[0.1, 0.45], [-0.3, 0.3], [0.5, 1.0]]
+        self._eu_lim = [[-m.pi/2, m.pi/2], [-m.pi/2, m.pi/2], [-m.pi/2, m.pi/2]]
+
+        # set initial hand pose (icub_env.py:66-74)
+        if self._control_arm == 'l':
+            self._home_hand_pose = [0.3, 0.26, 0.8, 0, 0, 0]  # x, y, z, roll, pitch, yaw
+            self._eu_lim = [[-m.pi / 2, m.pi / 2], [-m.pi / 2, m.pi / 2], [-m.pi / 2, m.pi / 2]]
+        else:
+            self._home_hand_pose = [0.3, -0.26, 0.8, 0, 0, m.pi]
+            self._eu_lim = [[-m.pi / 2, m.pi / 2], [-m.pi / 2, m.pi / 2], [m.pi / 2, 3 / 2 * m.pi]]
+
+        self._joints_to_control = []
+        self._joints_to_block = []
+        self._joint_name_to_ids = {}
+
+        self.robot_id = 0
+
+        self.ll, self.ul, self.jr, self.rs, self.jd = None, None, None, None, None
+
+        if control_eu_or_quat != 0:
+            raise NotImplementedError("control_eu_or_quat=1 (quaternion actions / observations) is not implemented")
+
+        self.seed()
+        self.reset()
+
+    def reset(self):
+        # Load robot model: parsed parameters -> RobotTable (replaces p.loadSDF + p.createConstraint, icub_env.py:91-103)
+        self.robot_table, self._model, self._info = icub_table(self._control_arm)
+        self._joint_name_to_ids = {}
+        for i, link in enumerate(self._model["links"]):
+            if link["jtype"] != 0:
+                assert link["joint_name"] in self.initial_positions.keys()
+                self._joint_name_to_ids[link["joint_name"]] = i
+
+        # save indices of the joints to control (icub_env.py:123-143): torso + the chosen arm, in link-index order
+        if len(self._joints_to_control) == 0:
+            for joint_name in self._joint_name_to_ids.keys():
+                if joint_name in self.joint_groups['torso']:
+                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
+                elif (joint_name in self.joint_groups['l_arm'] and self._control_arm == 'l') or \
+                     (joint_name in self.joint_groups['r_arm'] and self._control_arm == 'r'):
+                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
+                else:
+                    self._joints_to_block.append(self._joint_name_to_ids[joint_name])
+                if (self._control_arm == 'l' and joint_name == 'l_wrist_yaw') or \
+                   (self._control_arm == 'r' and joint_name == 'r_wrist_yaw'):
+                    self.end_eff_idx = self._joint_name_to_ids[joint_name]
+        assert self.end_eff_idx == self._info["ee_link"]
+
+        self.ll, self.ul, self.jr, self.rs, self.jd = self.get_joint_ranges()
+        # `if self._use_IK: self.apply_action(self._home_hand_pose)` + `p.stepSimulation()` (icub_env.py:147-151) happen inside
+        # the engine's reset (pbre_reset)
+
+    def controlled_dofs(self):
+        """DoF indices (engine numbering) of _joints_to_control, same order."""
+        dof_of_link = {}
+        d = 0
+        for i, link in enumerate(self._model["links"]):
+            if link["jtype"] != 0:
+                dof_of_link[i] = d
+                d += 1
+        return [dof_of_link[i] for i in self._joints_to_control]
+
+    def get_joint_ranges(self):
+        lower_limits, upper_limits, joint_ranges, rest_poses, joint_dumping = [], [], [], [], []
+        for joint_name in self._joint_name_to_ids.keys():
+            link = self._model["links"][self._joint_name_to_ids[joint_name]]
+            ll, ul = link["lower"], link["upper"]
+            lower_limits.append(ll)
+            upper_limits.append(ul)
+            joint_ranges.append(ul - ll)
+            rest_poses.append(self.initial_positions[joint_name])
+            joint_dumping.append(0.1 if self._joint_name_to_ids[joint_name] in self._joints_to_control else 100.)
+        return lower_limits, upper_limits, joint_ranges, rest_poses, joint_dumping
+
+    def get_workspace(self):
+        return [i[:] for i in self._workspace_lim]
+
+    def set_workspace(self, ws):
+        self._workspace_lim = [i[:] for i in ws]
+
+    def get_rotation_lim(self):
+        return [i[:] for i in self._eu_lim]
+
+    def set_rotation_lim(self, eu):
+        self._eu_lim = [i[:] for i in eu]
+
+    def get_action_dim(self):
+        if not self._use_IK:
+            return len(self._joints_to_control)
+        if self._control_orientation and self._control_eu_or_quat == 0:
+            return 6  # position x,y,z + roll/pitch/yaw of hand frame
+        elif self._control_orientation and self._control_eu_or_quat == 1:
+            return 7  # position x,y,z + quat of hand frame
+        return 3  # position x,y,z
+
+    def get_observation_dim(self):
+        return 9 + len(self._joints_to_control)
+
+    def get_observation_limits(self):
+        lim = []
+        lim.extend(list(self._workspace_lim))
+        lim.extend(self._eu_lim)
+        lim.extend([[-1, 1], [-1, 1], [-1, 1]])
+        lim.extend([[self.ll[i], self.ul[i]] for i, idx in enumerate(self._joint_name_to_ids.values())
+                    if idx in self._joints_to_control])
+        return lim
+
+    def get_observation(self):
+        """Hand COM pose (3 + 3 Euler), its linear velocity (3) and the controlled joint positions (10) with their limits
+        (icub_env.py:202-249).  List of 19 for a single env, [N, 19] array for a batch."""
+        eng = self._client.require_engine()
+        obs = eng.observe()[:, :self.get_observation_dim()].astype(np.float64)
+        if obs.shape[0] == 1:
+            return list(obs[0]), self.get_observation_limits()
+        return obs, self.get_observation_limits()
+
+    def _com_to_link_hand_frame(self):
+        if self._control_arm == 'r':
+            com_T_link_hand = ((0.064668, -0.0056, -0.022681), (0., 0., 0., 1.))
+        else:
+            com_T_link_hand = ((-0.064768, -0.00563, -0.02266), (0., 0., 0., 1.))
+        return com_T_link_hand
+
+    def apply_action(self, action, max_vel=-1):
+        raise NotImplementedError("IK and motor targets are applied inside the fused GPU step; use the task env's step()")
+
+    def delete_simulated_robot(self):
+        pass
+
+    def seed(self, seed=None):
+        self.np_random, seed = seeding.np_random(seed)
+        return [seed]
+
+    def debug_gui(self):
+        pass
+
+
+class iCubHandsEnv(object):
+    def __init__(self, *a, **kw):
+        raise NotImplementedError("iCubHandsEnv (icub_model_with_hands.sdf, 72 DoF) is not implemented by the MI355X engine yet "
+                                  "(DESIGN.md 'Out of scope': more than 32 DoF does not fit one wavefront's lanes)")

@@ -186,20 +186,22 @@ class PandaTaskBase(Env):
     # ------------------------------------------------------------------ reference attributes
     @property
     def _env_step_counter(self):
-        return self._squeeze(self._engine.get_state()[:, 35].astype(np.int64))
+        return self._squeeze(self._engine.get_state()[:, self._engine.x_off + 3].astype(np.int64))
 
     @property
     def terminated(self):
-        return self._squeeze(self._engine.get_state()[:, 36].astype(np.int64))
+        return self._squeeze(self._engine.get_state()[:, self._engine.x_off + 4].astype(np.int64))
 
     @property
     def _hand_pose(self):
         """Commanded hand pose (x, y, z, roll, pitch, yaw) of the IK mode (panda_push_gym_env.py:142-143, 197-222)."""
-        return self._squeeze(self._engine.get_state()[:, 38:44].astype(np.float64))
+        x = self._engine.x_off
+        return self._squeeze(self._engine.get_state()[:, x + 6:x + 12].astype(np.float64))
 
     @property
     def _target_pose(self):
-        return self._squeeze(self._engine.get_state()[:, 32:35].astype(np.float64))
+        x = self._engine.x_off
+        return self._squeeze(self._engine.get_state()[:, x:x + 3].astype(np.float64))
 
     def debug_gui(self):
         pass

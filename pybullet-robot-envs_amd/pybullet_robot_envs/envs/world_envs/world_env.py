@@ -81,8 +81,9 @@ class WorldEnv:
 
     def get_object_pose(self):
         """Batched object position [N,3] and quaternion [N,4]."""
-        st = self._client.require_engine().get_state()
-        return st[:, 9:12].astype(np.float64), st[:, 12:16].astype(np.float64)
+        eng = self._client.require_engine()
+        st, o = eng.get_state(), eng.ndof
+        return st[:, o:o + 3].astype(np.float64), st[:, o + 3:o + 7].astype(np.float64)
 
     def get_observation(self):
         """Object position + Euler angles and their limits (world_env.py:109-126).  A list of 6 floats for a
@@ -91,7 +92,9 @@ class WorldEnv:
         observation_lim.extend(self._ws_lim)
         observation_lim.extend([[-m.pi, m.pi], [-m.pi, m.pi], [-m.pi, m.pi]])
         if self._client.engine is None:       # before the task env built the engine: initial pose
-            pos = np.array([[0.45, 0.0, self._h_table + 0.07]])
+            x_min, x_max = self._ws_lim[0][0] + 0.05, self._ws_lim[0][1] - 0.1          # _sample_pose, world_env.py:147-160
+            y_min, y_max = self._ws_lim[1][0] + 0.05, self._ws_lim[1][1] - 0.05
+            pos = np.array([[x_min + 0.5 * (x_max - x_min), y_min + 0.5 * (y_max - y_min), self._h_table + 0.07]])
             quat = np.array([[0.0, 0.0, m.sin(m.pi / 8), m.cos(m.pi / 8)]])
         else:
             pos, quat = self.get_object_pose()

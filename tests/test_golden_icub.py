@@ -65,3 +65,54 @@ def test_reset_and_bookkeeping():
     st2, _ = o2.batch_reset(1)
     ref2 = G["pushI_reset_state"]
     assert np.abs(st2[0, :ox] - ref2[:ox]).max() < 1e-12
+
+
+# ------------------------------------------------------------------ the drop-in env classes (device algorithm through the CPU lane emulation)
+from pybullet_robot_envs.envs import iCubReachGymEnv, iCubPushGymEnv, iCubPushGymGoalEnv  # noqa: E402
+
+ENVS = [
+    (iCubReachGymEnv, "reach", "reachG", dict(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, max_steps=5)),
+    (iCubPushGymEnv, "push", "pushH", dict(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0, max_steps=1000, reward_type=0)),
+    (iCubPushGymEnv, "pushr", "pushI", dict(use_IK=1, control_arm='r', control_orientation=1, max_steps=6, reward_type=1)),
+    (iCubPushGymEnv, "pushj", "pushJ", dict(use_IK=0, control_arm='l', max_steps=1000, reward_type=1)),
+    (iCubPushGymGoalEnv, "goal", "goalK", dict(use_IK=1, control_arm='r', control_orientation=1, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0, max_steps=4)),
+]
+
+
+@pytest.mark.parametrize("cls,stag,tag,kw", ENVS)
+def test_env_classes_match_reference(emu_lib, cls, stag, tag, kw):
+    replay_env(emu_lib, cls, stag, tag, kw)
+
+
+def replay_env(lib, cls, stag, tag, kw):
+    """Spaces bit-identical to the reference's; step() returns what the reference classes returned (scaled obs, reward,
+    done, counter, is_success) step by step from the reference's own states."""
+    env = cls(_lib=lib, **kw)
+    goal = stag == "goal"
+    box = env.observation_space["observation"] if goal else env.observation_space
+    assert box.low.dtype == np.float32 and box.low.tobytes() == G[stag + "_obs_low"].tobytes()
+    assert box.high.tobytes() == G[stag + "_obs_high"].tobytes()
+    assert env.action_space.low.tobytes() == G[stag + "_act_low"].tobytes() and env.action_space.high.tobytes() == G[stag + "_act_high"].tobytes()
+    if stag in ("reach", "push"):
+        o = env.reset()
+        assert np.abs(o - G[tag + "_reset_obs"]).max() < 2e-3
+    pre, act = G[tag + "_pre_state"], G[tag + "_actions"]
+    for k in range(len(act)):
+        env._engine.set_state(pre[k:k + 1].astype(np.float32))
+        ob, r, d, info = env.step(act[k])
+        ob = ob["observation"] if goal else ob
+        assert ob.dtype == np.float64 and ob.shape == G[tag + "_obs"][k].shape
+        assert np.abs(ob - G[tag + "_obs"][k]).max() < 5e-3
+        assert abs(float(r) - G[tag + "_reward"][k]) < 1e-3 * max(1, abs(G[tag + "_reward"][k]))
+        assert float(d) == G[tag + "_done"][k]
+        assert int(env._env_step_counter) == G[tag + "_counter"][k]
+        if goal:
+            assert bool(info["is_success"]) == bool(G[tag + "_success"][k])
+    if stag == "pushr":   # host-side restatements of the reference helpers agree with what step() returned
+        assert abs(float(env._compute_reward()) - float(r)) < 1e-4 and float(env._termination()) == float(d)
+
+
+def test_registered_ids():
+    import pybullet_robot_envs
+    ids = [i for i, _, _ in pybullet_robot_envs._IDS]
+    assert ids[:3] == ['iCubReach-v0', 'iCubPush-v0', 'iCubPushGoal-v0']

@@ -37,3 +37,12 @@ def test_icub_masked_reset_and_rollout(hip_lib):
     assert np.array_equal(s2[keep], se[keep])
     assert (s2[[1, 5], 128 + 5] == 1).all() and (s2[keep, 128 + 5] == 0).all()      # episode numbers
     assert np.abs(s2[[1, 5], 128 + 6:128 + 9] - [0.3, 0.26, 0.8]).max() < 1e-6
+
+
+import test_golden_icub as tgi  # noqa: E402
+
+
+@pytest.mark.parametrize("cls,stag,tag,kw", tgi.ENVS)
+def test_env_classes_match_reference_outputs(hip_lib, cls, stag, tag, kw):
+    """The drop-in iCub Gym classes on the GPU against the outputs captured from the reference's own classes."""
+    tgi.replay_env(hip_lib, cls, stag, tag, kw)
