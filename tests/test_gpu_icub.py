@@ -46,3 +46,9 @@ import test_golden_icub as tgi  # noqa: E402
 def test_env_classes_match_reference_outputs(hip_lib, cls, stag, tag, kw):
     """The drop-in iCub Gym classes on the GPU against the outputs captured from the reference's own classes."""
     tgi.replay_env(hip_lib, cls, stag, tag, kw)
+
+
+def test_config1_icub_reach_trace(hip_lib):
+    """BASELINE config 1 (iCubReach-v0, 1 env, fixed action sequence, 500 closed-loop steps) against the trace captured from
+    the reference class."""
+    tgi.check_config1(hip_lib, 500)

@@ -196,6 +196,18 @@ envK = iCubPushGymGoalEnv(use_IK=1, control_arm='r', control_orientation=1, obj_
 spaces_of(envK, "goal", goal=True)
 rollout(envK, "goalK", rng.uniform(-1, 1, (8, 6)), goal=True, set_target=(0.33, -0.2, 0.64999))
 rollout(envK, "goalL", rng.uniform(-1, 1, (3, 6)), goal=True)
+# BASELINE config 1: iCubReach-v0 kwargs, 1 env, fixed action sequence, closed loop for 500 steps
+envC1 = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, max_steps=1000)
+builtins.print = lambda *a, **k: None
+o0 = envC1.reset()
+tr_obs, tr_rew, tr_done = [o0], [], []
+for t in range(500):
+    a = 0.5 * np.array([np.sin(0.05 * t), np.cos(0.05 * t), np.sin(0.03 * t)])
+    o, r, d, _ = envC1.step(a)
+    tr_obs.append(o); tr_rew.append(float(r)); tr_done.append(float(d))
+builtins.print = _print
+out["cfg1_obs_every10"] = np.array(tr_obs)[::10]
+out["cfg1_reward"] = np.array(tr_rew); out["cfg1_done"] = np.array(tr_done)
 out["joints_to_control_l"] = np.array(envJ._robot._joints_to_control)
 out["joints_to_control_r"] = np.array(envI._robot._joints_to_control)
 out["end_eff_idx"] = np.array([envJ._robot.end_eff_idx, envI._robot.end_eff_idx])
