@@ -45,7 +45,11 @@ enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
        PBRE_F_AUTO_RESET = 2,     /* done envs are re-initialised from the settled snapshot at the next step */
-       PBRE_F_FORCE_GENERAL = 4 };/* step every env with the general 16-lane row kernel (disable the lane-per-env fast path) */
+       PBRE_F_FORCE_GENERAL = 4,  /* step every env with the general 16-lane row kernel (disable the lane-per-env fast path) */
+       /* Envs with robot contacts / joints at a limit ("complex") are stepped by one of two kernels; the engine picks by
+        * their number (row kernel while they are few: lowest latency; lane-per-env k_fast_rc when many: highest throughput).
+        * These two flags pin the choice (validation, A/B): */
+       PBRE_F_COMPLEX_ROWS = 8, PBRE_F_COMPLEX_LANES = 16 };
 
 typedef struct pbre_ctx pbre_ctx;
 

@@ -77,10 +77,11 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 template <int MODE>
 __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                               const float* __restrict__ tgt) {
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
     const int env = blockIdx.x * FTPB + threadIdx.x;
-    if (env >= n || cls[env] != 0) return;
+    if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
+    if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                               (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                               (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
@@ -95,9 +96,10 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                  const float* __restrict__ tgt) {
-    int chunks[NB], total = 0;
-    PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; }
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total) {
+    int chunks[NB], total = 0, envs = 0;
+    PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; envs += cur_count[b]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_total = envs;    // pinned host memory: scheduling hint for the next launches
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         int b = 0, k = w;
         PBRE_UNROLL for (int j = 0; j < NB - 1; j++) if (b == j && k >= chunks[j]) { k -= chunks[j]; b = j + 1; }
@@ -107,6 +109,42 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
             const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                                          (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                                          (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+            publish_class(env, c, cls, next_list, next_count, cap);
+        }
+    }
+}
+
+// Complex envs, few of them: one env per 16-lane row (4 per wave) over the compacted list.  The physics of the step is the
+// general row kernel's (Core::step: all row types), the observation / reward / termination / auto-reset / class of the new
+// state is the lane-per-env kernels' Fast::finish run by lane 0 of the row, so both complex-env kernels are interchangeable.
+// A row spreads an env over 16 lanes, so a wave's latency is ~1/3 of a k_fast_rc wave's: with few complex envs the step is
+// no longer gated by that latency.  Grid-stride over the list (the host only has a hint of its length).
+template <int MODE>
+__global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
+                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base) {
+    static_assert(NB == 1, "the row kernel walks a single complex list");
+    const int total = cur_count[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_total = total;
+    const int row = threadIdx.x >> 4;
+    constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
+    for (int base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {
+        const int i = base + row;
+        const bool real = i < total;
+        const int env = real ? cur_list[i] : dummy_base + row;           // idle rows step a dummy record in lockstep
+        float* st = state + (size_t)env * STATE;
+        CoreD::step(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
+                    (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
+        if (real && (threadIdx.x & 15u) == 0) {
+            float q[NJ], qd[NJ];
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+            FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
+            FastD::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+            const int c = FastD::finish(*T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
+                                        P.env_id_base + (unsigned long long)env);
             publish_class(env, c, cls, next_list, next_count, cap);
         }
     }
@@ -127,6 +165,12 @@ __global__ __launch_bounds__(FTPB) void k_classify(const Tables* __restrict__ T,
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (env >= n) return;
     publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count, cap);
+}
+
+__global__ void k_total(const int* __restrict__ count, int* __restrict__ host_total) {
+    int t = 0;
+    for (int b = 0; b < NB; b++) t += count[b];
+    *host_total = t;
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -163,11 +207,14 @@ __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src
 // ------------------------------------------------------------------ context
 struct EnvBuf {                       // a batch of state records with its class bookkeeping
     float* state = nullptr;           // cap + 16 records
-    signed char* cls = nullptr;       // class per env
+    signed char* cls = nullptr;       // [2][cap] class per env: cls + cur*cap describes the current state, a step writes the other half (the
+                                      // two kernels of a step run concurrently, so k_fast must not see classes the other one just produced)
     float* tgt = nullptr;             // [cap + 16][NJ] joint targets of the IK mode
     int* list[2] = {nullptr, nullptr};  // each [NB][cap]
-    int* count = nullptr;             // [2][NB]
-    int cur = 0;                      // list[cur] / count + cur*NB: complex envs of the current state, per class
+    int* count = nullptr;             // [3][NB]: counters rotate over three buffers so that the one the step after next
+                                      // appends to can be zeroed by a kernel of the current step (no memset on the hot path)
+    int cur = 0, ccur = 0;            // list[cur] / count + ccur*NB: complex envs of the current state, per class
+    int* h_total = nullptr;           // pinned host int the device writes the complex-env count of the step it runs into
     int cap = 0;
 };
 
@@ -182,12 +229,15 @@ struct pbre_ctx {
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
     int n_simd = 1024;
+    int rc_first_min = 1;              // complex envs (reported by the device) from which their kernel is scheduled ahead of k_fast
+    int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING steps,
-    hipEvent_t ev_k[KRING][2] = {};            // recorded on the stream that kernel runs on
-    long k_steps = 0;
+    static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
+    static constexpr int KSAMPLE = 4;          // (every KSAMPLE-th launch is sampled) recorded on the stream that kernel runs on
+    hipEvent_t ev_k[KRING][2] = {};
+    long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
     std::string err;
 };
@@ -209,24 +259,28 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     b.cap = cap;
     hipError_t e;
     if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMalloc(&b.cls, (size_t)cap)) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.cls, (size_t)2 * cap)) != hipSuccess) return e;
     if ((e = hipMalloc(&b.tgt, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.tgt, 0, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMemset(b.cls, 0, (size_t)cap)) != hipSuccess) return e;
+    if ((e = hipMemset(b.cls, 0, (size_t)2 * cap)) != hipSuccess) return e;
     for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&b.count, 2 * NB * sizeof(int))) != hipSuccess) return e;
-    return hipMemset(b.count, 0, 2 * NB * sizeof(int));
+    if ((e = hipMalloc(&b.count, 3 * NB * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipHostMalloc(&b.h_total, sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
+    *b.h_total = 1;                   // unknown until the first step has run
+    return hipMemset(b.count, 0, 3 * NB * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
     for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
+    if (b.h_total) (void)hipHostFree(b.h_total);
 }
 
 // (re)build class array and current list of the first n envs of b
 static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t s) {
     if (!lane_per_env(c)) return hipSuccess;
-    hipError_t e = hipMemsetAsync(b.count + b.cur * NB, 0, NB * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(b.count + b.ccur * NB, 0, NB * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls, b.list[b.cur], b.count + b.cur * NB, b.cap);
+    hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls + (size_t)b.cur * b.cap, b.list[b.cur], b.count + b.ccur * NB, b.cap);
+    hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, b.count + b.ccur * NB, b.h_total);
     return hipGetLastError();
 }
 
@@ -243,25 +297,48 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         return hipGetLastError();
     }
     const int cur = b.cur, nxt = cur ^ 1;
+    const int cc = b.ccur, cn = (cc + 1) % 3, cz = (cc + 2) % 3;      // counters: current, next (zero on entry), the one after
     const int blocks = (n + FTPB - 1) / FTPB;
     hipError_t e;
-    if ((e = hipMemsetAsync(b.count + nxt * NB, 0, NB * sizeof(int), s)) != hipSuccess) return e;
-    // fork/join: k_fast_rc (few waves, whole register file each) is enqueued first on the caller's stream so that its waves
-    // claim their SIMDs before k_fast floods the chip from the side stream; both run concurrently and append to list[nxt]
+    // The two kernels of a step run concurrently on two streams (fork/join events) and both append to list[nxt].
+    // Which one gets the caller's stream is a scheduling choice made from the complex-env count the device reported for
+    // an earlier step (a hint; either order is correct):
+    //  * complex envs present: k_fast_rc (few waves, each needs a whole SIMD's register file, long latency) is enqueued first on
+    //    the caller's stream so that its waves claim their SIMDs before k_fast floods the chip from the side stream;
+    //  * none (e.g. the first steps after a reset): k_fast stays on the caller's stream, the (empty) k_fast_rc goes to the side
+    //    stream, and consecutive k_fast launches run back to back without a cross-stream dependency on their critical path.
+    const int hint = *b.h_total;
+    const bool rc_first = hint >= c->rc_first_min;
+    hipStream_t s_rc = rc_first ? s : c->side, s_fast = rc_first ? c->side : s;
     if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
-                       b.list[cur], b.count + cur * NB, b.cls, b.list[nxt], b.count + nxt * NB, b.cap, b.tgt);
+    // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
+    bool rows = NB == 1 && hint <= c->row_max;
+    if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
+    if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
+    if constexpr (NB == 1) {
+        if (rows) {
+            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));
+            hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(TPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+                               b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap);
+        }
+    }
+    if (!rows)
+        hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+                           b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
+    // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
+    const bool timed = (c->launches++ % pbre_ctx::KSAMPLE) == 0;
     hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
-    (void)hipEventRecord(ek[0], c->side);
-    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, c->side, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                       b.cls, b.list[nxt], b.count + nxt * NB, b.cap, b.tgt);
+    if (timed) (void)hipEventRecord(ek[0], s_fast);
+    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                       b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    (void)hipEventRecord(ek[1], c->side);
-    c->k_steps++;
+    if (timed) { (void)hipEventRecord(ek[1], s_fast); c->k_steps++; }
     if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
     if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+    b.ccur = cn;
     b.cur = nxt;
     return hipSuccess;
 }
@@ -325,6 +402,8 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->n = cfg->num_envs; c->npad = ceil16(c->n); c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg);
     c->ow = c->obs_dim + 2; c->device = cfg->device_id;
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
+    if (const char* ev = getenv("PBRE_RC_FIRST_MIN")) c->rc_first_min = atoi(ev);       // A/B knobs
+    if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     if ((cfg->flags & PBRE_F_AUTO_RESET) && !lane_per_env(c)) {
         g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel (needs the lane-per-env kernels: Panda topology, cube object, no PBRE_F_FORCE_GENERAL)";
         delete c; return PBRE_E_UNSUPPORTED;
@@ -469,6 +548,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_objz = rec[11];
         }
     }
+    c->k_steps = 0; c->launches = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -586,7 +666,7 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (lpe) {
         int cnt[NB] = {0};
         (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
-        (void)hipMemcpy(cnt, c->main.count + c->main.cur * NB, NB * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(cnt, c->main.count + c->main.ccur * NB, NB * sizeof(int), hipMemcpyDeviceToHost);
         for (int k = 0; k < NB; k++) complex_now += cnt[k];
     }
     const int v[7] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1};

@@ -47,6 +47,16 @@ struct Emu : pbre_ctx {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
                 if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
+                else if (cfg.flags & PBRE_F_COMPLEX_ROWS) {
+                    // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
+                    n_rc++;
+                    CoreH::step(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg);
+                    float q[NJ], qd[NJ];
+                    for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+                    FastH::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
+                    FastH::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+                    FastH::finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id);
+                }
                 else { n_rc++; FastH::step_rc(T, P, st, act, out, mode, flags, env_id, tg); }
                 return;
             }

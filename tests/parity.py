@@ -84,14 +84,14 @@ def contact_states(ora, panda, base, rng, n_table=8, n_obj=8):
         scenarios.object_contact_states(ora, panda["model"], panda["spheres"], base, n_obj, rng)])
 
 
-def check_auto_reset(Engine, lib, table, n=12, max_steps=4):
+def check_auto_reset(Engine, lib, table, n=12, max_steps=4, flags=0):
     """PBRE_F_AUTO_RESET: when an env finishes, the same step re-initialises it (snapshot reset).  The state it lands in
     must equal -- up to the settle transients the snapshot skips -- what an explicit masked pbre_reset produces for the
     same episode number, and the step returns the terminal transition's reward/done with the fresh observation."""
     F_AUTO = 2
     kw = dict(task=1, num_envs=n, lib=lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, max_steps=max_steps)
-    auto = Engine(table, flags=F_AUTO, **kw)
-    ref = Engine(table, **kw)
+    auto = Engine(table, flags=F_AUTO | flags, **kw)
+    ref = Engine(table, flags=flags, **kw)
     o_a, o_r = auto.reset(), ref.reset()
     assert np.array_equal(o_a, o_r)
     rng = np.random.default_rng(9)

@@ -15,18 +15,21 @@ def test_reset_and_steps(panda, emu_lib, task):
     parity.check_single_steps(eng, ora, st, np.random.default_rng(0), steps=4)
 
 
-def test_contact_rich_states(panda, emu_lib):
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS])
+def test_contact_rich_states(panda, emu_lib, flags):
+    """flags: which kernel steps the envs with robot contacts (0: lane-per-env k_fast_rc, F_COMPLEX_ROWS: row kernel + Fast::finish)"""
     eng0, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 1)
     base, _ = ora.batch_reset(1)
     rng = np.random.default_rng(1)
     S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
-    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], len(S))
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], len(S), flags=flags)
     # stiff motor-vs-contact conflicts amplify fp32 rounding: the oracle's own fp32 build is 1.5e-4 away
     parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
 
 
-def test_joint_limit_rows(panda, emu_lib):
-    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 4)
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS])
+def test_joint_limit_rows(panda, emu_lib, flags):
+    eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 4, flags=flags)
     st, _ = ora.batch_reset(4)
     st[0, 3] = 0.02       # joint 4 above its upper limit 0.0
     st[1, 5] = -0.12      # joint 6 below its lower limit -0.0873

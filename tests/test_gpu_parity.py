@@ -17,17 +17,21 @@ def test_reset_and_steps(panda, hip_lib, task):
     parity.check_single_steps(eng, ora, st, np.random.default_rng(0), steps=6)
 
 
-def test_contact_rich_states(panda, hip_lib):
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES])
+def test_contact_rich_states(panda, hip_lib, flags):
+    """flags: which kernel steps the envs with robot contacts (0: the engine's choice by their number, F_COMPLEX_ROWS: k_row_list,
+    F_COMPLEX_LANES: k_fast_rc)"""
     _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
     base, _ = ora.batch_reset(1)
     rng = np.random.default_rng(1)
     S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
-    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], len(S))
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], len(S), flags=flags)
     parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
 
 
-def test_joint_limit_rows(panda, hip_lib):
-    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 4)
+@pytest.mark.parametrize("flags", [_capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES])
+def test_joint_limit_rows(panda, hip_lib, flags):
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 4, flags=flags)
     st, _ = ora.batch_reset(4)
     st[0, 3] = 0.02
     st[1, 5] = -0.12
@@ -157,8 +161,9 @@ def test_reference_golden_outputs(hip_lib):
         env.close()
 
 
-def test_auto_reset(panda, hip_lib):
-    parity.check_auto_reset(_capi.Engine, hip_lib, panda["table"], n=200, max_steps=4)
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES])
+def test_auto_reset(panda, hip_lib, flags):
+    parity.check_auto_reset(_capi.Engine, hip_lib, panda["table"], n=200, max_steps=4, flags=flags)
 
 
 def test_lane_per_env_kernels_match_row_kernel(panda, hip_lib):
@@ -172,16 +177,19 @@ def test_lane_per_env_kernels_match_row_kernel(panda, hip_lib):
     n = len(S)
     a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
     kw = dict(task=1, num_envs=n, lib=hip_lib)
-    f = _capi.Engine(panda["table"], **kw)
     g = _capi.Engine(panda["table"], flags=_capi.F_FORCE_GENERAL, **kw)
-    f.set_state(S); g.set_state(S)
-    info = f.kernel_info()
-    assert info[2] == 1 and info[5] >= 40                      # fast path enabled, most of these states are "complex"
-    rf, rg = f.step(a), g.step(a)
+    g.set_state(S)
+    rg = g.step(a)
     amb = parity.ambiguous_envs(ora, S.astype(np.float64), a)
     ok = ~amb
-    assert parity.rel(f.get_state()[ok], g.get_state()[ok].astype(np.float64)).max() < 1e-3
-    assert parity.rel(rf[0][ok], rg[0][ok].astype(np.float64)).max() < 5e-3
+    for fl in (_capi.F_COMPLEX_LANES, _capi.F_COMPLEX_ROWS):   # both kernels for the complex envs
+        f = _capi.Engine(panda["table"], flags=fl, **kw)
+        f.set_state(S)
+        info = f.kernel_info()
+        assert info[2] == 1 and info[5] >= 40                  # fast path enabled, most of these states are "complex"
+        rf = f.step(a)
+        assert parity.rel(f.get_state()[ok], g.get_state()[ok].astype(np.float64)).max() < 1e-3
+        assert parity.rel(rf[0][ok], rg[0][ok].astype(np.float64)).max() < 5e-3
 
 
 def test_env_classes_and_tensor_api(hip_lib):
