@@ -92,7 +92,24 @@ struct Fast {
         return C;
     }
     static PBRE_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    static PBRE_HD float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // one v_med3_f32 (lo <= hi, no NaNs)
+    // Joint-space velocity vector as register pairs: w += d * column is 5 v_pk_fma_f32 (2 fp32 FMAs per lane and instruction)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    struct WV { f2 p[(ND + 1) / 2]; };
+    static PBRE_HD float wget(const WV& w, int k) { return w.p[k >> 1][k & 1]; }
+    static PBRE_HD void wset(WV& w, int k, float v) { w.p[k >> 1][k & 1] = v; }
+    static PBRE_HD void waxpy(WV& w, float d, const WV& col) {
+        const f2 dd = {d, d};
+        PBRE_UNROLL for (int i = 0; i < (ND + 1) / 2; i++) w.p[i] = __builtin_elementwise_fma(dd, col.p[i], w.p[i]);
+    }
+#else
     static PBRE_HD float med3(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+    struct WV { float v[2 * ((ND + 1) / 2)]; };
+    static PBRE_HD float wget(const WV& w, int k) { return w.v[k]; }
+    static PBRE_HD void wset(WV& w, int k, float v) { w.v[k] = v; }
+    static PBRE_HD void waxpy(WV& w, float d, const WV& col) { for (int k = 0; k < 2 * ((ND + 1) / 2); k++) w.v[k] = fmaf(d, col.v[k], w.v[k]); }
+#endif
     static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
     struct Q4 { float x, y, z, w; };
@@ -365,11 +382,15 @@ struct Fast {
         // ---- unconstrained joint velocities w = v*; motor rows (btMultiBodyJointMotor) written against the running
         //      velocity w = v* + dv:  t = dinv*w - rhs2 with rhs2 = (kp (q_des - q)/dt + (1 - kd) v*) dinv
         const float vmax = P.vmax;
-        float w[ND], m_dinv[ND], m_rhs[ND], m_app[ND];
+        WV w, Mc[ND];                 // Mc[j] = column j of M^-1 in the pair layout (entry ND of the padded vectors stays 0)
+        PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) { wset(w, k, 0.f); PBRE_UNROLL for (int j = 0; j < ND; j++) wset(Mc[j], k, 0.f); }
+        PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_UNROLL for (int k = 0; k < ND; k++) wset(Mc[j], k, Mi[sym(k, j)]);
+        float m_dinv[ND], m_rhs[ND], m_app[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
-            w[j] = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
+            const float wj = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
+            wset(w, j, wj);
             float qdes = T.home[j], kp = T.kp_hold[j], kd = T.kd_hold[j];
             if (mode & M_TGT) qdes = tgt[j];          // IK mode: all joints track the IK solution with the hold gains (panda_env.py:276-282)
             if (mode & M_ACTION) {
@@ -377,7 +398,7 @@ struct Fast {
                 if (j < T.n_act) qdes = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
             }
             m_dinv[j] = 1.f / Mi[sym(j, j)];
-            m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * w[j]) * m_dinv[j];
+            m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * wj) * m_dinv[j];
             m_app[j] = 0.f;
         }
 
@@ -524,17 +545,17 @@ struct Fast {
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
         const float mlim = P.motor_imp;
         auto motor = [&](int j) {
-            const float t = fmaf(m_dinv[j], w[j], -m_rhs[j]);
+            const float t = fmaf(m_dinv[j], wget(w, j), -m_rhs[j]);
             const float s = med3(m_app[j] - t, -mlim, mlim);
             const float d = s - m_app[j]; m_app[j] = s;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, Mi[sym(k, j)], w[k]);
+            waxpy(w, d, Mc[j]);
         };
         const float llim = P.limit_imp;
         auto limit = [&](int j) {
-            const float t = fmaf(m_dinv[j] * l_dir[j], w[j], -l_rhs[j]);
+            const float t = fmaf(m_dinv[j] * l_dir[j], wget(w, j), -l_rhs[j]);
             const float s = med3(l_app[j] - t, 0.f, llim);
             const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, Mi[sym(k, j)], w[k]);
+            waxpy(w, d, Mc[j]);
         };
         auto orow = [&](int c, int d) {
             const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
@@ -557,7 +578,7 @@ struct Fast {
         };
         auto rrow = [&](int c, int d) {       // robot contact row (RC only)
             float jv = 0.f;
-            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(rc_J[c][d][j], w[j], jv);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(rc_J[c][d][j], wget(w, j), jv);
             if (c < NC_RO) { const int co = c < NC_RO ? c : 0; jv -= dot(rc_dir[co][d], ov) + dot(rc_rxd[co][d], ow); }
             float s;
             if (d == 0) s = med3(rc_app[c][0] - fmaf(jv, rc_dinv[c][0], -rc_rhs[c]), 0.f, 1e10f);
@@ -567,7 +588,7 @@ struct Fast {
                 s = hi > 0.f ? s : rc_app[c][d];
             }
             const float dd = s - rc_app[c][d]; rc_app[c][d] = s;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(dd, rc_B[c][d][k], w[k]);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(dd, rc_B[c][d][k], wget(w, k)));
             if (c < NC_RO) {
                 const int co = c < NC_RO ? c : 0;
                 const float dm = -dd * inv_m, di = -dd * inv_I;
@@ -598,7 +619,7 @@ struct Fast {
         //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
         PBRE_REG_BARRIER();
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
-            const float v = clampf(w[j], -vmax, vmax);
+            const float v = clampf(wget(w, j), -vmax, vmax);
             qd[j] = v; q[j] = fmaf(dt, v, st[j]);
             st[j] = q[j]; st[16 + j] = v;
         }
