@@ -274,6 +274,9 @@ def main():
                          "note": "path is fp32-VALU/dependency bound (AI ~900 FLOP/B >> 25 FLOP/B machine balance); "
                                  "HBM fraction is small by construction, see valu"},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
+                     # the 157.3 TF peak assumes v_pk_fma_f32 at full rate; measured on this chip (profiles/r01_ubench_pkfma.txt) a
+                     # packed FMA takes ~2 passes, so the scalar-FMA peak (78.6 TF) is the practical ceiling of fp32 FMA code
+                     "peak_scalar_fma": FP32_VALU_PEAK_TFLOPS / 2, "frac_scalar_fma": ach_tf / (FP32_VALU_PEAK_TFLOPS / 2),
                      "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
         if not args.no_cpu_baseline and world == 1:
