@@ -163,6 +163,8 @@ def main():
             self.pending = [None, None]
             self.k = 0
 
+        gather = True
+
         def step(self, ev=None):
             b = self.k & 1
             if self.pending[b] is not None:            # the gather that read this buffer two steps ago
@@ -173,7 +175,7 @@ def main():
             self.eng.step_device(self.pool[self.k % self.pool.shape[0]].data_ptr(), self.out[b].data_ptr(), stream)
             if ev is not None:
                 ev[1].record()
-            if world > 1:                              # the one collective of the data path (RCCL over xGMI)
+            if world > 1 and self.gather:              # the one collective of the data path (RCCL over xGMI)
                 if backend == "nccl":
                     self.pending[b] = dist.gather(self.out[b], self.gathered, dst=0, async_op=True)
                 else:
@@ -202,7 +204,7 @@ def main():
             pair = float(np.mean([a.elapsed_time(b) for a, b in evs[::4]])) if events else 0.0
             return max_over_ranks([elapsed, pair])
 
-    job = Job(args.envs * world, args.warmup + 2 * args.steps + args.steady_preroll)
+    job = Job(args.envs * world, args.warmup + 3 * args.steps + args.steady_preroll)
     eng, n_local, total = job.eng, job.n_local, args.envs * world
     for k in range(args.warmup):
         job.step()
@@ -223,6 +225,16 @@ def main():
         steady = {"preroll_steps": args.steady_preroll, "value": total * args.steps / e2, "unit": "env-steps/s",
                   "ms_per_step": e2 / args.steps * 1e3, "complex_env_frac_rank0": eng.kernel_info()[5] / n_local}
     info = eng.kernel_info()
+    # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows): what the engine
+    # itself scales to when the stacked rows are not funnelled into one GPU (7 x 18.4 MB per step into rank 0 otherwise)
+    no_gather = None
+    if world > 1:
+        try:
+            job.gather = False
+            e4 = job.timed(args.steps)[0]
+            no_gather = {"value": total * args.steps / e4, "unit": "env-steps/s", "ms_per_step": e4 / args.steps * 1e3}
+        except Exception as e:
+            no_gather = {"error": repr(e)}
     del job
 
     # extra at N>1: BASELINE config 4 taken literally -- 131072 envs in TOTAL over the N GPUs (strong scaling), same gather
@@ -268,6 +280,7 @@ def main():
                        "complex_env_frac_after_timed_steps_rank0": complex_after / n_local},
             "steady_state": steady,
             "strong_scaling_128k_total": strong,
+            "sharded_consumers_no_gather": no_gather,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": pair_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
