@@ -190,16 +190,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     pbre_config cfg = c->cfg;
     cfg.phys = *phys;
     Params P2 = c->P;
-    {   // re-derive the device parameter block; the robot tables do not depend on pbre_physics
-        const pbre_physics& p = *phys;
-        if (p.solver_iters <= 0 || p.dt <= 0 || p.obj_mass <= 0) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
-        P2.dt = (float)p.dt; P2.inv_dt = (float)(1.0 / p.dt); P2.gz = (float)p.gravity_z; P2.iters = p.solver_iters;
-        P2.erp = (float)p.erp; P2.slop = (float)p.linear_slop; P2.margin = (float)p.contact_margin;
-        P2.kl = (float)p.lin_damping; P2.ka = (float)p.ang_damping; P2.vmax = (float)p.max_coord_vel;
-        P2.motor_imp = (float)p.max_motor_impulse; P2.limit_imp = (float)p.limit_max_impulse;
-        for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
-        P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
-    }
+    if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the object must keep an isotropic inertia (cube) once the lane-per-env kernels are in use"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;

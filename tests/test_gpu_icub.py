@@ -52,3 +52,8 @@ def test_config1_icub_reach_trace(hip_lib):
     """BASELINE config 1 (iCubReach-v0, 1 env, fixed action sequence, 500 closed-loop steps) against the trace captured from
     the reference class."""
     tgi.check_config1(hip_lib, 500)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5])
+def test_icub_ragged_batch_sizes(hip_lib, n):
+    parity.check_icub(_capi.Engine, hip_lib, 1, "l", 1, 0, 1, n=n, steps=2)

@@ -238,3 +238,12 @@ def test_ik_mode(panda, hip_lib, task, flags):
     eng = parity.check_ik_mode(_capi.Engine, hip_lib, panda["table"], task, flags=flags)
     info = eng.kernel_info()
     assert (info[2] == 1) == (flags == 0)
+
+
+@pytest.mark.parametrize("n", [1, 5, 17, 63, 65, 130])
+def test_ragged_batch_sizes(panda, hip_lib, n):
+    """Batch sizes that are not multiples of the 16-env row blocks / 64-env waves, with the complex envs spread over them."""
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], n)
+    st = parity.check_reset(eng, ora, n)
+    st[::3, 3] = 0.02                      # every third env: joint 4 over its limit -> complex list, row kernel
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(n), steps=2)
