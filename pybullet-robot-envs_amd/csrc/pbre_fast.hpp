@@ -94,7 +94,10 @@ struct Fast {
     static PBRE_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 #if defined(__HIP_DEVICE_COMPILE__)
     static PBRE_HD float med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }   // one v_med3_f32 (lo <= hi, no NaNs)
-    // Joint-space velocity vector as register pairs: w += d * column is 5 v_pk_fma_f32 (2 fp32 FMAs per lane and instruction)
+    // Joint-space velocity vector as (ND+1)/2 register pairs (the last pair padded with a zero): w += d * column is 5 v_pk_fma_f32 for
+    // the 9-DoF Panda.  A v_pk_fma_f32 occupies the SIMD for two passes on this chip (profiles/r01_ubench_pkfma.txt), so this is
+    // throughput-neutral against 9 scalar FMAs at 2 waves/SIMD, but it halves the dependent chain a lone wave waits for and the
+    // pair layout allocates with far fewer spills (44 vs 228-248 B/lane for the 4 pairs + 1 scalar and the scalar layouts).
     typedef float f2 __attribute__((ext_vector_type(2)));
     struct WV { f2 p[(ND + 1) / 2]; };
     static PBRE_HD float wget(const WV& w, int k) { return w.p[k >> 1][k & 1]; }
@@ -432,7 +435,12 @@ struct Fast {
             c_act[c] = false; c_rx[c] = c_ry[c] = c_rz[c] = 0.f; r_rhs[c] = 0.f;
             PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = r_app[c][d] = 0.f; }
         }
+        // The object is solved in scaled coordinates in which it has unit mass and unit (isotropic) inertia: lever arms
+        // r' = sk r and angular velocity u = omega / sk with sk = sqrt(m / I), object-table impulses in delta-v units (a = lambda / m).
+        // Then J M^-1 J^T = (1 + |r' x dir|^2) / m and a row update is ov += da dir, u += da (r' x dir): no per-row
+        // multiplications by 1/m and 1/I in the solver loop.
         const float inv_m = 1.f / P.obj_m, inv_I = 1.f / P.obj_I[0];
+        const float sk = sqrtf(inv_I / inv_m), inv_sk = 1.f / sk;
         const float mu = P.obj_mu * P.tab_mu;
         if (obj_on) {
             V3 oI = v3(P.obj_I[0], P.obj_I[1], P.obj_I[2]);
@@ -474,7 +482,7 @@ struct Fast {
                 }
                 if (vd[v] < P.margin && r < NK) {
                     PBRE_UNROLL for (int c = 0; c < NK; c++) if (slot == c) {
-                        c_act[c] = true; c_rx[c] = vr[v].x; c_ry[c] = vr[v].y; c_rz[c] = vr[v].z; c_dist[c] = vd[v];
+                        c_act[c] = true; c_rx[c] = sk * vr[v].x; c_ry[c] = sk * vr[v].y; c_rz[c] = sk * vr[v].z; c_dist[c] = vd[v];
                     }
                     slot++;
                 }
@@ -483,7 +491,7 @@ struct Fast {
                 const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
                 const V3 Ja[3] = {v3(ry, -rx, 0.f), v3(rz, 0.f, -rx), v3(0.f, rz, -ry)};   // r x dir for dir = +z, -y, +x
                 PBRE_UNROLL for (int d = 0; d < 3; d++)
-                    r_dinv[c][d] = c_act[c] ? 1.f / fmaf(dot(Ja[d], Ja[d]), inv_I, inv_m) : 0.f;
+                    r_dinv[c][d] = c_act[c] ? 1.f / (1.f + dot(Ja[d], Ja[d])) : 0.f;
                 // setupMultiBodyContactConstraint, restitution 0: only the positional part remains in the rhs because the
                 // row is evaluated against the running velocity
                 const float pen = c_dist[c] + P.slop;
@@ -531,7 +539,7 @@ struct Fast {
                     if (c < NC_RO) {
                         const int co = c < NC_RO ? c : 0;
                         const V3 rxd = cross(rB, dir);
-                        rc_dir[co][d] = rc_act[c] ? dir : v3(0.f, 0.f, 0.f); rc_rxd[co][d] = rc_act[c] ? rxd : v3(0.f, 0.f, 0.f);
+                        rc_dir[co][d] = rc_act[c] ? dir : v3(0.f, 0.f, 0.f); rc_rxd[co][d] = rc_act[c] ? scl(rxd, sk) : v3(0.f, 0.f, 0.f);
                         denom += fmaf(dot(rxd, rxd), inv_I, inv_m);
                     }
                     rc_dinv[c][d] = rc_act[c] ? 1.f / denom : 0.f;
@@ -543,6 +551,7 @@ struct Fast {
         }
 
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
+        ow = scl(ow, inv_sk);                 // scaled angular velocity u inside the solver loop
         const float mlim = P.motor_imp;
         auto motor = [&](int j) {
             const float t = fmaf(m_dinv[j], wget(w, j), -m_rhs[j]);
@@ -571,10 +580,9 @@ struct Fast {
                 s = hi > 0.f ? s : r_app[c][d];
             }
             const float dd = s - r_app[c][d]; r_app[c][d] = s;
-            const float dm = dd * inv_m, di = dd * inv_I;
-            if (d == 0) { ov.z += dm; ow.x = fmaf(di, ry, ow.x); ow.y = fmaf(-di, rx, ow.y); }
-            else if (d == 1) { ov.y -= dm; ow.x = fmaf(di, rz, ow.x); ow.z = fmaf(-di, rx, ow.z); }
-            else { ov.x += dm; ow.y = fmaf(di, rz, ow.y); ow.z = fmaf(-di, ry, ow.z); }
+            if (d == 0) { ov.z += dd; ow.x = fmaf(dd, ry, ow.x); ow.y = fmaf(-dd, rx, ow.y); }
+            else if (d == 1) { ov.y -= dd; ow.x = fmaf(dd, rz, ow.x); ow.z = fmaf(-dd, rx, ow.z); }
+            else { ov.x += dd; ow.y = fmaf(dd, rz, ow.y); ow.z = fmaf(-dd, ry, ow.z); }
         };
         auto rrow = [&](int c, int d) {       // robot contact row (RC only)
             float jv = 0.f;
@@ -591,9 +599,9 @@ struct Fast {
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(dd, rc_B[c][d][k], wget(w, k)));
             if (c < NC_RO) {
                 const int co = c < NC_RO ? c : 0;
-                const float dm = -dd * inv_m, di = -dd * inv_I;
+                const float dm = -dd * inv_m;      // robot-contact impulses stay in impulse units (the robot side needs them)
                 ov.x = fmaf(dm, rc_dir[co][d].x, ov.x); ov.y = fmaf(dm, rc_dir[co][d].y, ov.y); ov.z = fmaf(dm, rc_dir[co][d].z, ov.z);
-                ow.x = fmaf(di, rc_rxd[co][d].x, ow.x); ow.y = fmaf(di, rc_rxd[co][d].y, ow.y); ow.z = fmaf(di, rc_rxd[co][d].z, ow.z);
+                ow.x = fmaf(dm, rc_rxd[co][d].x, ow.x); ow.y = fmaf(dm, rc_rxd[co][d].y, ow.y); ow.z = fmaf(dm, rc_rxd[co][d].z, ow.z);
             }
         };
         bool any_c[NK], any_r[NR];
@@ -615,6 +623,7 @@ struct Fast {
             contacts();
         }
 
+        ow = scl(ow, sk);
         // ---- integrate.  Positions are re-read from the state record (still the old values) rather than kept in
         //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
         PBRE_REG_BARRIER();
