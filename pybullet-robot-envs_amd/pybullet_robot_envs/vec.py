@@ -1,0 +1,84 @@
+"""BatchedVecEnv -- the stable-baselines `VecEnv` protocol on top of one batched task env.
+
+The reference's training scripts wrap ONE env in `DummyVecEnv([lambda: env])` or several processes in `SubprocVecEnv`
+(reference examples/algos/train/baselines/panda_envs/train_ddpg_reaching.py:96, train_TD3_pushing_HER.py:15).  With the
+batched engine the N envs already live in one object, so this adapter only reshapes its API to what those libraries
+call: `num_envs, observation_space, action_space, reset(), step_async(actions), step_wait(), step(actions), close(),
+seed(), get_attr/set_attr/env_method`.  Like `DummyVecEnv`, a finished env is reset inside the step that finished it and the
+returned observation is the first one of the next episode: construct the task env with `auto_reset=True` (Panda; snapshot
+reset inside the kernel) or let the adapter issue masked resets (any env)."""
+import numpy as np
+
+
+class BatchedVecEnv(object):
+    def __init__(self, env):
+        self.env = env
+        self.num_envs = int(env.num_envs)
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self._actions = None
+        self._device_reset = bool(getattr(env, "_auto_reset", False))
+        self._goal = hasattr(env.observation_space, "spaces")
+
+    def _batch(self, x):
+        return x[None] if self.num_envs == 1 else x
+
+    def reset(self):
+        o = self.env.reset()
+        if self._goal:
+            return dict((k, self._batch(np.asarray(v))) for k, v in o.items())
+        return self._batch(np.asarray(o))
+
+    def step_async(self, actions):
+        self._actions = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, -1)
+
+    def step_wait(self):
+        obs, rew, done, info = self.env.step(self._actions if self.num_envs > 1 else self._actions[0])
+        rew = np.atleast_1d(np.asarray(rew, dtype=np.float32))
+        done = np.atleast_1d(np.asarray(done)).astype(bool)
+        if self._goal:
+            obs = dict((k, self._batch(np.asarray(v))) for k, v in obs.items())
+        else:
+            obs = self._batch(np.asarray(obs))
+        infos = [dict() for _ in range(self.num_envs)]
+        if "is_success" in info:
+            succ = np.atleast_1d(np.asarray(info["is_success"]))
+            for i in range(self.num_envs):
+                infos[i]["is_success"] = bool(succ[i])
+        if done.any() and not self._device_reset:
+            # DummyVecEnv semantics without the in-kernel snapshot reset: keep the terminal observation in the info
+            # dict, reset the finished envs (a masked pbre_reset) and return their first observation
+            idx = np.nonzero(done)[0]
+            for i in idx:
+                infos[i]["terminal_observation"] = dict((k, v[i].copy()) for k, v in obs.items()) if self._goal else obs[i].copy()
+            fresh = self.env.reset(mask=done.astype(np.uint8))
+            if self._goal:
+                for k in obs:
+                    obs[k][idx] = self._batch(np.asarray(fresh[k]))[idx]
+            else:
+                obs[idx] = self._batch(np.asarray(fresh))[idx]
+        return obs, rew, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.env.close()
+
+    def seed(self, seed=None):
+        return [self.env.seed(seed)[0]] * self.num_envs
+
+    def get_attr(self, name, indices=None):
+        v = getattr(self.env, name)
+        return [v] * (self.num_envs if indices is None else len(np.atleast_1d(indices)))
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self.env, name, value)
+
+    def env_method(self, name, *args, indices=None, **kwargs):
+        r = getattr(self.env, name)(*args, **kwargs)
+        return [r] * (self.num_envs if indices is None else len(np.atleast_1d(indices)))
+
+    def render(self, mode="rgb_array"):
+        return self.env.render(mode)
