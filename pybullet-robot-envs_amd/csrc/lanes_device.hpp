@@ -19,6 +19,9 @@ struct DevLanes {
     static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 15u]; }
     static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 15u] : 0.f; }
     static __device__ __forceinline__ F loadu(const float* p) { return *p; }                       // group-uniform address
+    static __device__ __forceinline__ float first(F x) { return x; }                               // a group-uniform value as a scalar
+    static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 15u) == 0; }
+    static __device__ __forceinline__ void fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }    // a lane reads what another lane of the group stored
     static __device__ __forceinline__ F loadx(const float* p, I idx, B m) { return m ? p[idx] : 0.f; }
     static __device__ __forceinline__ void storex(float* p, I idx, F x, B m) { if (m) p[idx] = x; }
     static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 15u] = x; }
@@ -92,6 +95,7 @@ struct DevLanes {
 // emulation so that CPU tests and device agree bit for bit).
 struct DevLanes64 : DevLanes {
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }
+    static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 63u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 63u]; }
     static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 63u]; }
     static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 63u] : 0.f; }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     float* o = nullptr;
     if (MODE & CoreD::M_ACTION) a = actions + (size_t)(real ? env : 0) * act_dim;
     if (MODE & CoreD::M_OBS) o = real ? out + (size_t)env * ow : scratch_row;
-    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, P.env_id_base + (unsigned long long)env);
 }
 
 // Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
@@ -404,10 +404,6 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     if (const char* ev = getenv("PBRE_RC_FIRST_MIN")) c->rc_first_min = atoi(ev);       // A/B knobs
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
-    if ((cfg->flags & PBRE_F_AUTO_RESET) && !lane_per_env(c)) {
-        g_err = "PBRE_F_AUTO_RESET is not implemented by the general row kernel (needs the lane-per-env kernels: Panda topology, cube object, no PBRE_F_FORCE_GENERAL)";
-        delete c; return PBRE_E_UNSUPPORTED;
-    }
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -544,8 +540,9 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
         if (full) {   // snapshot for PBRE_F_AUTO_RESET: settled robot pose and object height (identical in every env)
             float rec[STATE];
             HIPCHK(hipMemcpy(rec, c->main.state, sizeof rec, hipMemcpyDeviceToHost));
-            for (int k = 0; k < NJ; k++) c->P.rst_q[k] = rec[k];
+            for (int k = 0; k < NJ; k++) { c->P.rst_q[k] = rec[k]; c->T.rst_q[k] = rec[k]; }
             c->P.rst_objz = rec[11];
+            HIPCHK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
         }
     }
     c->k_steps = 0; c->launches = 0;      // pbre_timing[3] averages env steps only, not the settle launches above

@@ -312,7 +312,7 @@ struct Core {
     // One simulation step for one env group.  st: pointer to the env's 48-float record.
     // act: pointer to this env's action row or nullptr.  out: this env's [obs_dim+2] row or nullptr.
     static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                             const float* tgt = nullptr) {
+                             const float* tgt = nullptr, unsigned long long env_id = 0) {
         const I lane = L::lane();
         const F zero = L::c(0.f), one = L::c(1.f);
         const B robot = L::lti(lane, NJ);
@@ -647,16 +647,19 @@ struct Core {
         }
         L::store(st, Qn); L::store(st + W, Vn);
 
-        if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode);
+        if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode, flags, env_id);
     }
 
-    // Observation / reward / termination of the current state (Qn, Vn, Xr = the three state records).
-    static PBRE_HD void observe(const Tables& T, const Params& P, float* st, F Qn, F Vn, F Xr, float* out, int mode) {
+    // Geometric part of the observation of a state (Q, V, X = its three lane records).
+    struct Obs { V3 ee, eul, vn, op, oe, rel, er, tg; F q; };
+    static PBRE_HD Obs geom(const Tables& T, const Params& P, F Qn, F Vn, F Xr) {
         const I lane = L::lane();
-        const F zero = L::c(0.f), one = L::c(1.f);
+        const F zero = L::c(0.f);
         const B robot = L::lti(lane, NJ);
-        F q = L::sel(robot, Qn, zero), qd = L::sel(robot, Vn, zero);
-        Kin K; fk(T, q, K);
+        Obs o;
+        o.q = L::sel(robot, Qn, zero);
+        F qd = L::sel(robot, Vn, zero);
+        Kin K; fk(T, o.q, K);
         Sp Sq; Sq.a = scl(K.S.a, qd); Sq.l = scl(K.S.l, qd);
         Sp Vs = chain_sum(T, Sq);
         const int eo = T.ee_owner;
@@ -664,20 +667,33 @@ struct Core {
         V3 pe = bcastv(K.p, eo);
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = L::c(T.ee_R[k]);
         M3 Ree = mm(Re, Eo);
-        V3 ee = add(pe, mv(Re, v3(L::c(T.ee_p[0]), L::c(T.ee_p[1]), L::c(T.ee_p[2]))));
-        V3 vee = add(bcastv(Vs.l, eo), cross(bcastv(Vs.a, eo), ee));
-        V3 eul = quat_euler(R_quat(Ree));
-        V3 op = v3(L::bcast(Qn, LC), L::bcast(Qn, LC + 1), L::bcast(Qn, LC + 2));
+        o.ee = add(pe, mv(Re, v3(L::c(T.ee_p[0]), L::c(T.ee_p[1]), L::c(T.ee_p[2]))));
+        V3 vee = add(bcastv(Vs.l, eo), cross(bcastv(Vs.a, eo), o.ee));
+        o.eul = quat_euler(R_quat(Ree));
+        o.op = v3(L::bcast(Qn, LC), L::bcast(Qn, LC + 1), L::bcast(Qn, LC + 2));
         Q4 oq; oq.x = L::bcast(Qn, LC + 3); oq.y = L::bcast(Qn, LC + 4); oq.z = L::bcast(Qn, LC + 5); oq.w = L::bcast(Qn, LC + 6);
-        V3 oe = quat_euler(oq);
+        o.oe = quat_euler(oq);
         // object pose in the hand frame via the Euler round trip the reference performs (panda_push_gym_env.py:168-174)
-        Q4 qh = euler_quat(eul), qo = euler_quat(oe);
-        V3 rel = mtv(quat_R(qh), sub(op, ee));
+        Q4 qh = euler_quat(o.eul), qo = euler_quat(o.oe);
+        o.rel = mtv(quat_R(qh), sub(o.op, o.ee));
         Q4 qhi; qhi.x = zero - qh.x; qhi.y = zero - qh.y; qhi.z = zero - qh.z; qhi.w = qh.w;
-        V3 er = quat_euler(qmul(qhi, qo));
-        V3 tg = v3(L::bcast(Xr, 0), L::bcast(Xr, 1), L::bcast(Xr, 2));
+        o.er = quat_euler(qmul(qhi, qo));
+        o.tg = v3(L::bcast(Xr, 0), L::bcast(Xr, 1), L::bcast(Xr, 2));
         // Panda: normalised EE velocity (panda_env.py:174-178); iCub: raw (icub_env.py:233-236)
-        V3 vn = P.robot == 1 ? vee : v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
+        o.vn = P.robot == 1 ? vee : v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
+        return o;
+    }
+    static PBRE_HD V3 selv3(B c, const V3& a, const V3& b) { return selv(c, a, b); }
+
+    // Observation / reward / termination of the current state (Qn, Vn, Xr = the three state records).  With
+    // PBRE_F_AUTO_RESET (flags & 2) a finished env is re-initialised right here (snapshot reset): the
+    // transition's reward and done flag are returned together with the first observation of the next episode.
+    static PBRE_HD void observe(const Tables& T, const Params& P, float* st, F Qn, F Vn, F Xr, float* out, int mode,
+                                int flags = 0, unsigned long long env_id = 0) {
+        const I lane = L::lane();
+        const F zero = L::c(0.f), one = L::c(1.f);
+        Obs o = geom(T, P, Qn, Vn, Xr);
+        const V3 ee = o.ee, op = o.op, tg = o.tg;
 
         F reward = zero, done = zero;
         if (mode & M_INITD) {
@@ -722,23 +738,42 @@ struct Core {
             }
             F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, Xr));
             L::storem(st + 2 * W, Xn, L::lti(lane, 16));
+
+            if ((flags & 2) && L::any(L::ne(done, zero))) {
+                // ---- snapshot reset of the finished groups: the settled state of reset_simulation is invariant under the
+                // sampled object x, y, yaw (flat table, vertical drop), so the next episode starts from the settled robot pose
+                // and object height recorded at the last full reset, with freshly sampled pose and target
+                const B fin = L::ne(done, zero);
+                if (L::first(done) != 0.f && L::lane0()) snapshot_reset(T, P, env_id, st);    // scalar code, one lane per group
+                L::fence();
+                F Q2 = L::load(st), V2 = L::load(st + W), X2 = L::loadm(st + 2 * W, L::lti(lane, 16));
+                const Obs o2 = geom(T, P, Q2, V2, X2);
+                if (P.robot == 1 && P.task >= 1) {      // icub_push_gym_env.py:124-127
+                    F e1 = norm(sub(o2.ee, o2.op)), e2 = norm(sub(o2.op, o2.tg));
+                    F Xn2 = L::sel(L::eqi(lane, 12), e1, L::sel(L::eqi(lane, 13), e2, X2));
+                    L::storem(st + 2 * W, Xn2, L::band(fin, L::lti(lane, 16)));
+                }
+                o.ee = selv3(fin, o2.ee, o.ee); o.eul = selv3(fin, o2.eul, o.eul); o.vn = selv3(fin, o2.vn, o.vn);
+                o.op = selv3(fin, o2.op, o.op); o.oe = selv3(fin, o2.oe, o.oe); o.rel = selv3(fin, o2.rel, o.rel);
+                o.er = selv3(fin, o2.er, o.er); o.tg = selv3(fin, o2.tg, o.tg); o.q = L::sel(fin, o2.q, o.q);
+            }
         }
         if (out) {
             // row-major [obs | reward | done]; obs layout SURVEY Appendix C
             const int nd = T.n_obs_j;
             const int od = 9 + nd + 12 + (P.task >= 1 ? 3 : 0);
-            F head = L::sel(L::eqi(lane, 0), ee.x, L::sel(L::eqi(lane, 1), ee.y, L::sel(L::eqi(lane, 2), ee.z,
-                     L::sel(L::eqi(lane, 3), eul.x, L::sel(L::eqi(lane, 4), eul.y, L::sel(L::eqi(lane, 5), eul.z,
-                     L::sel(L::eqi(lane, 6), vn.x, L::sel(L::eqi(lane, 7), vn.y, vn.z))))))));
+            F head = L::sel(L::eqi(lane, 0), o.ee.x, L::sel(L::eqi(lane, 1), o.ee.y, L::sel(L::eqi(lane, 2), o.ee.z,
+                     L::sel(L::eqi(lane, 3), o.eul.x, L::sel(L::eqi(lane, 4), o.eul.y, L::sel(L::eqi(lane, 5), o.eul.z,
+                     L::sel(L::eqi(lane, 6), o.vn.x, L::sel(L::eqi(lane, 7), o.vn.y, o.vn.z))))))));
             L::storem(out, head, L::lti(lane, 9));
-            { I oi = L::loadI(T.obs_idx); L::storex(out + 9, oi, q, L::gei(oi, 0)); }
-            float* o2 = out + 9 + nd;
-            F tail = L::sel(L::eqi(lane, 0), op.x, L::sel(L::eqi(lane, 1), op.y, L::sel(L::eqi(lane, 2), op.z,
-                     L::sel(L::eqi(lane, 3), oe.x, L::sel(L::eqi(lane, 4), oe.y, L::sel(L::eqi(lane, 5), oe.z,
-                     L::sel(L::eqi(lane, 6), rel.x, L::sel(L::eqi(lane, 7), rel.y, L::sel(L::eqi(lane, 8), rel.z,
-                     L::sel(L::eqi(lane, 9), er.x, L::sel(L::eqi(lane, 10), er.y, L::sel(L::eqi(lane, 11), er.z,
-                     L::sel(L::eqi(lane, 12), tg.x, L::sel(L::eqi(lane, 13), tg.y, tg.z))))))))))))));
-            L::storem(o2, tail, L::lti(lane, P.task >= 1 ? 15 : 12));
+            { I oi = L::loadI(T.obs_idx); L::storex(out + 9, oi, o.q, L::gei(oi, 0)); }
+            float* o2p = out + 9 + nd;
+            F tail = L::sel(L::eqi(lane, 0), o.op.x, L::sel(L::eqi(lane, 1), o.op.y, L::sel(L::eqi(lane, 2), o.op.z,
+                     L::sel(L::eqi(lane, 3), o.oe.x, L::sel(L::eqi(lane, 4), o.oe.y, L::sel(L::eqi(lane, 5), o.oe.z,
+                     L::sel(L::eqi(lane, 6), o.rel.x, L::sel(L::eqi(lane, 7), o.rel.y, L::sel(L::eqi(lane, 8), o.rel.z,
+                     L::sel(L::eqi(lane, 9), o.er.x, L::sel(L::eqi(lane, 10), o.er.y, L::sel(L::eqi(lane, 11), o.er.z,
+                     L::sel(L::eqi(lane, 12), o.tg.x, L::sel(L::eqi(lane, 13), o.tg.y, o.tg.z))))))))))))));
+            L::storem(o2p, tail, L::lti(lane, P.task >= 1 ? 15 : 12));
             F rd = L::sel(L::eqi(lane, 0), reward, done);
             L::storem(out + od, rd, L::lti(lane, 2));
         }
@@ -890,6 +925,14 @@ struct Core {
         }
         X[0] = clamps(tx, tx_min, tx_max); X[1] = clamps(ty, P.ws[1][0], P.ws[1][1]); X[2] = ob[2];
         X[3] = 0.f; X[4] = 0.f;
+    }
+    // PBRE_F_AUTO_RESET: next episode of a finished env from the settled snapshot (scalar, one call per env)
+    static PBRE_HD void snapshot_reset(const Tables& T, const Params& P, unsigned long long env_id, float* st) {
+        const unsigned ep = (unsigned)(int)st[2 * W + 5] + 1u;
+        init_state(T, P, env_id, ep, st);                         // zeroed record, sampled object x, y, yaw, episode, home hand pose
+        for (int k = 0; k < T.ndof; k++) st[k] = T.rst_q[k];      // settled robot pose
+        st[LC + 2] = P.rst_objz;                                  // settled object height
+        sample_target(P, env_id, ep, st);
     }
 };
 

@@ -53,6 +53,7 @@ struct TablesT {
     float R0[9][W], p0[3][W];    // joint frame w.r.t. parent movable link frame at q = 0 (root: world)
     float sb_m[NSUB][W], sb_c[NSUB][3][W], sb_I[NSUB][6][W];   // xx yy zz xy xz yz, link axes, about sub-body COM
     float lower[W], upper[W], jdamp[W], home[W];
+    float rst_q[W];              // settled joint positions recorded at the last full reset (snapshot auto-reset); home until then
     float kp_hold[W], kd_hold[W], kp_act[W], kd_act[W];
     int   s_owner[W], s_valid[W];
     float s_c[3][W], s_r[W], s_mu[W];
@@ -190,7 +191,7 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
     T.n_obs_j = n_ctrl;
     if (observe_all) { for (int l = 0; l < ndof; l++) T.obs_idx[l] = l; T.n_obs_j = ndof; }
     for (int l = 0; l < ndof; l++) {
-        T.home[l] = (float)home[l];
+        T.home[l] = (float)home[l]; T.rst_q[l] = (float)home[l];
         const bool act = T.act_idx[l] >= 0;
         T.kp_act[l] = (float)(act ? gains[0] : gains[2]); T.kd_act[l] = (float)(act ? gains[1] : gains[3]);
         T.kp_hold[l] = (float)gains[2]; T.kd_hold[l] = (float)gains[3];

@@ -29,13 +29,14 @@ constexpr int WST = SW::STATE, WNJ = SW::NJ, WW = SW::W;
 constexpr int WPB = 4, WTPB = WPB * 64;          // envs (waves) per block
 
 template <int MODE>
-__global__ __launch_bounds__(WTPB) void kw_step(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(WTPB, 3) void kw_step(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
                                                 const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
                                                 int flags, const float* __restrict__ tgt) {
     const int env = blockIdx.x * WPB + (threadIdx.x >> 6);
     if (env >= n) return;                           // whole wave
     CoreW::step(*T, P, state + (size_t)env * WST, (MODE & CoreW::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                (MODE & CoreW::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, (MODE & CoreW::M_TGT) ? tgt + (size_t)env * WNJ : nullptr);
+                (MODE & CoreW::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, (MODE & CoreW::M_TGT) ? tgt + (size_t)env * WNJ : nullptr,
+                P.env_id_base + (unsigned long long)env);
 }
 template <bool RESET>
 __global__ __launch_bounds__(WTPB) void kw_ik(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
@@ -117,7 +118,7 @@ static hipError_t wsettle(WideEngine* w, float* st, float* tg, int n, int count,
     return hipSuccess;
 }
 static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hipStream_t s) {
-    const int flags = w->cfg.flags & PBRE_F_NO_OBJECT;
+    const int flags = w->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
     constexpr int OT = CoreW::M_OBS | CoreW::M_TASK;
     if (!w->P.use_ik) return wstep<CoreW::M_ACTION | OT>(w, w->state, w->tgt, w->n, d_act, d_out, flags, s, true);
     hipLaunchKernelGGL(kw_ik<false>, dim3(blocks_of(w->n)), dim3(WTPB), 0, s, w->dT, w->P, w->state, d_act, w->tgt, w->n, w->act_dim);
@@ -147,7 +148,6 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
         err = e; delete w;
         return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG);
     }
-    if (cfg->flags & PBRE_F_AUTO_RESET) { err = "PBRE_F_AUTO_RESET is not implemented by the 64-lane engine (iCub)"; delete w; return PBRE_E_UNSUPPORTED; }
     w->cfg.robot_table = nullptr;
     w->n = cfg->num_envs; w->obs_dim = obs_dim_of(w->T, w->P); w->act_dim = act_dim_of(*cfg); w->ow = w->obs_dim + 2; w->device = cfg->device_id;
     int ndev = 0;
@@ -254,6 +254,13 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
             // the IK targets of the reset envs are only needed while settling; the next step recomputes them
         }
         WCHK(hipStreamSynchronize(s));
+        if (full) {   // snapshot for PBRE_F_AUTO_RESET: settled robot pose and object height (identical in every env)
+            std::vector<float> rec(WST);
+            WCHK(hipMemcpy(rec.data(), w->state, WST * sizeof(float), hipMemcpyDeviceToHost));
+            for (int k = 0; k < WNJ; k++) { w->T.rst_q[k] = rec[k]; w->P.rst_q[k] = rec[k]; }
+            w->P.rst_objz = rec[SW::LC + 2];
+            WCHK(hipMemcpy(w->dT, &w->T, sizeof(TablesW), hipMemcpyHostToDevice));
+        }
     }
     if (obs) return wide_observe(w, obs);
     return PBRE_OK;

@@ -13,7 +13,7 @@ from pybullet_robot_envs.envs.world_envs.world_env import WorldEnv
 class ICubTaskBase(PandaTaskBase):
 
     def _setup_icub(self, action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std, tg_pose_rnd_std,
-                    renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib):
+                    renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset=False):
         self._time_step = 1. / 240.
         self._control_arm = control_arm
         self._use_IK = use_IK
@@ -28,7 +28,7 @@ class ICubTaskBase(PandaTaskBase):
         self._obj_pose_rnd_std = obj_pose_rnd_std
         self._reward_type = reward_type
         self.num_envs = int(num_envs)
-        self._auto_reset = False
+        self._auto_reset = bool(auto_reset)
         if action_repeat != 1:
             raise NotImplementedError("action_repeat != 1 is not implemented by the batched engine")
 
@@ -65,6 +65,7 @@ class ICubTaskBase(PandaTaskBase):
         overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed, max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
                          target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),
+                         flags=_capi.F_AUTO_RESET if self._auto_reset else 0,
                          use_ik=1 if self._use_IK else 0, control_orientation=ori, reward_type=int(self._reward_type),
                          num_controlled_joints=len(dofs), num_joints_ctrl=len(dofs), act_dof=dofs + [-1] * (16 - len(dofs)),
                          home=home + [0.0] * (40 - len(home)),

@@ -62,7 +62,7 @@ struct Emu : pbre_ctx {
             }
         }
         n_general++;
-        CoreH::step(T, P, st, act, out, mode, flags, tg);
+        CoreH::step(T, P, st, act, out, mode, flags, tg, env_id);
     }
     void ik(float* st, const float* act, float* tg, bool rst) {
         if constexpr (PANDA) FastH::ik_targets(T, P, st, act, tg, rst);
@@ -91,7 +91,7 @@ struct Emu : pbre_ctx {
                 CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
             }
         }
-        if (!mask) { for (int k = 0; k < NJ; k++) P.rst_q[k] = state[k]; P.rst_objz = state[S::LC + 2]; }
+        if (!mask) { for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; }
     }
     void step(const float* actions, float* out) override {
         const int ow = obs_dim + 2;
@@ -131,7 +131,6 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     c->tgt.assign((size_t)c->n * S::NJ, 0.f);
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
     if constexpr (std::is_same<S, Shape16>::value) c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
-    if ((cfg->flags & PBRE_F_AUTO_RESET) && (!c->fast_ok || (cfg->flags & PBRE_F_FORCE_GENERAL))) { g_err = "PBRE_F_AUTO_RESET is not implemented by the general lane-group kernel"; delete c; return PBRE_E_UNSUPPORTED; }
     *out = c;
     return PBRE_OK;
 }

@@ -26,6 +26,9 @@ struct HostLanesT {
     static I loadI(const int* p) { I r; for (int i = 0; i < W; i++) r.v[i] = p[i]; return r; }
     static F loadm(const float* p, const B& m) { F r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? p[i] : 0.f; return r; }
     static F loadu(const float* p) { return F(*p); }
+    static float first(const F& x) { return x.v[0]; }
+    static bool lane0() { return true; }
+    static void fence() {}
     static F loadx(const float* p, const I& idx, const B& m) { F r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? p[idx.v[i]] : 0.f; return r; }
     static void storex(float* p, const I& idx, const F& x, const B& m) { for (int i = 0; i < W; i++) if (m.v[i]) p[idx.v[i]] = x.v[i]; }
     static void store(float* p, const F& x) { for (int i = 0; i < W; i++) p[i] = x.v[i]; }

@@ -84,20 +84,22 @@ def contact_states(ora, panda, base, rng, n_table=8, n_obj=8):
         scenarios.object_contact_states(ora, panda["model"], panda["spheres"], base, n_obj, rng)])
 
 
-def check_auto_reset(Engine, lib, table, n=12, max_steps=4, flags=0):
+def check_auto_reset(Engine, lib, table, n=12, max_steps=4, flags=0, act_dim=7, **over):
     """PBRE_F_AUTO_RESET: when an env finishes, the same step re-initialises it (snapshot reset).  The state it lands in
     must equal -- up to the settle transients the snapshot skips -- what an explicit masked pbre_reset produces for the
     same episode number, and the step returns the terminal transition's reward/done with the fresh observation."""
     F_AUTO = 2
     kw = dict(task=1, num_envs=n, lib=lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, max_steps=max_steps)
+    kw.update(over)
     auto = Engine(table, flags=F_AUTO | flags, **kw)
     ref = Engine(table, flags=flags, **kw)
     o_a, o_r = auto.reset(), ref.reset()
     assert np.array_equal(o_a, o_r)
+    nd, vo, xo = auto.ndof, auto.v_off, auto.x_off
     rng = np.random.default_rng(9)
     finished = np.zeros(n, bool)
     for t in range(max_steps + 3):
-        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        a = rng.uniform(-1, 1, (n, act_dim)).astype(np.float32)
         ob_a, rw_a, dn_a = auto.step(a)
         ob_r, rw_r, dn_r = ref.step(a)
         assert np.array_equal(dn_a, dn_r) and np.allclose(rw_a, rw_r, atol=1e-5)      # the transition itself is unchanged
@@ -106,15 +108,16 @@ def check_auto_reset(Engine, lib, table, n=12, max_steps=4, flags=0):
         if d.any():
             ref.reset(mask=d.astype(np.uint8))                                        # explicit reset of the same envs
             sa, sr = auto.get_state(), ref.get_state()
-            assert np.array_equal(sa[d, 37], sr[d, 37]) and (sa[d, 35] == 0).all() and (sa[d, 36] == 0).all()
-            assert np.abs(sa[d][:, :16] - sr[d][:, :16]).max() < 2e-5                # same sampled pose, settled height
-            assert np.abs(sa[d][:, 16:31]).max() < 1e-6 and np.abs(sr[d][:, 16:31]).max() < 1e-3
-            assert np.abs(sa[d][:, 32:35] - sr[d][:, 32:35]).max() < 2e-5            # same sampled target
-            assert np.abs(ob_a[d] - ref.observe()[d]).max() < 1e-3                    # returned obs = first obs of the new episode
+            assert np.array_equal(sa[d, xo + 5], sr[d, xo + 5]) and (sa[d, xo + 3] == 0).all() and (sa[d, xo + 4] == 0).all()
+            assert np.abs(sa[d][:, :nd + 7] - sr[d][:, :nd + 7]).max() < 5e-5         # same sampled pose, settled height
+            assert np.abs(sa[d][:, vo:vo + nd + 6]).max() < 1e-6 and np.abs(sr[d][:, vo:vo + nd + 6]).max() < 2e-3
+            assert np.abs(sa[d][:, xo:xo + 3] - sr[d][:, xo:xo + 3]).max() < 5e-5    # same sampled target
+            assert np.abs(sa[d][:, xo + 6:xo + 14] - sr[d][:, xo + 6:xo + 14]).max() < 2e-4    # hand pose, initial distances (iCub push)
+            assert np.abs(ob_a[d] - ref.observe()[d]).max() < 2e-3                    # returned obs = first obs of the new episode
             ref.set_state(sa)                                                         # continue from identical states
             finished |= d
     assert finished.all()
-    ep = auto.get_state()[:, 37]
+    ep = auto.get_state()[:, xo + 5]
     assert (ep >= 1).all()
 
 

@@ -84,6 +84,11 @@ def test_auto_reset(panda, emu_lib):
     parity.check_auto_reset(_capi.Engine, emu_lib, panda["table"], n=6, max_steps=3)
 
 
+def test_auto_reset_general_row_kernel(panda, emu_lib):
+    """The same snapshot reset implemented in the lane-group core (the path the iCub engine uses), on the Panda."""
+    parity.check_auto_reset(_capi.Engine, emu_lib, panda["table"], n=3, max_steps=3, flags=_capi.F_FORCE_GENERAL)
+
+
 def test_auto_reset_env_class(emu_lib):
     from pybullet_robot_envs.envs import pandaPushGymEnv
     env = pandaPushGymEnv(_lib=emu_lib, num_envs=3, max_steps=2, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, auto_reset=True)

@@ -57,3 +57,10 @@ def test_config1_icub_reach_trace(hip_lib):
 @pytest.mark.parametrize("n", [1, 3, 5])
 def test_icub_ragged_batch_sizes(hip_lib, n):
     parity.check_icub(_capi.Engine, hip_lib, 1, "l", 1, 0, 1, n=n, steps=2)
+
+
+def test_icub_auto_reset(hip_lib):
+    from pybullet_robot_envs.model.table import icub_table
+    tbl, model, info = icub_table("l")
+    ov = parity.icub_overrides(info, "l", 1, 0, 1)
+    parity.check_auto_reset(_capi.Engine, hip_lib, tbl, n=40, max_steps=3, act_dim=3, robot=_capi.ROBOT_ICUB, **ov)

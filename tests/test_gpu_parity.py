@@ -161,7 +161,7 @@ def test_reference_golden_outputs(hip_lib):
         env.close()
 
 
-@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES])
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
 def test_auto_reset(panda, hip_lib, flags):
     parity.check_auto_reset(_capi.Engine, hip_lib, panda["table"], n=200, max_steps=4, flags=flags)
 

@@ -39,8 +39,14 @@ def test_vec_env_device_reset_and_goal_env(emu_lib):
 
 
 def test_vec_env_single_icub(emu_lib):
-    v = BatchedVecEnv(iCubReachGymEnv(max_steps=3, _lib=emu_lib))
+    v = BatchedVecEnv(iCubReachGymEnv(max_steps=1, auto_reset=True, _lib=emu_lib))
     o = v.reset()
     assert o.shape == (1, 31)
-    o, r, d, infos = v.step(np.zeros((1, 3)))
-    assert o.shape == (1, 31) and r.shape == (1,) and d.shape == (1,)
+    seen = False
+    for t in range(4):
+        o, r, d, infos = v.step(np.zeros((1, 3)))
+        assert o.shape == (1, 31) and r.shape == (1,) and d.shape == (1,)
+        if d[0]:
+            seen = True
+            assert int(v.env._env_step_counter) == 0           # finished in this step and already re-initialised on the "device"
+    assert seen
