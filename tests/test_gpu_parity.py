@@ -247,3 +247,32 @@ def test_ragged_batch_sizes(panda, hip_lib, n):
     st = parity.check_reset(eng, ora, n)
     st[::3, 3] = 0.02                      # every third env: joint 4 over its limit -> complex list, row kernel
     parity.check_single_steps(eng, ora, st, np.random.default_rng(n), steps=2)
+
+
+@pytest.mark.parametrize("flags", [_capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES])
+def test_scripted_push_properties(panda, hip_lib, flags):
+    """A scripted closed-loop push (the hand sweeps through the cube, hundreds of steps in robot-object contact) on a batch
+    with randomised object poses, with either complex-env kernel: the cube is pushed forward, stays on the table top,
+    nothing blows up -- the properties tests/test_oracle.py asserts of the oracle for the same script."""
+    import scenarios
+    n = 48
+    eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], n, obj_std=0.02, tg_std=0.0, flags=flags)
+    eng.reset()
+    st = eng.get_state().astype(np.float64)
+    st[:, 32:35] = [0.6, 0.3, 0.65]                           # far target: no success latch during the script
+    eng.set_state(st.astype(np.float32))
+    plans = [scenarios.push_actions(ora, st[e]) for e in range(n)]
+    n1 = max(p[2] for p in plans)
+    x0 = st[:, 9:12].copy()
+    seen_complex = 0
+    for t in range(n1 + 500):
+        a = np.stack([scenarios.track(st[e], plans[e][0] if t < n1 else plans[e][1], 1.0 if t < n1 else 0.1) for e in range(n)])
+        eng.step(a.astype(np.float32))
+        st = eng.get_state().astype(np.float64)
+        if t % 50 == 0:
+            seen_complex = max(seen_complex, eng.kernel_info()[5])
+            assert np.isfinite(st).all()
+            assert (st[:, 11] > 0.64).all() and (st[:, 11] < 0.67).all()
+    assert seen_complex >= n // 2                             # the script really exercised the robot-contact kernels
+    moved = st[:, 9] - x0[:, 0]
+    assert (moved > 0.02).mean() > 0.9 and np.isfinite(st).all()
