@@ -101,9 +101,9 @@ def test_masked_reset(panda, hip_lib):
     assert np.array_equal(first, eng2.reset())
 
 
-def test_full_size_properties(panda, hip_lib):
-    """BASELINE config 3 size (32768 envs): size-independent properties."""
-    n = 32768
+@pytest.mark.parametrize("n", [32768, 131072, 1048576 + 37])
+def test_full_size_properties(panda, hip_lib, n):
+    """BASELINE config 3 / config 4 sizes (32768, 131072 envs) and a ragged 1 M batch: size-independent properties."""
     eng = _capi.Engine(panda["table"], task=1, num_envs=n, lib=hip_lib, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
     obs = eng.reset()
     st0 = eng.get_state()
