@@ -125,7 +125,7 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
                                                   const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base) {
-    static_assert(NB == 1, "the row kernel walks a single complex list");
+    static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
     const int total = cur_count[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) *host_total = total;
     const int row = threadIdx.x >> 4;
