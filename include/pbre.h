@@ -13,7 +13,7 @@
  * done above this ABI with one ctx per rank and env_id_base = rank * num_envs).
  *
  * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
- * (Panda: 48 floats), W = 64 otherwise (iCub: 144 floats); nd = number of DoF:
+ * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 otherwise; nd = number of DoF:
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
@@ -40,7 +40,7 @@ extern "C" {
 
 enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
 enum { PBRE_ROBOT_PANDA = 0,
-       PBRE_ROBOT_ICUB = 1 };     /* icub_model.sdf, 32 DoF: observation / reward / reset variants of R/envs/icub_envs */
+       PBRE_ROBOT_ICUB = 1 };     /* icub_model.sdf: observation / reward / reset variants of R/envs/icub_envs */
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
@@ -113,7 +113,7 @@ void pbre_destroy(pbre_ctx* ctx);
 const char* pbre_last_error(const pbre_ctx* ctx);   /* borrowed; ctx may be NULL for create errors */
 
 int pbre_dims(const pbre_ctx* ctx, int32_t* obs_dim, int32_t* act_dim, int32_t* num_envs);
-/* floats per env state record (48 Panda, 144 iCub) */
+/* floats per env state record (48 Panda, 80 iCub) */
 int pbre_state_floats(const pbre_ctx* ctx);
 
 /* replaces: pandaPushGymEnv.reset -> reset_simulation (panda_push_gym_env.py:105-148: resetSimulation,

@@ -121,7 +121,7 @@ void orc_euler_from_quat(const real q[4], real e[3]) {
 /* ------------------------------------------------------------------ model */
 int orc_sizeof_real(void) { return (int)sizeof(real); }
 /* state record layout (pbre_oracle.h) */
-static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : 64; }
+static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : (m->ndof <= 20 ? 32 : 64); }
 int orc_state_floats(const orc_model* m) { return 2 * lay_w(m) + 16; }
 #define OQ(m) ((m)->ndof)                 /* object position (then quaternion) inside Q */
 #define OV(m) (lay_w(m))                  /* V record */

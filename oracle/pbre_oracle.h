@@ -38,7 +38,7 @@ typedef double real;
 #define ORC_STATE 48     /* floats per env state record of a <= 9-DoF robot (see include/pbre.h) */
 #define ORC_MAXACT 16    /* controlled joints */
 /* State record layout (include/pbre.h): three lane records Q | V | X.  Q and V are W floats wide (W = 16 for robots
- * with <= 9 DoF, 64 otherwise), X is 16:  Q[0..nd) q, Q[nd..nd+3) object position, Q[nd+3..nd+7) object quaternion;
+ * with <= 9 DoF, 32 for <= 20 DoF, 64 otherwise), X is 16:  Q[0..nd) q, Q[nd..nd+3) object position, Q[nd+3..nd+7) object quaternion;
  * V[0..nd) qd, V[nd..nd+6) object twist;  X[0..2] target, X[3] counter, X[4] terminated, X[5] episode,
  * X[6..11] commanded hand pose, X[12] initial hand-object distance, X[13] initial object-target distance. */
 

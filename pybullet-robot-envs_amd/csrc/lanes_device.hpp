@@ -89,7 +89,42 @@ struct DevLanes {
     }
 };
 
-// One env = one whole wave64 (iCub, <= 32 DoF).  Broadcasts of a compile-time lane are v_readlane_b32 (the value becomes
+// One env = one half-wave of 32 lanes (<= 20 DoF: the iCub without its legs), 2 envs per wave64.  Broadcasts / gathers are
+// ds_bpermute_b32 inside the half-wave; an all-reduce is the 16-lane DPP butterfly plus one ds_swizzle_b32 (xor 16).
+struct DevLanes32 : DevLanes {
+    static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
+    static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
+    static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 31u]; }
+    static __device__ __forceinline__ I loadI(const int* p) { return p[threadIdx.x & 31u]; }
+    static __device__ __forceinline__ F loadm(const float* p, B m) { return m ? p[threadIdx.x & 31u] : 0.f; }
+    static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 31u] = x; }
+    static __device__ __forceinline__ void storem(float* p, F x, B m) { if (m) p[threadIdx.x & 31u] = x; }
+    static __device__ __forceinline__ int half_base() { return (int)(threadIdx.x & 32u); }
+    static __device__ __forceinline__ F gather(F a, I idx) {
+        return __int_as_float(__builtin_amdgcn_ds_bpermute((half_base() | (idx & 31)) << 2, __float_as_int(a)));
+    }
+    static __device__ __forceinline__ I gatherI(I a, I idx) { return __builtin_amdgcn_ds_bpermute((half_base() | (idx & 31)) << 2, a); }
+    static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
+    static __device__ __forceinline__ F swap16(F x) {     // lane i <-> lane i ^ 16 inside each 32-lane half (bit-mode swizzle: and 0x1F, or 0, xor 0x10)
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
+    }
+    static __device__ __forceinline__ F sum(F x) {
+        x += dpp<0xB1>(x);
+        x += dpp<0x4E>(x);
+        x += dpp<0x141>(x);
+        x += dpp<0x140>(x);              // every lane: sum of its 16-lane row
+        return x + swap16(x);            // + the other row of the half
+    }
+    static __device__ __forceinline__ F vmin(F x) {
+        x = __builtin_fminf(x, dpp<0xB1>(x));
+        x = __builtin_fminf(x, dpp<0x4E>(x));
+        x = __builtin_fminf(x, dpp<0x141>(x));
+        x = __builtin_fminf(x, dpp<0x140>(x));
+        return __builtin_fminf(x, swap16(x));
+    }
+};
+
+// One env = one whole wave64 (<= 32 DoF).  Broadcasts of a compile-time lane are v_readlane_b32 (the value becomes
 // an SGPR operand), gathers are ds_bpermute_b32 over the wave, all-reduces are the 16-lane DPP butterfly followed by
 // row_bcast15 / row_bcast31 and a v_readlane of lane 63 (summation order (r3 + r2) + (r1 + r0), mirrored by the host
 // emulation so that CPU tests and device agree bit for bit).

@@ -59,11 +59,11 @@ inline int default_config(pbre_config* c, int robot, int task) {
         // the right arm differs in home_hand_pose, eu_lim[2], ik_link_offset and act_dof, which the caller sets
         c->use_ik = 1; c->control_orientation = 0; c->max_steps = 2000; c->target_dist_min = 0.03;
         c->num_controlled_joints = 10; c->num_joints_ctrl = 10;
-        for (int k = 0; k < 16; k++) c->act_dof[k] = k < 10 ? 12 + k : -1;           // torso 12..14, left arm 15..21 in icub_model.sdf traversal order
+        for (int k = 0; k < 16; k++) c->act_dof[k] = k < 10 ? k : -1;                // torso 0..2, left arm 3..9 of the simulated model (legs pruned)
         for (int k = 0; k < 40; k++) c->home[k] = 0.0;
-        c->home[15] = -0.51; c->home[16] = 0.7; c->home[18] = 1.22;                  // l_shoulder_pitch, l_shoulder_roll, l_elbow
-        c->home[25] = -0.51; c->home[26] = 0.7; c->home[28] = 1.22;                  // right arm
-        c->home[22] = 0.008;                                                        // neck_pitch
+        c->home[3] = -0.51; c->home[4] = 0.7; c->home[6] = 1.22;                     // l_shoulder_pitch, l_shoulder_roll, l_elbow
+        c->home[13] = -0.51; c->home[14] = 0.7; c->home[16] = 1.22;                  // right arm
+        c->home[10] = 0.008;                                                        // neck_pitch
         c->ws_lim[0][0] = 0.1; c->ws_lim[0][1] = 0.45;                              // icub_env.py:62
         for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) c->robot_ws[a][b] = c->ws_lim[a][b];
         c->robot_ws[2][0] = c->h_table; c->robot_ws[2][1] = 1.0;                    // icub_reach_gym_env.py:78-80

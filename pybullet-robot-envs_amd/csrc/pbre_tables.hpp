@@ -34,7 +34,8 @@ struct ShapeT {
     static_assert(NJ_ + 7 <= W_ && NJ_ <= 32, "lane budget");
 };
 using Shape16 = ShapeT<16, 9, 3, 4>;      // Panda (<= 9 DoF): one env per 16-lane DPP row, 4 envs per wave
-using Shape64 = ShapeT<64, 32, 2, 4>;     // iCub (<= 32 DoF): one env per wave
+using Shape32 = ShapeT<32, 20, 2, 4>;     // iCub as simulated (legs pruned, 20 DoF): one env per half-wave, 2 envs per wave
+using Shape64 = ShapeT<64, 32, 2, 4>;     // <= 32 DoF: one env per wave
 
 // the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
 constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;

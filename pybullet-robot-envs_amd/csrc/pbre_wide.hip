@@ -1,8 +1,10 @@
-// pbre_wide.hip -- the 64-lane engine: robots with up to 32 DoF (iCub) are stepped one env per wavefront by the lane-group
-// core (pbre_core.hpp instantiated for Shape64).  Lane k of the wave owns DoF k (32 robot lanes, 6 object lanes, the
-// constant lane); M^-1 rows, constraint rows and the 150-iteration PGS state live in VGPRs, cross-lane traffic is
-// v_readlane (broadcast of a row's owner), DPP (all-reduce) and ds_bpermute (tree gathers).  No LDS, no barriers; a
-// block is 4 independent waves.  State: 144 floats per env (Q[64] | V[64] | X[16]).
+// pbre_wide.hip -- the wide lane-group engine: robots with more than 9 DoF (iCub) are stepped by the lane-group core
+// (pbre_core.hpp) with one env per half-wave (Shape32: <= 20 DoF, 2 envs per wavefront -- the iCub as the engine simulates
+// it, i.e. without the legs, model/table.py prune_base_branches) or one env per wavefront (Shape64: <= 32 DoF).  Lane k of
+// the group owns DoF k (robot lanes, 6 object lanes, the constant lane); M^-1 rows, constraint rows and the 150-iteration
+// PGS state live in VGPRs; cross-lane traffic is DPP / ds_swizzle (all-reduce), ds_bpermute (gathers, broadcasts inside a
+// half-wave) and v_readlane (broadcasts inside a whole wave).  No LDS memory, no barriers; a block is 4 independent waves.
+// State: Q[W] | V[W] | X[16] floats per env (80 for Shape32, 144 for Shape64).
 //
 // Replaces, per env (reference file:line): iCubReachGymEnv / iCubPushGymEnv / iCubPushGymGoalEnv .step and .reset
 // (icub_reach_gym_env.py:114-259, icub_push_gym_env.py:116-282, icub_push_gym_goal_env.py:69-139), iCubEnv.apply_action /
@@ -22,63 +24,66 @@
 
 namespace pbre {
 
-using SW = Shape64;
-using CoreW = Core<DevLanes64, SW>;
-using TablesW = TablesT<SW>;
-constexpr int WST = SW::STATE, WNJ = SW::NJ, WW = SW::W;
-constexpr int WPB = 4, WTPB = WPB * 64;          // envs (waves) per block
+constexpr int WTPB = 256;                        // 4 independent waves per block
 
-template <int MODE>
-__global__ __launch_bounds__(WTPB, 3) void kw_step(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
-                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
-                                                int flags, const float* __restrict__ tgt) {
-    const int env = blockIdx.x * WPB + (threadIdx.x >> 6);
-    if (env >= n) return;                           // whole wave
-    CoreW::step(*T, P, state + (size_t)env * WST, (MODE & CoreW::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                (MODE & CoreW::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, (MODE & CoreW::M_TGT) ? tgt + (size_t)env * WNJ : nullptr,
-                P.env_id_base + (unsigned long long)env);
+template <class S, class L, int MODE>
+__global__ __launch_bounds__(WTPB, 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                   const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
+                                                   int flags, const float* __restrict__ tgt) {
+    using C = Core<L, S>;
+    constexpr int EPB = WTPB / S::W;
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
+    if (env >= n) return;                           // whole lane group; a partially filled wave keeps running its other group
+    C::step(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+            (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, (MODE & C::M_TGT) ? tgt + (size_t)env * S::NJ : nullptr,
+            P.env_id_base + (unsigned long long)env);
 }
-template <bool RESET>
-__global__ __launch_bounds__(WTPB) void kw_ik(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
+template <class S, class L, bool RESET>
+__global__ __launch_bounds__(WTPB) void kw_ik(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                                               const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
-    const int env = blockIdx.x * WPB + (threadIdx.x >> 6);
+    constexpr int EPB = WTPB / S::W;
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
     if (env >= n) return;
-    CoreW::ik_targets(*T, P, state + (size_t)env * WST, RESET ? nullptr : actions + (size_t)env * act_dim, tgt + (size_t)env * WNJ, RESET);
+    Core<L, S>::ik_targets(*T, P, state + (size_t)env * S::STATE, RESET ? nullptr : actions + (size_t)env * act_dim, tgt + (size_t)env * S::NJ, RESET);
 }
-template <int MODE>
-__global__ __launch_bounds__(WTPB) void kw_observe(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
+template <class S, class L, int MODE>
+__global__ __launch_bounds__(WTPB) void kw_observe(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    float* __restrict__ out, int n, int ow) {
-    const int env = blockIdx.x * WPB + (threadIdx.x >> 6);
+    using C = Core<L, S>;
+    constexpr int EPB = WTPB / S::W;
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
     if (env >= n) return;
-    float* st = state + (size_t)env * WST;
-    float Q = DevLanes64::load(st), V = DevLanes64::load(st + WW), X = DevLanes64::loadm(st + 2 * WW, DevLanes64::lane() < 16);
-    CoreW::observe(*T, P, st, Q, V, X, (MODE & CoreW::M_OBS) ? out + (size_t)env * ow : nullptr, MODE);
+    float* st = state + (size_t)env * S::STATE;
+    float Q = L::load(st), V = L::load(st + S::W), X = L::loadm(st + 2 * S::W, L::lane() < 16);
+    C::observe(*T, P, st, Q, V, X, (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE);
 }
-__global__ void kw_init(const TablesW* __restrict__ T, const Params P, float* __restrict__ state,
+template <class S, class L>
+__global__ void kw_init(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                         const unsigned long long* __restrict__ ids, const unsigned* __restrict__ ep, int cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) CoreW::init_state(*T, P, ids[i], ep[i], state + (size_t)i * WST);
+    if (i < cnt) Core<L, S>::init_state(*T, P, ids[i], ep[i], state + (size_t)i * S::STATE);
 }
+template <class S, class L>
 __global__ void kw_target(const Params P, float* __restrict__ state, const unsigned long long* __restrict__ ids,
                           const unsigned* __restrict__ ep, int cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) CoreW::sample_target(P, ids[i], ep[i], state + (size_t)i * WST);
+    if (i < cnt) Core<L, S>::sample_target(P, ids[i], ep[i], state + (size_t)i * S::STATE);
 }
-__global__ void kw_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, unsigned* __restrict__ ep) {
+__global__ void kw_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, unsigned* __restrict__ ep, int sf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) ep[i] = (unsigned)((int)state[(size_t)idx[i] * WST + 2 * WW + 5] + 1);
+    if (i < cnt) ep[i] = (unsigned)((int)state[(size_t)idx[i] * sf + (sf - 16) + 5] + 1);
 }
-__global__ void kw_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt) {
+__global__ void kw_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt, int sf) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = t / WST, k = t % WST;
-    if (i < cnt) dst[(size_t)idx[i] * WST + k] = src[(size_t)i * WST + k];
+    const int i = t / sf, k = t % sf;
+    if (i < cnt) dst[(size_t)idx[i] * sf + k] = src[(size_t)i * sf + k];
 }
 
+// shape-independent part of an engine + the launches that depend on the lane-group shape
 struct WideEngine {
     pbre_config cfg;
-    TablesW T; Params P;
-    int n = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0;
-    TablesW* dT = nullptr;
+    Params P;
+    int n = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0, sf = 0, nj = 0, lc = 0;
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
@@ -89,6 +94,75 @@ struct WideEngine {
     long k_steps = 0;
     double ms[3] = {0, 0, 0};
     std::string err;
+    enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT };
+    virtual ~WideEngine() {}
+    virtual std::string tables(const pbre_config& c) = 0;
+    virtual hipError_t upload_tables() = 0;
+    virtual void free_tables() = 0;
+    virtual void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) = 0;
+    virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) = 0;
+    virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
+    virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
+    virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
+    virtual void snapshot(const float* rec) = 0;
+    virtual void limits(float* lo, float* hi) const = 0;
+    virtual int vgprs() const = 0;
+};
+
+template <class S, class L>
+struct WideImpl : WideEngine {
+    using C = Core<L, S>;
+    static constexpr int EPB = WTPB / S::W;
+    TablesT<S> T;
+    TablesT<S>* dT = nullptr;
+    static int blocks_of(int cnt) { return (cnt + EPB - 1) / EPB; }
+    std::string tables(const pbre_config& c) override {
+        std::string e = make_tables<S>(c, T, P);
+        if (e.empty()) { obs_dim = obs_dim_of(T, P); sf = S::STATE; nj = S::NJ; lc = S::LC; }
+        return e;
+    }
+    hipError_t upload_tables() override {
+        if (!dT) { hipError_t e = hipMalloc(&dT, sizeof(TablesT<S>)); if (e != hipSuccess) return e; }
+        return hipMemcpy(dT, &T, sizeof(TablesT<S>), hipMemcpyHostToDevice);
+    }
+    void free_tables() override { if (dT) (void)hipFree(dT); dT = nullptr; }
+    template <int MODE>
+    void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
+        hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg);
+    }
+    void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) override {
+        constexpr int OT = C::M_OBS | C::M_TASK;
+        switch (kind) {
+            case K_SETTLE: step_t<0>(st, tg, cnt, act, out, flags, s); break;
+            case K_SETTLE_TGT: step_t<C::M_TGT>(st, tg, cnt, act, out, flags, s); break;
+            case K_STEP_ACT: step_t<C::M_ACTION | OT>(st, tg, cnt, act, out, flags, s); break;
+            default: step_t<C::M_TGT | OT>(st, tg, cnt, act, out, flags, s); break;
+        }
+    }
+    void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) override {
+        if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
+        else hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
+    }
+    void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) override {
+        if (initd) hipLaunchKernelGGL((kw_observe<S, L, C::M_INITD>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
+        else hipLaunchKernelGGL((kw_observe<S, L, C::M_OBS>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
+    }
+    void launch_init(float* st, int cnt, hipStream_t s) override {
+        hipLaunchKernelGGL((kw_init<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, dT, P, st, d_ids, d_ep, cnt);
+    }
+    void launch_target(float* st, int cnt, hipStream_t s) override {
+        hipLaunchKernelGGL((kw_target<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, P, st, d_ids, d_ep, cnt);
+    }
+    void snapshot(const float* rec) override {
+        for (int k = 0; k < S::NJ; k++) { T.rst_q[k] = rec[k]; P.rst_q[k] = rec[k]; }
+        P.rst_objz = rec[S::LC + 2];
+    }
+    void limits(float* lo, float* hi) const override { obs_limits(cfg, T, lo, hi); }
+    int vgprs() const override {
+        hipFuncAttributes fa;
+        constexpr int M = C::M_ACTION | C::M_OBS | C::M_TASK;
+        return hipFuncGetAttributes(&fa, (const void*)kw_step<S, L, M>) == hipSuccess ? fa.numRegs : -1;
+    }
 };
 
 #define WCHK(call)                                                                  \
@@ -100,38 +174,35 @@ struct WideEngine {
         }                                                                           \
     } while (0)
 
-static int blocks_of(int n) { return (n + WPB - 1) / WPB; }
-
-template <int MODE>
-static hipError_t wstep(WideEngine* w, float* st, float* tg, int n, const float* act, float* out, int flags, hipStream_t s, bool timed = false) {
+static hipError_t wstep(WideEngine* w, int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s, bool timed = false) {
     hipEvent_t* ek = w->ev_k[w->k_steps % WideEngine::KRING];
     if (timed) (void)hipEventRecord(ek[0], s);
-    hipLaunchKernelGGL(kw_step<MODE>, dim3(blocks_of(n)), dim3(WTPB), 0, s, w->dT, w->P, st, act, out, n, w->act_dim, w->ow, flags, tg);
+    w->launch_step(kind, st, tg, cnt, act, out, flags, s);
     if (timed) { (void)hipEventRecord(ek[1], s); w->k_steps++; }
     return hipGetLastError();
 }
-static hipError_t wsettle(WideEngine* w, float* st, float* tg, int n, int count, int flags, hipStream_t s) {
+static hipError_t wsettle(WideEngine* w, float* st, float* tg, int cnt, int count, int flags, hipStream_t s) {
     for (int i = 0; i < count; i++) {
-        hipError_t e = w->P.use_ik ? wstep<CoreW::M_TGT>(w, st, tg, n, nullptr, nullptr, flags, s) : wstep<0>(w, st, tg, n, nullptr, nullptr, flags, s);
+        hipError_t e = wstep(w, w->P.use_ik ? WideEngine::K_SETTLE_TGT : WideEngine::K_SETTLE, st, tg, cnt, nullptr, nullptr, flags, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hipStream_t s) {
     const int flags = w->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
-    constexpr int OT = CoreW::M_OBS | CoreW::M_TASK;
-    if (!w->P.use_ik) return wstep<CoreW::M_ACTION | OT>(w, w->state, w->tgt, w->n, d_act, d_out, flags, s, true);
-    hipLaunchKernelGGL(kw_ik<false>, dim3(blocks_of(w->n)), dim3(WTPB), 0, s, w->dT, w->P, w->state, d_act, w->tgt, w->n, w->act_dim);
+    if (!w->P.use_ik) return wstep(w, WideEngine::K_STEP_ACT, w->state, w->tgt, w->n, d_act, d_out, flags, s, true);
+    w->launch_ik(false, w->state, d_act, w->tgt, w->n, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return wstep<CoreW::M_TGT | OT>(w, w->state, w->tgt, w->n, nullptr, d_out, flags, s, true);
+    return wstep(w, WideEngine::K_STEP_TGT, w->state, w->tgt, w->n, nullptr, d_out, flags, s, true);
 }
 
 void wide_destroy(WideEngine* w) {
     if (!w) return;
     (void)hipSetDevice(w->device);
     if (w->stream) (void)hipStreamSynchronize(w->stream);
-    for (void* p : {(void*)w->dT, (void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
+    w->free_tables();
+    for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
                     (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
@@ -141,15 +212,16 @@ void wide_destroy(WideEngine* w) {
 }
 
 int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
-    WideEngine* w = new WideEngine();
+    WideEngine* w = table_ndof(*cfg) <= Shape32::NJ ? static_cast<WideEngine*>(new WideImpl<Shape32, DevLanes32>())
+                                                    : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>());
     w->cfg = *cfg;
-    std::string e = make_tables<SW>(*cfg, w->T, w->P);
+    std::string e = w->tables(*cfg);
     if (!e.empty()) {
         err = e; delete w;
         return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG);
     }
     w->cfg.robot_table = nullptr;
-    w->n = cfg->num_envs; w->obs_dim = obs_dim_of(w->T, w->P); w->act_dim = act_dim_of(*cfg); w->ow = w->obs_dim + 2; w->device = cfg->device_id;
+    w->n = cfg->num_envs; w->act_dim = act_dim_of(*cfg); w->ow = w->obs_dim + 2; w->device = cfg->device_id;
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) { err = std::string("no HIP device available (") + hipGetErrorString(he) + "); libpbre has no CPU fallback"; delete w; return PBRE_E_DEVICE; }
@@ -159,15 +231,14 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     CK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     for (auto& ev : w->ev) CK(hipEventCreate(&ev));
     for (auto& pr : w->ev_k) for (auto& ev : pr) CK(hipEventCreate(&ev));
-    const size_t n = (size_t)w->n;
-    CK(hipMalloc(&w->dT, sizeof(TablesW)));
-    CK(hipMemcpy(w->dT, &w->T, sizeof(TablesW), hipMemcpyHostToDevice));
-    CK(hipMalloc(&w->state, n * WST * sizeof(float)));
-    CK(hipMalloc(&w->tmp, n * WST * sizeof(float)));
-    CK(hipMalloc(&w->tgt, n * WNJ * sizeof(float)));
-    CK(hipMalloc(&w->tgt_tmp, n * WNJ * sizeof(float)));
-    CK(hipMemset(w->tgt, 0, n * WNJ * sizeof(float)));
-    CK(hipMemset(w->tgt_tmp, 0, n * WNJ * sizeof(float)));
+    const size_t n = (size_t)w->n, sf = (size_t)w->sf, nj = (size_t)w->nj;
+    CK(w->upload_tables());
+    CK(hipMalloc(&w->state, n * sf * sizeof(float)));
+    CK(hipMalloc(&w->tmp, n * sf * sizeof(float)));
+    CK(hipMalloc(&w->tgt, n * nj * sizeof(float)));
+    CK(hipMalloc(&w->tgt_tmp, n * nj * sizeof(float)));
+    CK(hipMemset(w->tgt, 0, n * nj * sizeof(float)));
+    CK(hipMemset(w->tgt_tmp, 0, n * nj * sizeof(float)));
     CK(hipMalloc(&w->d_act, n * w->act_dim * sizeof(float)));
     CK(hipMalloc(&w->d_out, n * w->ow * sizeof(float)));
     CK(hipMalloc(&w->d_ids, n * sizeof(unsigned long long)));
@@ -177,8 +248,8 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
         std::vector<unsigned long long> ids(n, w->P.env_id_base); std::vector<unsigned> ep(n, 0xFFFFFFFFu);
         CK(hipMemcpy(w->d_ids, ids.data(), n * 8, hipMemcpyHostToDevice));
         CK(hipMemcpy(w->d_ep, ep.data(), n * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(kw_init, dim3((w->n + 127) / 128), dim3(128), 0, w->stream, w->dT, w->P, w->state, w->d_ids, w->d_ep, w->n);
-        hipLaunchKernelGGL(kw_init, dim3((w->n + 127) / 128), dim3(128), 0, w->stream, w->dT, w->P, w->tmp, w->d_ids, w->d_ep, w->n);
+        w->launch_init(w->state, w->n, w->stream);
+        w->launch_init(w->tmp, w->n, w->stream);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(w->stream));
     }
@@ -192,7 +263,7 @@ void wide_dims(const WideEngine* w, int32_t* od, int32_t* ad, int32_t* n, int32_
     if (od) *od = w->obs_dim;
     if (ad) *ad = w->act_dim;
     if (n) *n = w->n;
-    if (sf) *sf = WST;
+    if (sf) *sf = w->sf;
 }
 int wide_sync(WideEngine* w) {
     WCHK(hipSetDevice(w->device));
@@ -201,7 +272,7 @@ int wide_sync(WideEngine* w) {
 }
 int wide_observe(WideEngine* w, float* obs) {
     WCHK(hipSetDevice(w->device));
-    hipLaunchKernelGGL(kw_observe<CoreW::M_OBS>, dim3(blocks_of(w->n)), dim3(WTPB), 0, w->stream, w->dT, w->P, w->state, w->d_out, w->n, w->ow);
+    w->launch_observe(false, w->state, w->d_out, w->n, w->stream);
     WCHK(hipGetLastError());
     WCHK(hipMemcpy2DAsync(obs, (size_t)w->obs_dim * 4, w->d_out, (size_t)w->ow * 4, (size_t)w->obs_dim * 4, w->n, hipMemcpyDeviceToHost, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
@@ -224,42 +295,41 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
         hipStream_t s = w->stream;
         WCHK(hipMemcpyAsync(w->d_ids, ids.data(), (size_t)cnt * 8, hipMemcpyHostToDevice, s));
         WCHK(hipMemcpyAsync(w->d_idx, idx.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(kw_next_episode, dim3((cnt + 127) / 128), dim3(128), 0, s, w->state, w->d_idx, cnt, w->d_ep);
+        hipLaunchKernelGGL(kw_next_episode, dim3((cnt + 127) / 128), dim3(128), 0, s, w->state, w->d_idx, cnt, w->d_ep, w->sf);
         WCHK(hipGetLastError());
         WCHK(hipStreamSynchronize(s));                      // host vectors go out of scope below
         const bool full = cnt == w->n;
         float* st = full ? w->state : w->tmp;               // a partial reset settles a compacted copy
         float* tg = full ? w->tgt : w->tgt_tmp;
         const int f0 = w->cfg.flags & PBRE_F_NO_OBJECT;
-        hipLaunchKernelGGL(kw_init, dim3((cnt + 127) / 128), dim3(128), 0, s, w->dT, w->P, st, w->d_ids, w->d_ep, cnt);
+        w->launch_init(st, cnt, s);
         WCHK(hipGetLastError());
         // iCubEnv.reset (icub_env.py:88-151): joints at their initial positions, IK targets of the home hand pose when
         // use_IK, one stepSimulation; then reset_simulation (icub_reach_gym_env.py:135-148): 100 steps robot alone,
         // world loaded, 100 + 1 steps
         if (w->P.use_ik) {
-            hipLaunchKernelGGL(kw_ik<true>, dim3(blocks_of(cnt)), dim3(WTPB), 0, s, w->dT, w->P, st, (const float*)nullptr, tg, cnt, w->act_dim);
+            w->launch_ik(true, st, nullptr, tg, cnt, s);
             WCHK(hipGetLastError());
         }
         WCHK(wsettle(w, st, tg, cnt, (w->P.use_ik || w->P.robot == PBRE_ROBOT_ICUB ? 1 : 0) + 100, PBRE_F_NO_OBJECT, s));
         WCHK(wsettle(w, st, tg, cnt, 101, f0, s));
-        hipLaunchKernelGGL(kw_target, dim3((cnt + 127) / 128), dim3(128), 0, s, w->P, st, w->d_ids, w->d_ep, cnt);
+        w->launch_target(st, cnt, s);
         WCHK(hipGetLastError());
         if (w->P.task >= 1) {   // iCubPushGymEnv.reset (icub_push_gym_env.py:124-127): distances the normalised reward divides by
-            hipLaunchKernelGGL(kw_observe<CoreW::M_INITD>, dim3(blocks_of(cnt)), dim3(WTPB), 0, s, w->dT, w->P, st, (float*)nullptr, cnt, w->ow);
+            w->launch_observe(true, st, nullptr, cnt, s);
             WCHK(hipGetLastError());
         }
         if (!full) {
-            hipLaunchKernelGGL(kw_scatter, dim3((cnt * WST + 255) / 256), dim3(256), 0, s, w->state, st, w->d_idx, cnt);
-            WCHK(hipGetLastError());
             // the IK targets of the reset envs are only needed while settling; the next step recomputes them
+            hipLaunchKernelGGL(kw_scatter, dim3((cnt * w->sf + 255) / 256), dim3(256), 0, s, w->state, st, w->d_idx, cnt, w->sf);
+            WCHK(hipGetLastError());
         }
         WCHK(hipStreamSynchronize(s));
         if (full) {   // snapshot for PBRE_F_AUTO_RESET: settled robot pose and object height (identical in every env)
-            std::vector<float> rec(WST);
-            WCHK(hipMemcpy(rec.data(), w->state, WST * sizeof(float), hipMemcpyDeviceToHost));
-            for (int k = 0; k < WNJ; k++) { w->T.rst_q[k] = rec[k]; w->P.rst_q[k] = rec[k]; }
-            w->P.rst_objz = rec[SW::LC + 2];
-            WCHK(hipMemcpy(w->dT, &w->T, sizeof(TablesW), hipMemcpyHostToDevice));
+            std::vector<float> rec(w->sf);
+            WCHK(hipMemcpy(rec.data(), w->state, (size_t)w->sf * sizeof(float), hipMemcpyDeviceToHost));
+            w->snapshot(rec.data());
+            WCHK(w->upload_tables());
         }
     }
     if (obs) return wide_observe(w, obs);
@@ -287,13 +357,13 @@ int wide_step(WideEngine* w, const float* actions, float* out) {
 int wide_get_state(WideEngine* w, float* s) {
     WCHK(hipSetDevice(w->device));
     WCHK(hipStreamSynchronize(w->stream));
-    WCHK(hipMemcpy(s, w->state, (size_t)w->n * WST * 4, hipMemcpyDeviceToHost));
+    WCHK(hipMemcpy(s, w->state, (size_t)w->n * w->sf * 4, hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
 int wide_set_state(WideEngine* w, const float* s) {
     WCHK(hipSetDevice(w->device));
     WCHK(hipStreamSynchronize(w->stream));
-    WCHK(hipMemcpy(w->state, s, (size_t)w->n * WST * 4, hipMemcpyHostToDevice));
+    WCHK(hipMemcpy(w->state, s, (size_t)w->n * w->sf * 4, hipMemcpyHostToDevice));
     return PBRE_OK;
 }
 int wide_get_physics(const WideEngine* w, pbre_physics* p) { *p = w->cfg.phys; return PBRE_OK; }
@@ -305,7 +375,7 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     w->cfg.phys = *p; w->P = P2;
     return PBRE_OK;
 }
-int wide_obs_limits(const WideEngine* w, float* lo, float* hi) { obs_limits(w->cfg, w->T, lo, hi); return PBRE_OK; }
+int wide_obs_limits(const WideEngine* w, float* lo, float* hi) { w->limits(lo, hi); return PBRE_OK; }
 int wide_timing(const WideEngine* w, double* ms, int32_t n) {
     double kd = 0.0;
     if (n > 3 && w->k_steps > 0) {
@@ -324,11 +394,7 @@ int wide_timing(const WideEngine* w, double* ms, int32_t n) {
     return PBRE_OK;
 }
 int wide_kernel_info(const WideEngine* w, int32_t* info, int32_t n) {
-    hipFuncAttributes fa;
-    int rg = -1;
-    constexpr int M = CoreW::M_ACTION | CoreW::M_OBS | CoreW::M_TASK;
-    if (hipFuncGetAttributes(&fa, (const void*)kw_step<M>) == hipSuccess) rg = fa.numRegs;
-    const int v[7] = {-1, rg, 0, 0, w->n, 0, -1};      // same slots as the Panda engine: [1] VGPRs of the lane-group kernel, [4] envs it steps
+    const int v[7] = {-1, w->vgprs(), 0, 0, w->n, 0, -1};      // same slots as the Panda engine: [1] VGPRs of the lane-group kernel, [4] envs it steps
     for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
     return PBRE_OK;
 }

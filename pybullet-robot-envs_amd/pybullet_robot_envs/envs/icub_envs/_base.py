@@ -1,5 +1,5 @@
 """Shared implementation of the three iCub task envs (reach / push / push-goal): the Panda task base with the iCub's
-constructor arguments, engine configuration, observation limits and state-record layout (144 floats per env)."""
+constructor arguments, engine configuration, observation limits and state-record layout (80 floats per env: 20 simulated DoF, one env per half-wave)."""
 import math as m
 
 import numpy as np
@@ -60,7 +60,7 @@ class ICubTaskBase(PandaTaskBase):
             c.engine.close()
         r = self._robot
         dofs = r.controlled_dofs()
-        home = [r.initial_positions[n] for n in r._info["dof_names"]]
+        home = r.sim_home()
         ori = 1 if self._control_orientation else 0
         overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed, max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
@@ -77,7 +77,7 @@ class ICubTaskBase(PandaTaskBase):
                          ws_lim=[x for lim in self._world.get_workspace() for x in lim],
                          robot_ws=[x for lim in r.get_workspace() for x in lim])
         c.engine = _capi.Engine(r.robot_table, task=self._TASK, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_ICUB, **overrides)
-        assert c.engine.act_dim == r.get_action_dim() and c.engine.state_floats == 144
+        assert c.engine.act_dim == r.get_action_dim() and c.engine.state_floats == 80
         self._engine = c.engine
 
     def _exact_limits(self, lim32):

@@ -67,7 +67,12 @@ class iCubEnv:
 
     def reset(self):
         # Load robot model: parsed parameters -> RobotTable (replaces p.loadSDF + p.createConstraint, icub_env.py:91-103)
-        self.robot_table, self._model, self._info = icub_table(self._control_arm)
+        # The reference's joint names / indices / limits cover the whole SDF model (38 links, 32 DoF); the engine simulates
+        # the model without the legs: limbs rooted at the fixed base are independent dynamical systems, the legs carry no
+        # collision geometry and no env observes them, so they cannot change any output (model/table.py prune_base_branches;
+        # tests/test_golden_icub.py::test_pruned_legs_are_exact).
+        self.robot_table, self._sim_model, self._info = icub_table(self._control_arm)
+        _, self._model, self._full_info = icub_table(self._control_arm, full=True)
         self._joint_name_to_ids = {}
         for i, link in enumerate(self._model["links"]):
             if link["jtype"] != 0:
@@ -87,21 +92,20 @@ class iCubEnv:
                 if (self._control_arm == 'l' and joint_name == 'l_wrist_yaw') or \
                    (self._control_arm == 'r' and joint_name == 'r_wrist_yaw'):
                     self.end_eff_idx = self._joint_name_to_ids[joint_name]
-        assert self.end_eff_idx == self._info["ee_link"]
+        assert self.end_eff_idx == self._full_info["ee_link"]
 
         self.ll, self.ul, self.jr, self.rs, self.jd = self.get_joint_ranges()
         # `if self._use_IK: self.apply_action(self._home_hand_pose)` + `p.stepSimulation()` (icub_env.py:147-151) happen inside
         # the engine's reset (pbre_reset)
 
     def controlled_dofs(self):
-        """DoF indices (engine numbering) of _joints_to_control, same order."""
-        dof_of_link = {}
-        d = 0
-        for i, link in enumerate(self._model["links"]):
-            if link["jtype"] != 0:
-                dof_of_link[i] = d
-                d += 1
-        return [dof_of_link[i] for i in self._joints_to_control]
+        """DoF indices (engine numbering, i.e. in the simulated model) of _joints_to_control, same order."""
+        sim = self._info["dof_names"]
+        return [sim.index(self._model["links"][i]["joint_name"]) for i in self._joints_to_control]
+
+    def sim_home(self):
+        """initial_positions per DoF of the simulated model"""
+        return [self.initial_positions[n] for n in self._info["dof_names"]]
 
     def get_joint_ranges(self):
         lower_limits, upper_limits, joint_ranges, rest_poses, joint_dumping = [], [], [], [], []

@@ -141,7 +141,8 @@ int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return 
 
 int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
-    return table_ndof(*cfg) > Shape16::NJ ? create<Shape64>(cfg, out) : create<Shape16>(cfg, out);
+    const int nd = table_ndof(*cfg);
+    return nd > Shape32::NJ ? create<Shape64>(cfg, out) : (nd > Shape16::NJ ? create<Shape32>(cfg, out) : create<Shape16>(cfg, out));
 }
 void pbre_destroy(pbre_ctx* c) { delete c; }
 const char* pbre_last_error(const pbre_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }

@@ -72,6 +72,7 @@ struct HostLanesT {
         for (int i = 0; i < W; i++) y.v[i] = x.v[i] + x.v[(i & ~7) | (7 - (i & 7))]; x = y;
         for (int i = 0; i < W; i++) y.v[i] = x.v[i] + x.v[(i & ~15) | (15 - (i & 15))]; x = y;
         if (W == 64) return F((x.v[48] + x.v[32]) + (x.v[16] + x.v[0]));
+        if (W == 32) return F(x.v[0] + x.v[16]);
         return x;
     }
     static F vmin(const F& a) { float m = a.v[0]; for (int i = 1; i < W; i++) m = std::fmin(m, a.v[i]); return F(m); }

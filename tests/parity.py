@@ -186,12 +186,13 @@ def make_icub_pair(Engine, lib, n, task=0, control_arm="l", use_ik=1, control_or
 def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, reward_type=1, n=2, steps=4, seed=3):
     """iCub lane-group kernel (one env per 64-lane wave) against the oracle: reset, then single steps from identical states."""
     eng, ora, info = make_icub_pair(Engine, lib, n, task, control_arm, use_ik, control_orientation, reward_type, obj_std=0.05, tg_std=0.2)
-    assert eng.state_floats == ora.state_floats == 144 and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim
+    assert eng.state_floats == ora.state_floats == 80 and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim
+    xo = eng.x_off
     obs = eng.reset()
     st_o, obs_o = ora.batch_reset(n)
     st_e = eng.get_state()
-    assert rel(st_e[:, :128], st_o[:, :128]).max() < 2e-3, rel(st_e[:, :128], st_o[:, :128]).max()
-    assert np.abs(st_e[:, 128:] - st_o[:, 128:]).max() < 2e-3
+    assert rel(st_e[:, :xo], st_o[:, :xo]).max() < 2e-3, rel(st_e[:, :xo], st_o[:, :xo]).max()
+    assert np.abs(st_e[:, xo:] - st_o[:, xo:]).max() < 2e-3
     assert rel(obs, obs_o).max() < 1e-2
     rng = np.random.default_rng(seed)
     st = st_o
@@ -202,8 +203,8 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
         ob, rw, dn = eng.step(a)
         so, out = ora.batch_step(s32.astype(np.float64), a)
         se = eng.get_state()
-        assert np.abs(se[:, 128 + 6:128 + 12] - so[:, 128 + 6:128 + 12]).max() < 1e-6      # commanded hand pose
-        assert rel(se[:, :128], so[:, :128]).max() < 2e-3, (k, rel(se[:, :128], so[:, :128]).max())
+        assert np.abs(se[:, xo + 6:xo + 12] - so[:, xo + 6:xo + 12]).max() < 1e-6      # commanded hand pose
+        assert rel(se[:, :xo], so[:, :xo]).max() < 2e-3, (k, rel(se[:, :xo], so[:, :xo]).max())
         assert rel(ob, out[:, :-2]).max() < 2e-2, (k, rel(ob, out[:, :-2]).max())
         assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
         assert (dn == out[:, -1]).all()

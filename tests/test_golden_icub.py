@@ -29,7 +29,7 @@ def test_oracle_glue_reproduces_reference(tag, arm, task, use_ik, ori, max_steps
     o, info = make(arm, task, use_ik, ori, max_steps, reward_type)
     pre, act = G[tag + "_pre_state"], G[tag + "_actions"]
     ox = o.state_floats - 16
-    assert pre.shape[1] == o.state_floats == 144 and act.shape[1] == o.task.n_act
+    assert pre.shape[1] == o.state_floats == 80 and act.shape[1] == o.task.n_act
     for k in range(len(act)):
         st, out = o.batch_step(pre[k:k + 1], act[k:k + 1])
         assert np.abs(out[0, :-2] - G[tag + "_raw_obs"][k]).max() < 1e-12
@@ -43,22 +43,46 @@ def test_oracle_glue_reproduces_reference(tag, arm, task, use_ik, ori, max_steps
                 assert np.abs(st[0, ox + 6:ox + 12] - nxt[ox + 6:ox + 12]).max() < 1e-12
 
 
+def test_pruned_legs_are_exact():
+    """The engine's iCub model drops the legs (limbs rooted at the fixed base are independent dynamical systems and no env
+    observes them): every output of the 20-DoF model equals the full 32-DoF model's, bit for bit (fp64 oracle)."""
+    from pybullet_robot_envs.model.table import icub_table
+
+    def mk(full):
+        tbl, model, info = icub_table("l", full=full)
+        o = orc.Oracle(tbl, task=1)
+        o.set_icub(info, 1, "l", 1, 0)
+        return o
+    a, b = mk(False), mk(True)
+    assert (a.ndof, b.ndof) == (20, 32)
+    sa, oa = a.batch_reset(1)
+    sb, ob = b.batch_reset(1)
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(0)
+    for k in range(12):
+        act = rng.uniform(-1, 1, (1, 3))
+        sa, ra = a.batch_step(sa, act)
+        sb, rb = b.batch_step(sb, act)
+        assert np.array_equal(ra, rb)
+
+
 def test_reset_and_bookkeeping():
     o, info = make("l", 0, 1, 0, 5, 1)
     st, obs = o.batch_reset(1)
     ref = G["reachG_reset_state"]
-    ox = 128
+    ox = o.state_floats - 16
     assert np.abs(st[0, :ox] - ref[:ox]).max() < 1e-12                 # IK at reset + 1 + 100 + 101 steps, settled object
     assert np.abs(st[0, ox + 6:ox + 12] - ref[ox + 6:ox + 12]).max() < 1e-12
     # joint bookkeeping the reference derives by name (icub_env.py:107-150)
-    names = info["dof_names"]
-    link_of = {n: i for i, n in enumerate([l for l in range(38)])}
+    # the reference numbers joints over the full SDF model (38 links, 32 DoF); the engine simulates it without the legs
     from pybullet_robot_envs.model.table import icub_table
-    _, model, info_r = icub_table("r")
-    jidx = [i for i, l in enumerate(model["links"]) if l["jtype"] != 0]
-    assert [jidx[d] for d in info["controlled"]] == list(G["joints_to_control_l"])
-    assert [jidx[d] for d in info_r["controlled"]] == list(G["joints_to_control_r"])
-    assert [info["ee_link"], info_r["ee_link"]] == list(G["end_eff_idx"])
+    _, full, fl = icub_table("l", full=True)
+    _, _, fr = icub_table("r", full=True)
+    jidx = [i for i, l in enumerate(full["links"]) if l["jtype"] != 0]
+    assert [jidx[d] for d in fl["controlled"]] == list(G["joints_to_control_l"])
+    assert [jidx[d] for d in fr["controlled"]] == list(G["joints_to_control_r"])
+    assert [fl["ee_link"], fr["ee_link"]] == list(G["end_eff_idx"])
+    assert [fl["dof_names"][d] for d in fl["controlled"]] == [info["dof_names"][d] for d in info["controlled"]]
     assert np.allclose(G["home_hand_pose_l"], o.task.home_hand_pose[:]) 
     o2, _ = make("r", 1, 1, 1, 6, 1)
     assert np.allclose(G["home_hand_pose_r"], o2.task.home_hand_pose[:])

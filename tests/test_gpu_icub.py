@@ -28,15 +28,16 @@ def test_icub_masked_reset_and_rollout(hip_lib):
         st_o, out = ora.batch_step(st_o, a)
     se = eng.get_state()
     assert np.isfinite(se).all() and np.isfinite(ob).all()
-    assert np.abs(se[:, :32] - st_o[:, :32]).max() < 2e-2              # joint angles after 40 closed-loop steps
-    assert np.abs(se[:, 32:35] - st_o[:, 32:35]).max() < 2e-2          # object position
+    nd, xo = eng.ndof, eng.x_off
+    assert np.abs(se[:, :nd] - st_o[:, :nd]).max() < 2e-2              # joint angles after 40 closed-loop steps
+    assert np.abs(se[:, nd:nd + 3] - st_o[:, nd:nd + 3]).max() < 2e-2  # object position
     mask = np.zeros(n, np.uint8); mask[[1, 5]] = 1
     eng.reset(mask)
     s2 = eng.get_state()
     keep = [i for i in range(n) if not mask[i]]
     assert np.array_equal(s2[keep], se[keep])
-    assert (s2[[1, 5], 128 + 5] == 1).all() and (s2[keep, 128 + 5] == 0).all()      # episode numbers
-    assert np.abs(s2[[1, 5], 128 + 6:128 + 9] - [0.3, 0.26, 0.8]).max() < 1e-6
+    assert (s2[[1, 5], xo + 5] == 1).all() and (s2[keep, xo + 5] == 0).all()      # episode numbers
+    assert np.abs(s2[[1, 5], xo + 6:xo + 9] - [0.3, 0.26, 0.8]).max() < 1e-6
 
 
 import test_golden_icub as tgi  # noqa: E402

@@ -71,7 +71,7 @@ class _World(object):
     def set_layout(self, nd):
         """state record layout of the oracle (oracle/pbre_oracle.h): Q | V | X"""
         self.nd = nd
-        self.w = 16 if nd <= 9 else 64
+        self.w = 16 if nd <= 9 else (32 if nd <= 20 else 64)
         self.ov, self.ox = self.w, 2 * self.w
         self.state = np.zeros(2 * self.w + 16)
         self.state[nd + 6] = 1.0
@@ -152,30 +152,37 @@ def loadSDF(path, physicsClientId=0, **k):
     bid = W.next_id
     W.next_id += 1
     raw = _sdf.parse_sdf(path)
-    model = _table.pin_base(raw)
+    full = _table.pin_base(raw)
     W.raw_base = (np.asarray(raw["base_position"]) + np.asarray(raw["base_R"]) @ np.asarray(raw["base"]["com"]),
                   _R_to_quat(np.asarray(raw["base_R"])))
-    W.model = model
-    W.icub_info = {a: _table.icub_info(model, a) for a in ("l", "r")}
-    W.set_layout(32)
-    W.bodies[bid] = "robot"
-    W.dof_of_joint = {}
+    # the reference sees every link / joint of the SDF (names, indices, limits); the physics underneath is the engine's
+    # model: legs pruned (limbs rooted at the fixed base are independent and unobserved, model/table.py prune_base_branches)
+    W.model = full
+    W.pruned = _table.prune_base_branches(full, ["l_hand", "r_hand"])
+    pnames = [l["name"] for l in W.pruned["links"]]
+    W.plink = {i: pnames.index(l["name"]) for i, l in enumerate(full["links"]) if l["name"] in pnames}
+    W.icub_info = {a: _table.icub_info(W.pruned, a) for a in ("l", "r")}
+    pdof = {}
     d = 0
-    for i, l in enumerate(model["links"]):
+    for i, l in enumerate(W.pruned["links"]):
         if l["jtype"] != 0:
-            W.dof_of_joint[i] = d
+            pdof[l["joint_name"]] = d
             d += 1
+    W.set_layout(d)
+    W.bodies[bid] = "robot"
+    W.dof_of_joint = {i: pdof.get(l["joint_name"]) for i, l in enumerate(full["links"]) if l["jtype"] != 0}
+    W.leg_q = {i: 0.0 for i, v in W.dof_of_joint.items() if v is None}
     W.oracle = None            # built lazily: the end-effector link (control arm) is only known at the first getLinkState / IK
     return (bid,)
 
 
 def _icub_oracle(ee_link):
-    names = [l["name"] for l in W.model["links"]]
-    arm = names[ee_link][0]
-    if W.oracle is None or W.control_arm != arm or W.oracle.model.ee_link != ee_link:
+    ee = W.plink[ee_link]
+    arm = W.pruned["links"][ee]["name"][0]
+    if W.oracle is None or W.control_arm != arm or W.oracle.model.ee_link != ee:
         info = W.icub_info[arm]
-        assert info["ee_link"] == ee_link
-        tbl = _table.build_table(W.model, _table.icub_spheres(W.model), ee_link=ee_link)
+        assert info["ee_link"] == ee
+        tbl = _table.build_table(W.pruned, _table.icub_spheres(W.pruned), ee_link=ee)
         W.oracle = orc.Oracle(tbl, task=1)
         W.oracle.set_icub(info, 1, arm, 1, 1)
         W.control_arm = arm
@@ -204,6 +211,9 @@ def getJointInfo(body, i, physicsClientId=0):
 
 def resetJointState(body, i, value, physicsClientId=0):
     d = W.dof_of_joint[i]
+    if d is None:              # pruned limb (iCub legs): remembered for getJointState only
+        W.leg_q[i] = value
+        return
     W.state[d] = value
     W.state[W.ov + d] = 0.0
 
@@ -212,6 +222,8 @@ def setJointMotorControl2(body, i, mode, targetPosition=0.0, positionGain=0.1, v
                           maxVelocity=None, physicsClientId=0, **k):
     assert mode == POSITION_CONTROL and force is None and (maxVelocity is None or maxVelocity == -1)
     d = W.dof_of_joint[i]
+    if d is None:
+        return
     W.q_des[d] = targetPosition
     W.kp[d] = positionGain
     W.kd[d] = velocityGain
@@ -232,13 +244,16 @@ def calculateInverseKinematics(body, ee, pos, orn, maxNumIterations=20, residual
     o.task.ik_link_offset[:] = [0.0, 0.0, 0.0]          # the caller already passes the LINK pose (icub_env.py:300-305)
     q, _ = o.ik(W.state[:W.nd], pos, getEulerFromQuaternion(orn))
     o.task.ik_link_offset[:] = list(off)
-    return tuple(q)
+    if W.nd == 9:
+        return tuple(q)
+    # one value per movable joint of the full model, in joint-index order (pruned joints keep their current value)
+    return tuple(q[d] if d is not None else W.leg_q[i] for i, d in sorted(W.dof_of_joint.items()))
 
 
 def stepSimulation(physicsClientId=0):
     o = W.oracle
     if o is None:
-        o = _icub_oracle(W.icub_info["l"]["ee_link"])
+        o = _icub_oracle([i for i, l in enumerate(W.model["links"]) if l["name"] == "l_hand"][0])
     o.params.flags = 0 if W.has_object else orc.F_NO_OBJECT
     W.state, _ = o.sim_step(W.state, W.q_des, W.kp, W.kd)
     W.steps += 1
@@ -265,6 +280,8 @@ def _R_to_quat(R):
 
 def getLinkState(body, link, computeLinkVelocity=0, computeForwardKinematics=0, physicsClientId=0):
     o = W.oracle if W.nd == 9 else _icub_oracle(link)
+    if W.nd != 9:
+        link = W.plink[link]
     m = o.model
     R, p = o.fk(W.state[:W.nd])
     com = p[link] + R[link] @ np.array(m.com[link])
@@ -286,7 +303,8 @@ def getLinkState(body, link, computeLinkVelocity=0, computeForwardKinematics=0, 
 
 
 def getJointStates(body, ids, physicsClientId=0):
-    return [(W.state[W.dof_of_joint[i]], W.state[W.ov + W.dof_of_joint[i]], (0,) * 6, 0.0) for i in ids]
+    return [(W.state[W.dof_of_joint[i]], W.state[W.ov + W.dof_of_joint[i]], (0,) * 6, 0.0) if W.dof_of_joint[i] is not None
+            else (W.leg_q[i], 0.0, (0,) * 6, 0.0) for i in ids]
 
 
 def getJointState(body, i, physicsClientId=0):
