@@ -1023,11 +1023,33 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
     if (obs) orc_observation(m, t, st, obs);
 }
 
+/* in-loop `if self._termination(): break` of apply_action: the termination test without side effects other than the latch */
+static int terminated_now(const orc_model* m, const orc_task* t, real* st) {
+    real pos[3], quat[4], vl[3];
+    real* X = st + OX(m); const real* ob = st + OQ(m);
+    ee_state(m, st, pos, quat, vl);
+    real d1 = 0, d2 = 0;
+    for (int k = 0; k < 3; k++) { real a = pos[k] - ob[k], b = ob[k] - X[k]; d1 += a*a; d2 += b*b; }
+    d1 = (real)sqrt((double)d1); d2 = (real)sqrt((double)d2);
+    const int cnt = (int)X[3];
+    if (t->task == 2) return cnt > t->max_steps;
+    const int succ = (t->task >= 1 ? d2 : d1) <= (real)t->target_dist_min;
+    if (succ) X[4] = 1;
+    return succ || (int)X[4] || cnt > t->max_steps;
+}
+
 void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, const real* action,
                   real* obs, real* reward, real* done) {
-    /* step -> apply_action (panda_push_gym_env.py:189-242; icub_reach_gym_env.py:182-246) */
+    /* step -> apply_action (panda_push_gym_env.py:189-242; icub_reach_gym_env.py:182-246): action_repeat iterations of
+     * [targets from the CURRENT state, stepSimulation, break on termination, counter++], then observation / done / reward */
     const int nd = m->ndof;
     real* X = st + OX(m);
+    const int reps = t->action_repeat > 1 ? t->action_repeat : 1;
+    /* the reference scales the action IN PLACE inside the loop (`action *= 0.05`, panda_push_gym_env.py:199-203,225;
+     * icub_reach_gym_env.py:206-212,232), so iteration r applies action * scale^(r+1) */
+    real sj = 1, sp = 1, sr = 1;
+    for (int rep = 0; rep < reps; rep++) {
+    sj *= (real)t->act_scale; sp *= (real)t->ik_pos_scale; sr *= (real)t->ik_rot_scale;
     real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
     hold_targets(t, nd, qdes, kp, kd);
     if (t->use_ik) {
@@ -1035,21 +1057,26 @@ void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, 
          * accumulate the scaled action on the commanded hand pose, clip rotation and workspace, solve IK */
         real hp[6];
         for (int k = 0; k < 6; k++) hp[k] = X[6 + k];
-        for (int k = 0; k < 3; k++) hp[k] += action[k] * (real)t->ik_pos_scale;
+        for (int k = 0; k < 3; k++) hp[k] += action[k] * sp;
         if (t->control_orientation)
-            for (int k = 3; k < 6; k++) hp[k] = clampr(hp[k] + action[k] * (real)t->ik_rot_scale, t->eu_lim[k-3][0], t->eu_lim[k-3][1]);
+            for (int k = 3; k < 6; k++) hp[k] = clampr(hp[k] + action[k] * sr, t->eu_lim[k-3][0], t->eu_lim[k-3][1]);
         for (int k = 0; k < 3; k++) hp[k] = clampr(hp[k], t->robot_ws[k][0], t->robot_ws[k][1]);
         for (int k = 0; k < 6; k++) X[6 + k] = hp[k];
         ik_targets(m, t, st, hp, qdes);
     } else
     for (int k = 0; k < t->n_act; k++) {
         const int d = t->act_dof[k], li = m->link_of_dof[d];
-        real tgt = st[d] + action[k] * (real)t->act_scale;                 /* :225-230 */
+        real tgt = st[d] + action[k] * sj;                                 /* :225-230 */
         tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);   /* panda_env.py:303, icub_env.py:347 */
         qdes[d] = tgt; kp[d] = (real)t->kp_act; kd[d] = (real)t->kd_act;
     }
     orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
-    orc_reward_done(m, t, st, 1, reward, done);
+    if (rep + 1 < reps) {                    /* not the last iteration: `if self._termination(): break` / counter++ here */
+        if (terminated_now(m, t, st)) { orc_reward_done(m, t, st, 0, reward, done); orc_observation(m, t, st, obs); return; }
+        X[3] += 1;
+    }
+    }
+    orc_reward_done(m, t, st, 1, reward, done);    /* last iteration's termination test + counter, then the final evaluation */
     orc_observation(m, t, st, obs);
 }
 

@@ -123,6 +123,7 @@ typedef struct {
     double eu_lim[3][2];
     double ik_link_offset[3];/* hand COM frame -> link frame (icub_env.py:252-258) */
     int reward_type;         /* iCub push: 0 / 1 (icub_push_gym_env.py:353-373) */
+    int action_repeat;       /* simulation steps per env.step() (apply_action loop, panda_push_gym_env.py:193-242); 0 = 1 */
 } orc_task;
 
 void orc_default_task(orc_task* t, int task);

@@ -44,6 +44,10 @@ constexpr int FTPB = 64;             // lane-per-env kernels: one wave per block
 constexpr int MODE_STEP = CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK;
 constexpr int MODE_STEP_IK = CoreD::M_TGT | CoreD::M_OBS | CoreD::M_TASK;      // use_IK = 1: targets from k_ik
 constexpr int MODE_SETTLE_IK = CoreD::M_TGT;
+// action_repeat > 1: the non-final iterations of the apply_action loop simulate, test termination and count, without outputs
+constexpr int MODE_INNER = CoreD::M_ACTION | CoreD::M_TASK | CoreD::M_INNER;
+constexpr int MODE_INNER_IK = CoreD::M_TGT | CoreD::M_TASK | CoreD::M_INNER;
+static_assert((int)CoreD::M_INNER == (int)FastD::M_INNER && (int)CoreD::M_TGT == (int)FastD::M_TGT, "mode bits shared by the row and lane kernels");
 
 // ------------------------------------------------------------------ kernels
 // General row kernel.  n = real env count; state has ceil16(n) + 16 records (the last 16 are valid dummy records for the
@@ -353,11 +357,24 @@ static hipError_t settle_steps(pbre_ctx* c, EnvBuf& b, int n, int count, int fla
 }
 static hipError_t full_step(pbre_ctx* c, const float* d_act, float* d_out, hipStream_t s) {
     const int flags = c->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
-    if (!c->P.use_ik) return launch_step<MODE_STEP>(c, c->main, c->n, d_act, d_out, flags, s);
-    hipLaunchKernelGGL(k_ik<false>, dim3((c->n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, c->main.state, d_act, c->main.tgt, c->n, c->act_dim);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return launch_step<MODE_STEP_IK>(c, c->main, c->n, nullptr, d_out, flags, s);
+    const int reps = c->cfg.action_repeat > 1 ? c->cfg.action_repeat : 1;
+    const Params P0 = c->P;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps && e == hipSuccess; r++) {
+        // apply_action loop (panda_push_gym_env.py:193-242): the reference scales the action in place in every iteration, so
+        // iteration r applies action * scale^(r+1); all but the last iteration only simulate, test termination and count
+        c->P.act_scale = (r ? c->P.act_scale : 1.f) * P0.act_scale; c->P.ik_ps = (r ? c->P.ik_ps : 1.f) * P0.ik_ps; c->P.ik_rs = (r ? c->P.ik_rs : 1.f) * P0.ik_rs;
+        const bool last = r + 1 == reps;
+        if (!c->P.use_ik) {
+            e = last ? launch_step<MODE_STEP>(c, c->main, c->n, d_act, d_out, flags, s) : launch_step<MODE_INNER>(c, c->main, c->n, d_act, nullptr, flags, s);
+        } else {
+            hipLaunchKernelGGL(k_ik<false>, dim3((c->n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, c->main.state, d_act, c->main.tgt, c->n, c->act_dim);
+            if ((e = hipGetLastError()) != hipSuccess) break;
+            e = last ? launch_step<MODE_STEP_IK>(c, c->main, c->n, nullptr, d_out, flags, s) : launch_step<MODE_INNER_IK>(c, c->main, c->n, nullptr, nullptr, flags, s);
+        }
+    }
+    c->P = P0;
+    return e;
 }
 
 extern "C" {

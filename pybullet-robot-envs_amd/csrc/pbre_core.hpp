@@ -280,7 +280,8 @@ struct Core {
 
     // ---------------------------------------------------------------- the step
     // mode bits
-    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8, M_INITD = 16 };
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8, M_INITD = 16,
+           M_INNER = 32 };   // a non-final iteration of the apply_action loop (action_repeat > 1): termination test + counter, no outputs
 
     struct Rows {             // register-resident solver data
         F Mi[NJ];             // row of M^-1 (lane k: Minv[k][j])
@@ -645,6 +646,10 @@ struct Core {
             F qc = L::sel(L::eqi(lane, LC + 3), nq.x, L::sel(L::eqi(lane, LC + 4), nq.y, L::sel(L::eqi(lane, LC + 5), nq.z, nq.w)));
             Qn = L::sel(L::band(L::gei(lane, LC + 3), L::lti(lane, LC + 7)), qc * in, Qn);
         }
+        {   // action_repeat > 1: a group that left the apply_action loop earlier in this env.step() (X[14]) does not simulate
+            const B skip = L::ne(L::bcast(Xr, 14), zero);
+            Qn = L::sel(skip, Qr, Qn); Vn = L::sel(skip, Vr, Vn);
+        }
         L::store(st, Qn); L::store(st + W, Vn);
 
         if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode, flags, env_id);
@@ -709,14 +714,17 @@ struct Core {
             B succ = L::le(dsucc, L::c(P.dist_min));
             F cnt = L::bcast(Xr, 3), term = L::bcast(Xr, 4);
             F mx = L::c((float)P.max_steps);
+            B left;          // `if self._termination(): break` fired in this iteration of the apply_action loop
             if (P.task == 2) {
                 // goal env (panda_push_gym_goal_env.py:89-122): _termination is only the step budget, success does
                 // not latch; done = budget or success; sparse reward -(d > threshold)
+                left = L::gt(cnt, mx);
                 cnt = L::sel(L::gt(cnt, mx), cnt, cnt + one);
                 done = L::sel(L::bor(succ, L::gt(cnt, mx)), one, zero);
                 reward = L::sel(succ, zero, zero - one);
             } else {
                 B d0 = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
+                left = d0;
                 cnt = L::sel(d0, cnt, cnt + one);
                 term = L::sel(succ, one, term);
                 B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
@@ -736,10 +744,11 @@ struct Core {
                 } else
                 reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
             }
-            F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, Xr));
+            const F lf = (mode & M_INNER) ? L::sel(left, one, zero) : zero;      // consumed by the remaining iterations, cleared by the last one
+            F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, L::sel(L::eqi(lane, 14), lf, Xr)));
             L::storem(st + 2 * W, Xn, L::lti(lane, 16));
 
-            if ((flags & 2) && L::any(L::ne(done, zero))) {
+            if ((flags & 2) && !(mode & M_INNER) && L::any(L::ne(done, zero))) {
                 // ---- snapshot reset of the finished groups: the settled state of reset_simulation is invariant under the
                 // sampled object x, y, yaw (flat table, vertical drop), so the next episode starts from the settled robot pose
                 // and object height recorded at the last full reset, with freshly sampled pose and target
@@ -817,7 +826,9 @@ struct Core {
         {
             F Xn = L::sel(L::eqi(lane, 6), pos.x, L::sel(L::eqi(lane, 7), pos.y, L::sel(L::eqi(lane, 8), pos.z,
                    L::sel(L::eqi(lane, 9), eul.x, L::sel(L::eqi(lane, 10), eul.y, eul.z)))));
-            L::storem(st + 2 * W, Xn, L::band(L::gei(lane, 6), L::lti(lane, 12)));
+            // a group that already left the apply_action loop of this env.step() (action_repeat > 1, X[14]) keeps its hand pose
+            const B live = L::eq(L::bcast(Xr, 14), zero);
+            L::storem(st + 2 * W, Xn, L::band(live, L::band(L::gei(lane, 6), L::lti(lane, 12))));
         }
         const M3 Rt = quat_R(euler_quat(eul));
         const V3 tp = add(cp, mv(Rt, v3(L::c(P.ik_off[0]), L::c(P.ik_off[1]), L::c(P.ik_off[2]))));

@@ -205,7 +205,8 @@ struct Fast {
         return len < 1e-9f ? -best - sr : len - sr;
     }
 
-    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8 };   // M_TGT: motor targets come from the IK target buffer
+    enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8,     // M_TGT: motor targets come from the IK target buffer
+           M_INNER = 32 };   // a non-final iteration of the apply_action loop (action_repeat > 1): termination test + counter, no outputs
 
     // full sphere-vs-box test: signed distance, world normal box->sphere, point on the box
     static PBRE_HD float sphere_box(V3 sc, float sr, V3 bc, const M3& Rb, V3 h, V3& n, V3& pb) {
@@ -243,10 +244,21 @@ struct Fast {
     // Both variants return the class of the state they produced.
     static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                             unsigned long long env_id = 0, const float* tgt = nullptr) {
+        if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
         return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt);
+    }
+    // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (`if self._termination():
+    // break`, panda_push_gym_env.py:239-240; flag X[14]): no simulation step, only the evaluation of the state it is in
+    static PBRE_HD int skipped(const Tables& T, const Params& P, float* st, float* out, int mode, int flags, unsigned long long env_id) {
+        float q[ND], qd[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+        V3 op = v3(st[9], st[10], st[11]);
+        Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+        return finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id);
     }
     static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                                unsigned long long env_id = 0, const float* tgt = nullptr) {
+        if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
         return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
     template <bool RC>
@@ -819,11 +831,11 @@ struct Fast {
     // reset = true: pandaEnv.reset with use_IK (panda_env.py:83-91): targets of the home hand pose.
     static PBRE_HD void ik_targets(const Tables& T, const Params& P, float* st, const float* act, float* tgt, bool reset) {
         float hp[6];
-        const float PI_ = 3.14159265358979323846f;
         if (reset) { PBRE_UNROLL for (int k = 0; k < 6; k++) hp[k] = P.home_hand[k]; }
         else {
-            PBRE_UNROLL for (int k = 0; k < 3; k++) hp[k] = clampf(fmaf(act[k], 0.005f, st[38 + k]), P.rws[k][0], P.rws[k][1]);
-            PBRE_UNROLL for (int k = 3; k < 6; k++) hp[k] = clampf(fmaf(act[k], 0.01f, st[38 + k]), -PI_, PI_);
+            if (st[46] != 0.f) return;       // action_repeat > 1: this env already left the apply_action loop of this env.step()
+            PBRE_UNROLL for (int k = 0; k < 3; k++) hp[k] = clampf(fmaf(act[k], P.ik_ps, st[38 + k]), P.rws[k][0], P.rws[k][1]);
+            PBRE_UNROLL for (int k = 3; k < 6; k++) hp[k] = clampf(fmaf(act[k], P.ik_rs, st[38 + k]), P.eu_lim[k - 3][0], P.eu_lim[k - 3][1]);
         }
         PBRE_UNROLL for (int k = 0; k < 6; k++) st[38 + k] = hp[k];
         float q0[ND], q[ND];
@@ -874,12 +886,15 @@ struct Fast {
                 const bool succ = dsucc <= P.dist_min;
                 float cnt = st[35], term = st[36];
                 const float mx = (float)P.max_steps;
+                bool left;        // `if self._termination(): break` fired in this iteration of the apply_action loop
                 if (P.task == 2) {
+                    left = cnt > mx;
                     cnt = cnt > mx ? cnt : cnt + 1.f;
                     done = (succ || cnt > mx) ? 1.f : 0.f;
                     reward = succ ? 0.f : -1.f;
                 } else {
                     const bool d0 = succ || term != 0.f || cnt > mx;
+                    left = d0;
                     cnt = d0 ? cnt : cnt + 1.f;
                     term = succ ? 1.f : term;
                     done = (succ || term != 0.f || cnt > mx) ? 1.f : 0.f;
@@ -887,8 +902,9 @@ struct Fast {
                     reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
                 }
                 st[35] = cnt; st[36] = term;
+                st[46] = ((mode & M_INNER) && left) ? 1.f : 0.f;      // consumed by the remaining iterations of this env.step(), cleared by its last one
             }
-            const bool again = pass == 0 && (flags & 2) && (mode & M_TASK) && done != 0.f;
+            const bool again = pass == 0 && (flags & 2) && (mode & M_TASK) && !(mode & M_INNER) && done != 0.f;
             if (out && !again) {
                 int o = 0;
                 out[o++] = ee.x; out[o++] = ee.y; out[o++] = ee.z; out[o++] = eul.x; out[o++] = eul.y; out[o++] = eul.z;

@@ -97,7 +97,7 @@ template <class S>
 inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     constexpr int NJ = S::NJ;
     if (c.num_envs <= 0) return "num_envs must be positive";
-    if (c.action_repeat != 1) return "action_repeat != 1 is not implemented";
+    if (c.action_repeat < 1 || c.action_repeat > 64) return "action_repeat out of range";
     if (c.num_controlled_joints < 1 || c.num_controlled_joints > 16 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
     int act_dof[16], n_ctrl = c.num_joints_ctrl;
     for (int k = 0; k < 16; k++) act_dof[k] = c.act_dof[k];

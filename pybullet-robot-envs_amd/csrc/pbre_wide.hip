@@ -94,7 +94,7 @@ struct WideEngine {
     long k_steps = 0;
     double ms[3] = {0, 0, 0};
     std::string err;
-    enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT };
+    enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT, K_INNER_ACT, K_INNER_TGT };
     virtual ~WideEngine() {}
     virtual std::string tables(const pbre_config& c) = 0;
     virtual hipError_t upload_tables() = 0;
@@ -136,6 +136,8 @@ struct WideImpl : WideEngine {
             case K_SETTLE: step_t<0>(st, tg, cnt, act, out, flags, s); break;
             case K_SETTLE_TGT: step_t<C::M_TGT>(st, tg, cnt, act, out, flags, s); break;
             case K_STEP_ACT: step_t<C::M_ACTION | OT>(st, tg, cnt, act, out, flags, s); break;
+            case K_INNER_ACT: step_t<C::M_ACTION | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
+            case K_INNER_TGT: step_t<C::M_TGT | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
             default: step_t<C::M_TGT | OT>(st, tg, cnt, act, out, flags, s); break;
         }
     }
@@ -190,11 +192,23 @@ static hipError_t wsettle(WideEngine* w, float* st, float* tg, int cnt, int coun
 }
 static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hipStream_t s) {
     const int flags = w->cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
-    if (!w->P.use_ik) return wstep(w, WideEngine::K_STEP_ACT, w->state, w->tgt, w->n, d_act, d_out, flags, s, true);
-    w->launch_ik(false, w->state, d_act, w->tgt, w->n, s);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    return wstep(w, WideEngine::K_STEP_TGT, w->state, w->tgt, w->n, nullptr, d_out, flags, s, true);
+    const int reps = w->cfg.action_repeat > 1 ? w->cfg.action_repeat : 1;
+    const Params P0 = w->P;
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps && e == hipSuccess; r++) {
+        // apply_action loop (icub_reach_gym_env.py:200-246): the reference scales the action in place in every iteration, so
+        // iteration r applies action * scale^(r+1); all but the last iteration only simulate, test termination and count
+        w->P.act_scale = (r ? w->P.act_scale : 1.f) * P0.act_scale; w->P.ik_ps = (r ? w->P.ik_ps : 1.f) * P0.ik_ps; w->P.ik_rs = (r ? w->P.ik_rs : 1.f) * P0.ik_rs;
+        const bool last = r + 1 == reps;
+        if (!w->P.use_ik) e = wstep(w, last ? WideEngine::K_STEP_ACT : WideEngine::K_INNER_ACT, w->state, w->tgt, w->n, d_act, last ? d_out : nullptr, flags, s, last);
+        else {
+            w->launch_ik(false, w->state, d_act, w->tgt, w->n, s);
+            if ((e = hipGetLastError()) != hipSuccess) break;
+            e = wstep(w, last ? WideEngine::K_STEP_TGT : WideEngine::K_INNER_TGT, w->state, w->tgt, w->n, nullptr, last ? d_out : nullptr, flags, s, last);
+        }
+    }
+    w->P = P0;
+    return e;
 }
 
 void wide_destroy(WideEngine* w) {

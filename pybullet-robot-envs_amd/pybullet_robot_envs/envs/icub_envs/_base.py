@@ -29,8 +29,6 @@ class ICubTaskBase(PandaTaskBase):
         self._reward_type = reward_type
         self.num_envs = int(num_envs)
         self._auto_reset = bool(auto_reset)
-        if action_repeat != 1:
-            raise NotImplementedError("action_repeat != 1 is not implemented by the batched engine")
 
         self._physics_client_id = _client.connect(num_envs, device_id, env_id_base, seed, _lib)
         self._client = _client.get(self._physics_client_id)
@@ -62,7 +60,7 @@ class ICubTaskBase(PandaTaskBase):
         dofs = r.controlled_dofs()
         home = r.sim_home()
         ori = 1 if self._control_orientation else 0
-        overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed, max_steps=int(self._max_steps),
+        overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed, action_repeat=int(self._action_repeat), max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
                          target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),
                          flags=_capi.F_AUTO_RESET if self._auto_reset else 0,

@@ -37,8 +37,6 @@ class PandaTaskBase(Env):
         self.includeVelObs = includeVelObs
         self.num_envs = int(num_envs)
         self._auto_reset = bool(auto_reset)
-        if action_repeat != 1:
-            raise NotImplementedError("action_repeat != 1 is not implemented by the batched engine")
 
         # "connect": one engine session instead of one PyBullet client (panda_push_gym_env.py:56-62)
         self._physics_client_id = _client.connect(num_envs, device_id, env_id_base, seed, _lib)
@@ -70,7 +68,7 @@ class PandaTaskBase(Env):
             c.engine.close()
         ws = self._world.get_workspace()
         cfg = _capi.Config()
-        overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed,
+        overrides = dict(device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed, action_repeat=int(self._action_repeat),
                          num_controlled_joints=self._robot.joint_action_space, max_steps=int(self._max_steps),
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
                          target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),

@@ -95,16 +95,27 @@ struct Emu : pbre_ctx {
     }
     void step(const float* actions, float* out) override {
         const int ow = obs_dim + 2;
-        for (int e = 0; e < n; e++) {
-            float* st = &state[(size_t)e * STATE];
-            const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
-            const unsigned long long id = P.env_id_base + (unsigned long long)e;
-            if (P.use_ik) {
-                ik(st, actions + (size_t)e * act_dim, &tgt[(size_t)e * NJ], false);
-                step_env(st, nullptr, out + (size_t)e * ow, CoreH::M_TGT | CoreH::M_OBS | CoreH::M_TASK, fl, id, &tgt[(size_t)e * NJ]);
-            } else
-                step_env(st, actions + (size_t)e * act_dim, out + (size_t)e * ow, CoreH::M_ACTION | CoreH::M_OBS | CoreH::M_TASK, fl, id);
+        const int reps = cfg.action_repeat > 1 ? cfg.action_repeat : 1;
+        const Params P0 = P;
+        for (int r = 0; r < reps; r++) {
+            // apply_action loop (panda_push_gym_env.py:193-242): the reference scales the action in place in every iteration, so
+            // iteration r applies action * scale^(r+1); all but the last iteration only simulate, test termination and count
+            P.act_scale = (r ? P.act_scale : 1.f) * P0.act_scale; P.ik_ps = (r ? P.ik_ps : 1.f) * P0.ik_ps; P.ik_rs = (r ? P.ik_rs : 1.f) * P0.ik_rs;
+            const bool last = r + 1 == reps;
+            const int tail = last ? (CoreH::M_OBS | CoreH::M_TASK) : (CoreH::M_TASK | CoreH::M_INNER);
+            for (int e = 0; e < n; e++) {
+                float* st = &state[(size_t)e * STATE];
+                const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
+                const unsigned long long id = P.env_id_base + (unsigned long long)e;
+                float* o = last ? out + (size_t)e * ow : nullptr;
+                if (P.use_ik) {
+                    ik(st, actions + (size_t)e * act_dim, &tgt[(size_t)e * NJ], false);
+                    step_env(st, nullptr, o, CoreH::M_TGT | tail, fl, id, &tgt[(size_t)e * NJ]);
+                } else
+                    step_env(st, actions + (size_t)e * act_dim, o, CoreH::M_ACTION | tail, fl, id);
+            }
         }
+        P = P0;
     }
     void observe(float* obs) override {
         std::vector<float> row(obs_dim + 2);

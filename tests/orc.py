@@ -54,7 +54,7 @@ class Task(C.Structure):
                 ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
                 ("robot", C.c_int), ("act_dof", C.c_int * MAXACT), ("n_joints_ctrl", C.c_int), ("control_orientation", C.c_int),
                 ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double), ("eu_lim", C.c_double * 2 * 3),
-                ("ik_link_offset", C.c_double * 3), ("reward_type", C.c_int)]
+                ("ik_link_offset", C.c_double * 3), ("reward_type", C.c_int), ("action_repeat", C.c_int)]
 
 
 F_NO_OBJECT = 1

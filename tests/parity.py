@@ -22,6 +22,8 @@ def make_pair(Engine, lib, table, n, task=1, obj_std=0.05, tg_std=0.2, **kw):
     ora.task.tg_pose_rnd_std = tg_std
     if kw.get("use_ik"):
         ora.set_ik_mode(True)
+    ora.task.action_repeat = kw.get("action_repeat", 1)
+    ora.task.max_steps = kw.get("max_steps", ora.task.max_steps)
     return eng, ora
 
 
@@ -179,6 +181,8 @@ def make_icub_pair(Engine, lib, n, task=0, control_arm="l", use_ik=1, control_or
     ora.task.tg_pose_rnd_std = tg_std
     ov = icub_overrides(info, control_arm, use_ik, control_orientation, reward_type)
     ov.update(kw)
+    ora.task.action_repeat = kw.get("action_repeat", 1)
+    ora.task.max_steps = kw.get("max_steps", ora.task.max_steps)
     eng = Engine(tbl, task=task, num_envs=n, lib=lib, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=obj_std, tg_pose_rnd_std=tg_std, **ov)
     return eng, ora, info
 
@@ -210,3 +214,27 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
         assert (dn == out[:, -1]).all()
         st = so
     return eng
+
+
+def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
+    """action_repeat = 3 (apply_action loop with the reference's compounding in-place action scaling, break on termination,
+    counter per iteration) against the oracle: free-running, so that envs leave the loop in different iterations."""
+    n = 6
+    eng, ora = make_pair(Engine, lib, table, n, task=1, use_ik=use_ik, action_repeat=3, max_steps=7, flags=flags)
+    eng.reset()
+    st_o, _ = ora.batch_reset(n)
+    st_o[:, 32:35] = [0.6, 0.3, 0.65]                    # far target: the step budget, not success, ends the episode
+    st_o = st_o.astype(np.float32).astype(np.float64)
+    eng.set_state(st_o.astype(np.float32))
+    rng = np.random.default_rng(11)
+    cnts = []
+    for k in range(5):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st_o, out = ora.batch_step(st_o, a)
+        se = eng.get_state()
+        assert np.array_equal(se[:, 35], st_o[:, 35]) and (dn == out[:, -1]).all()       # counters: 3, 6, 8, 8, 8 (budget 7)
+        assert rel(se[:, :35], st_o[:, :35]).max() < 2e-3 and rel(ob, out[:, :-2]).max() < 2e-2
+        assert (se[:, 46] == 0).all()                                                     # the loop-exit flag never outlives a step
+        cnts.append(int(se[0, 35]))
+    assert cnts == [3, 6, 8, 8, 8], cnts

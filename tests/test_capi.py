@@ -47,8 +47,8 @@ def _capi_err(name):
 def test_bad_arguments_are_rejected(panda, emu_lib):
     with pytest.raises(RuntimeError, match="robot_table"):
         _capi.Engine(np.zeros(10), lib=emu_lib)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        _capi.Engine(panda["table"], lib=emu_lib, action_repeat=2)
+    with pytest.raises(RuntimeError, match="action_repeat out of range"):
+        _capi.Engine(panda["table"], lib=emu_lib, action_repeat=1000)
     eng = _capi.Engine(panda["table"], lib=emu_lib, num_envs=2)
     with pytest.raises(ValueError):
         eng.step(np.zeros((3, 7), np.float32))

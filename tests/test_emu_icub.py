@@ -1,4 +1,5 @@
 """iCub (32 DoF, one env per 64-lane group) through the CPU lane emulation of the device algorithm vs the fp64 oracle."""
+import numpy as np
 import pytest
 
 import parity
@@ -16,3 +17,22 @@ def test_icub_auto_reset(emu_lib):
     tbl, model, info = icub_table("l")
     ov = parity.icub_overrides(info, "l", 1, 0, 1)
     parity.check_auto_reset(_capi.Engine, emu_lib, tbl, n=2, max_steps=2, act_dim=3, robot=_capi.ROBOT_ICUB, **ov)
+
+
+def test_icub_action_repeat(emu_lib):
+    n = 2
+    eng, ora, info = parity.make_icub_pair(_capi.Engine, emu_lib, n, task=0, control_arm="l", use_ik=1, control_orientation=0,
+                                           action_repeat=2, max_steps=4)
+    eng.reset()
+    st_o, _ = ora.batch_reset(n)
+    rng = np.random.default_rng(5)
+    xo = eng.x_off
+    for k in range(5):
+        a = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st_o, out = ora.batch_step(st_o, a)
+        se = eng.get_state()
+        assert np.array_equal(se[:, xo + 3], st_o[:, xo + 3]) and (dn == out[:, -1]).all()
+        assert np.abs(se[:, xo + 6:xo + 12] - st_o[:, xo + 6:xo + 12]).max() < 1e-6
+        assert parity.rel(ob, out[:, :-2]).max() < 2e-2
+    assert list(se[:, xo + 3]) == [5, 5]

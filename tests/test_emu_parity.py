@@ -122,3 +122,8 @@ def test_set_physics_matches_oracle(panda, emu_lib):
 def test_ik_mode(panda, emu_lib, task):
     """use_IK=1: Cartesian actions -> hand-pose accumulation/clipping -> damped-least-squares IK -> joint targets."""
     parity.check_ik_mode(_capi.Engine, emu_lib, panda["table"], task)
+
+
+@pytest.mark.parametrize("use_ik,flags", [(0, 0), (1, 0), (0, _capi.F_FORCE_GENERAL)])
+def test_action_repeat(panda, emu_lib, use_ik, flags):
+    parity.check_action_repeat(_capi.Engine, emu_lib, panda["table"], use_ik=use_ik, flags=flags)

@@ -12,7 +12,7 @@ from pybullet_robot_envs.envs import pandaPushGymEnv, pandaReachGymEnv, pandaPus
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "panda_glue.npz"))
 
-CASES = [("pushA", 1, 1000), ("pushB", 1, 6), ("reachC", 0, 5), ("goalD", 2, 4), ("goalE", 2, 4), ("ikF", 1, 1000)]
+CASES = [("pushA", 1, 1000), ("pushB", 1, 6), ("reachC", 0, 5), ("goalD", 2, 4), ("goalE", 2, 4), ("ikF", 1, 1000), ("repR", 1, 7)]
 
 
 @pytest.mark.parametrize("tag,task,max_steps", CASES)
@@ -21,6 +21,8 @@ def test_oracle_glue_reproduces_reference(panda, tag, task, max_steps):
     o.task.max_steps = max_steps
     if tag.startswith("ik"):
         o.set_ik_mode()
+    if tag.startswith("rep"):
+        o.task.action_repeat = 3
     pre, act = G[tag + "_pre_state"], G[tag + "_actions"]
     for k in range(len(act)):
         st, out = o.batch_step(pre[k:k + 1], act[k:k + 1])
@@ -77,7 +79,7 @@ def test_utils_bit_identical(emu_lib):
 @pytest.mark.parametrize("cls,tag,kw", [
     (pandaPushGymEnv, "pushA", {}), (pandaPushGymEnv, "pushB", {"max_steps": 6}),
     (pandaReachGymEnv, "reachC", {"max_steps": 5}), (pandaPushGymGoalEnv, "goalD", {"max_steps": 4, "tg_pose_rnd_std": 0.0}),
-    (pandaPushGymEnv, "ikF", {"use_IK": 1})])
+    (pandaPushGymEnv, "ikF", {"use_IK": 1}), (pandaPushGymEnv, "repR", {"action_repeat": 3, "max_steps": 7})])
 def test_env_classes_match_reference_outputs(emu_lib, cls, tag, kw):
     """The drop-in classes (fp32 device algorithm, run through the CPU lane emulation here) return what the
     reference classes returned: scaled obs, reward, done -- step by step from the reference's own states."""

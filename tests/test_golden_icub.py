@@ -14,7 +14,7 @@ G = np.load(os.path.join(os.path.dirname(__file__), "golden", "icub_glue.npz"))
 
 #        tag      arm task use_ik ori max_steps reward_type
 CASES = [("reachG", "l", 0, 1, 0, 5, 1), ("pushH", "l", 1, 1, 0, 1000, 0), ("pushI", "r", 1, 1, 1, 6, 1),
-         ("pushJ", "l", 1, 0, 0, 1000, 1), ("goalK", "r", 2, 1, 1, 4, 1), ("goalL", "r", 2, 1, 1, 4, 1)]
+         ("pushJ", "l", 1, 0, 0, 1000, 1), ("goalK", "r", 2, 1, 1, 4, 1), ("goalL", "r", 2, 1, 1, 4, 1), ("repS", "l", 0, 1, 0, 4, 1)]
 
 
 def make(arm, task, use_ik, ori, max_steps, reward_type):
@@ -27,6 +27,8 @@ def make(arm, task, use_ik, ori, max_steps, reward_type):
 @pytest.mark.parametrize("tag,arm,task,use_ik,ori,max_steps,reward_type", CASES)
 def test_oracle_glue_reproduces_reference(tag, arm, task, use_ik, ori, max_steps, reward_type):
     o, info = make(arm, task, use_ik, ori, max_steps, reward_type)
+    if tag.startswith("rep"):
+        o.task.action_repeat = 2
     pre, act = G[tag + "_pre_state"], G[tag + "_actions"]
     ox = o.state_floats - 16
     assert pre.shape[1] == o.state_floats == 80 and act.shape[1] == o.task.n_act
@@ -100,6 +102,7 @@ ENVS = [
     (iCubPushGymEnv, "pushr", "pushI", dict(use_IK=1, control_arm='r', control_orientation=1, max_steps=6, reward_type=1)),
     (iCubPushGymEnv, "pushj", "pushJ", dict(use_IK=0, control_arm='l', max_steps=1000, reward_type=1)),
     (iCubPushGymGoalEnv, "goal", "goalK", dict(use_IK=1, control_arm='r', control_orientation=1, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0, max_steps=4)),
+    (iCubReachGymEnv, "reach", "repS", dict(action_repeat=2, use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, max_steps=4)),
 ]
 
 

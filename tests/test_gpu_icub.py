@@ -65,3 +65,8 @@ def test_icub_auto_reset(hip_lib):
     tbl, model, info = icub_table("l")
     ov = parity.icub_overrides(info, "l", 1, 0, 1)
     parity.check_auto_reset(_capi.Engine, hip_lib, tbl, n=40, max_steps=3, act_dim=3, robot=_capi.ROBOT_ICUB, **ov)
+
+
+def test_icub_action_repeat(hip_lib):
+    import test_emu_icub
+    test_emu_icub.test_icub_action_repeat(hip_lib)

@@ -276,3 +276,8 @@ def test_scripted_push_properties(panda, hip_lib, flags):
     assert seen_complex >= n // 2                             # the script really exercised the robot-contact kernels
     moved = st[:, 9] - x0[:, 0]
     assert (moved > 0.02).mean() > 0.9 and np.isfinite(st).all()
+
+
+@pytest.mark.parametrize("use_ik,flags", [(0, 0), (1, 0), (0, _capi.F_FORCE_GENERAL), (0, _capi.F_COMPLEX_LANES)])
+def test_action_repeat(panda, hip_lib, use_ik, flags):
+    parity.check_action_repeat(_capi.Engine, hip_lib, panda["table"], use_ik=use_ik, flags=flags)

@@ -142,6 +142,10 @@ actF[3:6, 2] = -1.0          # drive z down
 actF[6:9, 0] = -1.0          # drive x below the workspace limit
 rollout(envF, "ikF", actF, set_target=(0.58, 0.25, 0.64999))
 
+# R: action_repeat=3 (apply_action loop: targets from the current state each iteration, break on termination, counter per iteration)
+envR = pandaPushGymEnv(action_repeat=3, max_steps=7)
+rollout(envR, "repR", rng.uniform(-1, 1, (5, 7)), set_target=(0.58, 0.25, 0.64999))
+
 # utils goldens
 box = envA.observation_space
 x = rng.uniform(-1, 1, (6, 33)) * (box.high - box.low) * 0.6 + 0.5 * (box.high + box.low)
@@ -208,6 +212,9 @@ for t in range(500):
 builtins.print = _print
 out["cfg1_obs_every10"] = np.array(tr_obs)[::10]
 out["cfg1_reward"] = np.array(tr_rew); out["cfg1_done"] = np.array(tr_done)
+# S: action_repeat=2 with IK control (the hand pose accumulates once per iteration)
+envS = iCubReachGymEnv(action_repeat=2, use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, max_steps=4)
+rollout(envS, "repS", rng.uniform(-1, 1, (5, 3)))
 out["joints_to_control_l"] = np.array(envJ._robot._joints_to_control)
 out["joints_to_control_r"] = np.array(envI._robot._joints_to_control)
 out["end_eff_idx"] = np.array([envJ._robot.end_eff_idx, envI._robot.end_eff_idx])
