@@ -17,7 +17,7 @@
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
- *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14..15] reserved
+ *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14] left the apply_action loop (action_repeat > 1)
  *
  * RobotTable (pbre_config.robot_table): float64 array, little endian
  *   [0] magic 1346523717 ('PBRE')  [1] version 1  [2] n_links  [3] n_dof  [4] ee_link  [5] n_spheres
@@ -78,7 +78,7 @@ typedef struct {
                                   angles: act_dim = 6 (dx,dy,dz,droll,dpitch,dyaw) with control_orientation=1
                                   (R/envs/panda_envs/panda_push_gym_env.py:197-222), 3 (dx,dy,dz) with 0 (iCub ids) */
     int32_t num_controlled_joints;   /* joints driven by the action in joint mode: 7 Panda, 10 iCub (torso + arm) */
-    int32_t action_repeat;     /* 1 */
+    int32_t action_repeat;     /* simulation steps per pbre_step: the apply_action loop (panda_push_gym_env.py:193-242); 1 in every registered id */
     int32_t max_steps;         /* 1000 */
     int32_t flags;             /* PBRE_F_* */
     double  obj_pose_rnd_std, tg_pose_rnd_std;
