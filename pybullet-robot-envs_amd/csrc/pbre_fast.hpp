@@ -397,9 +397,14 @@ struct Fast {
         // ---- unconstrained joint velocities w = v*; motor rows (btMultiBodyJointMotor) written against the running
         //      velocity w = v* + dv:  t = dinv*w - rhs2 with rhs2 = (kp (q_des - q)/dt + (1 - kd) v*) dinv
         const float vmax = P.vmax;
-        WV w, Mc[ND];                 // Mc[j] = column j of M^-1 in the pair layout (entry ND of the padded vectors stays 0)
-        PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) { wset(w, k, 0.f); PBRE_UNROLL for (int j = 0; j < ND; j++) wset(Mc[j], k, 0.f); }
-        PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_UNROLL for (int k = 0; k < ND; k++) wset(Mc[j], k, Mi[sym(k, j)]);
+        // Mc[j] = column j of M^-1 in the pair layout (entry ND of the padded vectors stays 0).  The complex-env variant keeps the
+        // 45-entry triangle instead: it is register-bound (dense robot-contact rows), 90 more live values cost more than they save.
+        WV w, Mc[RC ? 1 : ND];
+        PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) wset(w, k, 0.f);
+        if (!RC) {
+            PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) PBRE_UNROLL for (int j = 0; j < ND; j++) wset(Mc[j], k, 0.f);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_UNROLL for (int k = 0; k < ND; k++) wset(Mc[j], k, Mi[sym(k, j)]);
+        }
         float m_dinv[ND], m_rhs[ND], m_app[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
@@ -569,14 +574,16 @@ struct Fast {
             const float t = fmaf(m_dinv[j], wget(w, j), -m_rhs[j]);
             const float s = med3(m_app[j] - t, -mlim, mlim);
             const float d = s - m_app[j]; m_app[j] = s;
-            waxpy(w, d, Mc[j]);
+            if (RC) { PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k))); }
+            else waxpy(w, d, Mc[RC ? 0 : j]);
         };
         const float llim = P.limit_imp;
         auto limit = [&](int j) {
             const float t = fmaf(m_dinv[j] * l_dir[j], wget(w, j), -l_rhs[j]);
             const float s = med3(l_app[j] - t, 0.f, llim);
             const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
-            waxpy(w, d, Mc[j]);
+            if (RC) { PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k))); }
+            else waxpy(w, d, Mc[RC ? 0 : j]);
         };
         auto orow = [&](int c, int d) {
             const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
