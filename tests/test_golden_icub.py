@@ -173,3 +173,23 @@ def check_config1(lib, steps):
 
 def test_config1_trace_prefix(emu_lib):
     check_config1(emu_lib, 60)                     # the CPU lane emulation is slow: the first 60 steps; all 500 on the GPU
+
+
+def test_icub_model_compiler():
+    """model/sdf.py output (committed JSON): tree structure, masses and the base pinned at the fixed constraint's rest pose."""
+    from pybullet_robot_envs.model.table import icub_model, icub_info, ICUB_HOME
+    full, sim = icub_model(full=True), icub_model()
+    assert len(full["links"]) == 38 and sum(1 for l in full["links"] if l["jtype"]) == 32
+    assert len(sim["links"]) == 22 and sum(1 for l in sim["links"] if l["jtype"]) == 20        # legs (12 DoF + 4 fixed links) pruned
+    assert abs(sum(l["mass"] for l in full["links"]) + full["base"]["mass"] - 33.0617) < 1e-3   # icub_model.sdf total mass
+    names = [l["joint_name"] for l in full["links"] if l["jtype"]]
+    assert set(names) == set(ICUB_HOME) and names[12:15] == ["torso_pitch", "torso_roll", "torso_yaw"]
+    for i, l in enumerate(sim["links"]):
+        assert l["parent"] < i                                                                 # topological order survives the pruning
+    # base COM raised to 1.2 x its loaded height, orientation R_base^T (icub_env.py:97-103)
+    R = np.array(full["base_R"]); p = np.array(full["base_position"]); com = np.array(full["base"]["com"])
+    assert abs((p + R @ com)[2] - 1.2 * (0.63 - 0.044081)) < 1e-6
+    assert np.allclose(R, [[np.cos(-3.14), -np.sin(-3.14), 0], [np.sin(-3.14), np.cos(-3.14), 0], [0, 0, 1]], atol=1e-12)
+    info = icub_info(sim, "r")
+    assert [info["dof_names"][d] for d in info["controlled"]][3:] == ["r_shoulder_pitch", "r_shoulder_roll", "r_shoulder_yaw", "r_elbow",
+                                                                      "r_wrist_prosup", "r_wrist_pitch", "r_wrist_yaw"]
