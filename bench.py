@@ -265,6 +265,14 @@ def main():
             traffic = pmc["hbm_bytes_per_env_step"] * n_local
         except Exception:
             pass
+        sq = None
+        try:   # SQ issue counters of the same kernel (rocprofv3 --pmc pass, tools/pmc_sq.sh), committed summary
+            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")))["k_fast<7>"]
+            sq = {"valu_insts_per_wave": d["valu_insts_per_wave"], "valu_active_over_wave_cycles": d["valu_active_over_wave_cycles"],
+                  "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "waves_per_simd": 2,
+                  "note": "2 waves per SIMD x this per-wave VALU-active fraction = VALU pipe ~93% busy while the waves are resident"}
+        except Exception:
+            pass
         res = {
             "metric": "env-steps/sec (whole node), Panda-push 128k envs",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -290,7 +298,7 @@ def main():
                      # the 157.3 TF peak assumes v_pk_fma_f32 at full rate; measured on this chip (profiles/r01_ubench_pkfma.txt) a
                      # packed FMA takes ~2 passes, so the scalar-FMA peak (78.6 TF) is the practical ceiling of fp32 FMA code
                      "peak_scalar_fma": FP32_VALU_PEAK_TFLOPS / 2, "frac_scalar_fma": ach_tf / (FP32_VALU_PEAK_TFLOPS / 2),
-                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
+                     "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "sq_counters": sq, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
