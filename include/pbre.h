@@ -18,6 +18,9 @@
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
  *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14] left the apply_action loop (action_repeat > 1)
+ * iCub with hands (W = 128, nd = 60): additionally Q[nd+7..nd+12) mean normal force on each fingertip of the controlled hand,
+ *   Q[nd+12] fingertips in contact with the object, Q[nd+13] robot-object contact points (check_contact_fingertips /
+ *   check_collision, icub_env_with_hands.py:246-318); these 7 values are also the tail of the observation.
  *
  * RobotTable (pbre_config.robot_table): float64 array, little endian
  *   [0] magic 1346523717 ('PBRE')  [1] version 1  [2] n_links  [3] n_dof  [4] ee_link  [5] n_spheres
@@ -25,7 +28,7 @@
  *   then n_links records of 40: parent, jtype(0 fixed,1 revolute,2 prismatic), axis[3], origin_xyz[3],
  *        origin_R[9], mass, com[3], inertia[9] (about COM, link axes), lower, upper, damping,
  *        dof_index(-1 fixed), lateral_friction, effort, velocity, reserved[3]
- *   then n_spheres records of 8: link, centre[3], radius, friction, reserved[2]
+ *   then n_spheres records of 8: link, centre[3], radius, friction, fingertip slot + 1 (0: not a fingertip), reserved
  */
 #ifndef PBRE_H
 #define PBRE_H
@@ -40,7 +43,10 @@ extern "C" {
 
 enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
 enum { PBRE_ROBOT_PANDA = 0,
-       PBRE_ROBOT_ICUB = 1 };     /* icub_model.sdf: observation / reward / reset variants of R/envs/icub_envs */
+       PBRE_ROBOT_ICUB = 1,       /* icub_model.sdf: observation / reward / reset variants of R/envs/icub_envs */
+       PBRE_ROBOT_ICUB_HANDS = 2 };   /* icub_model_with_hands.sdf (R/envs/icub_envs/icub_env_with_hands.py): robot-level interface --
+                                     absolute joint / hand-pose commands, persistent finger motors (pbre_set_motors), fingertip
+                                     contact forces appended to the observation */
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
@@ -87,7 +93,7 @@ typedef struct {
     double  kp_act, kd_act, kp_hold, kd_hold;
     double  ws_lim[3][2];      /* world (object) workspace, world_env.py:72 */
     double  h_table;
-    double  home[40];          /* initial joint positions per DoF, panda_env.py:19-23 / icub_env.py:19-41 */
+    double  home[64];          /* initial joint positions per DoF, panda_env.py:19-23 / icub_env.py:19-41 */
     pbre_physics phys;
     /* use_ik = 1: damped-least-squares IK (replaces p.calculateInverseKinematics, panda_env.py:269-272) */
     double  ik_damping, ik_residual; int32_t ik_max_iters;   /* 0.1 [EXT-UNVERIFIED], 1e-3, 100 */
@@ -96,10 +102,12 @@ typedef struct {
     int32_t control_orientation;/* IK mode: 1 = the action carries droll,dpitch,dyaw; 0 = home orientation is kept (icub_env.py:281-283) */
     int32_t reward_type;        /* iCub push: 0 / 1 (icub_push_gym_env.py:353-373) */
     int32_t num_joints_ctrl;    /* controlled joints = observed joints of the iCub (10); Panda: = num_controlled_joints */
-    int32_t act_dof[16];        /* DoF index of controlled joint k, in the reference's _joints_to_control order (icub_env.py:127-138) */
+    int32_t act_dof[64];        /* DoF index of controlled joint k, in the reference's _joints_to_control order (icub_env.py:127-138) */
     double  ik_pos_scale, ik_rot_scale;   /* hand-pose increment per unit action (panda_push_gym_env.py:200-203; icub_reach_gym_env.py:206-212) */
     double  eu_lim[3][2];       /* Euler limits of the commanded hand orientation (panda_env.py:38, icub_env.py:63-74) */
     double  ik_link_offset[3];  /* hand COM frame -> hand link frame (icub_env.py:252-258); 0 for the Panda */
+    int32_t ik_absolute;        /* 1: IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-300) instead of
+                                   scaled increments accumulated by the task env; set for PBRE_ROBOT_ICUB_HANDS */
     const double* robot_table; size_t robot_table_len;   /* number of doubles */
 } pbre_config;
 
@@ -144,6 +152,19 @@ int pbre_observe(pbre_ctx* ctx, float* obs_out);
 /* `n` bare physics steps with hold motors (replaces the settle loops `for _ in range(100): p.stepSimulation`,
  * panda_push_gym_env.py:132-133,139-140); flags: PBRE_F_NO_OBJECT or 0 */
 int pbre_settle(pbre_ctx* ctx, int32_t n, int32_t flags);
+
+/* PBRE_ROBOT_ICUB_HANDS: command the persistent POSITION_CONTROL motors of `n` DoF -- replaces the
+ * p.setJointMotorControlArray calls of iCubHandsEnv.open_hand / pre_grasp / grasp (R/envs/icub_envs/icub_env_with_hands.py:
+ * 167-244).  dofs: DoF indices; targets: host [n], the same for every selected env; kp: positionGain; max_force: the
+ * `forces` entry in newtons (grasp: 10), <= 0 keeps PyBullet's default; env_mask: NULL = all envs, else num_envs bytes. */
+int pbre_set_motors(pbre_ctx* ctx, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force,
+                    const uint8_t* env_mask);
+
+/* PBRE_ROBOT_ICUB_HANDS: the command half of iCubEnv.apply_action alone (R/envs/icub_envs/icub_env.py:260-361) -- IK + the
+ * setJointMotorControl calls, no stepSimulation: the motors keep the command until the next one, the caller advances the
+ * simulation with pbre_settle (the reference's `p.stepSimulation()` loops, examples/helloworlds/helloworld_icub.py:61-125).
+ * actions: host [num_envs][act_dim], absolute joint targets (joint control) or hand poses x,y,z,roll,pitch,yaw (use_ik). */
+int pbre_apply_action(pbre_ctx* ctx, const float* actions);
 
 /* replace the physics constants of every env of the batch (replaces p.changeDynamics in change_physics_params,
  * R/envs/panda_envs/panda_push_gym_env.py:362-368: object mass / friction / link damping -- domain randomisation between

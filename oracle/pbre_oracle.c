@@ -121,7 +121,7 @@ void orc_euler_from_quat(const real q[4], real e[3]) {
 /* ------------------------------------------------------------------ model */
 int orc_sizeof_real(void) { return (int)sizeof(real); }
 /* state record layout (pbre_oracle.h) */
-static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : (m->ndof <= 20 ? 32 : 64); }
+static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : (m->ndof <= 20 ? 32 : (m->ndof <= 32 ? 64 : 128)); }
 int orc_state_floats(const orc_model* m) { return 2 * lay_w(m) + 16; }
 #define OQ(m) ((m)->ndof)                 /* object position (then quaternion) inside Q */
 #define OV(m) (lay_w(m))                  /* V record */
@@ -150,6 +150,9 @@ int orc_model_from_table(const double* t, size_t n, orc_model* m) {
         m->s_link[k] = (int)s[0];
         for (int c = 0; c < 3; c++) m->s_c[k][c] = (real)s[1+c];
         m->s_r[k] = (real)s[4]; m->s_mu[k] = (real)s[5];
+        m->s_tip[k] = (int)s[6];
+        if (m->s_tip[k] > ORC_NTIP) return -4;
+        if (m->s_tip[k] > 0) m->ntip = ORC_NTIP;
     }
     return 0;
 }
@@ -439,7 +442,7 @@ typedef struct { int idx; real dist; real n[3], pA[3], pB[3]; int link; real mu;
 
 /* keep the `cap` smallest-distance candidates with dist < margin, then order by idx */
 static int select_contacts(cand_t* c, int n, int cap, real margin, cand_t* out) {
-    int used[32] = {0}, cnt = 0;
+    int used[ORC_MAXS] = {0}, cnt = 0;
     for (int s = 0; s < cap; s++) {
         int best = -1;
         for (int i = 0; i < n; i++) if (!used[i] && c[i].dist < margin && (best < 0 || c[i].dist < c[best].dist)) best = i;
@@ -490,7 +493,12 @@ static void point_jacobian(const orc_model* m, const aba_ws* w, int link, const 
 
 void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const real* q_des, const real* kp,
                   const real* kd, orc_step_info* info) {
+    orc_sim_step_f(m, prm, st, q_des, kp, kd, NULL, info);
+}
+void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* st, const real* q_des, const real* kp,
+                    const real* kd, const real* fscale, orc_step_info* info) {
     const int nd = m->ndof;
+    const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : ORC_NC_RO;
     const real dt = (real)prm->dt;
     real* q = st; real* qd = st + OV(m);
     real* op = st + OQ(m); real* oq = op + 3; real* ov = qd + nd; real* ow = ov + 3;
@@ -530,7 +538,7 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
             cs[s].dist = sphere_box(sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
             for (int k = 0; k < 3; k++) cs[s].pA[k] = cs[s].pB[k] + cs[s].n[k] * cs[s].dist;
         }
-        n_ro = select_contacts(cs, m->ns, ORC_NC_RO, margin, sel + n_ot);
+        n_ro = select_contacts(cs, m->ns, nc_ro, margin, sel + n_ot);
     }
     {
         cand_t cs[ORC_MAXS];
@@ -612,7 +620,7 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
         r->dinv = 1 / r->bA[j];
         real verr = kp[j] * (q_des[j] - q[j]) / dt - kd[j] * vs[j];
         r->rhs = verr * r->dinv;
-        r->lo = -(real)prm->max_motor_impulse; r->hi = (real)prm->max_motor_impulse;
+        r->hi = (real)prm->max_motor_impulse * (fscale ? fscale[j] : (real)1); r->lo = -r->hi;
     }
     /* contacts: normal row + 2 friction rows (btPlaneSpace1 directions) */
     for (int c = 0; c < nsel; c++) {
@@ -703,6 +711,18 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
         quat_mul(dq, oq, nq);
         real nn = (real)sqrt((double)(nq[0]*nq[0] + nq[1]*nq[1] + nq[2]*nq[2] + nq[3]*nq[3]));
         for (int k = 0; k < 4; k++) oq[k] = nq[k] / nn;
+    }
+    if (m->ntip > 0) {
+        /* check_contact_fingertips / check_collision (icub_env_with_hands.py:246-318): mean normal force (impulse / dt) of the
+         * contact points of each fingertip with the object, tips in contact, robot-object contact points */
+        real tf[ORC_NTIP] = {0}; int tc[ORC_NTIP] = {0}, ntip = 0;
+        for (int c = n_ot; c < n_ot + n_ro; c++) {
+            const int tp = m->s_tip[sel[c].idx];
+            if (tp > 0) { tf[tp - 1] += rn[c].app / dt; tc[tp - 1]++; }
+        }
+        real* T = st + OQ(m) + 7;
+        for (int k = 0; k < ORC_NTIP; k++) { T[k] = tc[k] ? tf[k] / (real)tc[k] : 0; ntip += tc[k] > 0; }
+        T[ORC_NTIP] = (real)ntip; T[ORC_NTIP + 1] = (real)n_ro;
     }
     info->ncontacts = nsel;
     for (int c = 0; c < nsel; c++) {
@@ -838,8 +858,8 @@ void orc_task_icub(orc_task* t, int task, int right_arm, int use_ik, int control
     for (int k = 0; k < 3; k++) t->ik_link_offset[k] = right_arm ? orr[k] : ol[k];
     t->reward_type = 1;
 }
-static int n_obs_joints(const orc_task* t, const orc_model* m) { return t->robot == 1 ? t->n_joints_ctrl : m->ndof; }
-int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + n_obs_joints(t, m) + 6 + 6 + (t->task >= 1 ? 3 : 0); }
+static int n_obs_joints(const orc_task* t, const orc_model* m) { return t->robot >= 1 ? t->n_joints_ctrl : m->ndof; }
+int orc_obs_dim(const orc_task* t, const orc_model* m) { return 9 + n_obs_joints(t, m) + 6 + 6 + (t->task >= 1 ? 3 : 0) + (m->ntip > 0 ? ORC_NTIP + 2 : 0); }
 
 /* end-effector state as p.getLinkState(computeLinkVelocity=1) reports it: COM frame position, orientation, linear velocity */
 static void ee_state(const orc_model* m, const real* st, real* pos, real* quat, real* vlin) {
@@ -869,7 +889,7 @@ void orc_observation(const orc_model* m, const orc_task* t, const real* st, real
     int o = 0;
     for (int k = 0; k < 3; k++) obs[o++] = pos[k];
     for (int k = 0; k < 3; k++) obs[o++] = eu[k];
-    if (t->robot == 1) {                                   /* iCub: raw velocity, controlled joints only */
+    if (t->robot >= 1) {                                   /* iCub: raw velocity, controlled joints only */
         for (int k = 0; k < 3; k++) obs[o++] = vl[k];
         for (int k = 0; k < t->n_joints_ctrl; k++) obs[o++] = st[t->act_dof[k]];
     } else {
@@ -893,6 +913,7 @@ void orc_observation(const orc_model* m, const orc_task* t, const real* st, real
     for (int k = 0; k < 3; k++) obs[o++] = rel[k];
     for (int k = 0; k < 3; k++) obs[o++] = er[k];
     if (t->task >= 1) for (int k = 0; k < 3; k++) obs[o++] = st[OX(m)+k];
+    if (m->ntip > 0) for (int k = 0; k < ORC_NTIP + 2; k++) obs[o++] = st[OQ(m) + 7 + k];    /* fingertip forces and counts */
 }
 
 /* reward + termination; pre_increment=1 reproduces the in-loop `_termination()` + counter++ of apply_action
@@ -925,7 +946,7 @@ void orc_reward_done(const orc_model* m, const orc_task* t, real* st, int pre_in
     }
     if (succ) term = 1;
     *done = (succ || term || cnt > t->max_steps) ? (real)1 : (real)0;
-    if (t->robot == 1) {
+    if (t->robot >= 1) {
         if (t->task == 0) {                               /* icub_reach_gym_env.py:318-330: the bonus is ADDED */
             *reward = -d1; if (d1 <= thr) *reward += (real)1000 + ((real)100 - d1 * 80);
         } else if (t->reward_type == 0) {                 /* icub_push_gym_env.py:353-356 */
@@ -951,12 +972,18 @@ static real clampr(real x, double lo, double hi) { return x < (real)lo ? (real)l
 static void ik_targets(const orc_model* m, const orc_task* t, const real* st, const real* hp, real* qdes) {
     real sol[ORC_MAXD];
     orc_ik(m, t, st, hp, hp + 3, sol);
-    if (t->robot == 1) { for (int k = 0; k < t->n_joints_ctrl; k++) qdes[t->act_dof[k]] = sol[t->act_dof[k]]; }
+    if (t->robot >= 1) { for (int k = 0; k < t->n_joints_ctrl; k++) qdes[t->act_dof[k]] = sol[t->act_dof[k]]; }
     else for (int k = 0; k < m->ndof; k++) qdes[k] = sol[k];
 }
 
+static void env_reset_impl(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
+                           real* st, real* obs, real* mrec);
 void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
-                   real* st, real* obs) {
+                   real* st, real* obs) { env_reset_impl(m, prm, t, env_id, episode, st, obs, NULL); }
+void orc_hands_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
+                     real* st, real* mrec, real* obs) { env_reset_impl(m, prm, t, env_id, episode, st, obs, mrec); }
+static void env_reset_impl(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
+                           real* st, real* obs, real* mrec) {
     /* reset_simulation (panda_push_gym_env.py:117-148, icub_reach_gym_env.py:121-148): robot at home, 100 steps,
      * load world, 100 steps, 1 step */
     const int nd = m->ndof;
@@ -981,21 +1008,24 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
     real e[3] = {0, 0, yaw};
     ob[0] = px; ob[1] = py; ob[2] = pz;
     orc_quat_from_euler(e, ob + 3);
-    real qdes[ORC_MAXD], kp[ORC_MAXD], kd[ORC_MAXD];
+    real qdes_l[ORC_MAXD], kp_l[ORC_MAXD], kd[ORC_MAXD];
+    /* iCub with hands: the motors' commands persist in the env's motor record (iCubHandsEnv.reset, icub_env_with_hands.py:108-121) */
+    real* qdes = mrec ? mrec : qdes_l; real* kp = mrec ? mrec + ORC_MAXD : kp_l; real* fs = mrec ? mrec + 2 * ORC_MAXD : NULL;
     hold_targets(t, nd, qdes, kp, kd);
+    if (fs) for (int k = 0; k < ORC_MAXD; k++) fs[k] = 1;
     orc_params p1 = *prm; p1.flags |= ORC_F_NO_OBJECT;
     if (t->use_ik) {
         /* robot.reset with use_IK (panda_env.py:83-91, icub_env.py:147-148): apply_action(home_hand_pose) -> IK once from
          * the joint home pose, motors (all DoF, kp 0.2) hold that solution for the whole settle */
         real hp[6]; for (int k = 0; k < 6; k++) hp[k] = (real)t->home_hand_pose[k];
-        for (int k = t->robot == 1 ? 0 : 2; k < 3; k++) hp[k] = clampr(hp[k], t->robot_ws[k][0], t->robot_ws[k][1]);
+        for (int k = t->robot >= 1 ? 0 : 2; k < 3; k++) hp[k] = clampr(hp[k], t->robot_ws[k][0], t->robot_ws[k][1]);
         ik_targets(m, t, st, hp, qdes);
         for (int k = 0; k < 6; k++) X[6 + k] = (real)t->home_hand_pose[k];
     }
     /* one extra stepSimulation at the end of robot.reset: Panda only in IK mode (panda_env.py:91), iCub always (icub_env.py:151) */
-    if (t->use_ik || t->robot == 1) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
-    for (int i = 0; i < 100; i++) orc_sim_step(m, &p1, st, qdes, kp, kd, NULL);
-    for (int i = 0; i < 101; i++) orc_sim_step(m, prm, st, qdes, kp, kd, NULL);
+    if (t->use_ik || t->robot >= 1) orc_sim_step_f(m, &p1, st, qdes, kp, kd, fs, NULL);
+    for (int i = 0; i < 100; i++) orc_sim_step_f(m, &p1, st, qdes, kp, kd, fs, NULL);
+    for (int i = 0; i < 101; i++) orc_sim_step_f(m, prm, st, qdes, kp, kd, fs, NULL);
     /* sample_tg_pose (panda_push_gym_env.py:333-360, icub_push_gym_env.py:375-401) */
     if (t->task >= 1) {
         real tx_min = (real)t->ws_lim[0][0] + (real)0.07, tx_max = (real)t->ws_lim[0][1] - (real)0.07;
@@ -1013,7 +1043,7 @@ void orc_env_reset(const orc_model* m, const orc_params* prm, const orc_task* t,
         X[0] = tx; X[1] = ty; X[2] = tz;
     }
     X[3] = 0; X[4] = 0; X[5] = (real)episode;
-    if (t->robot == 1 && t->task >= 1) {
+    if (t->robot >= 1 && t->task >= 1) {
         /* iCubPushGymEnv.reset (icub_push_gym_env.py:124-127): distances the normalised reward divides by */
         real pos[3], quat[4], vl[3], d1 = 0, d2 = 0;
         ee_state(m, st, pos, quat, vl);
@@ -1077,6 +1107,65 @@ void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, 
     }
     }
     orc_reward_done(m, t, st, 1, reward, done);    /* last iteration's termination test + counter, then the final evaluation */
+    orc_observation(m, t, st, obs);
+}
+
+/* ---- iCub with hands: robot-level interface (icub_env_with_hands.py; icub_env.py:260-361) */
+void orc_task_hands(orc_task* t, int right_arm, int use_ik, const int* ctrl_dof, int n_ctrl, const double* home, int ndof) {
+    orc_default_task(t, 0);
+    t->robot = 2; t->max_steps = 1 << 30; t->target_dist_min = -1.0;      /* no episode logic at the robot level */
+    t->ws_lim[0][0] = 0.35; t->ws_lim[0][1] = 0.70; t->ws_lim[1][0] = -0.33; t->ws_lim[1][1] = 0.27;   /* object dropped at (0.5, -0.03), helloworld_icub.py:51 */
+    t->ws_lim[2][0] = t->h_table; t->ws_lim[2][1] = t->h_table + 0.3;
+    t->robot_ws[0][0] = 0.15; t->robot_ws[0][1] = 0.50; t->robot_ws[1][0] = -0.3; t->robot_ws[1][1] = 0.3;
+    t->robot_ws[2][0] = 0.5; t->robot_ws[2][1] = 1.0;                       /* icub_env_with_hands.py:63 */
+    for (int k = 0; k < ORC_MAXD; k++) t->home[k] = k < ndof ? home[k] : 0.0;
+    t->n_joints_ctrl = n_ctrl;
+    for (int k = 0; k < ORC_MAXACT; k++) t->act_dof[k] = k < n_ctrl ? ctrl_dof[k] : -1;
+    t->use_ik = use_ik; t->control_orientation = 1; t->ik_absolute = 1;
+    t->n_act = use_ik ? 6 : n_ctrl;
+    t->ik_pos_scale = 1.0; t->ik_rot_scale = 1.0;
+    const double hl[6] = {0.2, 0.3, 0.8, -PI, 0, -PI / 2}, hr[6] = {0.2, -0.3, 0.8, 0, 0, PI / 2};       /* :77-81 */
+    for (int k = 0; k < 6; k++) t->home_hand_pose[k] = right_arm ? hr[k] : hl[k];
+    const double el[3][2] = {{-1.5 * PI, -PI / 2}, {-PI / 2, PI / 2}, {0, -PI}}, er[3][2] = {{-PI / 2, PI / 2}, {-PI / 2, PI / 2}, {0, PI}};
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 2; b++) t->eu_lim[a][b] = right_arm ? er[a][b] : el[a][b];
+    const double ol[3] = {-0.011682, 0.051355, 0.000577}, orr[3] = {-0.011682, 0.051682, -0.000577};   /* :159-165 */
+    for (int k = 0; k < 3; k++) t->ik_link_offset[k] = right_arm ? orr[k] : ol[k];
+}
+void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force) {
+    /* p.setJointMotorControlArray(POSITION_CONTROL, targetPositions, positionGains[, forces]) of open_hand / pre_grasp / grasp (:167-244) */
+    const real fs = max_force > 0 ? (real)(max_force * prm->dt / prm->max_motor_impulse) : (real)1;
+    for (int k = 0; k < n; k++) { mrec[dofs[k]] = targets[k]; mrec[ORC_MAXD + dofs[k]] = (real)kp; mrec[2 * ORC_MAXD + dofs[k]] = fs; }
+}
+void orc_hands_settle(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, const real* mrec, int n) {
+    real kd[ORC_MAXD];
+    for (int k = 0; k < ORC_MAXD; k++) kd[k] = (real)t->kd_hold;
+    for (int i = 0; i < n; i++) orc_sim_step_f(m, prm, st, mrec, mrec + ORC_MAXD, kd, mrec + 2 * ORC_MAXD, NULL);
+}
+void orc_hands_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, real* mrec, const real* action,
+                    real* obs, real* reward, real* done) {
+    /* iCubEnv.apply_action (icub_env.py:260-361) with absolute commands, one stepSimulation, observation */
+    real* X = st + OX(m);
+    real* qdes = mrec; real* kp = mrec + ORC_MAXD; real* fs = mrec + 2 * ORC_MAXD;
+    real kd[ORC_MAXD];
+    for (int k = 0; k < ORC_MAXD; k++) kd[k] = (real)t->kd_hold;
+    if (t->use_ik) {
+        real hp[6];
+        for (int k = 0; k < 3; k++) hp[k] = clampr(action[k], t->robot_ws[k][0], t->robot_ws[k][1]);
+        for (int k = 3; k < 6; k++) hp[k] = t->control_orientation ? clampr(action[k], t->eu_lim[k-3][0], t->eu_lim[k-3][1]) : X[6 + k];
+        for (int k = 0; k < 6; k++) X[6 + k] = hp[k];
+        /* every joint is commanded (setJointMotorControlArray over all joints, gains 0.2): chain joints from the IK, the other
+         * controlled joints at the value the IK returns for them (their current position), blocked joints at rest */
+        for (int k = 0; k < m->ndof; k++) { qdes[k] = (real)t->home[k]; kp[k] = (real)t->kp_hold; fs[k] = 1; }
+        ik_targets(m, t, st, hp, qdes);
+    } else
+    for (int k = 0; k < t->n_act; k++) {
+        const int d = t->act_dof[k], li = m->link_of_dof[d];
+        real tgt = action[k];
+        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);     /* icub_env.py:347 */
+        qdes[d] = tgt; kp[d] = (real)t->kp_act; fs[d] = 1;
+    }
+    orc_sim_step_f(m, prm, st, qdes, kp, kd, fs, NULL);
+    orc_reward_done(m, t, st, 1, reward, done);
     orc_observation(m, t, st, obs);
 }
 

@@ -28,19 +28,22 @@ typedef float real;
 typedef double real;
 #endif
 
-#define ORC_MAXL 48      /* links (fixed joints kept as 0-DoF links) */
-#define ORC_MAXD 40      /* joint DoF */
-#define ORC_MAXS 16      /* collision spheres */
+#define ORC_MAXL 80      /* links (fixed joints kept as 0-DoF links) */
+#define ORC_MAXD 64      /* joint DoF */
+#define ORC_MAXS 64      /* collision spheres */
 #define ORC_NC_OT 4      /* object-table contact slots */
-#define ORC_NC_RO 2      /* robot-object contact slots */
+#define ORC_NC_RO 2      /* robot-object contact slots (6 for the iCub with hands: 5 fingertips + palm) */
+#define ORC_NC_RO_HANDS 6
 #define ORC_NC_RT 2      /* robot-table contact slots */
-#define ORC_NC (ORC_NC_OT + ORC_NC_RO + ORC_NC_RT)
+#define ORC_NC (ORC_NC_OT + ORC_NC_RO_HANDS + ORC_NC_RT)
+#define ORC_NTIP 5       /* fingertips of the controlled hand (icub_env_with_hands.py:248) */
 #define ORC_STATE 48     /* floats per env state record of a <= 9-DoF robot (see include/pbre.h) */
-#define ORC_MAXACT 16    /* controlled joints */
+#define ORC_MAXACT 64    /* controlled joints */
 /* State record layout (include/pbre.h): three lane records Q | V | X.  Q and V are W floats wide (W = 16 for robots
  * with <= 9 DoF, 32 for <= 20 DoF, 64 otherwise), X is 16:  Q[0..nd) q, Q[nd..nd+3) object position, Q[nd+3..nd+7) object quaternion;
  * V[0..nd) qd, V[nd..nd+6) object twist;  X[0..2] target, X[3] counter, X[4] terminated, X[5] episode,
- * X[6..11] commanded hand pose, X[12] initial hand-object distance, X[13] initial object-target distance. */
+ * X[6..11] commanded hand pose, X[12] initial hand-object distance, X[13] initial object-target distance.
+ * iCub with hands (W = 128): Q[nd+7..nd+12) mean normal force per fingertip, Q[nd+12] tips in contact, Q[nd+13] robot-object contact points. */
 
 typedef struct {
     int nl, ndof, ee_link, ns, fixed_base;
@@ -51,6 +54,8 @@ typedef struct {
     real lower[ORC_MAXL], upper[ORC_MAXL], damping[ORC_MAXL], friction[ORC_MAXL];
     int s_link[ORC_MAXS];
     real s_c[ORC_MAXS][3], s_r[ORC_MAXS], s_mu[ORC_MAXS];
+    int s_tip[ORC_MAXS];           /* fingertip slot + 1 of the sphere (0: not a fingertip) */
+    int ntip;                      /* > 0: the model reports fingertip contact forces (iCub with hands) */
     int link_of_dof[ORC_MAXD];
 } orc_model;
 
@@ -97,6 +102,9 @@ void orc_forward_dynamics(const orc_model* m, const orc_params* prm, const real*
 /* one stepSimulation(): state record [48], motor targets/gains per DoF */
 void orc_sim_step(const orc_model* m, const orc_params* prm, real* state,
                   const real* q_des, const real* kp, const real* kd, orc_step_info* info);
+/* same with a per-DoF scale of the motor impulse bound (setJointMotorControl `force` / default force); NULL = 1 */
+void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* state,
+                    const real* q_des, const real* kp, const real* kd, const real* fscale, orc_step_info* info);
 
 /* ---- task layer (reference Python glue restated) ---- */
 typedef struct {
@@ -124,6 +132,7 @@ typedef struct {
     double ik_link_offset[3];/* hand COM frame -> link frame (icub_env.py:252-258) */
     int reward_type;         /* iCub push: 0 / 1 (icub_push_gym_env.py:353-373) */
     int action_repeat;       /* simulation steps per env.step() (apply_action loop, panda_push_gym_env.py:193-242); 0 = 1 */
+    int ik_absolute;         /* IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-300) */
 } orc_task;
 
 void orc_default_task(orc_task* t, int task);
@@ -131,6 +140,15 @@ int  orc_obs_dim(const orc_task* t, const orc_model* m);
 int  orc_state_floats(const orc_model* m);
 /* set the iCub variants (robot=1): control_arm 0 left / 1 right, controlled DoF list, home pose per DoF */
 void orc_task_icub(orc_task* t, int task, int right_arm, int use_ik, int control_orientation, const int* ctrl_dof, const double* home, int ndof);
+/* iCub with hands (robot = 2, icub_env_with_hands.py): robot-level interface.  mrec = per-DoF persistent motor record
+ * target[ORC_MAXD] | kp[ORC_MAXD] | force scale[ORC_MAXD] (PyBullet motors keep their last command) */
+void orc_task_hands(orc_task* t, int right_arm, int use_ik, const int* ctrl_dof, int n_ctrl, const double* home, int ndof);
+void orc_hands_reset(const orc_model* m, const orc_params* prm, const orc_task* t, uint64_t env_id, uint32_t episode,
+                     real* state, real* mrec, real* obs);
+void orc_hands_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* state, real* mrec,
+                    const real* action, real* obs, real* reward, real* done);
+void orc_hands_settle(const orc_model* m, const orc_params* prm, const orc_task* t, real* state, const real* mrec, int n);
+void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force);
 void orc_observation(const orc_model* m, const orc_task* t, const real* state, real* obs);
 void orc_reward_done(const orc_model* m, const orc_task* t, real* state, int pre_increment,
                      real* reward, real* done);

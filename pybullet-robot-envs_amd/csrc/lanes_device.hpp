@@ -12,6 +12,10 @@ namespace pbre {
 
 struct DevLanes {
     using F = float; using I = int; using B = bool;
+    using Robot = DevLanes;                                       // robot-lane view (pbre_core.hpp): the backend itself
+    static __device__ __forceinline__ F lo(F x) { return x; }
+    static __device__ __forceinline__ F wide(F x) { return x; }
+    static __device__ __forceinline__ F fma_lo(F s, F m, F acc) { return __builtin_fmaf(s, m, acc); }
     static __device__ __forceinline__ F c(float x) { return x; }
     static __device__ __forceinline__ I ci(int x) { return x; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 15u); }
@@ -54,7 +58,7 @@ struct DevLanes {
     static __device__ __forceinline__ F sel(B m, F a, F b) { return m ? a : b; }
     static __device__ __forceinline__ I seli(B m, I a, I b) { return m ? a : b; }
     static __device__ __forceinline__ B bit(I m, int k) { return (m >> k) & 1; }
-    static __device__ __forceinline__ B biti(I m, I k) { return (m >> k) & 1; }
+    static __device__ __forceinline__ B biti(I m, I k) { return (m >> (k & 31)) & 1; }
     static __device__ __forceinline__ I maxi(I a, int b) { return a > b ? a : b; }
     static __device__ __forceinline__ F itof(I a) { return (float)a; }
     static __device__ __forceinline__ I ftoi(F a) { return (int)a; }
@@ -92,6 +96,7 @@ struct DevLanes {
 // One env = one half-wave of 32 lanes (<= 20 DoF: the iCub without its legs), 2 envs per wave64.  Broadcasts / gathers are
 // ds_bpermute_b32 inside the half-wave; an all-reduce is the 16-lane DPP butterfly plus one ds_swizzle_b32 (xor 16).
 struct DevLanes32 : DevLanes {
+    using Robot = DevLanes32;
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 31u]; }
@@ -129,6 +134,7 @@ struct DevLanes32 : DevLanes {
 // row_bcast15 / row_bcast31 and a v_readlane of lane 63 (summation order (r3 + r2) + (r1 + r0), mirrored by the host
 // emulation so that CPU tests and device agree bit for bit).
 struct DevLanes64 : DevLanes {
+    using Robot = DevLanes64;
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 63u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 63u]; }
@@ -165,6 +171,84 @@ struct DevLanes64 : DevLanes {
         const float c_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
         return __builtin_fminf(__builtin_fminf(a, b), __builtin_fminf(c_, d));
     }
+};
+
+// One env = one wave64 carrying 128 virtual lanes (<= 60 DoF + object + constant lane: the iCub with hands): physical
+// lane t holds virtual lanes t (.a) and t + 64 (.b).  Arithmetic is done on both halves; an all-reduce adds the halves and
+// runs the 64-lane butterfly once; a broadcast of a compile-time lane is one v_readlane of the half that holds it; a gather
+// is two ds_bpermute per source half.  Robot-lane-only data (rows of M^-1, motor / limit rows) live on the low half alone
+// (Robot = DevLanes64), which keeps the 60 x 60 inverse in 60 VGPRs.
+struct F2 { float a, b; };
+struct I2 { int a, b; __device__ __forceinline__ I2() {} __device__ __forceinline__ I2(int x) : a(x), b(x) {} __device__ __forceinline__ I2(int x, int y) : a(x), b(y) {} };
+struct B2 { bool a, b; };
+static __device__ __forceinline__ F2 operator+(F2 x, F2 y) { return F2{x.a + y.a, x.b + y.b}; }
+static __device__ __forceinline__ F2 operator-(F2 x, F2 y) { return F2{x.a - y.a, x.b - y.b}; }
+static __device__ __forceinline__ F2 operator*(F2 x, F2 y) { return F2{x.a * y.a, x.b * y.b}; }
+static __device__ __forceinline__ F2 operator/(F2 x, F2 y) { return F2{x.a / y.a, x.b / y.b}; }
+
+struct DevLanes128 {
+    using F = F2; using I = I2; using B = B2;
+    using Robot = DevLanes64;
+    using D = DevLanes64;
+    static __device__ __forceinline__ float lo(F x) { return x.a; }
+    static __device__ __forceinline__ F wide(float r) { return F{r, 0.f}; }
+    static __device__ __forceinline__ F fma_lo(float s, float m, F acc) { return F{__builtin_fmaf(s, m, acc.a), acc.b}; }
+    static __device__ __forceinline__ int t() { return (int)(threadIdx.x & 63u); }
+    static __device__ __forceinline__ F c(float x) { return F{x, x}; }
+    static __device__ __forceinline__ I ci(int x) { return I(x); }
+    static __device__ __forceinline__ I lane() { return I(t(), t() + 64); }
+    static __device__ __forceinline__ F load(const float* p) { return F{p[t()], p[t() + 64]}; }
+    static __device__ __forceinline__ I loadI(const int* p) { return I(p[t()], p[t() + 64]); }
+    static __device__ __forceinline__ F loadm(const float* p, B m) { return F{m.a ? p[t()] : 0.f, m.b ? p[t() + 64] : 0.f}; }
+    static __device__ __forceinline__ F loadu(const float* p) { const float v = *p; return F{v, v}; }
+    static __device__ __forceinline__ float first(F x) { return x.a; }
+    static __device__ __forceinline__ bool lane0() { return t() == 0; }
+    static __device__ __forceinline__ void fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+    static __device__ __forceinline__ F loadx(const float* p, I idx, B m) { return F{m.a ? p[idx.a] : 0.f, m.b ? p[idx.b] : 0.f}; }
+    static __device__ __forceinline__ void storex(float* p, I idx, F x, B m) { if (m.a) p[idx.a] = x.a; if (m.b) p[idx.b] = x.b; }
+    static __device__ __forceinline__ void store(float* p, F x) { p[t()] = x.a; p[t() + 64] = x.b; }
+    static __device__ __forceinline__ void storem(float* p, F x, B m) { if (m.a) p[t()] = x.a; if (m.b) p[t() + 64] = x.b; }
+#define PBRE_U1(name, fn) static __device__ __forceinline__ F name(F x) { return F{fn(x.a), fn(x.b)}; }
+    PBRE_U1(abs, __builtin_fabsf) PBRE_U1(sqrt, sqrtf) PBRE_U1(sin, sinf) PBRE_U1(cos, cosf) PBRE_U1(asin, asinf)
+#undef PBRE_U1
+    static __device__ __forceinline__ F atan2(F x, F y) { return F{atan2f(x.a, y.a), atan2f(x.b, y.b)}; }
+    static __device__ __forceinline__ F fma(F x, F y, F z) { return F{__builtin_fmaf(x.a, y.a, z.a), __builtin_fmaf(x.b, y.b, z.b)}; }
+    static __device__ __forceinline__ F min(F x, F y) { return F{__builtin_fminf(x.a, y.a), __builtin_fminf(x.b, y.b)}; }
+    static __device__ __forceinline__ F max(F x, F y) { return F{__builtin_fmaxf(x.a, y.a), __builtin_fmaxf(x.b, y.b)}; }
+    static __device__ __forceinline__ F med3(F x, F l, F h) { return F{__builtin_amdgcn_fmed3f(x.a, l.a, h.a), __builtin_amdgcn_fmed3f(x.b, l.b, h.b)}; }
+#define PBRE_CMP(name, op) static __device__ __forceinline__ B name(F x, F y) { return B{x.a op y.a, x.b op y.b}; }
+    PBRE_CMP(lt, <) PBRE_CMP(le, <=) PBRE_CMP(gt, >) PBRE_CMP(ge, >=) PBRE_CMP(eq, ==) PBRE_CMP(ne, !=)
+#undef PBRE_CMP
+#define PBRE_CMPI(name, op) static __device__ __forceinline__ B name(I x, I y) { return B{x.a op y.a, x.b op y.b}; }
+    PBRE_CMPI(eqi, ==) PBRE_CMPI(nei, !=) PBRE_CMPI(lti, <) PBRE_CMPI(gei, >=)
+#undef PBRE_CMPI
+    static __device__ __forceinline__ B band(B x, B y) { return B{(bool)(x.a & y.a), (bool)(x.b & y.b)}; }
+    static __device__ __forceinline__ B bor(B x, B y) { return B{(bool)(x.a | y.a), (bool)(x.b | y.b)}; }
+    static __device__ __forceinline__ B bnot(B x) { return B{!x.a, !x.b}; }
+    static __device__ __forceinline__ B bfalse() { return B{false, false}; }
+    static __device__ __forceinline__ bool any(B x) { return __any((int)(x.a | x.b)) != 0; }
+    static __device__ __forceinline__ F sel(B m, F x, F y) { return F{m.a ? x.a : y.a, m.b ? x.b : y.b}; }
+    static __device__ __forceinline__ I seli(B m, I x, I y) { return I(m.a ? x.a : y.a, m.b ? x.b : y.b); }
+    static __device__ __forceinline__ B bit(I m, int k) { return B{(bool)((m.a >> k) & 1), (bool)((m.b >> k) & 1)}; }
+    static __device__ __forceinline__ B biti(I m, I k) { return B{(bool)((m.a >> (k.a & 31)) & 1), (bool)((m.b >> (k.b & 31)) & 1)}; }
+    static __device__ __forceinline__ I maxi(I x, int y) { return I(x.a > y ? x.a : y, x.b > y ? x.b : y); }
+    static __device__ __forceinline__ F itof(I x) { return F{(float)x.a, (float)x.b}; }
+    static __device__ __forceinline__ I ftoi(F x) { return I((int)x.a, (int)x.b); }
+    // ---- cross-lane over the 128 virtual lanes
+    static __device__ __forceinline__ int g1(int lo_, int hi_, int idx) {
+        const int v0 = __builtin_amdgcn_ds_bpermute((idx & 63) << 2, lo_), v1 = __builtin_amdgcn_ds_bpermute((idx & 63) << 2, hi_);
+        return (idx & 64) ? v1 : v0;
+    }
+    static __device__ __forceinline__ F gather(F x, I idx) {
+        return F{__int_as_float(g1(__float_as_int(x.a), __float_as_int(x.b), idx.a)), __int_as_float(g1(__float_as_int(x.a), __float_as_int(x.b), idx.b))};
+    }
+    static __device__ __forceinline__ I gatherI(I x, I idx) { return I(g1(x.a, x.b, idx.a), g1(x.a, x.b, idx.b)); }
+    static __device__ __forceinline__ F bcast(F x, int k) {
+        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(k < 64 ? x.a : x.b), __builtin_amdgcn_readfirstlane(k & 63)));
+        return F{v, v};
+    }
+    static __device__ __forceinline__ F sum(F x) { const float s = D::sum(x.a + x.b); return F{s, s}; }
+    static __device__ __forceinline__ F vmin(F x) { const float s = D::vmin(__builtin_fminf(x.a, x.b)); return F{s, s}; }
 };
 
 }  // namespace pbre

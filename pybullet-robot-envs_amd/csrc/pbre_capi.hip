@@ -611,6 +611,18 @@ int pbre_set_state(pbre_ctx* c, const float* s) {
     return PBRE_OK;
 }
 
+int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
+    if (!c || n < 0 || (n > 0 && (!dofs || !targets))) return PBRE_E_ARG;
+    if (c->wide) return wide_set_motors(c->wide, n, dofs, targets, kp, max_force, mask);
+    c->err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record";
+    return PBRE_E_UNSUPPORTED;
+}
+int pbre_apply_action(pbre_ctx* c, const float* actions) {
+    if (!c || !actions) return PBRE_E_ARG;
+    if (c->wide) return wide_apply_action(c->wide, actions);
+    c->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record";
+    return PBRE_E_UNSUPPORTED;
+}
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
     if (c->wide) return wide_get_physics(c->wide, phys);

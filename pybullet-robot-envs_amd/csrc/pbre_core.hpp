@@ -39,6 +39,22 @@ struct Core {
     using B = typename L::B;
     using Tables = TablesT<SH>;
     static constexpr int W = SH::W, NJ = SH::NJ, LC = SH::LC, L1 = SH::L1, NSUB = SH::NSUB, NLEV = SH::NLEV, STATE = SH::STATE;
+    static constexpr int NC_OT = SH::NC_OT, NC_RO = SH::NC_RO, NC_RT = SH::NC_RT, NC = SH::NC, NMW = SH::NMW, NTIP = SH::NTIP, TIP0 = SH::TIP0;
+    // values that only exist on robot lanes (rows of M^-1, the motor / limit row a lane owns) use the backend's robot-lane
+    // view: L itself, except for a backend that packs two virtual lanes into one physical lane (DevLanes128), where it is
+    // the plain 64-lane backend of the low half
+    using LR = typename L::Robot;
+    using FR = typename LR::F;
+    using IR = typename LR::I;
+    using BR = typename LR::B;
+    struct Mask { I w[NMW]; };         // ancestor / subtree bit mask of this lane, 32 joints per word
+    static PBRE_HD Mask loadmask(const int (*m)[W]) { Mask r; PBRE_UNROLL for (int k = 0; k < NMW; k++) r.w[k] = L::loadI(m[k]); return r; }
+    static PBRE_HD B mbit(const Mask& m, int i) { return L::bit(m.w[i >> 5], i & 31); }
+    static PBRE_HD B mbiti(const Mask& m, I k) {     // bit k of the mask, k a lane value in 0..NJ-1
+        B r = L::biti(m.w[0], k);
+        PBRE_UNROLL for (int w = 1; w < NMW; w++) r = L::bor(L::band(L::lti(k, 32 * w), r), L::band(L::gei(k, 32 * w), L::biti(m.w[w], k)));
+        return r;
+    }
 
     struct V3 { F x, y, z; };
     struct Q4 { F x, y, z, w; };
@@ -245,7 +261,7 @@ struct Core {
             B hit = L::band(L::band(cand, L::bnot(chosen)), L::eq(key, mn));
             hit = L::band(hit, L::lt(mn, L::c(1e38f)));
             // lowest lane among hits
-            F lk = L::sel(hit, L::itof(lane), L::c(99.f));
+            F lk = L::sel(hit, L::itof(lane), L::c(999.f));
             F lm = L::vmin(lk);
             chosen = L::bor(chosen, L::band(hit, L::eq(lk, lm)));
         }
@@ -267,10 +283,10 @@ struct Core {
     // fetch the contact whose rank == r from the candidate lanes (all fields become group-uniform)
     static PBRE_HD Contact fetch(I rank, int r, const V3& n, const V3& pA, const V3& pB, F dist, F mu, I owner, I lane) {
         B mine = L::eqi(rank, r);
-        F lk = L::sel(mine, L::itof(lane), L::c(99.f));
+        F lk = L::sel(mine, L::itof(lane), L::c(999.f));
         F lm = L::vmin(lk);
         Contact c;
-        c.act = L::lt(lm, L::c(98.f));
+        c.act = L::lt(lm, L::c(998.f));
         I src = L::ftoi(L::min(lm, L::c((float)(W - 1))));
         c.n = bcastvI(n, src); c.pA = bcastvI(pA, src); c.pB = bcastvI(pB, src);
         c.dist = L::gather(dist, src); c.mu = L::gather(mu, src);
@@ -284,11 +300,12 @@ struct Core {
            M_INNER = 32 };   // a non-final iteration of the apply_action loop (action_repeat > 1): termination test + counter, no outputs
 
     struct Rows {             // register-resident solver data
-        F Mi[NJ];             // row of M^-1 (lane k: Minv[k][j])
-        F m_dinv, m_rhs;      // motor row owned by this lane (rhs already multiplied by dinv)
-        F l_j, l_rhs;         // limit row owned by this lane: J' = dir*dinv (0 if inactive), rhs'
-        F l_dir;
-        F m_app, l_app;       // applied impulse of the motor / limit row this lane owns
+        FR Mi[NJ];            // row of M^-1 (lane k: Minv[k][j])
+        FR m_dinv, m_rhs;     // motor row owned by this lane (rhs already multiplied by dinv)
+        FR l_j, l_rhs;        // limit row owned by this lane: J' = dir*dinv (0 if inactive), rhs'
+        FR l_dir;
+        FR m_app, l_app;      // applied impulse of the motor / limit row this lane owns
+        FR m_lim;             // impulse bound of the motor row
         F Jn[NC], Bn[NC], an[NC];
         F J1[NC], B1[NC], a1[NC];
         F J2[NC], B2[NC], a2[NC];
@@ -329,6 +346,25 @@ struct Core {
         // ---- motor targets (apply_action): q_des = clip(q + 0.05 a, ll, ul) for actuated lanes, else hold at home
         F lower = L::load(T.lower), upper = L::load(T.upper);
         F qdes = L::load(T.home), kp = L::load(T.kp_hold), kd = L::load(T.kd_hold);
+        FR fscale = LR::c(1.f);
+        if (SH::MREC) {
+            // PyBullet's motors persist between calls: target | kp | force scale of every joint live in the env's motor record
+            // (written by apply_action below, by the IK kernel and by the finger commands open_hand / pre_grasp / grasp)
+            float* mrec = const_cast<float*>(tgt);
+            qdes = L::load(mrec); kp = L::load(mrec + W);
+            F fs = L::load(mrec + 2 * W);
+            if (mode & M_ACTION) {
+                // iCubEnv.apply_action, joint branch (icub_env.py:341-361): absolute targets clipped to the joint limits,
+                // positionGain 0.5, default force
+                I ai = L::loadI(T.act_idx);
+                B al = L::gei(ai, 0);
+                F a = L::loadx(act, ai, al);
+                qdes = L::sel(al, clampf(a, lower, upper), qdes);
+                kp = L::sel(al, L::load(T.kp_act), kp); fs = L::sel(al, one, fs);
+                L::store(mrec, qdes); L::store(mrec + W, kp); L::store(mrec + 2 * W, fs);
+            }
+            fscale = L::lo(fs);
+        } else {
         if (mode & M_TGT) qdes = L::loadm(tgt, robot);     // IK mode: targets from the IK buffer, hold gains
         if (mode & M_ACTION) {
             I ai = L::loadI(T.act_idx);
@@ -337,6 +373,7 @@ struct Core {
             F tgt = clampf(L::fma(a, L::c(P.act_scale), q), lower, upper);
             qdes = L::sel(al, tgt, qdes);
             kp = L::load(T.kp_act); kd = L::load(T.kd_act);
+        }
         }
 
         // ---- object pose/twist as group-uniform values
@@ -390,11 +427,11 @@ struct Core {
             cI[3] = cI[3] + L::fma(zero - m, c.x*c.y, Iw.m[1]); cI[4] = cI[4] + L::fma(zero - m, c.x*c.z, Iw.m[2]); cI[5] = cI[5] + L::fma(zero - m, c.y*c.z, Iw.m[5]);
         }
         // ---- subtree sums (bias force + composite inertia): broadcast loop with descendant masks
-        I dmask = L::loadI(T.dmask);
+        const Mask dmask = loadmask(T.dmask);
         Sp Fs; Fs.a = v3(zero, zero, zero); Fs.l = v3(zero, zero, zero);
         F Cm = zero; V3 Ch = v3(zero, zero, zero); F CI[6] = {zero, zero, zero, zero, zero, zero};
         PBRE_UNROLL for (int i = 0; i < NJ; i++) {
-            B in = L::bit(dmask, i);
+            B in = mbit(dmask, i);
             Fs.a = add(Fs.a, selv(in, bcastv(Fo.a, i), v3(zero, zero, zero)));
             Fs.l = add(Fs.l, selv(in, bcastv(Fo.l, i), v3(zero, zero, zero)));
             Cm = Cm + L::sel(in, L::bcast(cm, i), zero);
@@ -406,34 +443,44 @@ struct Core {
         // ---- CRBA: G = Ic S (own), H[row=lane][i]
         M3 Io; Io.m[0] = CI[0]; Io.m[1] = CI[3]; Io.m[2] = CI[4]; Io.m[3] = CI[3]; Io.m[4] = CI[1]; Io.m[5] = CI[5]; Io.m[6] = CI[4]; Io.m[7] = CI[5]; Io.m[8] = CI[2];
         Sp G; G.a = add(mv(Io, K.S.a), cross(Ch, K.S.l)); G.l = add(scl(K.S.l, Cm), cross(K.S.a, Ch));
-        I amask = L::loadI(T.amask);
+        const Mask amask = loadmask(T.amask);
+        const IR laneR = LR::lane();
+        const FR zeroR = LR::c(0.f), oneR = LR::c(1.f);
         Rows R;
         PBRE_UNROLL for (int i = 0; i < NJ; i++) {
             V3 Sa = bcastv(K.S.a, i), Sl = bcastv(K.S.l, i), Ga = bcastv(G.a, i), Gl = bcastv(G.l, i);
             F up = dot(Sa, G.a) + dot(Sl, G.l);            // i is an ancestor-or-self of this lane
             F dn = dot(K.S.a, Ga) + dot(K.S.l, Gl);        // this lane is an ancestor of i
-            R.Mi[i] = L::sel(L::bit(amask, i), up, L::sel(L::bit(dmask, i), dn, zero));
+            R.Mi[i] = L::lo(L::sel(mbit(amask, i), up, L::sel(mbit(dmask, i), dn, zero)));
         }
         // unused robot lanes (fewer than 9 DoF): unit diagonal keeps the inverse well defined
-        PBRE_UNROLL for (int i = 0; i < NJ; i++) R.Mi[i] = L::sel(L::band(L::eqi(lane, i), L::eqi(L::loadI(T.jtype), 0)), one, R.Mi[i]);
+        {
+            const BR nojoint = LR::eqi(LR::loadI(T.jtype), 0);
+            PBRE_UNROLL for (int i = 0; i < NJ; i++) R.Mi[i] = LR::sel(LR::band(LR::eqi(laneR, i), nojoint), oneR, R.Mi[i]);
+        }
 
         // ---- M^-1 by in-place Gauss-Jordan (SPD, no pivoting), one matrix row per lane
         PBRE_UNROLL for (int c = 0; c < NJ; c++) {
-            F pc = L::bcast(R.Mi[c], c);
-            F inv = one / pc;
-            B isc = L::eqi(lane, c);
-            F f = R.Mi[c];
+            FR pc = LR::bcast(R.Mi[c], c);
+            FR inv = oneR / pc;
+            BR isc = LR::eqi(laneR, c);
+            FR f = R.Mi[c];
             PBRE_UNROLL for (int k = 0; k < NJ; k++) {
                 if (k == c) continue;
-                F rc = L::bcast(R.Mi[k], c) * inv;
-                R.Mi[k] = L::sel(isc, rc, L::fma(zero - f, rc, R.Mi[k]));
+                FR rc = LR::bcast(R.Mi[k], c) * inv;
+                R.Mi[k] = LR::sel(isc, rc, LR::fma(zeroR - f, rc, R.Mi[k]));
             }
-            R.Mi[c] = L::sel(isc, inv, zero - f * inv);
+            R.Mi[c] = LR::sel(isc, inv, zeroR - f * inv);
         }
 
         // ---- unconstrained velocities v* (ABA equivalent): qdd = M^-1 tau
-        F qdd = zero;
-        PBRE_UNROLL for (int j = 0; j < NJ; j++) qdd = L::fma(R.Mi[j], L::bcast(tau, j), qdd);
+        F qdd;
+        {
+            const FR tauR = L::lo(tau);
+            FR acc = zeroR;
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) acc = LR::fma(R.Mi[j], LR::bcast(tauR, j), acc);
+            qdd = L::wide(acc);
+        }
         const F vmax = L::c(P.vmax);
         F vstar = clampf(L::fma(dt, qdd, qd), zero - vmax, vmax);
         // object: gravity, damping, gyroscopic torque
@@ -507,22 +554,24 @@ struct Core {
         // ---- constraint rows
         // motors (btMultiBodyJointMotor, POSITION_CONTROL): velocity error kp (q_des - q)/dt - kd v*
         {
-            F dinv = zero;
-            PBRE_UNROLL for (int j = 0; j < NJ; j++) dinv = L::sel(L::eqi(lane, j), one / R.Mi[j], dinv);
+            FR diag = oneR;                                 // this lane's diagonal entry of M^-1 (1 on lanes without a joint)
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) diag = LR::sel(LR::eqi(laneR, j), R.Mi[j], diag);
+            F dinv = L::wide(oneR / diag);
             B live = L::band(robot, L::nei(L::loadI(T.jtype), 0));
-            R.m_dinv = L::sel(live, dinv, zero);
-            R.m_rhs = L::sel(live, (kp * (qdes - q) * inv_dt - kd * vstar) * dinv, zero);
+            R.m_dinv = L::lo(L::sel(live, dinv, zero));
+            R.m_rhs = L::lo(L::sel(live, (kp * (qdes - q) * inv_dt - kd * vstar) * dinv, zero));
             // joint limits (btMultiBodyJointLimitConstraint): row exists only while violated
             F pl = q - lower, pu = upper - q;
             B lo_v = L::band(live, L::le(pl, zero)), up_v = L::band(live, L::band(L::bnot(lo_v), L::le(pu, zero)));
             F dir = L::sel(lo_v, one, L::sel(up_v, zero - one, zero));
             F pen = L::sel(lo_v, pl, pu);
-            R.l_dir = dir;
-            R.l_j = dir * dinv;                            // J' = dir * dinv (dir^2 = 1 so dinv is unchanged)
-            R.l_rhs = L::sel(L::bor(lo_v, up_v), (zero - pen * L::c(P.erp) * inv_dt - dir * vstar) * dinv, zero);
-            R.m_app = zero; R.l_app = zero;
+            R.l_dir = L::lo(dir);
+            R.l_j = L::lo(dir * dinv);                     // J' = dir * dinv (dir^2 = 1 so dinv is unchanged)
+            R.l_rhs = L::lo(L::sel(L::bor(lo_v, up_v), (zero - pen * L::c(P.erp) * inv_dt - dir * vstar) * dinv, zero));
+            R.m_app = zeroR; R.l_app = zeroR;
+            R.m_lim = LR::c(P.motor_imp) * fscale;         // setJointMotorControl `force` (default for every joint but grasping fingers)
         }
-        const B any_limit = L::ne(R.l_dir, zero);
+        const BR any_limit = LR::ne(R.l_dir, zeroR);
         // contacts
         const F inv_m = L::c(1.f / P.obj_m);
         PBRE_UNROLL for (int c = 0; c < NC; c++) {
@@ -543,7 +592,7 @@ struct Core {
                 V3 q2 = v3(zero - n.z * p2.y, n.z * p2.x, a2 * k2);
                 t1 = selv(big, p1, p2); t2 = selv(big, q1, q2);
             }
-            B onchain = L::band(robot, L::biti(L::gatherI(amask, cc.owner), lane));   // this joint moves the contact link
+            B onchain = L::band(robot, mbiti(dmask, cc.owner));   // this joint moves the contact link (the link is in its subtree)
             V3 rO = sub(type == 0 ? cc.pA : cc.pB, op);
             PBRE_UNROLL for (int d = 0; d < 3; d++) {
                 const V3& dir = d == 0 ? n : (d == 1 ? t1 : t2);
@@ -561,9 +610,10 @@ struct Core {
                 // B = M^-1 J^T
                 F Bv = zero;
                 if (type != 0) {
-                    F Br = zero;
-                    PBRE_UNROLL for (int j = 0; j < NJ; j++) Br = L::fma(R.Mi[j], L::bcast(J, j), Br);
-                    Bv = L::sel(robot, Br, zero);
+                    const FR JR = L::lo(J);
+                    FR Br = zeroR;
+                    PBRE_UNROLL for (int j = 0; j < NJ; j++) Br = LR::fma(R.Mi[j], LR::bcast(JR, j), Br);
+                    Bv = L::sel(robot, L::wide(Br), zero);
                 }
                 if (type != 2) {
                     V3 Ja = v3(L::bcast(J, LC + 3), L::bcast(J, LC + 4), L::bcast(J, LC + 5));
@@ -589,22 +639,23 @@ struct Core {
 
         // ---- projected Gauss-Seidel (Bullet order: non-contact rows alternate direction, normals, frictions)
         F dv = L::sel(L::eqi(lane, L1), one, zero);
-        const F mlim = L::c(P.motor_imp), llim = L::c(P.limit_imp), big = L::c(1e10f);
+        const F big = L::c(1e10f);
+        const FR llim = LR::c(P.limit_imp), nmlim = zeroR - R.m_lim;
         // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
         // applied (Gauss-Seidel order is kept by the sequence of calls)
         auto motor = [&](int j) {
-            F t = L::fma(R.m_dinv, dv, zero - R.m_rhs);
-            F s = L::med3(R.m_app - t, zero - mlim, mlim);
-            F d = s - R.m_app;
-            R.m_app = L::sel(L::eqi(lane, j), s, R.m_app);
-            dv = L::fma(L::bcast(d, j), R.Mi[j], dv);
+            FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
+            FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
+            FR d = s - R.m_app;
+            R.m_app = LR::sel(LR::eqi(laneR, j), s, R.m_app);
+            dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
         auto limit = [&](int j) {
-            F t = L::fma(R.l_j, dv, zero - R.l_rhs);
-            F s = L::med3(R.l_app - t, zero, llim);
-            F d = s - R.l_app;
-            R.l_app = L::sel(L::eqi(lane, j), s, R.l_app);
-            dv = L::fma(L::bcast(d * R.l_dir, j), R.Mi[j], dv);
+            FR t = LR::fma(R.l_j, L::lo(dv), zeroR - R.l_rhs);
+            FR s = LR::med3(R.l_app - t, zeroR, llim);
+            FR d = s - R.l_app;
+            R.l_app = LR::sel(LR::eqi(laneR, j), s, R.l_app);
+            dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);
         };
         auto contacts = [&]() {
             PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) row(R.Jn[c], R.Bn[c], R.an[c], zero, big, dv);
@@ -614,7 +665,7 @@ struct Core {
                 frow(R.J2[c], R.B2[c], R.a2[c], lim, dv);
             }
         };
-        const bool has_limit = L::any(any_limit);
+        const bool has_limit = LR::any(any_limit);
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
             PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
@@ -633,6 +684,32 @@ struct Core {
         F Vn = L::sel(dyn, vnew, Vr);
         B posl = obj_on ? L::lti(lane, LC + 3) : robot;
         F Qn = L::sel(posl, L::fma(dt, vnew, Qr), Qr);
+        if (NTIP > 0) {
+            // check_contact_fingertips / check_collision (icub_env_with_hands.py:246-318): per fingertip the mean normal force
+            // (applied impulse / dt, getContactPoints()[9]) of its contact points with the object, the number of tips in
+            // contact and the number of robot-object contact points; kept in the Q record behind the object pose
+            const I tip = L::loadI(T.tip_of);
+            F tf[NTIP > 0 ? NTIP : 1], tc[NTIP > 0 ? NTIP : 1];
+            PBRE_UNROLL for (int t = 0; t < NTIP; t++) { tf[t] = zero; tc[t] = zero; }
+            F nro = zero;
+            PBRE_UNROLL for (int c = NC_OT; c < NC_OT + NC_RO; c++) {
+                if (!obj_on || !L::any(R.act[c])) continue;
+                const I ts = L::gatherI(tip, C[c].owner);
+                const F f = R.an[c] * inv_dt;
+                nro = nro + L::sel(R.act[c], one, zero);
+                PBRE_UNROLL for (int t = 0; t < NTIP; t++) {
+                    const B is = L::band(R.act[c], L::eqi(ts, t));
+                    tf[t] = tf[t] + L::sel(is, f, zero); tc[t] = tc[t] + L::sel(is, one, zero);
+                }
+            }
+            F ntip = zero;
+            PBRE_UNROLL for (int t = 0; t < NTIP; t++) {
+                const B hit = L::gt(tc[t], zero);
+                ntip = ntip + L::sel(hit, one, zero);
+                Qn = L::sel(L::eqi(lane, TIP0 + t), L::sel(hit, tf[t] / L::max(tc[t], one), zero), Qn);
+            }
+            Qn = L::sel(L::eqi(lane, TIP0 + NTIP), ntip, L::sel(L::eqi(lane, TIP0 + NTIP + 1), nro, Qn));
+        }
         if (obj_on) {
             V3 wn = v3(L::bcast(vnew, LC + 3), L::bcast(vnew, LC + 4), L::bcast(vnew, LC + 5));
             F ang = norm(wn);
@@ -685,7 +762,7 @@ struct Core {
         o.er = quat_euler(qmul(qhi, qo));
         o.tg = v3(L::bcast(Xr, 0), L::bcast(Xr, 1), L::bcast(Xr, 2));
         // Panda: normalised EE velocity (panda_env.py:174-178); iCub: raw (icub_env.py:233-236)
-        o.vn = P.robot == 1 ? vee : v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
+        o.vn = P.robot >= 1 ? vee : v3(vee.x / L::c(0.04f), (vee.y - L::c(0.01f)) / L::c(0.07f), vee.z / L::c(0.03f));
         return o;
     }
     static PBRE_HD V3 selv3(B c, const V3& a, const V3& b) { return selv(c, a, b); }
@@ -730,7 +807,7 @@ struct Core {
                 B dn = L::bor(L::bor(succ, L::ne(term, zero)), L::gt(cnt, mx));
                 done = L::sel(dn, one, zero);
                 F base = P.task == 1 ? zero - d1 - d2 : zero - d1;
-                if (P.robot == 1) {
+                if (P.robot >= 1) {
                     // iCub (icub_reach_gym_env.py:318-330: the bonus is added; icub_push_gym_env.py:346-373: reward types 0 / 1)
                     if (P.task == 0) reward = base + L::sel(succ, L::c(1000.f) + (L::c(100.f) - d1 * L::c(80.f)), zero);
                     else {
@@ -757,7 +834,7 @@ struct Core {
                 L::fence();
                 F Q2 = L::load(st), V2 = L::load(st + W), X2 = L::loadm(st + 2 * W, L::lti(lane, 16));
                 const Obs o2 = geom(T, P, Q2, V2, X2);
-                if (P.robot == 1 && P.task >= 1) {      // icub_push_gym_env.py:124-127
+                if (P.robot >= 1 && P.task >= 1) {      // icub_push_gym_env.py:124-127
                     F e1 = norm(sub(o2.ee, o2.op)), e2 = norm(sub(o2.op, o2.tg));
                     F Xn2 = L::sel(L::eqi(lane, 12), e1, L::sel(L::eqi(lane, 13), e2, X2));
                     L::storem(st + 2 * W, Xn2, L::band(fin, L::lti(lane, 16)));
@@ -770,7 +847,9 @@ struct Core {
         if (out) {
             // row-major [obs | reward | done]; obs layout SURVEY Appendix C
             const int nd = T.n_obs_j;
-            const int od = 9 + nd + 12 + (P.task >= 1 ? 3 : 0);
+            const int od0 = 9 + nd + 12 + (P.task >= 1 ? 3 : 0);
+            const int od = od0 + (NTIP > 0 ? NTIP + 2 : 0);
+            if (NTIP > 0) L::storem(out + od0 - TIP0, Qn, L::band(L::gei(lane, TIP0), L::lti(lane, TIP0 + NTIP + 2)));   // fingertip forces, counts
             F head = L::sel(L::eqi(lane, 0), o.ee.x, L::sel(L::eqi(lane, 1), o.ee.y, L::sel(L::eqi(lane, 2), o.ee.z,
                      L::sel(L::eqi(lane, 3), o.eul.x, L::sel(L::eqi(lane, 4), o.eul.y, L::sel(L::eqi(lane, 5), o.eul.z,
                      L::sel(L::eqi(lane, 6), o.vn.x, L::sel(L::eqi(lane, 7), o.vn.y, o.vn.z))))))));
@@ -810,6 +889,15 @@ struct Core {
             const F ps = L::c(P.ik_ps), rs = L::c(P.ik_rs);
             pos = v3(L::fma(L::loadu(act), ps, L::bcast(Xr, 6)), L::fma(L::loadu(act + 1), ps, L::bcast(Xr, 7)), L::fma(L::loadu(act + 2), ps, L::bcast(Xr, 8)));
             eul = v3(L::bcast(Xr, 9), L::bcast(Xr, 10), L::bcast(Xr, 11));
+            if (P.ik_abs) {
+                // robot-level apply_action (icub_env.py:262-300): the action is the hand pose itself
+                pos = v3(L::loadu(act), L::loadu(act + 1), L::loadu(act + 2));
+                if (P.ctrl_ori) {
+                    eul.x = clampf(L::loadu(act + 3), L::c(P.eu_lim[0][0]), L::c(P.eu_lim[0][1]));
+                    eul.y = clampf(L::loadu(act + 4), L::c(P.eu_lim[1][0]), L::c(P.eu_lim[1][1]));
+                    eul.z = clampf(L::loadu(act + 5), L::c(P.eu_lim[2][0]), L::c(P.eu_lim[2][1]));
+                }
+            } else
             if (P.ctrl_ori) {
                 eul.x = clampf(L::fma(L::loadu(act + 3), rs, eul.x), L::c(P.eu_lim[0][0]), L::c(P.eu_lim[0][1]));
                 eul.y = clampf(L::fma(L::loadu(act + 4), rs, eul.y), L::c(P.eu_lim[1][0]), L::c(P.eu_lim[1][1]));
@@ -817,7 +905,7 @@ struct Core {
             }
         }
         V3 cp = pos;                      // the pose handed to the IK; at reset the stored pose stays the unclipped home pose
-        if (!reset || P.robot == 1) {     // pandaEnv.apply_action clips z only (panda_env.py:243-247); the task env / iCub clip x, y, z
+        if (!reset || P.robot != 0) {     // pandaEnv.apply_action clips z only (panda_env.py:243-247); the task env / iCub clip x, y, z
             cp.x = clampf(cp.x, L::c(P.rws[0][0]), L::c(P.rws[0][1]));
             cp.y = clampf(cp.y, L::c(P.rws[1][0]), L::c(P.rws[1][1]));
         }
@@ -832,7 +920,7 @@ struct Core {
         }
         const M3 Rt = quat_R(euler_quat(eul));
         const V3 tp = add(cp, mv(Rt, v3(L::c(P.ik_off[0]), L::c(P.ik_off[1]), L::c(P.ik_off[2]))));
-        const B chain = L::band(robot, L::biti(L::ci(T.ee_chain), lane));
+        const B chain = L::band(robot, L::nei(L::loadI(T.on_chain), 0));
         const int eo = T.ee_owner;
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = L::c(T.ee_R[k]);
         const F l2 = L::c(P.ik_l2);
@@ -880,8 +968,9 @@ struct Core {
         }
         // joints off the chain: the iCub sends them to their rest pose (icub_env.py:316-317), PyBullet returns the Panda's
         // current finger positions
-        F qdes = L::sel(chain, q, P.robot == 1 ? L::load(T.home) : q0);
+        F qdes = L::sel(chain, q, L::sel(L::nei(L::loadI(T.blocked), 0), L::load(T.home), q0));
         L::storem(tgt, qdes, robot);
+        if (SH::MREC) { L::store(tgt + W, L::load(T.kp_hold)); L::store(tgt + 2 * W, one); }   // setJointMotorControlArray(all joints, positionGains 0.2), icub_env.py:319-336
     }
 
     // ---------------------------------------------------------------- reset (initial state before the settle steps)

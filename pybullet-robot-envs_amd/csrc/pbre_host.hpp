@@ -29,7 +29,7 @@ inline void default_physics(pbre_physics& p) {
 }
 
 inline int default_config(pbre_config* c, int robot, int task) {
-    if (!c || (robot != PBRE_ROBOT_PANDA && robot != PBRE_ROBOT_ICUB) || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
+    if (!c || (robot != PBRE_ROBOT_PANDA && robot != PBRE_ROBOT_ICUB && robot != PBRE_ROBOT_ICUB_HANDS) || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
     std::memset(c, 0, sizeof *c);
     c->robot = robot; c->task = task; c->num_envs = 1; c->device_id = 0; c->seed = 1234;
     c->use_ik = 0; c->num_controlled_joints = 7; c->action_repeat = 1; c->max_steps = 1000;
@@ -51,16 +51,45 @@ inline int default_config(pbre_config* c, int robot, int task) {
     c->robot_ws[2][0] = task == PBRE_TASK_REACH ? c->h_table : c->h_table - 0.2; c->robot_ws[2][1] = 1.5;   // panda_reach_gym_env.py:69 / panda_push_gym_env.py:74
     const double PI = 3.14159265358979323846;
     c->control_orientation = 1; c->reward_type = 1; c->num_joints_ctrl = 7;
-    for (int k = 0; k < 16; k++) c->act_dof[k] = k < 7 ? k : -1;
+    for (int k = 0; k < 64; k++) c->act_dof[k] = k < 7 ? k : -1;
     c->ik_pos_scale = 0.005; c->ik_rot_scale = 0.01;                                // panda_push_gym_env.py:200-203
     for (int k = 0; k < 3; k++) { c->eu_lim[k][0] = -PI; c->eu_lim[k][1] = PI; }     // panda_env.py:38
+    if (robot == PBRE_ROBOT_ICUB_HANDS) {
+        // iCubHandsEnv defaults, left arm (icub_env_with_hands.py:51-83): robot-level interface, joint control.  DoF order of the
+        // simulated model (legs pruned): torso 0..2, left arm 3..9, left hand 10..29, neck 30..32, right arm 33..39, right hand 40..59
+        c->task = PBRE_TASK_REACH; c->use_ik = 0; c->control_orientation = 1; c->ik_absolute = 1;
+        c->max_steps = 1 << 30; c->target_dist_min = -1.0;                          // no episode logic at the robot level
+        c->num_controlled_joints = 37; c->num_joints_ctrl = 37;
+        {   // _joints_to_control (:123-141; `a or b and c` keeps both arms) in joint-index order: torso, left arm, left hand, right arm
+            int k = 0;
+            for (int d = 0; d < 30; d++) c->act_dof[k++] = d;
+            for (int d = 33; d < 40; d++) c->act_dof[k++] = d;
+            for (; k < 64; k++) c->act_dof[k] = -1;
+        }
+        for (int k = 0; k < 64; k++) c->home[k] = 0.0;
+        c->home[3] = -0.51; c->home[4] = 0.7; c->home[6] = 1.22; c->home[30] = 0.008; c->home[33] = -0.51; c->home[34] = 0.7; c->home[36] = 1.22;
+        c->ws_lim[0][0] = 0.35; c->ws_lim[0][1] = 0.70; c->ws_lim[1][0] = -0.33; c->ws_lim[1][1] = 0.27;   // object dropped at (0.5, -0.03) (helloworld_icub.py:51)
+        c->robot_ws[0][0] = 0.15; c->robot_ws[0][1] = 0.50; c->robot_ws[1][0] = -0.3; c->robot_ws[1][1] = 0.3; c->robot_ws[2][0] = 0.5; c->robot_ws[2][1] = 1.0;   // :63
+        const double hl[6] = {0.2, 0.3, 0.8, -PI, 0.0, -PI / 2};                    // :77
+        for (int k = 0; k < 6; k++) c->home_hand_pose[k] = hl[k];
+        c->eu_lim[0][0] = -1.5 * PI; c->eu_lim[0][1] = -PI / 2; c->eu_lim[1][0] = -PI / 2; c->eu_lim[1][1] = PI / 2; c->eu_lim[2][0] = 0.0; c->eu_lim[2][1] = -PI;   // :78
+        c->ik_pos_scale = 1.0; c->ik_rot_scale = 1.0;
+        c->ik_link_offset[0] = -0.011682; c->ik_link_offset[1] = 0.051355; c->ik_link_offset[2] = 0.000577;   // :163
+        c->phys.table_c[0] = 1.0;                                                   // table.urdf at (1, 0, 0) (helloworld_icub.py:50)
+        c->phys.obj_h[0] = 0.025; c->phys.obj_h[1] = 0.0375; c->phys.obj_h[2] = 0.025;   // foam-brick sized box (the YCB asset is not available)
+        c->phys.obj_mass = 0.028;
+        for (int k = 0; k < 3; k++) {
+            const double a = 2 * c->phys.obj_h[(k + 1) % 3], b = 2 * c->phys.obj_h[(k + 2) % 3];
+            c->phys.obj_inertia[k] = c->phys.obj_mass * (a * a + b * b) / 12.0;
+        }
+    }
     if (robot == PBRE_ROBOT_ICUB) {
         // iCub*GymEnv defaults, left arm (icub_env.py:52-82, icub_reach_gym_env.py:27-51, icub_push_gym_env.py:27-57);
         // the right arm differs in home_hand_pose, eu_lim[2], ik_link_offset and act_dof, which the caller sets
         c->use_ik = 1; c->control_orientation = 0; c->max_steps = 2000; c->target_dist_min = 0.03;
         c->num_controlled_joints = 10; c->num_joints_ctrl = 10;
-        for (int k = 0; k < 16; k++) c->act_dof[k] = k < 10 ? k : -1;                // torso 0..2, left arm 3..9 of the simulated model (legs pruned)
-        for (int k = 0; k < 40; k++) c->home[k] = 0.0;
+        for (int k = 0; k < 64; k++) c->act_dof[k] = k < 10 ? k : -1;                // torso 0..2, left arm 3..9 of the simulated model (legs pruned)
+        for (int k = 0; k < 64; k++) c->home[k] = 0.0;
         c->home[3] = -0.51; c->home[4] = 0.7; c->home[6] = 1.22;                     // l_shoulder_pitch, l_shoulder_roll, l_elbow
         c->home[13] = -0.51; c->home[14] = 0.7; c->home[16] = 1.22;                  // right arm
         c->home[10] = 0.008;                                                        // neck_pitch
@@ -98,13 +127,15 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     constexpr int NJ = S::NJ;
     if (c.num_envs <= 0) return "num_envs must be positive";
     if (c.action_repeat < 1 || c.action_repeat > 64) return "action_repeat out of range";
-    if (c.num_controlled_joints < 1 || c.num_controlled_joints > 16 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
-    int act_dof[16], n_ctrl = c.num_joints_ctrl;
-    for (int k = 0; k < 16; k++) act_dof[k] = c.act_dof[k];
-    if (c.robot == PBRE_ROBOT_PANDA) { n_ctrl = c.num_controlled_joints; for (int k = 0; k < 16; k++) act_dof[k] = k; }   // panda_env.py:293-310: the first n joints
-    if (n_ctrl < c.num_controlled_joints || n_ctrl > 16) return "num_joints_ctrl out of range";
+    if (c.num_controlled_joints < 1 || c.num_controlled_joints > 64 || c.num_controlled_joints > NJ) return "num_controlled_joints out of range";
+    int act_dof[64], n_ctrl = c.num_joints_ctrl;
+    for (int k = 0; k < 64; k++) act_dof[k] = c.act_dof[k];
+    if (c.robot == PBRE_ROBOT_PANDA) { n_ctrl = c.num_controlled_joints; for (int k = 0; k < 64; k++) act_dof[k] = k; }   // panda_env.py:293-310: the first n joints
+    if (n_ctrl < c.num_controlled_joints || n_ctrl > 64) return "num_joints_ctrl out of range";
     if (c.use_ik && (c.ik_max_iters <= 0 || c.ik_damping <= 0)) return "bad IK parameters";
-    if (c.robot != PBRE_ROBOT_PANDA && c.robot != PBRE_ROBOT_ICUB) return "unknown robot";
+    if (c.robot != PBRE_ROBOT_PANDA && c.robot != PBRE_ROBOT_ICUB && c.robot != PBRE_ROBOT_ICUB_HANDS) return "unknown robot";
+    if ((c.robot == PBRE_ROBOT_ICUB_HANDS) != S::MREC) return "the iCub-with-hands interface needs the 60-DoF model (and only that model uses it)";
+    if (S::MREC && (c.action_repeat != 1 || (c.flags & PBRE_F_AUTO_RESET))) return "iCub with hands: action_repeat / auto-reset are not part of the robot-level interface";
     const double gains[4] = {c.kp_act, c.kd_act, c.kp_hold, c.kd_hold};
     std::string e = build_tables<S>(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, act_dof, n_ctrl,
                                     c.robot == PBRE_ROBOT_PANDA, T);
@@ -129,7 +160,7 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     for (int k = 0; k < 6; k++) P.home_hand[k] = (float)c.home_hand_pose[k];
     for (int a = 0; a < 3; a++) for (int b = 0; b < 2; b++) P.rws[a][b] = (float)c.robot_ws[a][b];
     P.robot = c.robot; P.reward_type = c.reward_type; P.ctrl_ori = c.control_orientation ? 1 : 0;
-    P.ik_ps = (float)c.ik_pos_scale; P.ik_rs = (float)c.ik_rot_scale;
+    P.ik_ps = (float)c.ik_pos_scale; P.ik_rs = (float)c.ik_rot_scale; P.ik_abs = c.ik_absolute ? 1 : 0;
     for (int a = 0; a < 3; a++) { P.ik_off[a] = (float)c.ik_link_offset[a]; for (int b = 0; b < 2; b++) P.eu_lim[a][b] = (float)c.eu_lim[a][b]; }
     for (int k = 0; k < NJ; k++) P.rst_q[k] = T.home[k];
     P.rst_objz = (float)(c.h_table + p.obj_h[2]);      // refined from the settled state after the first full reset
@@ -138,7 +169,7 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
 
 inline int act_dim_of(const pbre_config& c) { return c.use_ik ? (c.control_orientation ? 6 : 3) : c.num_controlled_joints; }
 template <class S>
-inline int obs_dim_of(const TablesT<S>& T, const Params& P) { return 9 + T.n_obs_j + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0); }
+inline int obs_dim_of(const TablesT<S>& T, const Params& P) { return 9 + T.n_obs_j + 12 + (P.task != PBRE_TASK_REACH ? 3 : 0) + (S::NTIP ? S::NTIP + 2 : 0); }
 
 // Observation limits exactly as the reference assembles them (panda_env.py:141-193 limits list,
 // panda_push_gym_env.py:73-75 / panda_reach_gym_env.py:68-70 z-min, :177-185 extras).
@@ -148,7 +179,7 @@ inline void obs_limits(const pbre_config& c, const TablesT<S>& T, float* lo, flo
     const double PI = 3.14159265358979323846;
     int o = 0;
     auto put = [&](double a, double b) { lo[o] = (float)a; hi[o] = (float)b; o++; };
-    if (c.robot == PBRE_ROBOT_ICUB) {
+    if (c.robot != PBRE_ROBOT_PANDA) {
         for (int k = 0; k < 3; k++) put(c.robot_ws[k][0], c.robot_ws[k][1]);
         for (int k = 0; k < 3; k++) put(c.eu_lim[k][0], c.eu_lim[k][1]);
         for (int k = 0; k < 3; k++) put(-1, 1);
@@ -165,6 +196,7 @@ inline void obs_limits(const pbre_config& c, const TablesT<S>& T, float* lo, flo
     for (int k = 0; k < 3; k++) put(-0.5, 0.5);
     for (int k = 0; k < 3; k++) put(0, 2 * PI);
     if (c.task != PBRE_TASK_REACH) for (int k = 0; k < 3; k++) put(c.ws_lim[k][0], c.ws_lim[k][1]);
+    if (S::NTIP) { for (int k = 0; k < S::NTIP; k++) put(0, 100); put(0, S::NTIP); put(0, S::NC_RO); }   // fingertip forces (N), tips in contact, contact points
 }
 
 }  // namespace pbre

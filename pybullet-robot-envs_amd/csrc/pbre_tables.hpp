@@ -22,7 +22,7 @@ namespace pbre {
 // Lane layout of one env group.  Lanes 0..NJ-1 own the robot DoF, lanes LC..LC+2 / LC+3..LC+5 the object's linear /
 // angular velocity (Q record: LC..LC+2 position, LC+3..LC+6 quaternion), lane L1 is the constant-one lane that carries
 // -rhs of a contact row through the row dot product.  State record = Q[W] | V[W] | X[16] floats.
-template <int W_, int NJ_, int NSUB_, int NLEV_>
+template <int W_, int NJ_, int NSUB_, int NLEV_, int NC_RO_ = 2, int NTIP_ = 0>
 struct ShapeT {
     static constexpr int W = W_;          // lanes per env
     static constexpr int NJ = NJ_;        // robot DoF lanes
@@ -31,24 +31,32 @@ struct ShapeT {
     static constexpr int NSUB = NSUB_;    // rigid sub-bodies per lane
     static constexpr int NLEV = NLEV_;    // pointer-jumping levels (chains up to 2^NLEV deep)
     static constexpr int STATE = 2 * W_ + 16;
-    static_assert(NJ_ + 7 <= W_ && NJ_ <= 32, "lane budget");
+    static constexpr int NMW = (NJ_ + 31) / 32;            // 32-bit words of an ancestor / subtree mask
+    static constexpr int NC_OT = 4, NC_RO = NC_RO_, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;   // contact slots: object-table, robot-object, robot-table
+    static constexpr int NTIP = NTIP_;    // fingertips whose contact force is reported (iCub hands); such a shape also keeps a
+    static constexpr bool MREC = NTIP_ > 0;   // per-env motor record target[W] | kp[W] | force scale[W] (PyBullet's persistent motors)
+    static constexpr int TGT = MREC ? 3 * W_ : NJ_;        // floats per env of the motor-target buffer
+    static constexpr int TIP0 = NJ_ + 7;                   // Q lanes TIP0..TIP0+NTIP+1: tip forces, tips in contact, other robot-object contacts
+    static_assert(NJ_ + 7 + (NTIP_ ? NTIP_ + 2 : 0) <= W_ && NJ_ <= 64, "lane budget");
 };
 using Shape16 = ShapeT<16, 9, 3, 4>;      // Panda (<= 9 DoF): one env per 16-lane DPP row, 4 envs per wave
 using Shape32 = ShapeT<32, 20, 2, 4>;     // iCub as simulated (legs pruned, 20 DoF): one env per half-wave, 2 envs per wave
 using Shape64 = ShapeT<64, 32, 2, 4>;     // <= 32 DoF: one env per wave
+using Shape128 = ShapeT<128, 60, 2, 4, 6, 5>;   // iCub with hands (legs pruned, 60 DoF): one env per wave, two virtual lanes per physical lane
 
 // the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
 constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;
 constexpr int NC_OT = 4, NC_RO = 2, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;
 constexpr int STATE = Shape16::STATE;
-constexpr int MAXJ = 32;     // DoF bound of any shape
+constexpr int MAXJ = 64;     // DoF bound of any shape
 
 template <class S>
 struct TablesT {
     static constexpr int W = S::W, NJ = S::NJ, NSUB = S::NSUB, NLEV = S::NLEV;
     int   anc[NLEV][W];          // 2^l-th movable ancestor lane, -1 past the root
-    int   amask[W];              // bit i: lane i is an ancestor-or-self of this lane
-    int   dmask[W];              // bit i: lane i is in the subtree of this lane (incl. self)
+    static constexpr int NMW = S::NMW;
+    int   amask[NMW][W];         // bit i (word i / 32): lane i is an ancestor-or-self of this lane
+    int   dmask[NMW][W];         // bit i: lane i is in the subtree of this lane (incl. self)
     int   jtype[W];              // 0 none, 1 revolute, 2 prismatic
     float axis[3][W];
     float R0[9][W], p0[3][W];    // joint frame w.r.t. parent movable link frame at q = 0 (root: world)
@@ -63,7 +71,9 @@ struct TablesT {
     int   ee_owner;
     float ee_R[9], ee_p[3];      // EE (link COM frame) in the owner lane's link frame
     float ee_lp[3];              // EE link frame origin in the owner lane's link frame (IK target frame)
-    int   ee_chain;              // bit l: lane l is on the chain base -> end effector (joints the IK moves)
+    int   on_chain[W];           // 1: this lane's joint is on the chain base -> end effector (joints the IK moves)
+    int   blocked[W];            // 1: a joint the robot env does not control: the IK branch sends it to its rest pose (icub_env.py:316-317)
+    int   tip_of[W];             // fingertip slot (0..NTIP-1) of the link this lane owns, -1 otherwise
     int   ndof, n_act, n_obs_j, nspheres;
 };
 using Tables = TablesT<Shape16>;
@@ -84,6 +94,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     float ik_l2, ik_res, home_hand[6], rws[3][2];   // lambda^2, position residual, home hand pose, robot workspace
     int   robot, reward_type, ctrl_ori;             // PBRE_ROBOT_*; iCub push reward variant; IK mode: orientation part of the action
     float ik_ps, ik_rs, eu_lim[3][2], ik_off[3];    // action scales, Euler limits, hand COM frame -> link frame offset
+    int   ik_abs;                                   // IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-330) instead of scaled increments
 };
 
 namespace detail {
@@ -112,7 +123,7 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
     const int nl = (int)t[2], ndof = (int)t[3], ee = (int)t[4], ns = (int)t[5];
     if (n < (size_t)(24 + nl * 40 + ns * 8)) return "robot_table: truncated";
     if (ndof > NJ) return "robot_table: more DoF than robot lanes of this kernel shape";
-    if (ns > 16) return "robot_table: more than 16 collision spheres";
+    if (ns > (W >= 64 ? 64 : 16)) return "robot_table: too many collision spheres";
     if ((int)t[18] != 1) return "robot_table: floating-base robots are not supported by this kernel";
     if (ee < 0 || ee >= nl) return "robot_table: ee_link out of range";
     auto L = [&](int i) { return t + 24 + i * 40; };
@@ -174,14 +185,14 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
     }
     // ancestor tables
     for (int v = 1; v < NLEV; v++) for (int l = 0; l < NJ; l++) { int a = T.anc[v-1][l]; T.anc[v][l] = a < 0 ? -1 : T.anc[v-1][a]; }
-    for (int l = 0; l < NJ; l++) { if (!T.jtype[l]) continue; for (int a = l; a >= 0; a = T.anc[0][a]) T.amask[l] |= (int)(1u << a); }
-    for (int l = 0; l < NJ; l++) for (int i = 0; i < NJ; i++) if (T.jtype[i] && ((unsigned)T.amask[i] >> l & 1u)) T.dmask[l] |= (int)(1u << i);
+    for (int l = 0; l < NJ; l++) { if (!T.jtype[l]) continue; for (int a = l; a >= 0; a = T.anc[0][a]) T.amask[a >> 5][l] |= (int)(1u << (a & 31)); }
+    for (int l = 0; l < NJ; l++) for (int i = 0; i < NJ; i++) if (T.jtype[i] && ((unsigned)T.amask[l >> 5][i] >> (l & 31) & 1u)) T.dmask[i >> 5][l] |= (int)(1u << (i & 31));
     for (int l = 0; l < NJ; l++) {           // NLEV doubling steps accumulate over self + (2^NLEV - 1) ancestors
         int depth = 0;
         for (int a = T.anc[0][l]; a >= 0; a = T.anc[0][a]) depth++;
         if (T.jtype[l] && depth > (1 << NLEV) - 1) return "robot_table: chain deeper than the pointer-jumping levels cover";
     }
-    for (int l = 0; l < W; l++) { T.act_idx[l] = -1; T.obs_idx[l] = -1; }
+    for (int l = 0; l < W; l++) { T.act_idx[l] = -1; T.obs_idx[l] = -1; T.tip_of[l] = -1; }
     if (n_act > n_ctrl) return "more action joints than controlled joints";
     for (int k = 0; k < n_ctrl; k++) {
         const int d = act_dof[k];
@@ -190,6 +201,7 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         T.obs_idx[d] = k;
     }
     T.n_obs_j = n_ctrl;
+    for (int l = 0; l < ndof; l++) T.blocked[l] = !observe_all && T.obs_idx[l] < 0;
     if (observe_all) { for (int l = 0; l < ndof; l++) T.obs_idx[l] = l; T.n_obs_j = ndof; }
     for (int l = 0; l < ndof; l++) {
         T.home[l] = (float)home[l]; T.rst_q[l] = (float)home[l];
@@ -206,7 +218,7 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         for (int k = 0; k < 9; k++) T.ee_R[k] = (float)F.R[k];
         for (int a = 0; a < 3; a++) T.ee_p[a] = (float)(F.p[a] + F.R[a*3] * r[18] + F.R[a*3+1] * r[19] + F.R[a*3+2] * r[20]);
         for (int a = 0; a < 3; a++) T.ee_lp[a] = (float)F.p[a];
-        T.ee_chain = T.amask[T.ee_owner];
+        for (int l = 0; l < NJ; l++) T.on_chain[l] = (int)((unsigned)T.amask[l >> 5][T.ee_owner] >> (l & 31) & 1u);
     }
     for (int s = 0; s < ns; s++) {
         const double* r = t + 24 + nl * 40 + s * 8;
@@ -216,6 +228,10 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         T.s_owner[s] = lane_of[owner[li]]; T.s_valid[s] = 1;
         for (int a = 0; a < 3; a++) T.s_c[a][s] = (float)(F.p[a] + F.R[a*3] * r[1] + F.R[a*3+1] * r[2] + F.R[a*3+2] * r[3]);
         T.s_r[s] = (float)r[4]; T.s_mu[s] = (float)r[5];
+        if ((int)r[6] > 0) {               // fingertip sphere: slot + 1
+            if ((int)r[6] > S::NTIP) return "robot_table: more fingertips than this kernel shape reports";
+            T.tip_of[T.s_owner[s]] = (int)r[6] - 1;
+        }
     }
     T.ndof = ndof; T.n_act = n_act; T.nspheres = ns;
     return "";

@@ -15,60 +15,10 @@
 #include <string>
 #include <vector>
 
-#define PBRE_HD __device__ __forceinline__
-#define PBRE_UNROLL _Pragma("unroll")
-#include "pbre_host.hpp"
-#include "lanes_device.hpp"
-#include "pbre_core.hpp"
-#include "pbre_wide.hpp"
+#include "pbre_wide_impl.hpp"
 
 namespace pbre {
 
-constexpr int WTPB = 256;                        // 4 independent waves per block
-
-template <class S, class L, int MODE>
-__global__ __launch_bounds__(WTPB, 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
-                                                   int flags, const float* __restrict__ tgt) {
-    using C = Core<L, S>;
-    constexpr int EPB = WTPB / S::W;
-    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
-    if (env >= n) return;                           // whole lane group; a partially filled wave keeps running its other group
-    C::step(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-            (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, (MODE & C::M_TGT) ? tgt + (size_t)env * S::NJ : nullptr,
-            P.env_id_base + (unsigned long long)env);
-}
-template <class S, class L, bool RESET>
-__global__ __launch_bounds__(WTPB) void kw_ik(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
-                                              const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
-    constexpr int EPB = WTPB / S::W;
-    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
-    if (env >= n) return;
-    Core<L, S>::ik_targets(*T, P, state + (size_t)env * S::STATE, RESET ? nullptr : actions + (size_t)env * act_dim, tgt + (size_t)env * S::NJ, RESET);
-}
-template <class S, class L, int MODE>
-__global__ __launch_bounds__(WTPB) void kw_observe(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   float* __restrict__ out, int n, int ow) {
-    using C = Core<L, S>;
-    constexpr int EPB = WTPB / S::W;
-    const int env = blockIdx.x * EPB + (int)(threadIdx.x / S::W);
-    if (env >= n) return;
-    float* st = state + (size_t)env * S::STATE;
-    float Q = L::load(st), V = L::load(st + S::W), X = L::loadm(st + 2 * S::W, L::lane() < 16);
-    C::observe(*T, P, st, Q, V, X, (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE);
-}
-template <class S, class L>
-__global__ void kw_init(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
-                        const unsigned long long* __restrict__ ids, const unsigned* __restrict__ ep, int cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) Core<L, S>::init_state(*T, P, ids[i], ep[i], state + (size_t)i * S::STATE);
-}
-template <class S, class L>
-__global__ void kw_target(const Params P, float* __restrict__ state, const unsigned long long* __restrict__ ids,
-                          const unsigned* __restrict__ ep, int cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) Core<L, S>::sample_target(P, ids[i], ep[i], state + (size_t)i * S::STATE);
-}
 __global__ void kw_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, unsigned* __restrict__ ep, int sf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) ep[i] = (unsigned)((int)state[(size_t)idx[i] * sf + (sf - 16) + 5] + 1);
@@ -78,94 +28,6 @@ __global__ void kw_scatter(float* __restrict__ dst, const float* __restrict__ sr
     const int i = t / sf, k = t % sf;
     if (i < cnt) dst[(size_t)idx[i] * sf + k] = src[(size_t)i * sf + k];
 }
-
-// shape-independent part of an engine + the launches that depend on the lane-group shape
-struct WideEngine {
-    pbre_config cfg;
-    Params P;
-    int n = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0, sf = 0, nj = 0, lc = 0;
-    float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
-    float *d_act = nullptr, *d_out = nullptr;
-    unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    static constexpr int KRING = 64;
-    hipEvent_t ev_k[KRING][2] = {};
-    long k_steps = 0;
-    double ms[3] = {0, 0, 0};
-    std::string err;
-    enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT, K_INNER_ACT, K_INNER_TGT };
-    virtual ~WideEngine() {}
-    virtual std::string tables(const pbre_config& c) = 0;
-    virtual hipError_t upload_tables() = 0;
-    virtual void free_tables() = 0;
-    virtual void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) = 0;
-    virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) = 0;
-    virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
-    virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
-    virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
-    virtual void snapshot(const float* rec) = 0;
-    virtual void limits(float* lo, float* hi) const = 0;
-    virtual int vgprs() const = 0;
-};
-
-template <class S, class L>
-struct WideImpl : WideEngine {
-    using C = Core<L, S>;
-    static constexpr int EPB = WTPB / S::W;
-    TablesT<S> T;
-    TablesT<S>* dT = nullptr;
-    static int blocks_of(int cnt) { return (cnt + EPB - 1) / EPB; }
-    std::string tables(const pbre_config& c) override {
-        std::string e = make_tables<S>(c, T, P);
-        if (e.empty()) { obs_dim = obs_dim_of(T, P); sf = S::STATE; nj = S::NJ; lc = S::LC; }
-        return e;
-    }
-    hipError_t upload_tables() override {
-        if (!dT) { hipError_t e = hipMalloc(&dT, sizeof(TablesT<S>)); if (e != hipSuccess) return e; }
-        return hipMemcpy(dT, &T, sizeof(TablesT<S>), hipMemcpyHostToDevice);
-    }
-    void free_tables() override { if (dT) (void)hipFree(dT); dT = nullptr; }
-    template <int MODE>
-    void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
-        hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg);
-    }
-    void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) override {
-        constexpr int OT = C::M_OBS | C::M_TASK;
-        switch (kind) {
-            case K_SETTLE: step_t<0>(st, tg, cnt, act, out, flags, s); break;
-            case K_SETTLE_TGT: step_t<C::M_TGT>(st, tg, cnt, act, out, flags, s); break;
-            case K_STEP_ACT: step_t<C::M_ACTION | OT>(st, tg, cnt, act, out, flags, s); break;
-            case K_INNER_ACT: step_t<C::M_ACTION | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
-            case K_INNER_TGT: step_t<C::M_TGT | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
-            default: step_t<C::M_TGT | OT>(st, tg, cnt, act, out, flags, s); break;
-        }
-    }
-    void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) override {
-        if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
-        else hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
-    }
-    void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) override {
-        if (initd) hipLaunchKernelGGL((kw_observe<S, L, C::M_INITD>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
-        else hipLaunchKernelGGL((kw_observe<S, L, C::M_OBS>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
-    }
-    void launch_init(float* st, int cnt, hipStream_t s) override {
-        hipLaunchKernelGGL((kw_init<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, dT, P, st, d_ids, d_ep, cnt);
-    }
-    void launch_target(float* st, int cnt, hipStream_t s) override {
-        hipLaunchKernelGGL((kw_target<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, P, st, d_ids, d_ep, cnt);
-    }
-    void snapshot(const float* rec) override {
-        for (int k = 0; k < S::NJ; k++) { T.rst_q[k] = rec[k]; P.rst_q[k] = rec[k]; }
-        P.rst_objz = rec[S::LC + 2];
-    }
-    void limits(float* lo, float* hi) const override { obs_limits(cfg, T, lo, hi); }
-    int vgprs() const override {
-        hipFuncAttributes fa;
-        constexpr int M = C::M_ACTION | C::M_OBS | C::M_TASK;
-        return hipFuncGetAttributes(&fa, (const void*)kw_step<S, L, M>) == hipSuccess ? fa.numRegs : -1;
-    }
-};
 
 #define WCHK(call)                                                                  \
     do {                                                                            \
@@ -185,7 +47,7 @@ static hipError_t wstep(WideEngine* w, int kind, float* st, float* tg, int cnt, 
 }
 static hipError_t wsettle(WideEngine* w, float* st, float* tg, int cnt, int count, int flags, hipStream_t s) {
     for (int i = 0; i < count; i++) {
-        hipError_t e = wstep(w, w->P.use_ik ? WideEngine::K_SETTLE_TGT : WideEngine::K_SETTLE, st, tg, cnt, nullptr, nullptr, flags, s);
+        hipError_t e = wstep(w, (w->P.use_ik || w->mrec) ? WideEngine::K_SETTLE_TGT : WideEngine::K_SETTLE, st, tg, cnt, nullptr, nullptr, flags, s);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -217,7 +79,7 @@ void wide_destroy(WideEngine* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     w->free_tables();
     for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
-                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx})
+                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : w->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
@@ -226,8 +88,10 @@ void wide_destroy(WideEngine* w) {
 }
 
 int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
-    WideEngine* w = table_ndof(*cfg) <= Shape32::NJ ? static_cast<WideEngine*>(new WideImpl<Shape32, DevLanes32>())
-                                                    : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>());
+    const int nd = table_ndof(*cfg);
+    WideEngine* w = nd > Shape64::NJ ? make_hands_engine()
+                  : (nd <= Shape32::NJ ? static_cast<WideEngine*>(new WideImpl<Shape32, DevLanes32>())
+                                       : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>()));
     w->cfg = *cfg;
     std::string e = w->tables(*cfg);
     if (!e.empty()) {
@@ -245,7 +109,7 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     CK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     for (auto& ev : w->ev) CK(hipEventCreate(&ev));
     for (auto& pr : w->ev_k) for (auto& ev : pr) CK(hipEventCreate(&ev));
-    const size_t n = (size_t)w->n, sf = (size_t)w->sf, nj = (size_t)w->nj;
+    const size_t n = (size_t)w->n, sf = (size_t)w->sf, nj = (size_t)w->tgs;
     CK(w->upload_tables());
     CK(hipMalloc(&w->state, n * sf * sizeof(float)));
     CK(hipMalloc(&w->tmp, n * sf * sizeof(float)));
@@ -264,6 +128,7 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
         CK(hipMemcpy(w->d_ep, ep.data(), n * 4, hipMemcpyHostToDevice));
         w->launch_init(w->state, w->n, w->stream);
         w->launch_init(w->tmp, w->n, w->stream);
+        w->launch_mrec_init(w->tgt, w->n, w->stream);
         CK(hipGetLastError());
         CK(hipStreamSynchronize(w->stream));
     }
@@ -317,6 +182,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
         float* tg = full ? w->tgt : w->tgt_tmp;
         const int f0 = w->cfg.flags & PBRE_F_NO_OBJECT;
         w->launch_init(st, cnt, s);
+        w->launch_mrec_init(tg, cnt, s);
         WCHK(hipGetLastError());
         // iCubEnv.reset (icub_env.py:88-151): joints at their initial positions, IK targets of the home hand pose when
         // use_IK, one stepSimulation; then reset_simulation (icub_reach_gym_env.py:135-148): 100 steps robot alone,
@@ -325,7 +191,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
             w->launch_ik(true, st, nullptr, tg, cnt, s);
             WCHK(hipGetLastError());
         }
-        WCHK(wsettle(w, st, tg, cnt, (w->P.use_ik || w->P.robot == PBRE_ROBOT_ICUB ? 1 : 0) + 100, PBRE_F_NO_OBJECT, s));
+        WCHK(wsettle(w, st, tg, cnt, (w->P.use_ik || w->P.robot != PBRE_ROBOT_PANDA ? 1 : 0) + 100, PBRE_F_NO_OBJECT, s));
         WCHK(wsettle(w, st, tg, cnt, 101, f0, s));
         w->launch_target(st, cnt, s);
         WCHK(hipGetLastError());
@@ -336,6 +202,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
         if (!full) {
             // the IK targets of the reset envs are only needed while settling; the next step recomputes them
             hipLaunchKernelGGL(kw_scatter, dim3((cnt * w->sf + 255) / 256), dim3(256), 0, s, w->state, st, w->d_idx, cnt, w->sf);
+            if (w->mrec) hipLaunchKernelGGL(kw_scatter, dim3((cnt * w->tgs + 255) / 256), dim3(256), 0, s, w->tgt, tg, w->d_idx, cnt, w->tgs);   // motors persist
             WCHK(hipGetLastError());
         }
         WCHK(hipStreamSynchronize(s));
@@ -378,6 +245,38 @@ int wide_set_state(WideEngine* w, const float* s) {
     WCHK(hipSetDevice(w->device));
     WCHK(hipStreamSynchronize(w->stream));
     WCHK(hipMemcpy(w->state, s, (size_t)w->n * w->sf * 4, hipMemcpyHostToDevice));
+    return PBRE_OK;
+}
+int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
+    if (!w->mrec) { w->err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    if (cnt > 64) { w->err = "pbre_set_motors: more than 64 joints"; return PBRE_E_ARG; }
+    MotorCmd cmd;
+    cmd.n = cnt; cmd.kp = (float)kp;
+    cmd.fscale = max_force > 0 ? (float)(max_force * w->cfg.phys.dt / w->cfg.phys.max_motor_impulse) : 1.f;
+    for (int k = 0; k < cnt; k++) {
+        if (dofs[k] < 0 || dofs[k] >= w->ndof()) { w->err = "pbre_set_motors: bad DoF index"; return PBRE_E_ARG; }
+        cmd.dof[k] = dofs[k]; cmd.target[k] = targets[k];
+    }
+    if (cnt == 0) return PBRE_OK;
+    WCHK(hipSetDevice(w->device));
+    if (mask) {
+        if (!w->d_mask) WCHK(hipMalloc(&w->d_mask, (size_t)w->n));
+        WCHK(hipMemcpyAsync(w->d_mask, mask, (size_t)w->n, hipMemcpyHostToDevice, w->stream));
+    }
+    w->launch_set_motors(cmd, mask ? w->d_mask : nullptr, w->stream);
+    WCHK(hipGetLastError());
+    WCHK(hipStreamSynchronize(w->stream));
+    return PBRE_OK;
+}
+int wide_apply_action(WideEngine* w, const float* actions) {
+    if (!w->mrec) { w->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    WCHK(hipSetDevice(w->device));
+    hipStream_t s = w->stream;
+    WCHK(hipMemcpyAsync(w->d_act, actions, (size_t)w->n * w->act_dim * 4, hipMemcpyHostToDevice, s));
+    if (w->P.use_ik) w->launch_ik(false, w->state, w->d_act, w->tgt, w->n, s);
+    else w->launch_cmd_joints(w->d_act, s);
+    WCHK(hipGetLastError());
+    WCHK(hipStreamSynchronize(s));
     return PBRE_OK;
 }
 int wide_get_physics(const WideEngine* w, pbre_physics* p) { *p = w->cfg.phys; return PBRE_OK; }

@@ -1,0 +1,200 @@
+// pbre_wide_impl.hpp -- kernels and the shape-specific half of the wide lane-group engine (pbre_wide.hip), as templates over
+// the lane-group shape S and the lane backend L.  Included by the translation units that instantiate them: pbre_wide.hip
+// (Shape32 / Shape64) and pbre_hands.hip (Shape128, the iCub with hands).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+
+#define PBRE_HD __device__ __forceinline__
+#define PBRE_UNROLL _Pragma("unroll")
+#include "pbre_host.hpp"
+#include "lanes_device.hpp"
+#include "pbre_core.hpp"
+#include "pbre_wide.hpp"
+
+namespace pbre {
+
+constexpr int WTPB = 256;                        // 4 independent waves per block
+template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }   // physical lanes of one env group (Shape128: two virtual lanes each)
+struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };     // pbre_set_motors, by value
+
+template <class S, class L, int MODE>
+__global__ __launch_bounds__(WTPB, S::W > 64 ? 1 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                   const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
+                                                   int flags, const float* __restrict__ tgt) {
+    using C = Core<L, S>;
+    constexpr int EPB = WTPB / phys_lanes<S>();
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
+    if (env >= n) return;                           // whole lane group; a partially filled wave keeps running its other group
+    C::step(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+            (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, ((MODE & C::M_TGT) || S::MREC) ? tgt + (size_t)env * S::TGT : nullptr,
+            P.env_id_base + (unsigned long long)env);
+}
+template <class S, class L, bool RESET>
+__global__ __launch_bounds__(WTPB) void kw_ik(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+                                              const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
+    constexpr int EPB = WTPB / phys_lanes<S>();
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
+    if (env >= n) return;
+    Core<L, S>::ik_targets(*T, P, state + (size_t)env * S::STATE, RESET ? nullptr : actions + (size_t)env * act_dim, tgt + (size_t)env * S::TGT, RESET);
+}
+template <class S, class L, int MODE>
+__global__ __launch_bounds__(WTPB) void kw_observe(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                   float* __restrict__ out, int n, int ow) {
+    using C = Core<L, S>;
+    constexpr int EPB = WTPB / phys_lanes<S>();
+    const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
+    if (env >= n) return;
+    float* st = state + (size_t)env * S::STATE;
+    const auto Q = L::load(st), V = L::load(st + S::W), X = L::loadm(st + 2 * S::W, L::lti(L::lane(), 16));
+    C::observe(*T, P, st, Q, V, X, (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE);
+}
+template <class S, class L>
+__global__ void kw_init(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+                        const unsigned long long* __restrict__ ids, const unsigned* __restrict__ ep, int cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) Core<L, S>::init_state(*T, P, ids[i], ep[i], state + (size_t)i * S::STATE);
+}
+// motor record of a freshly reset env (iCubHandsEnv.reset, icub_env_with_hands.py:108-121): initial positions, gain 0.2, default force
+template <class S>
+__global__ void kw_mrec_init(const TablesT<S>* __restrict__ T, float* __restrict__ tgt, int cnt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t / S::W, l = t % S::W;
+    if (i >= cnt) return;
+    float* m = tgt + (size_t)i * S::TGT;
+    m[l] = T->home[l]; m[S::W + l] = T->kp_hold[l]; m[2 * S::W + l] = 1.f;
+}
+// joint-control half of apply_action without the simulation step (icub_env.py:341-361): clipped absolute targets, gain 0.5, default force
+template <class S>
+__global__ void kw_cmd_joints(const TablesT<S>* __restrict__ T, float* __restrict__ tgt, const float* __restrict__ actions, int n, int act_dim) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / 64, l = t % 64;
+    if (e >= n) return;
+    const int k = T->act_idx[l];
+    if (k < 0) return;
+    float* m = tgt + (size_t)e * S::TGT;
+    m[l] = fminf(fmaxf(actions[(size_t)e * act_dim + k], T->lower[l]), T->upper[l]); m[S::W + l] = T->kp_act[l]; m[2 * S::W + l] = 1.f;
+}
+template <class S>
+__global__ void kw_set_motors(float* __restrict__ tgt, int n, const MotorCmd cmd, const unsigned char* __restrict__ mask) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / 64, k = t % 64;
+    if (e >= n || k >= cmd.n || (mask && !mask[e])) return;
+    float* m = tgt + (size_t)e * S::TGT;
+    m[cmd.dof[k]] = cmd.target[k]; m[S::W + cmd.dof[k]] = cmd.kp; m[2 * S::W + cmd.dof[k]] = cmd.fscale;
+}
+template <class S, class L>
+__global__ void kw_target(const Params P, float* __restrict__ state, const unsigned long long* __restrict__ ids,
+                          const unsigned* __restrict__ ep, int cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) Core<L, S>::sample_target(P, ids[i], ep[i], state + (size_t)i * S::STATE);
+}
+// shape-independent part of an engine + the launches that depend on the lane-group shape
+struct WideEngine {
+    pbre_config cfg;
+    Params P;
+    int n = 0, obs_dim = 0, act_dim = 0, ow = 0, device = 0, sf = 0, nj = 0, lc = 0, tgs = 0;   // tgs: floats per env of the motor-target buffer
+    bool mrec = false;                        // the shape keeps persistent motor records (iCub with hands)
+    unsigned char* d_mask = nullptr;
+    float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
+    float *d_act = nullptr, *d_out = nullptr;
+    unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int KRING = 64;
+    hipEvent_t ev_k[KRING][2] = {};
+    long k_steps = 0;
+    double ms[3] = {0, 0, 0};
+    std::string err;
+    enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT, K_INNER_ACT, K_INNER_TGT };
+    virtual ~WideEngine() {}
+    virtual std::string tables(const pbre_config& c) = 0;
+    virtual hipError_t upload_tables() = 0;
+    virtual void free_tables() = 0;
+    virtual void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) = 0;
+    virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) = 0;
+    virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
+    virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
+    virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
+    virtual void launch_mrec_init(float* tg, int cnt, hipStream_t s) = 0;
+    virtual void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) = 0;
+    virtual void launch_cmd_joints(const float* act, hipStream_t s) = 0;
+    virtual int ndof() const = 0;
+    virtual void snapshot(const float* rec) = 0;
+    virtual void limits(float* lo, float* hi) const = 0;
+    virtual int vgprs() const = 0;
+};
+
+template <class S, class L>
+struct WideImpl : WideEngine {
+    using C = Core<L, S>;
+    static constexpr int EPB = WTPB / phys_lanes<S>();
+    TablesT<S> T;
+    TablesT<S>* dT = nullptr;
+    static int blocks_of(int cnt) { return (cnt + EPB - 1) / EPB; }
+    std::string tables(const pbre_config& c) override {
+        std::string e = make_tables<S>(c, T, P);
+        if (e.empty()) { obs_dim = obs_dim_of(T, P); sf = S::STATE; nj = S::NJ; lc = S::LC; tgs = S::TGT; mrec = S::MREC; }
+        return e;
+    }
+    hipError_t upload_tables() override {
+        if (!dT) { hipError_t e = hipMalloc(&dT, sizeof(TablesT<S>)); if (e != hipSuccess) return e; }
+        return hipMemcpy(dT, &T, sizeof(TablesT<S>), hipMemcpyHostToDevice);
+    }
+    void free_tables() override { if (dT) (void)hipFree(dT); dT = nullptr; }
+    template <int MODE>
+    void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
+        hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg);
+    }
+    void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) override {
+        constexpr int OT = C::M_OBS | C::M_TASK;
+        if (S::MREC && kind == K_SETTLE) kind = K_SETTLE_TGT;      // the motor record is always the source of the targets
+        switch (kind) {
+            case K_SETTLE: step_t<0>(st, tg, cnt, act, out, flags, s); break;
+            case K_SETTLE_TGT: step_t<C::M_TGT>(st, tg, cnt, act, out, flags, s); break;
+            case K_STEP_ACT: step_t<C::M_ACTION | OT>(st, tg, cnt, act, out, flags, s); break;
+            case K_INNER_ACT: step_t<C::M_ACTION | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
+            case K_INNER_TGT: step_t<C::M_TGT | C::M_TASK | C::M_INNER>(st, tg, cnt, act, out, flags, s); break;
+            default: step_t<C::M_TGT | OT>(st, tg, cnt, act, out, flags, s); break;
+        }
+    }
+    void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) override {
+        if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
+        else hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
+    }
+    void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) override {
+        if (initd) hipLaunchKernelGGL((kw_observe<S, L, C::M_INITD>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
+        else hipLaunchKernelGGL((kw_observe<S, L, C::M_OBS>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
+    }
+    void launch_init(float* st, int cnt, hipStream_t s) override {
+        hipLaunchKernelGGL((kw_init<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, dT, P, st, d_ids, d_ep, cnt);
+    }
+    void launch_target(float* st, int cnt, hipStream_t s) override {
+        hipLaunchKernelGGL((kw_target<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, P, st, d_ids, d_ep, cnt);
+    }
+    void launch_mrec_init(float* tg, int cnt, hipStream_t s) override {
+        if (S::MREC) hipLaunchKernelGGL((kw_mrec_init<S>), dim3((cnt * S::W + 255) / 256), dim3(256), 0, s, dT, tg, cnt);
+    }
+    void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) override {
+        if (S::MREC) hipLaunchKernelGGL((kw_set_motors<S>), dim3((n * 64 + 255) / 256), dim3(256), 0, s, tgt, n, cmd, mask);
+    }
+    void launch_cmd_joints(const float* act, hipStream_t s) override {
+        if (S::MREC) hipLaunchKernelGGL((kw_cmd_joints<S>), dim3((n * 64 + 255) / 256), dim3(256), 0, s, dT, tgt, act, n, act_dim);
+    }
+    int ndof() const override { return T.ndof; }
+    void snapshot(const float* rec) override {
+        for (int k = 0; k < S::NJ; k++) { T.rst_q[k] = rec[k]; P.rst_q[k] = rec[k]; }
+        P.rst_objz = rec[S::LC + 2];
+    }
+    void limits(float* lo, float* hi) const override { obs_limits(cfg, T, lo, hi); }
+    int vgprs() const override {
+        hipFuncAttributes fa;
+        constexpr int M = C::M_ACTION | C::M_OBS | C::M_TASK;
+        return hipFuncGetAttributes(&fa, (const void*)kw_step<S, L, M>) == hipSuccess ? fa.numRegs : -1;
+    }
+};
+
+
+WideEngine* make_hands_engine();       // pbre_hands.hip
+
+}  // namespace pbre

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")   # PBRE_LIB: build-variant A/B runs
 
 STATE_FLOATS = 48
-ROBOT_PANDA, ROBOT_ICUB = 0, 1
+ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS = 0, 1, 2
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
 F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES = 1, 2, 4, 8, 16
 
@@ -37,13 +37,13 @@ class Config(C.Structure):
                 ("obj_pose_rnd_std", C.c_double), ("tg_pose_rnd_std", C.c_double),
                 ("target_dist_min", C.c_double), ("act_scale", C.c_double),
                 ("kp_act", C.c_double), ("kd_act", C.c_double), ("kp_hold", C.c_double), ("kd_hold", C.c_double),
-                ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 40),
+                ("ws_lim", C.c_double * 2 * 3), ("h_table", C.c_double), ("home", C.c_double * 64),
                 ("phys", Physics),
                 ("ik_damping", C.c_double), ("ik_residual", C.c_double), ("ik_max_iters", C.c_int32),
                 ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
                 ("control_orientation", C.c_int32), ("reward_type", C.c_int32), ("num_joints_ctrl", C.c_int32),
-                ("act_dof", C.c_int32 * 16), ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double),
-                ("eu_lim", C.c_double * 2 * 3), ("ik_link_offset", C.c_double * 3),
+                ("act_dof", C.c_int32 * 64), ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double),
+                ("eu_lim", C.c_double * 2 * 3), ("ik_link_offset", C.c_double * 3), ("ik_absolute", C.c_int32),
                 ("robot_table", C.c_void_p), ("robot_table_len", C.c_size_t)]
 
 
@@ -73,7 +73,7 @@ def load(path=None):
     lib.pbre_destroy.restype = None
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
-                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats"):
+                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -191,6 +191,25 @@ class Engine:
         obs = np.zeros((self.num_envs, self.obs_dim), np.float32)
         self._chk(self.lib.pbre_observe(self._ctx, _fp(obs)))
         return obs
+
+    def apply_action(self, actions):
+        """iCub with hands: the command half of apply_action (IK / clipped joint targets -> persistent motors), no simulation step."""
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        if a.shape != (self.num_envs, self.act_dim):
+            raise ValueError("actions must be [%d, %d]" % (self.num_envs, self.act_dim))
+        self._chk(self.lib.pbre_apply_action(self._ctx, _fp(a)))
+
+    def set_motors(self, dofs, targets, kp, max_force=0.0, mask=None):
+        """iCub with hands: persistent POSITION_CONTROL command of the given DoF (same targets in every selected env)."""
+        d = np.ascontiguousarray(dofs, dtype=np.int32)
+        t = np.ascontiguousarray(targets, dtype=np.float32)
+        if d.shape != t.shape or d.ndim != 1:
+            raise ValueError("dofs and targets must be 1-D and of equal length")
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if m is not None and m.shape != (self.num_envs,):
+            raise ValueError("mask must have num_envs entries")
+        self._chk(self.lib.pbre_set_motors(self._ctx, C.c_int32(d.size), _fp(d), _fp(t), C.c_double(kp), C.c_double(max_force),
+                                           None if m is None else _fp(m)))
 
     def settle(self, n, flags=0):
         self._chk(self.lib.pbre_settle(self._ctx, C.c_int32(n), C.c_int32(flags)))

@@ -180,9 +180,3 @@ class iCubEnv:
 
     def debug_gui(self):
         pass
-
-
-class iCubHandsEnv(object):
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("iCubHandsEnv (icub_model_with_hands.sdf, 72 DoF) is not implemented by the MI355X engine yet "
-                                  "(DESIGN.md 'Out of scope': more than 32 DoF does not fit one wavefront's lanes)")

@@ -31,6 +31,8 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     virtual void observe(float* obs) = 0;
     virtual void settle_all(int n, int flags) = 0;
     virtual void limits(float* lo, float* hi) = 0;
+    virtual int set_motors(int n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) = 0;
+    virtual int apply_action(const float* actions) = 0;
 };
 
 template <class S>
@@ -38,7 +40,7 @@ struct Emu : pbre_ctx {
     using L = pbre_emu::HostLanesT<S::W>;
     using CoreH = Core<L, S>;
     static constexpr bool PANDA = std::is_same<S, Shape16>::value;
-    static constexpr int STATE = S::STATE, NJ = S::NJ, W = S::W;
+    static constexpr int STATE = S::STATE, NJ = S::NJ, W = S::W, TG = S::TGT;
     TablesT<S> T;
 
     // same dispatch as the device: lane-per-env fast path first (Panda), general lane-group kernel otherwise
@@ -69,8 +71,8 @@ struct Emu : pbre_ctx {
         else CoreH::ik_targets(T, P, st, act, tg, rst);
     }
     void settle(int e, int cnt, int flags) {
-        const int mode = P.use_ik ? CoreH::M_TGT : 0;
-        for (int i = 0; i < cnt; i++) step_env(&state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &tgt[(size_t)e * NJ]);
+        const int mode = (P.use_ik || S::MREC) ? CoreH::M_TGT : 0;
+        for (int i = 0; i < cnt; i++) step_env(&state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &tgt[(size_t)e * TG]);
     }
     void settle_all(int cnt, int flags) override { for (int e = 0; e < n; e++) settle(e, cnt, flags); }
     void reset(const uint8_t* mask) override {
@@ -80,13 +82,17 @@ struct Emu : pbre_ctx {
             unsigned long long id = P.env_id_base + (unsigned long long)e;
             unsigned ep = (unsigned)((int)st[2 * W + 5] + 1);      // episode numbers live in the state records
             CoreH::init_state(T, P, id, ep, st);
-            if (P.use_ik) ik(st, nullptr, &tgt[(size_t)e * NJ], true);
+            if (S::MREC) {     // iCubHandsEnv.reset (icub_env_with_hands.py:108-121): every motor at its initial position, gain 0.2, default force
+                float* m = &tgt[(size_t)e * TG];
+                for (int l = 0; l < W; l++) { m[l] = T.home[l]; m[W + l] = T.kp_hold[l]; m[2 * W + l] = 1.f; }
+            }
+            if (P.use_ik) ik(st, nullptr, &tgt[(size_t)e * TG], true);
             // one extra stepSimulation at the end of robot.reset: Panda in IK mode (panda_env.py:91), iCub always (icub_env.py:151)
-            if (P.use_ik || P.robot == PBRE_ROBOT_ICUB) settle(e, 1, PBRE_F_NO_OBJECT);
+            if (P.use_ik || P.robot != PBRE_ROBOT_PANDA) settle(e, 1, PBRE_F_NO_OBJECT);
             settle(e, 100, PBRE_F_NO_OBJECT);                       // robot alone (panda_push_gym_env.py:129-133)
             settle(e, 101, cfg.flags & PBRE_F_NO_OBJECT);           // world loaded: 100 + 1 steps (:136-148)
             CoreH::sample_target(P, id, ep, st);
-            if (P.robot == PBRE_ROBOT_ICUB && P.task >= 1) {
+            if (P.robot != PBRE_ROBOT_PANDA && P.task >= 1) {
                 auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
                 CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
             }
@@ -109,10 +115,10 @@ struct Emu : pbre_ctx {
                 const unsigned long long id = P.env_id_base + (unsigned long long)e;
                 float* o = last ? out + (size_t)e * ow : nullptr;
                 if (P.use_ik) {
-                    ik(st, actions + (size_t)e * act_dim, &tgt[(size_t)e * NJ], false);
-                    step_env(st, nullptr, o, CoreH::M_TGT | tail, fl, id, &tgt[(size_t)e * NJ]);
+                    ik(st, actions + (size_t)e * act_dim, &tgt[(size_t)e * TG], false);
+                    step_env(st, nullptr, o, CoreH::M_TGT | tail, fl, id, &tgt[(size_t)e * TG]);
                 } else
-                    step_env(st, actions + (size_t)e * act_dim, o, CoreH::M_ACTION | tail, fl, id);
+                    step_env(st, actions + (size_t)e * act_dim, o, CoreH::M_ACTION | tail, fl, id, S::MREC ? &tgt[(size_t)e * TG] : nullptr);
             }
         }
         P = P0;
@@ -127,6 +133,31 @@ struct Emu : pbre_ctx {
         }
     }
     void limits(float* lo, float* hi) override { obs_limits(cfg, T, lo, hi); }
+    int apply_action(const float* actions) override {
+        if (!S::MREC) { err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+        for (int e = 0; e < n; e++) {
+            float* m = &tgt[(size_t)e * TG];
+            const float* a = actions + (size_t)e * act_dim;
+            if (P.use_ik) ik(&state[(size_t)e * STATE], a, m, false);
+            else for (int l = 0; l < T.ndof; l++) {
+                const int k = T.act_idx[l];
+                if (k < 0) continue;
+                m[l] = std::fmin(std::fmax(a[k], T.lower[l]), T.upper[l]); m[W + l] = T.kp_act[l]; m[2 * W + l] = 1.f;
+            }
+        }
+        return PBRE_OK;
+    }
+    int set_motors(int cnt, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) override {
+        if (!S::MREC) { err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+        for (int k = 0; k < cnt; k++) if (dofs[k] < 0 || dofs[k] >= T.ndof) { err = "pbre_set_motors: bad DoF index"; return PBRE_E_ARG; }
+        const float fs = max_force > 0 ? (float)(max_force * cfg.phys.dt / cfg.phys.max_motor_impulse) : 1.f;
+        for (int e = 0; e < n; e++) {
+            if (mask && !mask[e]) continue;
+            float* m = &tgt[(size_t)e * TG];
+            for (int k = 0; k < cnt; k++) { m[dofs[k]] = targets[k]; m[W + dofs[k]] = (float)kp; m[2 * W + dofs[k]] = fs; }
+        }
+        return PBRE_OK;
+    }
 };
 static std::string g_err;
 
@@ -139,7 +170,7 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     c->cfg.robot_table = nullptr;
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg); c->sf = S::STATE; c->nj = S::NJ;
     c->state.assign((size_t)c->n * S::STATE, 0.f);
-    c->tgt.assign((size_t)c->n * S::NJ, 0.f);
+    c->tgt.assign((size_t)c->n * S::TGT, 0.f);
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
     if constexpr (std::is_same<S, Shape16>::value) c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     *out = c;
@@ -153,6 +184,7 @@ int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return 
 int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
     const int nd = table_ndof(*cfg);
+    if (nd > Shape64::NJ) return create<Shape128>(cfg, out);
     return nd > Shape32::NJ ? create<Shape64>(cfg, out) : (nd > Shape16::NJ ? create<Shape32>(cfg, out) : create<Shape16>(cfg, out));
 }
 void pbre_destroy(pbre_ctx* c) { delete c; }
@@ -190,6 +222,14 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     if (!c || n < 0) return PBRE_E_ARG;
     c->settle_all(n, flags & PBRE_F_NO_OBJECT);
     return PBRE_OK;
+}
+int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
+    if (!c || n < 0 || (n > 0 && (!dofs || !targets))) return PBRE_E_ARG;
+    return c->set_motors(n, dofs, targets, kp, max_force, mask);
+}
+int pbre_apply_action(pbre_ctx* c, const float* actions) {
+    if (!c || !actions) return PBRE_E_ARG;
+    return c->apply_action(actions);
 }
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;

@@ -19,6 +19,10 @@ PBRE_EMU_BIN(+) PBRE_EMU_BIN(-) PBRE_EMU_BIN(*) PBRE_EMU_BIN(/)
 template <int W>
 struct HostLanesT {
     using F = VF<W>; using I = VI<W>; using B = VB<W>;
+    using Robot = HostLanesT<W>;
+    static F lo(const F& x) { return x; }
+    static F wide(const F& x) { return x; }
+    static F fma_lo(const F& s, const F& m, const F& acc) { return fma(s, m, acc); }
     static F c(float x) { return F(x); }
     static I ci(int x) { return I(x); }
     static I lane() { I r; for (int i = 0; i < W; i++) r.v[i] = i; return r; }
@@ -71,6 +75,16 @@ struct HostLanesT {
         for (int i = 0; i < W; i++) y.v[i] = x.v[i] + x.v[i ^ 2]; x = y;
         for (int i = 0; i < W; i++) y.v[i] = x.v[i] + x.v[(i & ~7) | (7 - (i & 7))]; x = y;
         for (int i = 0; i < W; i++) y.v[i] = x.v[i] + x.v[(i & ~15) | (15 - (i & 15))]; x = y;
+        if (W == 128) {   // two virtual lanes per physical lane: lane i and lane i + 64 are added first, then the 64-lane order
+            F h = a;
+            for (int i = 0; i < 64; i++) h.v[i] = a.v[i] + a.v[i + 64];
+            x = h;
+            for (int i = 0; i < 64; i++) y.v[i] = x.v[i] + x.v[i ^ 1]; x = y;
+            for (int i = 0; i < 64; i++) y.v[i] = x.v[i] + x.v[i ^ 2]; x = y;
+            for (int i = 0; i < 64; i++) y.v[i] = x.v[i] + x.v[(i & ~7) | (7 - (i & 7))]; x = y;
+            for (int i = 0; i < 64; i++) y.v[i] = x.v[i] + x.v[(i & ~15) | (15 - (i & 15))]; x = y;
+            return F((x.v[48] + x.v[32]) + (x.v[16] + x.v[0]));
+        }
         if (W == 64) return F((x.v[48] + x.v[32]) + (x.v[16] + x.v[0]));
         if (W == 32) return F(x.v[0] + x.v[16]);
         return x;

@@ -10,8 +10,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
 
-MAXL, MAXD, MAXS, MAXACT = 48, 40, 16, 16
-NC = 8
+MAXL, MAXD, MAXS, MAXACT = 80, 64, 64, 64
+NC = 12
+NTIP = 5
 STATE = 48
 
 
@@ -24,7 +25,7 @@ def _mk(real):
                     ("mass", real * MAXL), ("com", real * 3 * MAXL), ("inertia", real * 9 * MAXL),
                     ("lower", real * MAXL), ("upper", real * MAXL), ("damping", real * MAXL), ("friction", real * MAXL),
                     ("s_link", C.c_int * MAXS), ("s_c", real * 3 * MAXS), ("s_r", real * MAXS), ("s_mu", real * MAXS),
-                    ("link_of_dof", C.c_int * MAXD)]
+                    ("s_tip", C.c_int * MAXS), ("ntip", C.c_int), ("link_of_dof", C.c_int * MAXD)]
 
     class StepInfo(C.Structure):
         _fields_ = [("ncontacts", C.c_int), ("type", C.c_int * NC), ("link", C.c_int * NC), ("idx", C.c_int * NC),
@@ -54,7 +55,7 @@ class Task(C.Structure):
                 ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
                 ("robot", C.c_int), ("act_dof", C.c_int * MAXACT), ("n_joints_ctrl", C.c_int), ("control_orientation", C.c_int),
                 ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double), ("eu_lim", C.c_double * 2 * 3),
-                ("ik_link_offset", C.c_double * 3), ("reward_type", C.c_int), ("action_repeat", C.c_int)]
+                ("ik_link_offset", C.c_double * 3), ("reward_type", C.c_int), ("action_repeat", C.c_int), ("ik_absolute", C.c_int)]
 
 
 F_NO_OBJECT = 1
@@ -94,6 +95,54 @@ class Oracle:
         home = (C.c_double * self.ndof)(*info["home"])
         self.lib.orc_task_icub(C.byref(self.task), C.c_int(task), C.c_int(1 if control_arm == "r" else 0), C.c_int(use_ik),
                                C.c_int(control_orientation), ctrl, home, C.c_int(self.ndof))
+
+    def set_hands(self, info, control_arm="l", use_ik=0):
+        """iCub with hands, robot-level interface (reference icub_env_with_hands.py); info = model.table.icub_hands_info()."""
+        n = len(info["controlled"])
+        ctrl = (C.c_int * n)(*info["controlled"])
+        home = (C.c_double * self.ndof)(*info["home"])
+        self.lib.orc_task_hands(C.byref(self.task), C.c_int(1 if control_arm == "r" else 0), C.c_int(use_ik), ctrl, C.c_int(n),
+                                home, C.c_int(self.ndof))
+
+    # ---- iCub with hands: per-env motor records target | kp | force scale, MAXD each
+    def hands_reset(self, n, env_id0=0):
+        st = np.zeros((n, self.state_floats), self.np_real)
+        mrec = np.zeros((n, 3 * MAXD), self.np_real)
+        obs = np.zeros((n, self.obs_dim), self.np_real)
+        for e in range(n):
+            self.lib.orc_hands_reset(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_uint64(env_id0 + e),
+                                     C.c_uint32(0), self._p(st[e]), self._p(mrec[e]), self._p(obs[e]))
+        return st, mrec, obs
+
+    def hands_step(self, states, mrec, actions):
+        st, mr = self._a(states).copy(), self._a(mrec).copy()
+        act = self._a(actions)
+        n = st.shape[0]
+        out = np.zeros((n, self.obs_dim + 2), self.np_real)
+        for e in range(n):
+            o = out[e]
+            self.lib.orc_hands_step(C.byref(self.model), C.byref(self.params), C.byref(self.task), self._p(st[e]), self._p(mr[e]),
+                                    self._p(act[e]), self._p(o), self._p(o[self.obs_dim:]), self._p(o[self.obs_dim + 1:]))
+        return st, mr, out
+
+    def hands_settle(self, states, mrec, n_steps):
+        st = self._a(states).copy()
+        mr = self._a(mrec)
+        for e in range(st.shape[0]):
+            self.lib.orc_hands_settle(C.byref(self.model), C.byref(self.params), C.byref(self.task), self._p(st[e]), self._p(mr[e]),
+                                      C.c_int(n_steps))
+        return st
+
+    def hands_set_motors(self, mrec, dofs, targets, kp, max_force=0.0, mask=None):
+        mr = self._a(mrec).copy()
+        d = (C.c_int * len(dofs))(*[int(x) for x in dofs])
+        t = self._a(targets)
+        for e in range(mr.shape[0]):
+            if mask is not None and not mask[e]:
+                continue
+            self.lib.orc_hands_set_motors(C.byref(self.params), self._p(mr[e]), C.c_int(len(dofs)), d, self._p(t), C.c_double(kp),
+                                          C.c_double(max_force))
+        return mr
 
     def _a(self, x):
         return np.ascontiguousarray(x, dtype=self.np_real)
@@ -186,6 +235,14 @@ def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, **kw):
     tbl, model, info = icub_table(control_arm)
     o = Oracle(tbl, task=task, **kw)
     o.set_icub(info, task, control_arm, use_ik, control_orientation)
+    return o, tbl, info
+
+
+def hands_oracle(control_arm="l", use_ik=0, **kw):
+    from pybullet_robot_envs.model.table import icub_hands_table
+    tbl, model, info = icub_hands_table(control_arm)
+    o = Oracle(tbl, task=0, **kw)
+    o.set_hands(info, control_arm, use_ik)
     return o, tbl, info
 
 

@@ -238,3 +238,105 @@ def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
         assert (se[:, 46] == 0).all()                                                     # the loop-exit flag never outlives a step
         cnts.append(int(se[0, 35]))
     assert cnts == [3, 6, 8, 8, 8], cnts
+
+
+# ---------------------------------------------------------------------------------------------- iCub with hands
+def hands_overrides(info, control_arm="l", use_ik=0):
+    """pbre_config fields that differ from pbre_default_config(PBRE_ROBOT_ICUB_HANDS) (left arm, joint control)."""
+    n = len(info["controlled"])
+    ov = dict(use_ik=use_ik, act_dof=list(info["controlled"]) + [-1] * (64 - n), home=list(info["home"]),
+              num_controlled_joints=n, num_joints_ctrl=n)
+    if control_arm == "r":
+        ov.update(home_hand_pose=[0.2, -0.3, 0.8, 0.0, 0.0, np.pi / 2],
+                  eu_lim=[-np.pi / 2, np.pi / 2, -np.pi / 2, np.pi / 2, 0.0, np.pi],
+                  ik_link_offset=[-0.011682, 0.051682, -0.000577])
+    return ov
+
+
+def make_hands_pair(Engine, lib, n, control_arm="r", use_ik=0, obj_std=0.0, **kw):
+    from pybullet_robot_envs import _capi
+    ora, tbl, info = orc.hands_oracle(control_arm, use_ik=use_ik)
+    ora.task.obj_pose_rnd_std = obj_std
+    ov = hands_overrides(info, control_arm, use_ik)
+    ov.update(kw)
+    eng = Engine(tbl, task=0, num_envs=n, lib=lib, robot=_capi.ROBOT_ICUB_HANDS, obj_pose_rnd_std=obj_std, **ov)
+    ph = eng.get_physics()                     # scene of the demo (table at x = 1, brick-sized object): same numbers on both sides
+    for f in ("table_c", "table_h", "obj_h", "obj_inertia"):
+        for k in range(3):
+            getattr(ora.params, f)[k] = getattr(ph, f)[k]
+    ora.params.obj_mass = ph.obj_mass
+    return eng, ora, info
+
+
+def check_hands(Engine, lib, control_arm="r", use_ik=0, n=1, steps=3, seed=7, tol=2e-3):
+    """iCub with hands (60 DoF, one env per 128-virtual-lane group) against the oracle: reset, commands, single steps from identical
+    states; finger commands through pbre_set_motors."""
+    from pybullet_robot_envs.model.table import GRASP_POS
+    eng, ora, info = make_hands_pair(Engine, lib, n, control_arm, use_ik)
+    assert eng.state_floats == ora.state_floats == 272 and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim
+    xo = eng.x_off
+    obs = eng.reset()
+    st_o, mrec, obs_o = ora.hands_reset(n)
+    st_e = eng.get_state()
+    assert rel(st_e[:, :xo], st_o[:, :xo]).max() < tol, rel(st_e[:, :xo], st_o[:, :xo]).max()
+    assert rel(obs, obs_o).max() < 1e-2
+    rng = np.random.default_rng(seed)
+    home = np.asarray(info["home"])[info["controlled"]]
+    st = st_o
+    for k in range(steps):
+        if k == 1:      # pre_grasp / grasp of the controlled hand (icub_env_with_hands.py:181-234)
+            pos = list(GRASP_POS)
+            eng.set_motors(info["fingers"], pos, 0.1, 10.0)
+            mrec = ora.hands_set_motors(mrec, info["fingers"], pos, 0.1, 10.0)
+        if use_ik:
+            a = np.tile(np.array([0.3, -0.1 if control_arm == "r" else 0.1, 0.8, 0.0, 0.0, 1.0], np.float32), (n, 1))
+            a[:, :3] += rng.uniform(-0.02, 0.02, (n, 3)).astype(np.float32)
+        else:
+            a = (home[None, :] + rng.uniform(-0.2, 0.2, (n, len(home)))).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+        se = eng.get_state()
+        assert rel(se[:, :xo], so[:, :xo]).max() < tol, (k, rel(se[:, :xo], so[:, :xo]).max())
+        assert rel(ob, out[:, :-2]).max() < 2e-2, (k, rel(ob, out[:, :-2]).max())
+        assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
+        assert (dn == out[:, -1]).all() and not dn.any()
+        st = so
+    return eng, ora, info, st, mrec
+
+
+def check_hands_contacts(Engine, lib, control_arm="r", steps=3, tol=3e-3):
+    """Fingertip contacts: the object is placed under the index and middle fingertips of the closing hand (1.5 mm penetration);
+    states, fingertip forces / counts (observation tail) against the oracle."""
+    from pybullet_robot_envs.model.table import icub_hands_model, hand_joint_names
+    eng, ora, info, st, mrec = check_hands(Engine, lib, control_arm, 0, n=1, steps=2)
+    nd, xo = 60, eng.x_off
+    m = icub_hands_model()
+    by_joint = {l.get("joint_name"): i for i, l in enumerate(m["links"])}
+    R, p = ora.fk(st[0, :nd])
+    jn = hand_joint_names(control_arm)
+    tips = [by_joint[jn[k]] for k in (3, 11)]                    # index, middle
+    c = [p[i] + R[i] @ np.array([0.0168, 0.0, 0.0]) for i in tips]
+    ph = eng.get_physics()
+    s = st.copy()
+    mid = 0.5 * (c[0] + c[1])
+    s[0, nd:nd + 3] = [mid[0], mid[1], min(c[0][2], c[1][2]) - 0.0075 - ph.obj_h[2] + 0.0015]
+    s[0, nd + 3:nd + 7] = [0, 0, 0, 1]
+    s[0, eng.v_off + nd:eng.v_off + nd + 6] = 0
+    a = np.asarray(info["home"], np.float32)[info["controlled"]][None, :]
+    seen = 0.0
+    for k in range(steps):
+        s32 = s.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+        se = eng.get_state()
+        assert rel(se[:, :xo], so[:, :xo]).max() < tol, (k, rel(se[:, :xo], so[:, :xo]).max())
+        tail_e, tail_o = ob[0, -7:], out[0, -9:-2]
+        assert np.array_equal(tail_e[5:], tail_o[5:]), (tail_e, tail_o)                 # tips in contact, contact points
+        assert np.abs(tail_e[:5] - tail_o[:5]).max() < 2e-2 * (1.0 + np.abs(tail_o[:5]).max()), (tail_e, tail_o)
+        seen = max(seen, tail_o[5])
+        s = so
+    assert seen >= 1, "no fingertip contact was exercised"
+    return eng

@@ -1,0 +1,43 @@
+"""iCub with hands (icub_model_with_hands.sdf; 60 simulated DoF, one env per 128-virtual-lane group, persistent motor records,
+fingertip contact forces) through the CPU lane emulation of the device algorithm vs the fp64 oracle."""
+import numpy as np
+import pytest
+
+import parity
+from pybullet_robot_envs import _capi
+
+
+def test_hands_joint_control_and_finger_commands(emu_lib):
+    parity.check_hands(_capi.Engine, emu_lib, "r", 0, n=1, steps=3)
+
+
+def test_hands_ik_control(emu_lib):
+    parity.check_hands(_capi.Engine, emu_lib, "l", 1, n=1, steps=2)
+
+
+def test_hands_fingertip_contacts(emu_lib):
+    parity.check_hands_contacts(_capi.Engine, emu_lib, "r")
+
+
+def test_set_motors_is_hands_only_and_validates(emu_lib, panda):
+    eng = _capi.Engine(panda["table"], lib=emu_lib, num_envs=1)
+    with pytest.raises(RuntimeError, match="motor record"):
+        eng.set_motors([0], [0.0], 0.1)
+    eh, ora, info = parity.make_hands_pair(_capi.Engine, emu_lib, 2, "l", 0)
+    with pytest.raises(RuntimeError, match="bad DoF"):
+        eh.set_motors([60], [0.0], 0.1)
+    with pytest.raises(RuntimeError, match="robot-level"):
+        parity.make_hands_pair(_capi.Engine, emu_lib, 1, "l", 0, action_repeat=2)
+    # a masked command only reaches the selected envs: env 1 closes its hand, env 0 keeps it open
+    from pybullet_robot_envs.model.table import GRASP_POS
+    st = np.zeros((2, eh.state_floats), np.float32)
+    st[:, :60] = np.asarray(info["home"], np.float32)
+    st[:, 60:67] = [0.5, -0.03, 0.65, 0, 0, 0, 1]
+    st[:, eh.x_off + 5] = 0
+    eh.set_state(st)
+    eh.set_motors(list(range(60)), info["home"], 0.2)                  # what reset would have written
+    eh.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0, mask=[0, 1])
+    eh.settle(20)
+    s = eh.get_state()
+    f = info["fingers"]
+    assert np.abs(s[0, f]).max() < 1e-3 and s[1, f[1]] > 0.05

@@ -1,0 +1,63 @@
+"""iCub with hands on the MI355X (pbre_hands.hip: Shape128 / DevLanes128) vs the fp64 oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+import parity
+from pybullet_robot_envs import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hands_joint_control_and_finger_commands(hip_lib):
+    parity.check_hands(_capi.Engine, hip_lib, "r", 0, n=3, steps=4)
+
+
+def test_hands_ik_control(hip_lib):
+    parity.check_hands(_capi.Engine, hip_lib, "l", 1, n=2, steps=3)
+
+
+def test_hands_fingertip_contacts(hip_lib):
+    parity.check_hands_contacts(_capi.Engine, hip_lib, "r")
+    parity.check_hands_contacts(_capi.Engine, hip_lib, "l")
+
+
+def test_hands_device_matches_lane_emulation(hip_lib, emu_lib):
+    """Same fp32 algorithm and summation order on both sides: the device and its CPU lane emulation agree to rounding of the
+    transcendental functions after a reset (203 steps) and a grasp sequence."""
+    from pybullet_robot_envs.model.table import GRASP_POS
+    outs = []
+    for lib in (hip_lib, emu_lib):
+        eng, ora, info = parity.make_hands_pair(_capi.Engine, lib, 1, "r", 0)
+        eng.reset()
+        eng.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0)
+        a = np.asarray(info["home"], np.float32)[info["controlled"]][None, :]
+        for _ in range(5):
+            ob, rw, dn = eng.step(a)
+        outs.append((eng.get_state(), ob))
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 1e-4
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-3
+
+
+def test_hands_batch_ragged_and_masked_reset(hip_lib):
+    n = 67                                              # not a multiple of the 4 envs of a block
+    eng, ora, info = parity.make_hands_pair(_capi.Engine, hip_lib, n, "r", 0, obj_std=0.05)
+    obs = eng.reset()
+    assert np.isfinite(obs).all()
+    s0 = eng.get_state()
+    assert np.abs(s0[:, :60] - s0[0, :60]).max() < 1e-5          # the robot settles identically; only the object pose is sampled
+    assert np.ptp(s0[:, 60]) > 0.01
+    a = np.tile(np.asarray(info["home"], np.float32)[info["controlled"]], (n, 1))
+    a[:, 3] += 0.3
+    for _ in range(10):
+        ob, rw, dn = eng.step(a)
+    s1 = eng.get_state()
+    mask = np.zeros(n, np.uint8); mask[5] = 1; mask[66] = 1
+    eng.reset(mask)
+    s2 = eng.get_state()
+    keep = mask == 0
+    assert np.array_equal(s1[keep], s2[keep])
+    assert np.abs(s2[5, :60] - s0[5, :60]).max() < 1e-5 and s2[5, eng.x_off + 5] == 1
+    # the reset envs' motors were re-initialised (home targets), the others keep the commanded shoulder angle
+    for _ in range(30):
+        ob, rw, dn = eng.step(a)
+    assert np.isfinite(eng.get_state()).all()

@@ -26,3 +26,9 @@ m = sdf.parse_sdf(src)
 dst = os.path.join(ROOT, "pybullet-robot-envs_amd/pybullet_robot_envs/robot_data/iCub/icub_model.json")
 table.save_model_json(m, dst)
 print("wrote", dst, "links:", len(m["links"]), "dof:", sum(1 for l in m["links"] if l["jtype"]))
+
+src = os.path.join(ref, "pybullet_robot_envs/robot_data/iCub/icub_model_with_hands.sdf")
+m = sdf.parse_sdf(src)
+dst = os.path.join(ROOT, "pybullet-robot-envs_amd/pybullet_robot_envs/robot_data/iCub/icub_model_with_hands.json")
+table.save_model_json(m, dst)
+print("wrote", dst, "links:", len(m["links"]), "dof:", sum(1 for l in m["links"] if l["jtype"]))
