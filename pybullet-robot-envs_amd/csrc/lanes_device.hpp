@@ -16,6 +16,14 @@ struct DevLanes {
     static __device__ __forceinline__ F lo(F x) { return x; }
     static __device__ __forceinline__ F wide(F x) { return x; }
     static __device__ __forceinline__ F fma_lo(F s, F m, F acc) { return __builtin_fmaf(s, m, acc); }
+    static __device__ __forceinline__ F uni(F x) { return x; }     // a group-uniform value
+    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 15u) == j ? src : x; }   // lane j of every group <- src
+    template <int N> struct RowStore {                            // contact rows of the solver: registers
+        F v[N];
+        __device__ __forceinline__ void init() {}
+        __device__ __forceinline__ F get(int i) const { return v[i]; }
+        __device__ __forceinline__ void put(int i, F x) { v[i] = x; }
+    };
     static __device__ __forceinline__ F c(float x) { return x; }
     static __device__ __forceinline__ I ci(int x) { return x; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 15u); }
@@ -97,6 +105,7 @@ struct DevLanes {
 // ds_bpermute_b32 inside the half-wave; an all-reduce is the 16-lane DPP butterfly plus one ds_swizzle_b32 (xor 16).
 struct DevLanes32 : DevLanes {
     using Robot = DevLanes32;
+    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 31u]; }
@@ -135,6 +144,11 @@ struct DevLanes32 : DevLanes {
 // emulation so that CPU tests and device agree bit for bit).
 struct DevLanes64 : DevLanes {
     using Robot = DevLanes64;
+    static __device__ __forceinline__ F setlane(F x, int j, F src) {      // v_readlane + v_writelane: no lane mask to keep in SGPRs
+        const int v = __builtin_amdgcn_readlane(__float_as_int(src), j);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(v), "n"(j));      // j is a constant once the row loops are unrolled
+        return x;
+    }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 63u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 63u]; }
@@ -193,7 +207,28 @@ struct DevLanes128 {
     static __device__ __forceinline__ float lo(F x) { return x.a; }
     static __device__ __forceinline__ F wide(float r) { return F{r, 0.f}; }
     static __device__ __forceinline__ F fma_lo(float s, float m, F acc) { return F{__builtin_fmaf(s, m, acc.a), acc.b}; }
+    static __device__ __forceinline__ F uni(F x) { return F{x.a, x.a}; }   // group-uniform: both halves are the same value -- one register
     static __device__ __forceinline__ int t() { return (int)(threadIdx.x & 63u); }
+    // Contact rows of the solver (72 rows x 128 virtual lanes) do not fit the register file next to the 60 rows of M^-1: they
+    // live in LDS, one private region per wave (no barriers: a wave only ever touches its own region, and its LDS accesses
+    // are ordered); lane-contiguous, so every ds_read / ds_write is conflict-free.  4 waves x 36 KB of the CU's 160 KB.
+    static constexpr int WPB = 4;                                 // waves per block of the kernels that use this backend
+    typedef __attribute__((address_space(3))) float lds_float;
+    template <int N> struct RowStore {
+        lds_float* base;
+        __device__ __forceinline__ void init() {
+            __shared__ float lds[WPB * N * 128];
+            base = (lds_float*)lds + (threadIdx.x >> 6) * (N * 128) + (threadIdx.x & 63u);
+        }
+        // the rows are loop-invariant inside the solver loop; the empty asm makes every read's address opaque so that the
+        // compiler reads LDS where the row is used instead of hoisting 144 row registers out of the loop (and spilling them)
+        __device__ __forceinline__ F get(int i) const {
+            lds_float* b = base;
+            asm volatile("" : "+v"(b));
+            return F{b[i * 128], b[i * 128 + 64]};
+        }
+        __device__ __forceinline__ void put(int i, F x) { base[i * 128] = x.a; base[i * 128 + 64] = x.b; }
+    };
     static __device__ __forceinline__ F c(float x) { return F{x, x}; }
     static __device__ __forceinline__ I ci(int x) { return I(x); }
     static __device__ __forceinline__ I lane() { return I(t(), t() + 64); }

@@ -29,6 +29,9 @@
 #ifndef PBRE_UNROLL
 #define PBRE_UNROLL
 #endif
+#ifndef PBRE_OPAQUE
+#define PBRE_OPAQUE(p)       // device builds: hide a pointer's value from the optimiser (no instruction)
+#endif
 
 namespace pbre {
 
@@ -306,20 +309,24 @@ struct Core {
         FR l_dir;
         FR m_app, l_app;      // applied impulse of the motor / limit row this lane owns
         FR m_lim;             // impulse bound of the motor row
-        F Jn[NC], Bn[NC], an[NC];
-        F J1[NC], B1[NC], a1[NC];
-        F J2[NC], B2[NC], a2[NC];
+        // contact rows: row 6 c + 2 d (J') and 6 c + 2 d + 1 (B) of contact c, direction d (normal, two tangents).  The store is
+        // the backend's: registers, or wave-private LDS where the rows would not fit the register file (DevLanes128)
+        typename L::template RowStore<6 * NC> rs;
+        F an[NC], a1[NC], a2[NC];
         F mu[NC];
         B act[NC];
     };
 
+    // app / lim are group-uniform; L::uni tells a backend that stores a value in more than one register per lane so
     static PBRE_HD void row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
+        app = L::uni(app);
         F t = L::sum(Jp * dv);
         F s = L::med3(app - t, lo, hi);
         F d = s - app; app = s;
         dv = L::fma(d, Bv, dv);
     }
     static PBRE_HD void frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
+        app = L::uni(app); lim = L::uni(lim);
         F t = L::sum(Jp * dv);
         F s = L::med3(app - t, L::c(0.f) - lim, lim);
         s = L::sel(L::gt(lim, L::c(0.f)), s, app);
@@ -447,6 +454,7 @@ struct Core {
         const IR laneR = LR::lane();
         const FR zeroR = LR::c(0.f), oneR = LR::c(1.f);
         Rows R;
+        R.rs.init();
         PBRE_UNROLL for (int i = 0; i < NJ; i++) {
             V3 Sa = bcastv(K.S.a, i), Sl = bcastv(K.S.l, i), Ga = bcastv(G.a, i), Gl = bcastv(G.l, i);
             F up = dot(Sa, G.a) + dot(Sl, G.l);            // i is an ancestor-or-self of this lane
@@ -460,6 +468,24 @@ struct Core {
         }
 
         // ---- M^-1 by in-place Gauss-Jordan (SPD, no pivoting), one matrix row per lane
+        if (NJ > 40) {
+            // 60 x 60: a rolled pivot loop (fully unrolled it is ~20k instructions and beyond the compiler's unroll budget, which
+            // would leave R in scratch memory).  The columns rotate left by one per step, so the pivot column is always Mi[0] and
+            // every register index stays a compile-time constant; after NJ steps the columns are back in place.  Same
+            // arithmetic per element as the unrolled form below.
+            for (int c = 0; c < NJ; c++) {
+                FR pc = LR::bcast(R.Mi[0], c);
+                FR inv = oneR / pc;
+                BR isc = LR::eqi(laneR, c);
+                FR f = R.Mi[0];
+                FR piv = LR::sel(isc, inv, zeroR - f * inv);
+                PBRE_UNROLL for (int k = 1; k < NJ; k++) {
+                    FR rc = LR::bcast(R.Mi[k], c) * inv;
+                    R.Mi[k - 1] = LR::sel(isc, rc, LR::fma(zeroR - f, rc, R.Mi[k]));
+                }
+                R.Mi[NJ - 1] = piv;
+            }
+        } else
         PBRE_UNROLL for (int c = 0; c < NJ; c++) {
             FR pc = LR::bcast(R.Mi[c], c);
             FR inv = oneR / pc;
@@ -508,48 +534,52 @@ struct Core {
         vstar = L::sel(robot, vstar, vobj);                 // generalized v* of all 15 DoF (lane 15: 0)
 
         // ---- collision detection at q_t
+        // Per-lane candidates stay alive through the row setup; the group-uniform Contact of a slot is fetched where its
+        // rows are built (all NC of them at once would be 13 values x NC of register pressure on top of the M^-1 rows).
         const F margin = L::c(P.margin);
-        Contact C[NC];
+        I so, rk_ot, rk_ro, rk_rt;
+        V3 up, vx, vB, n_ro, pB_ro, pA_ro, n_rt, pB_rt, pA_rt;
+        F vd, d_ro, d_rt, smu;
         {
             // candidates: sphere lane s vs object / table; vertex lane v (0..7) vs support surface
-            I so = L::loadI(T.s_owner);
+            so = L::loadI(T.s_owner);
             B sv = L::nei(L::loadI(T.s_valid), 0);
             M3 Rs; PBRE_UNROLL for (int k = 0; k < 9; k++) Rs.m[k] = L::gather(K.R.m[k], so);
             V3 ps = bcastvI(K.p, so);
             V3 sc = add(ps, mv(Rs, v3(L::load(T.s_c[0]), L::load(T.s_c[1]), L::load(T.s_c[2]))));
-            F sr = L::load(T.s_r), smu = L::load(T.s_mu);
+            F sr = L::load(T.s_r);
+            smu = L::load(T.s_mu);
             V3 oh = v3(L::c(P.obj_h[0]), L::c(P.obj_h[1]), L::c(P.obj_h[2]));
             // object vertices
             F sgx = L::sel(L::bit(lane, 0), one, zero - one), sgy = L::sel(L::bit(lane, 1), one, zero - one), sgz = L::sel(L::bit(lane, 2), one, zero - one);
-            V3 vx = add(op, mv(Ro, v3(sgx * oh.x, sgy * oh.y, sgz * oh.z)));
+            vx = add(op, mv(Ro, v3(sgx * oh.x, sgy * oh.y, sgz * oh.z)));
             F top = L::c(P.tab_c[2] + P.tab_h[2]), bot = L::c(P.tab_c[2] - P.tab_h[2]);
             B infoot = L::band(L::le(L::abs(vx.x - L::c(P.tab_c[0])), L::c(P.tab_h[0])), L::le(L::abs(vx.y - L::c(P.tab_c[1])), L::c(P.tab_h[1])));
             F hs = L::sel(L::band(infoot, L::gt(vx.z, bot)), top, L::c(P.ground_z));
-            F vd = vx.z - hs;
-            V3 up = v3(zero, zero, one);
+            vd = vx.z - hs;
+            up = v3(zero, zero, one);
             I none = L::ci(-1);
-            I rk_ot = none, rk_ro = none;
-            V3 n_ro, pB_ro, pA_ro; F d_ro = L::c(1.f);
+            rk_ot = none; rk_ro = none;
+            d_ro = L::c(1.f);
             if (obj_on) {
                 rk_ot = select_k(vd, L::lti(lane, 8), margin, NC_OT, lane);
                 d_ro = sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro);
                 pA_ro = add(pB_ro, scl(n_ro, d_ro));
                 rk_ro = select_k(d_ro, sv, margin, NC_RO, lane);
             } else { n_ro = up; pB_ro = up; pA_ro = up; }
-            V3 n_rt, pB_rt;
             M3 Idm; PBRE_UNROLL for (int k = 0; k < 9; k++) Idm.m[k] = (k % 4 == 0) ? one : zero;
-            F d_rt = sphere_box(sc, sr, v3(L::c(P.tab_c[0]), L::c(P.tab_c[1]), L::c(P.tab_c[2])), Idm,
+            d_rt = sphere_box(sc, sr, v3(L::c(P.tab_c[0]), L::c(P.tab_c[1]), L::c(P.tab_c[2])), Idm,
                                 v3(L::c(P.tab_h[0]), L::c(P.tab_h[1]), L::c(P.tab_h[2])), n_rt, pB_rt);
-            V3 pA_rt = add(pB_rt, scl(n_rt, d_rt));
-            I rk_rt = select_k(d_rt, sv, margin, NC_RT, lane);
-            V3 vB = v3(vx.x, vx.y, hs);
-            PBRE_UNROLL for (int c = 0; c < NC_OT; c++)
-                C[c] = fetch(rk_ot, c, up, vx, vB, vd, L::c(P.obj_mu * P.tab_mu), L::ci(0), lane);
-            PBRE_UNROLL for (int c = 0; c < NC_RO; c++)
-                C[NC_OT + c] = fetch(rk_ro, c, n_ro, pA_ro, pB_ro, d_ro, smu * L::c(P.obj_mu), so, lane);
-            PBRE_UNROLL for (int c = 0; c < NC_RT; c++)
-                C[NC_OT + NC_RO + c] = fetch(rk_rt, c, n_rt, pA_rt, pB_rt, d_rt, smu * L::c(P.tab_mu), so, lane);
+            pA_rt = add(pB_rt, scl(n_rt, d_rt));
+            rk_rt = select_k(d_rt, sv, margin, NC_RT, lane);
+            vB = v3(vx.x, vx.y, hs);
         }
+        auto contact_of = [&](int c) -> Contact {
+            if (c < NC_OT) return fetch(rk_ot, c, up, vx, vB, vd, L::c(P.obj_mu * P.tab_mu), L::ci(0), lane);
+            if (c < NC_OT + NC_RO) return fetch(rk_ro, c - NC_OT, n_ro, pA_ro, pB_ro, d_ro, smu * L::c(P.obj_mu), so, lane);
+            return fetch(rk_rt, c - NC_OT - NC_RO, n_rt, pA_rt, pB_rt, d_rt, smu * L::c(P.tab_mu), so, lane);
+        };
+        I owner_ro[NC_RO];           // link lane of each robot-object contact (fingertip bookkeeping)
 
         // ---- constraint rows
         // motors (btMultiBodyJointMotor, POSITION_CONTROL): velocity error kp (q_des - q)/dt - kd v*
@@ -576,10 +606,11 @@ struct Core {
         const F inv_m = L::c(1.f / P.obj_m);
         PBRE_UNROLL for (int c = 0; c < NC; c++) {
             const int type = c < NC_OT ? 0 : (c < NC_OT + NC_RO ? 1 : 2);
-            Contact& cc = C[c];
-            R.act[c] = cc.act; R.mu[c] = L::sel(cc.act, cc.mu, zero);
+            const Contact cc = contact_of(c);
+            if (type == 1) owner_ro[c - NC_OT] = cc.owner;
+            R.act[c] = cc.act; R.mu[c] = L::uni(L::sel(cc.act, cc.mu, zero));
             R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
-            if (!L::any(cc.act)) { R.Jn[c] = zero; R.Bn[c] = zero; R.J1[c] = zero; R.B1[c] = zero; R.J2[c] = zero; R.B2[c] = zero; continue; }
+            if (!L::any(cc.act)) { PBRE_UNROLL for (int k = 0; k < 6; k++) R.rs.put(6 * c + k, zero); continue; }
             // btPlaneSpace1
             V3 n = cc.n, t1, t2;
             {
@@ -633,7 +664,7 @@ struct Core {
                 } else rhs = (zero - rel) * dinv;
                 F Jp = L::sel(L::eqi(lane, L1), zero - rhs, J * dinv);
                 Jp = L::sel(cc.act, Jp, zero);
-                if (d == 0) { R.Jn[c] = Jp; R.Bn[c] = Bv; } else if (d == 1) { R.J1[c] = Jp; R.B1[c] = Bv; } else { R.J2[c] = Jp; R.B2[c] = Bv; }
+                R.rs.put(6 * c + 2 * d, Jp); R.rs.put(6 * c + 2 * d + 1, Bv);
             }
         }
 
@@ -647,22 +678,24 @@ struct Core {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
             FR d = s - R.m_app;
-            R.m_app = LR::sel(LR::eqi(laneR, j), s, R.m_app);
+            R.m_app = LR::setlane(R.m_app, j, s);
             dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
         auto limit = [&](int j) {
             FR t = LR::fma(R.l_j, L::lo(dv), zeroR - R.l_rhs);
             FR s = LR::med3(R.l_app - t, zeroR, llim);
             FR d = s - R.l_app;
-            R.l_app = LR::sel(LR::eqi(laneR, j), s, R.l_app);
+            R.l_app = LR::setlane(R.l_app, j, s);
             dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);
         };
+        bool on[NC];                         // some group of the wave has contact c
+        PBRE_UNROLL for (int c = 0; c < NC; c++) on[c] = L::any(R.act[c]);
         auto contacts = [&]() {
-            PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) row(R.Jn[c], R.Bn[c], R.an[c], zero, big, dv);
-            PBRE_UNROLL for (int c = 0; c < NC; c++) if (L::any(R.act[c])) {
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) row(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) {
                 F lim = R.mu[c] * R.an[c];
-                frow(R.J1[c], R.B1[c], R.a1[c], lim, dv);
-                frow(R.J2[c], R.B2[c], R.a2[c], lim, dv);
+                frow(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
+                frow(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
             }
         };
         const bool has_limit = LR::any(any_limit);
@@ -694,7 +727,7 @@ struct Core {
             F nro = zero;
             PBRE_UNROLL for (int c = NC_OT; c < NC_OT + NC_RO; c++) {
                 if (!obj_on || !L::any(R.act[c])) continue;
-                const I ts = L::gatherI(tip, C[c].owner);
+                const I ts = L::gatherI(tip, owner_ro[c - NC_OT]);
                 const F f = R.an[c] * inv_dt;
                 nro = nro + L::sel(R.act[c], one, zero);
                 PBRE_UNROLL for (int t = 0; t < NTIP; t++) {
@@ -729,7 +762,13 @@ struct Core {
         }
         L::store(st, Qn); L::store(st + W, Vn);
 
-        if (mode & (M_OBS | M_TASK)) observe(T, P, st, Qn, Vn, Xr, out, mode, flags, env_id);
+        if (mode & (M_OBS | M_TASK)) {
+            // the observation re-reads the tables through a pointer the optimiser cannot identify with T: otherwise the table
+            // values both phases use (joint frames, ancestor tables, ...) stay in registers across the whole solver loop
+            const Tables* Tp = &T;
+            PBRE_OPAQUE(Tp);
+            observe(*Tp, P, st, Qn, Vn, Xr, out, mode, flags, env_id);
+        }
     }
 
     // Geometric part of the observation of a state (Q, V, X = its three lane records).

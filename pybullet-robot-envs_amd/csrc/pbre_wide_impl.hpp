@@ -7,6 +7,7 @@
 
 #define PBRE_HD __device__ __forceinline__
 #define PBRE_UNROLL _Pragma("unroll")
+#define PBRE_OPAQUE(p) asm volatile("" : "+s"(p))
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -15,6 +16,7 @@
 namespace pbre {
 
 constexpr int WTPB = 256;                        // 4 independent waves per block
+static_assert(WTPB == 64 * DevLanes128::WPB, "DevLanes128 sizes its per-wave LDS regions for this block size");
 template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }   // physical lanes of one env group (Shape128: two virtual lanes each)
 struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };     // pbre_set_motors, by value
 

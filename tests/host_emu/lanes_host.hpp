@@ -23,6 +23,14 @@ struct HostLanesT {
     static F lo(const F& x) { return x; }
     static F wide(const F& x) { return x; }
     static F fma_lo(const F& s, const F& m, const F& acc) { return fma(s, m, acc); }
+    static F uni(const F& x) { return x; }
+    static F setlane(const F& x, int j, const F& src) { F r = x; r.v[j] = src.v[j]; return r; }
+    template <int N> struct RowStore {
+        F v[N];
+        void init() {}
+        const F& get(int i) const { return v[i]; }
+        void put(int i, const F& x) { v[i] = x; }
+    };
     static F c(float x) { return F(x); }
     static I ci(int x) { return I(x); }
     static I lane() { I r; for (int i = 0; i < W; i++) r.v[i] = i; return r; }
