@@ -70,6 +70,11 @@ typedef struct {
     double max_motor_impulse, limit_max_impulse;
     double table_c[3], table_h[3], table_mu, ground_z;
     double obj_h[3], obj_mass, obj_inertia[3], obj_mu;
+    int32_t implicit_joint_damping;   /* 0: the joint damping torque -c qd is an explicit force (the restated Bullet step; stable while
+                                         c dt < 2 x the joint's effective inertia).  1: implicit, (M + dt C) dv = dt (tau - C v): needed
+                                         by the iCub's finger joints (c = 1 on links of inertia 1e-3) once their motors are force-limited
+                                         (grasp, force 10) -- default for PBRE_ROBOT_ICUB_HANDS only.  Not available on the Panda's
+                                         lane-per-env kernels (PBRE_E_UNSUPPORTED). */
 } pbre_physics;
 
 typedef struct {
@@ -165,6 +170,12 @@ int pbre_set_motors(pbre_ctx* ctx, int32_t n, const int32_t* dofs, const float* 
  * simulation with pbre_settle (the reference's `p.stepSimulation()` loops, examples/helloworlds/helloworld_icub.py:61-125).
  * actions: host [num_envs][act_dim], absolute joint targets (joint control) or hand poses x,y,z,roll,pitch,yaw (use_ik). */
 int pbre_apply_action(pbre_ctx* ctx, const float* actions);
+
+/* PBRE_ROBOT_ICUB_HANDS: the motor records, host [num_envs][3][128] float32 = target | positionGain | force scale per DoF
+ * lane (force scale = force / PyBullet's default force).  Together with pbre_get_state / pbre_set_state this is the complete
+ * simulator state of the hands engine (checkpoint / restore, parity tests). */
+int pbre_get_motor_state(pbre_ctx* ctx, float* motors);
+int pbre_set_motor_state(pbre_ctx* ctx, const float* motors);
 
 /* replace the physics constants of every env of the batch (replaces p.changeDynamics in change_physics_params,
  * R/envs/panda_envs/panda_push_gym_env.py:362-368: object mass / friction / link damping -- domain randomisation between

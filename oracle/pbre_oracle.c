@@ -267,7 +267,10 @@ static void spatial_inertia(real mass, const real* com, const real* Ic, real* I)
 }
 
 /* configuration-dependent part: transforms, articulated inertias (pass 2 without forces) */
-static void aba_config(const orc_model* m, const real* q, aba_ws* w) {
+static void aba_config_d(const orc_model* m, const real* q, aba_ws* w, real jd_dt);
+static void aba_config(const orc_model* m, const real* q, aba_ws* w) { aba_config_d(m, q, w, 0); }
+/* jd_dt > 0: implicit joint damping -- the joint-space inertia every pass divides by gets dt * damping added (an armature term) */
+static void aba_config_d(const orc_model* m, const real* q, aba_ws* w, real jd_dt) {
     orc_fk(m, q, &w->Rw[0][0], &w->pw[0][0]);
     for (int i = 0; i < m->nl; i++) {
         lws* L = &w->L[i];
@@ -290,7 +293,7 @@ static void aba_config(const orc_model* m, const real* q, aba_ws* w) {
         memcpy(Ia, L->IA, sizeof Ia);
         if (m->jtype[i] != 0) {
             m6_v(L->IA, L->S, L->U);
-            L->d = 0; for (int k = 0; k < 6; k++) L->d += L->S[k] * L->U[k];
+            L->d = jd_dt * m->damping[i]; for (int k = 0; k < 6; k++) L->d += L->S[k] * L->U[k];
             for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Ia[a*6+b] -= L->U[a] * L->U[b] / L->d;
         } else { memset(L->U, 0, sizeof L->U); L->d = 1; }
         if (m->parent[i] >= 0) {
@@ -508,7 +511,7 @@ void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* st, const r
     memset(info, 0, sizeof *info);
 
     /* 1. kinematics + articulated inertias at q_t */
-    aba_config(m, q, w);
+    aba_config_d(m, q, w, prm->implicit_joint_damping ? dt : 0);
     real Ro[9]; quat_to_R(oq, Ro);
 
     /* 2. collision detection at q_t (Bullet: performDiscreteCollisionDetection before the solve) */

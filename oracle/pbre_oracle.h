@@ -71,6 +71,7 @@ typedef struct {
     double table_mu, ground_z;
     double obj_h[3], obj_mass, obj_inertia[3], obj_mu;
     int flags;                     /* ORC_F_* */
+    int implicit_joint_damping;    /* 1: (M + dt C) dv = dt (tau - C v) instead of the explicit damping torque (include/pbre.h) */
 } orc_params;
 
 #define ORC_F_NO_OBJECT 1   /* object frozen and contact-free (reset phase 1; reach config 2) */

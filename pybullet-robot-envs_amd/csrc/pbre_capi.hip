@@ -623,6 +623,18 @@ int pbre_apply_action(pbre_ctx* c, const float* actions) {
     c->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record";
     return PBRE_E_UNSUPPORTED;
 }
+int pbre_get_motor_state(pbre_ctx* c, float* m) {
+    if (!c || !m) return PBRE_E_ARG;
+    if (c->wide) return wide_motor_state(c->wide, m, nullptr);
+    c->err = "pbre_get_motor_state: only the iCub-with-hands engine keeps a motor record";
+    return PBRE_E_UNSUPPORTED;
+}
+int pbre_set_motor_state(pbre_ctx* c, const float* m) {
+    if (!c || !m) return PBRE_E_ARG;
+    if (c->wide) return wide_motor_state(c->wide, nullptr, m);
+    c->err = "pbre_set_motor_state: only the iCub-with-hands engine keeps a motor record";
+    return PBRE_E_UNSUPPORTED;
+}
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
     if (c->wide) return wide_get_physics(c->wide, phys);
@@ -636,7 +648,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     cfg.phys = *phys;
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
-    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the object must keep an isotropic inertia (cube) once the lane-per-env kernels are in use"; return PBRE_E_UNSUPPORTED; }
+    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

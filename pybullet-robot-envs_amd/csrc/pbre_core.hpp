@@ -461,6 +461,10 @@ struct Core {
             F dn = dot(K.S.a, Ga) + dot(K.S.l, Gl);        // this lane is an ancestor of i
             R.Mi[i] = L::lo(L::sel(mbit(amask, i), up, L::sel(mbit(dmask, i), dn, zero)));
         }
+        if (P.jd_dt != 0.f) {     // implicit joint damping: M + dt C (pbre_physics.implicit_joint_damping)
+            const FR add = LR::c(P.jd_dt) * LR::load(T.jdamp);
+            PBRE_UNROLL for (int i = 0; i < NJ; i++) R.Mi[i] = LR::sel(LR::eqi(laneR, i), R.Mi[i] + add, R.Mi[i]);
+        }
         // unused robot lanes (fewer than 9 DoF): unit diagonal keeps the inverse well defined
         {
             const BR nojoint = LR::eqi(LR::loadI(T.jtype), 0);

@@ -50,7 +50,8 @@ struct TopoPanda {
 
 // fast path preconditions that are uniform over the batch (checked once on the host)
 inline bool fast_scene_ok(const Params& P) {
-    return P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2];   // isotropic object inertia (a cube)
+    return P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]    // isotropic object inertia (a cube)
+        && P.jd_dt == 0.f;                                          // explicit joint damping
 }
 
 template <class Topo>

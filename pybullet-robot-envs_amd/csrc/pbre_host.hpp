@@ -78,6 +78,7 @@ inline int default_config(pbre_config* c, int robot, int task) {
         c->phys.table_c[0] = 1.0;                                                   // table.urdf at (1, 0, 0) (helloworld_icub.py:50)
         c->phys.obj_h[0] = 0.025; c->phys.obj_h[1] = 0.0375; c->phys.obj_h[2] = 0.025;   // foam-brick sized box (the YCB asset is not available)
         c->phys.obj_mass = 0.028;
+        c->phys.implicit_joint_damping = 1;                                         // finger joints: c dt / I = 3.7, see include/pbre.h
         for (int k = 0; k < 3; k++) {
             const double a = 2 * c->phys.obj_h[(k + 1) % 3], b = 2 * c->phys.obj_h[(k + 2) % 3];
             c->phys.obj_inertia[k] = c->phys.obj_mass * (a * a + b * b) / 12.0;
@@ -112,6 +113,7 @@ inline bool apply_physics(const pbre_physics& p, Params& P2) {
     P2.erp = (float)p.erp; P2.slop = (float)p.linear_slop; P2.margin = (float)p.contact_margin;
     P2.kl = (float)p.lin_damping; P2.ka = (float)p.ang_damping; P2.vmax = (float)p.max_coord_vel;
     P2.motor_imp = (float)p.max_motor_impulse; P2.limit_imp = (float)p.limit_max_impulse;
+    P2.jd_dt = p.implicit_joint_damping ? (float)p.dt : 0.f;
     for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
     P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
     return true;
@@ -147,6 +149,7 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     P.erp = (float)p.erp; P.slop = (float)p.linear_slop; P.margin = (float)p.contact_margin;
     P.kl = (float)p.lin_damping; P.ka = (float)p.ang_damping; P.vmax = (float)p.max_coord_vel;
     P.motor_imp = (float)p.max_motor_impulse; P.limit_imp = (float)p.limit_max_impulse;
+    P.jd_dt = p.implicit_joint_damping ? (float)p.dt : 0.f;
     for (int k = 0; k < 3; k++) { P.tab_c[k] = (float)p.table_c[k]; P.tab_h[k] = (float)p.table_h[k]; P.obj_h[k] = (float)p.obj_h[k]; P.obj_I[k] = (float)p.obj_inertia[k]; }
     P.tab_mu = (float)p.table_mu; P.ground_z = (float)p.ground_z; P.obj_m = (float)p.obj_mass; P.obj_mu = (float)p.obj_mu;
     P.task = c.task; P.max_steps = c.max_steps; P.flags = c.flags;

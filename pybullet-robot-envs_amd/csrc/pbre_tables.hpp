@@ -82,6 +82,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     float dt, inv_dt, gz;
     int   iters;
     float erp, slop, margin, kl, ka, vmax, motor_imp, limit_imp;
+    float jd_dt;                  // dt when the joint damping is integrated implicitly (M + dt C), else 0
     float tab_c[3], tab_h[3], tab_mu, ground_z;
     float obj_h[3], obj_m, obj_I[3], obj_mu;
     int   task, max_steps, flags;

@@ -279,6 +279,14 @@ int wide_apply_action(WideEngine* w, const float* actions) {
     WCHK(hipStreamSynchronize(s));
     return PBRE_OK;
 }
+int wide_motor_state(WideEngine* w, float* out, const float* in) {
+    if (!w->mrec) { w->err = "pbre_get/set_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    WCHK(hipSetDevice(w->device));
+    WCHK(hipStreamSynchronize(w->stream));
+    if (out) WCHK(hipMemcpy(out, w->tgt, (size_t)w->n * w->tgs * 4, hipMemcpyDeviceToHost));
+    if (in) WCHK(hipMemcpy(w->tgt, in, (size_t)w->n * w->tgs * 4, hipMemcpyHostToDevice));
+    return PBRE_OK;
+}
 int wide_get_physics(const WideEngine* w, pbre_physics* p) { *p = w->cfg.phys; return PBRE_OK; }
 int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     Params P2 = w->P;

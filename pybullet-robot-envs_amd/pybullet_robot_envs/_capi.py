@@ -26,7 +26,7 @@ class Physics(C.Structure):
                 ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
-                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double)]
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("implicit_joint_damping", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -73,7 +73,7 @@ def load(path=None):
     lib.pbre_destroy.restype = None
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
-                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action"):
+                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state"):
         getattr(lib, name).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -191,6 +191,18 @@ class Engine:
         obs = np.zeros((self.num_envs, self.obs_dim), np.float32)
         self._chk(self.lib.pbre_observe(self._ctx, _fp(obs)))
         return obs
+
+    def get_motor_state(self):
+        """iCub with hands: [N, 3, 128] target | positionGain | force scale of every DoF lane."""
+        m = np.zeros((self.num_envs, 3, 128), np.float32)
+        self._chk(self.lib.pbre_get_motor_state(self._ctx, _fp(m)))
+        return m
+
+    def set_motor_state(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        if m.shape != (self.num_envs, 3, 128):
+            raise ValueError("motor state must be [%d, 3, 128]" % self.num_envs)
+        self._chk(self.lib.pbre_set_motor_state(self._ctx, _fp(m)))
 
     def apply_action(self, actions):
         """iCub with hands: the command half of apply_action (IK / clipped joint targets -> persistent motors), no simulation step."""

@@ -10,7 +10,9 @@ object dropped at (0.5, -0.03)) is the engine's default world for this robot, an
 motor record on the GPU): `apply_action` / the finger commands only write commands, `step_simulation` advances time, and
 `step(action)` is the fused command + one step + observation used for throughput.
 
-Not implemented: quaternion actions (7 values) and `max_vel` (the demo passes max_vel=5; the engine has no motor velocity cap)."""
+Hand-pose commands may be 3 values (position), 6 (position + Euler angles, clipped to the arm's Euler limits as in the
+reference) or 7 (position + quaternion, used as given, as in the reference).  Not implemented: `max_vel` (the demo passes
+max_vel=5; the engine's motors have no velocity cap) and control_eu_or_quat=1 observations."""
 import math as m
 
 import numpy as np
@@ -119,7 +121,7 @@ class iCubHandsEnv(iCubEnv):
                          use_ik=1 if self._use_IK else 0, control_orientation=1 if self._control_orientation else 0,
                          num_controlled_joints=len(dofs), num_joints_ctrl=len(dofs), act_dof=dofs + [-1] * (64 - len(dofs)),
                          home=self.sim_home(), home_hand_pose=[float(x) for x in self._home_hand_pose],
-                         eu_lim=[x for lim in self._eu_lim for x in lim],
+                         eu_lim=[-1e9, 1e9] * 3,        # Euler limits are applied here (apply_action): a quaternion command bypasses them
                          ik_link_offset=list(self._com_to_link_hand_frame()[0]),
                          robot_ws=[x for lim in self._workspace_lim for x in lim])
         c.engine = _capi.Engine(self.robot_table, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib,
@@ -142,22 +144,47 @@ class iCubHandsEnv(iCubEnv):
             a = np.tile(a, (self.num_envs, 1))
         return a
 
+    @staticmethod
+    def _euler_from_quat(q):
+        """pybullet.getEulerFromQuaternion for [N, 4] (x, y, z, w)."""
+        x, y, z, w = (q[:, k].astype(np.float64) for k in range(4))
+        sarg = -2.0 * (x * z - w * y)
+        roll = np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z)
+        pitch = np.arcsin(np.clip(sarg, -1.0, 1.0))
+        yaw = np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)
+        lo, hi = sarg <= -0.99999, sarg >= 0.99999
+        roll = np.where(lo | hi, 0.0, roll)
+        pitch = np.where(lo, -0.5 * m.pi, np.where(hi, 0.5 * m.pi, pitch))
+        yaw = np.where(lo, 2 * np.arctan2(x, -y), np.where(hi, 2 * np.arctan2(-x, y), yaw))
+        return np.stack([roll, pitch, yaw], axis=1)
+
+    def _hand_pose_command(self, a):
+        """3 / 6 / 7 command values -> what the engine takes (x, y, z[, roll, pitch, yaw]); icub_env.py:262-300."""
+        if not (a.shape[1] == 3 or a.shape[1] == 6 or a.shape[1] == 7):
+            raise AssertionError('number of action commands must be \n- 3: (dx,dy,dz)'
+                                 '\n- 6: (dx,dy,dz,droll,dpitch,dyaw)'
+                                 '\n- 7: (dx,dy,dz,qx,qy,qz,w)'
+                                 '\ninstead it is: ', a.shape[1])
+        ad = self._engine.act_dim         # 6 with control_orientation, else 3: the home orientation is kept (:281-283)
+        if ad == 3:
+            return np.ascontiguousarray(a[:, :3])
+        if a.shape[1] == 6:               # Euler angles, each `min(hi, max(lo, x))` (:289-291)
+            eu = a[:, 3:6].astype(np.float64)
+            for k in range(3):
+                eu[:, k] = np.minimum(self._eu_lim[k][1], np.maximum(self._eu_lim[k][0], eu[:, k]))
+        elif a.shape[1] == 7:             # quaternion, used as given (:296-297)
+            eu = self._euler_from_quat(a[:, 3:7])
+        else:                             # `else: use current orientation` (:299-300) is approximated by the home orientation
+            eu = np.tile(np.asarray(self._home_hand_pose[3:6], np.float64), (a.shape[0], 1))
+        return np.concatenate([a[:, :3], eu.astype(np.float32)], axis=1)
+
     def apply_action(self, action, max_vel=-1):
         """Command the motors (icub_env.py:260-361): joint control -- one absolute target per controlled joint (37: torso, both
         arms, the hand), clipped to the joint limits; IK -- the hand pose (x, y, z[, roll, pitch, yaw]).  A 1-D action is sent to
         every env, a [N, k] array per env.  Does not advance the simulation."""
         a = self._batch(action)
         if self._use_IK:
-            if a.shape[1] == 7:
-                raise NotImplementedError("quaternion hand-pose commands (7 values) are not implemented")
-            if not (a.shape[1] == 3 or a.shape[1] == 6):
-                raise AssertionError('number of action commands must be \n- 3: (dx,dy,dz)'
-                                     '\n- 6: (dx,dy,dz,droll,dpitch,dyaw)\ninstead it is: ', a.shape[1])
-            ad = self._engine.act_dim     # 6 with control_orientation, else 3: the home orientation is kept (icub_env.py:281-283)
-            if a.shape[1] > ad:
-                a = np.ascontiguousarray(a[:, :ad])
-            elif a.shape[1] < ad:    # `else: use current orientation` (:299-300) is approximated by the home orientation
-                a = np.concatenate([a, np.tile(np.asarray(self._home_hand_pose[3:6], np.float32), (a.shape[0], 1))], axis=1)
+            a = self._hand_pose_command(a)
         elif a.shape[1] != len(self._joints_to_control):
             raise AssertionError('number of motor commands differs from number of motor to control',
                                  a.shape[1], len(self._joints_to_control))
@@ -170,6 +197,8 @@ class iCubHandsEnv(iCubEnv):
     def step(self, action):
         """Fused apply_action + one simulation step + observation for the whole batch (one kernel launch)."""
         a = self._batch(action)
+        if self._use_IK:
+            a = self._hand_pose_command(a)
         obs, rew, done = self._engine.step(a)
         self._last_out = obs
         return obs

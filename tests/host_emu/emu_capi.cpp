@@ -231,6 +231,18 @@ int pbre_apply_action(pbre_ctx* c, const float* actions) {
     if (!c || !actions) return PBRE_E_ARG;
     return c->apply_action(actions);
 }
+int pbre_get_motor_state(pbre_ctx* c, float* m) {
+    if (!c || !m) return PBRE_E_ARG;
+    if (c->cfg.robot != PBRE_ROBOT_ICUB_HANDS) { c->err = "pbre_get_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    std::memcpy(m, c->tgt.data(), c->tgt.size() * 4);
+    return PBRE_OK;
+}
+int pbre_set_motor_state(pbre_ctx* c, const float* m) {
+    if (!c || !m) return PBRE_E_ARG;
+    if (c->cfg.robot != PBRE_ROBOT_ICUB_HANDS) { c->err = "pbre_set_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    std::memcpy(c->tgt.data(), m, c->tgt.size() * 4);
+    return PBRE_OK;
+}
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
     *phys = c->cfg.phys;
@@ -242,7 +254,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     cfg.phys = *phys;
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
-    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the object must keep an isotropic inertia (cube) once the lane-per-env kernels are in use"; return PBRE_E_UNSUPPORTED; }
+    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;
 }

@@ -42,7 +42,7 @@ class Params(C.Structure):
                 ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
-                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int)]
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int), ("implicit_joint_damping", C.c_int)]
 
 
 class Task(C.Structure):

@@ -265,6 +265,7 @@ def make_hands_pair(Engine, lib, n, control_arm="r", use_ik=0, obj_std=0.0, **kw
         for k in range(3):
             getattr(ora.params, f)[k] = getattr(ph, f)[k]
     ora.params.obj_mass = ph.obj_mass
+    ora.params.implicit_joint_damping = ph.implicit_joint_damping
     return eng, ora, info
 
 

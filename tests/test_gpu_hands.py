@@ -61,3 +61,48 @@ def test_hands_batch_ragged_and_masked_reset(hip_lib):
     for _ in range(30):
         ob, rw, dn = eng.step(a)
     assert np.isfinite(eng.get_state()).all()
+
+
+def test_motor_state_roundtrip_completes_the_checkpoint(hip_lib):
+    """state record + motor record = the whole simulator state: restoring both reproduces the following steps bit for bit."""
+    from pybullet_robot_envs.model.table import GRASP_POS
+    eng, ora, info = parity.make_hands_pair(_capi.Engine, hip_lib, 5, "r", 0, obj_std=0.03)
+    eng.reset()
+    eng.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0, mask=[1, 0, 1, 0, 1])
+    mot = eng.get_motor_state()
+    assert mot.shape == (5, 3, 128) and (mot[0, 2, info["fingers"]] < 1).all() and (mot[1, 2, info["fingers"]] == 1).all()
+    a = np.tile(np.asarray(info["home"], np.float32)[info["controlled"]], (5, 1))
+    a[:, 5] += 0.2
+    for _ in range(4):
+        eng.step(a)                  # joint control drives all 37 controlled joints, fingers included: default force again
+    st, mot = eng.get_state(), eng.get_motor_state()
+    assert (mot[:, 2, info["fingers"]] == 1).all() and np.allclose(mot[:, 1, info["fingers"]], 0.5)
+    ref = [eng.step(a)[0].copy() for _ in range(3)]
+    eng.set_state(st); eng.set_motor_state(mot)
+    for k in range(3):
+        assert np.array_equal(eng.step(a)[0], ref[k])
+
+
+def test_reference_grasp_demo_sequence(hip_lib):
+    """helloworld_icub.py's scripted phases on a batch: IK reaches the commanded hand poses, the closing fingers touch the object."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import demo_icub_hands
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+    cid = _client.connect(6, lib=hip_lib)
+    robot = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+    lines = []
+    demo_icub_hands.run(robot, log=lines.append)
+    assert len(lines) == 7
+    hand = lambda l: np.array(l.split("hand [")[1].split("]")[0].split(), float)
+    assert np.abs(hand(lines[1]) - [0.49, 0.0, 0.8]).max() < 5e-3
+    assert np.abs(hand(lines[2]) - [0.485, 0.0, 0.72]).max() < 5e-3
+    assert np.abs(hand(lines[5]) - [0.3, -0.2, 0.9]).max() < 5e-3
+    obj = lambda l: np.array(l.split("object [")[1].split("]")[0].split(), float)
+    assert np.abs(obj(lines[3]) - obj(lines[2])).max() > 5e-3          # the closing fingers reached (and moved) the object
+    obs, _ = robot.get_observation()
+    assert obs.shape == (6, 46) and np.isfinite(obs).all()
+    n, f = robot.check_contact_fingertips()
+    assert n.shape == (6,) and f.shape == (6, 5)
+    _client.disconnect(cid)

@@ -1,45 +1,55 @@
 #!/usr/bin/env python
-"""Throughput of the iCub-with-hands engine (BASELINE config 5 stand-in: 60 simulated DoF, grasp scenario with fingertip
-contacts) on one MI355X -- extra measurement, not the headline bench.  Scenario per env: reset, pre_grasp, the hand moves above
-the object (joint targets), grasp(force 10); the timed loop then keeps commanding absolute joint targets around that pose with
-the fingers closing on the object.  Device-resident actions.
-    python tools/bench_hands.py [--envs 8192] [--steps 20] [--ik]"""
+"""Throughput of the iCub-with-hands engine (BASELINE config 5 stand-in: 60 simulated DoF, multi-finger contacts) on one
+MI355X -- extra measurement, not the headline bench.  Every env runs the reference's grasp demo
+(examples/helloworlds/helloworld_icub.py:61-95) opening: pre_grasp, hand above the object; the hand is then lowered until the
+palm presses on the object and the fingers close (grasp, force 10); the timed loop keeps commanding hand poses around that
+pose (IK, device-resident actions), so every env carries robot-object and object-table contacts.  Reports env-steps/s, the step kernel's duration and how many envs have fingertip contacts in the timed region.
+    python tools/bench_hands.py [--envs 8192] [--steps 20] [--joint]"""
 import argparse
 import json
+import math as m
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=8192)
 ap.add_argument("--steps", type=int, default=20)
-ap.add_argument("--ik", action="store_true")
+ap.add_argument("--joint", action="store_true", help="joint control (37 absolute targets) instead of IK hand poses")
 args = ap.parse_args()
 
 import numpy as np
 import torch
-from pybullet_robot_envs import _capi
-from pybullet_robot_envs.model.table import icub_hands_table, GRASP_POS
-import parity
+from pybullet_robot_envs import _client
+from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+from demo_icub_hands import quat
 
-tbl, model, info = icub_hands_table("r")
-ov = parity.hands_overrides(info, "r", 1 if args.ik else 0)
-eng = _capi.Engine(tbl, task=_capi.TASK_REACH, num_envs=args.envs, robot=_capi.ROBOT_ICUB_HANDS, obj_pose_rnd_std=0.02, **ov)
+cid = _client.connect(args.envs)
 t0 = time.perf_counter()
-eng.reset()
+robot = iCubHandsEnv(cid, use_IK=0 if args.joint else 1, control_arm='r')
 t_reset = time.perf_counter() - t0
-eng.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0)
+eng = robot._engine
+pos_cl = [0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 1.57, 0.8, 0.5, 0.8]
 dev = torch.device("cuda", 0)
-if args.ik:
-    base = torch.tensor([0.3, -0.1, 0.8, 0.0, 0.0, 1.0], device=dev)
-    act = [base + (torch.rand((args.envs, 6), device=dev) - 0.5) * 0.04 for _ in range(4)]
-else:
-    home = torch.tensor(np.asarray(info["home"], np.float32)[info["controlled"]], device=dev)
+if args.joint:
+    robot.grasp(pos_cl)
+    home = torch.tensor(np.asarray(robot.sim_home(), np.float32)[robot.controlled_dofs()], device=dev)
     act = [home + (torch.rand((args.envs, eng.act_dim), device=dev) - 0.5) * 0.4 for _ in range(4)]
+else:
+    # hand above the object, palm down (demo phase 1), then lowered until the palm presses on the object, fingers closing:
+    # sustained robot-object contacts + the four object-table contacts in every env
+    q1 = quat([0, 0, m.pi / 2])
+    robot.pre_grasp(); robot.step_simulation(10)
+    robot.apply_action([0.5, -0.03, 0.72] + q1); robot.pre_grasp(); robot.step_simulation(60)
+    robot.apply_action([0.5, -0.03, 0.69] + q1); robot.pre_grasp(); robot.step_simulation(40)
+    robot.grasp(pos_cl); robot.step_simulation(20)
+    base = torch.tensor([0.5, -0.03, 0.69, 0.0, 0.0, m.pi / 2], dtype=torch.float32, device=dev)
+    jit = torch.tensor([0.004, 0.004, 0.002, 0.01, 0.01, 0.01], device=dev)
+    act = [base + (torch.rand((args.envs, 6), device=dev) - 0.5) * jit for _ in range(4)]
 out = torch.zeros((args.envs, eng.obs_dim + 2), device=dev)
 s = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(s)
@@ -52,7 +62,8 @@ for k in range(args.steps):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 tail = out[:, -9:-2]
-print(json.dumps({"workload": "iCubHandsEnv %s, %d envs" % ("IK pose control" if args.ik else "joint control (37 targets)", args.envs),
+print(json.dumps({"workload": "iCubHandsEnv %s, %d envs" % ("joint control (37 targets)" if args.joint else "palm pressing on the object, fingers closing, IK hand-pose control", args.envs),
                   "env_steps_per_s": args.envs * args.steps / el, "ms_per_step": el / args.steps * 1e3,
                   "kernel_ms": eng.timing()[3], "reset_s": t_reset, "vgprs": eng.kernel_info()[1],
-                  "envs_with_fingertip_contact": int((tail[:, 5] > 0).sum()), "finite": bool(torch.isfinite(out).all())}))
+                  "envs_with_fingertip_contact": int((tail[:, 5] > 0).sum()), "mean_contact_points": float(tail[:, 6].mean()),
+                  "finite": bool(torch.isfinite(out).all())}))

@@ -71,13 +71,15 @@ class _World(object):
     def set_layout(self, nd):
         """state record layout of the oracle (oracle/pbre_oracle.h): Q | V | X"""
         self.nd = nd
-        self.w = 16 if nd <= 9 else (32 if nd <= 20 else 64)
+        self.w = 16 if nd <= 9 else (32 if nd <= 20 else (64 if nd <= 32 else 128))
         self.ov, self.ox = self.w, 2 * self.w
         self.state = np.zeros(2 * self.w + 16)
         self.state[nd + 6] = 1.0
         self.q_des = np.zeros(nd)
         self.kp = np.zeros(nd)
         self.kd = np.ones(nd)
+        self.motor_log = []        # (joint index, target, positionGain, velocityGain, force or None) of every motor command
+        self.contact_points = []   # synthetic getContactPoints records: (linkIndexB, normalForce)
 
 
 W = _World()
@@ -148,7 +150,8 @@ def loadURDF(path, basePosition=(0, 0, 0), baseOrientation=(0, 0, 0, 1), useFixe
 
 
 def loadSDF(path, physicsClientId=0, **k):
-    assert os.path.basename(path) == "icub_model.sdf", path
+    hands = os.path.basename(path) == "icub_model_with_hands.sdf"
+    assert hands or os.path.basename(path) == "icub_model.sdf", path
     bid = W.next_id
     W.next_id += 1
     raw = _sdf.parse_sdf(path)
@@ -158,10 +161,10 @@ def loadSDF(path, physicsClientId=0, **k):
     # the reference sees every link / joint of the SDF (names, indices, limits); the physics underneath is the engine's
     # model: legs pruned (limbs rooted at the fixed base are independent and unobserved, model/table.py prune_base_branches)
     W.model = full
-    W.pruned = _table.prune_base_branches(full, ["l_hand", "r_hand"])
+    W.pruned = _table.prune_base_branches(full, ["l_hand::l_hand_base_link", "r_hand::r_hand_base_link"] if hands else ["l_hand", "r_hand"])
     pnames = [l["name"] for l in W.pruned["links"]]
     W.plink = {i: pnames.index(l["name"]) for i, l in enumerate(full["links"]) if l["name"] in pnames}
-    W.icub_info = {a: _table.icub_info(W.pruned, a) for a in ("l", "r")}
+    W.icub_info = {} if hands else {a: _table.icub_info(W.pruned, a) for a in ("l", "r")}
     pdof = {}
     d = 0
     for i, l in enumerate(W.pruned["links"]):
@@ -220,7 +223,9 @@ def resetJointState(body, i, value, physicsClientId=0):
 
 def setJointMotorControl2(body, i, mode, targetPosition=0.0, positionGain=0.1, velocityGain=1.0, force=None,
                           maxVelocity=None, physicsClientId=0, **k):
-    assert mode == POSITION_CONTROL and force is None and (maxVelocity is None or maxVelocity == -1)
+    assert mode == POSITION_CONTROL and (maxVelocity is None or maxVelocity == -1)
+    W.motor_log.append((int(i), float(targetPosition), float(positionGain), float(velocityGain), None if force is None else float(force)))
+    assert force is None or W.nd > 32      # only the hands model commands a force; its physics is not stepped through this stub
     d = W.dof_of_joint[i]
     if d is None:
         return
@@ -230,9 +235,20 @@ def setJointMotorControl2(body, i, mode, targetPosition=0.0, positionGain=0.1, v
 
 
 def setJointMotorControlArray(bodyUniqueId, jointIndices, controlMode, targetPositions=None, positionGains=None,
-                              velocityGains=None, physicsClientId=0, **k):
-    for i, t, kp_, kd_ in zip(list(jointIndices), targetPositions, positionGains, velocityGains):
-        setJointMotorControl2(bodyUniqueId, i, controlMode, targetPosition=t, positionGain=kp_, velocityGain=kd_)
+                              velocityGains=None, forces=None, physicsClientId=0, **k):
+    idx = list(jointIndices)
+    fs = [None] * len(idx) if forces is None else list(forces)
+    for i, t, kp_, kd_, f in zip(idx, targetPositions, positionGains, velocityGains, fs):
+        setJointMotorControl2(bodyUniqueId, i, controlMode, targetPosition=t, positionGain=kp_, velocityGain=kd_, force=f)
+
+
+def getContactPoints(bodyA=None, bodyB=None, linkIndexB=None, physicsClientId=0, **k):
+    """Synthetic contact list (W.contact_points): tuples shaped like PyBullet's, [4] = linkIndexB, [9] = normalForce."""
+    out = []
+    for link, force in W.contact_points:
+        if linkIndexB is None or link == linkIndexB:
+            out.append((0, bodyA, bodyB, -1, link, (0, 0, 0), (0, 0, 0), (0, 0, 1), 0.0, force))
+    return tuple(out)
 
 
 def calculateInverseKinematics(body, ee, pos, orn, maxNumIterations=20, residualThreshold=1e-4, physicsClientId=0,
