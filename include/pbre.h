@@ -13,7 +13,8 @@
  * done above this ABI with one ctx per rank and env_id_base = rank * num_envs).
  *
  * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
- * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 otherwise; nd = number of DoF:
+ * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 for <= 32 DoF, W = 128 for <= 60
+ * (the iCub with hands: 272 floats); nd = number of DoF:
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
@@ -126,7 +127,7 @@ void pbre_destroy(pbre_ctx* ctx);
 const char* pbre_last_error(const pbre_ctx* ctx);   /* borrowed; ctx may be NULL for create errors */
 
 int pbre_dims(const pbre_ctx* ctx, int32_t* obs_dim, int32_t* act_dim, int32_t* num_envs);
-/* floats per env state record (48 Panda, 80 iCub) */
+/* floats per env state record (48 Panda, 80 iCub, 272 iCub with hands) */
 int pbre_state_floats(const pbre_ctx* ctx);
 
 /* replaces: pandaPushGymEnv.reset -> reset_simulation (panda_push_gym_env.py:105-148: resetSimulation,
