@@ -211,23 +211,32 @@ struct DevLanes128 {
     static __device__ __forceinline__ int t() { return (int)(threadIdx.x & 63u); }
     // Contact rows of the solver (72 rows x 128 virtual lanes) do not fit the register file next to the 60 rows of M^-1: they
     // live in LDS, one private region per wave (no barriers: a wave only ever touches its own region, and its LDS accesses
-    // are ordered); lane-contiguous, so every ds_read / ds_write is conflict-free.  4 waves x 36 KB of the CU's 160 KB.
+    // are ordered).  The low halves are lane-contiguous (conflict-free); of a row's high half only virtual lanes 64..66 are
+    // ever non-zero (object angular y, z and the constant lane), so it is stored as 4 floats: lanes 0..2 own one each, every
+    // other lane reads the zero in slot 3 (an LDS broadcast).  19.6 KB per wave: two 4-wave blocks fit a CU's 160 KB.
     static constexpr int WPB = 4;                                 // waves per block of the kernels that use this backend
     typedef __attribute__((address_space(3))) float lds_float;
     template <int N> struct RowStore {
-        lds_float* base;
+        lds_float *lo, *hi;
         __device__ __forceinline__ void init() {
-            __shared__ float lds[WPB * N * 128];
-            base = (lds_float*)lds + (threadIdx.x >> 6) * (N * 128) + (threadIdx.x & 63u);
+            __shared__ float lds[WPB * N * 68];
+            lds_float* w = (lds_float*)lds + (threadIdx.x >> 6) * (N * 68);
+            const int t_ = (int)(threadIdx.x & 63u);
+            lo = w + t_;
+            hi = w + N * 64 + (t_ < 3 ? t_ : 3);
         }
         // the rows are loop-invariant inside the solver loop; the empty asm makes every read's address opaque so that the
         // compiler reads LDS where the row is used instead of hoisting 144 row registers out of the loop (and spilling them)
         __device__ __forceinline__ F get(int i) const {
-            lds_float* b = base;
-            asm volatile("" : "+v"(b));
-            return F{b[i * 128], b[i * 128 + 64]};
+            lds_float *a = lo, *b = hi;
+            asm volatile("" : "+v"(a), "+v"(b));
+            return F{a[i * 64], b[i * 4]};
         }
-        __device__ __forceinline__ void put(int i, F x) { base[i * 128] = x.a; base[i * 128 + 64] = x.b; }
+        __device__ __forceinline__ void put(int i, F x) {
+            lo[i * 64] = x.a;
+            const int t_ = (int)(threadIdx.x & 63u);
+            if (t_ < 4) hi[i * 4] = t_ < 3 ? x.b : 0.f;
+        }
     };
     static __device__ __forceinline__ F c(float x) { return F{x, x}; }
     static __device__ __forceinline__ I ci(int x) { return I(x); }

@@ -21,7 +21,7 @@ template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; } 
 struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };     // pbre_set_motors, by value
 
 template <class S, class L, int MODE>
-__global__ __launch_bounds__(WTPB, S::W > 64 ? 1 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
                                                    int flags, const float* __restrict__ tgt) {
     using C = Core<L, S>;
