@@ -78,6 +78,59 @@ def cpu_baseline(target_cpu_seconds=20.0):
                       "%.1f s wall incl. process start" % (n, steps, cores, wall)}
 
 
+def other_configs(torch, dev, steps=10):
+    """Extra, informative lines for the other BASELINE configs on one GPU (never the headline value): the batched
+    iCubReach-v0 (config 1's env, 32768 envs) and the iCub with hands (config 5 stand-in: 60 simulated DoF, the palm pressing
+    on the object with closing fingers, 8192 envs = 65536 / 8)."""
+    import math as m
+    out = {}
+
+    def timed(eng, acts):
+        o = torch.zeros((eng.num_envs, eng.obs_dim + 2), device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        for k in range(2):
+            eng.step_device(acts[k % len(acts)].data_ptr(), o.data_ptr(), s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            eng.step_device(acts[k % len(acts)].data_ptr(), o.data_ptr(), s)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"envs": eng.num_envs, "value": eng.num_envs * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3,
+                "outputs_finite": bool(torch.isfinite(o).all())}, o
+    try:
+        from pybullet_robot_envs.envs import iCubReachGymEnv
+        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)   # iCubReach-v0 kwargs
+        env.reset()
+        r, _ = timed(env._engine, [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(4)])
+        r["workload"] = "iCubReach-v0 (IK position control of the left hand), one env per half-wave"
+        out["icub_reach"] = r
+        env.close()
+    except Exception as e:
+        out["icub_reach"] = {"error": repr(e)}
+    try:
+        from pybullet_robot_envs import _client
+        from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+        cid = _client.connect(8192)
+        robot = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+        q1 = [0.0, 0.0, m.sin(m.pi / 4), m.cos(m.pi / 4)]           # yaw pi/2: palm down above the object
+        robot.pre_grasp(); robot.step_simulation(10)
+        robot.apply_action([0.5, -0.03, 0.72] + q1); robot.pre_grasp(); robot.step_simulation(60)
+        robot.apply_action([0.5, -0.03, 0.69] + q1); robot.pre_grasp(); robot.step_simulation(40)
+        robot.grasp(); robot.step_simulation(20)
+        base = torch.tensor([0.5, -0.03, 0.69, 0.0, 0.0, m.pi / 2], dtype=torch.float32, device=dev)
+        jit = torch.tensor([0.004, 0.004, 0.002, 0.01, 0.01, 0.01], device=dev)
+        r, o = timed(robot._engine, [base + (torch.rand((8192, 6), device=dev) - 0.5) * jit for _ in range(4)])
+        r["workload"] = ("iCubHandsEnv (60 simulated DoF, one env per wavefront): palm pressing on the object, fingers closing "
+                         "(grasp, force 10), IK hand-pose control")
+        r["mean_robot_object_contact_points"] = float(o[:, -3].mean())
+        out["icub_hands_config5_standin"] = r
+        _client.disconnect(cid)
+    except Exception as e:
+        out["icub_hands_config5_standin"] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +141,7 @@ def main():
     ap.add_argument("--steady-preroll", type=int, default=300,
                     help="untimed steps before the extra mid-episode measurement (0 disables it)")
     ap.add_argument("--no-strong", action="store_true", help="skip the extra fixed-total measurement at N>1")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the informative iCub / iCub-with-hands lines (N=1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -300,6 +354,8 @@ def main():
                      "peak_scalar_fma": FP32_VALU_PEAK_TFLOPS / 2, "frac_scalar_fma": ach_tf / (FP32_VALU_PEAK_TFLOPS / 2),
                      "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "sq_counters": sq, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
+        if world == 1 and not args.no_other_configs:
+            res["other_configs"] = other_configs(torch, dev)
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()
