@@ -341,3 +341,19 @@ def check_hands_contacts(Engine, lib, control_arm="r", steps=3, tol=3e-3):
         s = so
     assert seen >= 1, "no fingertip contact was exercised"
     return eng
+
+
+def check_implicit_damping(Engine, lib, table, n=6):
+    """pbre_physics.implicit_joint_damping on the Panda: the lane-per-env kernels do not implement it (the engine falls back to
+    the lane-group kernel at creation, refuses to switch later); results against the oracle with the same option."""
+    eng, ora = make_pair(Engine, lib, table, n, phys={"implicit_joint_damping": 1})
+    ora.params.implicit_joint_damping = 1
+    st = check_reset(eng, ora, n)
+    check_single_steps(eng, ora, st, np.random.default_rng(11), steps=3)
+    assert eng.kernel_info()[3] == 0, "the lane-per-env fast path must be off with implicit joint damping"
+    e2, o2 = make_pair(Engine, lib, table, n)
+    e2.reset()
+    assert rel(e2.get_state(), eng.get_state()).max() > 1e-6          # the option does change the dynamics
+    import pytest
+    with pytest.raises(RuntimeError, match="explicit joint damping"):
+        e2.set_physics(implicit_joint_damping=1)

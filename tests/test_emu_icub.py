@@ -36,3 +36,21 @@ def test_icub_action_repeat(emu_lib):
         assert np.abs(se[:, xo + 6:xo + 12] - st_o[:, xo + 6:xo + 12]).max() < 1e-6
         assert parity.rel(ob, out[:, :-2]).max() < 2e-2
     assert list(se[:, xo + 3]) == [5, 5]
+
+
+def test_implicit_joint_damping_option(emu_lib, panda):
+    parity.check_implicit_damping(_capi.Engine, emu_lib, panda["table"], n=2)
+
+
+def test_icub_implicit_joint_damping(emu_lib):
+    eng, ora, info = parity.make_icub_pair(_capi.Engine, emu_lib, 1, task=1, control_arm="l", use_ik=0, phys={"implicit_joint_damping": 1})
+    ora.params.implicit_joint_damping = 1
+    eng.reset()
+    st, _ = ora.batch_reset(1)
+    xo = eng.x_off
+    assert parity.rel(eng.get_state()[:, :xo], st[:, :xo]).max() < 2e-3
+    a = np.random.default_rng(2).uniform(-1, 1, (1, eng.act_dim)).astype(np.float32)
+    eng.set_state(st.astype(np.float32))
+    ob, rw, dn = eng.step(a)
+    so, out = ora.batch_step(st.astype(np.float32).astype(np.float64), a)
+    assert parity.rel(eng.get_state()[:, :xo], so[:, :xo]).max() < 2e-3 and parity.rel(ob, out[:, :-2]).max() < 2e-2

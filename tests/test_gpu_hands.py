@@ -106,3 +106,22 @@ def test_reference_grasp_demo_sequence(hip_lib):
     n, f = robot.check_contact_fingertips()
     assert n.shape == (6,) and f.shape == (6, 5)
     _client.disconnect(cid)
+
+
+def test_hands_sharding_invariance(hip_lib):
+    """RNG streams are keyed by the global env id: two shards with env_id_base 0 / 4 reproduce one 8-env engine bit for bit."""
+    kw = dict(obj_std=0.04)
+    full, _, info = parity.make_hands_pair(_capi.Engine, hip_lib, 8, "r", 0, **kw)
+    a, _, _ = parity.make_hands_pair(_capi.Engine, hip_lib, 4, "r", 0, env_id_base=0, **kw)
+    b, _, _ = parity.make_hands_pair(_capi.Engine, hip_lib, 4, "r", 0, env_id_base=4, **kw)
+    of, oa, ob_ = full.reset(), a.reset(), b.reset()
+    assert np.array_equal(of, np.concatenate([oa, ob_])) and np.ptp(of[:, 46]) > 1e-3        # object x differs between envs
+    act = np.tile(np.asarray(info["home"], np.float32)[info["controlled"]], (8, 1))
+    act += np.random.default_rng(3).uniform(-0.2, 0.2, act.shape).astype(np.float32)
+    for _ in range(3):
+        rf, ra, rb = full.step(act), a.step(act[:4]), b.step(act[4:])
+    assert np.array_equal(rf[0], np.concatenate([ra[0], rb[0]]))
+
+
+def test_implicit_joint_damping_option(hip_lib, panda):
+    parity.check_implicit_damping(_capi.Engine, hip_lib, panda["table"], n=64)
