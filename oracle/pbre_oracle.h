@@ -1,8 +1,8 @@
 /* pbre_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
  * CPU restatement (double precision by default, -DORC_FLOAT for a float build)
- * of the env.step() hot path of hsp-iit/pybullet-robot-envs for the Panda
- * reach/push tasks.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * of the env.step() hot path of hsp-iit/pybullet-robot-envs for the Panda and iCub
+ * reach/push tasks and the robot-level interface of the iCub with hands.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product (libpbre.so) never does.
  *
  * PARITY UNPINNED for the physics: the arithmetic of `p.stepSimulation()`

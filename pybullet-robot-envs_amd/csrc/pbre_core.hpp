@@ -1,7 +1,8 @@
 // pbre_core.hpp -- the env.step() hot path, written once against a "lane backend" L.
 //
 // Mapping: one environment = one lane group of shape S (pbre_tables.hpp): a 16-lane DPP row for the
-// Panda (4 envs per wave), a whole 64-lane wave for the iCub.  Lane k of a group owns generalized coordinate k:
+// Panda (4 envs per wave), a 32-lane half-wave for the iCub (2 envs per wave), 128 virtual lanes on one wave for the iCub
+// with hands (two per physical lane).  Lane k of a group owns generalized coordinate k:
 //     lanes 0..NJ-1     robot joints                         -- link/joint data of link k
 //     lanes LC..LC+2    object linear velocity x,y,z         lanes LC+3..LC+5 object angular velocity
 //     lane  L1          constant 1 (carries -rhs of a contact row through the row dot product)
@@ -9,8 +10,9 @@
 // (broadcast/gather inside the group).  No LDS allocation, no scratch.
 //
 // L provides: F (float per lane), I (int per lane), B (predicate per lane) and the ops used
-// below.  Device backend: lanes_device.hpp (F = float).  Host backend (CPU tests only):
-// tests/host_emu/lanes_host.hpp (F = 16 floats).  Control flow is group-uniform by
+// below, plus Robot (the view of values that only exist on robot lanes), RowStore (where the contact rows live) and
+// uni / setlane / fma_lo.  Device backends: lanes_device.hpp (F = float; DevLanes128: F = two floats).  Host backend
+// (CPU tests only): tests/host_emu/lanes_host.hpp (F = W floats).  Control flow is group-uniform by
 // construction; L::any() is only ever used to skip work that is a no-op when false.
 //
 // Replaces, per env (reference file:line):

@@ -4,7 +4,8 @@
 // the group owns DoF k (robot lanes, 6 object lanes, the constant lane); M^-1 rows, constraint rows and the 150-iteration
 // PGS state live in VGPRs; cross-lane traffic is DPP / ds_swizzle (all-reduce), ds_bpermute (gathers, broadcasts inside a
 // half-wave) and v_readlane (broadcasts inside a whole wave).  No LDS memory, no barriers; a block is 4 independent waves.
-// State: Q[W] | V[W] | X[16] floats per env (80 for Shape32, 144 for Shape64).
+// State: Q[W] | V[W] | X[16] floats per env (80 for Shape32, 144 for Shape64).  The kernels and the shape-specific engine half
+// are templates in pbre_wide_impl.hpp; the iCub with hands (Shape128, 60 DoF) is instantiated in pbre_hands.hip.
 //
 // Replaces, per env (reference file:line): iCubReachGymEnv / iCubPushGymEnv / iCubPushGymGoalEnv .step and .reset
 // (icub_reach_gym_env.py:114-259, icub_push_gym_env.py:116-282, icub_push_gym_goal_env.py:69-139), iCubEnv.apply_action /
