@@ -18,6 +18,11 @@ struct DevLanes {
     static __device__ __forceinline__ F fma_lo(F s, F m, F acc) { return __builtin_fmaf(s, m, acc); }
     static __device__ __forceinline__ F uni(F x) { return x; }     // a group-uniform value
     static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 15u) == j ? src : x; }   // lane j of every group <- src
+    static __device__ __forceinline__ unsigned long long lanebits(B b) {      // bit j: b holds on lane j of some group of the wave
+        unsigned long long m = __ballot((int)b);
+        m |= m >> 32; m |= m >> 16;
+        return m & 0xFFFFull;
+    }
     template <int N> struct RowStore {                            // contact rows of the solver: registers
         F v[N];
         __device__ __forceinline__ void init() {}
@@ -106,6 +111,7 @@ struct DevLanes {
 struct DevLanes32 : DevLanes {
     using Robot = DevLanes32;
     static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }
+    static __device__ __forceinline__ unsigned long long lanebits(B b) { unsigned long long m = __ballot((int)b); return (m | (m >> 32)) & 0xFFFFFFFFull; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 31u]; }
@@ -144,6 +150,7 @@ struct DevLanes32 : DevLanes {
 // emulation so that CPU tests and device agree bit for bit).
 struct DevLanes64 : DevLanes {
     using Robot = DevLanes64;
+    static __device__ __forceinline__ unsigned long long lanebits(B b) { return __ballot((int)b); }
     static __device__ __forceinline__ F setlane(F x, int j, F src) {      // v_readlane + v_writelane: no lane mask to keep in SGPRs
         const int v = __builtin_amdgcn_readlane(__float_as_int(src), j);
         asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(v), "n"(j));      // j is a constant once the row loops are unrolled

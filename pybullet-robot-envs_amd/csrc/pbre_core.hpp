@@ -704,15 +704,19 @@ struct Core {
                 frow(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
             }
         };
-        const bool has_limit = LR::any(any_limit);
+        // bit j: joint j is at a limit in some group of the wave; the limit rows of all other joints are exact no-ops (J' = rhs = 0)
+        // and are skipped (iCub, IK control: +22 %).  Not on the 60-DoF shape: there the per-row scalar branches cost more than
+        // the skipped rows save (measured -8 %), so its limit sweep stays all-or-nothing.
+        const unsigned long long lim_bits = LR::lanebits(any_limit);
+        const bool has_limit = lim_bits != 0ull;
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
             PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
-            if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) limit(j); }
+            if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
             contacts();
             if (it + 1 >= P.iters) break;
             // odd iteration: forward order
-            if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) limit(j); }
+            if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
             PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
             contacts();
         }

@@ -24,6 +24,7 @@ struct HostLanesT {
     static F wide(const F& x) { return x; }
     static F fma_lo(const F& s, const F& m, const F& acc) { return fma(s, m, acc); }
     static F uni(const F& x) { return x; }
+    static unsigned long long lanebits(const B& b) { unsigned long long m = 0; for (int i = 0; i < W && i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
     static F setlane(const F& x, int j, const F& src) { F r = x; r.v[j] = src.v[j]; return r; }
     template <int N> struct RowStore {
         F v[N];
