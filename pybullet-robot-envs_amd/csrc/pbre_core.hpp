@@ -259,6 +259,7 @@ struct Core {
     // returns the per-lane rank (0..cap-1 in lane order) or -1.  Ties resolve to the lowest lane.
     static PBRE_HD I select_k(F dist, B valid, F margin, int cap, I lane) {
         B cand = L::band(valid, L::lt(dist, margin));
+        if (!L::any(cand)) return L::ci(-1);         // nothing within the margin anywhere in the wave (the usual case)
         B chosen = L::bfalse();
         for (int r = 0; r < cap; r++) {
             F key = L::sel(L::band(cand, L::bnot(chosen)), dist, L::c(3e38f));
@@ -288,6 +289,12 @@ struct Core {
     // fetch the contact whose rank == r from the candidate lanes (all fields become group-uniform)
     static PBRE_HD Contact fetch(I rank, int r, const V3& n, const V3& pA, const V3& pB, F dist, F mu, I owner, I lane) {
         B mine = L::eqi(rank, r);
+        if (!L::any(mine)) {                         // empty slot in every group of the wave: no gathers
+            Contact e;
+            const F z = L::c(0.f);
+            e.act = L::bfalse(); e.n = v3(z, z, z); e.pA = e.n; e.pB = e.n; e.dist = z; e.mu = z; e.owner = L::ci(0);
+            return e;
+        }
         F lk = L::sel(mine, L::itof(lane), L::c(999.f));
         F lm = L::vmin(lk);
         Contact c;
