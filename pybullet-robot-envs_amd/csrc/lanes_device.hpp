@@ -104,6 +104,7 @@ struct DevLanes {
         x = __builtin_fminf(x, dpp<0x140>(x));
         return x;
     }
+    static __device__ __forceinline__ F sum_obj(F x) { return sum(x); }    // all-reduce of a value that is zero on the robot lanes
 };
 
 // One env = one half-wave of 32 lanes (<= 20 DoF: the iCub without its legs), 2 envs per wave64.  Broadcasts / gathers are
@@ -125,6 +126,18 @@ struct DevLanes32 : DevLanes {
     }
     static __device__ __forceinline__ I gatherI(I a, I idx) { return __builtin_amdgcn_ds_bpermute((half_base() | (idx & 31)) << 2, a); }
     static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
+    // x is zero on lanes 0..15 of either half (robot joints 0..15; the object lanes 20..26 are in the upper row): the half's sum is
+    // its upper row's sum, r1 + r0 with r0 = 0 exactly.  Row butterfly, then lane 16 / 48 to every lane by v_readlane + a select
+    // by half -- no trip through the LDS crossbar (ds_swizzle) on the solver's serial chain; same value as sum() bit for bit.
+    static __device__ __forceinline__ F sum_obj(F x) {
+        x += dpp<0xB1>(x);
+        x += dpp<0x4E>(x);
+        x += dpp<0x141>(x);
+        x += dpp<0x140>(x);
+        const float lo_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+        const float hi_ = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+        return (threadIdx.x & 32u) ? hi_ : lo_;
+    }
     static __device__ __forceinline__ F swap16(F x) {     // lane i <-> lane i ^ 16 inside each 32-lane half (bit-mode swizzle: and 0x1F, or 0, xor 0x10)
         return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401F));
     }
@@ -299,6 +312,7 @@ struct DevLanes128 {
         return F{v, v};
     }
     static __device__ __forceinline__ F sum(F x) { const float s = D::sum(x.a + x.b); return F{s, s}; }
+    static __device__ __forceinline__ F sum_obj(F x) { return sum(x); }
     static __device__ __forceinline__ F vmin(F x) { const float s = D::vmin(__builtin_fminf(x.a, x.b)); return F{s, s}; }
 };
 

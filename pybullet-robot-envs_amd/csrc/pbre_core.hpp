@@ -327,16 +327,20 @@ struct Core {
     };
 
     // app / lim are group-uniform; L::uni tells a backend that stores a value in more than one register per lane so
+    // OBJ: the row only touches the object (object-table contacts): its J' is zero on every robot lane, which lets a backend
+    // use a cheaper all-reduce (L::sum_obj; same value bit for bit)
+    template <bool OBJ = false>
     static PBRE_HD void row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
         app = L::uni(app);
-        F t = L::sum(Jp * dv);
+        F t = OBJ ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);
         F s = L::med3(app - t, lo, hi);
         F d = s - app; app = s;
         dv = L::fma(d, Bv, dv);
     }
+    template <bool OBJ = false>
     static PBRE_HD void frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
         app = L::uni(app); lim = L::uni(lim);
-        F t = L::sum(Jp * dv);
+        F t = OBJ ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);
         F s = L::med3(app - t, L::c(0.f) - lim, lim);
         s = L::sel(L::gt(lim, L::c(0.f)), s, app);
         F d = s - app; app = s;
@@ -704,11 +708,19 @@ struct Core {
         bool on[NC];                         // some group of the wave has contact c
         PBRE_UNROLL for (int c = 0; c < NC; c++) on[c] = L::any(R.act[c]);
         auto contacts = [&]() {
-            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) row(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) {
+                if (c < NC_OT) row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+                else row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+            }
             PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) {
                 F lim = R.mu[c] * R.an[c];
-                frow(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
-                frow(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                if (c < NC_OT) {
+                    frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
+                    frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                } else {
+                    frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
+                    frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                }
             }
         };
         // bit j: joint j is at a limit in some group of the wave; the limit rows of all other joints are exact no-ops (J' = rhs = 0)

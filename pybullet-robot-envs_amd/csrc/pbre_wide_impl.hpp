@@ -17,7 +17,8 @@ namespace pbre {
 
 constexpr int WTPB = 256;                        // 4 independent waves per block
 static_assert(WTPB == 64 * DevLanes128::WPB, "DevLanes128 sizes its per-wave LDS regions for this block size");
-template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }   // physical lanes of one env group (Shape128: two virtual lanes each)
+template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }
+static_assert(Shape32::LC >= 16, "DevLanes32::sum_obj assumes the object lanes lie in the upper 16-lane row of the half-wave");   // physical lanes of one env group (Shape128: two virtual lanes each)
 struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };     // pbre_set_motors, by value
 
 template <class S, class L, int MODE>

@@ -98,6 +98,7 @@ struct HostLanesT {
         if (W == 32) return F(x.v[0] + x.v[16]);
         return x;
     }
+    static F sum_obj(const F& a) { return sum(a); }
     static F vmin(const F& a) { float m = a.v[0]; for (int i = 1; i < W; i++) m = std::fmin(m, a.v[i]); return F(m); }
 };
 using HostLanes = HostLanesT<16>;
