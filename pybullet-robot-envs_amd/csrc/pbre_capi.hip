@@ -95,15 +95,25 @@ __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __
 // Complex envs (robot contacts and/or limit rows), compacted per class.  Persistent blocks (the host does not know the
 // list lengths): work item w = (bucket, 64-env chunk); block b takes items b, b + gridDim.x, ...  The grid is one block
 // per SIMD (the kernel needs a whole SIMD's register file), blocks without work exit at once.
+// Scheduling hints for the host (pinned memory, written by one thread of the complex-env kernel of every step): [0] complex envs
+// stepped in this step, [1] 16 while there were any, counting down by one per step once there are none -- "no complex env for
+// the last 16 steps" is what lets the host drop the second stream (launch_step).  `recent` is the device copy of [1].
+static __device__ __forceinline__ void report_hint(int total, int* __restrict__ recent, int* __restrict__ host_total) {
+    int r = *recent;
+    r = total > 0 ? 16 : (r > 0 ? r - 1 : 0);
+    *recent = r;
+    host_total[0] = total; host_total[1] = r;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                  const float* __restrict__ tgt, int* __restrict__ host_total) {
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int* __restrict__ recent) {
     int chunks[NB], total = 0, envs = 0;
     PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; envs += cur_count[b]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *host_total = envs;    // pinned host memory: scheduling hint for the next launches
+    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(envs, recent, host_total);
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
         int b = 0, k = w;
         PBRE_UNROLL for (int j = 0; j < NB - 1; j++) if (b == j && k >= chunks[j]) { k -= chunks[j]; b = j + 1; }
@@ -128,10 +138,10 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base) {
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
     static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
     const int total = cur_count[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *host_total = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
     const int row = threadIdx.x >> 4;
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
     for (int base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {
@@ -171,10 +181,11 @@ __global__ __launch_bounds__(FTPB) void k_classify(const Tables* __restrict__ T,
     publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count, cap);
 }
 
-__global__ void k_total(const int* __restrict__ count, int* __restrict__ host_total) {
+__global__ void k_total(const int* __restrict__ count, int* __restrict__ host_total, int* __restrict__ recent) {
     int t = 0;
     for (int b = 0; b < NB; b++) t += count[b];
-    *host_total = t;
+    *recent = 0;
+    report_hint(t, recent, host_total);
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -234,6 +245,9 @@ struct pbre_ctx {
     bool fast_ok = false;
     int n_simd = 1024;
     int rc_first_min = 1;              // complex envs (reported by the device) from which their kernel is scheduled ahead of k_fast
+    int idle_touch = 16;               // in that mode, an (empty) fork / join through the side stream every idle_touch-th step: a side stream
+                                       // left idle for hundreds of steps makes the first steps after the switch back ~8 % slower (0: never)
+    int idle_single = 1;               // with no complex envs reported, both kernels go to the caller's stream in order (no fork / join events); 0: A/B
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -268,10 +282,10 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     if ((e = hipMemset(b.tgt, 0, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.cls, 0, (size_t)2 * cap)) != hipSuccess) return e;
     for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&b.count, 3 * NB * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipHostMalloc(&b.h_total, sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
-    *b.h_total = 1;                   // unknown until the first step has run
-    return hipMemset(b.count, 0, 3 * NB * sizeof(int));
+    if ((e = hipMalloc(&b.count, (3 * NB + 1) * sizeof(int))) != hipSuccess) return e;      // + the device copy of the "recent" hint
+    if ((e = hipHostMalloc(&b.h_total, 2 * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
+    b.h_total[0] = 1; b.h_total[1] = 16;   // unknown until the first step has run
+    return hipMemset(b.count, 0, (3 * NB + 1) * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
     for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
@@ -284,7 +298,7 @@ static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t
     hipError_t e = hipMemsetAsync(b.count + b.ccur * NB, 0, NB * sizeof(int), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls + (size_t)b.cur * b.cap, b.list[b.cur], b.count + b.ccur * NB, b.cap);
-    hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, b.count + b.ccur * NB, b.h_total);
+    hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, b.count + b.ccur * NB, b.h_total, b.count + 3 * NB);
     return hipGetLastError();
 }
 
@@ -309,13 +323,20 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     // an earlier step (a hint; either order is correct):
     //  * complex envs present: k_fast_rc (few waves, each needs a whole SIMD's register file, long latency) is enqueued first on
     //    the caller's stream so that its waves claim their SIMDs before k_fast floods the chip from the side stream;
-    //  * none (e.g. the first steps after a reset): k_fast stays on the caller's stream, the (empty) k_fast_rc goes to the side
-    //    stream, and consecutive k_fast launches run back to back without a cross-stream dependency on their critical path.
-    const int hint = *b.h_total;
+    //  * none (e.g. the first steps after a reset): the (empty) complex-env kernel and k_fast are enqueued in order on the caller's
+    //    stream, with no fork / join events at all: the event packets and the concurrently dispatched empty kernel cost 6 % of the
+    //    step (613 M -> 650 M env-steps/s at 131072 envs).  Taken only when the device has reported no complex env for 16 steps in a
+    //    row (a count that flickers between 0 and a few would otherwise serialise the two kernels every other step); a stale
+    //    hint only serialises them for that step.
+    const int hint = b.h_total[0];
     const bool rc_first = hint >= c->rc_first_min;
-    hipStream_t s_rc = rc_first ? s : c->side, s_fast = rc_first ? c->side : s;
-    if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
+    const bool single = c->idle_single && hint == 0 && b.h_total[1] == 0;      // both kernels in order on the caller's stream
+    hipStream_t s_rc = (rc_first || single) ? s : c->side, s_fast = (rc_first && !single) ? c->side : s;
+    const bool touch_side = single && c->idle_touch > 0 && (c->launches % c->idle_touch) == 0;   // keep the side stream's queue mapped
+    if (!single || touch_side) {
+        if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
+    }
     // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
     bool rows = NB == 1 && hint <= c->row_max;
     if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
@@ -324,12 +345,12 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         if (rows) {
             const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));
             hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(TPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
-                               b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap);
+                               b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
     }
     if (!rows)
         hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
-                           b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total);
+                           b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.count + 3 * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
     // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
@@ -340,8 +361,10 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
                        b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed) { (void)hipEventRecord(ek[1], s_fast); c->k_steps++; }
-    if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+    if (!single || touch_side) {
+        if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+    }
     b.ccur = cn;
     b.cur = nxt;
     return hipSuccess;
@@ -420,6 +443,8 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->ow = c->obs_dim + 2; c->device = cfg->device_id;
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     if (const char* ev = getenv("PBRE_RC_FIRST_MIN")) c->rc_first_min = atoi(ev);       // A/B knobs
+    if (const char* ev = getenv("PBRE_IDLE_SINGLE")) c->idle_single = atoi(ev);
+    if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
