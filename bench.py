@@ -131,6 +131,9 @@ def other_configs(torch, dev, steps=10):
     return out
 
 
+EV_EVERY = int(os.environ.get("PBRE_BENCH_EV_EVERY", "8"))     # torch event pairs around every EV_EVERY-th step of the timed region
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,16 +249,16 @@ def main():
 
         def timed(self, steps, events=False):
             barrier()
-            # event pairs around every 4th step only: an event record is a barrier packet on the stream, and a pair per step
+            # event pairs around every EV_EVERY-th (8th) step only: an event record is a barrier packet on the stream, and a pair per step
             # costs ~10% of the 0.2 ms kernel it brackets
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
             t0 = time.perf_counter()
             for k in range(steps):
-                self.step(evs[k] if (events and k % 4 == 0) else None)
+                self.step(evs[k] if (events and k % EV_EVERY == 0) else None)
             self.drain()
             barrier()
             elapsed = time.perf_counter() - t0
-            pair = float(np.mean([a.elapsed_time(b) for a, b in evs[::4]])) if events else 0.0
+            pair = float(np.mean([a.elapsed_time(b) for a, b in evs[::EV_EVERY]])) if events else 0.0
             return max_over_ranks([elapsed, pair])
 
     job = Job(args.envs * world, args.warmup + 3 * args.steps + args.steady_preroll)

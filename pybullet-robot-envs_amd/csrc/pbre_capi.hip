@@ -253,7 +253,8 @@ struct pbre_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
-    static constexpr int KSAMPLE = 4;          // (every KSAMPLE-th launch is sampled) recorded on the stream that kernel runs on
+    static constexpr int KSAMPLE = 8;          // (every KSAMPLE-th launch is sampled) recorded on the stream that kernel runs on
+    int ksample = KSAMPLE;                     // PBRE_KSAMPLE: A/B of the sampling interval
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
@@ -354,7 +355,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
     // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
-    const bool timed = (c->launches++ % pbre_ctx::KSAMPLE) == 0;
+    const bool timed = (c->launches++ % c->ksample) == 0;
     hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
     if (timed) (void)hipEventRecord(ek[0], s_fast);
     hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
@@ -444,6 +445,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     if (const char* ev = getenv("PBRE_RC_FIRST_MIN")) c->rc_first_min = atoi(ev);       // A/B knobs
     if (const char* ev = getenv("PBRE_IDLE_SINGLE")) c->idle_single = atoi(ev);
+    if (const char* ev = getenv("PBRE_KSAMPLE")) c->ksample = std::max(1, atoi(ev));
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     int ndev = 0;
