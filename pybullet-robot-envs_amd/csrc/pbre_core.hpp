@@ -728,6 +728,30 @@ struct Core {
         // the skipped rows save (measured -8 %), so its limit sweep stays all-or-nothing.
         const unsigned long long lim_bits = LR::lanebits(any_limit);
         const bool has_limit = lim_bits != 0ull;
+        // The usual wave: the object rests on the table with all four object-table slots in use and the robot touches nothing.
+        // That case gets its own copy of the loop without the per-slot branches (and their mask bookkeeping); rows of a group
+        // that lacks one of the contacts are exact no-ops either way.
+        bool only_ot = true;
+        PBRE_UNROLL for (int c = 0; c < NC; c++) only_ot = only_ot && (on[c] == (c < NC_OT));
+        auto contacts_ot = [&]() {
+            PBRE_UNROLL for (int c = 0; c < NC_OT; c++) row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+            PBRE_UNROLL for (int c = 0; c < NC_OT; c++) {
+                F lim = R.mu[c] * R.an[c];
+                frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
+                frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+            }
+        };
+        if (only_ot) {
+            for (int it = 0; it < P.iters; it += 2) {
+                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+                if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+                contacts_ot();
+                if (it + 1 >= P.iters) break;
+                if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+                PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+                contacts_ot();
+            }
+        } else
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
             PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);

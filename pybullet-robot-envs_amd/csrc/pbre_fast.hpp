@@ -633,6 +633,24 @@ struct Fast {
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
             if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) { rrow(c, 1); rrow(c, 2); } }
         };
+        // The usual wave of the simple-env kernel has all four object-table slots in use (the cube rests on the table in every
+        // env): that case gets its own copy of the loop without the per-slot "does any lane use it" branches, which cost two
+        // VALU + two SALU instructions per slot and iteration (rows of a lane without the contact are exact no-ops either way).
+        bool all_slots = !RC;
+        PBRE_UNROLL for (int c = 0; c < NK; c++) all_slots = all_slots && any_c[c];
+        if (all_slots) {
+            auto contacts_all = [&]() {
+                PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
+                PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+            };
+            for (int it = 0; it < P.iters; it += 2) {
+                PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
+                contacts_all();
+                if (it + 1 >= P.iters) break;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
+                contacts_all();
+            }
+        } else
         for (int it = 0; it < P.iters; it += 2) {
             PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
             if (RC && any_lim) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) limit(j); }
