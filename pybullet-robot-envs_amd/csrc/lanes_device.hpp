@@ -17,7 +17,14 @@ struct DevLanes {
     static __device__ __forceinline__ F wide(F x) { return x; }
     static __device__ __forceinline__ F fma_lo(F s, F m, F acc) { return __builtin_fmaf(s, m, acc); }
     static __device__ __forceinline__ F uni(F x) { return x; }     // a group-uniform value
-    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 15u) == j ? src : x; }   // lane j of every group <- src
+    // lane j of every group <- src.  Written as one compare + select pair in asm: as plain C++ the compiler hoists the 2 x n_dof
+    // loop-invariant lane masks of the solver's row sweeps into SGPR pairs, runs out of SGPRs, and reloads every mask from a spill
+    // VGPR with two v_readlane per row.
+    static __device__ __forceinline__ F setlane_l(F x, int j, F src, int lane_) {
+        asm("v_cmp_eq_u32_e32 vcc, %2, %1\n\tv_cndmask_b32_e32 %0, %0, %3, vcc" : "+v"(x) : "v"(lane_), "n"(j), "v"(src) : "vcc");
+        return x;
+    }
+    static __device__ __forceinline__ F setlane(F x, int j, F src) { return setlane_l(x, j, src, (int)(threadIdx.x & 15u)); }
     static __device__ __forceinline__ unsigned long long lanebits(B b) {      // bit j: b holds on lane j of some group of the wave
         unsigned long long m = __ballot((int)b);
         m |= m >> 32; m |= m >> 16;
@@ -111,7 +118,7 @@ struct DevLanes {
 // ds_bpermute_b32 inside the half-wave; an all-reduce is the 16-lane DPP butterfly plus one ds_swizzle_b32 (xor 16).
 struct DevLanes32 : DevLanes {
     using Robot = DevLanes32;
-    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }
+    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }     // (the asm pair of the 16-lane backend measured 1.5 % slower here)
     static __device__ __forceinline__ unsigned long long lanebits(B b) { unsigned long long m = __ballot((int)b); return (m | (m >> 32)) & 0xFFFFFFFFull; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
