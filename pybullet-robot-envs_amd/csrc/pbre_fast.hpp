@@ -690,7 +690,7 @@ struct Fast {
         // are re-read after the solver loop instead of keeping ~130 of them live across it.
         const Tables* T2 = &T;
         PBRE_LAUNDER(T2);
-        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id);
+        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC);
     }
 
     // Class of a state (same distance arithmetic as the contact candidates of step_t<true>):
@@ -707,7 +707,9 @@ struct Fast {
 
     // One streaming sweep over the links (a link's frame is dropped as soon as its children are done): kinematics, the
     // class of the state, and -- when qd is given -- the frame and spatial velocity of the end-effector's owner link.
-    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags) {
+    // `bounds`: try cheap wave-wide lower bounds before the exact sphere-box distances (the simple-env kernel, where every lane is
+    // normally far from any contact; on the few waves of the complex-env kernels the extra tests would only add latency)
+    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags, bool bounds = false) {
         const bool obj_on = !(flags & 1);
         Tail t;
         bool lim = false;
@@ -716,6 +718,7 @@ struct Fast {
         const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
         const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
         M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+        const float orad = sqrtf(dot(oh, oh)), ztop = tc.z + th.z;
         int nO = 0, nT = 0;
         const int eo = T.ee_owner;
         t.Va = v3(0.f, 0.f, 0.f); t.Vl = v3(0.f, 0.f, 0.f); t.pe = v3(0.f, 0.f, 0.f);
@@ -741,8 +744,15 @@ struct Fast {
             for (int s = 0; s < T.nspheres; s++) {
                 if (T.s_owner[s] != j) continue;
                 V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
-                if (obj_on && sphere_box_dist(sc, T.s_r[s], op, Ro, oh) < P.margin) nO++;
-                if (sphere_box_dist(sc, T.s_r[s], tc, Id, th) < P.margin) nT++;
+                // cheap lower bounds on the two distances first (bounding sphere of the object; height above the table top); the
+                // exact sphere-box tests (a square root each) only run if some lane of the wave is not clearly far
+                const float sr = T.s_r[s];
+                if (obj_on) {
+                    const V3 dd = sub(sc, op);
+                    const float reach = sr + P.margin + orad;
+                    if ((!bounds || PBRE_ANY(!(dot(dd, dd) >= reach * reach))) && sphere_box_dist(sc, sr, op, Ro, oh) < P.margin) nO++;
+                }
+                if ((!bounds || PBRE_ANY(!(sc.z - sr - ztop >= P.margin))) && sphere_box_dist(sc, sr, tc, Id, th) < P.margin) nT++;
             }
             if (qd) {
                 bool anc = false;      // is j an ancestor-or-self of the EE owner?  (compile-time tree, uniform runtime owner)
@@ -886,12 +896,12 @@ struct Fast {
     // re-initialised right here (snapshot reset): the transition's reward and done flag are returned
     // together with the first observation of the next episode.
     static PBRE_HD int finish(const Tables& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
-                              float* out, int mode, int flags, unsigned long long env_id) {
+                              float* out, int mode, int flags, unsigned long long env_id, bool bounds = false) {
         const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
         float reward = 0.f, done = 0.f;
         int cls = 0;
         for (int pass = 0; pass < 2; pass++) {
-            const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
+            const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds);
             cls = tl.cls;
             if (!want_obs) return cls;
             const M3 Re = tl.Re; const V3 pe = tl.pe, Va = tl.Va, Vl = tl.Vl;
