@@ -327,7 +327,7 @@ def main():
             d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")))["k_fast<7>"]
             sq = {"valu_insts_per_wave": d["valu_insts_per_wave"], "valu_active_over_wave_cycles": d["valu_active_over_wave_cycles"],
                   "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "waves_per_simd": 2,
-                  "note": "2 waves per SIMD x this per-wave VALU-active fraction = VALU pipe ~93% busy while the waves are resident"}
+                  "note": "2 waves per SIMD x this per-wave VALU-active fraction = VALU pipe ~95% busy while the waves are resident"}
         except Exception:
             pass
         res = {
