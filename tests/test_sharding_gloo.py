@@ -67,6 +67,64 @@ def test_two_rank_gather_equals_single_process(panda, emu_lib):
         assert np.array_equal(res[k + 1], np.concatenate([o, r[:, None], d[:, None]], 1))
 
 
+def _hands_worker(rank, world, port, total, steps, q):
+    sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import parity
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_hands_table, GRASP_POS
+    from pybullet_robot_envs.sharding import ShardedEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _capi.load(os.path.join(ROOT, "tests", "host_emu", "build", "libpbre_emu.so"))
+    tbl, _, info = icub_hands_table("r")
+    se = ShardedEngine(tbl, total, task=_capi.TASK_REACH, lib=lib, device_id=0, robot=_capi.ROBOT_ICUB_HANDS, obj_pose_rnd_std=0.04,
+                       **parity.hands_overrides(info, "r", 0))
+    home = np.asarray(info["home"], np.float32)[info["controlled"]]
+    acts = home[None, None, :] + np.random.default_rng(12).uniform(-0.2, 0.2, (steps, total, len(home))).astype(np.float32)
+    res = [se.reset()]
+    se.engine.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0)          # finger command on every shard
+    for k in range(steps):
+        r = se.step(acts[k, se.env_id_base:se.env_id_base + se.n_local])
+        res.append(None if r is None else np.concatenate([r[0], r[1][:, None], r[2][:, None]], 1))
+    dist.barrier()
+    if rank == 0:
+        q.put(res)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_icub_hands(emu_lib):
+    """BASELINE config 5's sharding: the iCub-with-hands batch split over two ranks equals the single-process batch bit for bit."""
+    import torch.multiprocessing as mp
+    import parity
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_hands_table, GRASP_POS
+    total, steps, world = 2, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hands_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tbl, _, info = icub_hands_table("r")
+    eng = _capi.Engine(tbl, task=_capi.TASK_REACH, num_envs=total, lib=emu_lib, robot=_capi.ROBOT_ICUB_HANDS, obj_pose_rnd_std=0.04,
+                       **parity.hands_overrides(info, "r", 0))
+    home = np.asarray(info["home"], np.float32)[info["controlled"]]
+    acts = home[None, None, :] + np.random.default_rng(12).uniform(-0.2, 0.2, (steps, total, len(home))).astype(np.float32)
+    assert np.array_equal(res[0], eng.reset())
+    assert np.ptp(res[0][:, 46]) > 1e-4                                  # the two envs got different object poses
+    eng.set_motors(info["fingers"], GRASP_POS, 0.1, 10.0)
+    for k in range(steps):
+        o, r, d = eng.step(acts[k])
+        assert np.array_equal(res[k + 1], np.concatenate([o, r[:, None], d[:, None]], 1))
+
+
 def test_shard_range():
     from pybullet_robot_envs.sharding import shard_range
     assert shard_range(131072, 3, 8) == (49152, 16384)
