@@ -724,10 +724,27 @@ struct Core {
             }
         };
         // bit j: joint j is at a limit in some group of the wave; the limit rows of all other joints are exact no-ops (J' = rhs = 0)
-        // and are skipped (iCub, IK control: +22 %).  Not on the 60-DoF shape: there the per-row scalar branches cost more than
-        // the skipped rows save (measured -8 %), so its limit sweep stays all-or-nothing.
+        // and are skipped (iCub, IK control: +22 %)
         const unsigned long long lim_bits = LR::lanebits(any_limit);
         const bool has_limit = lim_bits != 0ull;
+        // sweeps over the limit rows: per joint on the small shapes; on the 60-DoF shape per block of 10 joints (there a scalar
+        // test per row costs more than the skipped rows save, but whole idle blocks -- arms away from their limits while the
+        // resting fingers sit on theirs -- are worth skipping)
+        constexpr int LB = 10;
+        auto limits_fwd = [&]() {
+            if (NJ <= 40) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit(j); }
+            else {
+                PBRE_UNROLL for (int b0 = 0; b0 < NJ; b0 += LB)
+                    if ((lim_bits >> b0) & ((1ull << LB) - 1ull)) { PBRE_UNROLL for (int j = b0; j < b0 + LB && j < NJ; j++) limit(j); }
+            }
+        };
+        auto limits_bwd = [&]() {
+            if (NJ <= 40) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit(j); }
+            else {
+                PBRE_UNROLL for (int b0 = ((NJ - 1) / LB) * LB; b0 >= 0; b0 -= LB)
+                    if ((lim_bits >> b0) & ((1ull << LB) - 1ull)) { PBRE_UNROLL for (int j = (b0 + LB < NJ ? b0 + LB : NJ) - 1; j >= b0; j--) limit(j); }
+            }
+        };
         // The usual wave: the object rests on the table with all four object-table slots in use and the robot touches nothing.
         // That case gets its own copy of the loop without the per-slot branches (and their mask bookkeeping); rows of a group
         // that lacks one of the contacts are exact no-ops either way.
@@ -744,10 +761,10 @@ struct Core {
         if (only_ot) {
             for (int it = 0; it < P.iters; it += 2) {
                 PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
-                if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+                if (has_limit) limits_bwd();
                 contacts_ot();
                 if (it + 1 >= P.iters) break;
-                if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+                if (has_limit) limits_fwd();
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
                 contacts_ot();
             }
@@ -755,11 +772,11 @@ struct Core {
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
             PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
-            if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+            if (has_limit) limits_bwd();
             contacts();
             if (it + 1 >= P.iters) break;
             // odd iteration: forward order
-            if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if (NJ > 40 || ((lim_bits >> j) & 1ull)) limit(j); }
+            if (has_limit) limits_fwd();
             PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
             contacts();
         }
