@@ -706,13 +706,14 @@ struct Core {
             dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);
         };
         bool on[NC];                         // some group of the wave has contact c
-        PBRE_UNROLL for (int c = 0; c < NC; c++) on[c] = L::any(R.act[c]);
+        unsigned on_bits = 0u;               // the same as a scalar bit mask: tested with one SALU instruction per slot inside the loop
+        PBRE_UNROLL for (int c = 0; c < NC; c++) { on[c] = L::any(R.act[c]); on_bits |= on[c] ? (1u << c) : 0u; }
         auto contacts = [&]() {
-            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) {
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if ((on_bits >> c) & 1u) {
                 if (c < NC_OT) row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
                 else row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
             }
-            PBRE_UNROLL for (int c = 0; c < NC; c++) if (on[c]) {
+            PBRE_UNROLL for (int c = 0; c < NC; c++) if ((on_bits >> c) & 1u) {
                 F lim = R.mu[c] * R.an[c];
                 if (c < NC_OT) {
                     frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
