@@ -108,3 +108,39 @@ def test_fingertip_statistics(robot):
         assert n == int(G[t + "contacts%d_n" % ci])
         assert np.allclose(forces, G[t + "contacts%d_f" % ci], atol=1e-6)
         assert r.check_collision() == bool(G[t + "contacts%d_collision" % ci])
+
+
+def test_hand_pose_commands_3_6_7_values(emu_lib):
+    """IK control: a quaternion command (7 values, used as given) and the Euler command (6 values) of the same pose give the same motor
+    targets; with control_orientation=0 the engine takes 3 values and keeps the home orientation; the hand goes where it is told."""
+    import math as m
+    cid = _client.connect(1, lib=emu_lib)
+    r = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+    eu = [0.1, 0.2, 1.2]                                    # inside the right arm's Euler limits
+    cr, sr, cp, sp, cy, sy = m.cos(eu[0] / 2), m.sin(eu[0] / 2), m.cos(eu[1] / 2), m.sin(eu[1] / 2), m.cos(eu[2] / 2), m.sin(eu[2] / 2)
+    q = [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+    st = r._engine.get_state()
+    r.apply_action([0.3, -0.15, 0.8] + eu)
+    m6 = r._engine.get_motor_state()
+    r._engine.set_state(st)
+    r.apply_action([0.3, -0.15, 0.8] + q)
+    m7 = r._engine.get_motor_state()
+    assert np.abs(m6 - m7).max() < 2e-4
+    assert (m6[0, 1, :60] == np.float32(0.2)).all() and (m6[0, 2, :60] == 1.0).all()     # every joint commanded, gain 0.2, default force
+    # Euler commands are clipped to the arm's limits (yaw of the right arm: [0, pi]), quaternions are not
+    r._engine.set_state(st); r.apply_action([0.3, -0.15, 0.8, 0.0, 0.0, -1.0]); a = r._engine.get_motor_state()
+    r._engine.set_state(st); r.apply_action([0.3, -0.15, 0.8, 0.0, 0.0, 0.0]); b = r._engine.get_motor_state()
+    assert np.abs(a - b).max() < 1e-6
+    r.step_simulation(40)
+    obs, _ = r.get_observation()
+    assert np.abs(np.asarray(obs[:3]) - [0.3, -0.15, 0.8]).max() < 5e-3
+    with pytest.raises(AssertionError):
+        r.apply_action([0.3, 0.0])
+    _client.disconnect(cid)
+    cid = _client.connect(1, lib=emu_lib)
+    r3 = iCubHandsEnv(cid, use_IK=1, control_arm='l', control_orientation=0)
+    assert r3.get_action_dim() == 3 and r3._engine.act_dim == 3
+    r3.apply_action([0.3, 0.2, 0.85]); r3.step_simulation(40)
+    obs, _ = r3.get_observation()
+    assert np.abs(np.asarray(obs[:3]) - [0.3, 0.2, 0.85]).max() < 5e-3
+    _client.disconnect(cid)
