@@ -216,6 +216,29 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
     return eng
 
 
+def check_icub_force_limited(Engine, lib, n=1, steps=3, imp=0.004):
+    """iCub with a motor impulse bound that binds (pbre_physics.max_motor_impulse; ~1 N m against gravity torques of a few N m):
+    the clamp-free motor rows of the half-wave solver must hand over to the clamping rows (pbre_core.hpp FREE_ROWS)."""
+    eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=0, phys={"max_motor_impulse": imp})
+    ref, _, _ = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=0)
+    ora.params.max_motor_impulse = imp
+    xo = eng.x_off
+    eng.reset(); ref.reset()
+    st, _ = ora.batch_reset(n)
+    assert rel(eng.get_state()[:, :xo], st[:, :xo]).max() < 2e-3
+    assert rel(ref.get_state()[:, :xo], eng.get_state()[:, :xo]).max() > 1e-3, "the bound does not bind: nothing tested"
+    rng = np.random.default_rng(4)
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(s32.astype(np.float64), a)
+        assert rel(eng.get_state()[:, :xo], st[:, :xo]).max() < 2e-3, (k, rel(eng.get_state()[:, :xo], st[:, :xo]).max())
+        assert rel(ob, out[:, :-2]).max() < 2e-2
+    return eng
+
+
 def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
     """action_repeat = 3 (apply_action loop with the reference's compounding in-place action scaling, break on termination,
     counter per iteration) against the oracle: free-running, so that envs leave the loop in different iterations."""

@@ -54,3 +54,7 @@ def test_icub_implicit_joint_damping(emu_lib):
     ob, rw, dn = eng.step(a)
     so, out = ora.batch_step(st.astype(np.float32).astype(np.float64), a)
     assert parity.rel(eng.get_state()[:, :xo], so[:, :xo]).max() < 2e-3 and parity.rel(ob, out[:, :-2]).max() < 2e-2
+
+
+def test_icub_force_limited_motors(emu_lib):
+    parity.check_icub_force_limited(_capi.Engine, emu_lib)

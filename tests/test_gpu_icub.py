@@ -70,3 +70,7 @@ def test_icub_auto_reset(hip_lib):
 def test_icub_action_repeat(hip_lib):
     import test_emu_icub
     test_emu_icub.test_icub_action_repeat(hip_lib)
+
+
+def test_icub_force_limited_motors(hip_lib):
+    parity.check_icub_force_limited(_capi.Engine, hip_lib, n=5, steps=4)
