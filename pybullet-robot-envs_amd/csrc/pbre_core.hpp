@@ -349,8 +349,10 @@ struct Core {
 
     // One simulation step for one env group.  st: pointer to the env's 48-float record.
     // act: pointer to this env's action row or nullptr.  out: this env's [obs_dim+2] row or nullptr.
+    // objv: nullptr, or this group's W-float side record whose object-twist lanes hold the object's twist after a step without
+    // robot-object contact (pbre_objstep.hpp); used by the groups that have no such contact.
     static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                             const float* tgt = nullptr, unsigned long long env_id = 0) {
+                             const float* tgt = nullptr, unsigned long long env_id = 0, const float* objv = nullptr) {
         const I lane = L::lane();
         const F zero = L::c(0.f), one = L::c(1.f);
         const B robot = L::lti(lane, NJ);
@@ -597,6 +599,18 @@ struct Core {
             return fetch(rk_rt, c - NC_OT - NC_RO, n_rt, pA_rt, pB_rt, d_rt, smu * L::c(P.tab_mu), so, lane);
         };
         I owner_ro[NC_RO];           // link lane of each robot-object contact (fingertip bookkeeping)
+        // Groups without a robot-object contact: robot rows and object rows share no unknown, the object's half of the solve was done
+        // by kw_obj (one thread per env).  `split`: lanes of such groups; split_all: the whole wave -- then the object-table rows are
+        // not even built.  In a mixed wave a split group's object rows are solved along with the others' and their result dropped,
+        // so what an env computes never depends on the env it shares a wave with.
+        const bool use_objv = objv != nullptr && obj_on;
+        B split = L::lti(lane, 0);
+        bool split_all = false;
+        if (use_objv) {
+            const Contact c0 = contact_of(NC_OT);       // slots fill in rank order: slot 0 is in use iff there is any such contact
+            split = L::bnot(c0.act);
+            split_all = !L::any(c0.act);
+        }
 
         // ---- constraint rows
         // motors (btMultiBodyJointMotor, POSITION_CONTROL): velocity error kp (q_des - q)/dt - kd v*
@@ -623,10 +637,15 @@ struct Core {
         const F inv_m = L::c(1.f / P.obj_m);
         PBRE_UNROLL for (int c = 0; c < NC; c++) {
             const int type = c < NC_OT ? 0 : (c < NC_OT + NC_RO ? 1 : 2);
+            R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
+            if (type == 0 && split_all) {
+                R.act[c] = L::lti(lane, 0); R.mu[c] = L::uni(zero);
+                PBRE_UNROLL for (int k = 0; k < 6; k++) R.rs.put(6 * c + k, zero);
+                continue;
+            }
             const Contact cc = contact_of(c);
             if (type == 1) owner_ro[c - NC_OT] = cc.owner;
             R.act[c] = cc.act; R.mu[c] = L::uni(L::sel(cc.act, cc.mu, zero));
-            R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
             if (!L::any(cc.act)) { PBRE_UNROLL for (int k = 0; k < 6; k++) R.rs.put(6 * c + k, zero); continue; }
             // btPlaneSpace1
             V3 n = cc.n, t1, t2;
@@ -769,6 +788,14 @@ struct Core {
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
                 contacts_ot();
             }
+        } else if (on_bits == 0u) {      // no contact row in the wave (the object rows are kw_obj's, or there is no object)
+            for (int it = 0; it < P.iters; it += 2) {
+                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+                if (has_limit) limits_bwd();
+                if (it + 1 >= P.iters) break;
+                if (has_limit) limits_fwd();
+                PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+            }
         } else
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
@@ -784,6 +811,7 @@ struct Core {
 
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
+        if (use_objv) vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew);
         B dyn = obj_on ? L::bor(robot, obj_lane) : robot;
         F Vn = L::sel(dyn, vnew, Vr);
         B posl = obj_on ? L::lti(lane, LC + 3) : robot;

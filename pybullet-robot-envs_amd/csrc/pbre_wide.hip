@@ -80,7 +80,7 @@ void wide_destroy(WideEngine* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     w->free_tables();
     for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
-                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask})
+                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : w->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
@@ -118,6 +118,14 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     CK(hipMalloc(&w->tgt_tmp, n * nj * sizeof(float)));
     CK(hipMemset(w->tgt, 0, n * nj * sizeof(float)));
     CK(hipMemset(w->tgt_tmp, 0, n * nj * sizeof(float)));
+    {   // side records of the per-env object solve (pbre_objstep.hpp); PBRE_OBJ_SPLIT=0 keeps every object row in kw_step (A/B runs)
+        const char* knob = getenv("PBRE_OBJ_SPLIT");
+        if (!(knob && knob[0] == '0')) {
+            const size_t wl = (sf - 16) / 2;
+            CK(hipMalloc(&w->objv, n * wl * sizeof(float)));
+            CK(hipMemset(w->objv, 0, n * wl * sizeof(float)));
+        }
+    }
     CK(hipMalloc(&w->d_act, n * w->act_dim * sizeof(float)));
     CK(hipMalloc(&w->d_out, n * w->ow * sizeof(float)));
     CK(hipMalloc(&w->d_ids, n * sizeof(unsigned long long)));

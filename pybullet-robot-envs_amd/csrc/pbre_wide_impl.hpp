@@ -11,6 +11,7 @@
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
+#include "pbre_objstep.hpp"
 #include "pbre_wide.hpp"
 
 namespace pbre {
@@ -24,14 +25,27 @@ struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };    
 template <class S, class L, int MODE>
 __global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
-                                                   int flags, const float* __restrict__ tgt) {
+                                                   int flags, const float* __restrict__ tgt, const float* __restrict__ objv) {
     using C = Core<L, S>;
     constexpr int EPB = WTPB / phys_lanes<S>();
     const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
     if (env >= n) return;                           // whole lane group; a partially filled wave keeps running its other group
     C::step(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
             (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, ((MODE & C::M_TGT) || S::MREC) ? tgt + (size_t)env * S::TGT : nullptr,
-            P.env_id_base + (unsigned long long)env);
+            P.env_id_base + (unsigned long long)env, objv ? objv + (size_t)env * S::W : nullptr);
+}
+// The object's half of the step for every env, one thread per env (pbre_objstep.hpp): twist after a step without robot-object contact,
+// into the object lanes of the env's side record.  kw_step takes it where its collision detection finds no such contact.
+template <class S>
+__global__ __launch_bounds__(64) void kw_obj(const Params P, const float* __restrict__ state, float* __restrict__ objv, int n) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n) return;
+    const float* st = state + (size_t)e * S::STATE;
+    float pose[7], tw[6], o[6];
+    PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[S::LC + k];
+    PBRE_UNROLL for (int k = 0; k < 6; k++) tw[k] = st[S::W + S::LC + k];
+    ObjStep::run(P, pose, tw, o);
+    PBRE_UNROLL for (int k = 0; k < 6; k++) objv[(size_t)e * S::W + S::LC + k] = o[k];
 }
 template <class S, class L, bool RESET>
 __global__ __launch_bounds__(WTPB) void kw_ik(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
@@ -101,6 +115,7 @@ struct WideEngine {
     unsigned char* d_mask = nullptr;
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
+    float* objv = nullptr;                    // [n][W] side records of kw_obj, or nullptr: object rows always solved in kw_step
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -147,7 +162,9 @@ struct WideImpl : WideEngine {
     void free_tables() override { if (dT) (void)hipFree(dT); dT = nullptr; }
     template <int MODE>
     void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
-        hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg);
+        const float* ov = (objv && !(flags & 1)) ? objv : nullptr;
+        if (ov) hipLaunchKernelGGL((kw_obj<S>), dim3((cnt + 63) / 64), dim3(64), 0, s, P, st, objv, cnt);
+        hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg, ov);
     }
     void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) override {
         constexpr int OT = C::M_OBS | C::M_TASK;

@@ -11,6 +11,7 @@
 #include "../../pybullet-robot-envs_amd/csrc/pbre_host.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
+#include "../../pybullet-robot-envs_amd/csrc/pbre_objstep.hpp"
 
 #include <type_traits>
 
@@ -25,6 +26,7 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     std::string err;
     bool fast_ok = false;
     long n_fast = 0, n_rc = 0, n_general = 0;
+    bool obj_split = !(getenv("PBRE_OBJ_SPLIT") && getenv("PBRE_OBJ_SPLIT")[0] == '0');
     virtual ~pbre_ctx() {}
     virtual void reset(const uint8_t* mask) = 0;
     virtual void step(const float* actions, float* out) = 0;
@@ -64,6 +66,19 @@ struct Emu : pbre_ctx {
             }
         }
         n_general++;
+        if constexpr (!PANDA) {
+            // the device's kw_obj + kw_step pair (pbre_wide_impl.hpp): the object's half of the step per env, used by Core::step
+            // when the group has no robot-object contact
+            if (obj_split && !(flags & 1)) {
+                float side[W] = {0.f}, pose[7], tw[6], o[6];
+                for (int k = 0; k < 7; k++) pose[k] = st[S::LC + k];
+                for (int k = 0; k < 6; k++) tw[k] = st[W + S::LC + k];
+                ObjStep::run(P, pose, tw, o);
+                for (int k = 0; k < 6; k++) side[S::LC + k] = o[k];
+                CoreH::step(T, P, st, act, out, mode, flags, tg, env_id, side);
+                return;
+            }
+        }
         CoreH::step(T, P, st, act, out, mode, flags, tg, env_id);
     }
     void ik(float* st, const float* act, float* tg, bool rst) {

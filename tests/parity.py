@@ -239,6 +239,48 @@ def check_icub_force_limited(Engine, lib, n=1, steps=3, imp=0.004):
     return eng
 
 
+def check_obj_split(Engine, lib, n=4, steps=3):
+    """Lane-group engines solve the object's rows per env in a kernel of their own (pbre_objstep.hpp) and use the result in every env
+    whose robot does not touch the object.  Against the same engine with PBRE_OBJ_SPLIT=0 (all rows in one solve): the robot's state
+    is bit-identical either way, the object agrees to rounding, an env WITH a robot-object contact is bit-identical as a whole even
+    when it shares a wavefront with one without (env 1 of each pair has the object pushed into the hand), and all of it matches
+    the oracle's coupled solve."""
+    import os
+    os.environ["PBRE_OBJ_SPLIT"] = "0"
+    try:
+        one, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=1, obj_std=0.05, tg_std=0.2)
+    finally:
+        del os.environ["PBRE_OBJ_SPLIT"]
+    two, _, _ = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=1, obj_std=0.05, tg_std=0.2)
+    xo, lc = one.x_off, 20
+    one.reset(); two.reset()
+    s1, s2 = one.get_state(), two.get_state()
+    assert np.array_equal(s1[:, :lc], s2[:, :lc]) and np.array_equal(s1[:, 32:32 + lc], s2[:, 32:32 + lc])
+    assert np.abs(s1 - s2).max() < 1e-5
+    st, _ = ora.batch_reset(n)
+    hand = two.observe()[:, :3]
+    st = st.copy()
+    st[1::2, lc:lc + 3] = hand[1::2] + np.array([0.0, 0.0, -0.045])      # object right under the hand of every second env
+    rng = np.random.default_rng(8)
+    touched = 0.0
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, one.act_dim)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        one.set_state(s32); two.set_state(s32)
+        o1, r1, d1 = one.step(a)
+        o2, r2, d2 = two.step(a)
+        st, out = ora.batch_step(s32.astype(np.float64), a)
+        e1, e2 = one.get_state(), two.get_state()
+        assert np.array_equal(e1[:, :lc], e2[:, :lc]) and np.array_equal(e1[:, 32:32 + lc], e2[:, 32:32 + lc]), k
+        assert np.array_equal(e1[1::2], e2[1::2]) and np.array_equal(o1[1::2], o2[1::2]), k
+        assert np.abs(e1 - e2).max() < 1e-5 and np.abs(o1 - o2).max() < 1e-4
+        assert rel(e2[:, :xo], st[:, :xo]).max() < 2e-3, (k, rel(e2[:, :xo], st[:, :xo]).max())
+        assert rel(o2, out[:, :-2]).max() < 2e-2
+        touched = max(touched, np.abs(st[1::2, 32 + lc:32 + lc + 2]).max())
+    assert touched > 1e-3, "the hand never pushed the object: the coupled case was not exercised"
+    return two
+
+
 def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
     """action_repeat = 3 (apply_action loop with the reference's compounding in-place action scaling, break on termination,
     counter per iteration) against the oracle: free-running, so that envs leave the loop in different iterations."""

@@ -58,3 +58,7 @@ def test_icub_implicit_joint_damping(emu_lib):
 
 def test_icub_force_limited_motors(emu_lib):
     parity.check_icub_force_limited(_capi.Engine, emu_lib)
+
+
+def test_icub_object_rows_split(emu_lib):
+    parity.check_obj_split(_capi.Engine, emu_lib, n=2)

@@ -74,3 +74,7 @@ def test_icub_action_repeat(hip_lib):
 
 def test_icub_force_limited_motors(hip_lib):
     parity.check_icub_force_limited(_capi.Engine, hip_lib, n=5, steps=4)
+
+
+def test_icub_object_rows_split(hip_lib):
+    parity.check_obj_split(_capi.Engine, hip_lib, n=7, steps=4)
