@@ -23,6 +23,9 @@ timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | 
 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/icub_bench_$TAG.json
 timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 2>&1 | tail -1 | tee gpurun_out/hands_bench_$TAG.json
 timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/hands_bench_$TAG.json
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/bench_icub.py --envs 32768 --steps 20 > $ROOTDIR/gpurun_out/rocprof_icub_$TAG.log 2>&1)
+f=$(find gpurun_out/prof_icub_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
+find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" -size +8M -delete; find gpurun_out/prof_icub_$TAG -name "*.db" -delete
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_hands_$TAG -o run -- python $ROOTDIR/tools/bench_hands.py --envs 8192 --steps 20 > $ROOTDIR/gpurun_out/rocprof_hands_$TAG.log 2>&1)
 f=$(find gpurun_out/prof_hands_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
 find gpurun_out/prof_hands_$TAG -name "*kernel_trace.csv" -size +8M -delete; find gpurun_out/prof_hands_$TAG -name "*.db" -delete
