@@ -118,7 +118,10 @@ struct DevLanes {
 // ds_bpermute_b32 inside the half-wave; an all-reduce is the 16-lane DPP butterfly plus one ds_swizzle_b32 (xor 16).
 struct DevLanes32 : DevLanes {
     using Robot = DevLanes32;
-    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }     // (the asm pair of the 16-lane backend measured 1.5 % slower here)
+    // (measured slower here: the 16-lane backend's compare + select pair in asm, -1.5 %; the mask written to VCC by two s_mov and one
+    // select, as in DevLanes64::setlane, -6 % although it removes the v_readlane pairs that restore the compiler's spilled SGPR masks
+    // -- the half-wave solver loop is bound by its per-wave serial chain, not by VALU issue)
+    static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }
     static __device__ __forceinline__ unsigned long long lanebits(B b) { unsigned long long m = __ballot((int)b); return (m | (m >> 32)) & 0xFFFFFFFFull; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
@@ -171,9 +174,9 @@ struct DevLanes32 : DevLanes {
 struct DevLanes64 : DevLanes {
     using Robot = DevLanes64;
     static __device__ __forceinline__ unsigned long long lanebits(B b) { return __ballot((int)b); }
-    static __device__ __forceinline__ F setlane(F x, int j, F src) {      // v_readlane + v_writelane: no lane mask to keep in SGPRs
-        const int v = __builtin_amdgcn_readlane(__float_as_int(src), j);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(v), "n"(j));      // j is a constant once the row loops are unrolled
+    static __device__ __forceinline__ F setlane(F x, int j, F src) {      // constant one-lane mask written to VCC by the scalar unit + one select
+        asm("s_mov_b32 vcc_lo, %2\n\ts_mov_b32 vcc_hi, %3\n\tv_cndmask_b32_e32 %0, %0, %1, vcc"       // (j is a constant once the row loops are unrolled)
+            : "+v"(x) : "v"(src), "n"(j < 32 ? 1u << (j & 31) : 0u), "n"(j >= 32 ? 1u << (j & 31) : 0u) : "vcc");
         return x;
     }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }

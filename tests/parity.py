@@ -281,6 +281,28 @@ def check_obj_split(Engine, lib, n=4, steps=3):
     return two
 
 
+def check_icub_full_model(Engine, lib, n=2, steps=3):
+    """The unpruned iCub (32 DoF with the legs: one env per 64-lane group, Shape64) against the engine's default 20-DoF model
+    (Shape32): the legs cannot change any output (tests/test_golden_icub.py::test_pruned_legs_are_exact shows it for the oracle), so
+    observations, rewards and terminations of the two engines agree to fp32 rounding through reset and closed-loop steps."""
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_table
+    tblf, _, infof = icub_table("l", full=True)
+    ov = icub_overrides(infof, "l", 1, 0, 1)
+    full = Engine(tblf, task=1, num_envs=n, lib=lib, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, **ov)
+    small, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=1, obj_std=0.05, tg_std=0.2)
+    assert full.state_floats == 144 and small.state_floats == 80 and full.obs_dim == small.obs_dim
+    of, os_ = full.reset(), small.reset()
+    assert rel(of, os_).max() < 2e-3, rel(of, os_).max()
+    rng = np.random.default_rng(12)
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, small.act_dim)).astype(np.float32)
+        (of, rf, df), (os_, rs, ds) = full.step(a), small.step(a)
+        assert rel(of, os_).max() < 5e-3, (k, rel(of, os_).max())
+        assert np.abs(rf - rs).max() < 1e-3 * max(1.0, np.abs(rs).max()) and (df == ds).all()
+    return full
+
+
 def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
     """action_repeat = 3 (apply_action loop with the reference's compounding in-place action scaling, break on termination,
     counter per iteration) against the oracle: free-running, so that envs leave the loop in different iterations."""

@@ -62,3 +62,7 @@ def test_icub_force_limited_motors(emu_lib):
 
 def test_icub_object_rows_split(emu_lib):
     parity.check_obj_split(_capi.Engine, emu_lib, n=2)
+
+
+def test_icub_full_model_one_env_per_64_lanes(emu_lib):
+    parity.check_icub_full_model(_capi.Engine, emu_lib, n=1, steps=2)

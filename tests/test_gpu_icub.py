@@ -78,3 +78,7 @@ def test_icub_force_limited_motors(hip_lib):
 
 def test_icub_object_rows_split(hip_lib):
     parity.check_obj_split(_capi.Engine, hip_lib, n=7, steps=4)
+
+
+def test_icub_full_model_one_env_per_wave(hip_lib):
+    parity.check_icub_full_model(_capi.Engine, hip_lib, n=5, steps=4)
