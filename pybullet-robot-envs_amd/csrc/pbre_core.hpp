@@ -778,34 +778,97 @@ struct Core {
                 frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
             }
         };
-        if (only_ot) {
+        // Half-wave shape (iCub): in waves without robot contact rows the motor rows first run WITHOUT their clamp.  While a motor stays
+        // inside its impulse bound (PyBullet's default force of 1e5 N is far out of these robots' reach) Bullet's row is
+        // delta = rhs' - dinv dv_j, applied += delta: one fma whose result goes straight to the broadcast, instead of the
+        // fma - sub - med3 - sub chain that bounds this loop (three waves per SIMD, each row waiting for the previous one's broadcast).
+        // The applied impulses are still accumulated, off that chain, and tested against the bound after every sweep (a motor's
+        // impulse only changes in its own row, so every value it takes is seen); if one ever leaves the bound the solve is repeated
+        // with clamping rows.  Those (motor_x) return exactly the same delta for a row whose clamp does not bind, so what an env
+        // computes does not depend on which of the two paths its wave took.
+        constexpr bool FREE_ROWS = SH::W == 32 && !SH::MREC;
+        auto motor_x = [&](int j) {
+            FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
+            FR u = R.m_app - t;
+            FR s = LR::med3(u, nmlim, R.m_lim);
+            FR d = LR::sel(LR::eq(s, u), zeroR - t, s - R.m_app);
+            R.m_app = LR::setlane(R.m_app, j, s);
+            dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
+        };
+        auto mrow = [&](int j) { if (FREE_ROWS) motor_x(j); else motor(j); };
+        bool solved = false;
+        if (FREE_ROWS && (only_ot || on_bits == 0u)) {
+            const FR m_ndinv = zeroR - R.m_dinv;
+            bool over = false;
+            FR dsel = zeroR;              // lane j: the delta of row j in the current sweep
+            auto motor_free = [&](int j) {
+                FR d = LR::fma(m_ndinv, L::lo(dv), R.m_rhs);
+                dsel = LR::setlane(dsel, j, d);
+                dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
+            };
+            auto in_bound = [&]() {       // end of a sweep over the motor rows
+                R.m_app = R.m_app + dsel;
+                return !LR::any(LR::bnot(LR::le(LR::abs(R.m_app), R.m_lim)));      // (a NaN fails the test as well)
+            };
+            if (only_ot) {
+                for (int it = 0; it < P.iters; it += 2) {
+                    PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor_free(j);
+                    if (!in_bound()) { over = true; break; }
+                    if (has_limit) limits_bwd();
+                    contacts_ot();
+                    if (it + 1 >= P.iters) break;
+                    if (has_limit) limits_fwd();
+                    PBRE_UNROLL for (int j = 0; j < NJ; j++) motor_free(j);
+                    if (!in_bound()) { over = true; break; }
+                    contacts_ot();
+                }
+            } else {
+                for (int it = 0; it < P.iters; it += 2) {
+                    PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor_free(j);
+                    if (!in_bound()) { over = true; break; }
+                    if (has_limit) limits_bwd();
+                    if (it + 1 >= P.iters) break;
+                    if (has_limit) limits_fwd();
+                    PBRE_UNROLL for (int j = 0; j < NJ; j++) motor_free(j);
+                    if (!in_bound()) { over = true; break; }
+                }
+            }
+            solved = !over;
+            if (over) {             // start over with clamping rows
+                dv = L::sel(L::eqi(lane, L1), one, zero);
+                R.m_app = zeroR; R.l_app = zeroR;
+                PBRE_UNROLL for (int c = 0; c < NC; c++) { R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero; }
+            }
+        }
+        if (solved) {
+        } else if (only_ot) {
             for (int it = 0; it < P.iters; it += 2) {
-                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
                 if (has_limit) limits_bwd();
                 contacts_ot();
                 if (it + 1 >= P.iters) break;
                 if (has_limit) limits_fwd();
-                PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+                PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
                 contacts_ot();
             }
         } else if (on_bits == 0u) {      // no contact row in the wave (the object rows are kw_obj's, or there is no object)
             for (int it = 0; it < P.iters; it += 2) {
-                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+                PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
                 if (has_limit) limits_bwd();
                 if (it + 1 >= P.iters) break;
                 if (has_limit) limits_fwd();
-                PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+                PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
             }
         } else
         for (int it = 0; it < P.iters; it += 2) {
             // even iteration: reversed non-contact order
-            PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) motor(j);
+            PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
             if (has_limit) limits_bwd();
             contacts();
             if (it + 1 >= P.iters) break;
             // odd iteration: forward order
             if (has_limit) limits_fwd();
-            PBRE_UNROLL for (int j = 0; j < NJ; j++) motor(j);
+            PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
             contacts();
         }
 

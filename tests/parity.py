@@ -303,6 +303,35 @@ def check_icub_full_model(Engine, lib, n=2, steps=3):
     return full
 
 
+def check_wave_neighbour_independence(Engine, lib, steps=3):
+    """Two envs share a wavefront on the device (half-wave shape).  The solver's wave-level shortcuts -- clamp-free motor rows with a
+    fall-back to clamping rows, object rows taken from the per-env object kernel, skipped limit rows -- must not leak between them:
+    env 0 steps bit-identically whether env 1 is an ordinary state or one whose joint velocities (50 rad/s) push the wave onto the
+    clamping fall-back, and also when env 1 has the object pushed into its hand (coupled solve for that group)."""
+    eng, ora, info = make_icub_pair(Engine, lib, 2, task=1, control_arm="l", use_ik=0, obj_std=0.05, tg_std=0.2)
+    xo, lc = eng.x_off, 20
+    eng.reset()
+    base = eng.get_state()
+    hand = eng.observe()[:, :3]
+    fast = base.copy(); fast[1, 32:32 + lc] = 50.0
+    push = base.copy(); push[1, lc:lc + 3] = hand[1] + np.array([0.0, 0.0, -0.045])
+    rng = np.random.default_rng(21)
+    acts = rng.uniform(-1, 1, (steps, 2, eng.act_dim)).astype(np.float32)
+    runs = []
+    for st in (base, fast, push):
+        eng.set_state(st)
+        outs = []
+        for k in range(steps):
+            o, r, d = eng.step(acts[k])
+            outs.append((o[0].copy(), float(r[0]), float(d[0]), eng.get_state()[0].copy()))
+        runs.append(outs)
+    for other in runs[1:]:
+        for (o0, r0, d0, s0), (o1, r1, d1, s1) in zip(runs[0], other):
+            assert np.array_equal(o0, o1) and r0 == r1 and d0 == d1 and np.array_equal(s0, s1)
+    assert not np.array_equal(runs[0][0][3], base[0])
+    return eng
+
+
 def check_action_repeat(Engine, lib, table, use_ik=0, flags=0):
     """action_repeat = 3 (apply_action loop with the reference's compounding in-place action scaling, break on termination,
     counter per iteration) against the oracle: free-running, so that envs leave the loop in different iterations."""

@@ -66,3 +66,7 @@ def test_icub_object_rows_split(emu_lib):
 
 def test_icub_full_model_one_env_per_64_lanes(emu_lib):
     parity.check_icub_full_model(_capi.Engine, emu_lib, n=1, steps=2)
+
+
+def test_icub_neighbour_independence(emu_lib):
+    parity.check_wave_neighbour_independence(_capi.Engine, emu_lib, steps=2)

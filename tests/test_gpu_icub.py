@@ -82,3 +82,7 @@ def test_icub_object_rows_split(hip_lib):
 
 def test_icub_full_model_one_env_per_wave(hip_lib):
     parity.check_icub_full_model(_capi.Engine, hip_lib, n=5, steps=4)
+
+
+def test_icub_wave_neighbour_independence(hip_lib):
+    parity.check_wave_neighbour_independence(_capi.Engine, hip_lib)
