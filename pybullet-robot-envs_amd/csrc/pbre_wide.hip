@@ -65,8 +65,8 @@ static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hi
         const bool last = r + 1 == reps;
         if (!w->P.use_ik) e = wstep(w, last ? WideEngine::K_STEP_ACT : WideEngine::K_INNER_ACT, w->state, w->tgt, w->n, d_act, last ? d_out : nullptr, flags, s, last);
         else {
-            w->launch_ik(false, w->state, d_act, w->tgt, w->n, s);
-            if ((e = hipGetLastError()) != hipSuccess) break;
+            w->launch_ik(false, w->state, d_act, w->tgt, w->n, s, true);
+            if ((e = hipGetLastError()) != hipSuccess) { w->obj_done = nullptr; break; }
             e = wstep(w, last ? WideEngine::K_STEP_TGT : WideEngine::K_INNER_TGT, w->state, w->tgt, w->n, nullptr, last ? d_out : nullptr, flags, s, last);
         }
     }

@@ -37,9 +37,7 @@ __global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT
 // The object's half of the step for every env, one thread per env (pbre_objstep.hpp): twist after a step without robot-object contact,
 // into the object lanes of the env's side record.  kw_step takes it where its collision detection finds no such contact.
 template <class S>
-__global__ __launch_bounds__(64) void kw_obj(const Params P, const float* __restrict__ state, float* __restrict__ objv, int n) {
-    const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e >= n) return;
+PBRE_HD void obj_env(const Params& P, const float* __restrict__ state, float* __restrict__ objv, int e) {
     const float* st = state + (size_t)e * S::STATE;
     float pose[7], tw[6], o[6];
     PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[S::LC + k];
@@ -47,9 +45,23 @@ __global__ __launch_bounds__(64) void kw_obj(const Params P, const float* __rest
     ObjStep::run(P, pose, tw, o);
     PBRE_UNROLL for (int k = 0; k < 6; k++) objv[(size_t)e * S::W + S::LC + k] = o[k];
 }
+template <class S>
+__global__ __launch_bounds__(64) void kw_obj(const Params P, const float* __restrict__ state, float* __restrict__ objv, int n) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e < n) obj_env<S>(P, state, objv, e);
+}
+// Cartesian control: joint targets of the step (lane groups, blocks [0, ik_blocks)).  The object solve of the same step does not
+// depend on them, so it rides along as extra blocks (one thread per env) instead of a launch of its own ahead of kw_step: its 45 us
+// dependency chain disappears under this kernel's 100 us.
 template <class S, class L, bool RESET>
 __global__ __launch_bounds__(WTPB) void kw_ik(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
-                                              const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
+                                              const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim,
+                                              int ik_blocks, float* __restrict__ objv) {
+    if ((int)blockIdx.x >= ik_blocks) {
+        const int e = ((int)blockIdx.x - ik_blocks) * WTPB + (int)threadIdx.x;
+        if (e < n) obj_env<S>(P, state, objv, e);
+        return;
+    }
     constexpr int EPB = WTPB / phys_lanes<S>();
     const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
     if (env >= n) return;
@@ -116,6 +128,7 @@ struct WideEngine {
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
     float* objv = nullptr;                    // [n][W] side records of kw_obj, or nullptr: object rows always solved in kw_step
+    const float* obj_done = nullptr;          // state buffer whose object solve rode along with the last kw_ik launch (consumed by the next step)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -130,7 +143,7 @@ struct WideEngine {
     virtual hipError_t upload_tables() = 0;
     virtual void free_tables() = 0;
     virtual void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) = 0;
-    virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) = 0;
+    virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s, bool step_follows = false) = 0;   // step_follows: the next launch on s is launch_step on st
     virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
     virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
     virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
@@ -163,7 +176,9 @@ struct WideImpl : WideEngine {
     template <int MODE>
     void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
         const float* ov = (objv && !(flags & 1)) ? objv : nullptr;
-        if (ov) hipLaunchKernelGGL((kw_obj<S>), dim3((cnt + 63) / 64), dim3(64), 0, s, P, st, objv, cnt);
+        const bool done = ov && obj_done == st;
+        obj_done = nullptr;
+        if (ov && !done) hipLaunchKernelGGL((kw_obj<S>), dim3((cnt + 63) / 64), dim3(64), 0, s, P, st, objv, cnt);
         hipLaunchKernelGGL((kw_step<S, L, MODE>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg, ov);
     }
     void launch_step(int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) override {
@@ -178,9 +193,15 @@ struct WideImpl : WideEngine {
             default: step_t<C::M_TGT | OT>(st, tg, cnt, act, out, flags, s); break;
         }
     }
-    void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s) override {
-        if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
-        else hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim);
+    void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s, bool step_follows = false) override {
+        const int ikb = blocks_of(cnt);
+        if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(ikb), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim, ikb, (float*)nullptr);
+        else {
+            const bool ride = step_follows && objv != nullptr && !(cfg.flags & PBRE_F_NO_OBJECT);
+            hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(ikb + (ride ? (cnt + WTPB - 1) / WTPB : 0)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim,
+                               ikb, ride ? objv : nullptr);
+            obj_done = ride ? st : nullptr;
+        }
     }
     void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) override {
         if (initd) hipLaunchKernelGGL((kw_observe<S, L, C::M_INITD>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
