@@ -92,6 +92,7 @@ struct DevLanes {
         return __builtin_amdgcn_ds_bpermute((row_base() | (idx & 15)) << 2, a);
     }
     static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
+    static __device__ __forceinline__ F bcast_row(F a, int k) { return gather(a, k); }      // (DevLanes32 has a low-latency form)
 
     template <int CTRL>
     static __device__ __forceinline__ F dpp(F x) {
@@ -136,6 +137,14 @@ struct DevLanes32 : DevLanes {
     }
     static __device__ __forceinline__ I gatherI(I a, I idx) { return __builtin_amdgcn_ds_bpermute((half_base() | (idx & 31)) << 2, a); }
     static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
+    // Broadcast of lane k of each half without the LDS round trip: two v_readlane and a select.  Four vector instructions more than
+    // ds_bpermute_b32, a much shorter wait: for the one place where the row-to-row dependency chain is all that is left (the clamp-free
+    // motor rows of Core::step, vector pipe half idle); everywhere else the solver loops are issue-bound and bcast() is the cheaper one.
+    static __device__ __forceinline__ F bcast_row(F a, int k) {
+        const int ai = __float_as_int(a);
+        const int lo = __builtin_amdgcn_readlane(ai, k), hi = __builtin_amdgcn_readlane(ai, k + 32);
+        return __int_as_float((threadIdx.x & 32u) ? hi : lo);
+    }
     // x is zero on lanes 0..15 of either half (robot joints 0..15; the object lanes 20..26 are in the upper row): the half's sum is
     // its upper row's sum, r1 + r0 with r0 = 0 exactly.  Row butterfly, then lane 16 / 48 to every lane by v_readlane + a select
     // by half -- no trip through the LDS crossbar (ds_swizzle) on the solver's serial chain; same value as sum() bit for bit.
@@ -193,6 +202,7 @@ struct DevLanes64 : DevLanes {
     static __device__ __forceinline__ F bcast(F a, int k) {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), __builtin_amdgcn_readfirstlane(k)));
     }
+    static __device__ __forceinline__ F bcast_row(F a, int k) { return bcast(a, k); }
     template <int CTRL, int ROWS>
     static __device__ __forceinline__ F dppr(F x) {      // rows outside ROWS receive 0
         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWS, 0xF, false));

@@ -710,6 +710,7 @@ struct Core {
         const FR llim = LR::c(P.limit_imp), nmlim = zeroR - R.m_lim;
         // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
         // applied (Gauss-Seidel order is kept by the sequence of calls)
+        constexpr bool FREE_ROWS = SH::W == 32 && !SH::MREC;      // half-wave shape: clamp-free motor rows first, see below
         auto motor = [&](int j) {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
@@ -722,7 +723,7 @@ struct Core {
             FR s = LR::med3(R.l_app - t, zeroR, llim);
             FR d = s - R.l_app;
             R.l_app = LR::setlane(R.l_app, j, s);
-            dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);
+            dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);      // (bcast_row here: -4 % with IK control, where limit rows are frequent)
         };
         bool on[NC];                         // some group of the wave has contact c
         unsigned on_bits = 0u;               // the same as a scalar bit mask: tested with one SALU instruction per slot inside the loop
@@ -786,7 +787,6 @@ struct Core {
         // impulse only changes in its own row, so every value it takes is seen); if one ever leaves the bound the solve is repeated
         // with clamping rows.  Those (motor_x) return exactly the same delta for a row whose clamp does not bind, so what an env
         // computes does not depend on which of the two paths its wave took.
-        constexpr bool FREE_ROWS = SH::W == 32 && !SH::MREC;
         auto motor_x = [&](int j) {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR u = R.m_app - t;
@@ -804,7 +804,7 @@ struct Core {
             auto motor_free = [&](int j) {
                 FR d = LR::fma(m_ndinv, L::lo(dv), R.m_rhs);
                 dsel = LR::setlane(dsel, j, d);
-                dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
+                dv = L::fma_lo(LR::bcast_row(d, j), R.Mi[j], dv);
             };
             auto in_bound = [&]() {       // end of a sweep over the motor rows
                 R.m_app = R.m_app + dsel;

@@ -74,6 +74,7 @@ struct HostLanesT {
     static I ftoi(const F& a) { I r; for (int i = 0; i < W; i++) r.v[i] = (int)a.v[i]; return r; }
     // cross-lane
     static F bcast(const F& a, int k) { return F(a.v[k]); }
+    static F bcast_row(const F& a, int k) { return bcast(a, k); }
     static F gather(const F& a, const I& idx) { F r; for (int i = 0; i < W; i++) r.v[i] = a.v[idx.v[i] & (W - 1)]; return r; }
     static I gatherI(const I& a, const I& idx) { I r; for (int i = 0; i < W; i++) r.v[i] = a.v[idx.v[i] & (W - 1)]; return r; }
     // summation order identical to the device: inside each 16-lane row the DPP butterfly (xor 1, xor 2, half mirror,
