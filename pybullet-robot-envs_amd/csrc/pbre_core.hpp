@@ -710,7 +710,7 @@ struct Core {
         const FR llim = LR::c(P.limit_imp), nmlim = zeroR - R.m_lim;
         // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
         // applied (Gauss-Seidel order is kept by the sequence of calls)
-        constexpr bool FREE_ROWS = SH::W == 32 && !SH::MREC;      // half-wave shape: clamp-free motor rows first, see below
+        constexpr bool FREE_ROWS = SH::W == 32 || SH::MREC;       // iCub shapes: clamp-free motor rows first, see below
         auto motor = [&](int j) {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
@@ -779,7 +779,7 @@ struct Core {
                 frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
             }
         };
-        // Half-wave shape (iCub): in waves without robot contact rows the motor rows first run WITHOUT their clamp.  While a motor stays
+        // iCub shapes: in waves without robot contact rows the motor rows first run WITHOUT their clamp.  While a motor stays
         // inside its impulse bound (PyBullet's default force of 1e5 N is far out of these robots' reach) Bullet's row is
         // delta = rhs' - dinv dv_j, applied += delta: one fma whose result goes straight to the broadcast, instead of the
         // fma - sub - med3 - sub chain that bounds this loop (three waves per SIMD, each row waiting for the previous one's broadcast).
@@ -795,9 +795,11 @@ struct Core {
             R.m_app = LR::setlane(R.m_app, j, s);
             dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
-        auto mrow = [&](int j) { if (FREE_ROWS) motor_x(j); else motor(j); };
+        // (a shape with one env per wave has no neighbour to be independent of: its clamping rows stay the plain ones)
+        auto mrow = [&](int j) { if (FREE_ROWS && SH::W <= 32) motor_x(j); else motor(j); };
         bool solved = false;
-        if (FREE_ROWS && (only_ot || on_bits == 0u)) {
+        // (not attempted while some motor of the wave is force-limited -- grasping fingers, force 10: those do reach their bound)
+        if (FREE_ROWS && (only_ot || on_bits == 0u) && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
             const FR m_ndinv = zeroR - R.m_dinv;
             bool over = false;
             FR dsel = zeroR;              // lane j: the delta of row j in the current sweep

@@ -423,6 +423,20 @@ def check_hands(Engine, lib, control_arm="r", use_ik=0, n=1, steps=3, seed=7, to
     return eng, ora, info, st, mrec
 
 
+def check_hands_force_limited_reset(Engine, lib, n=1, imp=0.004):
+    """pbre_physics.max_motor_impulse small enough to bind on the hands model: the clamp-free motor rows are attempted (no motor
+    has a reduced force), leave the bound and hand over to the clamping rows; reset (202 settle steps) against the oracle."""
+    eng, ora, info = make_hands_pair(Engine, lib, n, "r", 0, phys={"max_motor_impulse": imp})
+    ref, _, _ = make_hands_pair(Engine, lib, n, "r", 0)
+    ora.params.max_motor_impulse = imp
+    xo = eng.x_off
+    eng.reset(); ref.reset()
+    st_o, mrec, obs_o = ora.hands_reset(n)
+    assert rel(eng.get_state()[:, :xo], st_o[:, :xo]).max() < 3e-3, rel(eng.get_state()[:, :xo], st_o[:, :xo]).max()
+    assert rel(ref.get_state()[:, :xo], eng.get_state()[:, :xo]).max() > 1e-3, "the bound does not bind: nothing tested"
+    return eng
+
+
 def check_hands_contacts(Engine, lib, control_arm="r", steps=3, tol=3e-3):
     """Fingertip contacts: the object is placed under the index and middle fingertips of the closing hand (1.5 mm penetration);
     states, fingertip forces / counts (observation tail) against the oracle."""

@@ -41,3 +41,7 @@ def test_set_motors_is_hands_only_and_validates(emu_lib, panda):
     s = eh.get_state()
     f = info["fingers"]
     assert np.abs(s[0, f]).max() < 1e-3 and s[1, f[1]] > 0.05
+
+
+def test_hands_force_limited_reset(emu_lib):
+    parity.check_hands_force_limited_reset(_capi.Engine, emu_lib)

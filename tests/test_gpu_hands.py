@@ -125,3 +125,7 @@ def test_hands_sharding_invariance(hip_lib):
 
 def test_implicit_joint_damping_option(hip_lib, panda):
     parity.check_implicit_damping(_capi.Engine, hip_lib, panda["table"], n=64)
+
+
+def test_hands_force_limited_reset(hip_lib):
+    parity.check_hands_force_limited_reset(_capi.Engine, hip_lib, n=3)

@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--joint", action="store_true")
+ap.add_argument("--iters", type=int, default=0, help="solver iterations (default: the reference's 150); 2 isolates everything but the solver loop")
 args = ap.parse_args()
 
 import numpy as np
@@ -26,7 +27,8 @@ import parity
 
 tbl, model, info = icub_table("l")
 ov = parity.icub_overrides(info, "l", 0 if args.joint else 1, 0, 1)
-eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=args.envs, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, **ov)
+eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=args.envs, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+                   **(dict(phys={"solver_iters": args.iters}) if args.iters else {}), **ov)
 t0 = time.perf_counter()
 eng.reset()
 t_reset = time.perf_counter() - t0
