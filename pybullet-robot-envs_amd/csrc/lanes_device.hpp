@@ -91,8 +91,22 @@ struct DevLanes {
     static __device__ __forceinline__ I gatherI(I a, I idx) {
         return __builtin_amdgcn_ds_bpermute((row_base() | (idx & 15)) << 2, a);
     }
-    static __device__ __forceinline__ F bcast(F a, int k) { return gather(a, k); }
-    static __device__ __forceinline__ F bcast_row(F a, int k) { return gather(a, k); }      // (DevLanes32 has a low-latency form)
+    // Broadcast of lane k of every row: one DPP move with row_newbcast:k (gfx90a+) instead of a ds_bpermute_b32 round trip through the
+    // LDS crossbar.  k is a constant wherever the solver calls this (unrolled row loops), so the switch folds to one instruction.
+    template <int K>
+    static __device__ __forceinline__ F row_bc(F x) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
+    }
+    static __device__ __forceinline__ F bcast16(F a, int k) {
+        switch (k & 15) {
+            case 0: return row_bc<0>(a);   case 1: return row_bc<1>(a);   case 2: return row_bc<2>(a);   case 3: return row_bc<3>(a);
+            case 4: return row_bc<4>(a);   case 5: return row_bc<5>(a);   case 6: return row_bc<6>(a);   case 7: return row_bc<7>(a);
+            case 8: return row_bc<8>(a);   case 9: return row_bc<9>(a);   case 10: return row_bc<10>(a); case 11: return row_bc<11>(a);
+            case 12: return row_bc<12>(a); case 13: return row_bc<13>(a); case 14: return row_bc<14>(a); default: return row_bc<15>(a);
+        }
+    }
+    static __device__ __forceinline__ F bcast(F a, int k) { return bcast16(a, k); }
+    static __device__ __forceinline__ F bcast_row(F a, int k) { return bcast16(a, k); }
 
     template <int CTRL>
     static __device__ __forceinline__ F dpp(F x) {
@@ -143,6 +157,12 @@ struct DevLanes32 : DevLanes {
     // (Feeding the two scalars straight into one v_fmac per half under a half EXEC mask -- no v_mov / v_cndmask on the chain --
     // measured 8 % slower with IK control: three s_mov exec per row.)
     static __device__ __forceinline__ F bcast_row(F a, int k) {
+        if (k < 16) {
+            // source in the lower row of each half: row_newbcast:k inside the rows, then row_bcast:15 carries lane 15 of rows 0 and 2
+            // (which now hold the value) into rows 1 and 3 -- two DPP moves, no scalar round trip
+            const int r = __float_as_int(bcast16(a, k));
+            return __int_as_float(__builtin_amdgcn_update_dpp(r, r, 0x142, 0xA, 0xF, false));
+        }
         const int ai = __float_as_int(a);
         const int lo = __builtin_amdgcn_readlane(ai, k), hi = __builtin_amdgcn_readlane(ai, k + 32);
         return __int_as_float((threadIdx.x & 32u) ? hi : lo);
