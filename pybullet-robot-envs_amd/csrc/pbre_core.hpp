@@ -710,7 +710,7 @@ struct Core {
         const FR llim = LR::c(P.limit_imp), nmlim = zeroR - R.m_lim;
         // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
         // applied (Gauss-Seidel order is kept by the sequence of calls)
-        constexpr bool FREE_ROWS = SH::W == 32 || SH::MREC;       // iCub shapes: clamp-free motor rows first, see below
+        constexpr bool FREE_ROWS = SH::W == 32 || SH::MREC;       // iCub shapes: clamp-free motor rows first, see below (16-lane Panda rows: no gain)
         auto motor = [&](int j) {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
@@ -723,7 +723,7 @@ struct Core {
             FR s = LR::med3(R.l_app - t, zeroR, llim);
             FR d = s - R.l_app;
             R.l_app = LR::setlane(R.l_app, j, s);
-            dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);      // (bcast_row here: -4 % with IK control, where limit rows are frequent)
+            dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);      // (bcast_row here: no gain with IK control, where limit rows are frequent)
         };
         bool on[NC];                         // some group of the wave has contact c
         unsigned on_bits = 0u;               // the same as a scalar bit mask: tested with one SALU instruction per slot inside the loop
