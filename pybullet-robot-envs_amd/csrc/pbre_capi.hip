@@ -355,7 +355,9 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
     // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
-    const bool timed = (c->launches++ % c->ksample) == 0;
+    // (the last launch of every group of KSAMPLE: the first launches after a reset -- cold instruction cache, first touch of the
+    // state -- are warm-up, not samples)
+    const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
     hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
     if (timed) (void)hipEventRecord(ek[0], s_fast);
     hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
