@@ -787,16 +787,17 @@ struct Core {
         // impulse only changes in its own row, so every value it takes is seen); if one ever leaves the bound the solve is repeated
         // with clamping rows.  Those (motor_x) return exactly the same delta for a row whose clamp does not bind, so what an env
         // computes does not depend on which of the two paths its wave took.
+        // clamping row in delta form: clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied); an unclamped row
+        // returns delta itself, bit for bit, and the two bounds are off the row-to-row chain (fma -> med3 -> broadcast -> fma)
+        const FR m_ndinv_x = zeroR - R.m_dinv;
         auto motor_x = [&](int j) {
-            FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
-            FR u = R.m_app - t;
-            FR s = LR::med3(u, nmlim, R.m_lim);
-            FR d = LR::sel(LR::eq(s, u), zeroR - t, s - R.m_app);
-            R.m_app = LR::setlane(R.m_app, j, s);
+            FR nt = LR::fma(m_ndinv_x, L::lo(dv), R.m_rhs);
+            FR d = LR::med3(nt, nmlim - R.m_app, R.m_lim - R.m_app);
+            R.m_app = LR::setlane(R.m_app, j, R.m_app + d);
             dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
         // (a shape with one env per wave has no neighbour to be independent of: its clamping rows stay the plain ones)
-        auto mrow = [&](int j) { if (FREE_ROWS && SH::W <= 32) motor_x(j); else motor(j); };
+        auto mrow = [&](int j) { if (SH::W <= 32) motor_x(j); else motor(j); };
         bool solved = false;
         // (not attempted while some motor of the wave is force-limited -- grasping fingers, force 10: those do reach their bound)
         if (FREE_ROWS && (only_ot || on_bits == 0u) && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
