@@ -571,10 +571,12 @@ struct Fast {
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
         ow = scl(ow, inv_sk);                 // scaled angular velocity u inside the solver loop
         const float mlim = P.motor_imp;
+        // motor row in delta form: clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied), so a row whose clamp
+        // does not bind returns Bullet's delta = rhs' - dinv w_j bit for bit -- the same value the clamp-free rows below produce
         auto motor = [&](int j) {
-            const float t = fmaf(m_dinv[j], wget(w, j), -m_rhs[j]);
-            const float s = med3(m_app[j] - t, -mlim, mlim);
-            const float d = s - m_app[j]; m_app[j] = s;
+            const float nt = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
+            const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
+            m_app[j] += d;
             if (RC) { PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k))); }
             else waxpy(w, d, Mc[RC ? 0 : j]);
         };
@@ -643,6 +645,39 @@ struct Fast {
                 PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
                 PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
             };
+            // Clamp-free motor rows first (the kernel is VALU-issue bound: fma + |.|-accumulate instead of fma, 2 sub, med3, add per row).
+            // No motor comes near PyBullet's default force bound (1e5 N dt = 417 against impulses of a few units), and
+            // sum |delta_j| over the solve bounds every value the applied impulse of motor j ever had, so one test after the loop
+            // decides; a wave in which it fails starts over with the clamping rows from the solver's initial values, which were
+            // parked in the velocity slots of the env's state record (the old velocities are dead by now; the integration below
+            // overwrites the slots with the new ones).
+            bool solved = false;
+            {
+                PBRE_UNROLL for (int j = 0; j < ND; j++) st[16 + j] = wget(w, j);
+                st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
+                auto motor_free = [&](int j) {       // (m_app[j] accumulates |delta| here; the clamping rows start from 0 again)
+                    const float d = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
+                    m_app[j] += fabsf(d);
+                    waxpy(w, d, Mc[RC ? 0 : j]);
+                };
+                for (int it = 0; it < P.iters; it += 2) {
+                    PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor_free(j);
+                    contacts_all();
+                    if (it + 1 >= P.iters) break;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) motor_free(j);
+                    contacts_all();
+                }
+                bool over = false;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) over = over || !(m_app[j] <= mlim);      // (a NaN fails the test as well)
+                solved = !PBRE_ANY(over);
+                if (!solved) {
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, st[16 + j]);
+                    ov = v3(st[25], st[26], st[27]); ow = v3(st[28], st[29], st[30]);
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) m_app[j] = 0.f;
+                }
+            }
+            if (!solved)
             for (int it = 0; it < P.iters; it += 2) {
                 PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
                 contacts_all();

@@ -473,6 +473,20 @@ def check_hands_contacts(Engine, lib, control_arm="r", steps=3, tol=3e-3):
     return eng
 
 
+def check_panda_force_limited(Engine, lib, table, n=6, imp=0.02):
+    """Panda with a motor impulse bound that binds (pbre_physics.max_motor_impulse 0.02 ~ 5 N m against gravity torques of tens of
+    N m): the lane-per-env kernel's clamp-free motor rows must detect it (sum |delta| over the solve exceeds the bound) and start
+    over with the clamping rows; reset and single steps against the oracle with the same bound."""
+    eng, ora = make_pair(Engine, lib, table, n, phys={"max_motor_impulse": imp})
+    ref, _ = make_pair(Engine, lib, table, n)
+    ora.params.max_motor_impulse = imp
+    st = check_reset(eng, ora, n)
+    ref.reset()
+    assert rel(ref.get_state()[:, :9], eng.get_state()[:, :9]).max() > 1e-3, "the bound does not bind: nothing tested"
+    check_single_steps(eng, ora, st, np.random.default_rng(13), steps=3)
+    return eng
+
+
 def check_implicit_damping(Engine, lib, table, n=6):
     """pbre_physics.implicit_joint_damping on the Panda: the lane-per-env kernels do not implement it (the engine falls back to
     the lane-group kernel at creation, refuses to switch later); results against the oracle with the same option."""

@@ -127,3 +127,7 @@ def test_ik_mode(panda, emu_lib, task):
 @pytest.mark.parametrize("use_ik,flags", [(0, 0), (1, 0), (0, _capi.F_FORCE_GENERAL)])
 def test_action_repeat(panda, emu_lib, use_ik, flags):
     parity.check_action_repeat(_capi.Engine, emu_lib, panda["table"], use_ik=use_ik, flags=flags)
+
+
+def test_force_limited_motors(emu_lib, panda):
+    parity.check_panda_force_limited(_capi.Engine, emu_lib, panda["table"], n=3)

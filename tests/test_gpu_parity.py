@@ -281,3 +281,8 @@ def test_scripted_push_properties(panda, hip_lib, flags):
 @pytest.mark.parametrize("use_ik,flags", [(0, 0), (1, 0), (0, _capi.F_FORCE_GENERAL), (0, _capi.F_COMPLEX_LANES)])
 def test_action_repeat(panda, hip_lib, use_ik, flags):
     parity.check_action_repeat(_capi.Engine, hip_lib, panda["table"], use_ik=use_ik, flags=flags)
+
+
+def test_force_limited_motors(hip_lib, panda):
+    eng = parity.check_panda_force_limited(_capi.Engine, hip_lib, panda["table"], n=70)
+    assert eng.kernel_info()[3] == 1, "the lane-per-env path was expected to run"
