@@ -37,7 +37,7 @@ out = {
     },
     kf: {"envs_per_launch": n_envs, "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
          "hbm_bytes_per_env_step": (fetch + write) / n_envs, "algorithmic_bytes_per_env_step": 444,
-         "note": "552 B/env of padded record + output accesses plus the remaining register spills around the solver loop"},
+         "note": "552 B/env of padded record + output accesses, 60 B of solver start values parked in the record, and the register spills around the solver loop"},
 }
 json.dump(out, open("profiles/%s_pmc_hbm.json" % tag, "w"), indent=1)
 print(json.dumps(out[kf], indent=1))
