@@ -484,6 +484,16 @@ def check_panda_force_limited(Engine, lib, table, n=6, imp=0.02):
     ref.reset()
     assert rel(ref.get_state()[:, :9], eng.get_state()[:, :9]).max() > 1e-3, "the bound does not bind: nothing tested"
     check_single_steps(eng, ora, st, np.random.default_rng(13), steps=3)
+    # and one step from the state the unlimited arm settles in (no contact, no joint at a limit: the simple-env kernel's own case)
+    s0 = ref.get_state()
+    a = np.random.default_rng(14).uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+    eng.set_state(s0)
+    ob, rw, dn = eng.step(a)
+    so, out = ora.batch_step(s0.astype(np.float64), a)
+    assert rel(eng.get_state()[:, :31], so[:, :31]).max() < TOL_STATE and rel(ob, out[:, :-2]).max() < TOL_OBS
+    ref.set_state(s0)
+    ref.step(a)
+    assert rel(ref.get_state()[:, :9], eng.get_state()[:, :9]).max() > 1e-4      # the bound changed that step too
     return eng
 
 
