@@ -106,25 +106,27 @@ struct ObjStep {
         // P.iters sweeps, normals then frictions; an unused slot has dinv = rhs = 0 and its rows change nothing
         for (int it = 0; it < P.iters; it++) {
             PBRE_UNROLL for (int c = 0; c < NK; c++) {
+                // rows in delta form (clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied)): one operation less
+                // on the row-to-row dependency chain, which is all this kernel's time; the upper bound 1e10 of a normal row never binds
                 const float jv = vz + c_ry[c] * wx - c_rx[c] * wy;
-                const float s = med3(r_app[c][0] - fmaf(jv, r_dinv[c][0], -r_rhs[c]), 0.f, 1e10f);
-                const float dd = s - r_app[c][0]; r_app[c][0] = s;
+                const float dd = fmaxf(fmaf(-jv, r_dinv[c][0], r_rhs[c]), -r_app[c][0]);
+                r_app[c][0] += dd;
                 vz += dd; wx = fmaf(dd, g[c][0][0], wx); wy = fmaf(dd, g[c][0][1], wy); wz = fmaf(dd, g[c][0][2], wz);
             }
             PBRE_UNROLL for (int c = 0; c < NK; c++) {
                 const float hi = mu * r_app[c][0];
                 {
                     const float jv = -vy + c_rz[c] * wx - c_rx[c] * wz;
-                    float s = med3(r_app[c][1] - jv * r_dinv[c][1], -hi, hi);
-                    s = hi > 0.f ? s : r_app[c][1];
-                    const float dd = s - r_app[c][1]; r_app[c][1] = s;
+                    float dd = med3(-jv * r_dinv[c][1], -hi - r_app[c][1], hi - r_app[c][1]);
+                    dd = hi > 0.f ? dd : 0.f;
+                    r_app[c][1] += dd;
                     vy -= dd; wx = fmaf(dd, g[c][1][0], wx); wy = fmaf(dd, g[c][1][1], wy); wz = fmaf(dd, g[c][1][2], wz);
                 }
                 {
                     const float jv = vx + c_rz[c] * wy - c_ry[c] * wz;
-                    float s = med3(r_app[c][2] - jv * r_dinv[c][2], -hi, hi);
-                    s = hi > 0.f ? s : r_app[c][2];
-                    const float dd = s - r_app[c][2]; r_app[c][2] = s;
+                    float dd = med3(-jv * r_dinv[c][2], -hi - r_app[c][2], hi - r_app[c][2]);
+                    dd = hi > 0.f ? dd : 0.f;
+                    r_app[c][2] += dd;
                     vx += dd; wx = fmaf(dd, g[c][2][0], wx); wy = fmaf(dd, g[c][2][1], wy); wz = fmaf(dd, g[c][2][2], wz);
                 }
             }
