@@ -1,24 +1,30 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/sec of the batched Panda-push step() hot path on MI355X.
 
-Workload (BASELINE.json `metric`): pandaPushGymEnv, joint control,
-obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, 150 PGS iterations, dt=1/240, actions U(-1,1).
-N=1 runs the 131072-env batch the metric is quoted on.  Envs are independent, so the batch shards
-with no data dependence between ranks: for N>1 every GPU keeps a 131072-env shard (weak scaling,
-131072*N envs in total) and, per step, one RCCL gather returns the stacked [obs|reward|done] rows
-to rank 0, overlapped with the next step's kernels (double-buffered output).  The literal config 4
-(131072 envs in TOTAL over N GPUs, same gather) is measured in the same run and reported under
-"strong_scaling_128k_total".
-A "step" = one batched env.step() of every env: pbre_step_device, actions and outputs resident in HBM.
+Workload (BASELINE.json `metric`): pandaPushGymEnv, joint control, obj_pose_rnd_std=0.05,
+tg_pose_rnd_std=0.2, 150 PGS iterations, dt=1/240, actions U(-1,1) i.i.d. per (step, env), **131072 envs in total**, done
+envs re-initialised inside the step that finishes them (PBRE_F_AUTO_RESET) and counted as steps.
+A "step" = one batched env.step() of every env: pbre_step_device, actions and [obs|reward|done] rows resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs PER_GPU]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+The headline (`value`) is the STEADY STATE: the timed K steps follow an untimed pre-roll of >= 1000 steps, so the batch holds
+episodes of every age, a fraction of the envs has a joint at its limit or a robot contact ("complex" envs) and envs finish and
+restart inside the timed region.  The figure right after a fresh reset() (no complex env yet) is reported as `fresh_reset`.
+
+N > 1 (one process per GPU, RCCL over xGMI): the SAME 131072 envs are sharded over the N GPUs (strong scaling, BASELINE
+config 4: 16384 envs per GPU at N = 8) and one RCCL gather per step returns the stacked rows to rank 0, overlapped with the next
+step's kernels.  Extra keys: `weak_scaling_128k_per_gpu` (every GPU keeps a 131072-env shard) and
+`sharded_consumers_no_gather`.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: starts its own N ranks
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,8 +39,21 @@ ALG_BYTES_PER_ENV_STEP = 444.0      # read 172 B + write 272 B (Pan
 ALG_FLOP_PER_ENV_STEP = 150 * 439 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
+PROFILE_TAG = "r02"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
 
 
+def _profile(name, key=None):
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))))
+            return (d[key] if key else d), "profiles/%s_%s.json" % (tag, name)
+        except Exception:
+            continue
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------ CPU baselines
 def _cpu_worker(args):
     n, steps, seed = args
     import numpy as np
@@ -44,8 +63,7 @@ def _cpu_worker(args):
     o = orc.Oracle(tbl, task=1)
     o.task.obj_pose_rnd_std = 0.05
     o.task.tg_pose_rnd_std = 0.2
-    # one settled state replicated with the per-env object/target randomisation applied analytically would not
-    # be the oracle's own reset; resetting n envs costs 201 steps each, so reset a few and tile them.
+    # resetting n envs costs 201 steps each, so reset a few and tile them
     st0, _ = o.batch_reset(min(n, 8), env_id0=seed * 1000)
     st = np.tile(st0, (n // st0.shape[0] + 1, 1))[:n].copy()
     rng = np.random.default_rng(seed)
@@ -56,11 +74,41 @@ def _cpu_worker(args):
     return n * steps, time.perf_counter() - t0
 
 
+def _pybullet_worker(args):
+    """The reference-equivalent loop on real PyBullet (tests/live_pybullet.py), without the reference's time.sleep(1/240)
+    (panda_push_gym_env.py:237: the sleep is GUI pacing, not simulation work).  Only runs where `import pybullet` works."""
+    steps, seed = args
+    import numpy as np
+    import live_pybullet
+    env = live_pybullet.LivePandaPush(seed=seed)
+    env.reset()
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        _, _, done = env.step(rng.uniform(-1, 1, 7))
+        if done:
+            env.reset()
+    return steps, time.perf_counter() - t0
+
+
 def cpu_baseline(target_cpu_seconds=20.0):
-    """Oracle (CPU port of the same step, double precision) on this box's host cores, bounded sample."""
+    """CPU baseline on this box's host cores, bounded sample.  Real PyBullet (kind "reference") when it is importable --
+    BASELINE.md 3.1 -- otherwise the oracle (CPU port of the same step, double precision; kind "port")."""
     import concurrent.futures as cf
     cores = len(os.sched_getaffinity(0))
-    # calibrate: ~1e-4 s per env-step per core
+    try:
+        import pybullet  # noqa: F401
+        have_pb = True
+    except Exception:
+        have_pb = False
+    if have_pb:
+        w1, t1 = _pybullet_worker((200, 0))
+        steps = max(200, int(target_cpu_seconds / (t1 / w1)))
+        with cf.ProcessPoolExecutor(max_workers=cores) as ex:
+            res = list(ex.map(_pybullet_worker, [(steps, i + 1) for i in range(cores)]))
+        return {"value": sum(r[0] for r in res) / max(r[1] for r in res), "unit": "env-steps/s", "cores": cores, "kind": "reference",
+                "single_core": w1 / t1,
+                "sample": "PyBullet DIRECT, one process per core, %d steps each, time.sleep removed" % steps}
     n, steps = 256, 8
     work, dt = _cpu_worker((n, steps, 0))
     per = dt / work
@@ -74,20 +122,23 @@ def cpu_baseline(target_cpu_seconds=20.0):
     done = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     return {"value": done / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "pybullet": "absent on this box (import pybullet fails): PyBullet baseline unavailable, the oracle is the stated substitute",
             "sample": "%d envs x %d steps per core on %d cores (oracle/pbre_oracle.c, fp64, 150 PGS iters), "
                       "%.1f s wall incl. process start" % (n, steps, cores, wall)}
 
 
+# ------------------------------------------------------------------------------------------------ other configs (N = 1)
 def other_configs(torch, dev, steps=10):
     """Extra, informative lines for the other BASELINE configs on one GPU (never the headline value): the batched
     iCubReach-v0 (config 1's env, 32768 envs) and the iCub with hands (config 5 stand-in: 60 simulated DoF, the palm pressing
-    on the object with closing fingers, 8192 envs = 65536 / 8)."""
+    on the object with closing fingers, 8192 envs = 65536 / 8), each with its own roofline / valu objects."""
     import math as m
+    from pybullet_robot_envs import _capi
     out = {}
 
     def timed(eng, acts):
         o = torch.zeros((eng.num_envs, eng.obs_dim + 2), device=dev)
-        s = torch.cuda.current_stream(dev).cuda_stream
+        s = _capi.torch_stream(dev)
         for k in range(2):
             eng.step_device(acts[k % len(acts)].data_ptr(), o.data_ptr(), s)
         torch.cuda.synchronize()
@@ -98,12 +149,31 @@ def other_configs(torch, dev, steps=10):
         el = time.perf_counter() - t0
         return {"envs": eng.num_envs, "value": eng.num_envs * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3,
                 "outputs_finite": bool(torch.isfinite(o).all())}, o
+
+    def roof(r, eng, alg_bytes, pmc_name, valu_key):
+        kms = float(eng.timing()[3])
+        if kms > 0:
+            gbs = alg_bytes * eng.num_envs / (kms * 1e-3) / 1e9
+            r["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                             "kernel_ms": kms, "algorithmic_bytes_per_env_step": alg_bytes,
+                             "note": "fp32-VALU / dependency bound like the Panda path; see valu"}
+        d, src = _profile(pmc_name)
+        if d:
+            envs_per_wave = r.pop("_envs_per_wave")
+            r["valu"] = {"valu_insts_per_env_step": d[valu_key] / envs_per_wave,
+                         "valu_active_over_wave_cycles": d.get("valu_active_over_wave_cycles", d.get("sq_active_inst_valu_over_wave_cycles")),
+                         "source": src}
+        r.pop("_envs_per_wave", None)
+
     try:
         from pybullet_robot_envs.envs import iCubReachGymEnv
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)   # iCubReach-v0 kwargs
         env.reset()
         r, _ = timed(env._engine, [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(4)])
-        r["workload"] = "iCubReach-v0 (IK position control of the left hand), one env per half-wave"
+        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs"
+        r["_envs_per_wave"] = 2
+        # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
+        roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
         out["icub_reach"] = r
         env.close()
     except Exception as e:
@@ -122,8 +192,10 @@ def other_configs(torch, dev, steps=10):
         jit = torch.tensor([0.004, 0.004, 0.002, 0.01, 0.01, 0.01], device=dev)
         r, o = timed(robot._engine, [base + (torch.rand((8192, 6), device=dev) - 0.5) * jit for _ in range(4)])
         r["workload"] = ("iCubHandsEnv (60 simulated DoF, one env per wavefront): palm pressing on the object, fingers closing "
-                         "(grasp, force 10), IK hand-pose control")
+                         "(grasp, force 10), IK hand-pose control, 8192 envs")
         r["mean_robot_object_contact_points"] = float(o[:, -3].mean())
+        r["_envs_per_wave"] = 1
+        roof(r, robot._engine, 1750.0, "pmc_hands", "valu_insts_per_wave")      # ~1.75 KB per env-step
         out["icub_hands_config5_standin"] = r
         _client.disconnect(cid)
     except Exception as e:
@@ -134,18 +206,45 @@ def other_configs(torch, dev, steps=10):
 EV_EVERY = int(os.environ.get("PBRE_BENCH_EV_EVERY", "8"))     # torch event pairs around every EV_EVERY-th step of the timed region
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--envs", type=int, default=131072, help="envs per GPU")
+    ap.add_argument("--envs", type=int, default=TOTAL_ENVS, help="envs in TOTAL (sharded over the GPUs)")
+    ap.add_argument("--preroll", type=int, default=1000, help="untimed steps before the timed region of the headline (steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--steady-preroll", type=int, default=300,
-                    help="untimed steps before the extra mid-episode measurement (0 disables it)")
-    ap.add_argument("--no-strong", action="store_true", help="skip the extra fixed-total measurement at N>1")
+    ap.add_argument("--no-fresh", action="store_true", help="skip the extra measurement right after reset()")
+    ap.add_argument("--no-weak", action="store_true", help="skip the extra 131072-envs-per-GPU measurement at N>1")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive pbre_step measurement (N=1 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informative iCub / iCub-with-hands lines (N=1 only)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the same command line the driver uses)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(p.stdout[-4000:] + "\n" + p.stderr[-8000:] + "\n")
+        raise SystemExit(p.returncode or 1)
+    print(line)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import numpy as np
     import torch
@@ -157,15 +256,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     # test hooks (single-GPU box): PBRE_BENCH_ONE_DEVICE=1 puts every rank on GPU 0, PBRE_BENCH_BACKEND=gloo stages the
-    # gather through host memory.  The driver's runs use neither.
-    if os.environ.get("PBRE_BENCH_ONE_DEVICE") == "1":
+    # gather through host memory (RCCL refuses two ranks on one device).  The driver's runs use neither.
+    one_dev = os.environ.get("PBRE_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
         local_rank = 0
-    backend = os.environ.get("PBRE_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("PBRE_BENCH_BACKEND", "gloo" if one_dev else "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -200,36 +300,41 @@ def main():
         return [float(v) for v in t]
 
     class Job(object):
-        """One sharded batch: engine, resident action pool, double-buffered output rows, pipelined gather."""
+        """One sharded batch: engine, resident action pool for the timed steps, double-buffered output rows, pipelined gather."""
 
-        def __init__(self, total_envs, n_actions):
+        def __init__(self, total_envs, pool_steps):
             self.sh = ShardedEngine(tbl, total_envs, task=_capi.TASK_PUSH, device_id=local_rank, seed=1234,
-                                    obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+                                    obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, flags=_capi.F_AUTO_RESET)
+            self.total = total_envs
             self.eng = eng = self.sh.engine
             self.n_local = n = self.sh.n_local
             assert self.sh.env_id_base == rank * n
             eng.reset()
-            # actions U(-1,1), i.i.d. per (step, env) (SURVEY 8d), generated up front and resident in HBM: one slice per
-            # step of the run (a short recycled pool would add a constant bias to every env's random walk and drive the
-            # joints into their limits within a few hundred steps)
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(1234 + rank)
-            self.pool = torch.rand((n_actions, n, eng.act_dim), device=dev, generator=gen) * 2 - 1
+            # actions U(-1,1), i.i.d. per (step, env) (SURVEY 8d).  Timed steps read slices of a pool generated up front and
+            # resident in HBM; the untimed pre-roll draws a fresh slice per step (a short recycled pool would add a constant
+            # bias to every env's random walk and drive the joints into their limits within a few hundred steps)
+            self.gen = torch.Generator(device=dev)
+            self.gen.manual_seed(1234 + rank)
+            self.pool = torch.rand((pool_steps, n, eng.act_dim), device=dev, generator=self.gen) * 2 - 1
+            self.fresh = torch.empty((n, eng.act_dim), device=dev)
             self.out = [torch.zeros((n, eng.obs_dim + 2), device=dev, dtype=torch.float32) for _ in range(2)]
             self.gathered = [torch.zeros_like(self.out[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
             self.pending = [None, None]
             self.k = 0
+            self.steps_done = 0
 
         gather = True
 
-        def step(self, ev=None):
+        def step(self, ev=None, act=None):
             b = self.k & 1
             if self.pending[b] is not None:            # the gather that read this buffer two steps ago
                 self.pending[b].wait()
                 self.pending[b] = None
+            if act is None:
+                act = self.pool[self.k % self.pool.shape[0]]
             if ev is not None:
                 ev[0].record()
-            self.eng.step_device(self.pool[self.k % self.pool.shape[0]].data_ptr(), self.out[b].data_ptr(), stream)
+            self.eng.step_device(act.data_ptr(), self.out[b].data_ptr(), stream)
             if ev is not None:
                 ev[1].record()
             if world > 1 and self.gather:              # the one collective of the data path (RCCL over xGMI)
@@ -240,6 +345,14 @@ def main():
                     h = self.out[b].cpu()
                     dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
             self.k += 1
+            self.steps_done += 1
+
+        def preroll(self, upto):
+            """untimed steps with fresh i.i.d. actions until the batch has taken `upto` steps since reset()"""
+            while self.steps_done < upto:
+                self.fresh.uniform_(-1, 1, generator=self.gen)
+                self.step(act=self.fresh)
+            self.drain()
 
         def drain(self):
             for b in range(2):
@@ -247,7 +360,10 @@ def main():
                     self.pending[b].wait()
                     self.pending[b] = None
 
-        def timed(self, steps, events=False):
+        def timed(self, steps, warmup, events=False):
+            for _ in range(warmup):
+                self.step()
+            self.drain()
             barrier()
             # event pairs around every EV_EVERY-th (8th) step only: an event record is a barrier packet on the stream, and a pair per step
             # costs ~10% of the 0.2 ms kernel it brackets
@@ -259,98 +375,125 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
             pair = float(np.mean([a.elapsed_time(b) for a, b in evs[::EV_EVERY]])) if events else 0.0
-            return max_over_ranks([elapsed, pair])
+            el, pr = max_over_ranks([elapsed, pair])
+            return {"value": self.total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "_elapsed": el, "_pair_ms": pr}
 
-    job = Job(args.envs * world, args.warmup + 3 * args.steps + args.steady_preroll)
-    eng, n_local, total = job.eng, job.n_local, args.envs * world
-    for k in range(args.warmup):
-        job.step()
-    elapsed, pair_ms = job.timed(args.steps, events=True)   # pair_ms: whole launch pair (fork/join incl.), HIP events on the caller's stream
+        def complex_frac(self):
+            return self.eng.kernel_info()[5] / float(self.n_local)
+
+    def clean(d):
+        return dict((k, v) for k, v in d.items() if not k.startswith("_"))
+
+    total = args.envs
+    job = Job(total, 2 * (args.steps + args.warmup))
+    eng, n_local = job.eng, job.n_local
+
+    # (side key) right after reset(): no complex env yet, nothing finishes inside the timed region
+    fresh = None
+    if not args.no_fresh:
+        fresh = job.timed(args.steps, args.warmup)
+        fresh.update({"start_state": "fresh reset() of every env (reference reset_simulation)", "complex_env_frac_rank0": job.complex_frac()})
+
+    # headline: steady state after the pre-roll
+    job.preroll(args.preroll - args.warmup)
+    head = job.timed(args.steps, args.warmup, events=True)
+    steps_before = job.steps_done - args.steps
+    complex_after = job.complex_frac()
     finite = bool(torch.isfinite(job.out[0]).all() and torch.isfinite(job.out[1]).all())
-    complex_after = eng.kernel_info()[5]
-    # duration of the dominant kernel (k_fast) alone: mean over the last <= 64 timed steps of the HIP event pairs the library
-    # records around that kernel on the stream it is launched on (pbre_timing[3])
-    kern_ms = float(eng.timing()[3])
-
-    # extra, reported separately: the same K steps measured mid-episode (after an untimed pre-roll), when a few per cent
-    # of the envs have robot contacts / joints at a limit and take the heavier k_fast_rc kernel
-    steady = None
-    if args.steady_preroll > 0:
-        for k in range(args.steady_preroll):
-            job.step()
-        e2 = job.timed(args.steps)[0]
-        steady = {"preroll_steps": args.steady_preroll, "value": total * args.steps / e2, "unit": "env-steps/s",
-                  "ms_per_step": e2 / args.steps * 1e3, "complex_env_frac_rank0": eng.kernel_info()[5] / n_local}
+    done_frac = float(job.out[(job.k - 1) & 1][:, -1].mean())
+    kern_ms = float(eng.timing()[3])      # k_fast alone: mean of the HIP event pairs the library records around it on its stream
     info = eng.kernel_info()
-    # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows): what the engine
-    # itself scales to when the stacked rows are not funnelled into one GPU (7 x 18.4 MB per step into rank 0 otherwise)
+    episodes = float(torch.as_tensor(eng.get_state()[:, eng.x_off + 5]).mean()) if rank == 0 else 0.0
+
+    # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows)
     no_gather = None
     if world > 1:
         try:
             job.gather = False
-            e4 = job.timed(args.steps)[0]
-            no_gather = {"value": total * args.steps / e4, "unit": "env-steps/s", "ms_per_step": e4 / args.steps * 1e3}
+            no_gather = clean(job.timed(args.steps, args.warmup))
         except Exception as e:
             no_gather = {"error": repr(e)}
+
+    # extra at N=1: what env.step() delivers through the host-buffer entry point (action upload + kernels + row download
+    # through pinned staging buffers, SURVEY 8(d)'s literal metric)
+    host = None
+    if world == 1 and not args.no_host_path:
+        try:
+            acts = [job.pool[k].cpu().numpy() for k in range(4)]
+            for k in range(2):
+                eng.step(acts[k])
+            t0 = time.perf_counter()
+            for k in range(10):
+                eng.step(acts[k % 4])
+            el = time.perf_counter() - t0
+            ms = eng.timing()
+            host = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3,
+                    "h2d_ms": ms[0], "kernels_ms": ms[1], "d2h_ms": ms[2],
+                    "note": "Engine.step(): numpy actions in, [obs|reward|done] rows out through pinned staging buffers (PCIe-bound); never `value`"}
+        except Exception as e:
+            host = {"error": repr(e)}
     del job
 
-    # extra at N>1: BASELINE config 4 taken literally -- 131072 envs in TOTAL over the N GPUs (strong scaling), same gather
-    strong = None
-    if world > 1 and not args.no_strong:
+    # extra at N>1: weak scaling -- every GPU keeps the 131072-env shard (131072 x N envs in total), same gather
+    weak = None
+    if world > 1 and not args.no_weak:
         try:
-            j2 = Job(131072, args.warmup + args.steps)
-            for k in range(args.warmup):
-                j2.step()
-            e3 = j2.timed(args.steps)[0]
-            strong = {"envs_total": 131072, "envs_per_gpu": j2.n_local, "value": 131072 * args.steps / e3, "unit": "env-steps/s",
-                      "ms_per_step": e3 / args.steps * 1e3}
+            j2 = Job(total * world, args.steps + args.warmup)
+            j2.preroll(args.preroll - args.warmup)
+            weak = clean(j2.timed(args.steps, args.warmup))
+            weak.update({"envs_total": total * world, "envs_per_gpu": j2.n_local})
             del j2
         except Exception as e:   # informative only
-            strong = {"error": repr(e)}
+            weak = {"error": repr(e)}
 
     if rank == 0:
-        value = total * args.steps / elapsed
-        kern_s = kern_ms * 1e-3
+        kern_s = max(kern_ms, 1e-9) * 1e-3
         ach_gbs = ALG_BYTES_PER_ENV_STEP * n_local / kern_s / 1e9
         ach_tf = ALG_FLOP_PER_ENV_STEP * n_local / kern_s / 1e12
         # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, corrected as
-        # calibrated in profiles/r01_pmc_hbm.json); counters cannot be read from inside this process, so the committed
-        # per-env figure of the profiled run is scaled to this launch's env count.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")))["k_fast<7>"]
-            traffic = pmc["hbm_bytes_per_env_step"] * n_local
-        except Exception:
-            pass
+        # calibrated in the profile file).  Counters cannot be read from inside this process: the figure is the committed
+        # per-env summary of the counter passes over this same command, scaled to this launch's env count.
+        traffic, traffic_src = None, None
+        pmc, src = _profile("pmc_hbm", "k_fast<7>")
+        if pmc:
+            traffic, traffic_src = pmc["hbm_bytes_per_env_step"] * n_local, src
         sq = None
-        try:   # SQ issue counters of the same kernel (rocprofv3 --pmc pass, tools/pmc_sq.sh), committed summary
-            d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")))["k_fast<7>"]
+        d, src = _profile("pmc_sq", "k_fast<7>")
+        if d:
             sq = {"valu_insts_per_wave": d["valu_insts_per_wave"], "valu_active_over_wave_cycles": d["valu_active_over_wave_cycles"],
-                  "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "waves_per_simd": 2,
-                  "note": "2 waves per SIMD x this per-wave VALU-active fraction = VALU pipe ~95% busy while the waves are resident"}
-        except Exception:
-            pass
+                  "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "waves_per_simd": 2, "source": src}
+        rccl = None
+        if world > 1:
+            try:
+                rccl = {"backend": backend, "ranks_seen": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+            except Exception as e:
+                rccl = {"backend": backend, "ranks_seen": dist.get_world_size(), "version": repr(e)}
         res = {
             "metric": "env-steps/sec (whole node), Panda-push 128k envs",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": head["value"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "pandaPushGymEnv joint-control step, %d envs per GPU (%d in total), 150 PGS iters, "
-                                   "dt 1/240, obj_pose_rnd_std 0.05, tg_pose_rnd_std 0.2, actions U(-1,1) resident in HBM"
-                                   % (n_local, total),
+            "config": {"workload": "pandaPushGymEnv joint-control step, %d envs in total (%d per GPU), 150 PGS iters, dt 1/240, "
+                                   "obj_pose_rnd_std 0.05, tg_pose_rnd_std 0.2, actions U(-1,1) resident in HBM, done envs re-initialised "
+                                   "in the step (auto-reset) and counted" % (total, n_local),
                        "envs_total": total, "envs_per_gpu": n_local, "parallelism": "dp%d" % world,
                        "collective": "rccl gather of [obs|reward|done] rows to rank 0 per step, overlapped with the next step"
                                      if world > 1 else "none",
-                       "outputs_finite": finite, "start_state": "fresh reset() of every env (reference reset_simulation)",
-                       "complex_env_frac_after_timed_steps_rank0": complex_after / n_local},
-            "steady_state": steady,
-            "strong_scaling_128k_total": strong,
+                       "rccl": rccl,
+                       "outputs_finite": finite,
+                       "start_state": "steady state: %d untimed steps since reset() before the timed region (pre-roll + warm-up)" % steps_before,
+                       "complex_env_frac_rank0": complex_after, "done_frac_last_step_rank0": done_frac,
+                       "mean_episodes_completed_per_env_rank0": episodes},
+            "fresh_reset": clean(fresh) if fresh else None,
+            "weak_scaling_128k_per_gpu": weak,
             "sharded_consumers_no_gather": no_gather,
+            "host_inclusive": host,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": pair_ms, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
-                         "note": "path is fp32-VALU/dependency bound (AI ~900 FLOP/B >> 25 FLOP/B machine balance); "
-                                 "HBM fraction is small by construction, see valu"},
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
+                         "note": "path is fp32-VALU/dependency bound (AI ~166 FLOP/B of the sparse formulation >> 25 FLOP/B machine "
+                                 "balance); HBM fraction is small by construction, see valu"},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
                      # the 157.3 TF peak assumes v_pk_fma_f32 at full rate; measured on this chip (profiles/r01_ubench_pkfma.txt) a
                      # packed FMA takes ~2 passes, so the scalar-FMA peak (78.6 TF) is the practical ceiling of fp32 FMA code
@@ -365,7 +508,9 @@ def main():
             except Exception as e:  # the baseline is informative; never lose the GPU line over it
                 res["cpu_baseline"] = {"value": None, "unit": "env-steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -144,15 +144,31 @@ int pbre_reset(pbre_ctx* ctx, const uint8_t* env_mask, float* obs_out);
  * out: host [num_envs][obs_dim+2] float32 = raw observation | reward | done.  Synchronous. */
 int pbre_step(pbre_ctx* ctx, const float* actions, float* out);
 
-/* Same with device-resident buffers (HIP device pointers on ctx's GPU) enqueued on `stream`
- * (a hipStream_t, NULL = the ctx's own stream); asynchronous.  For device-resident policies
- * (replaces the stable-baselines DummyVecEnv hop, R/examples/algos/train/.../train_ddpg_reaching.py:96). */
+/* Same with device-resident buffers (HIP device pointers on ctx's GPU) enqueued on `stream`; asynchronous.  For
+ * device-resident policies (replaces the stable-baselines DummyVecEnv hop, R/examples/algos/train/.../train_ddpg_reaching.py:96).
+ * stream: a hipStream_t.  The step reads d_actions and writes d_out in stream order on THAT stream, so work that produced the
+ * actions / consumes the rows on the same stream needs no further synchronisation.
+ *   PBRE_STREAM_LEGACY  HIP's legacy default stream (hipStreamLegacy) -- what `torch.cuda.current_stream().cuda_stream == 0` means;
+ *   NULL                the ctx's own NON-BLOCKING stream: it is not ordered against any other stream (not even the legacy
+ *                       default stream); the caller orders inputs / outputs with events or pbre_sync().
+ * Every host-synchronous entry point (pbre_reset, pbre_get_state, pbre_set_state, pbre_observe, pbre_settle, pbre_set_physics,
+ * pbre_step, pbre_sync, ...) first waits for all steps enqueued this way, whatever stream they went to. */
+#define PBRE_STREAM_LEGACY ((void*)1)
 int pbre_step_device(pbre_ctx* ctx, const float* d_actions, float* d_out, void* stream);
 int pbre_sync(pbre_ctx* ctx);
 
 /* raw simulator state, host [num_envs][pbre_state_floats()] float32 (parity tests, checkpoint/restore) */
 int pbre_get_state(pbre_ctx* ctx, float* state);
 int pbre_set_state(pbre_ctx* ctx, const float* state);
+/* `count` consecutive floats of every env's state record starting at float `first`, host [num_envs][count] -- the reference
+ * attributes `_env_step_counter`, `terminated`, `_hand_pose`, `_target_pose` (R/envs/panda_envs/panda_push_gym_env.py:45-46,142-143)
+ * without downloading the whole batch state */
+int pbre_get_state_cols(pbre_ctx* ctx, int32_t first, int32_t count, float* out);
+
+/* Page-locked host memory for the buffers handed to pbre_step / pbre_reset / pbre_observe: DMA straight into the caller's
+ * arrays instead of the runtime's staging copies (the rows of a 131072-env step are 18 MB).  NULL on failure. */
+void* pbre_host_alloc(size_t bytes);
+void pbre_host_free(void* p);
 /* recompute the observation of the current state (replaces get_extended_observation, :150-187) */
 int pbre_observe(pbre_ctx* ctx, float* obs_out);
 /* `n` bare physics steps with hold motors (replaces the settle loops `for _ in range(100): p.stepSimulation`,

@@ -258,6 +258,7 @@ struct pbre_ctx {
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
+    bool ext_dirty = false;            // a pbre_step_device was enqueued on a caller-supplied stream since the last quiesce()
     std::string err;
 };
 static std::string g_err;
@@ -272,6 +273,19 @@ static std::string g_err;
     } while (0)
 
 static int ceil16(int n) { return (n + EPB - 1) / EPB * EPB; }
+// Every host-synchronous entry point starts here: all work the ctx has in flight is complete on return.  Steps enqueued on a
+// caller-supplied stream (pbre_step_device) are not ordered against the ctx's own non-blocking streams, so after one of those the
+// whole device is drained (these entry points are not on the hot path).
+static hipError_t quiesce(pbre_ctx* c) {
+    hipError_t e;
+    if (c->ext_dirty) {
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+        c->ext_dirty = false;
+        return hipSuccess;
+    }
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(c->side);
+}
 static bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL); }
 
 static hipError_t alloc_buf(EnvBuf& b, int cap) {
@@ -515,8 +529,7 @@ int pbre_sync(pbre_ctx* c) {
     if (!c) return PBRE_E_ARG;
     if (c->wide) return wide_sync(c->wide);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipStreamSynchronize(c->side));
+    HIPCHK(quiesce(c));
     return PBRE_OK;
 }
 
@@ -524,6 +537,7 @@ int pbre_observe(pbre_ctx* c, float* obs) {
     if (!c || !obs) return PBRE_E_ARG;
     if (c->wide) return wide_observe(c->wide, obs);
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
     hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->main.state, c->d_out, c->d_scratch, c->n, c->ow);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy2DAsync(obs, (size_t)c->obs_dim * 4, c->d_out, (size_t)c->ow * 4, (size_t)c->obs_dim * 4, c->n, hipMemcpyDeviceToHost, c->stream));
@@ -535,6 +549,7 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     if (!c || n < 0) return PBRE_E_ARG;
     if (c->wide) return wide_settle(c->wide, n, flags);
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
     const int f = flags & PBRE_F_NO_OBJECT, f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
     if (f != f0) HIPCHK(classify(c, c->main, c->n, f, c->stream));           // classes depend on whether the object is present
     HIPCHK(settle_steps(c, c->main, c->n, n, f, c->stream));
@@ -547,6 +562,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
     if (!c) return PBRE_E_ARG;
     if (c->wide) return wide_reset(c->wide, mask, obs);
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
     std::vector<int> idx;
     for (int e = 0; e < c->n; e++) if (!mask || mask[e]) idx.push_back(e);
     const int cnt = (int)idx.size();
@@ -600,7 +616,8 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
     if (c->wide) return wide_step_device(c->wide, d_actions, d_out, stream);
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;      // PBRE_STREAM_LEGACY == hipStreamLegacy
+    if (stream) c->ext_dirty = true;
     HIPCHK(full_step(c, d_actions, d_out, s));
     return PBRE_OK;
 }
@@ -609,6 +626,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
     if (c->wide) return wide_step(c->wide, actions, out);
     HIPCHK(hipSetDevice(c->device));
+    if (c->ext_dirty) HIPCHK(quiesce(c));
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -625,7 +643,7 @@ int pbre_get_state(pbre_ctx* c, float* s) {
     if (!c || !s) return PBRE_E_ARG;
     if (c->wide) return wide_get_state(c->wide, s);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(quiesce(c));
     HIPCHK(hipMemcpy(s, c->main.state, (size_t)c->n * STATE * 4, hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
@@ -633,12 +651,26 @@ int pbre_set_state(pbre_ctx* c, const float* s) {
     if (!c || !s) return PBRE_E_ARG;
     if (c->wide) return wide_set_state(c->wide, s);
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(quiesce(c));
     HIPCHK(hipMemcpy(c->main.state, s, (size_t)c->n * STATE * 4, hipMemcpyHostToDevice));
     HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return PBRE_OK;
 }
+
+int pbre_get_state_cols(pbre_ctx* c, int32_t first, int32_t count, float* out) {
+    if (!c || !out || first < 0 || count <= 0 || first + count > pbre_state_floats(c)) return PBRE_E_ARG;
+    if (c->wide) return wide_get_state_cols(c->wide, first, count, out);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
+    HIPCHK(hipMemcpy2D(out, (size_t)count * 4, c->main.state + first, (size_t)STATE * 4, (size_t)count * 4, c->n, hipMemcpyDeviceToHost));
+    return PBRE_OK;
+}
+void* pbre_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void pbre_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
     if (!c || n < 0 || (n > 0 && (!dofs || !targets))) return PBRE_E_ARG;
@@ -680,7 +712,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(quiesce(c));
     HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));     // the contact margin may have changed
     HIPCHK(hipStreamSynchronize(c->stream));
     return PBRE_OK;

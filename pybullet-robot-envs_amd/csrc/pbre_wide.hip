@@ -39,6 +39,16 @@ __global__ void kw_scatter(float* __restrict__ dst, const float* __restrict__ sr
         }                                                                           \
     } while (0)
 
+// all work of the engine complete on return (see quiesce() in pbre_capi.hip)
+static hipError_t wquiesce(WideEngine* w) {
+    if (w->ext_dirty) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        w->ext_dirty = false;
+        return hipSuccess;
+    }
+    return hipStreamSynchronize(w->stream);
+}
 static hipError_t wstep(WideEngine* w, int kind, float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s, bool timed = false) {
     hipEvent_t* ek = w->ev_k[w->k_steps % WideEngine::KRING];
     if (timed) (void)hipEventRecord(ek[0], s);
@@ -155,11 +165,12 @@ void wide_dims(const WideEngine* w, int32_t* od, int32_t* ad, int32_t* n, int32_
 }
 int wide_sync(WideEngine* w) {
     WCHK(hipSetDevice(w->device));
-    WCHK(hipStreamSynchronize(w->stream));
+    WCHK(wquiesce(w));
     return PBRE_OK;
 }
 int wide_observe(WideEngine* w, float* obs) {
     WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
     w->launch_observe(false, w->state, w->d_out, w->n, w->stream);
     WCHK(hipGetLastError());
     WCHK(hipMemcpy2DAsync(obs, (size_t)w->obs_dim * 4, w->d_out, (size_t)w->ow * 4, (size_t)w->obs_dim * 4, w->n, hipMemcpyDeviceToHost, w->stream));
@@ -168,12 +179,14 @@ int wide_observe(WideEngine* w, float* obs) {
 }
 int wide_settle(WideEngine* w, int32_t n, int32_t flags) {
     WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
     WCHK(wsettle(w, w->state, w->tgt, w->n, n, flags & PBRE_F_NO_OBJECT, w->stream));
     WCHK(hipStreamSynchronize(w->stream));
     return PBRE_OK;
 }
 int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
     WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
     std::vector<int> idx;
     for (int e = 0; e < w->n; e++) if (!mask || mask[e]) idx.push_back(e);
     const int cnt = (int)idx.size();
@@ -227,11 +240,13 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
 }
 int wide_step_device(WideEngine* w, const float* d_actions, float* d_out, void* stream) {
     WCHK(hipSetDevice(w->device));
+    if (stream) w->ext_dirty = true;
     WCHK(wfull_step(w, d_actions, d_out, stream ? (hipStream_t)stream : w->stream));
     return PBRE_OK;
 }
 int wide_step(WideEngine* w, const float* actions, float* out) {
     WCHK(hipSetDevice(w->device));
+    if (w->ext_dirty) WCHK(wquiesce(w));
     hipStream_t s = w->stream;
     WCHK(hipEventRecord(w->ev[0], s));
     WCHK(hipMemcpyAsync(w->d_act, actions, (size_t)w->n * w->act_dim * 4, hipMemcpyHostToDevice, s));
@@ -246,13 +261,19 @@ int wide_step(WideEngine* w, const float* actions, float* out) {
 }
 int wide_get_state(WideEngine* w, float* s) {
     WCHK(hipSetDevice(w->device));
-    WCHK(hipStreamSynchronize(w->stream));
+    WCHK(wquiesce(w));
     WCHK(hipMemcpy(s, w->state, (size_t)w->n * w->sf * 4, hipMemcpyDeviceToHost));
+    return PBRE_OK;
+}
+int wide_get_state_cols(WideEngine* w, int32_t first, int32_t count, float* out) {
+    WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
+    WCHK(hipMemcpy2D(out, (size_t)count * 4, w->state + first, (size_t)w->sf * 4, (size_t)count * 4, w->n, hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
 int wide_set_state(WideEngine* w, const float* s) {
     WCHK(hipSetDevice(w->device));
-    WCHK(hipStreamSynchronize(w->stream));
+    WCHK(wquiesce(w));
     WCHK(hipMemcpy(w->state, s, (size_t)w->n * w->sf * 4, hipMemcpyHostToDevice));
     return PBRE_OK;
 }
@@ -268,6 +289,7 @@ int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float
     }
     if (cnt == 0) return PBRE_OK;
     WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
     if (mask) {
         if (!w->d_mask) WCHK(hipMalloc(&w->d_mask, (size_t)w->n));
         WCHK(hipMemcpyAsync(w->d_mask, mask, (size_t)w->n, hipMemcpyHostToDevice, w->stream));
@@ -280,6 +302,7 @@ int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float
 int wide_apply_action(WideEngine* w, const float* actions) {
     if (!w->mrec) { w->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
     WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
     hipStream_t s = w->stream;
     WCHK(hipMemcpyAsync(w->d_act, actions, (size_t)w->n * w->act_dim * 4, hipMemcpyHostToDevice, s));
     if (w->P.use_ik) w->launch_ik(false, w->state, w->d_act, w->tgt, w->n, s);
@@ -291,7 +314,7 @@ int wide_apply_action(WideEngine* w, const float* actions) {
 int wide_motor_state(WideEngine* w, float* out, const float* in) {
     if (!w->mrec) { w->err = "pbre_get/set_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
     WCHK(hipSetDevice(w->device));
-    WCHK(hipStreamSynchronize(w->stream));
+    WCHK(wquiesce(w));
     if (out) WCHK(hipMemcpy(out, w->tgt, (size_t)w->n * w->tgs * 4, hipMemcpyDeviceToHost));
     if (in) WCHK(hipMemcpy(w->tgt, in, (size_t)w->n * w->tgs * 4, hipMemcpyHostToDevice));
     return PBRE_OK;
@@ -301,7 +324,7 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     Params P2 = w->P;
     if (!apply_physics(*p, P2)) { w->err = "bad physics parameters"; return PBRE_E_ARG; }
     WCHK(hipSetDevice(w->device));
-    WCHK(hipStreamSynchronize(w->stream));
+    WCHK(wquiesce(w));
     w->cfg.phys = *p; w->P = P2;
     return PBRE_OK;
 }

@@ -19,6 +19,7 @@ int  wide_step_device(WideEngine* w, const float* d_actions, float* d_out, void*
 int  wide_sync(WideEngine* w);
 int  wide_get_state(WideEngine* w, float* s);
 int  wide_set_state(WideEngine* w, const float* s);
+int  wide_get_state_cols(WideEngine* w, int32_t first, int32_t count, float* out);
 int  wide_observe(WideEngine* w, float* obs);
 int  wide_settle(WideEngine* w, int32_t n, int32_t flags);
 int  wide_set_motors(WideEngine* w, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask);

@@ -136,6 +136,7 @@ struct WideEngine {
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0;
     double ms[3] = {0, 0, 0};
+    bool ext_dirty = false;                   // a step was enqueued on a caller-supplied stream since the last wquiesce()
     std::string err;
     enum { K_SETTLE, K_SETTLE_TGT, K_STEP_ACT, K_STEP_TGT, K_INNER_ACT, K_INNER_TGT };
     virtual ~WideEngine() {}

@@ -73,8 +73,13 @@ def load(path=None):
     lib.pbre_destroy.restype = None
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
-                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state"):
+                 "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
+                 "pbre_get_state_cols"):
         getattr(lib, name).restype = C.c_int
+    lib.pbre_host_alloc.restype = C.c_void_p
+    lib.pbre_host_alloc.argtypes = [C.c_size_t]
+    lib.pbre_host_free.restype = None
+    lib.pbre_host_free.argtypes = [C.c_void_p]
     if path is None:
         _LIB = lib
     return lib
@@ -82,6 +87,17 @@ def load(path=None):
 
 def _fp(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+STREAM_LEGACY = 1      # PBRE_STREAM_LEGACY (include/pbre.h) == hipStreamLegacy
+
+
+def torch_stream(device=None):
+    """hipStream_t of torch's current stream on `device` as the int pbre_step_device takes.  Torch's default stream is HIP's
+    legacy null stream, whose handle is 0; 0 would select the engine's own non-blocking stream (which is not ordered against
+    the null stream), so it is mapped to PBRE_STREAM_LEGACY."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream or STREAM_LEGACY
 
 
 class Engine:
@@ -130,7 +146,22 @@ class Engine:
         self.ndof = int(self._table[3])
         self.v_off = (self.state_floats - 16) // 2
         self.x_off = self.state_floats - 16
-        self._out = np.zeros((self.num_envs, self.obs_dim + 2), np.float32)
+        # page-locked staging buffers of the host path (pbre_step DMAs straight from / into them): actions, and two row
+        # buffers used alternately so that the arrays step(copy=False) returned stay valid for one more step
+        self._pinned = []
+        self._act = self._pinned_array((self.num_envs, self.act_dim))
+        self._outs = [self._pinned_array((self.num_envs, self.obs_dim + 2)) for _ in range(2)]
+        self._flip = 0
+
+    def _pinned_array(self, shape):
+        nbytes = int(np.prod(shape)) * 4
+        p = self.lib.pbre_host_alloc(C.c_size_t(nbytes))
+        if not p:
+            raise RuntimeError("pbre_host_alloc(%d) failed" % nbytes)
+        self._pinned.append(p)
+        a = np.ctypeslib.as_array((C.c_float * (nbytes // 4)).from_address(p)).reshape(shape)
+        a[...] = 0
+        return a
 
     def _chk(self, rc):
         if rc != 0:
@@ -140,6 +171,10 @@ class Engine:
         if getattr(self, "_ctx", None):
             self.lib.pbre_destroy(self._ctx)
             self._ctx = None
+            self._act = self._outs = None
+            for p in self._pinned:
+                self.lib.pbre_host_free(C.c_void_p(p))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -162,15 +197,24 @@ class Engine:
         self._chk(self.lib.pbre_reset(self._ctx, _fp(m) if m is not None else None, _fp(obs)))
         return obs
 
-    def step(self, actions):
-        a = np.ascontiguousarray(actions, dtype=np.float32)
+    def step(self, actions, copy=True):
+        """Host-buffer step: (raw obs [N, obs_dim], reward [N], done [N]) float32.  copy=False returns views of a page-locked
+        row buffer that the step after next overwrites (two buffers alternate) -- no 18 MB of copies per 131072-env step."""
+        a = np.asarray(actions)
         if a.shape != (self.num_envs, self.act_dim):
             raise ValueError("actions must have shape (%d, %d), got %r" % (self.num_envs, self.act_dim, a.shape))
-        self._chk(self.lib.pbre_step(self._ctx, _fp(a), _fp(self._out)))
-        o = self._out
-        return o[:, :self.obs_dim].copy(), o[:, self.obs_dim].copy(), o[:, self.obs_dim + 1].copy()
+        np.copyto(self._act, a, casting="unsafe")
+        o = self._outs[self._flip]
+        self._flip ^= 1
+        self._chk(self.lib.pbre_step(self._ctx, _fp(self._act), _fp(o)))
+        if copy:
+            return o[:, :self.obs_dim].copy(), o[:, self.obs_dim].copy(), o[:, self.obs_dim + 1].copy()
+        return o[:, :self.obs_dim], o[:, self.obs_dim], o[:, self.obs_dim + 1]
 
     def step_device(self, d_actions_ptr, d_out_ptr, stream=None):
+        """Asynchronous step on device-resident buffers.  `stream`: a hipStream_t handle as an int -- pass
+        `torch_stream(device)` so that the step is ordered with the torch work that produced the actions and consumes the rows;
+        None = the engine's own non-blocking stream (NOT ordered against torch streams: the caller orders inputs / outputs)."""
         self._chk(self.lib.pbre_step_device(self._ctx, C.c_void_p(d_actions_ptr), C.c_void_p(d_out_ptr),
                                             C.c_void_p(stream or 0)))
 
@@ -180,6 +224,12 @@ class Engine:
     def get_state(self):
         s = np.zeros((self.num_envs, self.state_floats), np.float32)
         self._chk(self.lib.pbre_get_state(self._ctx, _fp(s)))
+        return s
+
+    def get_state_cols(self, first, count=1):
+        """[N, count] float32: `count` consecutive floats of every state record from float `first` (no whole-batch download)."""
+        s = np.zeros((self.num_envs, count), np.float32)
+        self._chk(self.lib.pbre_get_state_cols(self._ctx, C.c_int32(first), C.c_int32(count), _fp(s)))
         return s
 
     def set_state(self, s):

@@ -152,8 +152,10 @@ class PandaTaskBase(Env):
     def step_tensor(self, actions):
         """Batched step with device-resident data (replaces the DummyVecEnv hop of the reference's training scripts,
         train_ddpg_reaching.py:96): `actions` is a CUDA float32 tensor [num_envs, act_dim] on this env's GPU; returns
-        (scaled_obs [N, obs_dim], reward [N], done [N]) CUDA float32 tensors.  Asynchronous on torch's current stream;
-        observation scaling (scale_gym_data with the float32 Box limits) runs on the device in float32."""
+        (scaled_obs [N, obs_dim], reward [N], done [N]) CUDA float32 tensors that the caller owns (fresh tensors every call).
+        Asynchronous and in stream order on torch's CURRENT stream (the kernels are enqueued on that very stream, so they see the
+        actions the preceding torch kernels produce and later torch ops see the rows); observation scaling (scale_gym_data with
+        the float32 Box limits) runs on the device in float32."""
         import torch
         a = actions.contiguous()
         assert a.is_cuda and a.dtype == torch.float32 and tuple(a.shape) == (self.num_envs, self._engine.act_dim)
@@ -162,13 +164,10 @@ class PandaTaskBase(Env):
             box = self.observation_space["observation"] if hasattr(self.observation_space, "spaces") else self.observation_space
             self._t_low = torch.as_tensor(box.low, device=a.device)
             self._t_inv = 1.0 / (torch.as_tensor(box.high, device=a.device) - self._t_low)
-        stream = torch.cuda.current_stream(a.device).cuda_stream
-        self._engine.step_device(a.data_ptr(), self._t_out.data_ptr(), stream or None)
-        if not stream:
-            self._engine.sync()          # the null stream maps to the engine's own stream: order it before torch ops
+        self._engine.step_device(a.data_ptr(), self._t_out.data_ptr(), _capi.torch_stream(a.device))
         od = self._engine.obs_dim
         obs = 2.0 * ((self._t_out[:, :od] - self._t_low) * self._t_inv) - 1.0
-        return obs, self._t_out[:, od], self._t_out[:, od + 1]
+        return obs, self._t_out[:, od].clone(), self._t_out[:, od + 1].clone()
 
     def seed(self, seed=None):
         self.np_random, seed = seeding.np_random(seed)
@@ -184,22 +183,20 @@ class PandaTaskBase(Env):
     # ------------------------------------------------------------------ reference attributes
     @property
     def _env_step_counter(self):
-        return self._squeeze(self._engine.get_state()[:, self._engine.x_off + 3].astype(np.int64))
+        return self._squeeze(self._engine.get_state_cols(self._engine.x_off + 3)[:, 0].astype(np.int64))
 
     @property
     def terminated(self):
-        return self._squeeze(self._engine.get_state()[:, self._engine.x_off + 4].astype(np.int64))
+        return self._squeeze(self._engine.get_state_cols(self._engine.x_off + 4)[:, 0].astype(np.int64))
 
     @property
     def _hand_pose(self):
         """Commanded hand pose (x, y, z, roll, pitch, yaw) of the IK mode (panda_push_gym_env.py:142-143, 197-222)."""
-        x = self._engine.x_off
-        return self._squeeze(self._engine.get_state()[:, x + 6:x + 12].astype(np.float64))
+        return self._squeeze(self._engine.get_state_cols(self._engine.x_off + 6, 6).astype(np.float64))
 
     @property
     def _target_pose(self):
-        x = self._engine.x_off
-        return self._squeeze(self._engine.get_state()[:, x:x + 3].astype(np.float64))
+        return self._squeeze(self._engine.get_state_cols(self._engine.x_off, 3).astype(np.float64))
 
     def debug_gui(self):
         pass

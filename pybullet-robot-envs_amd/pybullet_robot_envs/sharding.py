@@ -62,9 +62,13 @@ class ShardedEngine(object):
         return out[:, :self.obs_dim], out[:, self.obs_dim], out[:, self.obs_dim + 1]
 
     # ---- device-resident path (torch CUDA tensors; one RCCL gather per step) ----
-    def step_device(self, actions, out, gathered=None, stream=0):
+    def step_device(self, actions, out, gathered=None, stream=None):
         """actions [n_local, act_dim] and out [n_local, obs_dim + 2]: CUDA float32 tensors on this rank's GPU;
-        gathered: list of `world` tensors like `out` on rank 0 (None elsewhere).  Asynchronous on `stream`."""
+        gathered: list of `world` tensors like `out` on rank 0 (None elsewhere).  Asynchronous.  The step kernels go to torch's
+        current stream (stream=None) -- the stream RCCL orders the gather against -- or to the given hipStream_t handle, which then
+        must be the stream torch.distributed sees as current (torch.cuda.set_stream / with torch.cuda.stream(...))."""
+        if stream is None:
+            stream = _capi.torch_stream(actions.device)
         self.engine.step_device(actions.data_ptr(), out.data_ptr(), stream)
         if self.distributed:
             self.dist.gather(out, gathered if self.rank == 0 else None, dst=0)

@@ -228,6 +228,13 @@ int pbre_sync(pbre_ctx*) { return PBRE_OK; }
 int pbre_get_state(pbre_ctx* c, float* s) { if (!c || !s) return PBRE_E_ARG; std::memcpy(s, c->state.data(), c->state.size() * 4); return PBRE_OK; }
 int pbre_set_state(pbre_ctx* c, const float* s) { if (!c || !s) return PBRE_E_ARG; std::memcpy(c->state.data(), s, c->state.size() * 4); return PBRE_OK; }
 
+int pbre_get_state_cols(pbre_ctx* c, int32_t first, int32_t count, float* out) {
+    if (!c || !out || first < 0 || count <= 0 || first + count > c->sf) return PBRE_E_ARG;
+    for (int e = 0; e < c->n; e++) std::memcpy(out + (size_t)e * count, c->state.data() + (size_t)e * c->sf + first, (size_t)count * 4);
+    return PBRE_OK;
+}
+void* pbre_host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+void pbre_host_free(void* p) { std::free(p); }
 int pbre_observe(pbre_ctx* c, float* obs) {
     if (!c || !obs) return PBRE_E_ARG;
     c->observe(obs);

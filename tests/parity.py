@@ -5,14 +5,119 @@ import numpy as np
 import orc
 import scenarios
 
-# float tolerances: device arithmetic is fp32, oracle fp64.  `rel` is |a-b| / (1 + |b|).
-TOL_STATE = 2e-4      # one step from identical states, all state entries
-TOL_OBS = 2e-3        # raw observation (EE velocity entries are divided by 0.03..0.07)
+# Float tolerances.  Device arithmetic is fp32, the oracle fp64.  They are stated PER QUANTITY, as absolute errors in the quantity's
+# own unit after one step from identical fp32 states (calibrated on the fp32 lane emulation and the GPU: about 4x the worst
+# value seen over the scenarios of tests/test_emu_parity.py / test_gpu_parity.py; `tools/parity_report.py` prints the measured ones).
+# Observation entries are compared in the raw (unscaled) layout of Appendix C of SURVEY.md.
+TOL = {
+    "q": 1.5e-6,          # joint angles [rad] (a step moves a joint by <= 0.025 rad; measured 1.8e-7)
+    "qd": 1.5e-4,         # joint velocities [rad/s] (measured 1.4e-5)
+    "obj_pos": 3e-7,      # object position [m]
+    "obj_quat": 8e-7,     # object quaternion components (sign-aligned)
+    "obj_v": 5e-5,        # object linear velocity [m/s]
+    "obj_w": 5e-6,        # object angular velocity [rad/s]
+    "obs_ee_pos": 1.5e-6, # end-effector position [m]
+    "obs_ee_eul": 3e-6,   # end-effector Euler angles [rad] (compared modulo 2 pi)
+    "obs_ee_vel": 2e-3,   # (v - offset) / [0.04, 0.07, 0.03]: the reference's normalised EE velocity (panda_env.py:174-178); measured 2.5e-4
+    "obs_q": 1.5e-6,
+    "obs_obj_pos": 3e-7, "obs_obj_eul": 1e-6,
+    "obs_rel_pos": 2.5e-6, "obs_rel_eul": 3e-6,   # object pose in the hand frame
+    "obs_target": 1e-7,
+    "reward": 2e-6,       # |dr| / (1 + |r|)
+}
+# Contact-rich crafted states (penetrating robot-table / robot-object contacts, stiff motor-vs-contact conflicts, 150 PGS sweeps
+# amplify fp32 rounding; the oracle's own fp32 build is ~1.5e-4 away from its fp64 build in the lumped measure there)
+TOL_CONTACT = {
+    "q": 1e-5, "qd": 2.5e-3, "obj_pos": 5e-7, "obj_quat": 5e-6, "obj_v": 1e-4, "obj_w": 3e-3,
+    "obs_ee_pos": 2e-6, "obs_ee_eul": 4e-6, "obs_ee_vel": 5e-3, "obs_q": 1e-5, "obs_obj_pos": 5e-7, "obs_obj_eul": 1e-5,
+    "obs_rel_pos": 2.5e-6, "obs_rel_eul": 1e-5, "obs_target": 1e-7, "reward": 2e-6,
+}
+TOL_STATE = 2e-4      # lumped |a-b| / (1 + |b|) bounds, kept for the free-running / multi-step checks
+TOL_OBS = 2e-3
 TOL_REWARD = 1e-4
 
 
 def rel(a, b):
     return np.abs(np.asarray(a, np.float64) - b) / (1.0 + np.abs(b))
+
+
+def angdiff(a, b):
+    d = np.abs(np.asarray(a, np.float64) - b) % (2 * np.pi)
+    return np.minimum(d, 2 * np.pi - d)
+
+
+def panda_quantities(se, so, ob, out, rw=None, task=1):
+    """max abs error per quantity, Panda layout (state record: include/pbre.h; observation: SURVEY App. C)"""
+    q = {}
+    if len(se) == 0:
+        return q
+    se = np.asarray(se, np.float64)
+    q["q"] = np.abs(se[:, 0:9] - so[:, 0:9]).max()
+    q["qd"] = np.abs(se[:, 16:25] - so[:, 16:25]).max()
+    q["obj_pos"] = np.abs(se[:, 9:12] - so[:, 9:12]).max()
+    sgn = np.sign((se[:, 12:16] * so[:, 12:16]).sum(1, keepdims=True))          # q and -q are the same rotation
+    q["obj_quat"] = np.abs(se[:, 12:16] * sgn - so[:, 12:16]).max()
+    q["obj_v"] = np.abs(se[:, 25:28] - so[:, 25:28]).max()
+    q["obj_w"] = np.abs(se[:, 28:31] - so[:, 28:31]).max()
+    ob = np.asarray(ob, np.float64)
+    o = out[:, :-2]
+    q["obs_ee_pos"] = np.abs(ob[:, 0:3] - o[:, 0:3]).max()
+    q["obs_ee_eul"] = angdiff(ob[:, 3:6], o[:, 3:6]).max()
+    q["obs_ee_vel"] = np.abs(ob[:, 6:9] - o[:, 6:9]).max()
+    q["obs_q"] = np.abs(ob[:, 9:18] - o[:, 9:18]).max()
+    q["obs_obj_pos"] = np.abs(ob[:, 18:21] - o[:, 18:21]).max()
+    q["obs_obj_eul"] = angdiff(ob[:, 21:24], o[:, 21:24]).max()
+    q["obs_rel_pos"] = np.abs(ob[:, 24:27] - o[:, 24:27]).max()
+    q["obs_rel_eul"] = angdiff(ob[:, 27:30], o[:, 27:30]).max()
+    if ob.shape[1] > 30:
+        q["obs_target"] = np.abs(ob[:, 30:33] - o[:, 30:33]).max()
+    if rw is not None:
+        q["reward"] = rel(rw, out[:, -2]).max()
+    return q
+
+
+def group_quantities(eng, se, so, ob, out, tail=0):
+    """max abs error per quantity for the lane-group engines (iCub: 20 DoF, iCub with hands: 60 DoF; state record Q[W] | V[W] | X[16],
+    observation = EE position, EE Euler angles, EE linear velocity (raw, m/s), controlled joints, world / task entries, and for
+    the hands `tail` = 7 fingertip force / count entries)"""
+    nd, vo = eng.ndof, eng.v_off
+    se = np.asarray(se, np.float64); ob = np.asarray(ob, np.float64)
+    o = out[:, :-2]
+    q = {"q": np.abs(se[:, :nd] - so[:, :nd]).max(), "qd": np.abs(se[:, vo:vo + nd] - so[:, vo:vo + nd]).max(),
+         "obj_pos": np.abs(se[:, nd:nd + 3] - so[:, nd:nd + 3]).max()}
+    sgn = np.sign((se[:, nd + 3:nd + 7] * so[:, nd + 3:nd + 7]).sum(1, keepdims=True))
+    q["obj_quat"] = np.abs(se[:, nd + 3:nd + 7] * sgn - so[:, nd + 3:nd + 7]).max()
+    q["obj_v"] = np.abs(se[:, vo + nd:vo + nd + 3] - so[:, vo + nd:vo + nd + 3]).max()
+    q["obj_w"] = np.abs(se[:, vo + nd + 3:vo + nd + 6] - so[:, vo + nd + 3:vo + nd + 6]).max()
+    q["obs_ee_pos"] = np.abs(ob[:, 0:3] - o[:, 0:3]).max()
+    q["obs_ee_eul"] = angdiff(ob[:, 3:6], o[:, 3:6]).max()
+    q["obs_ee_vel"] = np.abs(ob[:, 6:9] - o[:, 6:9]).max()
+    end = ob.shape[1] - tail
+    rest_e, rest_o = ob[:, 9:end], o[:, 9:end]
+    q["obs_rest"] = np.minimum(np.abs(rest_e - rest_o), angdiff(rest_e, rest_o)).max()      # joints, positions, Euler angles (mod 2 pi)
+    return q
+
+
+# iCub (half-wave engine), one step from identical fp32 states, JOINT control; measured on the lane emulation: q 7e-8, qd 1.2e-5,
+# EE velocity 3.4e-6 m/s, everything else <= 2.2e-7
+TOL_ICUB = {"q": 1e-6, "qd": 1.5e-4, "obj_pos": 3e-7, "obj_quat": 5e-7, "obj_v": 5e-5, "obj_w": 5e-6,
+            "obs_ee_pos": 1e-6, "obs_ee_eul": 2e-6, "obs_ee_vel": 5e-5, "obs_rest": 2e-6}
+# IK control: the damped-least-squares iteration stops at a 1 mm residual, so fp32 and fp64 may stop one iteration apart; an env
+# in which that happens gets joint targets ~3e-3 rad apart (1 mm at a 0.3 m lever) and moves kp = 0.2 of that in the step.  Such
+# envs are held to TOL_ICUB_IK_FLIP, counted and reported; all others to TOL_ICUB.
+TOL_ICUB_IK_FLIP = {"q": 1e-3, "qd": 0.25, "obs_ee_pos": 5e-4, "obs_ee_eul": 2e-3, "obs_ee_vel": 0.1, "obs_rest": 1e-3}
+
+
+def merge_worst(worst, q):
+    for k, v in q.items():
+        worst[k] = max(worst.get(k, 0.0), float(v))
+    return worst
+
+
+def assert_within(worst, tol=None, context=""):
+    tol = TOL if tol is None else tol
+    bad = dict((k, (v, tol[k])) for k, v in worst.items() if k in tol and not v <= tol[k])
+    assert not bad, "per-quantity tolerance exceeded (measured, bound): %r %s" % (bad, context)
 
 
 def make_pair(Engine, lib, table, n, task=1, obj_std=0.05, tg_std=0.2, **kw):
@@ -51,11 +156,17 @@ def ambiguous_envs(ora, s64, a, delta=3e-6):
     return bad
 
 
-def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_obs=TOL_OBS, skip_ambiguous=False):
-    """From identical fp32 states, one step each; re-synchronised every step."""
+def check_single_steps(eng, ora, states, rng, steps=1, tol=None, skip_ambiguous=False, max_skip=0.2, report=None):
+    """From identical fp32 states, one step each; re-synchronised every step.  Every quantity is held to its own bound (`tol`:
+    TOL by default, TOL_CONTACT for contact-rich states).  skip_ambiguous: envs whose contact set flips under a +-3 um nudge of the contact margin are excluded (a
+    discontinuity, not an error); the excluded fraction is bounded by `max_skip` and reported, like the number of envs whose
+    done flag differs (a success threshold crossed by an fp32 rounding).  Returns the report dict (also filled into `report`)."""
     st = np.asarray(states, np.float64)
     n = st.shape[0]
-    worst = {"state": 0.0, "obs": 0.0, "reward": 0.0}
+    worst = {}
+    rep = report if report is not None else {}
+    rep.update({"envs": n, "steps": steps, "skipped_ambiguous": 0, "done_flips": 0, "compared": 0})
+    task = ora.task.task if hasattr(ora.task, "task") else 1
     for _ in range(steps):
         a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
         s32 = st.astype(np.float32)
@@ -63,21 +174,24 @@ def check_single_steps(eng, ora, states, rng, steps=1, tol_state=TOL_STATE, tol_
         ob, rw, dn = eng.step(a)
         se = eng.get_state()
         so, out = ora.batch_step(s32.astype(np.float64), a)
+        ok = np.ones(n, bool)
         if skip_ambiguous:
             ok = ~ambiguous_envs(ora, s32.astype(np.float64), a)
-            assert ok.mean() > 0.8, "too many threshold-ambiguous states"
-            se, so, ob, rw, dn, out = se[ok], so[ok], ob[ok], rw[ok], dn[ok], out[ok]
-        worst["state"] = max(worst["state"], rel(se, so).max())
-        worst["obs"] = max(worst["obs"], rel(ob, out[:, :-2]).max())
-        # reward/done: a success threshold can flip on an fp32 rounding; compare away from the threshold
-        flip = dn != out[:, -1]
-        assert flip.sum() <= max(1, n // 100), "done flags differ in %d envs" % flip.sum()
-        worst["reward"] = max(worst["reward"], rel(rw[~flip], out[~flip, -2]).max())
-        st = so if not skip_ambiguous else None
-    assert worst["state"] < tol_state, worst
-    assert worst["obs"] < tol_obs, worst
-    assert worst["reward"] < TOL_REWARD, worst
-    return worst
+            rep["skipped_ambiguous"] += int((~ok).sum())
+            assert (~ok).mean() <= max_skip, "threshold-ambiguous states: %d of %d skipped (bound %.0f %%)" % ((~ok).sum(), n, 100 * max_skip)
+        # reward/done: a success threshold can flip on an fp32 rounding; such envs are counted and their reward is not compared
+        flip = (dn != out[:, -1]) & ok
+        rep["done_flips"] += int(flip.sum())
+        assert flip.sum() <= max(1, n // 100), "done flags differ in %d of %d envs" % (flip.sum(), n)
+        rep["compared"] += int(ok.sum())
+        merge_worst(worst, panda_quantities(se[ok], so[ok], ob[ok], out[ok]))
+        k2 = ok & ~flip
+        if k2.any():
+            merge_worst(worst, {"reward": rel(rw[k2], out[k2, -2]).max()})
+        st = so
+    rep["worst"] = worst
+    assert_within(worst, tol, "(%d envs x %d steps, %d skipped as ambiguous, %d done flips)" % (n, steps, rep["skipped_ambiguous"], rep["done_flips"]))
+    return rep
 
 
 def contact_states(ora, panda, base, rng, n_table=8, n_obj=8):
@@ -200,6 +314,7 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
     assert rel(obs, obs_o).max() < 1e-2
     rng = np.random.default_rng(seed)
     st = st_o
+    worst, flips = {}, 0
     for k in range(steps):
         a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
         s32 = st.astype(np.float32)
@@ -208,11 +323,18 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
         so, out = ora.batch_step(s32.astype(np.float64), a)
         se = eng.get_state()
         assert np.abs(se[:, xo + 6:xo + 12] - so[:, xo + 6:xo + 12]).max() < 1e-6      # commanded hand pose
-        assert rel(se[:, :xo], so[:, :xo]).max() < 2e-3, (k, rel(se[:, :xo], so[:, :xo]).max())
-        assert rel(ob, out[:, :-2]).max() < 2e-2, (k, rel(ob, out[:, :-2]).max())
+        nd = eng.ndof
+        flip = np.abs(se[:, :nd] - so[:, :nd]).max(1) > TOL_ICUB["q"] if use_ik else np.zeros(n, bool)
+        flips += int(flip.sum())
+        if (~flip).any():
+            merge_worst(worst, group_quantities(eng, se[~flip], so[~flip], ob[~flip], out[~flip]))
+        if flip.any():
+            assert_within(group_quantities(eng, se[flip], so[flip], ob[flip], out[flip]), TOL_ICUB_IK_FLIP, "(IK stopped one iteration apart, step %d)" % k)
         assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
         assert (dn == out[:, -1]).all()
         st = so
+    assert flips <= max(1, n * steps // 10), "IK iteration-count flips in %d of %d env-steps" % (flips, n * steps)
+    assert_within(worst, TOL_ICUB, "(iCub, %d envs x %d steps, %d IK flips)" % (n, steps, flips))
     return eng
 
 
@@ -385,6 +507,12 @@ def make_hands_pair(Engine, lib, n, control_arm="r", use_ik=0, obj_std=0.0, **kw
     return eng, ora, info
 
 
+# iCub with hands (one env per wavefront), one step from identical fp32 states; measured on the lane emulation: joint control q 6e-8,
+# qd 5e-6; IK control q 6e-7, qd 1.4e-4, EE velocity 9e-6 m/s
+TOL_HANDS = {"q": 5e-6, "qd": 1e-3, "obj_pos": 3e-7, "obj_quat": 8e-7, "obj_v": 5e-5, "obj_w": 5e-6,
+             "obs_ee_pos": 1e-6, "obs_ee_eul": 3e-6, "obs_ee_vel": 1e-4, "obs_rest": 5e-6}
+
+
 def check_hands(Engine, lib, control_arm="r", use_ik=0, n=1, steps=3, seed=7, tol=2e-3):
     """iCub with hands (60 DoF, one env per 128-virtual-lane group) against the oracle: reset, commands, single steps from identical
     states; finger commands through pbre_set_motors."""
@@ -400,6 +528,7 @@ def check_hands(Engine, lib, control_arm="r", use_ik=0, n=1, steps=3, seed=7, to
     rng = np.random.default_rng(seed)
     home = np.asarray(info["home"])[info["controlled"]]
     st = st_o
+    worst, flips = {}, 0
     for k in range(steps):
         if k == 1:      # pre_grasp / grasp of the controlled hand (icub_env_with_hands.py:181-234)
             pos = list(GRASP_POS)
@@ -415,11 +544,19 @@ def check_hands(Engine, lib, control_arm="r", use_ik=0, n=1, steps=3, seed=7, to
         ob, rw, dn = eng.step(a)
         so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
         se = eng.get_state()
-        assert rel(se[:, :xo], so[:, :xo]).max() < tol, (k, rel(se[:, :xo], so[:, :xo]).max())
-        assert rel(ob, out[:, :-2]).max() < 2e-2, (k, rel(ob, out[:, :-2]).max())
+        nd = eng.ndof
+        flip = np.abs(se[:, :nd] - so[:, :nd]).max(1) > TOL_HANDS["q"] if use_ik else np.zeros(n, bool)     # see TOL_ICUB_IK_FLIP
+        flips += int(flip.sum())
+        if (~flip).any():
+            merge_worst(worst, group_quantities(eng, se[~flip], so[~flip], ob[~flip], out[~flip], tail=7))
+        if flip.any():
+            assert_within(group_quantities(eng, se[flip], so[flip], ob[flip], out[flip], tail=7), TOL_ICUB_IK_FLIP, "(IK flip, step %d)" % k)
+        assert np.abs(ob[:, -7:] - out[:, -9:-2]).max() < 1e-6                       # no fingertip contact in this scenario: forces / counts are 0
         assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
         assert (dn == out[:, -1]).all() and not dn.any()
         st = so
+    assert flips <= max(1, n * steps // 10), "IK iteration-count flips in %d of %d env-steps" % (flips, n * steps)
+    assert_within(worst, TOL_HANDS, "(hands, %d envs x %d steps, %d IK flips)" % (n, steps, flips))
     return eng, ora, info, st, mrec
 
 
@@ -511,3 +648,96 @@ def check_implicit_damping(Engine, lib, table, n=6):
     import pytest
     with pytest.raises(RuntimeError, match="explicit joint damping"):
         e2.set_physics(implicit_joint_damping=1)
+
+
+# ---------------------------------------------------------------------------------------------- full-episode rollouts, glue-only
+def check_panda_full_episode(Engine, lib, table, n=8, steps=1000, seed=3):
+    """A whole 1000-step Panda-push episode, free running (no re-synchronisation) with i.i.d. U(-1,1) actions, against the
+    oracle.  Stated drift bounds at EVERY step: joint angles 2e-5 rad, joint velocities 5e-4 rad/s (the position-controlled arm
+    is contractive); the object of an env whose robot never came within the contact margin of it stays within 1e-6 m / 2e-6
+    (quaternion); once a robot-object contact has happened the closed loop is contact-chaotic (a 1e-7 difference decides
+    whether a candidate is inside the margin), so those envs are only bounded loosely (2 cm) and their number is reported."""
+    eng, ora = make_pair(Engine, lib, table, n, max_steps=steps + 10)
+    st = check_reset(eng, ora, n)
+    st[:, 32:35] = [0.6, 0.3, 0.65]                      # far target: no success latch, the episode runs its full length
+    st = st.astype(np.float32).astype(np.float64)
+    eng.set_state(st.astype(np.float32))
+    obj0 = st[:, 9:12].copy()
+    rng = np.random.default_rng(seed)
+    worst = {"q": 0.0, "qd": 0.0, "obj_untouched": 0.0, "obj_touched": 0.0}
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(st, a)
+        if k % 25 == 24 or k == steps - 1:
+            se = eng.get_state().astype(np.float64)
+            touched = np.abs(st[:, 9:12] - obj0).max(1) > 1e-5
+            worst["q"] = max(worst["q"], np.abs(se[:, :9] - st[:, :9]).max())
+            worst["qd"] = max(worst["qd"], np.abs(se[:, 16:25] - st[:, 16:25]).max())
+            d = np.abs(se[:, 9:16] - st[:, 9:16]).max(1)
+            if (~touched).any():
+                worst["obj_untouched"] = max(worst["obj_untouched"], d[~touched].max())
+            if touched.any():
+                worst["obj_touched"] = max(worst["obj_touched"], d[touched].max())
+            assert not dn.any() and not out[:, -1].any()
+    worst["touched_envs"] = int(touched.sum())
+    assert worst["q"] < 2e-5 and worst["qd"] < 5e-4 and worst["obj_untouched"] < 2e-6 and worst["obj_touched"] < 2e-2, worst
+    assert (eng.get_state()[:, 35] == steps).all() and (st[:, 35] == steps).all()
+    return worst
+
+
+def check_icub_full_episode(Engine, lib, n=2, steps=2000, seed=5):
+    """A whole 2000-step iCub-push episode in joint control (10 torso + arm joints, U(-1,1) actions), free running against the
+    oracle; drift bounds at every 50th step: joint angles 2e-5 rad, joint velocities 5e-4 rad/s, object pose 2e-6.  (With IK
+    control the restated closed loop is chaotic after ~250 steps -- tests/test_golden_icub.py: check_config1 -- so the
+    full-length drift bound is stated for joint control.)"""
+    eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=0, obj_std=0.05, tg_std=0.2, max_steps=steps + 10)
+    eng.reset()
+    st, _ = ora.batch_reset(n)
+    xo, nd, vo = eng.x_off, eng.ndof, eng.v_off
+    st[:, xo:xo + 3] = [0.9, 0.5, 0.65]
+    st = st.astype(np.float32).astype(np.float64)
+    eng.set_state(st.astype(np.float32))
+    rng = np.random.default_rng(seed)
+    worst = {"q": 0.0, "qd": 0.0, "obj": 0.0}
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(st, a)
+        if k % 50 == 49:
+            se = eng.get_state().astype(np.float64)
+            worst["q"] = max(worst["q"], np.abs(se[:, :nd] - st[:, :nd]).max())
+            worst["qd"] = max(worst["qd"], np.abs(se[:, vo:vo + nd] - st[:, vo:vo + nd]).max())
+            worst["obj"] = max(worst["obj"], np.abs(se[:, nd:nd + 7] - st[:, nd:nd + 7]).max())
+            assert not dn.any()
+    assert worst["q"] < 2e-5 and worst["qd"] < 5e-4 and worst["obj"] < 2e-6, worst
+    return worst
+
+
+def check_device_glue(Engine, lib, table):
+    """The observation glue ALONE on the device (<= 1e-6 relative in the fp32 path): pbre_set_state from the states of
+    the reference-captured trajectories (tests/golden/panda_glue.npz, `*_pre_state[k+1]` = the state after step k), pbre_observe,
+    against the raw observation the reference's own get_extended_observation produced for that state (`*_raw_obs[k]`).
+    Bounds: |d| / (1 + |x|) <= 1e-6 on every entry except the three normalised end-effector velocity entries, which the
+    reference divides by 0.04 / 0.07 / 0.03 (panda_env.py:174-178): those are held to 3e-6 m/s before the division (the fp32 rounding of
+    the nine joint velocities of the input state alone is ~1e-6 m/s at the hand)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "panda_glue.npz"))
+    worst = {"rel": 0.0, "ee_vel_mps": 0.0}
+    for tag, task, ik in (("pushA", 1, 0), ("pushB", 1, 0), ("reachC", 0, 0), ("goalD", 2, 0), ("ikF", 1, 1)):
+        pre, raw = G[tag + "_pre_state"], G[tag + "_raw_obs"]
+        n = len(pre) - 1
+        eng = Engine(table, task=task, num_envs=n, lib=lib, use_ik=ik)
+        eng.set_state(pre[1:].astype(np.float32))
+        ob = eng.observe().astype(np.float64)
+        ref = raw[:-1]
+        e = np.abs(ob - ref) / (1.0 + np.abs(ref))
+        ang = [3, 4, 5, 21, 22, 23, 27, 28, 29]
+        e[:, ang] = angdiff(ob[:, ang], ref[:, ang]) / (1.0 + np.abs(ref[:, ang]))
+        vel = np.abs(ob[:, 6:9] - ref[:, 6:9]) * np.array([0.04, 0.07, 0.03])
+        e[:, 6:9] = 0.0
+        worst["rel"] = max(worst["rel"], e.max())
+        worst["ee_vel_mps"] = max(worst["ee_vel_mps"], vel.max())
+        eng.close()
+    assert worst["rel"] <= 1e-6 and worst["ee_vel_mps"] <= 3e-6, worst
+    return worst

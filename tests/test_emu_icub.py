@@ -70,3 +70,8 @@ def test_icub_full_model_one_env_per_64_lanes(emu_lib):
 
 def test_icub_neighbour_independence(emu_lib):
     parity.check_wave_neighbour_independence(_capi.Engine, emu_lib, steps=2)
+
+
+def test_icub_full_episode_rollout(emu_lib):
+    """2000 free-running steps (a whole iCub episode, joint control) against the oracle with stated drift bounds"""
+    parity.check_icub_full_episode(_capi.Engine, emu_lib, n=2, steps=2000)

@@ -24,7 +24,7 @@ def test_contact_rich_states(panda, emu_lib, flags):
     S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
     eng, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], len(S), flags=flags)
     # stiff motor-vs-contact conflicts amplify fp32 rounding: the oracle's own fp32 build is 1.5e-4 away
-    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol=parity.TOL_CONTACT, skip_ambiguous=True, max_skip=0.1)
 
 
 @pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS])
@@ -131,3 +131,13 @@ def test_action_repeat(panda, emu_lib, use_ik, flags):
 
 def test_force_limited_motors(emu_lib, panda):
     parity.check_panda_force_limited(_capi.Engine, emu_lib, panda["table"], n=3)
+
+
+def test_device_glue_only(panda, emu_lib):
+    """observation glue alone, from reference-captured states, <= 1e-6 (tests/parity.py: check_device_glue)"""
+    parity.check_device_glue(_capi.Engine, emu_lib, panda["table"])
+
+
+def test_full_episode_rollout(panda, emu_lib):
+    """1000 free-running steps (a whole Panda episode) against the oracle with stated drift bounds"""
+    parity.check_panda_full_episode(_capi.Engine, emu_lib, panda["table"], n=4, steps=1000)

@@ -55,6 +55,11 @@ def test_config1_icub_reach_trace(hip_lib):
     tgi.check_config1(hip_lib, 500)
 
 
+def test_icub_full_episode_rollout(hip_lib):
+    """A whole 2000-step iCub-push episode (joint control), free running, against the oracle; drift bounds in parity.py."""
+    print("iCub full-episode drift:", parity.check_icub_full_episode(_capi.Engine, hip_lib, n=6, steps=2000))
+
+
 @pytest.mark.parametrize("n", [1, 3, 5])
 def test_icub_ragged_batch_sizes(hip_lib, n):
     parity.check_icub(_capi.Engine, hip_lib, 1, "l", 1, 0, 1, n=n, steps=2)

@@ -26,7 +26,7 @@ def test_contact_rich_states(panda, hip_lib, flags):
     rng = np.random.default_rng(1)
     S = parity.contact_states(ora, panda, base[0], rng, 24, 24)
     eng, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], len(S), flags=flags)
-    parity.check_single_steps(eng, ora, S, rng, steps=1, tol_state=1e-3, tol_obs=5e-3, skip_ambiguous=True)
+    parity.check_single_steps(eng, ora, S, rng, steps=1, tol=parity.TOL_CONTACT, skip_ambiguous=True, max_skip=0.1)
 
 
 @pytest.mark.parametrize("flags", [_capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES])
@@ -51,6 +51,17 @@ def test_free_running_rollout(panda, hip_lib):
         st, out = ora.batch_step(st, a)
     assert parity.rel(eng.get_state(), st).max() < 2e-3
     assert parity.rel(ob, out[:, :-2]).max() < 1e-2
+
+
+def test_full_episode_rollout(panda, hip_lib):
+    """A whole 1000-step episode, free running, against the oracle: drift bounds stated in parity.check_panda_full_episode."""
+    w = parity.check_panda_full_episode(_capi.Engine, hip_lib, panda["table"], n=24, steps=1000)
+    print("full-episode drift:", w)
+
+
+def test_device_glue_only(panda, hip_lib):
+    """The observation glue alone on the GPU from reference-captured states: <= 1e-6."""
+    print("glue-only:", parity.check_device_glue(_capi.Engine, hip_lib, panda["table"]))
 
 
 def test_matches_host_lane_emulation(panda, hip_lib, emu_lib):
@@ -137,6 +148,7 @@ def test_reference_golden_outputs(hip_lib):
     """Outputs of the reference's own classes (tests/golden, captured over the oracle's physics) reproduced by the
     HIP engine through the drop-in classes, step by step from the reference's states."""
     import os
+    import test_golden_glue as tgg
     from pybullet_robot_envs.envs import pandaPushGymEnv, pandaReachGymEnv, pandaPushGymGoalEnv
     G = np.load(os.path.join(os.path.dirname(__file__), "golden", "panda_glue.npz"))
     for cls, tag, kw in [(pandaPushGymEnv, "pushA", {}), (pandaPushGymEnv, "pushB", {"max_steps": 6}),
@@ -154,11 +166,12 @@ def test_reference_golden_outputs(hip_lib):
             env._engine.set_state(s)
             ob, r, d, info = env.step(G[tag + "_actions"][k])
             ob = ob["observation"] if goal else ob
-            assert np.abs(ob - G[tag + "_obs"][k]).max() < 5e-3
-            assert abs(float(r) - G[tag + "_reward"][k]) < 1e-3 * max(1, abs(G[tag + "_reward"][k]))
+            tgg.check_scaled_obs(ob, G[tag + "_obs"][k], tag, k)
+            assert abs(float(r) - G[tag + "_reward"][k]) < 2e-5 * max(1, abs(G[tag + "_reward"][k]))
             assert float(d) == G[tag + "_done"][k]
             assert int(env._env_step_counter) == G[tag + "_counter"][k]
         env.close()
+    print("golden replay worst (scaled obs):", tgg.WORST)
 
 
 @pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
@@ -210,6 +223,40 @@ def test_env_classes_and_tensor_api(hip_lib):
     assert np.allclose(rew_t.cpu().numpy(), rew_h, atol=1e-5) and np.array_equal(done_t.cpu().numpy(), done_h)
     env.change_physics_params(0.2, 0.7, 0.05, 0.05)
     assert env._engine.get_physics().obj_mass == 0.2
+    env.close(); ref.close()
+
+
+def test_step_tensor_is_ordered_with_the_producing_stream(hip_lib):
+    """on torch's default (null) stream the actions may still be in flight when step_tensor is called.  The
+    step must be enqueued in stream order behind the kernels that produce the actions and ahead of kernels that overwrite them;
+    host-synchronous entry points called right after must see the finished step."""
+    import torch
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    n = 4096
+    env = pandaPushGymEnv(num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    ref = pandaPushGymEnv(num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    env.reset(); ref.reset()
+    a = np.random.default_rng(2).uniform(-1, 1, (n, 7)).astype(np.float32)
+    a_dev = torch.as_tensor(a, device="cuda")
+    torch.cuda.synchronize()
+    for stream in (None, torch.cuda.Stream()):
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream()):
+            x = torch.randn(2048, 2048, device="cuda")
+            for _ in range(30):                        # tens of ms of queued work ahead of the actions
+                x = torch.tanh(x @ x) * 0.01
+            act = a_dev + 0.0 * x[0, 0]                # produced at the end of that chain, asynchronously
+            obs_t, rew_t, done_t = env.step_tensor(act)
+            act.fill_(7.0)                             # overwritten right after the step was enqueued
+            st = env._engine.get_state()               # host-synchronous entry point right behind an external-stream step
+        obs_h, rew_h, done_h, _ = ref.step(a)
+        assert np.array_equal(st, ref._engine.get_state())
+        assert np.abs(obs_t.cpu().numpy() - obs_h).max() < 1e-4
+        assert np.allclose(rew_t.cpu().numpy(), rew_h, atol=1e-5) and np.array_equal(done_t.cpu().numpy(), done_h)
+    # returned reward / done tensors are the caller's: a later step does not overwrite them
+    keep = rew_t.clone()
+    env.step_tensor(a_dev * 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(keep, rew_t)
     env.close(); ref.close()
 
 
