@@ -129,3 +129,33 @@ def test_implicit_joint_damping_option(hip_lib, panda):
 
 def test_hands_force_limited_reset(hip_lib):
     parity.check_hands_force_limited_reset(_capi.Engine, hip_lib, n=3)
+
+
+def test_config5_at_size(hip_lib):
+    """BASELINE config 5 at its per-GPU size (8192 = 65536 / 8 envs of the 60-DoF iCub with hands): reset and the reference demo's
+    scripted phases (pre-grasp -> approach -> grasp -> lift -> move -> open, helloworld_icub.py:61-125) on the whole batch.
+    Size-independent properties: everything finite, unit quaternions, the closing fingers are in contact with the object in every
+    env during the grasp phase, and -- the object pose is not randomised here -- all 8192 replicas are bit-identical."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import demo_icub_hands
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+    n = 8192
+    cid = _client.connect(n, lib=hip_lib)
+    robot = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+    eng = robot._engine
+    seen = {"tips": 0, "points": 0}
+
+    def log(line):
+        st = eng.get_state()
+        nd = eng.ndof
+        assert np.isfinite(st).all(), line
+        assert np.abs(np.linalg.norm(st[:, nd + 3:nd + 7], axis=1) - 1).max() < 1e-5, line
+        assert (st == st[0]).all(), "replicas diverged: " + line
+        seen["tips"] = max(seen["tips"], int(st[0, nd + 12])); seen["points"] = max(seen["points"], int(st[0, nd + 13]))
+    demo_icub_hands.run(robot, log=log)
+    assert seen["tips"] >= 1 and seen["points"] >= 1, seen          # fingertip / robot-object contacts were exercised
+    obs, _ = robot.get_observation()
+    assert obs.shape == (n, 46) and np.isfinite(obs).all()
+    _client.disconnect(cid)
