@@ -396,7 +396,9 @@ def main():
 
     # headline: steady state after the pre-roll
     job.preroll(args.preroll - args.warmup)
+    csum0 = eng.kernel_info()[7]
     head = job.timed(args.steps, args.warmup, events=True)
+    complex_per_step = ((eng.kernel_info()[7] - csum0) % (1 << 31)) / float(args.steps + args.warmup)
     steps_before = job.steps_done - args.steps
     complex_after = job.complex_frac()
     finite = bool(torch.isfinite(job.out[0]).all() and torch.isfinite(job.out[1]).all())
@@ -421,10 +423,10 @@ def main():
         try:
             acts = [job.pool[k].cpu().numpy() for k in range(4)]
             for k in range(2):
-                eng.step(acts[k])
+                eng.step(acts[k], copy=False)
             t0 = time.perf_counter()
             for k in range(10):
-                eng.step(acts[k % 4])
+                eng.step(acts[k % 4], copy=False)
             el = time.perf_counter() - t0
             ms = eng.timing()
             host = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3,
@@ -482,7 +484,8 @@ def main():
                        "rccl": rccl,
                        "outputs_finite": finite,
                        "start_state": "steady state: %d untimed steps since reset() before the timed region (pre-roll + warm-up)" % steps_before,
-                       "complex_env_frac_rank0": complex_after, "done_frac_last_step_rank0": done_frac,
+                       "complex_env_frac_rank0": complex_after, "complex_envs_per_step_timed_region_rank0": complex_per_step,
+                       "done_frac_last_step_rank0": done_frac,
                        "mean_episodes_completed_per_env_rank0": episodes},
             "fresh_reset": clean(fresh) if fresh else None,
             "weak_scaling_128k_per_gpu": weak,

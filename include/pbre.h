@@ -14,12 +14,13 @@
  *
  * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
  * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 for <= 32 DoF, W = 128 for <= 60
- * (the iCub with hands: 272 floats); nd = number of DoF:
+ * (the iCub with hands: 272 floats); the Panda's robot-level engine (robot_level = 1) uses W = 32 (80 floats); nd = number of DoF:
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
  *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14] left the apply_action loop (action_repeat > 1)
- * iCub with hands (W = 128, nd = 60): additionally Q[nd+7..nd+12) mean normal force on each fingertip of the controlled hand,
+ *   Panda task envs: X[12], X[13], X[15] per-env object mass / lateral friction / 1 + linear damping (pbre_set_physics_per_env; 0 = batch value)
+ * Robot-level engines (iCub with hands: W = 128, nd = 60; Panda: W = 32, nd = 9, fingertip slots 0 / 1 = left / right finger): additionally Q[nd+7..nd+12) mean normal force on each fingertip of the controlled hand,
  *   Q[nd+12] fingertips in contact with the object, Q[nd+13] robot-object contact points (check_contact_fingertips /
  *   check_collision, icub_env_with_hands.py:246-318); these 7 values are also the tail of the observation.
  *
@@ -43,7 +44,9 @@ extern "C" {
 #define PBRE_STATE_FLOATS 48       /* Panda; see pbre_state_floats() */
 
 enum { PBRE_OK = 0, PBRE_E_ARG = -1, PBRE_E_TABLE = -2, PBRE_E_DEVICE = -3, PBRE_E_UNSUPPORTED = -4 };
-enum { PBRE_ROBOT_PANDA = 0,
+enum { PBRE_ROBOT_PANDA_ARM = 3,   /* pbre_default_config only: the Panda with the robot-level interface -- fills the config with
+                                     robot = PBRE_ROBOT_PANDA, robot_level = 1 and the scene of examples/helloworlds/helloworld_panda.py */
+       PBRE_ROBOT_PANDA = 0,
        PBRE_ROBOT_ICUB = 1,       /* icub_model.sdf: observation / reward / reset variants of R/envs/icub_envs */
        PBRE_ROBOT_ICUB_HANDS = 2 };   /* icub_model_with_hands.sdf (R/envs/icub_envs/icub_env_with_hands.py): robot-level interface --
                                      absolute joint / hand-pose commands, persistent finger motors (pbre_set_motors), fingertip
@@ -113,7 +116,12 @@ typedef struct {
     double  eu_lim[3][2];       /* Euler limits of the commanded hand orientation (panda_env.py:38, icub_env.py:63-74) */
     double  ik_link_offset[3];  /* hand COM frame -> hand link frame (icub_env.py:252-258); 0 for the Panda */
     int32_t ik_absolute;        /* 1: IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-300) instead of
-                                   scaled increments accumulated by the task env; set for PBRE_ROBOT_ICUB_HANDS */
+                                   scaled increments accumulated by the task env; set for the robot-level interfaces */
+    int32_t robot_level;        /* 1: the robot-level interface of pandaEnv / iCubHandsEnv used without a task env (R/envs/panda_envs/
+                                   panda_env.py:195-365, R/envs/icub_envs/icub_env_with_hands.py): absolute commands, persistent
+                                   POSITION_CONTROL motors (pbre_set_motors, pbre_apply_action: target | gain | force | max velocity
+                                   per joint), fingertip contact statistics appended to the observation, no episode logic.  Always
+                                   1 for PBRE_ROBOT_ICUB_HANDS; PBRE_ROBOT_PANDA with 1 = what pbre_default_config(PBRE_ROBOT_PANDA_ARM) fills */
     const double* robot_table; size_t robot_table_len;   /* number of doubles */
 } pbre_config;
 
@@ -175,22 +183,26 @@ int pbre_observe(pbre_ctx* ctx, float* obs_out);
  * panda_push_gym_env.py:132-133,139-140); flags: PBRE_F_NO_OBJECT or 0 */
 int pbre_settle(pbre_ctx* ctx, int32_t n, int32_t flags);
 
-/* PBRE_ROBOT_ICUB_HANDS: command the persistent POSITION_CONTROL motors of `n` DoF -- replaces the
- * p.setJointMotorControlArray calls of iCubHandsEnv.open_hand / pre_grasp / grasp (R/envs/icub_envs/icub_env_with_hands.py:
- * 167-244).  dofs: DoF indices; targets: host [n], the same for every selected env; kp: positionGain; max_force: the
- * `forces` entry in newtons (grasp: 10), <= 0 keeps PyBullet's default; env_mask: NULL = all envs, else num_envs bytes. */
+/* Robot-level engines (robot_level = 1): command the persistent POSITION_CONTROL motors of `n` DoF -- replaces the
+ * p.setJointMotorControlArray / setJointMotorControl2 calls of iCubHandsEnv.open_hand / pre_grasp / grasp (R/envs/icub_envs/
+ * icub_env_with_hands.py:167-244) and pandaEnv.apply_action_fingers (R/envs/panda_envs/panda_env.py:201-225).  dofs: DoF
+ * indices; targets: host [n], the same for every selected env; kp: positionGain; max_force: the `force(s)` entry in newtons
+ * (grasp: 10), <= 0 keeps PyBullet's default; max_vel: `maxVelocity` (rad/s or m/s), <= 0 none; env_mask: NULL = all envs,
+ * else num_envs bytes. */
 int pbre_set_motors(pbre_ctx* ctx, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force,
-                    const uint8_t* env_mask);
+                    double max_vel, const uint8_t* env_mask);
 
-/* PBRE_ROBOT_ICUB_HANDS: the command half of iCubEnv.apply_action alone (R/envs/icub_envs/icub_env.py:260-361) -- IK + the
- * setJointMotorControl calls, no stepSimulation: the motors keep the command until the next one, the caller advances the
- * simulation with pbre_settle (the reference's `p.stepSimulation()` loops, examples/helloworlds/helloworld_icub.py:61-125).
- * actions: host [num_envs][act_dim], absolute joint targets (joint control) or hand poses x,y,z,roll,pitch,yaw (use_ik). */
-int pbre_apply_action(pbre_ctx* ctx, const float* actions);
+/* Robot-level engines: the command half of iCubEnv.apply_action / pandaEnv.apply_action alone (R/envs/icub_envs/icub_env.py:
+ * 260-361, R/envs/panda_envs/panda_env.py:227-310) -- IK + the setJointMotorControl calls, no stepSimulation: the motors keep
+ * the command until the next one, the caller advances the simulation with pbre_settle (the reference's `p.stepSimulation()`
+ * loops, examples/helloworlds/helloworld_icub.py:61-125, helloworld_panda.py:89-140).
+ * actions: host [num_envs][act_dim], absolute joint targets (joint control) or hand poses x,y,z[,roll,pitch,yaw] (use_ik).
+ * max_vel: the `max_vel` argument (maxVelocity of the commanded motors); <= 0 (the reference's -1): none. */
+int pbre_apply_action(pbre_ctx* ctx, const float* actions, double max_vel);
 
-/* PBRE_ROBOT_ICUB_HANDS: the motor records, host [num_envs][3][128] float32 = target | positionGain | force scale per DoF
- * lane (force scale = force / PyBullet's default force).  Together with pbre_get_state / pbre_set_state this is the complete
- * simulator state of the hands engine (checkpoint / restore, parity tests). */
+/* Robot-level engines: the motor records, host [num_envs][4][W] float32 = target | positionGain | force scale | max velocity per
+ * DoF lane (W = 128 iCub with hands, 32 Panda; force scale = force / PyBullet's default force; max velocity 0 = none).  Together
+ * with pbre_get_state / pbre_set_state this is the complete simulator state of such an engine (checkpoint / restore, parity tests). */
 int pbre_get_motor_state(pbre_ctx* ctx, float* motors);
 int pbre_set_motor_state(pbre_ctx* ctx, const float* motors);
 
@@ -199,6 +211,15 @@ int pbre_set_motor_state(pbre_ctx* ctx, const float* motors);
  * episodes; batch-uniform).  The object must stay a cube (isotropic inertia) for the lane-per-env kernels. */
 int pbre_set_physics(pbre_ctx* ctx, const pbre_physics* phys);
 int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
+
+/* Per-env domain randomisation of the object (replaces the per-env, per-episode p.changeDynamics(obj_id, mass=, lateralFriction=,
+ * linearDamping=) of change_physics_params, R/envs/panda_envs/panda_push_gym_env.py:362-364, as the reference's Dyn-Rand training
+ * calls it once per env).  Arrays are host [num_envs] float32 or NULL (unchanged); env_mask NULL = all envs.  The values live in the
+ * env's state record (X[12] mass, X[13] lateral friction, X[15] 1 + linear damping; 0 = the batch value of pbre_physics), survive
+ * resets and travel with pbre_get_state / pbre_set_state; the (cube) object's inertia scales with its mass.  The robot links' linear
+ * damping (`robot_damping`, :366-367) is the batch-uniform pbre_physics.lin_damping.  Panda task envs only. */
+int pbre_set_physics_per_env(pbre_ctx* ctx, const uint8_t* env_mask, const float* obj_mass, const float* obj_mu,
+                             const float* obj_lin_damping);
 
 /* observation limits used by the Gym Box space / scale_gym_data (create_gym_spaces, :83-103) */
 int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
@@ -209,7 +230,8 @@ int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);
 int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
 /* kernel facts for the bench/roofline report: [0] VGPRs of the fast kernel, [1] VGPRs of the general kernel,
  * [2] fast path enabled, [3..5] envs stepped in the most recent step by the fast kernel / the general row kernel / the
- * lane-per-env robot-contact kernel, [6] VGPRs of the robot-contact kernel */
+ * lane-per-env robot-contact kernel, [6] VGPRs of the robot-contact kernel, [7] running sum of the complex envs stepped so far
+ * (env-steps taken by the robot-contact / limit-row kernels; wraps at 2^31) */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

@@ -121,7 +121,7 @@ void orc_euler_from_quat(const real q[4], real e[3]) {
 /* ------------------------------------------------------------------ model */
 int orc_sizeof_real(void) { return (int)sizeof(real); }
 /* state record layout (pbre_oracle.h) */
-static int lay_w(const orc_model* m) { return m->ndof <= 9 ? 16 : (m->ndof <= 20 ? 32 : (m->ndof <= 32 ? 64 : 128)); }
+static int lay_w(const orc_model* m) { return m->ndof <= 9 ? (m->ntip > 0 ? 32 : 16) : (m->ndof <= 20 ? 32 : (m->ndof <= 32 ? 64 : 128)); }   /* a <= 9-DoF robot with fingertip statistics (pandaEnv alone) needs the 32-lane record */
 int orc_state_floats(const orc_model* m) { return 2 * lay_w(m) + 16; }
 #define OQ(m) ((m)->ndof)                 /* object position (then quaternion) inside Q */
 #define OV(m) (lay_w(m))                  /* V record */
@@ -498,10 +498,28 @@ void orc_sim_step(const orc_model* m, const orc_params* prm, real* st, const rea
                   const real* kd, orc_step_info* info) {
     orc_sim_step_f(m, prm, st, q_des, kp, kd, NULL, info);
 }
+static void sim_step_fv(const orc_model* m, const orc_params* prm, real* st, const real* q_des, const real* kp,
+                        const real* kd, const real* fscale, const real* vmaxv, orc_step_info* info);
 void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* st, const real* q_des, const real* kp,
                     const real* kd, const real* fscale, orc_step_info* info) {
+    sim_step_fv(m, prm, st, q_des, kp, kd, fscale, NULL, info);
+}
+/* vmaxv: NULL or per-DoF `maxVelocity` of the POSITION_CONTROL motors (0: none) */
+static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, const real* q_des, const real* kp,
+                        const real* kd, const real* fscale, const real* vmaxv, orc_step_info* info) {
     const int nd = m->ndof;
-    const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : ORC_NC_RO;
+    /* per-env object parameters of the Panda task envs (domain randomisation; change_physics_params, panda_push_gym_env.py:362-368):
+     * X[12] mass, X[13] lateral friction, X[15] 1 + linear damping of the object, 0 = the batch value; inertia scales with mass */
+    orc_params pp = *prm_in;
+    real okl = (real)pp.lin_damping;
+    if (lay_w(m) == 16) {
+        const real* X = st + OX(m);
+        if (X[12] > 0) { for (int k = 0; k < 3; k++) pp.obj_inertia[k] *= (double)X[12] / pp.obj_mass; pp.obj_mass = (double)X[12]; }
+        if (X[13] > 0) pp.obj_mu = (double)X[13];
+        if (X[15] > 0) okl = X[15] - 1;
+    }
+    const orc_params* prm = &pp;
+    const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : (m->ntip > 0 ? 4 : ORC_NC_RO);      /* robot-level Panda: both spheres of both fingers */
     const real dt = (real)prm->dt;
     real* q = st; real* qd = st + OV(m);
     real* op = st + OQ(m); real* oq = op + 3; real* ov = qd + nd; real* ow = ov + 3;
@@ -577,7 +595,7 @@ void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* st, const r
         m3_T(Ro, RoT); m3_mul(Ro, D, T); m3_mul(T, RoT, Iinv);
         real Dm[9] = {Il[0], 0, 0, 0, Il[1], 0, 0, 0, Il[2]}, Iw[9];
         m3_mul(Ro, Dm, T); m3_mul(T, RoT, Iw);
-        real kl = (real)prm->lin_damping, ka = (real)prm->ang_damping;
+        real kl = okl, ka = (real)prm->ang_damping;
         real acc[6], Lw[3], gy[3], tq[3];
         real sl = kl + kl * norm3(ov);
         acc[0] = -sl * ov[0]; acc[1] = -sl * ov[1]; acc[2] = (real)prm->gravity_z - sl * ov[2];
@@ -622,6 +640,13 @@ void orc_sim_step_f(const orc_model* m, const orc_params* prm, real* st, const r
         aba_solve(m, w, r->jA, 0, NULL, zero_ab, r->bA);
         r->dinv = 1 / r->bA[j];
         real verr = kp[j] * (q_des[j] - q[j]) / dt - kd[j] * vs[j];
+        if (vmaxv && vmaxv[j] > 0) {
+            /* setJointMotorControl2(maxVelocity): the target velocity kp dq/dt + (1 - kd) v of the row is clamped to +-maxVelocity
+             * (btMultiBodyJointMotor m_rhsClamp [EXT-UNVERIFIED]); the velocity error is target - v */
+            real vt = kp[j] * (q_des[j] - q[j]) / dt + (1 - kd[j]) * vs[j];
+            vt = vt > vmaxv[j] ? vmaxv[j] : (vt < -vmaxv[j] ? -vmaxv[j] : vt);
+            verr = vt - vs[j];
+        }
         r->rhs = verr * r->dinv;
         r->hi = (real)prm->max_motor_impulse * (fscale ? fscale[j] : (real)1); r->lo = -r->hi;
     }
@@ -991,7 +1016,13 @@ static void env_reset_impl(const orc_model* m, const orc_params* prm, const orc_
      * load world, 100 steps, 1 step */
     const int nd = m->ndof;
     real* X = st + OX(m); real* ob = st + OQ(m);
-    memset(st, 0, (size_t)orc_state_floats(m) * sizeof(real));
+    {   /* the per-env object parameters (X[12], X[13], X[15] of a Panda task env) are not part of the episode: a reset keeps them */
+        real keep[3] = {0, 0, 0};
+        const int pe = lay_w(m) == 16;
+        if (pe) { keep[0] = st[OX(m) + 12]; keep[1] = st[OX(m) + 13]; keep[2] = st[OX(m) + 15]; }
+        memset(st, 0, (size_t)orc_state_floats(m) * sizeof(real));
+        if (pe) { st[OX(m) + 12] = keep[0]; st[OX(m) + 13] = keep[1]; st[OX(m) + 15] = keep[2]; }
+    }
     for (int k = 0; k < nd; k++) st[k] = (real)t->home[k];
     /* WorldEnv._sample_pose (world_env.py:145-176) */
     real x_min = (real)t->ws_lim[0][0] + (real)0.05, x_max = (real)t->ws_lim[0][1] - (real)0.1;
@@ -1015,7 +1046,7 @@ static void env_reset_impl(const orc_model* m, const orc_params* prm, const orc_
     /* iCub with hands: the motors' commands persist in the env's motor record (iCubHandsEnv.reset, icub_env_with_hands.py:108-121) */
     real* qdes = mrec ? mrec : qdes_l; real* kp = mrec ? mrec + ORC_MAXD : kp_l; real* fs = mrec ? mrec + 2 * ORC_MAXD : NULL;
     hold_targets(t, nd, qdes, kp, kd);
-    if (fs) for (int k = 0; k < ORC_MAXD; k++) fs[k] = 1;
+    if (fs) for (int k = 0; k < ORC_MAXD; k++) { fs[k] = 1; mrec[3 * ORC_MAXD + k] = 0; }
     orc_params p1 = *prm; p1.flags |= ORC_F_NO_OBJECT;
     if (t->use_ik) {
         /* robot.reset with use_IK (panda_env.py:83-91, icub_env.py:147-148): apply_action(home_hand_pose) -> IK once from
@@ -1134,40 +1165,70 @@ void orc_task_hands(orc_task* t, int right_arm, int use_ik, const int* ctrl_dof,
     const double ol[3] = {-0.011682, 0.051355, 0.000577}, orr[3] = {-0.011682, 0.051682, -0.000577};   /* :159-165 */
     for (int k = 0; k < 3; k++) t->ik_link_offset[k] = right_arm ? orr[k] : ol[k];
 }
-void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force) {
-    /* p.setJointMotorControlArray(POSITION_CONTROL, targetPositions, positionGains[, forces]) of open_hand / pre_grasp / grasp (:167-244) */
+void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force, double max_vel) {
+    /* p.setJointMotorControlArray(POSITION_CONTROL, targetPositions, positionGains[, forces]) of open_hand / pre_grasp / grasp (:167-244);
+     * pandaEnv.apply_action_fingers: setJointMotorControl2(targetPosition, force=10, maxVelocity=1) (panda_env.py:218-225) */
     const real fs = max_force > 0 ? (real)(max_force * prm->dt / prm->max_motor_impulse) : (real)1;
-    for (int k = 0; k < n; k++) { mrec[dofs[k]] = targets[k]; mrec[ORC_MAXD + dofs[k]] = (real)kp; mrec[2 * ORC_MAXD + dofs[k]] = fs; }
+    for (int k = 0; k < n; k++) {
+        mrec[dofs[k]] = targets[k]; mrec[ORC_MAXD + dofs[k]] = (real)kp; mrec[2 * ORC_MAXD + dofs[k]] = fs;
+        mrec[3 * ORC_MAXD + dofs[k]] = max_vel > 0 ? (real)max_vel : 0;
+    }
 }
 void orc_hands_settle(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, const real* mrec, int n) {
     real kd[ORC_MAXD];
     for (int k = 0; k < ORC_MAXD; k++) kd[k] = (real)t->kd_hold;
-    for (int i = 0; i < n; i++) orc_sim_step_f(m, prm, st, mrec, mrec + ORC_MAXD, kd, mrec + 2 * ORC_MAXD, NULL);
+    for (int i = 0; i < n; i++) sim_step_fv(m, prm, st, mrec, mrec + ORC_MAXD, kd, mrec + 2 * ORC_MAXD, mrec + 3 * ORC_MAXD, NULL);
 }
-void orc_hands_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, real* mrec, const real* action,
-                    real* obs, real* reward, real* done) {
-    /* iCubEnv.apply_action (icub_env.py:260-361) with absolute commands, one stepSimulation, observation */
+/* the command half of apply_action(action, max_vel) alone (icub_env.py:260-361, panda_env.py:227-310): writes the motor record */
+void orc_hands_apply_action(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, real* mrec, const real* action, double max_vel) {
+    (void)prm;
     real* X = st + OX(m);
-    real* qdes = mrec; real* kp = mrec + ORC_MAXD; real* fs = mrec + 2 * ORC_MAXD;
-    real kd[ORC_MAXD];
-    for (int k = 0; k < ORC_MAXD; k++) kd[k] = (real)t->kd_hold;
+    real* qdes = mrec; real* kp = mrec + ORC_MAXD; real* fs = mrec + 2 * ORC_MAXD; real* vm = mrec + 3 * ORC_MAXD;
+    const real mv = max_vel > 0 ? (real)max_vel : 0;
     if (t->use_ik) {
         real hp[6];
-        for (int k = 0; k < 3; k++) hp[k] = clampr(action[k], t->robot_ws[k][0], t->robot_ws[k][1]);
+        for (int k = 0; k < 3; k++) hp[k] = (t->robot >= 1 || k == 2) ? clampr(action[k], t->robot_ws[k][0], t->robot_ws[k][1]) : action[k];   /* pandaEnv clips z only */
         for (int k = 3; k < 6; k++) hp[k] = t->control_orientation ? clampr(action[k], t->eu_lim[k-3][0], t->eu_lim[k-3][1]) : X[6 + k];
         for (int k = 0; k < 6; k++) X[6 + k] = hp[k];
-        /* every joint is commanded (setJointMotorControlArray over all joints, gains 0.2): chain joints from the IK, the other
-         * controlled joints at the value the IK returns for them (their current position), blocked joints at rest */
-        for (int k = 0; k < m->ndof; k++) { qdes[k] = (real)t->home[k]; kp[k] = (real)t->kp_hold; fs[k] = 1; }
-        ik_targets(m, t, st, hp, qdes);
+        if (t->robot >= 1) {
+            /* every joint is commanded (setJointMotorControlArray / per-joint calls over all joints, gain 0.2[, maxVelocity]) */
+            for (int k = 0; k < m->ndof; k++) { qdes[k] = (real)t->home[k]; kp[k] = (real)t->kp_hold; fs[k] = 1; vm[k] = mv; }
+            ik_targets(m, t, st, hp, qdes);
+        } else {
+            /* pandaEnv: all 9 joints with gain 0.2; with max_vel only the 7 arm joints, PyBullet's default gain 0.1 [EXT-UNVERIFIED] */
+            real sol[ORC_MAXD];
+            for (int k = 0; k < m->ndof; k++) sol[k] = st[k];
+            ik_targets(m, t, st, hp, sol);
+            const int nj = mv > 0 ? 7 : m->ndof;
+            for (int k = 0; k < nj; k++) { qdes[k] = sol[k]; kp[k] = mv > 0 ? (real)0.1 : (real)t->kp_hold; fs[k] = 1; vm[k] = mv; }
+        }
     } else
     for (int k = 0; k < t->n_act; k++) {
         const int d = t->act_dof[k], li = m->link_of_dof[d];
         real tgt = action[k];
-        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);     /* icub_env.py:347 */
-        qdes[d] = tgt; kp[d] = (real)t->kp_act; fs[d] = 1;
+        tgt = tgt < m->lower[li] ? m->lower[li] : (tgt > m->upper[li] ? m->upper[li] : tgt);     /* icub_env.py:347, panda_env.py:303 */
+        qdes[d] = tgt; kp[d] = (real)t->kp_act; fs[d] = 1; vm[d] = t->robot >= 1 ? mv : 0;       /* the iCub's joint branch passes maxVelocity */
     }
-    orc_sim_step_f(m, prm, st, qdes, kp, kd, fs, NULL);
+}
+/* pandaEnv used alone: the robot-level interface of the Panda (panda_env.py:25-91, 195-365), scene of helloworld_panda.py:72-85 */
+void orc_task_panda_arm(orc_task* t, int use_ik, int control_orientation) {
+    orc_default_task(t, 0);
+    t->robot = 0; t->max_steps = 1 << 30; t->target_dist_min = -1.0;
+    t->ws_lim[0][0] = 0.35; t->ws_lim[0][1] = 0.70;
+    t->robot_ws[2][0] = 0.65; t->robot_ws[2][1] = 1.5;
+    t->n_joints_ctrl = 9;
+    for (int k = 0; k < ORC_MAXACT; k++) t->act_dof[k] = k < 9 ? k : -1;
+    t->use_ik = use_ik; t->control_orientation = control_orientation; t->ik_absolute = 1;
+    t->n_act = use_ik ? (control_orientation ? 6 : 3) : 9;
+    t->ik_pos_scale = 1.0; t->ik_rot_scale = 1.0;
+}
+void orc_hands_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* st, real* mrec, const real* action,
+                    real* obs, real* reward, real* done) {
+    /* apply_action (absolute commands, no max_vel), one stepSimulation, observation */
+    real kd[ORC_MAXD];
+    for (int k = 0; k < ORC_MAXD; k++) kd[k] = (real)t->kd_hold;
+    orc_hands_apply_action(m, prm, t, st, mrec, action, -1.0);
+    sim_step_fv(m, prm, st, mrec, mrec + ORC_MAXD, kd, mrec + 2 * ORC_MAXD, mrec + 3 * ORC_MAXD, NULL);
     orc_reward_done(m, t, st, 1, reward, done);
     orc_observation(m, t, st, obs);
 }

@@ -149,7 +149,9 @@ void orc_hands_reset(const orc_model* m, const orc_params* prm, const orc_task* 
 void orc_hands_step(const orc_model* m, const orc_params* prm, const orc_task* t, real* state, real* mrec,
                     const real* action, real* obs, real* reward, real* done);
 void orc_hands_settle(const orc_model* m, const orc_params* prm, const orc_task* t, real* state, const real* mrec, int n);
-void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force);
+void orc_hands_set_motors(const orc_params* prm, real* mrec, int n, const int* dofs, const real* targets, double kp, double max_force, double max_vel);
+void orc_hands_apply_action(const orc_model* m, const orc_params* prm, const orc_task* t, real* state, real* mrec, const real* action, double max_vel);
+void orc_task_panda_arm(orc_task* t, int use_ik, int control_orientation);
 void orc_observation(const orc_model* m, const orc_task* t, const real* state, real* obs);
 void orc_reward_done(const orc_model* m, const orc_task* t, real* state, int pre_increment,
                      real* reward, real* done);

@@ -102,6 +102,7 @@ static __device__ __forceinline__ void report_hint(int total, int* __restrict__ 
     int r = *recent;
     r = total > 0 ? 16 : (r > 0 ? r - 1 : 0);
     *recent = r;
+    recent[1] += total;                 // running sum of complex env-steps (pbre_kernel_info[7]; wraps at 2^31)
     host_total[0] = total; host_total[1] = r;
 }
 
@@ -185,7 +186,9 @@ __global__ void k_total(const int* __restrict__ count, int* __restrict__ host_to
     int t = 0;
     for (int b = 0; b < NB; b++) t += count[b];
     *recent = 0;
+    const int acc = recent[1];
     report_hint(t, recent, host_total);
+    recent[1] = acc;                    // a (re)classification is not a step
 }
 
 __global__ __launch_bounds__(TPB) void k_observe(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
@@ -208,9 +211,14 @@ __global__ void k_target(const Params P, float* __restrict__ state, const unsign
     if (i < cnt) CoreD::sample_target(P, ids[i], ep[i], state + (size_t)i * STATE);
 }
 // episode number of the next reset of env idx[i]: one more than the episode stored in its record (-1 = never reset)
-__global__ void k_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, int cpad, unsigned* __restrict__ ep) {
+// (also hands the env's per-env object parameters X[12], X[13], X[15] -- which a reset keeps -- to the record it is re-initialised in)
+__global__ void k_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, int cpad, unsigned* __restrict__ ep,
+                               float* __restrict__ work) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cpad) ep[i] = (unsigned)((int)state[(size_t)idx[i < cnt ? i : cnt - 1] * STATE + 37] + 1);
+    if (i >= cpad) return;
+    const float* src = state + (size_t)idx[i < cnt ? i : cnt - 1] * STATE;
+    ep[i] = (unsigned)((int)src[37] + 1);
+    if (work != state) { float* dst = work + (size_t)i * STATE; dst[44] = src[44]; dst[45] = src[45]; dst[47] = src[47]; }
 }
 // dst[idx[i]] <- src[i], 48 floats per record
 __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt) {
@@ -292,15 +300,16 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     b.cap = cap;
     hipError_t e;
     if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMemset(b.state, 0, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;     // k_init keeps X[12], X[13], X[15]
     if ((e = hipMalloc(&b.cls, (size_t)2 * cap)) != hipSuccess) return e;
     if ((e = hipMalloc(&b.tgt, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.tgt, 0, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.cls, 0, (size_t)2 * cap)) != hipSuccess) return e;
     for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&b.count, (3 * NB + 1) * sizeof(int))) != hipSuccess) return e;      // + the device copy of the "recent" hint
+    if ((e = hipMalloc(&b.count, (3 * NB + 2) * sizeof(int))) != hipSuccess) return e;      // + the device copy of the "recent" hint
     if ((e = hipHostMalloc(&b.h_total, 2 * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
     b.h_total[0] = 1; b.h_total[1] = 16;   // unknown until the first step has run
-    return hipMemset(b.count, 0, (3 * NB + 1) * sizeof(int));
+    return hipMemset(b.count, 0, (3 * NB + 2) * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
     for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
@@ -443,7 +452,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
     *out = nullptr;
     pbre_ctx* c = new pbre_ctx();
-    if (table_ndof(*cfg) > NJ) {
+    if (table_ndof(*cfg) > NJ || cfg->robot_level) {      // iCub shapes, and the robot-level interface (motor records) of either robot
         const int rc = wide_create(cfg, &c->wide, g_err);
         if (rc != PBRE_OK) { delete c; return rc; }
         *out = c;
@@ -573,11 +582,11 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
         HIPCHK(hipMemcpyAsync(c->d_ids, ids.data(), (size_t)cpad * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(c->d_idx, idx.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, c->stream));
         // episode numbers live in the state records (the device advances them on auto-reset)
-        hipLaunchKernelGGL(k_next_episode, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->main.state, c->d_idx, cnt, cpad, c->d_ep);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(c->stream));          // host vectors go out of scope below
         const bool full = cnt == c->n;
         EnvBuf& work = full ? c->main : c->tmp;           // a partial reset settles a compacted copy
+        hipLaunchKernelGGL(k_next_episode, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->main.state, c->d_idx, cnt, cpad, c->d_ep, work.state);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(c->stream));          // host vectors go out of scope below
         const int f0 = c->cfg.flags & PBRE_F_NO_OBJECT;
         hipLaunchKernelGGL(k_init, dim3((cpad + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, work.state, c->d_ids, c->d_ep, cpad);
         HIPCHK(hipGetLastError());
@@ -616,7 +625,9 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     if (!c || !d_actions || !d_out) return PBRE_E_ARG;
     if (c->wide) return wide_step_device(c->wide, d_actions, d_out, stream);
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;      // PBRE_STREAM_LEGACY == hipStreamLegacy
+    // PBRE_STREAM_LEGACY: the null stream (HIP's legacy default stream; the runtime torch bundles dereferences the symbolic
+    // hipStreamLegacy handle, so it is passed as stream 0)
+    hipStream_t s = stream == PBRE_STREAM_LEGACY ? (hipStream_t) nullptr : (stream ? (hipStream_t)stream : c->stream);
     if (stream) c->ext_dirty = true;
     HIPCHK(full_step(c, d_actions, d_out, s));
     return PBRE_OK;
@@ -672,28 +683,28 @@ void* pbre_host_alloc(size_t bytes) {
 }
 void pbre_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
+int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) {
     if (!c || n < 0 || (n > 0 && (!dofs || !targets))) return PBRE_E_ARG;
-    if (c->wide) return wide_set_motors(c->wide, n, dofs, targets, kp, max_force, mask);
-    c->err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record";
+    if (c->wide) return wide_set_motors(c->wide, n, dofs, targets, kp, max_force, max_vel, mask);
+    c->err = "pbre_set_motors: only the robot-level engines (pbre_config.robot_level) keep a motor record";
     return PBRE_E_UNSUPPORTED;
 }
-int pbre_apply_action(pbre_ctx* c, const float* actions) {
+int pbre_apply_action(pbre_ctx* c, const float* actions, double max_vel) {
     if (!c || !actions) return PBRE_E_ARG;
-    if (c->wide) return wide_apply_action(c->wide, actions);
-    c->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record";
+    if (c->wide) return wide_apply_action(c->wide, actions, max_vel);
+    c->err = "pbre_apply_action: only the robot-level engines (pbre_config.robot_level) keep a motor record";
     return PBRE_E_UNSUPPORTED;
 }
 int pbre_get_motor_state(pbre_ctx* c, float* m) {
     if (!c || !m) return PBRE_E_ARG;
     if (c->wide) return wide_motor_state(c->wide, m, nullptr);
-    c->err = "pbre_get_motor_state: only the iCub-with-hands engine keeps a motor record";
+    c->err = "pbre_get_motor_state: only the robot-level engines keep a motor record";
     return PBRE_E_UNSUPPORTED;
 }
 int pbre_set_motor_state(pbre_ctx* c, const float* m) {
     if (!c || !m) return PBRE_E_ARG;
     if (c->wide) return wide_motor_state(c->wide, nullptr, m);
-    c->err = "pbre_set_motor_state: only the iCub-with-hands engine keeps a motor record";
+    c->err = "pbre_set_motor_state: only the robot-level engines keep a motor record";
     return PBRE_E_UNSUPPORTED;
 }
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
@@ -715,6 +726,30 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     HIPCHK(quiesce(c));
     HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));     // the contact margin may have changed
     HIPCHK(hipStreamSynchronize(c->stream));
+    return PBRE_OK;
+}
+
+int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping) {
+    if (!c) return PBRE_E_ARG;
+    if (c->wide) { c->err = "pbre_set_physics_per_env: implemented for the Panda task envs (change_physics_params, panda_push_gym_env.py:362-368)"; return PBRE_E_UNSUPPORTED; }
+    for (int e = 0; e < c->n; e++) {
+        if (mask && !mask[e]) continue;
+        if ((obj_mass && !(obj_mass[e] > 0.f)) || (obj_mu && !(obj_mu[e] > 0.f)) || (obj_lin_damping && !(obj_lin_damping[e] >= 0.f))) {
+            c->err = "pbre_set_physics_per_env: mass and friction must be > 0, damping >= 0"; return PBRE_E_ARG;
+        }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
+    // three strided columns of the state records: X[12] mass, X[13] lateral friction, X[15] 1 + linear damping (0 = batch value)
+    std::vector<float> col((size_t)c->n);
+    const float* src[3] = {obj_mass, obj_mu, obj_lin_damping};
+    const int slot[3] = {44, 45, 47};
+    for (int k = 0; k < 3; k++) {
+        if (!src[k]) continue;
+        HIPCHK(hipMemcpy2D(col.data(), 4, c->main.state + slot[k], (size_t)STATE * 4, 4, c->n, hipMemcpyDeviceToHost));
+        for (int e = 0; e < c->n; e++) if (!mask || mask[e]) col[e] = src[k][e] + (k == 2 ? 1.f : 0.f);
+        HIPCHK(hipMemcpy2D(c->main.state + slot[k], (size_t)STATE * 4, col.data(), 4, 4, c->n, hipMemcpyHostToDevice));
+    }
     return PBRE_OK;
 }
 
@@ -751,16 +786,17 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP>) == hipSuccess) rf = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
-    int complex_now = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
+    int complex_now = 0, complex_sum = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
     const bool lpe = lane_per_env(c);
     if (lpe) {
         int cnt[NB] = {0};
         (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
         (void)hipMemcpy(cnt, c->main.count + c->main.ccur * NB, NB * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&complex_sum, c->main.count + 3 * NB + 1, sizeof(int), hipMemcpyDeviceToHost);
         for (int k = 0; k < NB; k++) complex_now += cnt[k];
     }
-    const int v[7] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1};
-    for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
+    const int v[8] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum};
+    for (int i = 0; i < n; i++) info[i] = i < 8 ? v[i] : 0;
     return PBRE_OK;
 }
 

@@ -332,7 +332,7 @@ struct Core {
     template <bool OBJ = false>
     static PBRE_HD void row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
         app = L::uni(app);
-        F t = OBJ ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);
+        F t = (OBJ && LC >= 16) ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);      // (sum_obj: the object lanes lie in the upper 16-lane row)
         F s = L::med3(app - t, lo, hi);
         F d = s - app; app = s;
         dv = L::fma(d, Bv, dv);
@@ -340,7 +340,7 @@ struct Core {
     template <bool OBJ = false>
     static PBRE_HD void frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
         app = L::uni(app); lim = L::uni(lim);
-        F t = OBJ ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);
+        F t = (OBJ && LC >= 16) ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);      // (sum_obj: the object lanes lie in the upper 16-lane row)
         F s = L::med3(app - t, L::c(0.f) - lim, lim);
         s = L::sel(L::gt(lim, L::c(0.f)), s, app);
         F d = s - app; app = s;
@@ -369,12 +369,14 @@ struct Core {
         F lower = L::load(T.lower), upper = L::load(T.upper);
         F qdes = L::load(T.home), kp = L::load(T.kp_hold), kd = L::load(T.kd_hold);
         FR fscale = LR::c(1.f);
+        F vmx = zero;                // MREC: maxVelocity of the motor (0: unlimited)
         if (SH::MREC) {
             // PyBullet's motors persist between calls: target | kp | force scale of every joint live in the env's motor record
             // (written by apply_action below, by the IK kernel and by the finger commands open_hand / pre_grasp / grasp)
             float* mrec = const_cast<float*>(tgt);
             qdes = L::load(mrec); kp = L::load(mrec + W);
             F fs = L::load(mrec + 2 * W);
+            vmx = L::load(mrec + 3 * W);
             if (mode & M_ACTION) {
                 // iCubEnv.apply_action, joint branch (icub_env.py:341-361): absolute targets clipped to the joint limits,
                 // positionGain 0.5, default force
@@ -382,8 +384,8 @@ struct Core {
                 B al = L::gei(ai, 0);
                 F a = L::loadx(act, ai, al);
                 qdes = L::sel(al, clampf(a, lower, upper), qdes);
-                kp = L::sel(al, L::load(T.kp_act), kp); fs = L::sel(al, one, fs);
-                L::store(mrec, qdes); L::store(mrec + W, kp); L::store(mrec + 2 * W, fs);
+                kp = L::sel(al, L::load(T.kp_act), kp); fs = L::sel(al, one, fs); vmx = L::sel(al, zero, vmx);
+                L::store(mrec, qdes); L::store(mrec + W, kp); L::store(mrec + 2 * W, fs); L::store(mrec + 3 * W, vmx);
             }
             fscale = L::lo(fs);
         } else {
@@ -528,8 +530,17 @@ struct Core {
         }
         const F vmax = L::c(P.vmax);
         F vstar = clampf(L::fma(dt, qdd, qd), zero - vmax, vmax);
+        // per-env object parameters of the Panda task envs (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral
+        // friction, X[15] 1 + linear damping, 0 = the batch value; the inertia scales with the mass.  (W = 16 only: on the iCub X[12],
+        // X[13] are the distances of the push reward.)
+        F o_m = L::c(P.obj_m), o_mu = L::c(P.obj_mu), o_kl = L::c(P.kl);
+        if (W == 16) {
+            const F x12 = L::bcast(Xr, 12), x13 = L::bcast(Xr, 13), x15 = L::bcast(Xr, 15);
+            o_m = L::sel(L::gt(x12, zero), x12, o_m); o_mu = L::sel(L::gt(x13, zero), x13, o_mu); o_kl = L::sel(L::gt(x15, zero), x15 - one, o_kl);
+        }
         // object: gravity, damping, gyroscopic torque
-        M3 Iinv; V3 oI = v3(L::c(P.obj_I[0]), L::c(P.obj_I[1]), L::c(P.obj_I[2]));
+        const F isc = o_m / L::c(P.obj_m);
+        M3 Iinv; V3 oI = v3(L::c(P.obj_I[0]) * isc, L::c(P.obj_I[1]) * isc, L::c(P.obj_I[2]) * isc);
         {
             M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
             PBRE_UNROLL for (int i = 0; i < 3; i++)
@@ -540,7 +551,7 @@ struct Core {
         if (obj_on) {
             V3 wl = mtv(Ro, ow);
             V3 Lw = mv(Ro, v3(wl.x * oI.x, wl.y * oI.y, wl.z * oI.z));   // I_w w
-            F sl = L::fma(L::c(P.kl), norm(ov), L::c(P.kl));
+            F sl = L::fma(o_kl, norm(ov), o_kl);
             V3 al = v3(zero - sl * ov.x, zero - sl * ov.y, L::c(P.gz) - sl * ov.z);
             F sa = L::fma(L::c(P.ka), norm(ow), L::c(P.ka));
             V3 tq = sub(scl(cross(ow, Lw), zero - one), scl(Lw, sa));
@@ -594,8 +605,8 @@ struct Core {
             vB = v3(vx.x, vx.y, hs);
         }
         auto contact_of = [&](int c) -> Contact {
-            if (c < NC_OT) return fetch(rk_ot, c, up, vx, vB, vd, L::c(P.obj_mu * P.tab_mu), L::ci(0), lane);
-            if (c < NC_OT + NC_RO) return fetch(rk_ro, c - NC_OT, n_ro, pA_ro, pB_ro, d_ro, smu * L::c(P.obj_mu), so, lane);
+            if (c < NC_OT) return fetch(rk_ot, c, up, vx, vB, vd, o_mu * L::c(P.tab_mu), L::ci(0), lane);
+            if (c < NC_OT + NC_RO) return fetch(rk_ro, c - NC_OT, n_ro, pA_ro, pB_ro, d_ro, smu * o_mu, so, lane);
             return fetch(rk_rt, c - NC_OT - NC_RO, n_rt, pA_rt, pB_rt, d_rt, smu * L::c(P.tab_mu), so, lane);
         };
         I owner_ro[NC_RO];           // link lane of each robot-object contact (fingertip bookkeeping)
@@ -620,7 +631,14 @@ struct Core {
             F dinv = L::wide(oneR / diag);
             B live = L::band(robot, L::nei(L::loadI(T.jtype), 0));
             R.m_dinv = L::lo(L::sel(live, dinv, zero));
-            R.m_rhs = L::lo(L::sel(live, (kp * (qdes - q) * inv_dt - kd * vstar) * dinv, zero));
+            F verr = kp * (qdes - q) * inv_dt - kd * vstar;
+            if (SH::MREC) {
+                // setJointMotorControl2(maxVelocity=v): Bullet clamps the motor row's target velocity kp dq/dt + (1 - kd) v to +-v
+                // (btMultiBodyJointMotor m_rhsClamp, set from maxVelocity [EXT-UNVERIFIED]); the velocity error is target - v*
+                const F vt = L::fma(kp * (qdes - q), inv_dt, (one - kd) * vstar);
+                verr = L::sel(L::gt(vmx, zero), clampf(vt, zero - vmx, vmx) - vstar, verr);
+            }
+            R.m_rhs = L::lo(L::sel(live, verr * dinv, zero));
             // joint limits (btMultiBodyJointLimitConstraint): row exists only while violated
             F pl = q - lower, pu = upper - q;
             B lo_v = L::band(live, L::le(pl, zero)), up_v = L::band(live, L::band(L::bnot(lo_v), L::le(pu, zero)));
@@ -634,7 +652,7 @@ struct Core {
         }
         const BR any_limit = LR::ne(R.l_dir, zeroR);
         // contacts
-        const F inv_m = L::c(1.f / P.obj_m);
+        const F inv_m = one / o_m;
         PBRE_UNROLL for (int c = 0; c < NC; c++) {
             const int type = c < NC_OT ? 0 : (c < NC_OT + NC_RO ? 1 : 2);
             R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
@@ -1109,7 +1127,7 @@ struct Core {
             }
         }
         V3 cp = pos;                      // the pose handed to the IK; at reset the stored pose stays the unclipped home pose
-        if (!reset || P.robot != 0) {     // pandaEnv.apply_action clips z only (panda_env.py:243-247); the task env / iCub clip x, y, z
+        if (P.robot != 0 || (!reset && !P.ik_abs)) {     // pandaEnv.apply_action clips z only (panda_env.py:243-247); the task env / iCub clip x, y, z
             cp.x = clampf(cp.x, L::c(P.rws[0][0]), L::c(P.rws[0][1]));
             cp.y = clampf(cp.y, L::c(P.rws[1][0]), L::c(P.rws[1][1]));
         }
@@ -1173,8 +1191,17 @@ struct Core {
         // joints off the chain: the iCub sends them to their rest pose (icub_env.py:316-317), PyBullet returns the Panda's
         // current finger positions
         F qdes = L::sel(chain, q, L::sel(L::nei(L::loadI(T.blocked), 0), L::load(T.home), q0));
-        L::storem(tgt, qdes, robot);
-        if (SH::MREC) { L::store(tgt + W, L::load(T.kp_hold)); L::store(tgt + 2 * W, one); }   // setJointMotorControlArray(all joints, positionGains 0.2), icub_env.py:319-336
+        if (SH::MREC) {
+            // setJointMotorControlArray(all joints, positionGains 0.2) (icub_env.py:319-336, panda_env.py:275-282); with max_vel the
+            // iCub commands every joint with positionGain 0.2 and maxVelocity (:338-346), the Panda its 7 arm joints with PyBullet's
+            // default gain and maxVelocity (panda_env.py:284-290): P.cmd_nj / cmd_kp / cmd_vmax
+            const B cmd = P.cmd_nj > 0 ? L::band(robot, L::lti(lane, P.cmd_nj)) : L::lti(lane, W);
+            L::storem(tgt, qdes, L::band(cmd, robot));
+            L::storem(tgt + W, P.cmd_kp > 0.f ? L::c(P.cmd_kp) : L::load(T.kp_hold), cmd);
+            L::storem(tgt + 2 * W, one, cmd);
+            L::storem(tgt + 3 * W, L::c(P.cmd_vmax), cmd);
+        } else
+            L::storem(tgt, qdes, robot);
     }
 
     // ---------------------------------------------------------------- reset (initial state before the settle steps)
@@ -1193,7 +1220,10 @@ struct Core {
     static PBRE_HD void init_state(const Tables& T, const Params& P, unsigned long long env_id, unsigned episode, float* st) {
         float* ob = st + LC;                       // object position (3) + quaternion (4) inside the Q record
         float* X = st + 2 * W;
+        // (the per-env object parameters X[12], X[13], X[15] of a Panda task env are not part of the episode: a reset keeps them)
+        const float k12 = st[2 * W + 12], k13 = st[2 * W + 13], k15 = st[2 * W + 15];
         for (int k = 0; k < STATE; k++) st[k] = 0.f;
+        if (W == 16) { st[2 * W + 12] = k12; st[2 * W + 13] = k13; st[2 * W + 15] = k15; }
         for (int k = 0; k < T.ndof; k++) st[k] = T.home[k];
         const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
         const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;

@@ -274,6 +274,9 @@ struct Fast {
         V3 op = v3(st[9], st[10], st[11]);
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
         M3 Ro = quat_R(oq);
+        // per-env object parameters (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral friction,
+        // X[15] 1 + linear damping; 0 = the batch value.  The inertia of the (cube) object scales with its mass.
+        const float o_m = st[44] > 0.f ? st[44] : P.obj_m, o_mu = st[45] > 0.f ? st[45] : P.obj_mu, o_kl = st[47] > 0.f ? st[47] - 1.f : P.kl;
 
         // ---- one forward sweep over the links: FK, joint axes, velocities, velocity-product accelerations,
         //      collision-sphere distances, per-link bias force and spatial inertia (world frame, about the world origin)
@@ -322,7 +325,7 @@ struct Fast {
                         Cand c; c.idx = s; c.owner = j;
                         if (obj_on) {
                             c.dist = sphere_box(sc, T.s_r[s], op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
-                            c.mu = T.s_mu[s] * P.obj_mu;
+                            c.mu = T.s_mu[s] * o_mu;
                             keep2(c, P.margin, k1[0], k2[0]);
                         }
                         c.dist = sphere_box(sc, T.s_r[s], tc, Id, th, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
@@ -457,11 +460,12 @@ struct Fast {
         // r' = sk r and angular velocity u = omega / sk with sk = sqrt(m / I), object-table impulses in delta-v units (a = lambda / m).
         // Then J M^-1 J^T = (1 + |r' x dir|^2) / m and a row update is ov += da dir, u += da (r' x dir): no per-row
         // multiplications by 1/m and 1/I in the solver loop.
-        const float inv_m = 1.f / P.obj_m, inv_I = 1.f / P.obj_I[0];
+        const float inv_m = 1.f / o_m, inv_I = P.obj_m / (P.obj_I[0] * o_m);
         const float sk = sqrtf(inv_I / inv_m), inv_sk = 1.f / sk;
-        const float mu = P.obj_mu * P.tab_mu;
+        const float mu = o_mu * P.tab_mu;
         if (obj_on) {
-            V3 oI = v3(P.obj_I[0], P.obj_I[1], P.obj_I[2]);
+            const float isc = o_m / P.obj_m;
+            V3 oI = v3(P.obj_I[0] * isc, P.obj_I[1] * isc, P.obj_I[2] * isc);
             M3 Iinv;
             {
                 M3 D; PBRE_UNROLL for (int i = 0; i < 3; i++) { D.m[i*3] = Ro.m[i*3] / oI.x; D.m[i*3+1] = Ro.m[i*3+1] / oI.y; D.m[i*3+2] = Ro.m[i*3+2] / oI.z; }
@@ -471,7 +475,7 @@ struct Fast {
             }
             V3 wl = mtv(Ro, ow);
             V3 Lw = mv(Ro, v3(wl.x * oI.x, wl.y * oI.y, wl.z * oI.z));
-            float sl_ = fmaf(P.kl, norm(ov), P.kl);
+            float sl_ = fmaf(o_kl, norm(ov), o_kl);
             V3 al = v3(-sl_ * ov.x, -sl_ * ov.y, P.gz - sl_ * ov.z);
             float sa_ = fmaf(P.ka, norm(ow), P.ka);
             V3 tq = sub(scl(cross(ow, Lw), -1.f), scl(Lw, sa_));
@@ -641,9 +645,29 @@ struct Fast {
         bool all_slots = !RC;
         PBRE_UNROLL for (int c = 0; c < NK; c++) all_slots = all_slots && any_c[c];
         if (all_slots) {
-            auto contacts_all = [&]() {
-                PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
-                PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+            // One sweep = the ND motor rows (reversed on even sweeps) and the 12 object rows (4 normals, then the friction pairs).  In
+            // this class the two blocks share no unknown, so any interleaving of the two sequences gives each block bit for bit the
+            // iterates of Bullet's order (motors, normals, frictions).  The rows are ISSUED interleaved -- motor, object, motor, ... --
+            // because each block is one dependent chain (a row waits for the previous row's update) and the scheduler keeps source
+            // order: back to back they cost a lone wave the sum of both chains' latencies, interleaved the longer of the two
+            // (PBRE_INTERLEAVE=0 restores the sequential order for A/B runs).
+#ifndef PBRE_INTERLEAVE
+#define PBRE_INTERLEAVE 1
+#endif
+            constexpr bool IL = PBRE_INTERLEAVE != 0 && ND == 9 && NK == 4;
+            auto obj_k = [&](int k) {           // k-th object row of a sweep in Bullet's order
+                if (k < NK) orow(k, 0); else orow((k - NK) / 2, 1 + ((k - NK) & 1));
+            };
+            auto sweep_rows = [&](auto&& mrow, bool rev) {
+                if (IL) {
+                    // 9 motor rows and 12 object rows: m o m o m o m o m o m o m o m o m o o o o
+                    PBRE_UNROLL for (int k = 0; k < ND; k++) { mrow(rev ? ND - 1 - k : k); obj_k(k); }
+                    PBRE_UNROLL for (int k = ND; k < 3 * NK; k++) obj_k(k);
+                } else {
+                    if (rev) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) mrow(j); } else { PBRE_UNROLL for (int j = 0; j < ND; j++) mrow(j); }
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+                }
             };
             // Clamp-free motor rows first (the kernel is VALU-issue bound: fma + |.|-accumulate instead of fma, 2 sub, med3, add per row).
             // No motor comes near PyBullet's default force bound (1e5 N dt = 417 against impulses of a few units), and
@@ -661,11 +685,9 @@ struct Fast {
                     waxpy(w, d, Mc[RC ? 0 : j]);
                 };
                 for (int it = 0; it < P.iters; it += 2) {
-                    PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor_free(j);
-                    contacts_all();
+                    sweep_rows(motor_free, true);
                     if (it + 1 >= P.iters) break;
-                    PBRE_UNROLL for (int j = 0; j < ND; j++) motor_free(j);
-                    contacts_all();
+                    sweep_rows(motor_free, false);
                 }
                 bool over = false;
                 PBRE_UNROLL for (int j = 0; j < ND; j++) over = over || !(m_app[j] <= mlim);      // (a NaN fails the test as well)
@@ -679,11 +701,9 @@ struct Fast {
             }
             if (!solved)
             for (int it = 0; it < P.iters; it += 2) {
-                PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
-                contacts_all();
+                sweep_rows(motor, true);
                 if (it + 1 >= P.iters) break;
-                PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
-                contacts_all();
+                sweep_rows(motor, false);
             }
         } else
         for (int it = 0; it < P.iters; it += 2) {

@@ -29,6 +29,8 @@ inline void default_physics(pbre_physics& p) {
 }
 
 inline int default_config(pbre_config* c, int robot, int task) {
+    const bool panda_arm = robot == PBRE_ROBOT_PANDA_ARM;
+    if (panda_arm) robot = PBRE_ROBOT_PANDA;
     if (!c || (robot != PBRE_ROBOT_PANDA && robot != PBRE_ROBOT_ICUB && robot != PBRE_ROBOT_ICUB_HANDS) || (task != PBRE_TASK_REACH && task != PBRE_TASK_PUSH && task != PBRE_TASK_PUSH_GOAL)) return PBRE_E_ARG;
     std::memset(c, 0, sizeof *c);
     c->robot = robot; c->task = task; c->num_envs = 1; c->device_id = 0; c->seed = 1234;
@@ -54,7 +56,27 @@ inline int default_config(pbre_config* c, int robot, int task) {
     for (int k = 0; k < 64; k++) c->act_dof[k] = k < 7 ? k : -1;
     c->ik_pos_scale = 0.005; c->ik_rot_scale = 0.01;                                // panda_push_gym_env.py:200-203
     for (int k = 0; k < 3; k++) { c->eu_lim[k][0] = -PI; c->eu_lim[k][1] = PI; }     // panda_env.py:38
+    if (panda_arm) {
+        // pandaEnv used alone (panda_env.py:25-91, 195-365) in the scene of examples/helloworlds/helloworld_panda.py:72-85: table.urdf at
+        // (1, 0, 0), a lego brick dropped at (0.5, 0, 0.8) -- stand-in [pybullet_data/lego is not available]: a 3.2 x 2.4 x 5 cm box of
+        // 0.1 kg, tall enough for the demo's grasp height (hand at z = 0.67, 4.5 cm above the table top) to close the fingers on it
+        c->task = PBRE_TASK_REACH; c->robot_level = 1; c->ik_absolute = 1;
+        c->max_steps = 1 << 30; c->target_dist_min = -1.0;                          // no episode logic at the robot level
+        c->num_controlled_joints = 9; c->num_joints_ctrl = 9;                       // joint_action_space = 9 (panda_env.py:26)
+        for (int k = 0; k < 64; k++) c->act_dof[k] = k < 9 ? k : -1;
+        c->ws_lim[0][0] = 0.35; c->ws_lim[0][1] = 0.70;                             // object dropped at x = 0.5, y = 0
+        c->robot_ws[2][0] = 0.65; c->robot_ws[2][1] = 1.5;                          // panda_env.py:37
+        c->ik_pos_scale = 1.0; c->ik_rot_scale = 1.0;
+        c->phys.table_c[0] = 1.0;
+        c->phys.obj_h[0] = 0.016; c->phys.obj_h[1] = 0.012; c->phys.obj_h[2] = 0.025;
+        c->phys.obj_mass = 0.1;
+        for (int k = 0; k < 3; k++) {
+            const double a = 2 * c->phys.obj_h[(k + 1) % 3], b = 2 * c->phys.obj_h[(k + 2) % 3];
+            c->phys.obj_inertia[k] = c->phys.obj_mass * (a * a + b * b) / 12.0;
+        }
+    }
     if (robot == PBRE_ROBOT_ICUB_HANDS) {
+        c->robot_level = 1;
         // iCubHandsEnv defaults, left arm (icub_env_with_hands.py:51-83): robot-level interface, joint control.  DoF order of the
         // simulated model (legs pruned): torso 0..2, left arm 3..9, left hand 10..29, neck 30..32, right arm 33..39, right hand 40..59
         c->task = PBRE_TASK_REACH; c->use_ik = 0; c->control_orientation = 1; c->ik_absolute = 1;
@@ -136,8 +158,8 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     if (n_ctrl < c.num_controlled_joints || n_ctrl > 64) return "num_joints_ctrl out of range";
     if (c.use_ik && (c.ik_max_iters <= 0 || c.ik_damping <= 0)) return "bad IK parameters";
     if (c.robot != PBRE_ROBOT_PANDA && c.robot != PBRE_ROBOT_ICUB && c.robot != PBRE_ROBOT_ICUB_HANDS) return "unknown robot";
-    if ((c.robot == PBRE_ROBOT_ICUB_HANDS) != S::MREC) return "the iCub-with-hands interface needs the 60-DoF model (and only that model uses it)";
-    if (S::MREC && (c.action_repeat != 1 || (c.flags & PBRE_F_AUTO_RESET))) return "iCub with hands: action_repeat / auto-reset are not part of the robot-level interface";
+    if ((c.robot == PBRE_ROBOT_ICUB_HANDS || c.robot_level != 0) != S::MREC) return "the robot-level interface (iCub with hands, pbre_config.robot_level) needs a motor-record kernel shape (and only those shapes use it)";
+    if (S::MREC && (c.action_repeat != 1 || (c.flags & PBRE_F_AUTO_RESET))) return "robot-level interface: action_repeat / auto-reset are not part of it";
     const double gains[4] = {c.kp_act, c.kd_act, c.kp_hold, c.kd_hold};
     std::string e = build_tables<S>(c.robot_table, c.robot_table_len, c.home, gains, c.num_controlled_joints, act_dof, n_ctrl,
                                     c.robot == PBRE_ROBOT_PANDA, T);

@@ -34,8 +34,8 @@ struct ShapeT {
     static constexpr int NMW = (NJ_ + 31) / 32;            // 32-bit words of an ancestor / subtree mask
     static constexpr int NC_OT = 4, NC_RO = NC_RO_, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;   // contact slots: object-table, robot-object, robot-table
     static constexpr int NTIP = NTIP_;    // fingertips whose contact force is reported (iCub hands); such a shape also keeps a
-    static constexpr bool MREC = NTIP_ > 0;   // per-env motor record target[W] | kp[W] | force scale[W] (PyBullet's persistent motors)
-    static constexpr int TGT = MREC ? 3 * W_ : NJ_;        // floats per env of the motor-target buffer
+    static constexpr bool MREC = NTIP_ > 0;   // per-env motor record target[W] | kp[W] | force scale[W] | max velocity[W] (PyBullet's persistent motors)
+    static constexpr int TGT = MREC ? 4 * W_ : NJ_;        // floats per env of the motor-target buffer
     static constexpr int TIP0 = NJ_ + 7;                   // Q lanes TIP0..TIP0+NTIP+1: tip forces, tips in contact, other robot-object contacts
     static_assert(NJ_ + 7 + (NTIP_ ? NTIP_ + 2 : 0) <= W_ && NJ_ <= 64, "lane budget");
 };
@@ -43,6 +43,9 @@ using Shape16 = ShapeT<16, 9, 3, 4>;      // Panda (<= 9 DoF): one env per 16-la
 using Shape32 = ShapeT<32, 20, 2, 4>;     // iCub as simulated (legs pruned, 20 DoF): one env per half-wave, 2 envs per wave
 using Shape64 = ShapeT<64, 32, 2, 4>;     // <= 32 DoF: one env per wave
 using Shape128 = ShapeT<128, 60, 2, 4, 6, 5>;   // iCub with hands (legs pruned, 60 DoF): one env per wave, two virtual lanes per physical lane
+using ShapePA = ShapeT<32, 9, 3, 4, 4, 5>;      // Panda, robot-level interface (pandaEnv alone: persistent motors, fingertip statistics -- 2 of the
+                                                // 5 fingertip slots are used; 4 robot-object contact slots: both spheres of both fingers): one env
+                                                // per half-wave, object at Q[9..15], statistics at Q[16..22]
 
 // the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
 constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;
@@ -96,6 +99,8 @@ struct Params {                  // float copies of pbre_physics + task constant
     int   robot, reward_type, ctrl_ori;             // PBRE_ROBOT_*; iCub push reward variant; IK mode: orientation part of the action
     float ik_ps, ik_rs, eu_lim[3][2], ik_off[3];    // action scales, Euler limits, hand COM frame -> link frame offset
     int   ik_abs;                                   // IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-330) instead of scaled increments
+    float cmd_vmax, cmd_kp;                         // robot-level apply_action(max_vel): maxVelocity of the commanded motors (0: none) and their
+    int   cmd_nj;                                   // positionGain (0: the hold gain); cmd_nj > 0: only the first cmd_nj DoF are commanded (pandaEnv, panda_env.py:284-290)
 };
 
 namespace detail {

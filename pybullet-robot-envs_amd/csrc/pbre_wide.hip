@@ -101,8 +101,9 @@ void wide_destroy(WideEngine* w) {
 int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     const int nd = table_ndof(*cfg);
     WideEngine* w = nd > Shape64::NJ ? make_hands_engine()
+                  : (cfg->robot_level && nd <= ShapePA::NJ ? static_cast<WideEngine*>(new WideImpl<ShapePA, DevLanes32>())     // pandaEnv alone
                   : (nd <= Shape32::NJ ? static_cast<WideEngine*>(new WideImpl<Shape32, DevLanes32>())
-                                       : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>()));
+                                       : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>())));
     w->cfg = *cfg;
     std::string e = w->tables(*cfg);
     if (!e.empty()) {
@@ -241,7 +242,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
 int wide_step_device(WideEngine* w, const float* d_actions, float* d_out, void* stream) {
     WCHK(hipSetDevice(w->device));
     if (stream) w->ext_dirty = true;
-    WCHK(wfull_step(w, d_actions, d_out, stream ? (hipStream_t)stream : w->stream));
+    WCHK(wfull_step(w, d_actions, d_out, stream == PBRE_STREAM_LEGACY ? (hipStream_t) nullptr : (stream ? (hipStream_t)stream : w->stream)));
     return PBRE_OK;
 }
 int wide_step(WideEngine* w, const float* actions, float* out) {
@@ -277,12 +278,13 @@ int wide_set_state(WideEngine* w, const float* s) {
     WCHK(hipMemcpy(w->state, s, (size_t)w->n * w->sf * 4, hipMemcpyHostToDevice));
     return PBRE_OK;
 }
-int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
-    if (!w->mrec) { w->err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) {
+    if (!w->mrec) { w->err = "pbre_set_motors: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
     if (cnt > 64) { w->err = "pbre_set_motors: more than 64 joints"; return PBRE_E_ARG; }
     MotorCmd cmd;
     cmd.n = cnt; cmd.kp = (float)kp;
     cmd.fscale = max_force > 0 ? (float)(max_force * w->cfg.phys.dt / w->cfg.phys.max_motor_impulse) : 1.f;
+    cmd.vmax = max_vel > 0 ? (float)max_vel : 0.f;
     for (int k = 0; k < cnt; k++) {
         if (dofs[k] < 0 || dofs[k] >= w->ndof()) { w->err = "pbre_set_motors: bad DoF index"; return PBRE_E_ARG; }
         cmd.dof[k] = dofs[k]; cmd.target[k] = targets[k];
@@ -299,14 +301,23 @@ int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float
     WCHK(hipStreamSynchronize(w->stream));
     return PBRE_OK;
 }
-int wide_apply_action(WideEngine* w, const float* actions) {
-    if (!w->mrec) { w->err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+int wide_apply_action(WideEngine* w, const float* actions, double max_vel) {
+    if (!w->mrec) { w->err = "pbre_apply_action: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
     hipStream_t s = w->stream;
     WCHK(hipMemcpyAsync(w->d_act, actions, (size_t)w->n * w->act_dim * 4, hipMemcpyHostToDevice, s));
-    if (w->P.use_ik) w->launch_ik(false, w->state, w->d_act, w->tgt, w->n, s);
-    else w->launch_cmd_joints(w->d_act, s);
+    const bool panda = w->P.robot == PBRE_ROBOT_PANDA;
+    const float vm = max_vel > 0 ? (float)max_vel : 0.f;
+    if (w->P.use_ik) {
+        // with max_vel the iCub commands every joint (positionGain 0.2, icub_env.py:338-346), the Panda its 7 arm joints with
+        // PyBullet's default positionGain 0.1 [EXT-UNVERIFIED] (panda_env.py:284-290)
+        const Params P0 = w->P;
+        w->P.cmd_vmax = vm;
+        if (panda && vm > 0.f) { w->P.cmd_kp = 0.1f; w->P.cmd_nj = 7; }
+        w->launch_ik(false, w->state, w->d_act, w->tgt, w->n, s);
+        w->P = P0;
+    } else w->launch_cmd_joints(w->d_act, panda ? 0.f : vm, s);      // the joint branch passes maxVelocity on the iCub only (icub_env.py:353-360)
     WCHK(hipGetLastError());
     WCHK(hipStreamSynchronize(s));
     return PBRE_OK;

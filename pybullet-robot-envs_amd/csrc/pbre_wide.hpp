@@ -22,8 +22,8 @@ int  wide_set_state(WideEngine* w, const float* s);
 int  wide_get_state_cols(WideEngine* w, int32_t first, int32_t count, float* out);
 int  wide_observe(WideEngine* w, float* obs);
 int  wide_settle(WideEngine* w, int32_t n, int32_t flags);
-int  wide_set_motors(WideEngine* w, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask);
-int  wide_apply_action(WideEngine* w, const float* actions);
+int  wide_set_motors(WideEngine* w, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask);
+int  wide_apply_action(WideEngine* w, const float* actions, double max_vel);
 int  wide_motor_state(WideEngine* w, float* out, const float* in);
 int  wide_set_physics(WideEngine* w, const pbre_physics* p);
 int  wide_get_physics(const WideEngine* w, pbre_physics* p);

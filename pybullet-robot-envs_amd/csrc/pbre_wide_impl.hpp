@@ -20,7 +20,7 @@ constexpr int WTPB = 256;                        // 4 independent waves per bloc
 static_assert(WTPB == 64 * DevLanes128::WPB, "DevLanes128 sizes its per-wave LDS regions for this block size");
 template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }
 static_assert(Shape32::LC >= 16, "DevLanes32::sum_obj assumes the object lanes lie in the upper 16-lane row of the half-wave");   // physical lanes of one env group (Shape128: two virtual lanes each)
-struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale; };     // pbre_set_motors, by value
+struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale, vmax; };     // pbre_set_motors, by value
 
 template <class S, class L, int MODE>
 __global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
@@ -91,18 +91,18 @@ __global__ void kw_mrec_init(const TablesT<S>* __restrict__ T, float* __restrict
     const int i = t / S::W, l = t % S::W;
     if (i >= cnt) return;
     float* m = tgt + (size_t)i * S::TGT;
-    m[l] = T->home[l]; m[S::W + l] = T->kp_hold[l]; m[2 * S::W + l] = 1.f;
+    m[l] = T->home[l]; m[S::W + l] = T->kp_hold[l]; m[2 * S::W + l] = 1.f; m[3 * S::W + l] = 0.f;
 }
 // joint-control half of apply_action without the simulation step (icub_env.py:341-361): clipped absolute targets, gain 0.5, default force
 template <class S>
-__global__ void kw_cmd_joints(const TablesT<S>* __restrict__ T, float* __restrict__ tgt, const float* __restrict__ actions, int n, int act_dim) {
+__global__ void kw_cmd_joints(const TablesT<S>* __restrict__ T, float* __restrict__ tgt, const float* __restrict__ actions, int n, int act_dim, float vmax) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = t / 64, l = t % 64;
     if (e >= n) return;
     const int k = T->act_idx[l];
     if (k < 0) return;
     float* m = tgt + (size_t)e * S::TGT;
-    m[l] = fminf(fmaxf(actions[(size_t)e * act_dim + k], T->lower[l]), T->upper[l]); m[S::W + l] = T->kp_act[l]; m[2 * S::W + l] = 1.f;
+    m[l] = fminf(fmaxf(actions[(size_t)e * act_dim + k], T->lower[l]), T->upper[l]); m[S::W + l] = T->kp_act[l]; m[2 * S::W + l] = 1.f; m[3 * S::W + l] = vmax;
 }
 template <class S>
 __global__ void kw_set_motors(float* __restrict__ tgt, int n, const MotorCmd cmd, const unsigned char* __restrict__ mask) {
@@ -110,7 +110,7 @@ __global__ void kw_set_motors(float* __restrict__ tgt, int n, const MotorCmd cmd
     const int e = t / 64, k = t % 64;
     if (e >= n || k >= cmd.n || (mask && !mask[e])) return;
     float* m = tgt + (size_t)e * S::TGT;
-    m[cmd.dof[k]] = cmd.target[k]; m[S::W + cmd.dof[k]] = cmd.kp; m[2 * S::W + cmd.dof[k]] = cmd.fscale;
+    m[cmd.dof[k]] = cmd.target[k]; m[S::W + cmd.dof[k]] = cmd.kp; m[2 * S::W + cmd.dof[k]] = cmd.fscale; m[3 * S::W + cmd.dof[k]] = cmd.vmax;
 }
 template <class S, class L>
 __global__ void kw_target(const Params P, float* __restrict__ state, const unsigned long long* __restrict__ ids,
@@ -150,7 +150,7 @@ struct WideEngine {
     virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
     virtual void launch_mrec_init(float* tg, int cnt, hipStream_t s) = 0;
     virtual void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) = 0;
-    virtual void launch_cmd_joints(const float* act, hipStream_t s) = 0;
+    virtual void launch_cmd_joints(const float* act, float vmax, hipStream_t s) = 0;
     virtual int ndof() const = 0;
     virtual void snapshot(const float* rec) = 0;
     virtual void limits(float* lo, float* hi) const = 0;
@@ -220,8 +220,8 @@ struct WideImpl : WideEngine {
     void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) override {
         if (S::MREC) hipLaunchKernelGGL((kw_set_motors<S>), dim3((n * 64 + 255) / 256), dim3(256), 0, s, tgt, n, cmd, mask);
     }
-    void launch_cmd_joints(const float* act, hipStream_t s) override {
-        if (S::MREC) hipLaunchKernelGGL((kw_cmd_joints<S>), dim3((n * 64 + 255) / 256), dim3(256), 0, s, dT, tgt, act, n, act_dim);
+    void launch_cmd_joints(const float* act, float vmax, hipStream_t s) override {
+        if (S::MREC) hipLaunchKernelGGL((kw_cmd_joints<S>), dim3((n * 64 + 255) / 256), dim3(256), 0, s, dT, tgt, act, n, act_dim, vmax);
     }
     int ndof() const override { return T.ndof; }
     void snapshot(const float* rec) override {

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libpbre.so")   # PBRE_LIB: build-variant A/B runs
 
 STATE_FLOATS = 48
-ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS = 0, 1, 2
+ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS, ROBOT_PANDA_ARM = 0, 1, 2, 3
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
 F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES = 1, 2, 4, 8, 16
 
@@ -43,7 +43,7 @@ class Config(C.Structure):
                 ("home_hand_pose", C.c_double * 6), ("robot_ws", C.c_double * 2 * 3),
                 ("control_orientation", C.c_int32), ("reward_type", C.c_int32), ("num_joints_ctrl", C.c_int32),
                 ("act_dof", C.c_int32 * 64), ("ik_pos_scale", C.c_double), ("ik_rot_scale", C.c_double),
-                ("eu_lim", C.c_double * 2 * 3), ("ik_link_offset", C.c_double * 3), ("ik_absolute", C.c_int32),
+                ("eu_lim", C.c_double * 2 * 3), ("ik_link_offset", C.c_double * 3), ("ik_absolute", C.c_int32), ("robot_level", C.c_int32),
                 ("robot_table", C.c_void_p), ("robot_table_len", C.c_size_t)]
 
 
@@ -74,7 +74,7 @@ def load(path=None):
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
-                 "pbre_get_state_cols"):
+                 "pbre_get_state_cols", "pbre_set_physics_per_env"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_host_alloc.restype = C.c_void_p
     lib.pbre_host_alloc.argtypes = [C.c_size_t]
@@ -242,27 +242,30 @@ class Engine:
         self._chk(self.lib.pbre_observe(self._ctx, _fp(obs)))
         return obs
 
+    def _motor_w(self):
+        return (self.state_floats - 16) // 2
+
     def get_motor_state(self):
-        """iCub with hands: [N, 3, 128] target | positionGain | force scale of every DoF lane."""
-        m = np.zeros((self.num_envs, 3, 128), np.float32)
+        """Robot-level engines: [N, 4, W] target | positionGain | force scale | max velocity of every DoF lane (W = 128 / 32)."""
+        m = np.zeros((self.num_envs, 4, self._motor_w()), np.float32)
         self._chk(self.lib.pbre_get_motor_state(self._ctx, _fp(m)))
         return m
 
     def set_motor_state(self, m):
         m = np.ascontiguousarray(m, dtype=np.float32)
-        if m.shape != (self.num_envs, 3, 128):
-            raise ValueError("motor state must be [%d, 3, 128]" % self.num_envs)
+        if m.shape != (self.num_envs, 4, self._motor_w()):
+            raise ValueError("motor state must be [%d, 4, %d]" % (self.num_envs, self._motor_w()))
         self._chk(self.lib.pbre_set_motor_state(self._ctx, _fp(m)))
 
-    def apply_action(self, actions):
-        """iCub with hands: the command half of apply_action (IK / clipped joint targets -> persistent motors), no simulation step."""
+    def apply_action(self, actions, max_vel=-1.0):
+        """Robot-level engines: the command half of apply_action (IK / clipped joint targets -> persistent motors), no simulation step."""
         a = np.ascontiguousarray(actions, dtype=np.float32)
         if a.shape != (self.num_envs, self.act_dim):
             raise ValueError("actions must be [%d, %d]" % (self.num_envs, self.act_dim))
-        self._chk(self.lib.pbre_apply_action(self._ctx, _fp(a)))
+        self._chk(self.lib.pbre_apply_action(self._ctx, _fp(a), C.c_double(max_vel)))
 
-    def set_motors(self, dofs, targets, kp, max_force=0.0, mask=None):
-        """iCub with hands: persistent POSITION_CONTROL command of the given DoF (same targets in every selected env)."""
+    def set_motors(self, dofs, targets, kp, max_force=0.0, mask=None, max_vel=0.0):
+        """Robot-level engines: persistent POSITION_CONTROL command of the given DoF (same targets in every selected env)."""
         d = np.ascontiguousarray(dofs, dtype=np.int32)
         t = np.ascontiguousarray(targets, dtype=np.float32)
         if d.shape != t.shape or d.ndim != 1:
@@ -271,7 +274,7 @@ class Engine:
         if m is not None and m.shape != (self.num_envs,):
             raise ValueError("mask must have num_envs entries")
         self._chk(self.lib.pbre_set_motors(self._ctx, C.c_int32(d.size), _fp(d), _fp(t), C.c_double(kp), C.c_double(max_force),
-                                           None if m is None else _fp(m)))
+                                           C.c_double(max_vel), None if m is None else _fp(m)))
 
     def settle(self, n, flags=0):
         self._chk(self.lib.pbre_settle(self._ctx, C.c_int32(n), C.c_int32(flags)))
@@ -294,12 +297,25 @@ class Engine:
                 setattr(ph, k, v)
         self._chk(self.lib.pbre_set_physics(self._ctx, C.byref(ph)))
 
+    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None):
+        """Per-env object mass / lateral friction / linear damping ([N] arrays or None = unchanged): domain randomisation of the
+        Panda task envs (reference change_physics_params, called per env and episode by the Dyn-Rand training)."""
+        def arr(x):
+            if x is None:
+                return None
+            a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float32), (self.num_envs,)))
+            return a
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        a, b, c = arr(obj_mass), arr(obj_mu), arr(obj_lin_damping)
+        self._chk(self.lib.pbre_set_physics_per_env(self._ctx, None if m is None else _fp(m), None if a is None else _fp(a),
+                                                    None if b is None else _fp(b), None if c is None else _fp(c)))
+
     def timing(self):
         ms = (C.c_double * 4)()
         self._chk(self.lib.pbre_timing(self._ctx, ms, C.c_int32(4)))
         return list(ms)
 
     def kernel_info(self):
-        info = (C.c_int32 * 7)()
-        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(7)))
+        info = (C.c_int32 * 8)()
+        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(8)))
         return list(info)

@@ -11,8 +11,8 @@ motor record on the GPU): `apply_action` / the finger commands only write comman
 `step(action)` is the fused command + one step + observation used for throughput.
 
 Hand-pose commands may be 3 values (position), 6 (position + Euler angles, clipped to the arm's Euler limits as in the
-reference) or 7 (position + quaternion, used as given, as in the reference).  Not implemented: `max_vel` (the demo passes
-max_vel=5; the engine's motors have no velocity cap) and control_eu_or_quat=1 observations."""
+reference) or 7 (position + quaternion, used as given, as in the reference).  `max_vel` is the motors' `maxVelocity` (the rhs
+clamp of Bullet's motor row [EXT-UNVERIFIED]); control_eu_or_quat=1 returns quaternion observations (converted on the host)."""
 import math as m
 
 import numpy as np
@@ -188,7 +188,7 @@ class iCubHandsEnv(iCubEnv):
         elif a.shape[1] != len(self._joints_to_control):
             raise AssertionError('number of motor commands differs from number of motor to control',
                                  a.shape[1], len(self._joints_to_control))
-        self._engine.apply_action(a)
+        self._engine.apply_action(a, max_vel=float(max_vel))
 
     def step_simulation(self, n=1):
         """`for _ in range(n): p.stepSimulation()` of the demo script."""

@@ -26,16 +26,16 @@ class pandaPushGymEnv(PandaTaskBase):
                     tg_pose_rnd_std, includeVelObs, 0.1, num_envs, device_id, env_id_base, seed, _lib, auto_reset)
 
     def change_physics_params(self, obj_mass, obj_friction, obj_dumping, robot_damping):
-        """Domain randomisation hook of the reference (panda_push_gym_env.py:362-368: p.changeDynamics on the object's
-        mass / lateral friction / linear damping and on the arm links' linear damping), applied to every env of the
-        batch.  The engine has one linear-damping constant for all bodies (Bullet's default 0.04 each), so
-        `obj_dumping` and `robot_damping` must agree.  The cube's inertia is rescaled with its mass."""
-        if obj_dumping != robot_damping:
-            raise NotImplementedError("separate object / robot linear damping is not supported (one batch-uniform constant)")
-        ph = self._engine.get_physics()
-        scale = float(obj_mass) / ph.obj_mass
-        self._engine.set_physics(obj_mass=float(obj_mass), obj_mu=float(obj_friction), lin_damping=float(obj_dumping),
-                                 obj_inertia=[ph.obj_inertia[i] * scale for i in range(3)])
+        """Domain randomisation hook of the reference (panda_push_gym_env.py:362-368: p.changeDynamics on the object's mass /
+        lateral friction / linear damping, then on the arm links' linear damping).  Scalars apply to every env of the batch, [N]
+        arrays give every env its own object (the reference calls this per env and episode); the values persist across resets.
+        `robot_damping` is one constant for the batch (a scalar).  The reference's own loop over the arm links reads a
+        non-existent attribute (`_num_dof_no_fingers`, :366) and raises after the object was changed; here both parts are applied.
+        The cube's inertia is rescaled with its mass."""
+        if np.ndim(robot_damping) != 0:
+            raise ValueError("robot_damping is batch-uniform (a scalar)")
+        self._engine.set_physics(lin_damping=float(robot_damping))
+        self._engine.set_physics_per_env(obj_mass=obj_mass, obj_mu=obj_friction, obj_lin_damping=obj_dumping)
         return 0
 
     # host-side restatements of the reference helpers on the current state (the GPU step already returns them)

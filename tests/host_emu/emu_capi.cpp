@@ -33,8 +33,9 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     virtual void observe(float* obs) = 0;
     virtual void settle_all(int n, int flags) = 0;
     virtual void limits(float* lo, float* hi) = 0;
-    virtual int set_motors(int n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) = 0;
-    virtual int apply_action(const float* actions) = 0;
+    virtual int set_motors(int n, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) = 0;
+    virtual int apply_action(const float* actions, double max_vel) = 0;
+    bool mrec = false;
 };
 
 template <class S>
@@ -99,7 +100,7 @@ struct Emu : pbre_ctx {
             CoreH::init_state(T, P, id, ep, st);
             if (S::MREC) {     // iCubHandsEnv.reset (icub_env_with_hands.py:108-121): every motor at its initial position, gain 0.2, default force
                 float* m = &tgt[(size_t)e * TG];
-                for (int l = 0; l < W; l++) { m[l] = T.home[l]; m[W + l] = T.kp_hold[l]; m[2 * W + l] = 1.f; }
+                for (int l = 0; l < W; l++) { m[l] = T.home[l]; m[W + l] = T.kp_hold[l]; m[2 * W + l] = 1.f; m[3 * W + l] = 0.f; }
             }
             if (P.use_ik) ik(st, nullptr, &tgt[(size_t)e * TG], true);
             // one extra stepSimulation at the end of robot.reset: Panda in IK mode (panda_env.py:91), iCub always (icub_env.py:151)
@@ -148,8 +149,13 @@ struct Emu : pbre_ctx {
         }
     }
     void limits(float* lo, float* hi) override { obs_limits(cfg, T, lo, hi); }
-    int apply_action(const float* actions) override {
-        if (!S::MREC) { err = "pbre_apply_action: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    int apply_action(const float* actions, double max_vel) override {
+        if (!S::MREC) { err = "pbre_apply_action: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
+        const bool panda = P.robot == PBRE_ROBOT_PANDA;
+        const float vm = max_vel > 0 ? (float)max_vel : 0.f;
+        const Params P0 = P;
+        P.cmd_vmax = vm;
+        if (panda && vm > 0.f) { P.cmd_kp = 0.1f; P.cmd_nj = 7; }       // same host logic as wide_apply_action (pbre_wide.hip)
         for (int e = 0; e < n; e++) {
             float* m = &tgt[(size_t)e * TG];
             const float* a = actions + (size_t)e * act_dim;
@@ -157,19 +163,20 @@ struct Emu : pbre_ctx {
             else for (int l = 0; l < T.ndof; l++) {
                 const int k = T.act_idx[l];
                 if (k < 0) continue;
-                m[l] = std::fmin(std::fmax(a[k], T.lower[l]), T.upper[l]); m[W + l] = T.kp_act[l]; m[2 * W + l] = 1.f;
+                m[l] = std::fmin(std::fmax(a[k], T.lower[l]), T.upper[l]); m[W + l] = T.kp_act[l]; m[2 * W + l] = 1.f; m[3 * W + l] = panda ? 0.f : vm;
             }
         }
+        P = P0;
         return PBRE_OK;
     }
-    int set_motors(int cnt, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) override {
-        if (!S::MREC) { err = "pbre_set_motors: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    int set_motors(int cnt, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) override {
+        if (!S::MREC) { err = "pbre_set_motors: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
         for (int k = 0; k < cnt; k++) if (dofs[k] < 0 || dofs[k] >= T.ndof) { err = "pbre_set_motors: bad DoF index"; return PBRE_E_ARG; }
         const float fs = max_force > 0 ? (float)(max_force * cfg.phys.dt / cfg.phys.max_motor_impulse) : 1.f;
         for (int e = 0; e < n; e++) {
             if (mask && !mask[e]) continue;
             float* m = &tgt[(size_t)e * TG];
-            for (int k = 0; k < cnt; k++) { m[dofs[k]] = targets[k]; m[W + dofs[k]] = (float)kp; m[2 * W + dofs[k]] = fs; }
+            for (int k = 0; k < cnt; k++) { m[dofs[k]] = targets[k]; m[W + dofs[k]] = (float)kp; m[2 * W + dofs[k]] = fs; m[3 * W + dofs[k]] = max_vel > 0 ? (float)max_vel : 0.f; }
         }
         return PBRE_OK;
     }
@@ -186,6 +193,7 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg); c->sf = S::STATE; c->nj = S::NJ;
     c->state.assign((size_t)c->n * S::STATE, 0.f);
     c->tgt.assign((size_t)c->n * S::TGT, 0.f);
+    c->mrec = S::MREC;
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
     if constexpr (std::is_same<S, Shape16>::value) c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
     *out = c;
@@ -200,6 +208,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (!cfg || !out) { g_err = "null argument"; return PBRE_E_ARG; }
     const int nd = table_ndof(*cfg);
     if (nd > Shape64::NJ) return create<Shape128>(cfg, out);
+    if (cfg->robot_level && nd <= ShapePA::NJ) return create<ShapePA>(cfg, out);
     return nd > Shape32::NJ ? create<Shape64>(cfg, out) : (nd > Shape16::NJ ? create<Shape32>(cfg, out) : create<Shape16>(cfg, out));
 }
 void pbre_destroy(pbre_ctx* c) { delete c; }
@@ -245,23 +254,23 @@ int pbre_settle(pbre_ctx* c, int32_t n, int32_t flags) {
     c->settle_all(n, flags & PBRE_F_NO_OBJECT);
     return PBRE_OK;
 }
-int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, const uint8_t* mask) {
+int pbre_set_motors(pbre_ctx* c, int32_t n, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) {
     if (!c || n < 0 || (n > 0 && (!dofs || !targets))) return PBRE_E_ARG;
-    return c->set_motors(n, dofs, targets, kp, max_force, mask);
+    return c->set_motors(n, dofs, targets, kp, max_force, max_vel, mask);
 }
-int pbre_apply_action(pbre_ctx* c, const float* actions) {
+int pbre_apply_action(pbre_ctx* c, const float* actions, double max_vel) {
     if (!c || !actions) return PBRE_E_ARG;
-    return c->apply_action(actions);
+    return c->apply_action(actions, max_vel);
 }
 int pbre_get_motor_state(pbre_ctx* c, float* m) {
     if (!c || !m) return PBRE_E_ARG;
-    if (c->cfg.robot != PBRE_ROBOT_ICUB_HANDS) { c->err = "pbre_get_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    if (!c->mrec) { c->err = "pbre_get_motor_state: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
     std::memcpy(m, c->tgt.data(), c->tgt.size() * 4);
     return PBRE_OK;
 }
 int pbre_set_motor_state(pbre_ctx* c, const float* m) {
     if (!c || !m) return PBRE_E_ARG;
-    if (c->cfg.robot != PBRE_ROBOT_ICUB_HANDS) { c->err = "pbre_set_motor_state: only the iCub-with-hands engine keeps a motor record"; return PBRE_E_UNSUPPORTED; }
+    if (!c->mrec) { c->err = "pbre_set_motor_state: only the robot-level engines keep a motor record"; return PBRE_E_UNSUPPORTED; }
     std::memcpy(c->tgt.data(), m, c->tgt.size() * 4);
     return PBRE_OK;
 }
@@ -278,6 +287,18 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
+    return PBRE_OK;
+}
+int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping) {
+    if (!c) return PBRE_E_ARG;
+    if (c->sf != 48) { c->err = "pbre_set_physics_per_env: implemented for the Panda task envs"; return PBRE_E_UNSUPPORTED; }
+    for (int e = 0; e < c->n; e++) {
+        if (mask && !mask[e]) continue;
+        float* X = c->state.data() + (size_t)e * 48 + 32;
+        if (obj_mass) X[12] = obj_mass[e];
+        if (obj_mu) X[13] = obj_mu[e];
+        if (obj_lin_damping) X[15] = obj_lin_damping[e] + 1.f;
+    }
     return PBRE_OK;
 }
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; const_cast<pbre_ctx*>(c)->limits(lo, hi); return PBRE_OK; }

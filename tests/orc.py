@@ -104,10 +104,14 @@ class Oracle:
         self.lib.orc_task_hands(C.byref(self.task), C.c_int(1 if control_arm == "r" else 0), C.c_int(use_ik), ctrl, C.c_int(n),
                                 home, C.c_int(self.ndof))
 
-    # ---- iCub with hands: per-env motor records target | kp | force scale, MAXD each
+    def set_panda_arm(self, use_ik=0, control_orientation=1):
+        """pandaEnv used alone (robot-level interface, reference panda_env.py:195-365; scene of helloworld_panda.py)."""
+        self.lib.orc_task_panda_arm(C.byref(self.task), C.c_int(use_ik), C.c_int(control_orientation))
+
+    # ---- robot-level interfaces: per-env motor records target | kp | force scale | max velocity, MAXD each
     def hands_reset(self, n, env_id0=0):
         st = np.zeros((n, self.state_floats), self.np_real)
-        mrec = np.zeros((n, 3 * MAXD), self.np_real)
+        mrec = np.zeros((n, 4 * MAXD), self.np_real)
         obs = np.zeros((n, self.obs_dim), self.np_real)
         for e in range(n):
             self.lib.orc_hands_reset(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_uint64(env_id0 + e),
@@ -133,7 +137,16 @@ class Oracle:
                                       C.c_int(n_steps))
         return st
 
-    def hands_set_motors(self, mrec, dofs, targets, kp, max_force=0.0, mask=None):
+    def hands_apply_action(self, states, mrec, actions, max_vel=-1.0):
+        """the command half of apply_action(action, max_vel): returns (states, mrec) -- the state only changes in its commanded hand pose"""
+        st, mr = self._a(states).copy(), self._a(mrec).copy()
+        act = self._a(actions)
+        for e in range(st.shape[0]):
+            self.lib.orc_hands_apply_action(C.byref(self.model), C.byref(self.params), C.byref(self.task), self._p(st[e]), self._p(mr[e]),
+                                            self._p(act[e]), C.c_double(max_vel))
+        return st, mr
+
+    def hands_set_motors(self, mrec, dofs, targets, kp, max_force=0.0, mask=None, max_vel=0.0):
         mr = self._a(mrec).copy()
         d = (C.c_int * len(dofs))(*[int(x) for x in dofs])
         t = self._a(targets)
@@ -141,7 +154,7 @@ class Oracle:
             if mask is not None and not mask[e]:
                 continue
             self.lib.orc_hands_set_motors(C.byref(self.params), self._p(mr[e]), C.c_int(len(dofs)), d, self._p(t), C.c_double(kp),
-                                          C.c_double(max_force))
+                                          C.c_double(max_force), C.c_double(max_vel))
         return mr
 
     def _a(self, x):
@@ -244,6 +257,15 @@ def hands_oracle(control_arm="l", use_ik=0, **kw):
     o = Oracle(tbl, task=0, **kw)
     o.set_hands(info, control_arm, use_ik)
     return o, tbl, info
+
+
+def panda_arm_oracle(use_ik=0, control_orientation=1, **kw):
+    """Oracle + RobotTable of the Panda's robot-level interface (finger spheres carry fingertip slots 1 / 2)."""
+    from pybullet_robot_envs.model.table import panda_arm_table
+    tbl, model = panda_arm_table()
+    o = Oracle(tbl, task=0, **kw)
+    o.set_panda_arm(use_ik, control_orientation)
+    return o, tbl
 
 
 def panda_oracle(**kw):

