@@ -365,6 +365,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     bool rows = NB == 1 && hint <= c->row_max;
     if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
     if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
+    if (!c->P.obj_iso) rows = NB == 1;                 // a box with unequal principal inertias: k_fast_rc's object rows assume a cube
     if constexpr (NB == 1) {
         if (rows) {
             const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));
@@ -720,7 +721,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     cfg.phys = *phys;
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
-    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
+    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(quiesce(c));

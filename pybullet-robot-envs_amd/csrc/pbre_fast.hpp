@@ -33,6 +33,7 @@
 #ifndef PBRE_ANY            // wave-uniform "any lane" on the device; identity on the host (one env per call)
 #define PBRE_ANY(x) (x)
 #endif
+#include "pbre_objstep.hpp"
 
 namespace pbre {
 
@@ -50,8 +51,9 @@ struct TopoPanda {
 
 // fast path preconditions that are uniform over the batch (checked once on the host)
 inline bool fast_scene_ok(const Params& P) {
-    return P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]    // isotropic object inertia (a cube)
-        && P.jd_dt == 0.f;                                          // explicit joint damping
+    return P.jd_dt == 0.f;                                          // explicit joint damping
+    // (a box with unequal principal inertias is stepped by ObjStep inside the simple-env kernel, and its complex envs by the row
+    // kernel: P.obj_iso)
 }
 
 template <class Topo>
@@ -463,7 +465,18 @@ struct Fast {
         const float inv_m = 1.f / o_m, inv_I = P.obj_m / (P.obj_I[0] * o_m);
         const float sk = sqrtf(inv_I / inv_m), inv_sk = 1.f / sk;
         const float mu = o_mu * P.tab_mu;
-        if (obj_on) {
+        // A box with unequal principal inertias (obj_name other than the cube; P.obj_iso == 0): the in-line object rows below assume
+        // I_w^-1 = 1/I, so the object's half of the step -- it shares no unknown with the robot rows in this class -- is done by
+        // ObjStep (pbre_objstep.hpp: same rows, any principal inertia) and the solver loop runs the robot rows alone.  The envs with
+        // robot contacts of such a scene are stepped by the row kernel (launch_step), never by step_t<true>.
+        const bool obj_inline = obj_on && (P.obj_iso != 0);
+        float o_tw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (obj_on && !obj_inline) {
+            const float pose[7] = {op.x, op.y, op.z, oq.x, oq.y, oq.z, oq.w};
+            const float tw0[6] = {ov.x, ov.y, ov.z, ow.x, ow.y, ow.z};
+            ObjStep::run_p(P, pose, tw0, o_tw, o_m, o_mu, o_kl);
+        }
+        if (obj_inline) {
             const float isc = o_m / P.obj_m;
             V3 oI = v3(P.obj_I[0] * isc, P.obj_I[1] * isc, P.obj_I[2] * isc);
             M3 Iinv;
@@ -717,6 +730,7 @@ struct Fast {
         }
 
         ow = scl(ow, sk);
+        if (obj_on && !obj_inline) { ov = v3(o_tw[0], o_tw[1], o_tw[2]); ow = v3(o_tw[3], o_tw[4], o_tw[5]); }
         // ---- integrate.  Positions are re-read from the state record (still the old values) rather than kept in
         //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
         PBRE_REG_BARRIER();

@@ -138,6 +138,7 @@ inline bool apply_physics(const pbre_physics& p, Params& P2) {
     P2.jd_dt = p.implicit_joint_damping ? (float)p.dt : 0.f;
     for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
     P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
+    P2.obj_iso = (P2.obj_I[0] == P2.obj_I[1] && P2.obj_I[1] == P2.obj_I[2]) ? 1 : 0;
     return true;
 }
 
@@ -174,6 +175,7 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     P.jd_dt = p.implicit_joint_damping ? (float)p.dt : 0.f;
     for (int k = 0; k < 3; k++) { P.tab_c[k] = (float)p.table_c[k]; P.tab_h[k] = (float)p.table_h[k]; P.obj_h[k] = (float)p.obj_h[k]; P.obj_I[k] = (float)p.obj_inertia[k]; }
     P.tab_mu = (float)p.table_mu; P.ground_z = (float)p.ground_z; P.obj_m = (float)p.obj_mass; P.obj_mu = (float)p.obj_mu;
+    P.obj_iso = (P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]) ? 1 : 0;
     P.task = c.task; P.max_steps = c.max_steps; P.flags = c.flags;
     P.dist_min = (float)c.target_dist_min; P.act_scale = (float)c.act_scale;
     P.obj_std = (float)c.obj_pose_rnd_std; P.tg_std = (float)c.tg_pose_rnd_std;

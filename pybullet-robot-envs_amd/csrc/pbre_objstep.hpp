@@ -28,8 +28,12 @@ struct ObjStep {
 #endif
     // pose: position[3] | quaternion xyzw[4]; tw: linear[3] | angular[3] velocity at t.  o[6]: the twist at t + dt (after the
     // constraint solve, clamped to the velocity bound), which is all the caller needs to integrate the pose itself.
-    static PBRE_HD void run(const Params& P, const float* pose, const float* tw, float* o) {
+    static PBRE_HD void run(const Params& P, const float* pose, const float* tw, float* o) { run_p(P, pose, tw, o, P.obj_m, P.obj_mu, P.kl); }
+    // o_m, o_mu, o_kl: this env's object mass / lateral friction / linear damping (pbre_set_physics_per_env; the principal inertias
+    // P.obj_I scale with o_m / P.obj_m)
+    static PBRE_HD void run_p(const Params& P, const float* pose, const float* tw, float* o, float o_m, float o_mu, float o_kl) {
         const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
+        const float isc = o_m / P.obj_m;
         const float px = pose[0], py = pose[1], pz = pose[2];
         const float x = pose[3], y = pose[4], z = pose[5], w = pose[6];
         float R[9];
@@ -38,10 +42,10 @@ struct ObjStep {
         R[6] = 2.f * (x*z - w*y);       R[7] = 2.f * (y*z + w*x);       R[8] = 1.f - 2.f * (x*x + y*y);
         float vx = tw[0], vy = tw[1], vz = tw[2], wx = tw[3], wy = tw[4], wz = tw[5];
         {   // unconstrained velocity: gravity, linear / angular damping, gyroscopic torque  w x (I_w w)
-            const float I0 = P.obj_I[0], I1 = P.obj_I[1], I2 = P.obj_I[2];
+            const float I0 = P.obj_I[0] * isc, I1 = P.obj_I[1] * isc, I2 = P.obj_I[2] * isc;
             const float lx = I0 * (R[0]*wx + R[3]*wy + R[6]*wz), ly = I1 * (R[1]*wx + R[4]*wy + R[7]*wz), lz = I2 * (R[2]*wx + R[5]*wy + R[8]*wz);
             const float Lx = R[0]*lx + R[1]*ly + R[2]*lz, Ly = R[3]*lx + R[4]*ly + R[5]*lz, Lz = R[6]*lx + R[7]*ly + R[8]*lz;
-            const float sl = fmaf(P.kl, sqrtf(fmaf(vx, vx, fmaf(vy, vy, vz * vz))), P.kl);
+            const float sl = fmaf(o_kl, sqrtf(fmaf(vx, vx, fmaf(vy, vy, vz * vz))), o_kl);
             const float sa = fmaf(P.ka, sqrtf(fmaf(wx, wx, fmaf(wy, wy, wz * wz))), P.ka);
             const float tx = -(wy * Lz - wz * Ly) - Lx * sa, ty = -(wz * Lx - wx * Lz) - Ly * sa, tz = -(wx * Ly - wy * Lx) - Lz * sa;
             // I_w^-1 tq = R diag(1/I) R^T tq
@@ -54,10 +58,10 @@ struct ObjStep {
         // object-table contacts: the (at most NK) box vertices closest to their support surface within the margin, in vertex order.
         // Impulses in delta-v units (a = lambda / m): a row along dir at lever arm r has J = [dir, r x dir], changes the twist by
         // (a dir, a g) with g = m I_w^-1 (r x dir), and J M^-1 J^T = (1 + (r x dir) . g) / m.
-        const float mu = P.obj_mu * P.tab_mu;
+        const float mu = o_mu * P.tab_mu;
         float Ii[6];       // m * I_w^-1 = m R diag(1/I) R^T: xx yy zz xy xz yz
         {
-            const float a = P.obj_m / P.obj_I[0], b = P.obj_m / P.obj_I[1], c = P.obj_m / P.obj_I[2];
+            const float a = P.obj_m / P.obj_I[0], b = P.obj_m / P.obj_I[1], c = P.obj_m / P.obj_I[2];      // (m / I is independent of the per-env mass)
             Ii[0] = a*R[0]*R[0] + b*R[1]*R[1] + c*R[2]*R[2]; Ii[1] = a*R[3]*R[3] + b*R[4]*R[4] + c*R[5]*R[5]; Ii[2] = a*R[6]*R[6] + b*R[7]*R[7] + c*R[8]*R[8];
             Ii[3] = a*R[0]*R[3] + b*R[1]*R[4] + c*R[2]*R[5]; Ii[4] = a*R[0]*R[6] + b*R[1]*R[7] + c*R[2]*R[8]; Ii[5] = a*R[3]*R[6] + b*R[4]*R[7] + c*R[5]*R[8];
         }

@@ -88,6 +88,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     float jd_dt;                  // dt when the joint damping is integrated implicitly (M + dt C), else 0
     float tab_c[3], tab_h[3], tab_mu, ground_z;
     float obj_h[3], obj_m, obj_I[3], obj_mu;
+    int   obj_iso;                // the object's principal inertias are equal (a cube): the lane-per-env kernels' in-line object rows apply
     int   task, max_steps, flags;
     float dist_min, act_scale;
     float obj_std, tg_std, ws[3][2], h_table;

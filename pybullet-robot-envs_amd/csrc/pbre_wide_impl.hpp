@@ -98,7 +98,7 @@ template <class S>
 __global__ void kw_cmd_joints(const TablesT<S>* __restrict__ T, float* __restrict__ tgt, const float* __restrict__ actions, int n, int act_dim, float vmax) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int e = t / 64, l = t % 64;
-    if (e >= n) return;
+    if (e >= n || l >= S::W) return;              // (64 threads per env cover the <= 64 DoF lanes; the Panda's shape has 32 lanes)
     const int k = T->act_idx[l];
     if (k < 0) return;
     float* m = tgt + (size_t)e * S::TGT;

@@ -130,7 +130,11 @@ class Engine:
             for k, v in phys.items():
                 if not hasattr(self.cfg.phys, k):
                     raise TypeError("unknown pbre_physics field %r" % k)
-                setattr(self.cfg.phys, k, v)
+                if isinstance(v, (list, tuple, np.ndarray)):
+                    for i, x in enumerate(v):
+                        getattr(self.cfg.phys, k)[i] = x
+                else:
+                    setattr(self.cfg.phys, k, v)
         self._table = np.ascontiguousarray(robot_table, dtype=np.float64)
         self.cfg.robot_table = self._table.ctypes.data
         self.cfg.robot_table_len = self._table.size
@@ -319,3 +323,126 @@ class Engine:
         info = (C.c_int32 * 8)()
         self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(8)))
         return list(info)
+
+
+class MultiEngine(object):
+    """`num_envs` environments sharded over several GPUs of one node from ONE process (the Gym classes' `devices=[...]` kwarg, SURVEY
+    8b): one pbre_ctx per device, env i on device i // (N / G), RNG streams keyed by the global env id (so results are bitwise those
+    of a single engine), every call fanned out to the shards from one host thread per device (ctypes releases the GIL during the
+    C call).  Same methods as `Engine`; the device-pointer entry point is per shard (`shards[k].step_device`).  For one process per
+    GPU under torch.distributed use `sharding.ShardedEngine` instead."""
+
+    def __init__(self, robot_table, devices, num_envs=1, env_id_base=0, **kw):
+        from concurrent.futures import ThreadPoolExecutor
+        devices = [int(d) for d in devices]
+        g = len(devices)
+        if g < 1 or num_envs % g != 0:
+            raise ValueError("num_envs (%d) must be divisible by the number of devices (%d)" % (num_envs, g))
+        self.devices, self.n_shard = devices, num_envs // g
+        kw.pop("device_id", None)
+        self.shards = [Engine(robot_table, num_envs=self.n_shard, device_id=d, env_id_base=int(env_id_base) + k * self.n_shard, **kw)
+                       for k, d in enumerate(devices)]
+        e0 = self.shards[0]
+        self.obs_dim, self.act_dim, self.state_floats = e0.obs_dim, e0.act_dim, e0.state_floats
+        self.ndof, self.v_off, self.x_off, self.cfg, self.lib = e0.ndof, e0.v_off, e0.x_off, e0.cfg, e0.lib
+        self.num_envs = int(num_envs)
+        self._pool = ThreadPoolExecutor(max_workers=g)
+
+    def _sl(self, k):
+        return slice(k * self.n_shard, (k + 1) * self.n_shard)
+
+    def _map(self, fn):
+        return list(self._pool.map(fn, range(len(self.shards))))
+
+    def _cat(self, parts):
+        return np.concatenate(parts, axis=0)
+
+    def close(self):
+        for e in self.shards:
+            e.close()
+        self._pool.shutdown(wait=False)
+
+    def obs_limits(self):
+        return self.shards[0].obs_limits()
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        return self._cat(self._map(lambda k: self.shards[k].reset(None if m is None else m[self._sl(k)])))
+
+    def step(self, actions, copy=True):
+        a = np.asarray(actions)
+        if a.shape != (self.num_envs, self.act_dim):
+            raise ValueError("actions must have shape (%d, %d), got %r" % (self.num_envs, self.act_dim, a.shape))
+        r = self._map(lambda k: self.shards[k].step(a[self._sl(k)], copy=False))
+        return tuple(self._cat([x[i] for x in r]) for i in range(3))
+
+    def step_device(self, *a, **kw):
+        raise RuntimeError("step_device is per device: use MultiEngine.shards[k].step_device with buffers on that shard's GPU")
+
+    def sync(self):
+        self._map(lambda k: self.shards[k].sync())
+
+    def observe(self):
+        return self._cat(self._map(lambda k: self.shards[k].observe()))
+
+    def get_state(self):
+        return self._cat(self._map(lambda k: self.shards[k].get_state()))
+
+    def get_state_cols(self, first, count=1):
+        return self._cat(self._map(lambda k: self.shards[k].get_state_cols(first, count)))
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, dtype=np.float32)
+        assert s.shape == (self.num_envs, self.state_floats)
+        self._map(lambda k: self.shards[k].set_state(s[self._sl(k)]))
+
+    def settle(self, n, flags=0):
+        self._map(lambda k: self.shards[k].settle(n, flags))
+
+    def get_physics(self):
+        return self.shards[0].get_physics()
+
+    def set_physics(self, **fields):
+        for e in self.shards:
+            e.set_physics(**fields)
+
+    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None):
+        def part(x, k):
+            return None if x is None else np.broadcast_to(np.asarray(x, np.float32), (self.num_envs,))[self._sl(k)]
+        for k, e in enumerate(self.shards):
+            e.set_physics_per_env(part(obj_mass, k), part(obj_mu, k), part(obj_lin_damping, k), None if mask is None else np.asarray(mask)[self._sl(k)])
+
+    def get_motor_state(self):
+        return self._cat(self._map(lambda k: self.shards[k].get_motor_state()))
+
+    def set_motor_state(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        self._map(lambda k: self.shards[k].set_motor_state(m[self._sl(k)]))
+
+    def apply_action(self, actions, max_vel=-1.0):
+        a = np.ascontiguousarray(actions, dtype=np.float32)
+        self._map(lambda k: self.shards[k].apply_action(a[self._sl(k)], max_vel))
+
+    def set_motors(self, dofs, targets, kp, max_force=0.0, mask=None, max_vel=0.0):
+        for k, e in enumerate(self.shards):
+            e.set_motors(dofs, targets, kp, max_force, None if mask is None else np.asarray(mask)[self._sl(k)], max_vel)
+
+    def timing(self):
+        t = [e.timing() for e in self.shards]
+        return [max(x[i] for x in t) for i in range(4)]
+
+    def kernel_info(self):
+        infos = [e.kernel_info() for e in self.shards]
+        out = list(infos[0])
+        for i in (3, 4, 5, 7):
+            out[i] = sum(x[i] for x in infos)
+        return out
+
+
+def make_engine(robot_table, devices=None, **kw):
+    """An `Engine` on one GPU, or a `MultiEngine` over `devices` (a list of HIP device ordinals) when more than one is given."""
+    if devices is not None and len(devices) > 1:
+        return MultiEngine(robot_table, devices, **kw)
+    if devices is not None and len(devices) == 1:
+        kw["device_id"] = int(devices[0])
+    return Engine(robot_table, **kw)

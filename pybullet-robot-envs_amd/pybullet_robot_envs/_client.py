@@ -10,7 +10,10 @@ _ids = itertools.count()
 class Client(object):
     def __init__(self, num_envs=1, device_id=0, env_id_base=0, seed=1234, lib=None):
         self.num_envs = int(num_envs)
-        self.device_id = int(device_id)
+        # `device_id` may be one HIP device ordinal or a list of them (the Gym classes' `devices=[...]`): the batch is then sharded
+        # over those GPUs from this process (_capi.MultiEngine)
+        self.devices = [int(d) for d in device_id] if isinstance(device_id, (list, tuple)) else None
+        self.device_id = self.devices[0] if self.devices else int(device_id)
         self.env_id_base = int(env_id_base)
         self.seed = int(seed)
         self.lib = lib

@@ -74,7 +74,8 @@ class ICubTaskBase(PandaTaskBase):
                          ik_link_offset=list(r._com_to_link_hand_frame()[0]),
                          ws_lim=[x for lim in self._world.get_workspace() for x in lim],
                          robot_ws=[x for lim in r.get_workspace() for x in lim])
-        c.engine = _capi.Engine(r.robot_table, task=self._TASK, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_ICUB, **overrides)
+        c.engine = _capi.make_engine(r.robot_table, devices=c.devices, task=self._TASK, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_ICUB,
+                                      phys=self._world.object_physics(), **overrides)
         assert c.engine.act_dim == r.get_action_dim() and c.engine.state_floats == 80
         self._engine = c.engine
 

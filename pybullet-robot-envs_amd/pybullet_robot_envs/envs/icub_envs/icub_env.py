@@ -59,9 +59,6 @@ class iCubEnv:
 
         self.ll, self.ul, self.jr, self.rs, self.jd = None, None, None, None, None
 
-        if control_eu_or_quat != 0:
-            raise NotImplementedError("control_eu_or_quat=1 (quaternion actions / observations) is not implemented")
-
         self.seed()
         self.reset()
 
@@ -141,12 +138,15 @@ class iCubEnv:
         return 3  # position x,y,z
 
     def get_observation_dim(self):
-        return 9 + len(self._joints_to_control)
+        return (9 if self._control_eu_or_quat == 0 else 10) + len(self._joints_to_control)
 
     def get_observation_limits(self):
         lim = []
         lim.extend(list(self._workspace_lim))
-        lim.extend(self._eu_lim)
+        if self._control_eu_or_quat == 0:
+            lim.extend(self._eu_lim)
+        else:
+            lim.extend([[-1, 1], [-1, 1], [-1, 1], [-1, 1]])
         lim.extend([[-1, 1], [-1, 1], [-1, 1]])
         lim.extend([[self.ll[i], self.ul[i]] for i, idx in enumerate(self._joint_name_to_ids.values())
                     if idx in self._joints_to_control])
@@ -156,7 +156,10 @@ class iCubEnv:
         """Hand COM pose (3 + 3 Euler), its linear velocity (3) and the controlled joint positions (10) with their limits
         (icub_env.py:202-249).  List of 19 for a single env, [N, 19] array for a batch."""
         eng = self._client.require_engine()
-        obs = eng.observe()[:, :self.get_observation_dim()].astype(np.float64)
+        obs = eng.observe()[:, :9 + len(self._joints_to_control)].astype(np.float64)
+        if self._control_eu_or_quat != 0:      # hand orientation as a quaternion (icub_env.py:219-224): converted from the engine's Euler angles
+            from pybullet_robot_envs.envs.panda_envs.panda_env import pandaEnv
+            obs = np.concatenate([obs[:, :3], pandaEnv._quat_from_euler(obs[:, 3:6]), obs[:, 6:]], axis=1)
         if obs.shape[0] == 1:
             return list(obs[0]), self.get_observation_limits()
         return obs, self.get_observation_limits()

@@ -63,9 +63,6 @@ class iCubHandsEnv(iCubEnv):
             self._home_hand_pose = [0.2, -0.3, 0.8, 0, 0,  m.pi/2]
             self._eu_lim = [[-m.pi / 2, m.pi / 2], [-m.pi / 2, m.pi / 2], [0, m.pi]]
 
-        if control_eu_or_quat != 0:
-            raise NotImplementedError("control_eu_or_quat=1 (quaternion actions / observations) is not implemented")
-
         self._last_out = None
         self.seed()
         self.reset()
@@ -124,10 +121,10 @@ class iCubHandsEnv(iCubEnv):
                          eu_lim=[-1e9, 1e9] * 3,        # Euler limits are applied here (apply_action): a quaternion command bypasses them
                          ik_link_offset=list(self._com_to_link_hand_frame()[0]),
                          robot_ws=[x for lim in self._workspace_lim for x in lim])
-        c.engine = _capi.Engine(self.robot_table, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib,
+        c.engine = _capi.make_engine(self.robot_table, devices=c.devices, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib,
                                 robot=_capi.ROBOT_ICUB_HANDS, **overrides)
         self._engine = c.engine
-        assert self._engine.act_dim == self.get_action_dim() and self._engine.state_floats == 272
+        assert self._engine.act_dim == (len(dofs) if not self._use_IK else (6 if self._control_orientation else 3)) and self._engine.state_floats == 272
         self.num_envs = self._engine.num_envs
 
     def _com_to_link_hand_frame(self):
@@ -229,7 +226,9 @@ class iCubHandsEnv(iCubEnv):
     def get_action_dim(self):
         if not self._use_IK:
             return len(self._joints_to_control)
-        return 6 if self._control_orientation else 3
+        if self._control_orientation:
+            return 6 if self._control_eu_or_quat == 0 else 7      # the engine takes Euler angles; a quaternion command is converted
+        return 3
 
     def _tail(self):
         return self._engine.observe()[:, -7:].astype(np.float64)

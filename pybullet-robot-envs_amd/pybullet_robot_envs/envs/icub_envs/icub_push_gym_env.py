@@ -22,7 +22,8 @@ class iCubPushGymEnv(ICubTaskBase):
                  renders=False,
                  max_steps=2000,
                  reward_type=1,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+        device_id = devices if devices is not None else device_id
         self._setup_icub(action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std, tg_pose_rnd_std,
                          renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset)
 

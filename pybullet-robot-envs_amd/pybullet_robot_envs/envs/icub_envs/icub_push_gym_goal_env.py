@@ -23,7 +23,8 @@ class iCubPushGymGoalEnv(GoalEnv, iCubPushGymEnv):
                  renders=False,
                  max_steps=2000,
                  reward_type=1,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+        device_id = devices if devices is not None else device_id
         iCubPushGymEnv.__init__(self, action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std,
                                 tg_pose_rnd_std, renders, max_steps, reward_type,
                                 num_envs=num_envs, device_id=device_id, env_id_base=env_id_base, seed=seed, auto_reset=auto_reset, _lib=_lib)

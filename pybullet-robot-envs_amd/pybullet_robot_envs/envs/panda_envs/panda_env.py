@@ -134,7 +134,7 @@ class pandaEnv:
         if c.engine is None:
             tbl, _ = panda_arm_table(self._base_position)
             ws = self._workspace_lim
-            c.engine = _capi.Engine(tbl, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_PANDA_ARM,
+            c.engine = _capi.make_engine(tbl, devices=c.devices, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_PANDA_ARM,
                                     device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed,
                                     use_ik=1 if self._use_IK else 0, control_orientation=1 if self._control_orientation else 0,
                                     num_controlled_joints=int(self.joint_action_space), num_joints_ctrl=int(self.joint_action_space),

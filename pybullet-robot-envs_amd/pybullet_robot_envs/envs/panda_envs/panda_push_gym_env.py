@@ -20,7 +20,8 @@ class pandaPushGymEnv(PandaTaskBase):
                  obj_pose_rnd_std=0.0,
                  tg_pose_rnd_std=0.0,
                  includeVelObs=True,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+        device_id = devices if devices is not None else device_id
         self._target_dist_max = 0.3
         self._setup(numControlledJoints, use_IK, action_repeat, obj_name, renders, max_steps, obj_pose_rnd_std,
                     tg_pose_rnd_std, includeVelObs, 0.1, num_envs, device_id, env_id_base, seed, _lib, auto_reset)

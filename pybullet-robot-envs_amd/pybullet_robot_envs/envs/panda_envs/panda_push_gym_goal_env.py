@@ -21,7 +21,8 @@ class pandaPushGymGoalEnv(GoalEnv, pandaPushGymEnv):
                  max_steps=1000,
                  obj_pose_rnd_std=0, tg_pose_rnd_std=0.2,
                  includeVelObs=True,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+        device_id = devices if devices is not None else device_id
         pandaPushGymEnv.__init__(self, numControlledJoints, use_IK, action_repeat, obj_name, renders, max_steps,
                                  obj_pose_rnd_std, tg_pose_rnd_std, includeVelObs,
                                  num_envs=num_envs, device_id=device_id, env_id_base=env_id_base, seed=seed, auto_reset=auto_reset, _lib=_lib)

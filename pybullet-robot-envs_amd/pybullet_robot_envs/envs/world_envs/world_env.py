@@ -3,8 +3,9 @@
 Same constructor signature and method surface as the reference class; the simulation itself is the
 batched HIP engine owned by the task env.  The scene constants the reference reads from `pybullet_data`
 (absent from the reference checkout) are the engine's documented stand-ins: table top at h = 0.625
-(world_env.py:68-69), `cube_small` = 5 cm / 0.1 kg box.  Other `obj_name`s of get_objects_list() are
-accepted for API parity but simulated with the same box (their meshes are not available)."""
+(world_env.py:68-69), `cube_small` = 5 cm / 0.1 kg box.  Every other `obj_name` of get_objects_list() / get_ycb_objects_list() is a box
+with that object's approximate bounding dimensions, mass and friction (model/objects.py: the meshes are not available), so the name
+changes the dynamics; `YcbWorldEnv` / `SqWorldEnv` select from the YCB table."""
 import math as m
 
 import numpy as np
@@ -18,7 +19,9 @@ def get_objects_list():
 
 
 def get_ycb_objects_list():
-    raise NotImplementedError("pybullet_object_models (YCB meshes) is not available to this engine")
+    """names of pybullet_object_models.ycb_objects (reference world_env.py:28-32 lists the package's folders)"""
+    from pybullet_robot_envs.model.objects import YCB_OBJECTS
+    return sorted(YCB_OBJECTS)
 
 
 def euler_from_quat(q):
@@ -47,15 +50,13 @@ class WorldEnv:
 
         if workspace_lim is None:
             workspace_lim = [[0.25, 0.52], [-0.3, 0.3], [0.5, 1.0]]
-        if control_eu_or_quat != 0:
-            raise NotImplementedError("control_eu_or_quat=1 (quaternion observations) is not implemented")
-
         self._physics_client_id = physicsClientId
         self._client = _client.get(physicsClientId)
         self._client.world = self
         self._ws_lim = tuple([list(i) for i in workspace_lim])
         self._h_table = 0.625
         self._obj_name = obj_name
+        self.object_physics()           # unknown names fail here, as p.loadURDF would
         self._obj_pose_rnd_std = obj_pose_rnd_std
         self._obj_init_pose = []
         self._control_eu_or_quat = control_eu_or_quat
@@ -70,6 +71,24 @@ class WorldEnv:
         # engine reset (pbre_reset), including _sample_pose
         self._ws_lim[2][:] = [self._h_table, self._h_table + 0.3]
 
+    def object_physics(self):
+        """pbre_physics fields of this world's object (box stand-in of `obj_name`, model/objects.py): the task env hands them to the
+        engine -- the counterpart of load_object's p.loadURDF (world_env.py:76-84)."""
+        from pybullet_robot_envs.model.objects import object_physics
+        return object_physics(self._obj_name)
+
+    def load_object(self, obj_name):
+        """(world_env.py:76-84) switch the object; takes effect in the engine at once when the task env has built it"""
+        self._obj_name = obj_name
+        ph = self.object_physics()
+        if self._client.engine is not None:
+            self._client.engine.set_physics(**ph)
+
+    def get_object_shape_info(self):
+        """(world_env.py:95-98) geometry type 3 = box, dimensions = full extents"""
+        h = self.object_physics()["obj_h"]
+        return [self.obj_id, -1, 3, [2 * x for x in h], "", [0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+
     def get_table_height(self):
         return self._h_table
 
@@ -77,7 +96,7 @@ class WorldEnv:
         return [i[:] for i in self._ws_lim]
 
     def get_observation_dimension(self):
-        return 6
+        return 6 if self._control_eu_or_quat == 0 else 7
 
     def get_object_pose(self):
         """Batched object position [N,3] and quaternion [N,4]."""
@@ -86,11 +105,14 @@ class WorldEnv:
         return st[:, o:o + 3].astype(np.float64), st[:, o + 3:o + 7].astype(np.float64)
 
     def get_observation(self):
-        """Object position + Euler angles and their limits (world_env.py:109-126).  A list of 6 floats for a
-        single env, an [N, 6] array for a batch."""
+        """Object position + Euler angles (or, with control_eu_or_quat=1, the quaternion) and their limits (world_env.py:109-126).
+        A list of 6 (7) floats for a single env, an [N, 6 (7)] array for a batch."""
         observation_lim = []
         observation_lim.extend(self._ws_lim)
-        observation_lim.extend([[-m.pi, m.pi], [-m.pi, m.pi], [-m.pi, m.pi]])
+        if self._control_eu_or_quat == 0:
+            observation_lim.extend([[-m.pi, m.pi], [-m.pi, m.pi], [-m.pi, m.pi]])
+        else:
+            observation_lim.extend([[-1, 1], [-1, 1], [-1, 1], [-1, 1]])
         if self._client.engine is None:       # before the task env built the engine: initial pose
             x_min, x_max = self._ws_lim[0][0] + 0.05, self._ws_lim[0][1] - 0.1          # _sample_pose, world_env.py:147-160
             y_min, y_max = self._ws_lim[1][0] + 0.05, self._ws_lim[1][1] - 0.05
@@ -98,7 +120,7 @@ class WorldEnv:
             quat = np.array([[0.0, 0.0, m.sin(m.pi / 8), m.cos(m.pi / 8)]])
         else:
             pos, quat = self.get_object_pose()
-        obs = np.concatenate([pos, euler_from_quat(quat)], axis=1)
+        obs = np.concatenate([pos, euler_from_quat(quat) if self._control_eu_or_quat == 0 else quat], axis=1)
         if obs.shape[0] == 1:
             return list(obs[0]), observation_lim
         return obs, observation_lim
@@ -115,10 +137,14 @@ class WorldEnv:
 
 
 class YcbWorldEnv(WorldEnv):
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("YcbWorldEnv needs pybullet_object_models meshes, which this engine does not have")
+    """(world_env.py:179-196) a world whose object comes from the YCB set: box stand-ins of model/objects.py"""
+
+    def __init__(self, physicsClientId, obj_name='YcbMustardBottle', obj_pose_rnd_std=0.05, workspace_lim=None, control_eu_or_quat=0):
+        super(YcbWorldEnv, self).__init__(physicsClientId, obj_name, obj_pose_rnd_std, workspace_lim, control_eu_or_quat)
 
 
 class SqWorldEnv(WorldEnv):
-    def __init__(self, *a, **kw):
-        raise NotImplementedError("SqWorldEnv needs pybullet_object_models meshes, which this engine does not have")
+    """(world_env.py:199-216) superquadric approximations of the YCB objects: the same box stand-ins"""
+
+    def __init__(self, physicsClientId, obj_name='YcbMustardBottle', obj_pose_rnd_std=0.05, workspace_lim=None, control_eu_or_quat=0):
+        super(SqWorldEnv, self).__init__(physicsClientId, obj_name, obj_pose_rnd_std, workspace_lim, control_eu_or_quat)

@@ -52,7 +52,7 @@ struct Emu : pbre_ctx {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
                 if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
-                else if (cfg.flags & PBRE_F_COMPLEX_ROWS) {
+                else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
                     CoreH::step(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg);
@@ -285,7 +285,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     cfg.phys = *phys;
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
-    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need an isotropic object inertia (cube) and explicit joint damping"; return PBRE_E_UNSUPPORTED; }
+    if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;
 }

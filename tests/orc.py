@@ -243,6 +243,14 @@ class Oracle:
         return list(out)
 
 
+def set_object(o, ph):
+    """object stand-in (model/objects.py: object_physics) -> oracle parameters"""
+    for k in range(3):
+        o.params.obj_h[k] = ph["obj_h"][k]
+        o.params.obj_inertia[k] = ph["obj_inertia"][k]
+    o.params.obj_mass, o.params.obj_mu = ph["obj_mass"], ph["obj_mu"]
+
+
 def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, **kw):
     from pybullet_robot_envs.model.table import icub_table
     tbl, model, info = icub_table(control_arm)

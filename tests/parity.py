@@ -156,11 +156,13 @@ def ambiguous_envs(ora, s64, a, delta=3e-6):
     return bad
 
 
-def check_single_steps(eng, ora, states, rng, steps=1, tol=None, skip_ambiguous=False, max_skip=0.2, report=None):
+def check_single_steps(eng, ora, states, rng, steps=1, tol=None, skip_ambiguous=False, max_skip=0.2, report=None, ora32=None):
     """From identical fp32 states, one step each; re-synchronised every step.  Every quantity is held to its own bound (`tol`:
     TOL by default, TOL_CONTACT for contact-rich states).  skip_ambiguous: envs whose contact set flips under a +-3 um nudge of the contact margin are excluded (a
     discontinuity, not an error); the excluded fraction is bounded by `max_skip` and reported, like the number of envs whose
-    done flag differs (a success threshold crossed by an fp32 rounding).  Returns the report dict (also filled into `report`)."""
+    done flag differs (a success threshold crossed by an fp32 rounding).  ora32: the oracle's own fp32 build; with skip_ambiguous,
+    envs in which that build already differs from the fp64 build by more than the bounds (a friction cone that saturates or not
+    depending on the last bit of the input) are excluded and counted the same way.  Returns the report dict (also filled into `report`)."""
     st = np.asarray(states, np.float64)
     n = st.shape[0]
     worst = {}
@@ -177,6 +179,13 @@ def check_single_steps(eng, ora, states, rng, steps=1, tol=None, skip_ambiguous=
         ok = np.ones(n, bool)
         if skip_ambiguous:
             ok = ~ambiguous_envs(ora, s32.astype(np.float64), a)
+            if ora32 is not None:
+                s_f, o_f = ora32.batch_step(s32, a)
+                tt = TOL if tol is None else tol
+                for e in range(n):
+                    qf = panda_quantities(s_f[e:e + 1], so[e:e + 1], o_f[e:e + 1, :-2], out[e:e + 1])
+                    if any(v > tt[k] for k, v in qf.items() if k in tt):
+                        ok[e] = False
             rep["skipped_ambiguous"] += int((~ok).sum())
             assert (~ok).mean() <= max_skip, "threshold-ambiguous states: %d of %d skipped (bound %.0f %%)" % ((~ok).sum(), n, 100 * max_skip)
         # reward/done: a success threshold can flip on an fp32 rounding; such envs are counted and their reward is not compared
@@ -928,7 +937,10 @@ def check_per_env_physics(Engine, lib, table, n=8, flags=0):
     assert np.array_equal(se[:, 44], mass) and np.array_equal(se[:, 45], mu) and np.array_equal(se[:, 47], damp + 1)
     st = se.astype(np.float64)
     st[:, 25:28] = [0.3, -0.2, 0.0]                        # sliding cubes: friction, mass and damping all matter
-    rep = check_single_steps(eng, ora, st, rng, steps=3)
+    # (a cube sliding on four saturated friction rows: its angular velocity carries the rounding of the contact impulses divided by
+    # the 3.5 cm lever -- the bound of the contact-rich states applies to the object's rotation)
+    tol = dict(TOL, obj_w=TOL_CONTACT["obj_w"], obj_quat=TOL_CONTACT["obj_quat"], obs_obj_eul=TOL_CONTACT["obs_obj_eul"], obs_rel_eul=TOL_CONTACT["obs_rel_eul"])
+    rep = check_single_steps(eng, ora, st, rng, steps=3, tol=tol)
     # the same states with the batch defaults give a different object motion
     base = st.copy(); base[:, [44, 45, 47]] = 0
     eng.set_state(base.astype(np.float32))
@@ -947,3 +959,41 @@ def check_per_env_physics(Engine, lib, table, n=8, flags=0):
     want = mass.copy(); want[[1, n - 1]] = 0.2
     assert np.array_equal(eng.get_state()[:, 44], want)
     return rep
+
+
+def check_other_objects(Engine, lib, table, names=("YcbGelatinBox", "domino/domino", "YcbCrackerBox"), n=6, flags=0):
+    """obj_name other than the cube (reference world_env.py:18-25, 179-216): box stand-ins with their own size, mass, principal
+    inertias and friction (model/objects.py).  The lane-per-env kernel steps such an object with ObjStep, complex envs go to the row
+    kernel; against the oracle with the same box: reset (the object drops, tips and settles), sliding / spinning objects, a pushed
+    object (robot-object contact)."""
+    from pybullet_robot_envs.model.objects import object_physics
+    out = {}
+    for name in names:
+        ph = object_physics(name)
+        eng, ora = make_pair(Engine, lib, table, n, flags=flags, phys=ph)
+        orc.set_object(ora, ph)
+        ora32 = orc.Oracle(table, f32=True, task=1)
+        ora32.task.obj_pose_rnd_std, ora32.task.tg_pose_rnd_std = ora.task.obj_pose_rnd_std, ora.task.tg_pose_rnd_std
+        orc.set_object(ora32, ph)
+        eng.reset()
+        st, _ = ora.batch_reset(n)
+        se = eng.get_state()
+        assert np.isfinite(se).all()
+        assert rel(se[:, :31], st[:, :31]).max() < 5e-4, (name, rel(se[:, :31], st[:, :31]).max())
+        assert np.abs(se[:, 11] - (0.625 + ph["obj_h"][2])).max() < 2e-3, (name, se[:, 11])       # rests on its largest... on its z face
+        rng = np.random.default_rng(5)
+        s = st.copy()
+        s[:, 25:28] = rng.uniform(-0.1, 0.1, (n, 3)) * [1, 1, 0]            # sliding
+        s[:, 30] = rng.uniform(-1, 1, n)                                    # spinning about z
+        # (a tall narrow box that slides starts to rock on an edge: vertices enter / leave the contact margin, where fp32 and fp64 may
+        # pick different contact sets -- such states are excluded like the other threshold-ambiguous ones, and counted)
+        tol = dict(TOL_CONTACT, obj_pos=2e-6, obs_obj_pos=2e-6, obj_v=5e-4)
+        out[name] = check_single_steps(eng, ora, s, rng, steps=3, tol=tol, skip_ambiguous=True, max_skip=0.5, ora32=ora32)["worst"]
+        # robot-object contact: the object placed against the fingers (complex env -> row kernel for a non-cube box)
+        ee = eng.observe()[:, :3].astype(np.float64)
+        s2 = st.copy()
+        s2[:, 9:12] = ee + [0.0, 0.0, -(ph["obj_h"][2] + 0.012)]
+        s2[:, 12:16] = [0, 0, 0, 1]
+        check_single_steps(eng, ora, s2, rng, steps=1, tol=TOL_CONTACT, skip_ambiguous=True, max_skip=0.5, ora32=ora32)
+        eng.close()
+    return out

@@ -114,8 +114,13 @@ def test_set_physics_matches_oracle(panda, emu_lib):
     assert ph.obj_mass == 0.25 and ph.obj_mu == 0.6 and ph.solver_iters == 150
     st[:, 25:28] = [0.3, -0.2, 0.0]            # sliding cube: friction and damping matter
     parity.check_single_steps(eng, ora, st, np.random.default_rng(5), steps=3)
-    with pytest.raises(RuntimeError, match="isotropic"):
-        eng.set_physics(obj_inertia=[1e-4, 2e-4, 1e-4])
+    eng.set_physics(obj_inertia=[1e-4, 2e-4, 1e-4])      # unequal principal inertias: stepped by ObjStep inside the lane-per-env kernel
+    for k, v in enumerate([1e-4, 2e-4, 1e-4]):
+        ora.params.obj_inertia[k] = v
+    st[:, 28:31] = [0.5, -0.3, 1.0]
+    tol = dict(parity.TOL, obj_w=parity.TOL_CONTACT["obj_w"], obj_quat=parity.TOL_CONTACT["obj_quat"], obs_obj_eul=1e-5, obs_rel_eul=1e-5)
+    parity.check_single_steps(eng, ora, st, np.random.default_rng(6), steps=3, tol=tol)
+    assert eng.kernel_info()[3] > 0                        # still the lane-per-env path
 
 
 @pytest.mark.parametrize("task", [0, 1])
@@ -157,4 +162,27 @@ def test_change_physics_params_env_class(emu_lib):
     s = env._engine.get_state()
     assert np.allclose(s[:, 44], [0.1, 0.2, 0.3]) and np.allclose(s[:, 45], 0.7) and np.allclose(s[:, 47], [1.0, 1.1, 1.2])
     assert env._engine.get_physics().lin_damping == 0.05
+    env.close()
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_other_objects(panda, emu_lib, flags):
+    """obj_name changes the dynamics: YCB / pybullet_data box stand-ins against the oracle (lane-per-env + ObjStep, general rows)"""
+    parity.check_other_objects(_capi.Engine, emu_lib, panda["table"], n=3, flags=flags)
+
+
+def test_world_env_object_names(emu_lib):
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    from pybullet_robot_envs.envs.world_envs.world_env import get_objects_list, get_ycb_objects_list, YcbWorldEnv
+    assert "YcbMustardBottle" in get_ycb_objects_list() and len(get_objects_list()) == 4
+    env = pandaPushGymEnv(_lib=emu_lib, obj_name="YcbSugarBox")
+    ph = env._engine.get_physics()
+    assert abs(ph.obj_mass - 0.514) < 1e-12 and list(ph.obj_h) == [0.019, 0.0445, 0.0875] and ph.obj_mu == 0.5
+    env.reset()
+    assert abs(env._engine.get_state()[0, 11] - (0.625 + 0.0875)) < 2e-3          # the sugar box stands on the table
+    assert env._world.get_object_shape_info()[3] == [0.038, 0.089, 0.175]
+    with pytest.raises(ValueError, match="unknown obj_name"):
+        pandaPushGymEnv(_lib=emu_lib, obj_name="no_such_object")
+    w = YcbWorldEnv(env._physics_client_id)
+    assert w._obj_name == "YcbMustardBottle" and w.object_physics()["obj_mass"] == 0.603
     env.close()

@@ -35,6 +35,10 @@ def make(arm, task, use_ik, ori, max_steps, reward_type):
     o, tbl, info = orc.icub_oracle(arm, task=task, use_ik=use_ik, control_orientation=ori)
     o.task.max_steps = max_steps
     o.task.reward_type = reward_type
+    # the object of the scene: the reach env's default is duck_vhacd, the push envs' cube_small (icub_reach_gym_env.py:32,
+    # icub_push_gym_env.py:32), both simulated as the box stand-ins of model/objects.py
+    from pybullet_robot_envs.model.objects import object_physics
+    orc.set_object(o, object_physics("duck_vhacd" if task == 0 else "cube_small"))
     return o, info
 
 
@@ -207,3 +211,23 @@ def test_icub_model_compiler():
     info = icub_info(sim, "r")
     assert [info["dof_names"][d] for d in info["controlled"]][3:] == ["r_shoulder_pitch", "r_shoulder_roll", "r_shoulder_yaw", "r_elbow",
                                                                       "r_wrist_prosup", "r_wrist_pitch", "r_wrist_yaw"]
+
+
+def test_quaternion_observation_option(emu_lib):
+    """control_eu_or_quat=1 on the robot / world classes (icub_env.py:219-224, world_env.py:118-124): orientation entries are the
+    quaternion of the same rotation, limits +-1, one more entry."""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env import iCubEnv
+    from pybullet_robot_envs.envs.world_envs.world_env import WorldEnv, euler_from_quat
+    env = iCubReachGymEnv(use_IK=1, _lib=emu_lib)
+    env.reset()
+    cid = env._physics_client_id
+    eu, lim_e = env._robot.get_observation()
+    rq = iCubEnv.__new__(iCubEnv); rq.__dict__.update(env._robot.__dict__); rq._control_eu_or_quat = 1
+    q, lim_q = rq.get_observation()
+    assert len(q) == len(eu) + 1 == rq.get_observation_dim() and lim_q[3:7] == [[-1, 1]] * 4 and rq.get_action_dim() == 3
+    assert np.abs(euler_from_quat(np.array(q[3:7])) - np.array(eu[3:6])).max() < 1e-9 and q[7:] == eu[6:]
+    w = WorldEnv(cid, control_eu_or_quat=1)
+    ow, lw = w.get_observation()
+    assert len(ow) == 7 == w.get_observation_dimension() and lw[3:] == [[-1, 1]] * 4 and abs(np.linalg.norm(ow[3:]) - 1) < 1e-6
+    env.close()

@@ -226,6 +226,18 @@ def test_env_classes_and_tensor_api(hip_lib):
     env.close(); ref.close()
 
 
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_other_objects(panda, hip_lib, flags):
+    """obj_name other than the cube (YCB / pybullet_data box stand-ins): k_fast + ObjStep and k_row_list, and the general row kernel"""
+    print(parity.check_other_objects(_capi.Engine, hip_lib, panda["table"], n=40, flags=flags))
+
+
+def test_devices_kwarg(hip_lib):
+    """Gym classes with devices=[...]: one pbre_ctx per listed device driven from one process (two shards on this box's one GPU)."""
+    import test_vec_env
+    test_vec_env.test_devices_kwarg_shards_the_batch_in_one_process(hip_lib)
+
+
 @pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
 def test_per_env_domain_randomisation(panda, hip_lib, flags):
     """per-env object mass / friction / damping against the oracle (k_fast, k_fast_rc / k_row_list, general row kernel)"""

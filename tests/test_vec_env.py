@@ -50,3 +50,24 @@ def test_vec_env_single_icub(emu_lib):
             seen = True
             assert int(v.env._env_step_counter) == 0           # finished in this step and already re-initialised on the "device"
     assert seen
+
+
+def test_devices_kwarg_shards_the_batch_in_one_process(emu_lib):
+    """`devices=[...]` on the Gym classes: one engine per listed device, env-id-keyed RNG -> the sharded env returns bit
+    for bit what a single-engine env returns (here two shards on the emulation's single "device")."""
+    from pybullet_robot_envs.envs import pandaPushGymEnv
+    kw = dict(_lib=emu_lib, num_envs=6, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, max_steps=3)
+    one, two = pandaPushGymEnv(**kw), pandaPushGymEnv(devices=[0, 0], **kw)
+    assert type(two._engine).__name__ == "MultiEngine" and len(two._engine.shards) == 2 and two._engine.shards[1].cfg.env_id_base == 3
+    assert np.array_equal(one.reset(), two.reset())
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        a = rng.uniform(-1, 1, (6, 7))
+        r1, r2 = one.step(a), two.step(a)
+        assert all(np.array_equal(x, y) for x, y in zip(r1[:3], r2[:3]))
+    assert np.array_equal(one._env_step_counter, two._env_step_counter)
+    m = np.array([0, 1, 0, 0, 1, 0], np.uint8)
+    assert np.array_equal(one.reset(mask=m), two.reset(mask=m))
+    two.change_physics_params([0.1, 0.2, 0.3, 0.1, 0.2, 0.3], 0.7, 0.1, 0.04)
+    assert np.allclose(two._engine.get_state_cols(44)[:, 0], [0.1, 0.2, 0.3, 0.1, 0.2, 0.3])
+    one.close(); two.close()

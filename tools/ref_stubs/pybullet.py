@@ -27,6 +27,7 @@ def _load(name, rel):
 _urdf = _load("pbre_model_urdf", "model/urdf.py")
 sys.modules.setdefault("pybullet_robot_envs_model_urdf_for_stub", _urdf)
 _table = _load("pbre_model_table", "model/table.py")
+_objects = _load("pbre_model_objects", "model/objects.py")
 
 
 def _load_sdf():
@@ -65,6 +66,7 @@ class _World(object):
         self.model = None
         self.set_layout(9)
         self.has_object = False
+        self.obj_phys = None
         self.steps = 0
         self.control_arm = "l"
 
@@ -137,9 +139,11 @@ def loadURDF(path, basePosition=(0, 0, 0), baseOrientation=(0, 0, 0, 1), useFixe
         assert tuple(basePosition) == (0.85, 0.0, 0.0)
         W.bodies[bid] = "table"
     else:
-        # duck_vhacd (iCub reach default, icub_reach_gym_env.py:32) is a pybullet_data mesh that is not available: the
-        # cube stands in for it (the reach task only consumes the object's settled pose)
-        assert name in ("cube_small.urdf", "duck_vhacd.urdf"), name
+        # the objects are pybullet_data / pybullet_object_models meshes that are not available: the engine's box stand-ins
+        # (model/objects.py) take their place here too, so that the captured trajectories are those of the same scene
+        import pybullet_data as _pd
+        rel = os.path.relpath(path, _pd.getDataPath()) if path.startswith(_pd.getDataPath()) else name      # e.g. "domino/domino.urdf"
+        W.obj_phys = _objects.object_physics(rel)
         W.bodies[bid] = "object"
         nd = W.nd
         W.state[nd:nd + 3] = basePosition
@@ -271,6 +275,11 @@ def stepSimulation(physicsClientId=0):
     if o is None:
         o = _icub_oracle([i for i, l in enumerate(W.model["links"]) if l["name"] == "l_hand"][0])
     o.params.flags = 0 if W.has_object else orc.F_NO_OBJECT
+    ph = getattr(W, "obj_phys", None)
+    if ph is not None:
+        for k in range(3):
+            o.params.obj_h[k] = ph["obj_h"][k]; o.params.obj_inertia[k] = ph["obj_inertia"][k]
+        o.params.obj_mass, o.params.obj_mu = ph["obj_mass"], ph["obj_mu"]
     W.state, _ = o.sim_step(W.state, W.q_des, W.kp, W.kd)
     W.steps += 1
 
