@@ -310,6 +310,14 @@ def main():
             self.n_local = n = self.sh.n_local
             assert self.sh.env_id_base == rank * n
             eng.reset()
+            # De-synchronise the episode clocks: after reset() every env has step counter 0, so all envs that do not succeed early
+            # would hit max_steps (1000) in the same step and the whole batch would restart together, for ever in phase.  A rollout
+            # worker that has been running for a while has episodes of every age: start the counters at U{0..max_steps-1} (keyed by
+            # the global env id, so the sharded batch is the same batch).
+            st = eng.get_state()
+            ages = np.random.default_rng(4321).integers(0, 1000, total_envs)[self.sh.env_id_base:self.sh.env_id_base + n]
+            st[:, eng.x_off + 3] = ages.astype(np.float32)
+            eng.set_state(st)
             # actions U(-1,1), i.i.d. per (step, env).  Timed steps read slices of a pool generated up front and
             # resident in HBM; the untimed pre-roll draws a fresh slice per step (a short recycled pool would add a constant
             # bias to every env's random walk and drive the joints into their limits within a few hundred steps)
@@ -388,11 +396,11 @@ def main():
     job = Job(total, 2 * (args.steps + args.warmup))
     eng, n_local = job.eng, job.n_local
 
-    # (side key) right after reset(): no complex env yet, nothing finishes inside the timed region
+    # (side key) right after reset(): no complex env yet (only the step counters differ between envs)
     fresh = None
     if not args.no_fresh:
         fresh = job.timed(args.steps, args.warmup)
-        fresh.update({"start_state": "fresh reset() of every env (reference reset_simulation)", "complex_env_frac_rank0": job.complex_frac()})
+        fresh.update({"start_state": "fresh reset() of every env (reference reset_simulation: robots at the home pose, no complex env); step counters de-synchronised", "complex_env_frac_rank0": job.complex_frac()})
 
     # headline: steady state after the pre-roll
     job.preroll(args.preroll - args.warmup)
@@ -483,7 +491,9 @@ def main():
                                      if world > 1 else "none",
                        "rccl": rccl,
                        "outputs_finite": finite,
-                       "start_state": "steady state: %d untimed steps since reset() before the timed region (pre-roll + warm-up)" % steps_before,
+                       "start_state": "steady state: %d untimed steps since reset() before the timed region (pre-roll + warm-up); episode "
+                                      "clocks de-synchronised (initial step counters U{0..999}), so episodes of every age coexist and "
+                                      "envs finish and restart in every step" % steps_before,
                        "complex_env_frac_rank0": complex_after, "complex_envs_per_step_timed_region_rank0": complex_per_step,
                        "done_frac_last_step_rank0": done_frac,
                        "mean_episodes_completed_per_env_rank0": episodes},

@@ -145,6 +145,13 @@ int pbre_state_floats(const pbre_ctx* ctx);
  * obs_out: NULL or host [num_envs][obs_dim] raw (unscaled) observation, float32. */
 int pbre_reset(pbre_ctx* ctx, const uint8_t* env_mask, float* obs_out);
 
+/* Fast reset of the envs selected by env_mask (num_envs bytes) from the settled snapshot of the last full pbre_reset: what
+ * PBRE_F_AUTO_RESET does inside the step, as an entry point -- one small kernel instead of the 201 settle launches of a masked
+ * pbre_reset.  The settled state of reset_simulation is invariant under the sampled object x, y, yaw (flat table, vertical drop), so
+ * the new episode starts from the recorded settled robot pose / object height with freshly sampled object pose and target: within
+ * 2e-5 (Panda) / 5e-5 (iCub) of the explicit reset of the same episode.  Needs one full pbre_reset before.  Task envs only. */
+int pbre_reset_snapshot(pbre_ctx* ctx, const uint8_t* env_mask, float* obs_out);
+
 /* replaces: pandaPushGymEnv.step (panda_push_gym_env.py:244-255) = apply_action (:189-242: action*0.05,
  * clip to joint limits panda_env.py:303, 7 x setJointMotorControl2 :305-310, p.stepSimulation :236,
  * _termination :239, counter :242) + get_extended_observation (:150-187) + _termination (:301-316) +

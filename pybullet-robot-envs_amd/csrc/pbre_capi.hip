@@ -25,6 +25,7 @@
 #define PBRE_ANY(x) (__any((int)(x)) != 0)
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
+#define PBRE_PARK_STRIDE 64          // Fast::step parks the solver start values in wave-private LDS laid out [k][lane]
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -40,6 +41,9 @@ constexpr int TPB = EPB * W;         // 256 threads
 constexpr int FTPB = 64;             // lane-per-env kernels: one wave per block
 #ifndef PBRE_FAST_WAVES
 #define PBRE_FAST_WAVES 2            // waves per SIMD k_fast is register-limited to (A/B on MI355X: 1 -> 404, 2 -> 495, 3 -> 325 M env-steps/s)
+#endif
+#ifndef PBRE_RC_PRIO
+#define PBRE_RC_PRIO 3               // wave priority (s_setprio) of the complex-env kernels, 0: leave it (A/B)
 #endif
 constexpr int MODE_STEP = CoreD::M_ACTION | CoreD::M_OBS | CoreD::M_TASK;
 constexpr int MODE_STEP_IK = CoreD::M_TGT | CoreD::M_OBS | CoreD::M_TASK;      // use_IK = 1: targets from k_ik
@@ -77,18 +81,24 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
     if (c) next_list[(size_t)(c - 1) * cap + atomicAdd(next_count + (c - 1), 1)] = env;
 }
 
-// Simple envs: every env of the batch in natural order (coalesced), lanes of complex envs idle.
+// Simple envs: every env of the batch in natural order, lanes of complex envs idle.  Block = one wave.
+// LDS (wave-private, no barriers): the solver start values of the clamp-free rows' fall-back (Fast::step `park`, [k][lane]).
+// (Staging the wave's 64 output rows through LDS and streaming them out as one contiguous block with coalesced 256-byte stores was
+// measured too -- profiles/r02_pmc_hbm.json: WRITE_SIZE 62.1 MB against 63.3 MB with each lane writing its own 140-byte row, and the
+// same step time -- the L2 already merges the lanes' 4-byte stores into full lines; what WRITE_SIZE carries beyond the records and
+// rows is the register spill traffic.  The direct per-lane row writes stayed.)
 template <int MODE>
 __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                                int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
+    __shared__ float lds_park[FastD::PARK * FTPB];
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                               (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, lds_park + threadIdx.x);
     publish_class(env, c, cls, next_list, next_count, cap);
 }
 
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
                                                   const float* __restrict__ tgt, int* __restrict__ host_total, int* __restrict__ recent) {
+    if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);      // see k_row_list
     int chunks[NB], total = 0, envs = 0;
     PBRE_UNROLL for (int b = 0; b < NB; b++) { chunks[b] = (cur_count[b] + FTPB - 1) / FTPB; total += chunks[b]; envs += cur_count[b]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(envs, recent, host_total);
@@ -141,6 +152,9 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
                                                   const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
     static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
+    // These few waves are the tail of the step: each shares its SIMD with a k_fast wave, and a row wave is latency-bound (it leaves
+    // most issue slots to its neighbour anyway), so it gets the higher wave priority and runs at its lone-wave speed.
+    if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);
     const int total = cur_count[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
     const int row = threadIdx.x >> 4;
@@ -210,6 +224,11 @@ __global__ void k_target(const Params P, float* __restrict__ state, const unsign
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) CoreD::sample_target(P, ids[i], ep[i], state + (size_t)i * STATE);
 }
+// pbre_reset_snapshot: the selected envs start their next episode from the settled snapshot (what PBRE_F_AUTO_RESET does in-kernel)
+__global__ void k_snapshot_reset(const Tables* __restrict__ T, const Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && mask[e]) CoreD::snapshot_reset(*T, P, P.env_id_base + (unsigned long long)e, state + (size_t)e * STATE);
+}
 // episode number of the next reset of env idx[i]: one more than the episode stored in its record (-1 = never reset)
 // (also hands the env's per-env object parameters X[12], X[13], X[15] -- which a reset keeps -- to the record it is re-initialised in)
 __global__ void k_next_episode(const float* __restrict__ state, const int* __restrict__ idx, int cnt, int cpad, unsigned* __restrict__ ep,
@@ -266,6 +285,8 @@ struct pbre_ctx {
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
+    bool have_snapshot = false;        // a full pbre_reset has recorded the settled snapshot (rst_q, rst_objz)
+    unsigned char* d_mask = nullptr;
     bool ext_dirty = false;            // a pbre_step_device was enqueued on a caller-supplied stream since the last quiesce()
     std::string err;
 };
@@ -438,7 +459,7 @@ void pbre_destroy(pbre_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     free_buf(c->main); free_buf(c->tmp);
-    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx})
+    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -615,9 +636,26 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             for (int k = 0; k < NJ; k++) { c->P.rst_q[k] = rec[k]; c->T.rst_q[k] = rec[k]; }
             c->P.rst_objz = rec[11];
             HIPCHK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
+            c->have_snapshot = true;
         }
     }
     c->k_steps = 0; c->launches = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
+    if (obs) return pbre_observe(c, obs);
+    return PBRE_OK;
+}
+
+int pbre_reset_snapshot(pbre_ctx* c, const uint8_t* mask, float* obs) {
+    if (!c || !mask) return PBRE_E_ARG;
+    if (c->wide) return wide_reset_snapshot(c->wide, mask, obs);
+    if (!c->have_snapshot) { c->err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
+    if (!c->d_mask) HIPCHK(hipMalloc(&c->d_mask, (size_t)c->npad));
+    HIPCHK(hipMemcpyAsync(c->d_mask, mask, (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_snapshot_reset, dim3((c->n + 127) / 128), dim3(128), 0, c->stream, c->dT, c->P, c->main.state, c->d_mask, c->n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }

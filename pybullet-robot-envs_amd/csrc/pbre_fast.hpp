@@ -245,10 +245,16 @@ struct Fast {
     //   1  complex: robot contacts and/or active joint-limit rows -> step_t<true> (adds dense 9-DoF contact rows and the
     //               limit rows; needs the whole register file, launched only over the list of complex envs)
     // Both variants return the class of the state they produced.
+    // park: PARK floats of scratch per env with stride PBRE_PARK_STRIDE (the device passes wave-private LDS laid out [k][lane], the
+    // host build a local array): the solver's start values while the clamp-free motor rows are tried (see step_t)
+    static constexpr int PARK = ND + 6;
+#ifndef PBRE_PARK_STRIDE
+#define PBRE_PARK_STRIDE 1
+#endif
     static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                            unsigned long long env_id = 0, const float* tgt = nullptr) {
+                            unsigned long long env_id, const float* tgt, float* park) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt);
+        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt, park);
     }
     // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (`if self._termination():
     // break`, panda_push_gym_env.py:239-240; flag X[14]): no simulation step, only the evaluation of the state it is in
@@ -262,11 +268,11 @@ struct Fast {
     static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                                unsigned long long env_id = 0, const float* tgt = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
+        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr);
     }
     template <bool RC>
     static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                              unsigned long long env_id, const float* tgt) {
+                              unsigned long long env_id, const float* tgt, float* park) {
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
@@ -686,12 +692,12 @@ struct Fast {
             // No motor comes near PyBullet's default force bound (1e5 N dt = 417 against impulses of a few units), and
             // sum |delta_j| over the solve bounds every value the applied impulse of motor j ever had, so one test after the loop
             // decides; a wave in which it fails starts over with the clamping rows from the solver's initial values, which were
-            // parked in the velocity slots of the env's state record (the old velocities are dead by now; the integration below
-            // overwrites the slots with the new ones).
+            // parked in `park` (wave-private LDS on the device: no HBM traffic).
             bool solved = false;
             {
-                PBRE_UNROLL for (int j = 0; j < ND; j++) st[16 + j] = wget(w, j);
-                st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) park[j * PBRE_PARK_STRIDE] = wget(w, j);
+                park[(ND + 0) * PBRE_PARK_STRIDE] = ov.x; park[(ND + 1) * PBRE_PARK_STRIDE] = ov.y; park[(ND + 2) * PBRE_PARK_STRIDE] = ov.z;
+                park[(ND + 3) * PBRE_PARK_STRIDE] = ow.x; park[(ND + 4) * PBRE_PARK_STRIDE] = ow.y; park[(ND + 5) * PBRE_PARK_STRIDE] = ow.z;
                 auto motor_free = [&](int j) {       // (m_app[j] accumulates |delta| here; the clamping rows start from 0 again)
                     const float d = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
                     m_app[j] += fabsf(d);
@@ -706,8 +712,9 @@ struct Fast {
                 PBRE_UNROLL for (int j = 0; j < ND; j++) over = over || !(m_app[j] <= mlim);      // (a NaN fails the test as well)
                 solved = !PBRE_ANY(over);
                 if (!solved) {
-                    PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, st[16 + j]);
-                    ov = v3(st[25], st[26], st[27]); ow = v3(st[28], st[29], st[30]);
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, park[j * PBRE_PARK_STRIDE]);
+                    ov = v3(park[(ND + 0) * PBRE_PARK_STRIDE], park[(ND + 1) * PBRE_PARK_STRIDE], park[(ND + 2) * PBRE_PARK_STRIDE]);
+                    ow = v3(park[(ND + 3) * PBRE_PARK_STRIDE], park[(ND + 4) * PBRE_PARK_STRIDE], park[(ND + 5) * PBRE_PARK_STRIDE]);
                     PBRE_UNROLL for (int c = 0; c < NK; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
                     PBRE_UNROLL for (int j = 0; j < ND; j++) m_app[j] = 0.f;
                 }

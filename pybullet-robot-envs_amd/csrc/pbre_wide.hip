@@ -234,8 +234,22 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
             WCHK(hipMemcpy(rec.data(), w->state, (size_t)w->sf * sizeof(float), hipMemcpyDeviceToHost));
             w->snapshot(rec.data());
             WCHK(w->upload_tables());
+            w->have_snapshot = true;
         }
     }
+    if (obs) return wide_observe(w, obs);
+    return PBRE_OK;
+}
+int wide_reset_snapshot(WideEngine* w, const uint8_t* mask, float* obs) {
+    if (w->mrec) { w->err = "pbre_reset_snapshot: task envs only (the robot-level interfaces have no episodes)"; return PBRE_E_UNSUPPORTED; }
+    if (!w->have_snapshot) { w->err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+    WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
+    if (!w->d_mask) WCHK(hipMalloc(&w->d_mask, (size_t)w->n));
+    WCHK(hipMemcpyAsync(w->d_mask, mask, (size_t)w->n, hipMemcpyHostToDevice, w->stream));
+    w->launch_snapshot_reset(w->d_mask, w->stream);
+    WCHK(hipGetLastError());
+    WCHK(hipStreamSynchronize(w->stream));
     if (obs) return wide_observe(w, obs);
     return PBRE_OK;
 }

@@ -14,6 +14,7 @@ void wide_destroy(WideEngine* w);
 const char* wide_error(const WideEngine* w);
 void wide_dims(const WideEngine* w, int32_t* obs_dim, int32_t* act_dim, int32_t* num_envs, int32_t* state_floats);
 int  wide_reset(WideEngine* w, const uint8_t* mask, float* obs);
+int  wide_reset_snapshot(WideEngine* w, const uint8_t* mask, float* obs);
 int  wide_step(WideEngine* w, const float* actions, float* out);
 int  wide_step_device(WideEngine* w, const float* d_actions, float* d_out, void* stream);
 int  wide_sync(WideEngine* w);

@@ -112,6 +112,18 @@ __global__ void kw_set_motors(float* __restrict__ tgt, int n, const MotorCmd cmd
     float* m = tgt + (size_t)e * S::TGT;
     m[cmd.dof[k]] = cmd.target[k]; m[S::W + cmd.dof[k]] = cmd.kp; m[2 * S::W + cmd.dof[k]] = cmd.fscale; m[3 * S::W + cmd.dof[k]] = cmd.vmax;
 }
+// pbre_reset_snapshot (see pbre_capi.hip k_snapshot_reset); iCub push: the initial distances X[12], X[13] of the re-initialised envs are
+// taken from `initd`, a copy of the batch on which the M_INITD observation was run
+template <class S, class L>
+__global__ void kw_snapshot_reset(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state, const unsigned char* __restrict__ mask, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && mask[e]) Core<L, S>::snapshot_reset(*T, P, P.env_id_base + (unsigned long long)e, state + (size_t)e * S::STATE);
+}
+template <class S>
+__global__ void kw_take_initd(float* __restrict__ state, const float* __restrict__ initd, const unsigned char* __restrict__ mask, int n) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && mask[e]) { const size_t o = (size_t)e * S::STATE + 2 * S::W; state[o + 12] = initd[o + 12]; state[o + 13] = initd[o + 13]; }
+}
 template <class S, class L>
 __global__ void kw_target(const Params P, float* __restrict__ state, const unsigned long long* __restrict__ ids,
                           const unsigned* __restrict__ ep, int cnt) {
@@ -147,6 +159,8 @@ struct WideEngine {
     virtual void launch_ik(bool reset, float* st, const float* act, float* tg, int cnt, hipStream_t s, bool step_follows = false) = 0;   // step_follows: the next launch on s is launch_step on st
     virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
     virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
+    virtual void launch_snapshot_reset(const unsigned char* mask, hipStream_t s) = 0;
+    bool have_snapshot = false;
     virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
     virtual void launch_mrec_init(float* tg, int cnt, hipStream_t s) = 0;
     virtual void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) = 0;
@@ -207,6 +221,14 @@ struct WideImpl : WideEngine {
     void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) override {
         if (initd) hipLaunchKernelGGL((kw_observe<S, L, C::M_INITD>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
         else hipLaunchKernelGGL((kw_observe<S, L, C::M_OBS>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, out, cnt, ow);
+    }
+    void launch_snapshot_reset(const unsigned char* mask, hipStream_t s) override {
+        hipLaunchKernelGGL((kw_snapshot_reset<S, L>), dim3((n + 127) / 128), dim3(128), 0, s, dT, P, state, mask, n);
+        if (P.robot >= 1 && P.task >= 1) {          // icub_push_gym_env.py:124-127: distances of the new episode's first state
+            (void)hipMemcpyAsync(tmp, state, (size_t)n * S::STATE * sizeof(float), hipMemcpyDeviceToDevice, s);
+            launch_observe(true, tmp, nullptr, n, s);
+            hipLaunchKernelGGL((kw_take_initd<S>), dim3((n + 127) / 128), dim3(128), 0, s, state, tmp, mask, n);
+        }
     }
     void launch_init(float* st, int cnt, hipStream_t s) override {
         hipLaunchKernelGGL((kw_init<S, L>), dim3((cnt + 127) / 128), dim3(128), 0, s, dT, P, st, d_ids, d_ep, cnt);

@@ -74,7 +74,7 @@ def load(path=None):
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
-                 "pbre_get_state_cols", "pbre_set_physics_per_env"):
+                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_host_alloc.restype = C.c_void_p
     lib.pbre_host_alloc.argtypes = [C.c_size_t]
@@ -199,6 +199,14 @@ class Engine:
             m = np.ascontiguousarray(mask, dtype=np.uint8)
             assert m.shape == (self.num_envs,)
         self._chk(self.lib.pbre_reset(self._ctx, _fp(m) if m is not None else None, _fp(obs)))
+        return obs
+
+    def reset_snapshot(self, mask):
+        """Fast reset of the masked envs from the settled snapshot of the last full reset (pbre_reset_snapshot): one kernel."""
+        obs = np.zeros((self.num_envs, self.obs_dim), np.float32)
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert m.shape == (self.num_envs,)
+        self._chk(self.lib.pbre_reset_snapshot(self._ctx, _fp(m), _fp(obs)))
         return obs
 
     def step(self, actions, copy=True):
@@ -375,6 +383,10 @@ class MultiEngine(object):
             raise ValueError("actions must have shape (%d, %d), got %r" % (self.num_envs, self.act_dim, a.shape))
         r = self._map(lambda k: self.shards[k].step(a[self._sl(k)], copy=False))
         return tuple(self._cat([x[i] for x in r]) for i in range(3))
+
+    def reset_snapshot(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        return self._cat(self._map(lambda k: self.shards[k].reset_snapshot(m[self._sl(k)])))
 
     def step_device(self, *a, **kw):
         raise RuntimeError("step_device is per device: use MultiEngine.shards[k].step_device with buffers on that shard's GPU")

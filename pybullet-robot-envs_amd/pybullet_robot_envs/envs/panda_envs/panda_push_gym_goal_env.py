@@ -52,7 +52,9 @@ class pandaPushGymGoalEnv(GoalEnv, pandaPushGymEnv):
             d = dict((k, v[0]) for k, v in d.items())
         return d
 
-    def reset(self, mask=None):
+    def reset(self, mask=None, snapshot=False):
+        if snapshot and mask is not None:
+            return self._goal_dict(self._engine.reset_snapshot(mask))
         return self._goal_dict(self._engine.reset(mask))
 
     def step(self, action):

@@ -4,9 +4,12 @@ The reference's training scripts wrap ONE env in `DummyVecEnv([lambda: env])` or
 (reference examples/algos/train/baselines/panda_envs/train_ddpg_reaching.py:96, train_TD3_pushing_HER.py:15).  With the
 batched engine the N envs already live in one object, so this adapter only reshapes its API to what those libraries
 call: `num_envs, observation_space, action_space, reset(), step_async(actions), step_wait(), step(actions), close(),
-seed(), get_attr/set_attr/env_method`.  Like `DummyVecEnv`, a finished env is reset inside the step that finished it and the
-returned observation is the first one of the next episode: construct the task env with `auto_reset=True` (Panda; snapshot
-reset inside the kernel) or let the adapter issue masked resets (any env)."""
+seed(), get_attr/set_attr/env_method`.  Like `DummyVecEnv`, a finished env is reset inside the step that finished it, the returned
+observation is the first one of the next episode and `infos[i]["terminal_observation"]` keeps the last one of the finished episode
+(what SB-style libraries bootstrap from on a time-limit truncation): the adapter restarts the finished envs with a masked
+SNAPSHOT reset (`env.reset(mask, snapshot=True)` -> pbre_reset_snapshot: one small kernel, not the 201 settle launches of the
+explicit reset).  A task env constructed with `auto_reset=True` restarts finished envs inside the step kernel itself (fastest;
+for device-resident rollouts through `step_tensor`); the terminal observation is then not available, and the infos say so."""
 import numpy as np
 
 
@@ -45,13 +48,16 @@ class BatchedVecEnv(object):
             succ = np.atleast_1d(np.asarray(info["is_success"]))
             for i in range(self.num_envs):
                 infos[i]["is_success"] = bool(succ[i])
+        if done.any() and self._device_reset:
+            for i in np.nonzero(done)[0]:
+                infos[i]["terminal_observation"] = None       # in-kernel auto-reset: the row already holds the next episode's first observation
         if done.any() and not self._device_reset:
             # DummyVecEnv semantics without the in-kernel snapshot reset: keep the terminal observation in the info
             # dict, reset the finished envs (a masked pbre_reset) and return their first observation
             idx = np.nonzero(done)[0]
             for i in idx:
                 infos[i]["terminal_observation"] = dict((k, v[i].copy()) for k, v in obs.items()) if self._goal else obs[i].copy()
-            fresh = self.env.reset(mask=done.astype(np.uint8))
+            fresh = self.env.reset(mask=done.astype(np.uint8), snapshot=True)
             if self._goal:
                 for k in obs:
                     obs[k][idx] = self._batch(np.asarray(fresh[k]))[idx]

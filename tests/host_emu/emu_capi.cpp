@@ -29,6 +29,8 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     bool obj_split = !(getenv("PBRE_OBJ_SPLIT") && getenv("PBRE_OBJ_SPLIT")[0] == '0');
     virtual ~pbre_ctx() {}
     virtual void reset(const uint8_t* mask) = 0;
+    virtual int reset_snapshot(const uint8_t* mask) = 0;
+    bool have_snapshot = false;
     virtual void step(const float* actions, float* out) = 0;
     virtual void observe(float* obs) = 0;
     virtual void settle_all(int n, int flags) = 0;
@@ -51,7 +53,7 @@ struct Emu : pbre_ctx {
         if constexpr (PANDA) {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
-                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
+                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; float park[FastH::PARK]; FastH::step(T, P, st, act, out, mode, flags, env_id, tg, park); }
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
@@ -113,7 +115,21 @@ struct Emu : pbre_ctx {
                 CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
             }
         }
-        if (!mask) { for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; }
+        if (!mask) { for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; have_snapshot = true; }
+    }
+    int reset_snapshot(const uint8_t* mask) override {
+        if (S::MREC) { err = "pbre_reset_snapshot: task envs only"; return PBRE_E_UNSUPPORTED; }
+        if (!have_snapshot) { err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+        for (int e = 0; e < n; e++) {
+            if (!mask[e]) continue;
+            float* st = &state[(size_t)e * STATE];
+            CoreH::snapshot_reset(T, P, P.env_id_base + (unsigned long long)e, st);
+            if (P.robot != PBRE_ROBOT_PANDA && P.task >= 1) {
+                auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
+                CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
+            }
+        }
+        return PBRE_OK;
     }
     void step(const float* actions, float* out) override {
         const int ow = obs_dim + 2;
@@ -223,6 +239,13 @@ int pbre_state_floats(const pbre_ctx* c) { return c ? c->sf : PBRE_E_ARG; }
 int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
     if (!c) return PBRE_E_ARG;
     c->reset(mask);
+    if (obs) c->observe(obs);
+    return PBRE_OK;
+}
+int pbre_reset_snapshot(pbre_ctx* c, const uint8_t* mask, float* obs) {
+    if (!c || !mask) return PBRE_E_ARG;
+    const int rc = c->reset_snapshot(mask);
+    if (rc != PBRE_OK) return rc;
     if (obs) c->observe(obs);
     return PBRE_OK;
 }

@@ -75,3 +75,11 @@ def test_icub_neighbour_independence(emu_lib):
 def test_icub_full_episode_rollout(emu_lib):
     """2000 free-running steps (a whole iCub episode, joint control) against the oracle with stated drift bounds"""
     parity.check_icub_full_episode(_capi.Engine, emu_lib, n=2, steps=2000)
+
+
+def test_icub_reset_snapshot(emu_lib):
+    """pbre_reset_snapshot on the lane-group engine (iCub push: incl. the initial distances of the normalised reward)"""
+    from pybullet_robot_envs.model.table import icub_table
+    tbl, model, info = icub_table("l")
+    ov = parity.icub_overrides(info, "l", 1, 0, 1)
+    parity.check_reset_snapshot(_capi.Engine, emu_lib, tbl, n=4, robot=_capi.ROBOT_ICUB, **ov)

@@ -186,3 +186,8 @@ def test_world_env_object_names(emu_lib):
     w = YcbWorldEnv(env._physics_client_id)
     assert w._obj_name == "YcbMustardBottle" and w.object_physics()["obj_mass"] == 0.603
     env.close()
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_reset_snapshot(panda, emu_lib, flags):
+    parity.check_reset_snapshot(_capi.Engine, emu_lib, panda["table"], n=5, flags=flags)

@@ -91,3 +91,8 @@ def test_icub_full_model_one_env_per_wave(hip_lib):
 
 def test_icub_wave_neighbour_independence(hip_lib):
     parity.check_wave_neighbour_independence(_capi.Engine, hip_lib)
+
+
+def test_icub_reset_snapshot(hip_lib):
+    import test_emu_icub
+    test_emu_icub.test_icub_reset_snapshot(hip_lib)

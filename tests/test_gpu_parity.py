@@ -232,6 +232,11 @@ def test_other_objects(panda, hip_lib, flags):
     print(parity.check_other_objects(_capi.Engine, hip_lib, panda["table"], n=40, flags=flags))
 
 
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_reset_snapshot(panda, hip_lib, flags):
+    parity.check_reset_snapshot(_capi.Engine, hip_lib, panda["table"], n=70, flags=flags)
+
+
 def test_devices_kwarg(hip_lib):
     """Gym classes with devices=[...]: one pbre_ctx per listed device driven from one process (two shards on this box's one GPU)."""
     import test_vec_env

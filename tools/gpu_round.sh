@@ -13,7 +13,7 @@ echo "== bench"
 timeout 900 python bench.py "$@" 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
 echo "== rocprof"
 ROOTDIR=$(pwd)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --steady-preroll 0 > $ROOTDIR/gpurun_out/rocprof_$TAG.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-other-configs --no-host-path --preroll 200 > $ROOTDIR/gpurun_out/rocprof_$TAG.log 2>&1)
 tail -3 gpurun_out/rocprof_$TAG.log
 find gpurun_out/prof_$TAG -name "*.csv" | head
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"

@@ -4,7 +4,7 @@
 TAG=$1; shift
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $ROOTDIR/gpurun_out/pmc_${TAG}_$C -o run -- python $ROOTDIR/bench.py --no-cpu-baseline --steady-preroll 0 "$@" > $ROOTDIR/gpurun_out/pmc_${TAG}_$C.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $ROOTDIR/gpurun_out/pmc_${TAG}_$C -o run -- python $ROOTDIR/bench.py --no-cpu-baseline --no-other-configs --no-host-path --preroll 200 "$@" > $ROOTDIR/gpurun_out/pmc_${TAG}_$C.log 2>&1)
   f=$(find gpurun_out/pmc_${TAG}_$C -name "*counter_collection.csv" | head -1)
   echo "== $C: $f"
   [ -n "$f" ] && python - "$f" $C <<'PY'

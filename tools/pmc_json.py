@@ -39,5 +39,5 @@ out = {
          "hbm_bytes_per_env_step": (fetch + write) / n_envs, "algorithmic_bytes_per_env_step": 444,
          "note": "552 B/env of padded record + output accesses, 60 B of solver start values parked in the record, and the register spills around the solver loop"},
 }
-json.dump(out, open("profiles/%s_pmc_hbm.json" % tag, "w"), indent=1)
+json.dump(out, open("gpurun_out/%s_pmc_hbm.json" % tag, "w"), indent=1)
 print(json.dumps(out[kf], indent=1))

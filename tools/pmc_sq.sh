@@ -3,7 +3,7 @@
 TAG=$1; shift
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 C="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"
-(cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $ROOTDIR/gpurun_out/pmcsq_$TAG -o run -- python $ROOTDIR/bench.py --no-cpu-baseline --steady-preroll 0 "$@" > $ROOTDIR/gpurun_out/pmcsq_$TAG.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d $ROOTDIR/gpurun_out/pmcsq_$TAG -o run -- python $ROOTDIR/bench.py --no-cpu-baseline --no-other-configs --no-host-path --preroll 200 "$@" > $ROOTDIR/gpurun_out/pmcsq_$TAG.log 2>&1)
 f=$(find gpurun_out/pmcsq_$TAG -name "*counter_collection.csv" | head -1)
 echo "== $f"
 [ -n "$f" ] && python - "$f" <<'PY'
