@@ -315,7 +315,7 @@ def main():
             # worker that has been running for a while has episodes of every age: start the counters at U{0..max_steps-1} (keyed by
             # the global env id, so the sharded batch is the same batch).
             st = eng.get_state()
-            ages = np.random.default_rng(4321).integers(0, 1000, total_envs)[self.sh.env_id_base:self.sh.env_id_base + n]
+            ages = np.random.default_rng(4321).integers(0, 1 if os.environ.get("PBRE_BENCH_NO_DESYNC") == "1" else 1000, total_envs)[self.sh.env_id_base:self.sh.env_id_base + n]
             st[:, eng.x_off + 3] = ages.astype(np.float32)
             eng.set_state(st)
             # actions U(-1,1), i.i.d. per (step, env).  Timed steps read slices of a pool generated up front and

@@ -81,6 +81,27 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
     if (c) next_list[(size_t)(c - 1) * cap + atomicAdd(next_count + (c - 1), 1)] = env;
 }
 
+// Simple envs: every env of the batch in natural order, lanes of complex envs idle.  Block = one wave.
+// LDS (wave-private, no barriers): the solver start values of the clamp-free rows' fall-back (Fast::step `park`, [k][lane]).
+// (Staging the wave's 64 output rows through LDS and streaming them out as one contiguous block with coalesced 256-byte stores was
+// measured too -- profiles/r02_pmc_hbm.json: WRITE_SIZE 62.1 MB against 63.3 MB with each lane writing its own 140-byte row, and the
+// same step time -- the L2 already merges the lanes' 4-byte stores into full lines; what WRITE_SIZE carries beyond the records and
+// rows is the register spill traffic.  The direct per-lane row writes stayed.)
+template <int MODE>
+__global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
+    __shared__ float lds_park[FastD::PARK * FTPB];
+    const int env = blockIdx.x * FTPB + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
+    if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
+    const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, lds_park + threadIdx.x);
+    publish_class(env, c, cls, next_list, next_count, cap);
+}
+
 // Complex envs (robot contacts and/or limit rows), compacted per class.  Persistent blocks (the host does not know the
 // list lengths): work item w = (bucket, 64-env chunk); block b takes items b, b + gridDim.x, ...  The grid is one block
 // per SIMD (the kernel needs a whole SIMD's register file), blocks without work exit at once.
@@ -124,21 +145,21 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
 // state is the lane-per-env kernels' Fast::finish run by lane 0 of the row, so both complex-env kernels are interchangeable.
 // A row spreads an env over 16 lanes, so a wave's latency is ~1/3 of a k_fast_rc wave's: with few complex envs the step is
 // no longer gated by that latency.  Grid-stride over the list (the host only has a hint of its length).
-// body shared by k_row_list (256-thread blocks) and the leading blocks of k_fast (64-thread blocks): EPBX rows per block
-template <int MODE, int EPBX>
-static __device__ __forceinline__ void row_list_body(int blk, int nblk, const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
-                                                     const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
-                                                     const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                     signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                     const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
+template <int MODE>
+__global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
+                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
     static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
-    // These few waves are the tail of the step: each shares its SIMD with a k_fast wave (PBRE_RC_PRIO: measured neutral).
+    // These few waves are the tail of the step: each shares its SIMD with a k_fast wave, and a row wave is latency-bound (it leaves
+    // most issue slots to its neighbour anyway), so it gets the higher wave priority and runs at its lone-wave speed.
     if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);
     const int total = cur_count[0];
-    if (blk == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
+    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
     const int row = threadIdx.x >> 4;
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
-    for (int base = blk * EPBX; base < total; base += nblk * EPBX) {
+    for (int base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {
         const int i = base + row;
         const bool real = i < total;
         const int env = real ? cur_list[i] : dummy_base + row;           // idle rows step a dummy record in lockstep
@@ -156,52 +177,6 @@ static __device__ __forceinline__ void row_list_body(int blk, int nblk, const Ta
             publish_class(env, c, cls, next_list, next_count, cap);
         }
     }
-}
-template <int MODE>
-__global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
-                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
-    row_list_body<MODE, EPB>(blockIdx.x, gridDim.x, T, P, state, actions, out, act_dim, ow, flags, cur_list, cur_count, cls, next_list, next_count, cap,
-                             tgt, host_total, dummy_base, recent);
-}
-
-// The step kernel of the lane-per-env path.  Block = one wave.
-//  * blocks [rb, rb + ceil(n / 64)): simple envs -- every env of the batch in natural order, lanes of complex envs idle.
-//    LDS (wave-private, no barriers): the solver start values of the clamp-free rows' fall-back (Fast::step `park`, [k][lane]).
-//  * blocks [0, rb): the few complex envs of the step by the 16-lane row formulation (row_list_body, 4 envs per wave), in the SAME
-//    launch: the leading blocks dispatch first, so these waves -- the tail of the step -- claim their SIMDs before the simple-env
-//    waves flood the chip, with one launch and no fork / join events through a second stream (which cost ~0.02 ms of a 0.26 ms
-//    steady-state step).  rb = 0 when the complex envs are many and go to k_fast_rc on the side stream instead.
-// (Staging the wave's 64 output rows through LDS and streaming them out as one contiguous block with coalesced 256-byte stores was
-// measured too -- profiles/r02_pmc_hbm.json: WRITE_SIZE 62.1 MB against 63.3 MB with each lane writing its own 140-byte row, and the
-// same step time -- the L2 already merges the lanes' 4-byte stores into full lines; what WRITE_SIZE carries beyond the records and
-// rows is the register spill traffic.  The direct per-lane row writes stayed.)
-constexpr int FEPB = FTPB / 16;      // rows (envs) per 64-thread block of the leading row blocks
-template <int MODE>
-__global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
-                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count,
-                                               int rb, const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                               int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
-    if constexpr (NB == 1) {
-        if ((int)blockIdx.x < rb) {
-            row_list_body<MODE, FEPB>(blockIdx.x, rb, T, P, state, actions, out, act_dim, ow, flags, cur_list, cur_count, cls, next_list, next_count, cap,
-                                      tgt, host_total, dummy_base, recent);
-            return;
-        }
-    }
-    __shared__ float lds_park[FastD::PARK * FTPB];
-    const int blk = (int)blockIdx.x - rb;
-    const int env = blk * FTPB + threadIdx.x;
-    if (blk == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
-    if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
-    const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, lds_park + threadIdx.x);
-    publish_class(env, c, cls, next_list, next_count, cap);
 }
 
 // use_IK = 1: hand-pose update + inverse kinematics -> joint targets (one thread per env).  RESET: targets of the home hand pose.
@@ -221,10 +196,6 @@ __global__ __launch_bounds__(FTPB) void k_classify(const Tables* __restrict__ T,
     publish_class(env, FastD::classify_state(*T, P, state + (size_t)env * STATE, flags), cls, list, count, cap);
 }
 
-// Sampled steps launch this empty kernel ahead of the first timing event: an event recorded straight behind a long-running kernel
-// of the same stream takes over that kernel's timestamps (measured: 0.71 ms reported for a 0.26 ms kernel); behind a kernel that
-// has nothing to do the pair brackets exactly the step kernel (the pattern round 1 measured with, agreeing with rocprofv3).
-__global__ void k_nop() {}
 __global__ void k_total(const int* __restrict__ count, int* __restrict__ host_total, int* __restrict__ recent) {
     int t = 0;
     for (int b = 0; b < NB; b++) t += count[b];
@@ -304,8 +275,7 @@ struct pbre_ctx {
     int idle_touch = 16;               // in that mode, an (empty) fork / join through the side stream every idle_touch-th step: a side stream
                                        // left idle for hundreds of steps makes the first steps after the switch back ~8 % slower (0: never)
     int idle_single = 1;               // with no complex envs reported, both kernels go to the caller's stream in order (no fork / join events); 0: A/B
-    int row_max = 4096;                // up to this many complex envs they are stepped by the row formulation (1 wave per 4 envs)
-    int fuse_rows = 1;                 // their row blocks lead the grid of k_fast (one launch per step); 0: k_row_list on its own stream (A/B)
+    int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -393,39 +363,30 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     const int cc = b.ccur, cn = (cc + 1) % 3, cz = (cc + 2) % 3;      // counters: current, next (zero on entry), the one after
     const int blocks = (n + FTPB - 1) / FTPB;
     hipError_t e;
+    // The two kernels of a step run concurrently on two streams (fork/join events) and both append to list[nxt].
+    // Which one gets the caller's stream is a scheduling choice made from the complex-env count the device reported for
+    // an earlier step (a hint; either order is correct):
+    //  * complex envs present: k_fast_rc (few waves, each needs a whole SIMD's register file, long latency) is enqueued first on
+    //    the caller's stream so that its waves claim their SIMDs before k_fast floods the chip from the side stream;
+    //  * none (e.g. the first steps after a reset): the (empty) complex-env kernel and k_fast are enqueued in order on the caller's
+    //    stream, with no fork / join events at all: the event packets and the concurrently dispatched empty kernel cost 6 % of the
+    //    step (613 M -> 650 M env-steps/s at 131072 envs).  Taken only when the device has reported no complex env for 16 steps in a
+    //    row (a count that flickers between 0 and a few would otherwise serialise the two kernels every other step); a stale
+    //    hint only serialises them for that step.
     const int hint = b.h_total[0];
-    // complex envs: row formulation while they are few (latency), lane-per-env k_fast_rc when many (throughput)
+    const bool rc_first = hint >= c->rc_first_min;
+    const bool single = c->idle_single && hint == 0 && b.h_total[1] == 0;      // both kernels in order on the caller's stream
+    hipStream_t s_rc = (rc_first || single) ? s : c->side, s_fast = (rc_first && !single) ? c->side : s;
+    const bool touch_side = single && c->idle_touch > 0 && (c->launches % c->idle_touch) == 0;   // keep the side stream's queue mapped
+    if (!single || touch_side) {
+        if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
+    }
+    // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
     bool rows = NB == 1 && hint <= c->row_max;
     if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
     if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
     if (!c->P.obj_iso) rows = NB == 1;                 // a box with unequal principal inertias: k_fast_rc's object rows assume a cube
-    // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
-    // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
-    // (the last launch of every group of KSAMPLE: the first launches after a reset -- cold instruction cache, first touch of the
-    // state -- are warm-up, not samples)
-    const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
-    hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
-    if (rows && c->fuse_rows) {
-        // one launch: the complex envs' row blocks lead the grid (see k_fast); sized from the count the device reported for an
-        // earlier step (a hint: the blocks grid-stride over the list, idle ones exit at once)
-        const int rb = std::max(FEPB * 2, std::min(c->n_simd / 2, (hint + FEPB - 1) / FEPB + 8));
-        if (timed) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(1), 0, s); (void)hipEventRecord(ek[0], s); }
-        hipLaunchKernelGGL(k_fast<MODE>, dim3(rb + blocks), dim3(FTPB), 0, s, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                           b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB,
-                           rb, b.list[cur], b.count + cc * NB, b.h_total, b.cap, b.count + 3 * NB);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }
-        b.ccur = cn;
-        b.cur = nxt;
-        return hipSuccess;
-    }
-    // Otherwise the two kernels of a step run concurrently on two streams (fork/join events) and both append to list[nxt]:
-    // the complex-env kernel (few waves, long latency) is enqueued first on the caller's stream so that its waves claim their
-    // SIMDs before k_fast floods the chip from the side stream (PBRE_RC_FIRST_MIN: A/B of the order).
-    const bool rc_first = hint >= c->rc_first_min;
-    hipStream_t s_rc = rc_first ? s : c->side, s_fast = rc_first ? c->side : s;
-    if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     if constexpr (NB == 1) {
         if (rows) {
             const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));
@@ -437,14 +398,21 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                            b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.count + 3 * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
+    // an event record is a barrier packet the next dispatch waits for, a pair per step costs ~10% of this kernel
+    // (the last launch of every group of KSAMPLE: the first launches after a reset -- cold instruction cache, first touch of the
+    // state -- are warm-up, not samples)
+    const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
+    hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
     if (timed) (void)hipEventRecord(ek[0], s_fast);
     hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                       b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB,
-                       0, b.list[cur], b.count + cc * NB, b.h_total, b.cap, b.count + 3 * NB);
+                       b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed) { (void)hipEventRecord(ek[1], s_fast); c->k_steps++; }
-    if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-    if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+    if (!single || touch_side) {
+        if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+    }
     b.ccur = cn;
     b.cur = nxt;
     return hipSuccess;
@@ -527,7 +495,6 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_KSAMPLE")) c->ksample = std::max(1, atoi(ev));
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
-    if (const char* ev = getenv("PBRE_FUSE_ROWS")) c->fuse_rows = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -670,6 +637,16 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_objz = rec[11];
             HIPCHK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
             c->have_snapshot = true;
+            // end-effector pose of the settled robot (the first 6 observation entries of env 0) for the in-kernel restart
+            hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->main.state, c->d_out, c->d_scratch, c->n, c->ow);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            float row[6]; int complex_now[NB] = {0};
+            HIPCHK(hipMemcpy(row, c->d_out, sizeof row, hipMemcpyDeviceToHost));
+            if (lane_per_env(c)) HIPCHK(hipMemcpy(complex_now, c->main.count + c->main.ccur * NB, sizeof complex_now, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 6; k++) c->P.rst_ee[k] = row[k];
+            int nc = 0; for (int k = 0; k < NB; k++) nc += complex_now[k];
+            c->P.rst_ok = nc == 0 ? 1 : 0;         // every env of the freshly reset batch is in the simple class
         }
     }
     c->k_steps = 0; c->launches = 0;      // pbre_timing[3] averages env steps only, not the settle launches above

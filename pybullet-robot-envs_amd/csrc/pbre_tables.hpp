@@ -95,6 +95,8 @@ struct Params {                  // float copies of pbre_physics + task constant
     unsigned seed_lo, seed_hi;
     unsigned long long env_id_base;
     float rst_q[MAXJ], rst_objz;  // settled robot pose / object height recorded at the last full reset (snapshot auto-reset)
+    float rst_ee[6]; int rst_ok;  // ... and the end-effector position / Euler angles of that pose (lane-per-env kernels: the first
+                                  // observation of a restarted episode needs no kinematic sweep); rst_ok: recorded and a simple-class state
     int   use_ik, ik_iters;       // Cartesian control (use_IK=1): damped-least-squares IK
     float ik_l2, ik_res, home_hand[6], rws[3][2];   // lambda^2, position residual, home hand pose, robot workspace
     int   robot, reward_type, ctrl_ori;             // PBRE_ROBOT_*; iCub push reward variant; IK mode: orientation part of the action

@@ -115,7 +115,15 @@ struct Emu : pbre_ctx {
                 CoreH::observe(T, P, st, Q, V, X, nullptr, CoreH::M_INITD);
             }
         }
-        if (!mask) { for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; have_snapshot = true; }
+        if (!mask) {
+            for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; have_snapshot = true;
+            std::vector<float> row(obs_dim + 2);
+            float* st = &state[0];
+            auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
+            CoreH::observe(T, P, st, Q, V, X, row.data(), CoreH::M_OBS);
+            for (int k = 0; k < 6; k++) P.rst_ee[k] = row[k];
+            if constexpr (PANDA) { bool ok = true; for (int e = 0; e < n; e++) ok = ok && FastH::classify_state(T, P, &state[(size_t)e * STATE], cfg.flags & PBRE_F_NO_OBJECT) == 0; P.rst_ok = ok ? 1 : 0; }
+        }
     }
     int reset_snapshot(const uint8_t* mask) override {
         if (S::MREC) { err = "pbre_reset_snapshot: task envs only"; return PBRE_E_UNSUPPORTED; }

@@ -1,31 +1,30 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, smoke, bench, rocprof kernel-trace stats.  Logs -> gpurun_out/
-# usage: tools/gpu_round.sh <tag> [bench args...]
-TAG=${1:-r01}; shift
+# One GPU-box visit: parity tests, smoke, bench, rocprofv3 kernel-trace stats + PMC passes of the bench command, the iCub / hands
+# side benches, the N=2 control flow on one device.  Logs -> gpurun_out/<tag>_*; tools/collect_profiles.sh copies the summaries
+# into profiles/.        usage: tools/gpu_round.sh <tag>
+TAG=${1:-r02}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "== rocminfo" ; /opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4
-echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee gpurun_out/pytest_gpu_$TAG.log
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee gpurun_out/smoke_$TAG.log
-echo "== bench"
-timeout 900 python bench.py "$@" 2>&1 | tail -3 | tee gpurun_out/bench_$TAG.log
-echo "== rocprof"
 ROOTDIR=$(pwd)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-other-configs --no-host-path --preroll 200 > $ROOTDIR/gpurun_out/rocprof_$TAG.log 2>&1)
-tail -3 gpurun_out/rocprof_$TAG.log
-find gpurun_out/prof_$TAG -name "*.csv" | head
-f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
-find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -size +8M -delete; find gpurun_out/prof_$TAG -name "*.db" -delete
+/opt/rocm/bin/rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | sed -n 2,3p
+echo "== pytest -m gpu"
+timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -vE "^/opt/amdgpu" gpurun_out/${TAG}_pytest_gpu.log | tail -6 | cut -c1-300
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -4 | tee gpurun_out/${TAG}_smoke.log
+echo "== bench"
+timeout 900 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json; tail -2 gpurun_out/${TAG}_bench.err; cut -c1-600 gpurun_out/${TAG}_bench.json
+echo "== rocprofv3 --kernel-trace --stats (same command, CPU baseline leg off)"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --no-cpu-baseline > $ROOTDIR/gpurun_out/${TAG}_rocprof.log 2>&1)
+f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_kernel_stats.csv && head -8 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-60,100-
+t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_steps.py $t 8 | tail -3
+find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/prof_$TAG -name "*.db" -delete
+echo "== PMC HBM / SQ (separate passes, no tracing domains)"
+bash tools/pmc.sh $TAG --steps 20 --warmup 3 2>&1 | grep -E "k_fast<7>|==" | head -6
+python tools/pmc_json.py $TAG 131072 2>&1 | tail -9
+bash tools/pmc_sq.sh $TAG --steps 20 --warmup 3 2>&1 | tail -30 | grep -E "valu_insts_per_wave|valu_active|wait_any" | head -8
 echo "== iCub / hands benches"
-timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | tee gpurun_out/icub_bench_$TAG.json
-timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/icub_bench_$TAG.json
-timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 2>&1 | tail -1 | tee gpurun_out/hands_bench_$TAG.json
-timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/hands_bench_$TAG.json
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/bench_icub.py --envs 32768 --steps 20 > $ROOTDIR/gpurun_out/rocprof_icub_$TAG.log 2>&1)
-f=$(find gpurun_out/prof_icub_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
-find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" -size +8M -delete; find gpurun_out/prof_icub_$TAG -name "*.db" -delete
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_hands_$TAG -o run -- python $ROOTDIR/tools/bench_hands.py --envs 8192 --steps 20 > $ROOTDIR/gpurun_out/rocprof_hands_$TAG.log 2>&1)
-f=$(find gpurun_out/prof_hands_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f"
-find gpurun_out/prof_hands_$TAG -name "*kernel_trace.csv" -size +8M -delete; find gpurun_out/prof_hands_$TAG -name "*.db" -delete
+timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | tee gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 2>&1 | tail -1 | tee gpurun_out/${TAG}_hands_bench.json | cut -c1-300
+echo "== bench N=2 on one device (control flow, gloo-staged gather)"
+PBRE_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 20 --preroll 200 2> gpurun_out/${TAG}_bench2.err | tail -1 > gpurun_out/${TAG}_bench2.json; echo rc=$?; cut -c1-300 gpurun_out/${TAG}_bench2.json
