@@ -302,7 +302,7 @@ def main():
     class Job(object):
         """One sharded batch: engine, resident action pool for the timed steps, double-buffered output rows, pipelined gather."""
 
-        def __init__(self, total_envs, pool_steps):
+        def __init__(self, total_envs, pool_steps, desync=True):
             self.sh = ShardedEngine(tbl, total_envs, task=_capi.TASK_PUSH, device_id=local_rank, seed=1234,
                                     obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, flags=_capi.F_AUTO_RESET)
             self.total = total_envs
@@ -315,7 +315,7 @@ def main():
             # worker that has been running for a while has episodes of every age: start the counters at U{0..max_steps-1} (keyed by
             # the global env id, so the sharded batch is the same batch).
             st = eng.get_state()
-            ages = np.random.default_rng(4321).integers(0, 1 if os.environ.get("PBRE_BENCH_NO_DESYNC") == "1" else 1000, total_envs)[self.sh.env_id_base:self.sh.env_id_base + n]
+            ages = np.random.default_rng(4321).integers(0, 1000 if (desync and os.environ.get("PBRE_BENCH_NO_DESYNC") != "1") else 1, total_envs)[self.sh.env_id_base:self.sh.env_id_base + n]
             st[:, eng.x_off + 3] = ages.astype(np.float32)
             eng.set_state(st)
             # actions U(-1,1), i.i.d. per (step, env).  Timed steps read slices of a pool generated up front and
@@ -444,6 +444,21 @@ def main():
             host = {"error": repr(e)}
     del job
 
+    # extra at N=1: the same pre-roll with SYNCHRONISED episode clocks (every env starts its first episode at step 0, so all envs that
+    # do not succeed early restart together every 1000 steps): right behind such a mass restart the batch is close to the fresh state,
+    # which is what a plain "reset(), 1000 steps, measure" protocol sees
+    sync_clocks = None
+    if world == 1 and not args.no_fresh:
+        try:
+            j3 = Job(total, args.steps + args.warmup, desync=False)
+            j3.preroll(args.preroll - args.warmup)
+            c0 = j3.eng.kernel_info()[7]
+            sync_clocks = clean(j3.timed(args.steps, args.warmup))
+            sync_clocks["complex_envs_per_step"] = ((j3.eng.kernel_info()[7] - c0) % (1 << 31)) / float(args.steps + args.warmup)
+            del j3
+        except Exception as e:
+            sync_clocks = {"error": repr(e)}
+
     # extra at N>1: weak scaling -- every GPU keeps the 131072-env shard (131072 x N envs in total), same gather
     weak = None
     if world > 1 and not args.no_weak:
@@ -498,6 +513,7 @@ def main():
                        "done_frac_last_step_rank0": done_frac,
                        "mean_episodes_completed_per_env_rank0": episodes},
             "fresh_reset": clean(fresh) if fresh else None,
+            "steady_synchronised_clocks": sync_clocks,
             "weak_scaling_128k_per_gpu": weak,
             "sharded_consumers_no_gather": no_gather,
             "host_inclusive": host,
