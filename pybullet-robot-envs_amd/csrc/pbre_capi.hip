@@ -285,6 +285,7 @@ struct pbre_ctx {
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
+    int zero_copy = 0;                 // PBRE_ZERO_COPY (A/B): pbre_step lets the kernels access page-locked host buffers directly
     bool have_snapshot = false;        // a full pbre_reset has recorded the settled snapshot (rst_q, rst_objz)
     unsigned char* d_mask = nullptr;
     bool ext_dirty = false;            // a pbre_step_device was enqueued on a caller-supplied stream since the last quiesce()
@@ -495,6 +496,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_KSAMPLE")) c->ksample = std::max(1, atoi(ev));
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
+    if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
     if (he != hipSuccess || ndev <= 0) {
@@ -687,12 +689,21 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (c->wide) return wide_step(c->wide, actions, out);
     HIPCHK(hipSetDevice(c->device));
     if (c->ext_dirty) HIPCHK(quiesce(c));
+    // zero-copy (PBRE_ZERO_COPY bit 0: actions, bit 1: rows): a page-locked buffer (pbre_host_alloc) is accessed by the kernels
+    // themselves, over PCIe, instead of being staged through HBM with a copy
+    bool za = false, zo = false;
+    if (c->zero_copy) {
+        hipPointerAttribute_t pa;
+        za = (c->zero_copy & 1) && hipPointerGetAttributes(&pa, actions) == hipSuccess && pa.type == hipMemoryTypeHost;
+        zo = (c->zero_copy & 2) && hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+    }
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
+    if (!za) HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(full_step(c, c->d_act, c->d_out, c->stream));
+    HIPCHK(full_step(c, za ? actions : c->d_act, zo ? out : c->d_out, c->stream));
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!zo) HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) { float t = 0; HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1])); c->ms[i] = t; }
@@ -728,7 +739,11 @@ int pbre_get_state_cols(pbre_ctx* c, int32_t first, int32_t count, float* out) {
 }
 void* pbre_host_alloc(size_t bytes) {
     void* p = nullptr;
-    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    // PBRE_HOST_NONCOHERENT=1 (A/B with PBRE_ZERO_COPY): coarse-grained host memory, device writes are cached in L2 and written back at
+    // the end of the kernel in full lines instead of going out as they are issued
+    const char* nc = getenv("PBRE_HOST_NONCOHERENT");
+    const unsigned flags = (nc && nc[0] == '1') ? (hipHostMallocNonCoherent | hipHostMallocMapped) : hipHostMallocDefault;
+    return hipHostMalloc(&p, bytes ? bytes : 1, flags) == hipSuccess ? p : nullptr;
 }
 void pbre_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
