@@ -1,0 +1,665 @@
+// pbre_lane.hpp -- lane-per-env step for robots of the wide shapes (the iCub as simulated: 20 DoF, Shape32 state records).
+//
+// One thread = one env, 64 envs per wavefront, as in pbre_fast.hpp for the Panda -- against the lane-group kernel of pbre_core.hpp
+// (one env per half-wave, every scalar of a row replicated over 32 lanes and every row ending in a cross-lane broadcast) a motor
+// row costs a wave ~1/8 of the issue slots per env.  What does not fit the Panda recipe is M^-1: 210 floats per env (symmetric
+// 20 x 20) cannot live in registers next to the solver state, so it lives in wave-private LDS laid out [entry][lane] (conflict
+// free, every address an immediate offset); the PBRE_LANE_MREG entries with the highest indices stay in registers so that four
+// waves -- one per SIMD -- fit a CU's 160 KB.
+//
+// Handled here ("simple" class of this engine): motors, joint-limit rows (frequent on the iCub under Cartesian control, where the
+// IK targets push joints into their stops) and the object's own rows against the table (ObjStep, swept inside the same loop).
+// An env with a robot collision sphere within the contact margin of the object or the table ("complex") is stepped by the
+// lane-group kernel (Core::step) and only finished here (finish(): observation, reward, termination, auto-reset, class of the
+// new state), exactly the split of k_row_list / Fast::finish on the Panda.
+//
+// Same mathematics and reference call sites as pbre_core.hpp / pbre_fast.hpp: world-frame RNEA + CRBA + explicit M^-1, Bullet's
+// row order, iCubReachGymEnv / iCubPushGymEnv / iCubPushGymGoalEnv .step (icub_reach_gym_env.py:182-259,
+// icub_push_gym_env.py:208-282), iCubEnv.apply_action / get_observation (icub_env.py:202-361).
+// Plain C++: compiled for the device in pbre_wide.hip and for the host in tests/host_emu.
+#pragma once
+#include <math.h>
+#include "pbre_fast.hpp"
+#include "pbre_objstep.hpp"
+
+#ifndef PBRE_LANE_MSTRIDE      // floats between consecutive M^-1 entries of one env (device: 64 = [entry][lane]; host: 1)
+#define PBRE_LANE_MSTRIDE 1
+#endif
+#ifndef PBRE_OPAQUE_I          // device: the optimiser must assume the (per-lane) int changed (asm volatile("" : "+v"(x))); host: nothing
+#define PBRE_OPAQUE_I(x) do {} while (0)
+#endif
+#ifndef PBRE_OPAQUE_F          // the same for a float: starts a new live range (a value the register allocator spilled during the setup
+#define PBRE_OPAQUE_F(x) do {} while (0)   // phase is reloaded once here instead of at every use inside the solver loop)
+#endif
+#ifndef PBRE_NOUNROLL          // device: _Pragma("nounroll")
+#define PBRE_NOUNROLL
+#endif
+#ifndef PBRE_LANE_MREG         // M^-1 entries (highest triangle indices) kept in registers instead of LDS
+#define PBRE_LANE_MREG 0
+#endif
+
+namespace pbre {
+
+// The iCub as flattened by build_tables() from model/table.py: icub_table (legs pruned): torso 0-1-2, left arm 3..9, head 10..12,
+// right arm 13..19, the three branches attached to torso lane 2; lanes 5 and 15 carry two rigid sub-bodies.
+struct TopoICub {
+    static constexpr int ND = 20;
+    static constexpr int parent(int j) { return j == 0 ? -1 : ((j == 10 || j == 13) ? 2 : j - 1); }
+    static constexpr int jtype(int) { return 1; }
+    static constexpr int nsub(int j) { return (j == 5 || j == 15) ? 2 : 1; }
+    static constexpr bool is_anc(int i, int j) {   // i ancestor-or-self of j
+        return i == j || (j >= 0 && parent(j) >= 0 && is_anc(i, parent(j)));
+    }
+    // the tree as chains of consecutive lanes: chain 0 is the trunk (from the root), every other chain hangs on a trunk link
+    static constexpr int NCHAIN = 4;
+    static constexpr int chain_first(int c) { return c == 0 ? 0 : (c == 1 ? 3 : (c == 2 ? 10 : 13)); }
+    static constexpr int chain_last(int c) { return c == 0 ? 2 : (c == 1 ? 9 : (c == 2 ? 12 : 19)); }
+};
+
+template <class Topo, class S>
+inline bool lane_topo_matches(const TablesT<S>& T) {
+    if (T.ndof != Topo::ND || Topo::ND > S::NJ) return false;
+    for (int j = 0; j < Topo::ND; j++) {
+        if (T.anc[0][j] != Topo::parent(j) || T.jtype[j] != Topo::jtype(j)) return false;
+        for (int b = 0; b < S::NSUB; b++) if ((T.sb_m[b][j] != 0.f || T.sb_I[b][0][j] != 0.f) != (b < Topo::nsub(j))) return false;
+    }
+    return true;
+}
+
+template <class Topo, class S>
+struct Lane {
+    using FX = Fast<Topo>;
+    using V3 = typename FX::V3; using M3 = typename FX::M3; using Q4 = typename FX::Q4;
+    using Tab = TablesT<S>;
+    static constexpr int ND = Topo::ND, W = S::W, LC = S::LC, XO = 2 * S::W, NSUB = S::NSUB;
+    static constexpr int NM = ND * (ND + 1) / 2;
+    static constexpr int MREG = PBRE_LANE_MREG, MLDS = NM - MREG;      // entries [0, MLDS) in LDS, [MLDS, NM) in registers
+    static constexpr int MS = PBRE_LANE_MSTRIDE;
+    static_assert(!S::MREC && S::NTIP == 0, "task-env shapes only");
+    enum { M_ACTION = FX::M_ACTION, M_OBS = FX::M_OBS, M_TASK = FX::M_TASK, M_TGT = FX::M_TGT, M_INNER = FX::M_INNER };
+
+    static PBRE_HD V3 v3(float x, float y, float z) { return FX::v3(x, y, z); }
+    static PBRE_HD V3 add(V3 a, V3 b) { return FX::add(a, b); }
+    static PBRE_HD V3 sub(V3 a, V3 b) { return FX::sub(a, b); }
+    static PBRE_HD V3 scl(V3 a, float s) { return FX::scl(a, s); }
+    static PBRE_HD float dot(V3 a, V3 b) { return FX::dot(a, b); }
+    static PBRE_HD V3 cross(V3 a, V3 b) { return FX::cross(a, b); }
+    static PBRE_HD float norm(V3 a) { return FX::norm(a); }
+    static PBRE_HD V3 mv(const M3& A, V3 v) { return FX::mv(A, v); }
+    static PBRE_HD V3 mtv(const M3& A, V3 v) { return FX::mtv(A, v); }
+    static PBRE_HD M3 mm(const M3& A, const M3& B) { return FX::mm(A, B); }
+    static PBRE_HD float clampf(float x, float lo, float hi) { return FX::clampf(x, lo, hi); }
+    static PBRE_HD float med3(float x, float lo, float hi) { return FX::med3(x, lo, hi); }
+    static constexpr int sym(int i, int j) { return FX::sym(i, j); }
+
+    // M^-1 (during setup: M, then the sweep operator's intermediate) behind one accessor: entry k of this env
+    struct Mat {
+        float* lds;                                   // this lane's column of the wave's LDS region
+        float reg[MREG > 0 ? MREG : 1];
+        PBRE_HD float get(int k) const { return k < MLDS ? lds[k * MS] : reg[k < MLDS ? 0 : k - MLDS]; }
+        // solver loop: entry k read through an offset `o` (always 0) the optimiser cannot see through -- refreshed per row, so that it
+        // neither hoists the loads out of the loop nor merges them with the other use of the entry in the same sweep (either would
+        // keep all 210 entries live in registers, which is what the LDS copy is there to avoid)
+        PBRE_HD float geto(int k, int o) const { return k < MLDS ? lds[k * MS + o] : reg[k < MLDS ? 0 : k - MLDS]; }
+        PBRE_HD void set(int k, float v) { if (k < MLDS) lds[k * MS] = v; else reg[k < MLDS ? 0 : k - MLDS] = v; }
+    };
+
+    // joint frame of link j in its parent's frame at angle qj
+    static PBRE_HD void joint_xf(const Tab& T, int j, float qj, M3& Rl, V3& pl, V3& ax) {
+        ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
+        M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
+        const V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
+        if (Topo::jtype(j) == 1) {
+            float c, sn;
+            sincosf(qj, &sn, &c);                     // one range reduction for both
+            const float C = 1.f - c;
+            M3 Rj;
+            Rj.m[0] = c + ax.x*ax.x*C;       Rj.m[1] = ax.x*ax.y*C - ax.z*sn; Rj.m[2] = ax.x*ax.z*C + ax.y*sn;
+            Rj.m[3] = ax.y*ax.x*C + ax.z*sn; Rj.m[4] = c + ax.y*ax.y*C;       Rj.m[5] = ax.y*ax.z*C - ax.x*sn;
+            Rj.m[6] = ax.z*ax.x*C - ax.y*sn; Rj.m[7] = ax.z*ax.y*C + ax.x*sn; Rj.m[8] = c + ax.z*ax.z*C;
+            Rl = mm(R0, Rj); pl = p0;
+        } else {
+            Rl = R0; const V3 d = mv(R0, ax); pl = v3(fmaf(d.x, qj, p0.x), fmaf(d.y, qj, p0.y), fmaf(d.z, qj, p0.z));
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------ the step
+    // st: the env's Q[W] | V[W] | X[16] record.  mi: this lane's slice of the wave's LDS region (MLDS floats, stride MS).
+    // Returns the class of the state it produced (0 simple, 1 complex).
+    static PBRE_HD int step(const Tab& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                            unsigned long long env_id, const float* tgt, float* mi) {
+        const bool obj_on = !(flags & 1);
+        float q[ND], qd[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[W + j]; }
+        // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (X[14]): it does not simulate
+        // (its lane runs along and stores nothing), only the evaluation of the state it is in
+        const bool skip = st[XO + 14] != 0.f;
+        const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
+
+        // ---- kinematics + dynamics, chain by chain (Topo::chain_*: the trunk, then every branch): forward over the chain's links
+        //      (FK, joint axes, velocities, velocity-product accelerations, per-link bias force and spatial inertia; world frame, about
+        //      the world origin), then backward over them (subtree forces -> bias torques, composite inertias -> rows of M, CRBA).  A
+        //      branch hands its composite to the trunk link it hangs on; the trunk's backward pass runs last.  Only the trunk's and the
+        //      current branch's per-link data are live at any time.
+        Mat Mi; Mi.lds = mi;
+        float tau[ND];
+        V3 Sa[ND], Sl[ND];                    // joint axes: a link needs those of its ancestors (its chain and the trunk)
+        V3 Fa[ND], Fl[ND];
+        float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
+        M3 R[ND]; V3 p[ND], Va[ND], Vl[ND], Aa[ND], Al[ND];
+        auto forward = [&](int j) {
+            const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+            const bool root = Topo::parent(j) < 0;
+            M3 Rl; V3 pl, ax;
+            joint_xf(T, j, q[j], Rl, pl, ax);
+            if (root) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+            const V3 aw = mv(R[j], ax);
+            if (Topo::jtype(j) == 1) { Sa[j] = aw; Sl[j] = cross(p[j], aw); } else { Sa[j] = v3(0.f, 0.f, 0.f); Sl[j] = aw; }
+            const V3 sa = scl(Sa[j], qd[j]), sl = scl(Sl[j], qd[j]);
+            if (root) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj], sa); Vl[j] = add(Vl[pj], sl); }
+            const V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
+            if (root) { Aa[j] = ca; Al[j] = v3(cl.x, cl.y, cl.z - P.gz); } else { Aa[j] = add(Aa[pj], ca); Al[j] = add(Al[pj], cl); }
+            Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
+            PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
+            PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
+                if (b >= Topo::nsub(j)) continue;
+                const float m = T.sb_m[b][j];
+                const V3 c = add(p[j], mv(R[j], v3(T.sb_c[b][0][j], T.sb_c[b][1][j], T.sb_c[b][2][j])));
+                M3 Il; Il.m[0] = T.sb_I[b][0][j]; Il.m[1] = T.sb_I[b][3][j]; Il.m[2] = T.sb_I[b][4][j];
+                Il.m[3] = Il.m[1]; Il.m[4] = T.sb_I[b][1][j]; Il.m[5] = T.sb_I[b][5][j]; Il.m[6] = Il.m[2]; Il.m[7] = Il.m[5]; Il.m[8] = T.sb_I[b][2][j];
+                const M3 RI = mm(R[j], Il); M3 Iw;
+                PBRE_UNROLL for (int a = 0; a < 3; a++)
+                    PBRE_UNROLL for (int bb = 0; bb < 3; bb++)
+                        Iw.m[a*3+bb] = fmaf(RI.m[a*3], R[j].m[bb*3], fmaf(RI.m[a*3+1], R[j].m[bb*3+1], RI.m[a*3+2] * R[j].m[bb*3+2]));
+                const V3 w = Va[j];
+                const V3 vc = add(Vl[j], cross(w, c));
+                const V3 ac = add(add(Al[j], cross(Aa[j], c)), cross(w, vc));
+                const float sl_ = fmaf(P.kl, norm(vc), P.kl);            // Bullet velocity damping K1 + K2 |v|
+                const V3 f = scl(add(ac, scl(vc, sl_)), m);
+                const V3 Iww = mv(Iw, w);
+                const float sa_ = fmaf(P.ka, norm(w), P.ka);
+                const V3 nc = add(add(mv(Iw, Aa[j]), cross(w, Iww)), scl(Iww, sa_));
+                Fa[j] = add(Fa[j], add(nc, cross(c, f))); Fl[j] = add(Fl[j], f);
+                Cm[j] += m; Ch[j] = add(Ch[j], scl(c, m));
+                const float cc = dot(c, c);
+                CI[j][0] += fmaf(m, cc - c.x*c.x, Iw.m[0]); CI[j][1] += fmaf(m, cc - c.y*c.y, Iw.m[4]); CI[j][2] += fmaf(m, cc - c.z*c.z, Iw.m[8]);
+                CI[j][3] += fmaf(-m, c.x*c.y, Iw.m[1]); CI[j][4] += fmaf(-m, c.x*c.z, Iw.m[2]); CI[j][5] += fmaf(-m, c.y*c.z, Iw.m[5]);
+            }
+        };
+        auto backward = [&](int j) {
+            tau[j] = -(dot(Sa[j], Fa[j]) + dot(Sl[j], Fl[j])) - T.jdamp[j] * qd[j];      // bias torque + explicit joint damping
+            M3 Io; Io.m[0] = CI[j][0]; Io.m[1] = CI[j][3]; Io.m[2] = CI[j][4]; Io.m[3] = CI[j][3]; Io.m[4] = CI[j][1]; Io.m[5] = CI[j][5];
+            Io.m[6] = CI[j][4]; Io.m[7] = CI[j][5]; Io.m[8] = CI[j][2];
+            const V3 Ga = add(mv(Io, Sa[j]), cross(Ch[j], Sl[j]));
+            const V3 Gl = add(scl(Sl[j], Cm[j]), cross(Sa[j], Ch[j]));
+            PBRE_UNROLL for (int i = 0; i < ND; i++) {
+                if (i > j) { if (!Topo::is_anc(j, i)) Mi.set(sym(i, j), 0.f); continue; }      // unrelated branches
+                Mi.set(sym(j, i), Topo::is_anc(i, j) ? dot(Sa[i], Ga) + dot(Sl[i], Gl) : 0.f);
+            }
+            if (Topo::parent(j) >= 0) {
+                const int pp = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+                Fa[pp] = add(Fa[pp], Fa[j]); Fl[pp] = add(Fl[pp], Fl[j]);
+                Cm[pp] += Cm[j]; Ch[pp] = add(Ch[pp], Ch[j]);
+                PBRE_UNROLL for (int k = 0; k < 6; k++) CI[pp][k] += CI[j][k];
+            }
+        };
+        PBRE_UNROLL for (int j = Topo::chain_first(0); j <= Topo::chain_last(0); j++) forward(j);
+        PBRE_UNROLL for (int c = 1; c < Topo::NCHAIN; c++) {
+            PBRE_UNROLL for (int j = Topo::chain_first(c); j <= Topo::chain_last(c); j++) forward(j);
+            PBRE_UNROLL for (int j = Topo::chain_last(c); j >= Topo::chain_first(c); j--) backward(j);
+        }
+        PBRE_UNROLL for (int j = Topo::chain_last(0); j >= Topo::chain_first(0); j--) backward(j);
+        if (P.jd_dt != 0.f) { PBRE_UNROLL for (int j = 0; j < ND; j++) Mi.set(sym(j, j), fmaf(P.jd_dt, T.jdamp[j], Mi.get(sym(j, j)))); }   // implicit joint damping: M + dt C
+        // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle, in place
+        PBRE_UNROLL for (int k = 0; k < ND; k++) {
+            float b[ND];
+            PBRE_UNROLL for (int i = 0; i < ND; i++) b[i] = Mi.get(sym(i, k));
+            const float pv = 1.f / b[k];
+            PBRE_UNROLL for (int i = 0; i < ND; i++) {
+                if (i == k) continue;
+                const float bp = b[i] * pv;
+                PBRE_UNROLL for (int j = 0; j <= i; j++) { if (j == k) continue; Mi.set(sym(i, j), fmaf(-bp, b[j], Mi.get(sym(i, j)))); }
+                Mi.set(sym(i, k), bp);
+            }
+            Mi.set(sym(k, k), -pv);
+        }
+        PBRE_UNROLL for (int i = 0; i < NM; i++) Mi.set(i, -Mi.get(i));
+
+        // ---- unconstrained joint velocities w = v*, motor rows against the running velocity (see Fast::step_t), limit rows
+        float w[ND], w0[ND], m_dinv[ND], m_rhs[ND], m_app[ND];
+        float l_dir[ND], l_rhs[ND], l_app[ND];
+        bool lim_any[ND], has_limit = false;
+        {
+            float acc[ND];
+            PBRE_UNROLL for (int j = 0; j < ND; j++) acc[j] = 0.f;
+            PBRE_UNROLL for (int j = 0; j < ND; j++)
+                PBRE_UNROLL for (int k = 0; k <= j; k++) {
+                    const float e = Mi.get(sym(j, k));
+                    acc[j] = fmaf(e, tau[k], acc[j]);
+                    if (k != j) acc[k] = fmaf(e, tau[j], acc[k]);
+                }
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                const float wj = clampf(fmaf(dt, acc[j], qd[j]), -vmax, vmax);
+                w[j] = wj; w0[j] = wj;
+                float qdes = T.home[j], kp = T.kp_hold[j], kd = T.kd_hold[j];
+                if (mode & M_TGT) qdes = tgt[j];                     // Cartesian control: every joint tracks the IK solution with the hold gains
+                if (mode & M_ACTION) {                               // joint control (icub_env.py:341-361 through the task env's scaling)
+                    kp = T.kp_act[j]; kd = T.kd_act[j];
+                    const int ai = T.act_idx[j];
+                    if (ai >= 0) qdes = clampf(fmaf(act[ai], P.act_scale, q[j]), T.lower[j], T.upper[j]);
+                }
+                m_dinv[j] = 1.f / Mi.get(sym(j, j));
+                m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * wj) * m_dinv[j];
+                m_app[j] = 0.f;
+                // joint-limit row (btMultiBodyJointLimitConstraint): exists while the joint is at / beyond the limit
+                const float pl = q[j] - T.lower[j], pu = T.upper[j] - q[j];
+                const bool lo_v = pl <= 0.f, up_v = !lo_v && pu <= 0.f;
+                l_dir[j] = lo_v ? 1.f : (up_v ? -1.f : 0.f);
+                const float pen = lo_v ? pl : pu;
+                l_rhs[j] = (lo_v || up_v) ? (-pen * P.erp * inv_dt) * m_dinv[j] : 0.f;
+                l_app[j] = 0.f;
+                lim_any[j] = PBRE_ANY(lo_v || up_v);                 // wave-uniform: the row of a joint nobody has at a limit is skipped
+                has_limit = has_limit || lim_any[j];
+            }
+        }
+
+        // ---- the object's half of the step: rows against the table only (this class has no robot-object contact)
+        ObjStep ob;
+        float pose[7], tw0[6];
+        if (obj_on) {
+            PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[LC + k];
+            PBRE_UNROLL for (int k = 0; k < 6; k++) tw0[k] = st[W + LC + k];
+            ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
+        }
+
+        // ---- projected Gauss-Seidel, Bullet order: motors and limits reversed on even sweeps, forward on odd ones; contacts
+        const float mlim = P.motor_imp, llim = P.limit_imp;
+        // Column j of M^-1 is fetched from LDS one row ahead of its use (`cn`, loaded before the arithmetic of the current row is
+        // written down, so the reads are in flight while the current row's 20 FMAs issue).
+        float cc[ND], cn[ND];
+        auto fetch = [&](int j, float* c) {
+            int o = 0;
+            PBRE_OPAQUE_I(o);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) c[k] = Mi.geto(sym(k, j), o);
+        };
+        auto axpy = [&](const float* c, float d) { PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(d, c[k], w[k]); };
+        auto motor = [&](int j, const float* c) {        // delta form, see Fast::step_t
+            const float nt = fmaf(-m_dinv[j], w[j], m_rhs[j]);
+            const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
+            m_app[j] += d;
+            axpy(c, d);
+        };
+        float m_peak = 0.f;              // clamp-free rows: the largest |applied impulse| any motor ever had
+        auto motor_free = [&](int j, const float* c) {
+            const float d = fmaf(-m_dinv[j], w[j], m_rhs[j]);
+            m_app[j] += d;
+            m_peak = fmaxf(m_peak, fabsf(m_app[j]));
+            axpy(c, d);
+        };
+        auto limit = [&](int j) {
+            float c[ND];
+            fetch(j, c);
+            const float t = fmaf(m_dinv[j] * l_dir[j], w[j], -l_rhs[j]);
+            const float s = med3(l_app[j] - t, 0.f, llim);
+            const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
+            axpy(c, d);
+        };
+        auto motors = [&](auto&& mrow, bool rev) {          // (two buffers used alternately: after unrolling every index is static, no copies)
+            fetch(rev ? ND - 1 : 0, cc);
+            PBRE_UNROLL for (int t = 0; t < ND; t++) {
+                const int j = rev ? ND - 1 - t : t;
+                float* cur = (t & 1) ? cn : cc;
+                float* nxt = (t & 1) ? cc : cn;
+                if (t + 1 < ND) fetch(rev ? j - 1 : j + 1, nxt);
+                mrow(j, cur);
+            }
+        };
+        auto solve = [&](auto&& mrow) {
+            for (int it = 0; it < P.iters; it += 2) {
+                motors(mrow, true);
+                if (has_limit) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) if (lim_any[j]) limit(j); }
+                if (obj_on) ob.sweep();
+                if (it + 1 >= P.iters) break;
+                if (has_limit) { PBRE_UNROLL for (int j = 0; j < ND; j++) if (lim_any[j]) limit(j); }
+                motors(mrow, false);
+                if (obj_on) ob.sweep();
+            }
+        };
+        // Clamp-free motor rows first (no motor comes near PyBullet's default force bound; the largest |applied impulse| is tracked off
+        // the row-to-row chain); one test after the loop decides, a wave in which it fails starts over with the clamping rows (same
+        // deltas bit for bit wherever a clamp does not bind).
+        PBRE_REG_BARRIER();
+        // everything the loop reads starts a fresh live range here
+        PBRE_UNROLL for (int k = 0; k < (MREG > 0 ? MREG : 1); k++) PBRE_OPAQUE_F(Mi.reg[k]);
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { PBRE_OPAQUE_F(m_dinv[j]); PBRE_OPAQUE_F(m_rhs[j]); PBRE_OPAQUE_F(w[j]); }
+        if (obj_on) {
+            PBRE_UNROLL for (int c = 0; c < ObjStep::NK; c++) {
+                PBRE_OPAQUE_F(ob.c_rx[c]); PBRE_OPAQUE_F(ob.c_ry[c]); PBRE_OPAQUE_F(ob.c_rz[c]); PBRE_OPAQUE_F(ob.r_rhs[c]);
+                PBRE_UNROLL for (int d = 0; d < 3; d++) { PBRE_OPAQUE_F(ob.r_dinv[c][d]); PBRE_UNROLL for (int e = 0; e < 3; e++) PBRE_OPAQUE_F(ob.g[c][d][e]); }
+            }
+        }
+        solve(motor_free);
+        {
+            const bool over = !(m_peak <= mlim);      // (a NaN fails the test as well)
+#ifdef PBRE_LANE_NOFALLBACK
+            if (false) {
+#else
+            if (PBRE_ANY(over)) {
+#endif
+                PBRE_UNROLL for (int j = 0; j < ND; j++) { w[j] = w0[j]; m_app[j] = 0.f; l_app[j] = 0.f; }
+                if (obj_on) ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
+                solve(motor);
+            }
+        }
+
+        // ---- integrate (semi-implicit Euler; quaternion exponential map for the object)
+        PBRE_REG_BARRIER();
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            const float v = clampf(w[j], -vmax, vmax);
+            qd[j] = skip ? st[W + j] : v; q[j] = skip ? st[j] : fmaf(dt, v, st[j]);
+            st[j] = q[j]; st[W + j] = qd[j];
+        }
+        V3 op = v3(st[LC], st[LC + 1], st[LC + 2]);
+        Q4 oq; oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+        if (obj_on && !skip) {
+            float o[6];
+            ob.result(P, o);
+            const V3 ov = v3(o[0], o[1], o[2]), ow = v3(o[3], o[4], o[5]);
+            op = v3(fmaf(dt, ov.x, op.x), fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
+            float ang = norm(ow);
+            if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * inv_dt;
+            const float sc_ = ang < 0.001f ? 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang : sinf(0.5f * ang * dt) / ang;
+            Q4 dq; dq.x = ow.x * sc_; dq.y = ow.y * sc_; dq.z = ow.z * sc_; dq.w = cosf(ang * dt * 0.5f);
+            const Q4 nq = FX::qmul(dq, oq);
+            const float in = 1.f / sqrtf(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
+            oq.x = nq.x * in; oq.y = nq.y * in; oq.z = nq.z * in; oq.w = nq.w * in;
+            st[LC] = op.x; st[LC + 1] = op.y; st[LC + 2] = op.z; st[LC + 3] = oq.x; st[LC + 4] = oq.y; st[LC + 5] = oq.z; st[LC + 6] = oq.w;
+            PBRE_UNROLL for (int k = 0; k < 6; k++) st[W + LC + k] = o[k];
+        }
+        const Tab* T2 = &T;
+        PBRE_LAUNDER(T2);
+        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id);
+    }
+
+    // ------------------------------------------------------------------------------------------------ class + end effector
+    struct Tail { int cls; M3 Re; V3 pe, Va, Vl; };
+    // One streaming sweep over the links: class of the state (any robot collision sphere within the contact margin of the object
+    // or the table -> 1) and, when qd is given, the frame and spatial velocity of the end effector's owner link.
+    static PBRE_HD Tail sweep(const Tab& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags) {
+        const bool obj_on = !(flags & 1);
+        Tail t;
+        const M3 Ro = FX::quat_R(oq);
+        const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
+        const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
+        M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+        const float orad = sqrtf(dot(oh, oh)), ztop = tc.z + th.z;
+        int nO = 0, nT = 0;
+        const int eo = T.ee_owner;
+        t.Va = v3(0.f, 0.f, 0.f); t.Vl = v3(0.f, 0.f, 0.f); t.pe = v3(0.f, 0.f, 0.f);
+        PBRE_UNROLL for (int k = 0; k < 9; k++) t.Re.m[k] = 0.f;
+        M3 R[ND]; V3 p[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+            const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+            M3 Rl; V3 pl, ax;
+            joint_xf(T, j, q[j], Rl, pl, ax);
+            if (Topo::parent(j) < 0) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+            for (int s = 0; s < T.nspheres; s++) {
+                if (T.s_owner[s] != j) continue;
+                const V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][s], T.s_c[1][s], T.s_c[2][s])));
+                // cheap wave-wide lower bounds first (bounding sphere of the object; height above the table top)
+                const float sr = T.s_r[s];
+                if (obj_on) {
+                    const V3 dd = sub(sc, op);
+                    const float reach = sr + P.margin + orad;
+                    if (PBRE_ANY(!(dot(dd, dd) >= reach * reach)) && FX::sphere_box_dist(sc, sr, op, Ro, oh) < P.margin) nO++;
+                }
+                if (PBRE_ANY(!(sc.z - sr - ztop >= P.margin)) && FX::sphere_box_dist(sc, sr, tc, Id, th) < P.margin) nT++;
+            }
+            if (qd) {
+                bool anc = false;      // is j an ancestor-or-self of the EE owner?  (compile-time tree, uniform runtime owner)
+                PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && eo == e) anc = true;
+                if (anc) {
+                    const V3 aw = mv(R[j], ax);
+                    if (Topo::jtype(j) == 1) { t.Va = add(t.Va, scl(aw, qd[j])); t.Vl = add(t.Vl, scl(cross(p[j], aw), qd[j])); }
+                    else t.Vl = add(t.Vl, scl(aw, qd[j]));
+                }
+                if (eo == j) { t.Re = R[j]; t.pe = p[j]; }
+            }
+        }
+        t.cls = (nO != 0 || nT != 0) ? 1 : 0;
+        return t;
+    }
+    static PBRE_HD int classify_state(const Tab& T, const Params& P, const float* st, int flags) {
+        float q[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
+        Q4 oq; oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+        return sweep(T, P, q, nullptr, v3(st[LC], st[LC + 1], st[LC + 2]), oq, flags).cls;
+    }
+
+    // ------------------------------------------------------------------------------------------------ observation / task
+    // Observation, reward, termination of the state (q, qd, op, oq; already stored in st) and its class.  Same logic as Core::observe
+    // (iCub branches: icub_reach_gym_env.py:262-330, icub_push_gym_env.py:284-373, icub_push_gym_goal_env.py:89-139); with
+    // PBRE_F_AUTO_RESET a finished env restarts from the settled snapshot right here.
+    static PBRE_HD int finish(const Tab& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
+                              float* out, int mode, int flags, unsigned long long env_id) {
+        const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
+        float reward = 0.f, done = 0.f;
+        V3 ee, eul, vee;
+        int cls;
+        // The kinematic sweep is needed for the state the step produced and, when some env of the wave finishes its episode under
+        // PBRE_F_AUTO_RESET, again for the first state of the next one: a two-pass loop around ONE copy of the code.
+        float* X = st + XO;
+        V3 tg = v3(X[0], X[1], X[2]);
+        V3 ee0 = v3(0.f, 0.f, 0.f), eul0 = ee0, vee0 = ee0, op0 = op, tg0 = tg; Q4 oq0 = oq; int cls0 = 0;
+        bool again = false;
+        PBRE_NOUNROLL for (int pass = 0; pass < 2; pass++) {
+            const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
+            cls = tl.cls;
+            if (!want_obs) return cls;
+            {
+                M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
+                const M3 Ree = mm(tl.Re, Eo);
+                ee = add(tl.pe, mv(tl.Re, v3(T.ee_p[0], T.ee_p[1], T.ee_p[2])));
+                vee = add(tl.Vl, cross(tl.Va, ee));
+                eul = FX::quat_euler(FX::R_quat(Ree));
+            }
+            if (pass == 1) {
+                if (again) {
+                    if (P.robot >= 1 && P.task >= 1) { X[12] = norm(sub(ee, op)); X[13] = norm(sub(op, tg)); }     // icub_push_gym_env.py:124-127
+                } else { ee = ee0; eul = eul0; vee = vee0; op = op0; oq = oq0; tg = tg0; cls = cls0; }
+                break;
+            }
+            if (mode & M_TASK) {
+                const float d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
+                const float dsucc = P.task >= 1 ? d2 : d1;
+                const bool succ = dsucc <= P.dist_min;
+                float cnt = X[3], term = X[4];
+                const float mx = (float)P.max_steps;
+                bool left;        // `if self._termination(): break` fired in this iteration of the apply_action loop
+                if (P.task == 2) {
+                    left = cnt > mx;
+                    cnt = cnt > mx ? cnt : cnt + 1.f;
+                    done = (succ || cnt > mx) ? 1.f : 0.f;
+                    reward = succ ? 0.f : -1.f;
+                } else {
+                    const bool d0 = succ || term != 0.f || cnt > mx;
+                    left = d0;
+                    cnt = d0 ? cnt : cnt + 1.f;
+                    term = succ ? 1.f : term;
+                    done = (succ || term != 0.f || cnt > mx) ? 1.f : 0.f;
+                    float base = P.task == 1 ? -d1 - d2 : -d1;
+                    if (P.robot >= 1) {
+                        // iCub (icub_reach_gym_env.py:318-330: the bonus is added; icub_push_gym_env.py:346-373: reward types 0 / 1)
+                        if (P.task == 0) reward = base + (succ ? 1000.f + (100.f - d1 * 80.f) : 0.f);
+                        else {
+                            if (P.reward_type != 0) {
+                                const float r1 = 0.125f * (1.f - d1 / X[12]);
+                                const float r2 = 0.25f * (1.f - d2 / X[13]);
+                                base = r1 + (d1 > 0.1f ? 0.f : r2);
+                            }
+                            reward = base + (succ ? 1000.f : 0.f);
+                        }
+                    } else
+                        reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
+                }
+                X[3] = cnt; X[4] = term;
+                X[14] = ((mode & M_INNER) && left) ? 1.f : 0.f;
+                again = (flags & 2) && !(mode & M_INNER) && done != 0.f;
+            }
+            if (!PBRE_ANY(again)) break;
+            // snapshot reset of the finished envs (settled robot pose and object height of the last full reset, freshly sampled object
+            // pose and target), then the first observation of the new episode in the second pass
+            ee0 = ee; eul0 = eul; vee0 = vee; op0 = op; tg0 = tg; oq0 = oq; cls0 = cls;
+            if (again) {
+                snapshot_reset(T, P, env_id, st);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = 0.f; }
+                op = v3(st[LC], st[LC + 1], st[LC + 2]);
+                oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+                tg = v3(X[0], X[1], X[2]);
+            }
+        }
+        if (out) {
+            const V3 oe = FX::quat_euler(oq);
+            const Q4 qh = FX::euler_quat(eul), qo = FX::euler_quat(oe);
+            const V3 rel = mtv(FX::quat_R(qh), sub(op, ee));
+            Q4 qhi; qhi.x = -qh.x; qhi.y = -qh.y; qhi.z = -qh.z; qhi.w = qh.w;
+            const V3 er = FX::quat_euler(FX::qmul(qhi, qo));
+            // Panda: normalised EE velocity (panda_env.py:174-178); iCub: raw (icub_env.py:233-236)
+            const V3 vn = P.robot >= 1 ? vee : v3(vee.x / 0.04f, (vee.y - 0.01f) / 0.07f, vee.z / 0.03f);
+            out[0] = ee.x; out[1] = ee.y; out[2] = ee.z; out[3] = eul.x; out[4] = eul.y; out[5] = eul.z;
+            out[6] = vn.x; out[7] = vn.y; out[8] = vn.z;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) { const int oi = T.obs_idx[j]; if (oi >= 0) out[9 + oi] = q[j]; }
+            float* o2 = out + 9 + T.n_obs_j;
+            o2[0] = op.x; o2[1] = op.y; o2[2] = op.z; o2[3] = oe.x; o2[4] = oe.y; o2[5] = oe.z;
+            o2[6] = rel.x; o2[7] = rel.y; o2[8] = rel.z; o2[9] = er.x; o2[10] = er.y; o2[11] = er.z;
+            int o = 12;
+            if (P.task >= 1) { o2[12] = tg.x; o2[13] = tg.y; o2[14] = tg.z; o = 15; }
+            o2[o] = reward; o2[o + 1] = done;
+        }
+        return cls;
+    }
+
+    // ------------------------------------------------------------------------------------------------ reset helpers (scalar, as Core's)
+    static PBRE_HD float clamps(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+    static PBRE_HD void snapshot_reset(const Tab& T, const Params& P, unsigned long long env_id, float* st) {
+        const unsigned ep = (unsigned)(int)st[XO + 5] + 1u;
+        float* ob = st + LC;
+        float* X = st + XO;
+        for (int k = 0; k < S::STATE; k++) st[k] = 0.f;
+        for (int k = 0; k < ND; k++) st[k] = T.rst_q[k];                // settled robot pose
+        const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
+        const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;
+        float px = x_min + 0.5f * (x_max - x_min), py = y_min + 0.5f * (y_max - y_min);
+        float yaw = 0.78539816339744831f;
+        unsigned r[4];
+        if (P.obj_std > 0.f) {
+            FX::philox((unsigned)env_id, (unsigned)(env_id >> 32), ep, 0u, P.seed_lo, P.seed_hi, r);
+            px += -P.obj_std + 2.f * P.obj_std * FX::u01(r[0]);
+            py += -P.obj_std + 2.f * P.obj_std * FX::u01(r[1]);
+            yaw = -0.78539816339744831f + 1.57079632679489662f * FX::u01(r[2]);
+        }
+        ob[0] = clamps(px, x_min, x_max); ob[1] = clamps(py, y_min, y_max); ob[2] = P.rst_objz;      // settled object height
+        ob[3] = 0.f; ob[4] = 0.f; ob[5] = sinf(0.5f * yaw); ob[6] = cosf(0.5f * yaw);
+        X[5] = (float)(int)ep;
+        if (P.use_ik) for (int k = 0; k < 6; k++) X[6 + k] = P.home_hand[k];
+        if (P.task >= 1) {                                               // sample_tg_pose on the settled object position
+            const float tx_min = P.ws[0][0] + 0.07f, tx_max = P.ws[0][1] - 0.07f;
+            float tx = ob[0] + 0.05f, ty = ob[1] + 0.05f;
+            if (P.tg_std > 0.f) {
+                FX::philox((unsigned)env_id, (unsigned)(env_id >> 32), ep, 1u, P.seed_lo, P.seed_hi, r);
+                const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = FX::u01(r[1]);
+                const float rad = sqrtf(-2.f * logf(u1)) * P.tg_std;
+                tx = ob[0] + rad * cosf(6.28318530717958648f * u2);
+                ty = ob[1] + rad * sinf(6.28318530717958648f * u2);
+            }
+            X[0] = clamps(tx, tx_min, tx_max); X[1] = clamps(ty, P.ws[1][0], P.ws[1][1]); X[2] = ob[2];
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------ Cartesian control
+    // apply_action, IK branch (icub_reach_gym_env.py:204-230 + icub_env.py:262-330): accumulate the scaled action on the commanded
+    // hand pose (X[6..11]), clip rotation and workspace, damped-least-squares IK from the current joint angles over the joints of
+    // the chain to the end effector; same algorithm and stopping rule as Core::ik_targets / oracle orc_ik.  Writes tgt[0..ND) and
+    // X[6..11].  (The reset-time targets of the home hand pose are the lane-group kernel's.)
+    static PBRE_HD void ik_targets(const Tab& T, const Params& P, float* st, const float* act, float* tgt) {
+        float* X = st + XO;
+        V3 pos = v3(fmaf(act[0], P.ik_ps, X[6]), fmaf(act[1], P.ik_ps, X[7]), fmaf(act[2], P.ik_ps, X[8]));
+        V3 eul = v3(X[9], X[10], X[11]);
+        if (P.ctrl_ori) {
+            eul.x = clampf(fmaf(act[3], P.ik_rs, eul.x), P.eu_lim[0][0], P.eu_lim[0][1]);
+            eul.y = clampf(fmaf(act[4], P.ik_rs, eul.y), P.eu_lim[1][0], P.eu_lim[1][1]);
+            eul.z = clampf(fmaf(act[5], P.ik_rs, eul.z), P.eu_lim[2][0], P.eu_lim[2][1]);
+        }
+        pos.x = clampf(pos.x, P.rws[0][0], P.rws[0][1]); pos.y = clampf(pos.y, P.rws[1][0], P.rws[1][1]); pos.z = clampf(pos.z, P.rws[2][0], P.rws[2][1]);
+        if (X[14] == 0.f) { X[6] = pos.x; X[7] = pos.y; X[8] = pos.z; X[9] = eul.x; X[10] = eul.y; X[11] = eul.z; }   // (an env that left the apply_action loop keeps its pose)
+        const M3 Rt = FX::quat_R(FX::euler_quat(eul));
+        const V3 tp = add(pos, mv(Rt, v3(P.ik_off[0], P.ik_off[1], P.ik_off[2])));
+        const int eo = T.ee_owner;
+        M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
+        float q[ND], q0[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; q0[j] = q[j]; }
+        for (int it = 0; it < P.ik_iters; it++) {
+            // FK of the chain links only (a link off the chain has no chain link below it)
+            M3 R[ND]; V3 p[ND], aw[ND];
+            M3 Re = Eo; V3 po = v3(0.f, 0.f, 0.f);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                if (!T.on_chain[j]) continue;
+                const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
+                M3 Rl; V3 pl, ax;
+                joint_xf(T, j, q[j], Rl, pl, ax);
+                if (Topo::parent(j) < 0) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
+                aw[j] = mv(R[j], ax);
+                if (eo == j) { Re = R[j]; po = p[j]; }
+            }
+            const V3 pe = add(po, mv(Re, v3(T.ee_lp[0], T.ee_lp[1], T.ee_lp[2])));
+            float e[6];
+            e[0] = tp.x - pe.x; e[1] = tp.y - pe.y; e[2] = tp.z - pe.z;
+            const bool go = sqrtf(fmaf(e[0], e[0], fmaf(e[1], e[1], e[2] * e[2]))) >= P.ik_res;
+            if (!PBRE_ANY(go)) break;
+            {   // orientation error as a world-frame rotation vector: axis-angle of Rt (Re Eo)^T
+                const M3 Ree = mm(Re, Eo);
+                M3 Rr;
+                PBRE_UNROLL for (int a = 0; a < 3; a++)
+                    PBRE_UNROLL for (int b = 0; b < 3; b++)
+                        Rr.m[a*3+b] = fmaf(Rt.m[a*3], Ree.m[b*3], fmaf(Rt.m[a*3+1], Ree.m[b*3+1], Rt.m[a*3+2] * Ree.m[b*3+2]));
+                const float sx = Rr.m[7] - Rr.m[5], sy = Rr.m[2] - Rr.m[6], sz = Rr.m[3] - Rr.m[1];
+                const float s2 = sqrtf(fmaf(sx, sx, fmaf(sy, sy, sz * sz))) * 0.5f;
+                const float c2 = (Rr.m[0] + Rr.m[4] + Rr.m[8] - 1.f) * 0.5f;
+                const float ang = atan2f(s2, c2);
+                const float f = s2 > 1e-9f ? ang / (2.f * fmaxf(s2, 1e-30f)) : 0.5f;
+                e[3] = f * sx; e[4] = f * sy; e[5] = f * sz;
+            }
+            // A = J J^T + lambda^2 I over the chain joints (column j: [S_l + S_a x pe ; S_a]), Cholesky, y = A^-1 e, dq = J^T y
+            float A[6][6];
+            PBRE_UNROLL for (int a = 0; a < 6; a++) PBRE_UNROLL for (int b = 0; b <= a; b++) A[a][b] = a == b ? P.ik_l2 : 0.f;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                if (!T.on_chain[j]) continue;
+                const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
+                const V3 ja = Topo::jtype(j) == 1 ? aw[j] : v3(0.f, 0.f, 0.f);
+                const float J[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
+                PBRE_UNROLL for (int a = 0; a < 6; a++) PBRE_UNROLL for (int b = 0; b <= a; b++) A[a][b] = fmaf(J[a], J[b], A[a][b]);
+            }
+            float y[6];
+            PBRE_UNROLL for (int a = 0; a < 6; a++)
+                PBRE_UNROLL for (int b = 0; b <= a; b++) {
+                    float sum = A[a][b];
+                    PBRE_UNROLL for (int k = 0; k < b; k++) sum = fmaf(-A[a][k], A[b][k], sum);
+                    A[a][b] = a == b ? sqrtf(sum) : sum / A[b][b];
+                }
+            PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum / A[a][a]; }
+            PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum / A[a][a]; }
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                if (!T.on_chain[j]) continue;
+                const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
+                const V3 ja = Topo::jtype(j) == 1 ? aw[j] : v3(0.f, 0.f, 0.f);
+                const float dq = fmaf(jl.x, y[0], fmaf(jl.y, y[1], fmaf(jl.z, y[2], fmaf(ja.x, y[3], fmaf(ja.y, y[4], ja.z * y[5])))));
+                q[j] = go ? q[j] + dq : q[j];
+            }
+        }
+        // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
+        // their current angle
+        PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = T.on_chain[j] ? q[j] : (T.blocked[j] ? T.home[j] : q0[j]);
+    }
+};
+
+}  // namespace pbre

@@ -32,6 +32,17 @@ struct ObjStep {
     // o_m, o_mu, o_kl: this env's object mass / lateral friction / linear damping (pbre_set_physics_per_env; the principal inertias
     // P.obj_I scale with o_m / P.obj_m)
     static PBRE_HD void run_p(const Params& P, const float* pose, const float* tw, float* o, float o_m, float o_mu, float o_kl) {
+        ObjStep s;
+        s.setup(P, pose, tw, o_m, o_mu, o_kl);
+        for (int it = 0; it < P.iters; it++) s.sweep();
+        s.result(P, o);
+    }
+
+    // The same step in three parts, for a caller that runs the object rows inside its own solver loop (pbre_lane.hpp: one sweep per
+    // iteration next to the robot's rows, so that the two dependency chains overlap): setup, P.iters x sweep, result.
+    float vx, vy, vz, wx, wy, wz, mu;
+    float c_rx[NK], c_ry[NK], c_rz[NK], g[NK][3][3], r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
+    PBRE_HD void setup(const Params& P, const float* pose, const float* tw, float o_m, float o_mu, float o_kl) {
         const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
         const float isc = o_m / P.obj_m;
         const float px = pose[0], py = pose[1], pz = pose[2];
@@ -40,7 +51,7 @@ struct ObjStep {
         R[0] = 1.f - 2.f * (y*y + z*z); R[1] = 2.f * (x*y - w*z);       R[2] = 2.f * (x*z + w*y);
         R[3] = 2.f * (x*y + w*z);       R[4] = 1.f - 2.f * (x*x + z*z); R[5] = 2.f * (y*z - w*x);
         R[6] = 2.f * (x*z - w*y);       R[7] = 2.f * (y*z + w*x);       R[8] = 1.f - 2.f * (x*x + y*y);
-        float vx = tw[0], vy = tw[1], vz = tw[2], wx = tw[3], wy = tw[4], wz = tw[5];
+        vx = tw[0]; vy = tw[1]; vz = tw[2]; wx = tw[3]; wy = tw[4]; wz = tw[5];
         {   // unconstrained velocity: gravity, linear / angular damping, gyroscopic torque  w x (I_w w)
             const float I0 = P.obj_I[0] * isc, I1 = P.obj_I[1] * isc, I2 = P.obj_I[2] * isc;
             const float lx = I0 * (R[0]*wx + R[3]*wy + R[6]*wz), ly = I1 * (R[1]*wx + R[4]*wy + R[7]*wz), lz = I2 * (R[2]*wx + R[5]*wy + R[8]*wz);
@@ -58,14 +69,13 @@ struct ObjStep {
         // object-table contacts: the (at most NK) box vertices closest to their support surface within the margin, in vertex order.
         // Impulses in delta-v units (a = lambda / m): a row along dir at lever arm r has J = [dir, r x dir], changes the twist by
         // (a dir, a g) with g = m I_w^-1 (r x dir), and J M^-1 J^T = (1 + (r x dir) . g) / m.
-        const float mu = o_mu * P.tab_mu;
+        mu = o_mu * P.tab_mu;
         float Ii[6];       // m * I_w^-1 = m R diag(1/I) R^T: xx yy zz xy xz yz
         {
             const float a = P.obj_m / P.obj_I[0], b = P.obj_m / P.obj_I[1], c = P.obj_m / P.obj_I[2];      // (m / I is independent of the per-env mass)
             Ii[0] = a*R[0]*R[0] + b*R[1]*R[1] + c*R[2]*R[2]; Ii[1] = a*R[3]*R[3] + b*R[4]*R[4] + c*R[5]*R[5]; Ii[2] = a*R[6]*R[6] + b*R[7]*R[7] + c*R[8]*R[8];
             Ii[3] = a*R[0]*R[3] + b*R[1]*R[4] + c*R[2]*R[5]; Ii[4] = a*R[0]*R[6] + b*R[1]*R[7] + c*R[2]*R[8]; Ii[5] = a*R[3]*R[6] + b*R[4]*R[7] + c*R[5]*R[8];
         }
-        float c_rx[NK], c_ry[NK], c_rz[NK], g[NK][3][3], r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             c_rx[c] = c_ry[c] = c_rz[c] = 0.f; r_rhs[c] = 0.f;
             PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = 0.f; r_app[c][d] = 0.f; g[c][d][0] = g[c][d][1] = g[c][d][2] = 0.f; }
@@ -107,34 +117,37 @@ struct ObjStep {
                 }
             }
         }
-        // P.iters sweeps, normals then frictions; an unused slot has dinv = rhs = 0 and its rows change nothing
-        for (int it = 0; it < P.iters; it++) {
-            PBRE_UNROLL for (int c = 0; c < NK; c++) {
-                // rows in delta form (clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied)): one operation less
-                // on the row-to-row dependency chain, which is all this kernel's time; the upper bound 1e10 of a normal row never binds
-                const float jv = vz + c_ry[c] * wx - c_rx[c] * wy;
-                const float dd = fmaxf(fmaf(-jv, r_dinv[c][0], r_rhs[c]), -r_app[c][0]);
-                r_app[c][0] += dd;
-                vz += dd; wx = fmaf(dd, g[c][0][0], wx); wy = fmaf(dd, g[c][0][1], wy); wz = fmaf(dd, g[c][0][2], wz);
+    }
+    // one sweep: normals then frictions; an unused slot has dinv = rhs = 0 and its rows change nothing
+    PBRE_HD void sweep() {
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            // rows in delta form (clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied)): one operation less
+            // on the row-to-row dependency chain, which is all this kernel's time; the upper bound 1e10 of a normal row never binds
+            const float jv = vz + c_ry[c] * wx - c_rx[c] * wy;
+            const float dd = fmaxf(fmaf(-jv, r_dinv[c][0], r_rhs[c]), -r_app[c][0]);
+            r_app[c][0] += dd;
+            vz += dd; wx = fmaf(dd, g[c][0][0], wx); wy = fmaf(dd, g[c][0][1], wy); wz = fmaf(dd, g[c][0][2], wz);
+        }
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            const float hi = mu * r_app[c][0];
+            {
+                const float jv = -vy + c_rz[c] * wx - c_rx[c] * wz;
+                float dd = med3(-jv * r_dinv[c][1], -hi - r_app[c][1], hi - r_app[c][1]);
+                dd = hi > 0.f ? dd : 0.f;
+                r_app[c][1] += dd;
+                vy -= dd; wx = fmaf(dd, g[c][1][0], wx); wy = fmaf(dd, g[c][1][1], wy); wz = fmaf(dd, g[c][1][2], wz);
             }
-            PBRE_UNROLL for (int c = 0; c < NK; c++) {
-                const float hi = mu * r_app[c][0];
-                {
-                    const float jv = -vy + c_rz[c] * wx - c_rx[c] * wz;
-                    float dd = med3(-jv * r_dinv[c][1], -hi - r_app[c][1], hi - r_app[c][1]);
-                    dd = hi > 0.f ? dd : 0.f;
-                    r_app[c][1] += dd;
-                    vy -= dd; wx = fmaf(dd, g[c][1][0], wx); wy = fmaf(dd, g[c][1][1], wy); wz = fmaf(dd, g[c][1][2], wz);
-                }
-                {
-                    const float jv = vx + c_rz[c] * wy - c_ry[c] * wz;
-                    float dd = med3(-jv * r_dinv[c][2], -hi - r_app[c][2], hi - r_app[c][2]);
-                    dd = hi > 0.f ? dd : 0.f;
-                    r_app[c][2] += dd;
-                    vx += dd; wx = fmaf(dd, g[c][2][0], wx); wy = fmaf(dd, g[c][2][1], wy); wz = fmaf(dd, g[c][2][2], wz);
-                }
+            {
+                const float jv = vx + c_rz[c] * wy - c_ry[c] * wz;
+                float dd = med3(-jv * r_dinv[c][2], -hi - r_app[c][2], hi - r_app[c][2]);
+                dd = hi > 0.f ? dd : 0.f;
+                r_app[c][2] += dd;
+                vx += dd; wx = fmaf(dd, g[c][2][0], wx); wy = fmaf(dd, g[c][2][1], wy); wz = fmaf(dd, g[c][2][2], wz);
             }
         }
+    }
+    PBRE_HD void result(const Params& P, float* o) const {
+        const float vmax = P.vmax;
         o[0] = clampf(vx, -vmax, vmax); o[1] = clampf(vy, -vmax, vmax); o[2] = clampf(vz, -vmax, vmax);
         o[3] = clampf(wx, -vmax, vmax); o[4] = clampf(wy, -vmax, vmax); o[5] = clampf(wz, -vmax, vmax);
     }

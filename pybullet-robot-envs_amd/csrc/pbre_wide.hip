@@ -73,6 +73,11 @@ static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hi
         // iteration r applies action * scale^(r+1); all but the last iteration only simulate, test termination and count
         w->P.act_scale = (r ? w->P.act_scale : 1.f) * P0.act_scale; w->P.ik_ps = (r ? w->P.ik_ps : 1.f) * P0.ik_ps; w->P.ik_rs = (r ? w->P.ik_rs : 1.f) * P0.ik_rs;
         const bool last = r + 1 == reps;
+        if (w->lane_ok()) {     // lane-per-env path (pbre_lane.hpp)
+            if (w->P.use_ik) w->launch_lane_ik(d_act, s);
+            e = w->launch_lane_step(w->P.use_ik ? (last ? WideEngine::K_STEP_TGT : WideEngine::K_INNER_TGT) : (last ? WideEngine::K_STEP_ACT : WideEngine::K_INNER_ACT),
+                                    d_act, last ? d_out : nullptr, flags, s, last);
+        } else
         if (!w->P.use_ik) e = wstep(w, last ? WideEngine::K_STEP_ACT : WideEngine::K_INNER_ACT, w->state, w->tgt, w->n, d_act, last ? d_out : nullptr, flags, s, last);
         else {
             w->launch_ik(false, w->state, d_act, w->tgt, w->n, s, true);
@@ -102,7 +107,7 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     const int nd = table_ndof(*cfg);
     WideEngine* w = nd > Shape64::NJ ? make_hands_engine()
                   : (cfg->robot_level && nd <= ShapePA::NJ ? static_cast<WideEngine*>(new WideImpl<ShapePA, DevLanes32>())     // pandaEnv alone
-                  : (nd <= Shape32::NJ ? static_cast<WideEngine*>(new WideImpl<Shape32, DevLanes32>())
+                  : (nd <= Shape32::NJ ? make_lane_engine()
                                        : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>())));
     w->cfg = *cfg;
     std::string e = w->tables(*cfg);
@@ -139,6 +144,7 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     }
     CK(hipMalloc(&w->d_act, n * w->act_dim * sizeof(float)));
     CK(hipMalloc(&w->d_out, n * w->ow * sizeof(float)));
+    CK(w->lane_alloc());
     CK(hipMalloc(&w->d_ids, n * sizeof(unsigned long long)));
     CK(hipMalloc(&w->d_ep, n * sizeof(unsigned)));
     CK(hipMalloc(&w->d_idx, n * sizeof(int)));
@@ -182,12 +188,14 @@ int wide_settle(WideEngine* w, int32_t n, int32_t flags) {
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
     WCHK(wsettle(w, w->state, w->tgt, w->n, n, flags & PBRE_F_NO_OBJECT, w->stream));
+    w->lane_invalidate();
     WCHK(hipStreamSynchronize(w->stream));
     return PBRE_OK;
 }
 int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
+    w->lane_invalidate();
     std::vector<int> idx;
     for (int e = 0; e < w->n; e++) if (!mask || mask[e]) idx.push_back(e);
     const int cnt = (int)idx.size();
@@ -247,6 +255,7 @@ int wide_reset_snapshot(WideEngine* w, const uint8_t* mask, float* obs) {
     WCHK(wquiesce(w));
     if (!w->d_mask) WCHK(hipMalloc(&w->d_mask, (size_t)w->n));
     WCHK(hipMemcpyAsync(w->d_mask, mask, (size_t)w->n, hipMemcpyHostToDevice, w->stream));
+    w->lane_invalidate();
     w->launch_snapshot_reset(w->d_mask, w->stream);
     WCHK(hipGetLastError());
     WCHK(hipStreamSynchronize(w->stream));
@@ -290,6 +299,7 @@ int wide_set_state(WideEngine* w, const float* s) {
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
     WCHK(hipMemcpy(w->state, s, (size_t)w->n * w->sf * 4, hipMemcpyHostToDevice));
+    w->lane_invalidate();
     return PBRE_OK;
 }
 int wide_set_motors(WideEngine* w, int32_t cnt, const int32_t* dofs, const float* targets, double kp, double max_force, double max_vel, const uint8_t* mask) {
@@ -351,6 +361,7 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
     w->cfg.phys = *p; w->P = P2;
+    w->lane_invalidate();          // the contact margin may have changed
     return PBRE_OK;
 }
 int wide_obs_limits(const WideEngine* w, float* lo, float* hi) { w->limits(lo, hi); return PBRE_OK; }
@@ -372,7 +383,11 @@ int wide_timing(const WideEngine* w, double* ms, int32_t n) {
     return PBRE_OK;
 }
 int wide_kernel_info(const WideEngine* w, int32_t* info, int32_t n) {
-    const int v[7] = {-1, w->vgprs(), 0, 0, w->n, 0, -1};      // same slots as the Panda engine: [1] VGPRs of the lane-group kernel, [4] envs it steps
+    int lv = -1, cn = 0;
+    const bool lane = w->lane_ok() && const_cast<WideEngine*>(w)->lane_info(&lv, &cn);
+    // same slots as the Panda engine: [0] VGPRs of the lane-per-env kernel, [1] of the lane-group kernel, [2] lane-per-env path in use,
+    // [3] envs in the simple class, [4] envs the lane-group kernel steps when the lane path is off, [5] complex envs
+    const int v[7] = {lane ? lv : -1, w->vgprs(), lane ? 1 : 0, lane ? w->n - cn : 0, lane ? 0 : w->n, lane ? cn : 0, -1};
     for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
     return PBRE_OK;
 }

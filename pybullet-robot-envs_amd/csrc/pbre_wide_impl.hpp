@@ -169,6 +169,13 @@ struct WideEngine {
     virtual void snapshot(const float* rec) = 0;
     virtual void limits(float* lo, float* hi) const = 0;
     virtual int vgprs() const = 0;
+    // lane-per-env path (pbre_lane.hpp; the Shape32 engine of pbre_wide.hip overrides these): steps of the whole batch on `state`
+    virtual bool lane_ok() const { return false; }
+    virtual hipError_t lane_alloc() { return hipSuccess; }   // after the shape-independent buffers exist
+    virtual void lane_invalidate() {}                  // the records were changed by something other than a lane step: classes are stale
+    virtual void launch_lane_ik(const float* act, hipStream_t s) {}
+    virtual hipError_t launch_lane_step(int kind, const float* act, float* out, int flags, hipStream_t s, bool timed) { return hipSuccess; }
+    virtual int lane_info(int* vg, int* complex_now) { return 0; }
 };
 
 template <class S, class L>
@@ -260,5 +267,6 @@ struct WideImpl : WideEngine {
 
 
 WideEngine* make_hands_engine();       // pbre_hands.hip
+WideEngine* make_lane_engine();        // pbre_lane.hip
 
 }  // namespace pbre
