@@ -84,6 +84,218 @@ __global__ __launch_bounds__(LTPB) void kw_lane_ik(const TablesT<Shape32>* __res
     if (env >= n) return;
     LaneD::ik_targets(*T, P, state + (size_t)env * Shape32::STATE, actions + (size_t)env * act_dim, tgt + (size_t)env * Shape32::TGT);
 }
+
+// ------------------------------------------------------------------ the quad pipeline: kw_dyn -> kw_quad -> kw_fin
+// The lane-per-env kernel above keeps a whole SIMD's register file and 40 KB of LDS per wave and still runs as a lone, latency-bound
+// wave per SIMD.  The pipeline below splits the step where the data layouts want to differ:
+//   kw_dyn   one thread per env: kinematics + dynamics (Lane::dynamics) -> bias torques and the joint-space inertia M, streamed to an
+//            HBM side buffer (no LDS, no M^-1 in this kernel);
+//   kw_quad  FOUR lanes per env (a DPP quad; 16 envs per wave): lane r owns DoF 5r..5r+4, i.e. five rows of M -- 100 registers, no
+//            LDS.  Gauss-Jordan inversion across the quad, unconstrained velocities, motor / limit rows, the 150 PGS sweeps (a row is
+//            one fma for its delta, a quad broadcast folded into the five fmacs of the velocity update), integration of the joints;
+//   kw_fin   one thread per env: the object's pose from kw_obj's twist, observation / reward / termination / auto-reset / class
+//            (Lane::finish).
+// Side buffer layout: float4 chunks [chunk][env * 4 + r]: chunks 0..24 = rows 5r..5r+4 of M (element i * 20 + col), chunk 25 and the
+// first float of chunk 26 = tau[5r..5r+4]; a wave of kw_quad reads each chunk as one contiguous 1 KB block.
+constexpr int QD = 5, DCH = 27;
+static_assert(LaneD::ND == 4 * QD, "four lanes per env, five DoF each");
+struct DynSink {
+    float* base;        // dyn + env * 16 floats (the env's four float4 slots of chunk 0)
+    size_t cs;          // floats per chunk: 16 * n_pad
+    __device__ __forceinline__ void st(int row, int col, float v) { const int e = (row % QD) * 20 + col; base[(size_t)(e / 4) * cs + (row / QD) * 4 + (e % 4)] = v; }
+    __device__ __forceinline__ void put(int j, int i, float v) { st(j, i, v); if (i != j) st(i, j, v); }
+    __device__ __forceinline__ void zero(int, int) {}      // unrelated branch pairs: the buffer is zeroed once, nobody writes them
+    __device__ __forceinline__ void tau(int j, float v) { const int e = 100 + (j % QD); base[(size_t)(e / 4) * cs + (j / QD) * 4 + (e % 4)] = v; }
+};
+__global__ __launch_bounds__(LTPB, 2) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n,
+                                                  const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
+    const int env = blockIdx.x * LTPB + threadIdx.x;
+    if (env >= n || cls_cur[env] != 0) return;
+    const float* st = state + (size_t)env * Shape32::STATE;
+    if (st[2 * Shape32::W + 14] != 0.f) return;          // left the apply_action loop: no simulation step
+    float q[LaneD::ND], qd[LaneD::ND], tau[LaneD::ND];
+    PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
+    DynSink sink; sink.base = dyn + (size_t)env * 16; sink.cs = cs;
+    LaneD::dynamics(*T, P, q, qd, sink, tau);
+    PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.tau(j, tau[j]);
+}
+
+// value of quad lane o in every lane of the quad (o static after unrolling)
+template <int O> __device__ __forceinline__ float qb_t(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), O * 0x55, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float qb(float x, int o) { return o == 0 ? qb_t<0>(x) : (o == 1 ? qb_t<1>(x) : (o == 2 ? qb_t<2>(x) : qb_t<3>(x))); }
+
+__global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                   const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
+                                                   const signed char* __restrict__ cls_cur, const float* __restrict__ dyn, size_t cs) {
+    constexpr int ND = LaneD::ND, W = Shape32::W, XO = 2 * Shape32::W;
+    const int gl = blockIdx.x * LTPB + threadIdx.x;
+    const int env = gl >> 2, r = gl & 3;
+    if (env >= n || cls_cur[env] != 0) return;             // (whole quads)
+    float* st = state + (size_t)env * Shape32::STATE;
+    if (st[XO + 14] != 0.f) return;
+    const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
+    float own[4];                                          // 1 on the lane that owns block o
+    PBRE_UNROLL for (int o = 0; o < 4; o++) own[o] = r == o ? 1.f : 0.f;
+
+    // ---- rows 5r..5r+4 of M and the bias torques of this lane's DoF
+    float A[QD][ND], tl[QD];
+    {
+        const float4* d4 = reinterpret_cast<const float4*>(dyn);
+        const size_t c4s = cs / 4;
+        PBRE_UNROLL for (int c = 0; c < 25; c++) {
+            const float4 v = d4[(size_t)c * c4s + gl];
+            A[(4 * c) / ND][(4 * c) % ND] = v.x; A[(4 * c + 1) / ND][(4 * c + 1) % ND] = v.y;
+            A[(4 * c + 2) / ND][(4 * c + 2) % ND] = v.z; A[(4 * c + 3) / ND][(4 * c + 3) % ND] = v.w;
+        }
+        const float4 t0 = d4[(size_t)25 * c4s + gl];
+        tl[0] = t0.x; tl[1] = t0.y; tl[2] = t0.z; tl[3] = t0.w; tl[4] = dyn[(size_t)26 * cs + (size_t)gl * 4];
+    }
+    const int d0 = QD * r;                                 // this lane's first DoF
+    float q[QD], qd[QD];
+    PBRE_UNROLL for (int i = 0; i < QD; i++) { q[i] = st[d0 + i]; qd[i] = st[W + d0 + i]; }
+    if (P.jd_dt != 0.f) {                                  // implicit joint damping: M + dt C
+        PBRE_UNROLL for (int i = 0; i < QD; i++) {
+            const float a = P.jd_dt * T->jdamp[d0 + i];
+            PBRE_UNROLL for (int o = 0; o < 4; o++) A[i][QD * o + i] = fmaf(a, own[o], A[i][QD * o + i]);
+        }
+    }
+    // ---- M^-1 by in-place Gauss-Jordan (SPD, no pivoting) across the quad: the pivot row is broadcast from its owner; the owner's own
+    //      copy of it is brought to pivot_row / pivot by the same fma as every other row (with f - 1 in place of f)
+    PBRE_UNROLL for (int c = 0; c < ND; c++) {
+        const int o = c / QD, i0 = c % QD;
+        float rc[ND];
+        const float inv = 1.f / qb(A[i0][c], o);
+        PBRE_UNROLL for (int k = 0; k < ND; k++) rc[k] = k == c ? 0.f : qb(A[i0][k], o) * inv;
+        PBRE_UNROLL for (int i = 0; i < QD; i++) {
+            const float f = A[i][c];
+            const float fp = i == i0 ? f - own[o] : f;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) { if (k == c) continue; A[i][k] = fmaf(-fp, rc[k], A[i][k]); }
+            const float off = -f * inv;
+            A[i][c] = i == i0 ? (r == o ? inv : off) : off;
+        }
+    }
+    // ---- unconstrained velocities v* = qd + dt M^-1 tau, motor rows against the running velocity, limit rows (see Lane::step)
+    float w[QD], w0[QD], m_dinv[QD], m_rhs[QD], sabs[QD], l_dir[QD], l_rhs[QD], l_app[QD];
+    unsigned long long lim_b[QD];
+    {
+        float acc[QD];
+        PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = 0.f;
+        PBRE_UNROLL for (int c = 0; c < ND; c++) {
+            const float tc = qb(tl[c % QD], c / QD);
+            PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = fmaf(A[i][c], tc, acc[i]);
+        }
+        PBRE_UNROLL for (int i = 0; i < QD; i++) {
+            const int d = d0 + i;
+            const float wj = fminf(fmaxf(fmaf(dt, acc[i], qd[i]), -vmax), vmax);
+            w[i] = wj; w0[i] = wj;
+            float qdes = T->home[d], kp = T->kp_hold[d], kd = T->kd_hold[d];
+            const float lo = T->lower[d], up = T->upper[d];
+            if (MODE & LaneD::M_TGT) qdes = tgt[(size_t)env * Shape32::TGT + d];
+            if (MODE & LaneD::M_ACTION) {
+                kp = T->kp_act[d]; kd = T->kd_act[d];
+                const int ai = T->act_idx[d];
+                if (ai >= 0) qdes = fminf(fmaxf(fmaf(actions[(size_t)env * act_dim + ai], P.act_scale, q[i]), lo), up);
+            }
+            float diag = 0.f;
+            PBRE_UNROLL for (int o = 0; o < 4; o++) diag = fmaf(own[o], A[i][QD * o + i], diag);
+            m_dinv[i] = 1.f / diag;
+            m_rhs[i] = (kp * (qdes - q[i]) * inv_dt + (1.f - kd) * wj) * m_dinv[i];
+            sabs[i] = 0.f;
+            const float pl = q[i] - lo, pu = up - q[i];
+            const bool lo_v = pl <= 0.f, up_v = !lo_v && pu <= 0.f;
+            l_dir[i] = lo_v ? 1.f : (up_v ? -1.f : 0.f);
+            const float pen = lo_v ? pl : pu;
+            l_rhs[i] = (lo_v || up_v) ? (-pen * P.erp * inv_dt) * m_dinv[i] : 0.f;
+            l_app[i] = 0.f;
+            lim_b[i] = __ballot(lo_v || up_v);             // which quad lanes of the wave have their DoF 5r+i at a limit
+        }
+    }
+    bool lim_on[ND], has_limit = false;                    // row j = 5 o + i runs if any env of the wave has joint j at a limit
+    PBRE_UNROLL for (int j = 0; j < ND; j++) { lim_on[j] = (lim_b[j % QD] & (0x1111111111111111ull << (j / QD))) != 0ull; has_limit = has_limit || lim_on[j]; }
+
+    const float mlim = P.motor_imp, llim = P.limit_imp;
+    auto axpy = [&](int j, float d) { PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(d, A[k][j], w[k]); };
+    auto motor_free = [&](int j) {     // clamp-free row; sabs: sum of |delta| of the motor this lane owns (bounds every value its impulse had)
+        const int o = j / QD, i0 = j % QD;
+        const float d = qb(fmaf(-m_dinv[i0], w[i0], m_rhs[i0]), o);
+        sabs[i0] = fmaf(fabsf(d), own[o], sabs[i0]);
+        axpy(j, d);
+    };
+    auto motor = [&](int j) {          // clamping row, delta form (sabs holds the applied impulse here)
+        const int o = j / QD, i0 = j % QD;
+        const float nt = fmaf(-m_dinv[i0], w[i0], m_rhs[i0]);
+        const float d = qb(__builtin_amdgcn_fmed3f(nt, -mlim - sabs[i0], mlim - sabs[i0]), o);
+        sabs[i0] = fmaf(d, own[o], sabs[i0]);
+        axpy(j, d);
+    };
+    auto limit = [&](int j) {
+        const int o = j / QD, i0 = j % QD;
+        const float t = fmaf(m_dinv[i0] * l_dir[i0], w[i0], -l_rhs[i0]);
+        const float s = __builtin_amdgcn_fmed3f(l_app[i0] - t, 0.f, llim);
+        const float d = qb((s - l_app[i0]) * l_dir[i0], o);
+        l_app[i0] = r == o ? s : l_app[i0];
+        axpy(j, d);
+    };
+    auto solve = [&](auto&& mrow) {
+        for (int it = 0; it < P.iters; it += 2) {
+            PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) mrow(j);
+            if (has_limit) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) if (lim_on[j]) limit(j); }
+            if (it + 1 >= P.iters) break;
+            if (has_limit) { PBRE_UNROLL for (int j = 0; j < ND; j++) if (lim_on[j]) limit(j); }
+            PBRE_UNROLL for (int j = 0; j < ND; j++) mrow(j);
+        }
+    };
+    solve(motor_free);
+    {
+        bool over = false;
+        PBRE_UNROLL for (int i = 0; i < QD; i++) over = over || !(sabs[i] <= mlim);      // (a NaN fails the test as well)
+        if (__any((int)over)) {
+            PBRE_UNROLL for (int i = 0; i < QD; i++) { w[i] = w0[i]; sabs[i] = 0.f; l_app[i] = 0.f; }
+            solve(motor);
+        }
+    }
+    // ---- integrate the joints (semi-implicit Euler)
+    PBRE_UNROLL for (int i = 0; i < QD; i++) {
+        const float v = fminf(fmaxf(w[i], -vmax), vmax);
+        st[W + d0 + i] = v; st[d0 + i] = fmaf(dt, v, q[i]);
+    }
+}
+
+// The end of a simple env's step: object pose from the twist kw_obj left in the side record, then Lane::finish.
+__global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state, float* __restrict__ out,
+                                               int n, int ow, int flags, int MODE, const float* __restrict__ objv,
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int* __restrict__ zero_count) {
+    constexpr int ND = LaneD::ND, W = Shape32::W, LC = Shape32::LC, XO = 2 * Shape32::W;
+    const int env = blockIdx.x * LTPB + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_count = 0;
+    if (env >= n || cls_cur[env] != 0) return;
+    float* st = state + (size_t)env * Shape32::STATE;
+    float q[ND], qd[ND];
+    PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[W + j]; }
+    LaneD::V3 op; op.x = st[LC]; op.y = st[LC + 1]; op.z = st[LC + 2];
+    LaneD::Q4 oq; oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+    if (!(flags & 1) && st[XO + 14] == 0.f) {
+        const float dt = P.dt;
+        const float* o = objv + (size_t)env * W + LC;
+        LaneD::V3 ov, ow_; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ow_.x = o[3]; ow_.y = o[4]; ow_.z = o[5];
+        op.x = fmaf(dt, ov.x, op.x); op.y = fmaf(dt, ov.y, op.y); op.z = fmaf(dt, ov.z, op.z);
+        float ang = sqrtf(fmaf(ow_.x, ow_.x, fmaf(ow_.y, ow_.y, ow_.z * ow_.z)));
+        if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * P.inv_dt;
+        const float sc_ = ang < 0.001f ? 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang : sinf(0.5f * ang * dt) / ang;
+        LaneD::Q4 dq; dq.x = ow_.x * sc_; dq.y = ow_.y * sc_; dq.z = ow_.z * sc_; dq.w = cosf(ang * dt * 0.5f);
+        const LaneD::Q4 nq = LaneD::FX::qmul(dq, oq);
+        const float in = 1.f / sqrtf(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
+        oq.x = nq.x * in; oq.y = nq.y * in; oq.z = nq.z * in; oq.w = nq.w * in;
+        st[LC] = op.x; st[LC + 1] = op.y; st[LC + 2] = op.z; st[LC + 3] = oq.x; st[LC + 4] = oq.y; st[LC + 5] = oq.z; st[LC + 6] = oq.w;
+        PBRE_UNROLL for (int k = 0; k < 6; k++) st[W + LC + k] = o[k];
+    }
+    const int c = LaneD::finish(*T, P, st, q, qd, op, oq, (MODE & LaneD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
+    wpublish(env, c, cls, next_list, next_count);
+}
+
 // class of every env's current state (after reset / set_state / settle steps)
 __global__ __launch_bounds__(LTPB) void kw_lane_classify(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
                                                          signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count) {
@@ -101,19 +313,29 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     int* count = nullptr;             // [3]
     int cur = 0, ccur = 0;
     bool cls_valid = false, topo_ok = false, enabled = true;
+    int variant = 1;                  // PBRE_ICUB_LANE: 1 = the quad pipeline (kw_dyn / kw_quad / kw_fin), 2 = the one-kernel LDS variant (kw_lane; A/B)
+    float* dyn = nullptr;             // side buffer of the quad pipeline
+    size_t dyn_cs = 0;
     int n_simd = 1024;
-    ~WideLane() override { for (void* p : {(void*)cls, (void*)list, (void*)count}) if (p) (void)hipFree(p); }
-    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr; }
+    ~WideLane() override { for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn}) if (p) (void)hipFree(p); }
+    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && (variant == 2 || objv != nullptr); }
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");
-        enabled = knob && knob[0] == '1';            // off by default: see DESIGN.md (measured slower than the lane-group kernel so far)
+        enabled = !(knob && knob[0] == '0');         // PBRE_ICUB_LANE=0: every step by the lane-group kernel (A/B, validation)
+        variant = (knob && knob[0] == '2') ? 2 : 1;
         topo_ok = lane_topo_matches<TopoICub, Shape32>(T);
         if (!enabled || !topo_ok) return hipSuccess;
         hipError_t e;
         if ((e = hipMalloc(&cls, 2 * (size_t)n)) != hipSuccess) return e;
         if ((e = hipMalloc(&list, 2 * (size_t)n * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMalloc(&count, 3 * sizeof(int))) != hipSuccess) return e;
+        if (variant == 1) {
+            const size_t npad = ((size_t)n + 15) / 16 * 16;
+            dyn_cs = 16 * npad;
+            if ((e = hipMalloc(&dyn, (size_t)DCH * dyn_cs * sizeof(float))) != hipSuccess) return e;
+            if ((e = hipMemset(dyn, 0, (size_t)DCH * dyn_cs * sizeof(float))) != hipSuccess) return e;
+        }
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, device) == hipSuccess) n_simd = pr.multiProcessorCount * 4;
         return hipSuccess;
@@ -128,8 +350,16 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         const int gl = std::min((n + 7) / 8, n_simd);      // persistent blocks of 8 groups; blocks without work exit at once
         hipLaunchKernelGGL(kw_list, dim3(gl), dim3(WTPB), 0, s, dT, P, state, act, out, act_dim, ow, flags, MODE, tgt, l_cur, k_cur, c_nxt, l_nxt, k_nxt);
         if (ek) (void)hipEventRecord(ek[0], s);
-        hipLaunchKernelGGL(kw_lane, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, out, n, act_dim, ow, flags, MODE, tgt,
-                           c_cur, c_nxt, l_nxt, k_nxt, k_zero);
+        if (variant == 2)
+            hipLaunchKernelGGL(kw_lane, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, out, n, act_dim, ow, flags, MODE, tgt,
+                               c_cur, c_nxt, l_nxt, k_nxt, k_zero);
+        else {
+            const int be = (n + LTPB - 1) / LTPB;
+            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s, P, state, objv, n);
+            hipLaunchKernelGGL(kw_dyn, dim3(be), dim3(LTPB), 0, s, dT, P, state, n, c_cur, dyn, dyn_cs);
+            hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs);
+            hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
+        }
         if (ek) (void)hipEventRecord(ek[1], s);
         cur ^= 1; ccur = (ccur + 1) % 3;
     }

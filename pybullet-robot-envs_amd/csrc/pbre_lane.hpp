@@ -102,6 +102,8 @@ struct Lane {
         // keep all 210 entries live in registers, which is what the LDS copy is there to avoid)
         PBRE_HD float geto(int k, int o) const { return k < MLDS ? lds[k * MS + o] : reg[k < MLDS ? 0 : k - MLDS]; }
         PBRE_HD void set(int k, float v) { if (k < MLDS) lds[k * MS] = v; else reg[k < MLDS ? 0 : k - MLDS] = v; }
+        PBRE_HD void put(int j, int i, float v) { set(sym(j, i), v); }      // dynamics() sink
+        PBRE_HD void zero(int j, int i) { set(sym(j, i), 0.f); }
     };
 
     // joint frame of link j in its parent's frame at angle qj
@@ -123,26 +125,17 @@ struct Lane {
         }
     }
 
-    // ------------------------------------------------------------------------------------------------ the step
-    // st: the env's Q[W] | V[W] | X[16] record.  mi: this lane's slice of the wave's LDS region (MLDS floats, stride MS).
-    // Returns the class of the state it produced (0 simple, 1 complex).
-    static PBRE_HD int step(const Tab& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                            unsigned long long env_id, const float* tgt, float* mi) {
-        const bool obj_on = !(flags & 1);
-        float q[ND], qd[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[W + j]; }
-        // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (X[14]): it does not simulate
-        // (its lane runs along and stores nothing), only the evaluation of the state it is in
-        const bool skip = st[XO + 14] != 0.f;
-        const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
-
+    // ------------------------------------------------------------------------------------------------ dynamics
+    // Kinematics + dynamics of the state (q, qd): bias torques tau (gravity, velocity products, Bullet's link damping, explicit joint
+    // damping) and the joint-space inertia M (CRBA).  sink.put(j, i, v): entry M[j][i] = M[i][j], j >= i, i an ancestor-or-self of j;
+    // sink.zero(j, i): a pair on unrelated branches.
+    template <class Sink>
+    static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau) {
         // ---- kinematics + dynamics, chain by chain (Topo::chain_*: the trunk, then every branch): forward over the chain's links
         //      (FK, joint axes, velocities, velocity-product accelerations, per-link bias force and spatial inertia; world frame, about
         //      the world origin), then backward over them (subtree forces -> bias torques, composite inertias -> rows of M, CRBA).  A
         //      branch hands its composite to the trunk link it hangs on; the trunk's backward pass runs last.  Only the trunk's and the
         //      current branch's per-link data are live at any time.
-        Mat Mi; Mi.lds = mi;
-        float tau[ND];
         V3 Sa[ND], Sl[ND];                    // joint axes: a link needs those of its ancestors (its chain and the trunk)
         V3 Fa[ND], Fl[ND];
         float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
@@ -193,8 +186,8 @@ struct Lane {
             const V3 Ga = add(mv(Io, Sa[j]), cross(Ch[j], Sl[j]));
             const V3 Gl = add(scl(Sl[j], Cm[j]), cross(Sa[j], Ch[j]));
             PBRE_UNROLL for (int i = 0; i < ND; i++) {
-                if (i > j) { if (!Topo::is_anc(j, i)) Mi.set(sym(i, j), 0.f); continue; }      // unrelated branches
-                Mi.set(sym(j, i), Topo::is_anc(i, j) ? dot(Sa[i], Ga) + dot(Sl[i], Gl) : 0.f);
+                if (i > j) { if (!Topo::is_anc(j, i)) sink.zero(i, j); continue; }      // unrelated branches
+                if (Topo::is_anc(i, j)) sink.put(j, i, dot(Sa[i], Ga) + dot(Sl[i], Gl)); else sink.zero(j, i);
             }
             if (Topo::parent(j) >= 0) {
                 const int pp = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
@@ -209,6 +202,25 @@ struct Lane {
             PBRE_UNROLL for (int j = Topo::chain_last(c); j >= Topo::chain_first(c); j--) backward(j);
         }
         PBRE_UNROLL for (int j = Topo::chain_last(0); j >= Topo::chain_first(0); j--) backward(j);
+    }
+
+    // ------------------------------------------------------------------------------------------------ the step
+    // st: the env's Q[W] | V[W] | X[16] record.  mi: this lane's slice of the wave's LDS region (MLDS floats, stride MS).
+    // Returns the class of the state it produced (0 simple, 1 complex).
+    static PBRE_HD int step(const Tab& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+                            unsigned long long env_id, const float* tgt, float* mi) {
+        const bool obj_on = !(flags & 1);
+        float q[ND], qd[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[W + j]; }
+        // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (X[14]): it does not simulate
+        // (its lane runs along and stores nothing), only the evaluation of the state it is in
+        const bool skip = st[XO + 14] != 0.f;
+        const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
+
+        // ---- kinematics + dynamics -> bias torques tau and the joint-space inertia M (into the M^-1 store)
+        Mat Mi; Mi.lds = mi;
+        float tau[ND];
+        dynamics(T, P, q, qd, Mi, tau);
         if (P.jd_dt != 0.f) { PBRE_UNROLL for (int j = 0; j < ND; j++) Mi.set(sym(j, j), fmaf(P.jd_dt, T.jdamp[j], Mi.get(sym(j, j)))); }   // implicit joint damping: M + dt C
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle, in place
         PBRE_UNROLL for (int k = 0; k < ND; k++) {

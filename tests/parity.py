@@ -390,12 +390,15 @@ def check_icub_force_limited(Engine, lib, n=1, steps=3, imp=0.004):
     return eng
 
 
-def check_obj_split(Engine, lib, n=4, steps=3):
+def check_obj_split(Engine, lib, n=4, steps=3, exact=True):
     """Lane-group engines solve the object's rows per env in a kernel of their own (pbre_objstep.hpp) and use the result in every env
     whose robot does not touch the object.  Against the same engine with PBRE_OBJ_SPLIT=0 (all rows in one solve): the robot's state
     is bit-identical either way, the object agrees to rounding, an env WITH a robot-object contact is bit-identical as a whole even
     when it shares a wavefront with one without (env 1 of each pair has the object pushed into the hand), and all of it matches
-    the oracle's coupled solve."""
+    the oracle's coupled solve.
+    exact=False: the two engines run different kernels (device, lane-per-env pipeline on: PBRE_OBJ_SPLIT=0 also selects the lane-group
+    kernel for every step, the default engine the quad pipeline + the lane-group kernel for the envs with robot contacts), so the
+    bitwise assertions become rounding-level ones; both still have to match the oracle."""
     import os
     os.environ["PBRE_OBJ_SPLIT"] = "0"
     try:
@@ -406,7 +409,7 @@ def check_obj_split(Engine, lib, n=4, steps=3):
     xo, lc = one.x_off, 20
     one.reset(); two.reset()
     s1, s2 = one.get_state(), two.get_state()
-    assert np.array_equal(s1[:, :lc], s2[:, :lc]) and np.array_equal(s1[:, 32:32 + lc], s2[:, 32:32 + lc])
+    assert np.array_equal(s1[:, :lc], s2[:, :lc]) and np.array_equal(s1[:, 32:32 + lc], s2[:, 32:32 + lc])      # (resets: lane-group kernel in both)
     assert np.abs(s1 - s2).max() < 1e-5
     st, _ = ora.batch_reset(n)
     hand = two.observe()[:, :3]
@@ -422,14 +425,46 @@ def check_obj_split(Engine, lib, n=4, steps=3):
         o2, r2, d2 = two.step(a)
         st, out = ora.batch_step(s32.astype(np.float64), a)
         e1, e2 = one.get_state(), two.get_state()
-        assert np.array_equal(e1[:, :lc], e2[:, :lc]) and np.array_equal(e1[:, 32:32 + lc], e2[:, 32:32 + lc]), k
-        assert np.array_equal(e1[1::2], e2[1::2]) and np.array_equal(o1[1::2], o2[1::2]), k
-        assert np.abs(e1 - e2).max() < 1e-5 and np.abs(o1 - o2).max() < 1e-4
+        if exact:
+            assert np.array_equal(e1[:, :lc], e2[:, :lc]) and np.array_equal(e1[:, 32:32 + lc], e2[:, 32:32 + lc]), k
+            assert np.array_equal(e1[1::2], e2[1::2]) and np.array_equal(o1[1::2], o2[1::2]), k
+            assert np.abs(e1 - e2).max() < 1e-5 and np.abs(o1 - o2).max() < 1e-4
+        else:
+            assert rel(e1[:, :xo], e2[:, :xo]).max() < 2e-4 and rel(o1, o2).max() < 2e-3, (k, rel(e1[:, :xo], e2[:, :xo]).max(), rel(o1, o2).max())
+            assert rel(e1[:, :xo], st[:, :xo]).max() < 2e-3
         assert rel(e2[:, :xo], st[:, :xo]).max() < 2e-3, (k, rel(e2[:, :xo], st[:, :xo]).max())
         assert rel(o2, out[:, :-2]).max() < 2e-2
         touched = max(touched, np.abs(st[1::2, 32 + lc:32 + lc + 2]).max())
     assert touched > 1e-3, "the hand never pushed the object: the coupled case was not exercised"
     return two
+
+
+def check_icub_lane_ab(Engine, lib, monkeypatch, variant, n=64, steps=12, tol=2e-3):
+    """iCub: a lane-per-env variant (PBRE_ICUB_LANE=variant) against the lane-group kernel (=0) on the same seeded free-running batch
+    (joint and Cartesian control, auto-reset on and off).  The kernels round differently (M^-1 by Gauss-Jordan across a quad / by the
+    sweep operator / one row per lane), so agreement is at rounding level over a short horizon; returns the worst relative difference."""
+    worst = 0.0
+    for task, arm, use_ik, ori in [(0, "l", 1, 0), (1, "r", 1, 1), (1, "l", 0, 0)]:
+        for auto in (0, 2):
+            res = []
+            for lane in (0, variant):
+                monkeypatch.setenv("PBRE_ICUB_LANE", str(lane))
+                eng, ora, info = make_icub_pair(Engine, lib, n, task=task, control_arm=arm, use_ik=use_ik, control_orientation=ori,
+                                                obj_std=0.05, tg_std=0.1, max_steps=5, flags=auto)
+                eng.reset()
+                rng = np.random.default_rng(3)
+                rows = []
+                for k in range(steps):
+                    ob, rw, dn = eng.step(rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32))
+                    rows.append(np.concatenate([ob, rw[:, None], dn[:, None]], 1))
+                res.append((np.array(rows), eng.get_state(), eng.kernel_info()))
+            (a, sa, ia), (b, sb, ib) = res
+            assert ia[2] == 0 and ib[2] == 1, (ia, ib)
+            d = max(float(rel(a, b).max()), float(rel(sa, sb).max()))
+            assert d < tol, (task, arm, use_ik, ori, auto, d)
+            worst = max(worst, d)
+    monkeypatch.delenv("PBRE_ICUB_LANE")
+    return worst
 
 
 def check_icub_full_model(Engine, lib, n=2, steps=3):

@@ -83,3 +83,8 @@ def test_icub_reset_snapshot(emu_lib):
     tbl, model, info = icub_table("l")
     ov = parity.icub_overrides(info, "l", 1, 0, 1)
     parity.check_reset_snapshot(_capi.Engine, emu_lib, tbl, n=4, robot=_capi.ROBOT_ICUB, **ov)
+
+
+def test_icub_lane_path_matches_lane_group_kernel(emu_lib, monkeypatch):
+    """CPU emulation: the lane-per-env step (pbre_lane.hpp, Lane::step / finish / ik_targets) against the lane-group core"""
+    assert parity.check_icub_lane_ab(_capi.Engine, emu_lib, monkeypatch, 1, n=3, steps=8) < 2e-3

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("task,arm,use_ik,ori,rt", [(0, "l", 1, 0, 1), (1, "r", 1, 1, 1), (1, "l", 0, 0, 0), (2, "r", 1, 1, 1), (1, "l", 1, 0, 1)])
 def test_icub_reset_and_steps(hip_lib, task, arm, use_ik, ori, rt):
     eng = parity.check_icub(_capi.Engine, hip_lib, task, arm, use_ik, ori, rt, n=6, steps=4)
-    assert eng.kernel_info()[4] == 6 and 0 < eng.kernel_info()[1] <= 256
+    info = eng.kernel_info()
+    # the lane-per-env pipeline (pbre_lane.hip) steps the batch: [2] flag, [3] simple + [5] complex envs; [1] VGPRs of the lane-group kernel
+    assert info[2] == 1 and info[3] + info[5] == 6 and info[4] == 0 and 0 < info[1] <= 256
 
 
 def test_icub_masked_reset_and_rollout(hip_lib):
@@ -81,8 +83,24 @@ def test_icub_force_limited_motors(hip_lib):
     parity.check_icub_force_limited(_capi.Engine, hip_lib, n=5, steps=4)
 
 
-def test_icub_object_rows_split(hip_lib):
+def test_icub_object_rows_split(hip_lib, monkeypatch):
+    """the lane-group kernel's object split (PBRE_ICUB_LANE=0: every step by kw_step), bitwise"""
+    monkeypatch.setenv("PBRE_ICUB_LANE", "0")
     parity.check_obj_split(_capi.Engine, hip_lib, n=7, steps=4)
+
+
+def test_icub_lane_pipeline_with_robot_contacts(hip_lib):
+    """the lane-per-env pipeline (kw_dyn / kw_quad / kw_fin + kw_list for the envs whose hand touches the object) against the
+    lane-group kernel's coupled solve and the oracle"""
+    two = parity.check_obj_split(_capi.Engine, hip_lib, n=7, steps=4, exact=False)
+    info = two.kernel_info()
+    assert info[2] == 1 and info[5] >= 1, info          # some envs were in the complex class (robot contact) at the end
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_icub_lane_variants_match_lane_group_kernel(hip_lib, monkeypatch, variant):
+    """free-running batches: the quad pipeline (1) and the one-kernel LDS variant (2) against the lane-group kernel, rounding level"""
+    print(parity.check_icub_lane_ab(_capi.Engine, hip_lib, monkeypatch, variant, n=96, steps=12))
 
 
 def test_icub_full_model_one_env_per_wave(hip_lib):
