@@ -33,22 +33,6 @@ __device__ __forceinline__ void wpublish(int env, int c, signed char* __restrict
     cls[env] = (signed char)c;
     if (c) next_list[atomicAdd(next_count, 1)] = env;
 }
-// Simple envs (no robot collision sphere near the object / table): every env of the batch in natural order, lanes of complex envs idle.
-// One wave per SIMD (the kernel may use the whole register file); LDS: the wave's M^-1 entries.
-// (the mode bits are a kernel argument: wave-uniform branches, one instantiation of this large kernel)
-__global__ __launch_bounds__(LTPB, 1) void kw_lane(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags, int MODE,
-                                                   const float* __restrict__ tgt, const signed char* __restrict__ cls_cur, signed char* __restrict__ cls,
-                                                   int* __restrict__ next_list, int* __restrict__ next_count, int* __restrict__ zero_count) {
-    __shared__ float lds_m[LaneD::MLDS * LTPB];
-    const int env = blockIdx.x * LTPB + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *zero_count = 0;          // the counter the step after this one appends to (idle now)
-    if (env >= n || cls_cur[env] != 0) return;
-    const int c = LaneD::step(*T, P, state + (size_t)env * Shape32::STATE, (MODE & LaneD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                              (MODE & LaneD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                              (MODE & LaneD::M_TGT) ? tgt + (size_t)env * Shape32::TGT : nullptr, lds_m + threadIdx.x);
-    wpublish(env, c, cls, next_list, next_count);
-}
 // Complex envs over the compacted list: physics by the lane-group kernel (Core::step: all row types, one env per half-wave),
 // observation / reward / termination / auto-reset / class of the new state by Lane::finish on the group's first lane.
 __global__ __launch_bounds__(WTPB, 3) void kw_list(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
@@ -78,7 +62,7 @@ __global__ __launch_bounds__(WTPB, 3) void kw_list(const TablesT<Shape32>* __res
     }
 }
 // Cartesian control: hand-pose update + inverse kinematics -> joint targets, one thread per env
-__global__ __launch_bounds__(LTPB) void kw_lane_ik(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (env >= n) return;
@@ -97,7 +81,7 @@ __global__ __launch_bounds__(LTPB) void kw_lane_ik(const TablesT<Shape32>* __res
 //            (Lane::finish).
 // Side buffer layout: float4 chunks [chunk][env * 4 + r]: chunks 0..24 = rows 5r..5r+4 of M (element i * 20 + col), chunk 25 and the
 // first float of chunk 26 = tau[5r..5r+4]; a wave of kw_quad reads each chunk as one contiguous 1 KB block.
-constexpr int QD = 5, DCH = 27;
+constexpr int QD = 5, DCH = 37;       // + chunks 27, 28 (slot of quad lane 0): robot-table contact flags, friction, distances; 29..36: this lane's 30 Jacobian entries
 static_assert(LaneD::ND == 4 * QD, "four lanes per env, five DoF each");
 struct DynSink {
     float* base;        // dyn + env * 16 floats (the env's four float4 slots of chunk 0)
@@ -105,9 +89,10 @@ struct DynSink {
     __device__ __forceinline__ void st(int row, int col, float v) { const int e = (row % QD) * 20 + col; base[(size_t)(e / 4) * cs + (row / QD) * 4 + (e % 4)] = v; }
     __device__ __forceinline__ void put(int j, int i, float v) { st(j, i, v); if (i != j) st(i, j, v); }
     __device__ __forceinline__ void zero(int, int) {}      // unrelated branch pairs: the buffer is zeroed once, nobody writes them
+    __device__ __forceinline__ void f(int r, int e, float v) { base[(size_t)(e / 4) * cs + r * 4 + (e % 4)] = v; }      // float e of quad lane r
     __device__ __forceinline__ void tau(int j, float v) { const int e = 100 + (j % QD); base[(size_t)(e / 4) * cs + (j / QD) * 4 + (e % 4)] = v; }
 };
-__global__ __launch_bounds__(LTPB, 2) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n,
+__global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n,
                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (env >= n || cls_cur[env] != 0) return;
@@ -116,17 +101,32 @@ __global__ __launch_bounds__(LTPB, 2) void kw_dyn(const TablesT<Shape32>* __rest
     float q[LaneD::ND], qd[LaneD::ND], tau[LaneD::ND];
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
     DynSink sink; sink.base = dyn + (size_t)env * 16; sink.cs = cs;
-    LaneD::dynamics(*T, P, q, qd, sink, tau);
+    LaneD::RtC rt;
+    LaneD::dynamics(*T, P, q, qd, sink, tau, rt);
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.tau(j, tau[j]);
+    // robot-table contact slots: flags / friction / distances always, the Jacobian rows of the envs that have a contact
+    sink.f(0, 108, rt.act[0] ? 1.f : 0.f); sink.f(0, 109, rt.act[1] ? 1.f : 0.f); sink.f(0, 110, rt.mu[0]); sink.f(0, 111, rt.mu[1]);
+    sink.f(0, 112, rt.dist[0]); sink.f(0, 113, rt.dist[1]);
+    if (rt.act[0]) {
+        PBRE_UNROLL for (int c = 0; c < LaneD::NRT; c++)
+            PBRE_UNROLL for (int d = 0; d < 3; d++)
+                PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.f(j / QD, 116 + (c * 3 + d) * QD + (j % QD), rt.J[c][d][j]);
+    }
 }
 
 // value of quad lane o in every lane of the quad (o static after unrolling)
 template <int O> __device__ __forceinline__ float qb_t(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), O * 0x55, 0xF, 0xF, true));
 }
+template <int CTRL> __device__ __forceinline__ float qb_x(float x) {      // quad_perm CTRL (0xB1: lanes 1,0,3,2; 0x4E: lanes 2,3,0,1)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float qb(float x, int o) { return o == 0 ? qb_t<0>(x) : (o == 1 ? qb_t<1>(x) : (o == 2 ? qb_t<2>(x) : qb_t<3>(x))); }
 
-__global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
+#ifndef PBRE_QUAD_WAVES
+#define PBRE_QUAD_WAVES 2            // waves per SIMD kw_quad is register-limited to (A/B on MI355X, 65536 envs: 3 -> 100, 2 -> 115 M env-steps/s; no spills at 2)
+#endif
+__global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
                                                    const signed char* __restrict__ cls_cur, const float* __restrict__ dyn, size_t cs) {
     constexpr int ND = LaneD::ND, W = Shape32::W, XO = 2 * Shape32::W;
@@ -165,16 +165,15 @@ __global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __res
     //      copy of it is brought to pivot_row / pivot by the same fma as every other row (with f - 1 in place of f)
     PBRE_UNROLL for (int c = 0; c < ND; c++) {
         const int o = c / QD, i0 = c % QD;
-        float rc[ND];
         const float inv = 1.f / qb(A[i0][c], o);
-        PBRE_UNROLL for (int k = 0; k < ND; k++) rc[k] = k == c ? 0.f : qb(A[i0][k], o) * inv;
-        PBRE_UNROLL for (int i = 0; i < QD; i++) {
-            const float f = A[i][c];
-            const float fp = i == i0 ? f - own[o] : f;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) { if (k == c) continue; A[i][k] = fmaf(-fp, rc[k], A[i][k]); }
-            const float off = -f * inv;
-            A[i][c] = i == i0 ? (r == o ? inv : off) : off;
+        float fp[QD], off[QD];
+        PBRE_UNROLL for (int i = 0; i < QD; i++) { const float f = A[i][c]; fp[i] = i == i0 ? f - own[o] : f; off[i] = -f * inv; }
+        PBRE_UNROLL for (int k = 0; k < ND; k++) {
+            if (k == c) continue;
+            const float rc = qb(A[i0][k], o) * inv;            // pivot-row entry / pivot (read before the owner's row is updated below)
+            PBRE_UNROLL for (int i = 0; i < QD; i++) A[i][k] = fmaf(-fp[i], rc, A[i][k]);
         }
+        PBRE_UNROLL for (int i = 0; i < QD; i++) A[i][c] = i == i0 ? (r == o ? inv : off[i]) : off[i];
     }
     // ---- unconstrained velocities v* = qd + dt M^-1 tau, motor rows against the running velocity, limit rows (see Lane::step)
     float w[QD], w0[QD], m_dinv[QD], m_rhs[QD], sabs[QD], l_dir[QD], l_rhs[QD], l_app[QD];
@@ -215,6 +214,65 @@ __global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __res
     bool lim_on[ND], has_limit = false;                    // row j = 5 o + i runs if any env of the wave has joint j at a limit
     PBRE_UNROLL for (int j = 0; j < ND; j++) { lim_on[j] = (lim_b[j % QD] & (0x1111111111111111ull << (j / QD))) != 0ull; has_limit = has_limit || lim_on[j]; }
 
+    // ---- robot-table contact rows (the slots kw_dyn found): this lane's five entries of J and of B = M^-1 J^T per row; the row's
+    //      scalars (1 / (J B), applied impulse, rhs) are computed by every lane of the quad alike
+    constexpr int NRT = LaneD::NRT;
+    float rJ[NRT][3][QD], rB[NRT][3][QD], r_dinv[NRT][3], r_app[NRT][3], r_rhs[NRT], r_mu[NRT];
+    bool rt_on[NRT];
+    {
+        const size_t g0 = (size_t)(gl & ~3) * 4;              // the env's quad lane 0 slot
+        const float a0 = dyn[(size_t)27 * cs + g0], a1 = dyn[(size_t)27 * cs + g0 + 1];
+        rt_on[0] = __any((int)(a0 != 0.f)) != 0; rt_on[1] = __any((int)(a1 != 0.f)) != 0;      // wave-uniform; rows of a quad without the contact are exact no-ops
+        PBRE_UNROLL for (int c = 0; c < NRT; c++) {
+            r_rhs[c] = 0.f; r_mu[c] = 0.f;
+            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = 0.f; r_app[c][d] = 0.f; PBRE_UNROLL for (int i = 0; i < QD; i++) { rJ[c][d][i] = 0.f; rB[c][d][i] = 0.f; } }
+        }
+        if (rt_on[0]) {
+            float jl[32];
+            const float4* d4 = reinterpret_cast<const float4*>(dyn);
+            PBRE_UNROLL for (int c = 0; c < 8; c++) { const float4 v = d4[(size_t)(29 + c) * (cs / 4) + gl]; jl[4*c] = v.x; jl[4*c+1] = v.y; jl[4*c+2] = v.z; jl[4*c+3] = v.w; }
+            PBRE_UNROLL for (int c = 0; c < NRT; c++) {
+                if (!rt_on[c]) continue;
+                const bool act = (c == 0 ? a0 : a1) != 0.f;
+                r_mu[c] = act ? dyn[(size_t)27 * cs + g0 + 2 + c] : 0.f;
+                PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                    PBRE_UNROLL for (int i = 0; i < QD; i++) rJ[c][d][i] = act ? jl[(c * 3 + d) * QD + i] : 0.f;      // (stale rows of an earlier step where there is no contact)
+                    float b[QD];
+                    PBRE_UNROLL for (int i = 0; i < QD; i++) b[i] = 0.f;
+                    PBRE_UNROLL for (int col = 0; col < ND; col++) {
+                        const float jc = qb(rJ[c][d][col % QD], col / QD);
+                        PBRE_UNROLL for (int i = 0; i < QD; i++) b[i] = fmaf(A[i][col], jc, b[i]);
+                    }
+                    float den = 0.f;
+                    PBRE_UNROLL for (int i = 0; i < QD; i++) { rB[c][d][i] = b[i]; den = fmaf(rJ[c][d][i], b[i], den); }
+                    den += qb_x<0xB1>(den); den += qb_x<0x4E>(den);        // sum over the quad
+                    r_dinv[c][d] = act ? 1.f / den : 0.f;
+                }
+                const float pen = dyn[(size_t)28 * cs + g0 + c] + P.slop;
+                r_rhs[c] = act ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * r_dinv[c][0] : 0.f;
+            }
+        }
+    }
+    auto rrow = [&](int c, int d) {
+        float jv = 0.f;
+        PBRE_UNROLL for (int i = 0; i < QD; i++) jv = fmaf(rJ[c][d][i], w[i], jv);
+        jv += qb_x<0xB1>(jv); jv += qb_x<0x4E>(jv);
+        float sn;
+        if (d == 0) sn = __builtin_amdgcn_fmed3f(r_app[c][0] - fmaf(jv, r_dinv[c][0], -r_rhs[c]), 0.f, 1e10f);
+        else {
+            const float hi = r_mu[c] * r_app[c][0];
+            sn = __builtin_amdgcn_fmed3f(r_app[c][d] - jv * r_dinv[c][d], -hi, hi);
+            sn = hi > 0.f ? sn : r_app[c][d];
+        }
+        const float dd = sn - r_app[c][d]; r_app[c][d] = sn;
+        PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(dd, rB[c][d][k], w[k]);
+    };
+    auto contacts = [&]() {            // Bullet: normals, then frictions
+        PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) rrow(c, 0);
+        PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) { rrow(c, 1); rrow(c, 2); }
+    };
+    const bool has_rt = rt_on[0];
+
     const float mlim = P.motor_imp, llim = P.limit_imp;
     auto axpy = [&](int j, float d) { PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(d, A[k][j], w[k]); };
     auto motor_free = [&](int j) {     // clamp-free row; sabs: sum of |delta| of the motor this lane owns (bounds every value its impulse had)
@@ -242,9 +300,11 @@ __global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __res
         for (int it = 0; it < P.iters; it += 2) {
             PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) mrow(j);
             if (has_limit) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) if (lim_on[j]) limit(j); }
+            if (has_rt) contacts();
             if (it + 1 >= P.iters) break;
             if (has_limit) { PBRE_UNROLL for (int j = 0; j < ND; j++) if (lim_on[j]) limit(j); }
             PBRE_UNROLL for (int j = 0; j < ND; j++) mrow(j);
+            if (has_rt) contacts();
         }
     };
     solve(motor_free);
@@ -253,6 +313,7 @@ __global__ __launch_bounds__(LTPB, 3) void kw_quad(const TablesT<Shape32>* __res
         PBRE_UNROLL for (int i = 0; i < QD; i++) over = over || !(sabs[i] <= mlim);      // (a NaN fails the test as well)
         if (__any((int)over)) {
             PBRE_UNROLL for (int i = 0; i < QD; i++) { w[i] = w0[i]; sabs[i] = 0.f; l_app[i] = 0.f; }
+            PBRE_UNROLL for (int c = 0; c < NRT; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
             solve(motor);
         }
     }
@@ -296,6 +357,12 @@ __global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restric
     wpublish(env, c, cls, next_list, next_count);
 }
 
+// diagnostics (pbre_kernel_info[6]): envs whose class is 2 (robot-object contact)
+__global__ void kw_count_cls2(const signed char* __restrict__ cls, int n, int* __restrict__ res) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env < n && cls[env] == 2) atomicAdd(res, 1);
+}
+
 // class of every env's current state (after reset / set_state / settle steps)
 __global__ __launch_bounds__(LTPB) void kw_lane_classify(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
                                                          signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count) {
@@ -313,24 +380,36 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     int* count = nullptr;             // [3]
     int cur = 0, ccur = 0;
     bool cls_valid = false, topo_ok = false, enabled = true;
-    int variant = 1;                  // PBRE_ICUB_LANE: 1 = the quad pipeline (kw_dyn / kw_quad / kw_fin), 2 = the one-kernel LDS variant (kw_lane; A/B)
     float* dyn = nullptr;             // side buffer of the quad pipeline
+    hipStream_t side = nullptr;       // kw_list (few lane-group waves, latency-bound) and kw_obj run beside kw_dyn / kw_quad
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t dyn_cs = 0;
     int n_simd = 1024;
-    ~WideLane() override { for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn}) if (p) (void)hipFree(p); }
-    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && (variant == 2 || objv != nullptr); }
+    ~WideLane() override {
+        for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn}) if (p) (void)hipFree(p);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_ik) (void)hipEventDestroy(ev_ik);
+        if (side) (void)hipStreamDestroy(side);
+    }
+    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr; }
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");
         enabled = !(knob && knob[0] == '0');         // PBRE_ICUB_LANE=0: every step by the lane-group kernel (A/B, validation)
-        variant = (knob && knob[0] == '2') ? 2 : 1;
         topo_ok = lane_topo_matches<TopoICub, Shape32>(T);
         if (!enabled || !topo_ok) return hipSuccess;
         hipError_t e;
         if ((e = hipMalloc(&cls, 2 * (size_t)n)) != hipSuccess) return e;
         if ((e = hipMalloc(&list, 2 * (size_t)n * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMalloc(&count, 3 * sizeof(int))) != hipSuccess) return e;
-        if (variant == 1) {
+        if (!(getenv("PBRE_ICUB_SIDE") && getenv("PBRE_ICUB_SIDE")[0] == '0')) {      // PBRE_ICUB_SIDE=0: everything in stream order (A/B)
+            if ((e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_ik, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        {
             const size_t npad = ((size_t)n + 15) / 16 * 16;
             dyn_cs = 16 * npad;
             if ((e = hipMalloc(&dyn, (size_t)DCH * dyn_cs * sizeof(float))) != hipSuccess) return e;
@@ -340,7 +419,10 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         if (hipGetDeviceProperties(&pr, device) == hipSuccess) n_simd = pr.multiProcessorCount * 4;
         return hipSuccess;
     }
+    bool ik_pending = false;          // Cartesian control: the IK kernel of this step is launched by lane_t (beside kw_dyn, which does not need the targets)
+    hipEvent_t ev_ik = nullptr;
     void launch_lane_ik(const float* act, hipStream_t s) override {
+        if (side) { ik_pending = true; return; }
         hipLaunchKernelGGL(kw_lane_ik, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, tgt, n, act_dim);
     }
     void lane_t(int MODE, const float* act, float* out, int flags, hipStream_t s, hipEvent_t* ek) {
@@ -348,19 +430,29 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         int* l_cur = list + (size_t)cur * n; int* l_nxt = list + (size_t)(cur ^ 1) * n;
         int* k_cur = count + ccur; int* k_nxt = count + (ccur + 1) % 3; int* k_zero = count + (ccur + 2) % 3;
         const int gl = std::min((n + 7) / 8, n_simd);      // persistent blocks of 8 groups; blocks without work exit at once
-        hipLaunchKernelGGL(kw_list, dim3(gl), dim3(WTPB), 0, s, dT, P, state, act, out, act_dim, ow, flags, MODE, tgt, l_cur, k_cur, c_nxt, l_nxt, k_nxt);
-        if (ek) (void)hipEventRecord(ek[0], s);
-        if (variant == 2)
-            hipLaunchKernelGGL(kw_lane, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, out, n, act_dim, ow, flags, MODE, tgt,
-                               c_cur, c_nxt, l_nxt, k_nxt, k_zero);
-        else {
-            const int be = (n + LTPB - 1) / LTPB;
-            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s, P, state, objv, n);
+        const int be = (n + LTPB - 1) / LTPB;
+        {
+            // the complex envs' kernel (a few lane-group waves, ~0.3 ms of latency) and the object solve (45 us of latency) on the side
+            // stream, beside kw_dyn -> kw_quad; kw_fin needs the object twists, the next step both kernels' classes
+            hipStream_t s2 = side ? side : s;
+            if (side) { (void)hipEventRecord(ev_fork, s); (void)hipStreamWaitEvent(side, ev_fork, 0); }
+            const bool ik_side = ik_pending;
+            if (ik_side) {
+                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim);
+                (void)hipEventRecord(ev_ik, side);
+                ik_pending = false;
+            }
+            hipLaunchKernelGGL(kw_list, dim3(gl), dim3(WTPB), 0, s2, dT, P, state, act, out, act_dim, ow, flags, MODE, tgt, l_cur, k_cur, c_nxt, l_nxt, k_nxt);
+            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
+            if (side) (void)hipEventRecord(ev_join, side);
+            if (ek) (void)hipEventRecord(ek[0], s);
             hipLaunchKernelGGL(kw_dyn, dim3(be), dim3(LTPB), 0, s, dT, P, state, n, c_cur, dyn, dyn_cs);
+            if (ik_side) (void)hipStreamWaitEvent(s, ev_ik, 0);
             hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs);
+            if (ek) (void)hipEventRecord(ek[1], s);
+            if (side) (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
         }
-        if (ek) (void)hipEventRecord(ek[1], s);
         cur ^= 1; ccur = (ccur + 1) % 3;
     }
     hipError_t launch_lane_step(int kind, const float* act, float* out, int flags, hipStream_t s, bool timed) override {
@@ -384,10 +476,20 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     }
     int lane_info(int* vg, int* complex_now) override {
         hipFuncAttributes fa;
-        *vg = hipFuncGetAttributes(&fa, (const void*)kw_lane) == hipSuccess ? fa.numRegs : -1;
+        *vg = hipFuncGetAttributes(&fa, (const void*)kw_quad) == hipSuccess ? fa.numRegs : -1;
         *complex_now = 0;
         if (cls_valid) { (void)hipDeviceSynchronize(); (void)hipMemcpy(complex_now, count + ccur, sizeof(int), hipMemcpyDeviceToHost); }
         return 1;
+    }
+    int lane_cls2() override {
+        if (!cls_valid) return 0;
+        int* d = nullptr; int h = 0;
+        if (hipMalloc(&d, sizeof(int)) != hipSuccess) return -1;
+        (void)hipMemset(d, 0, sizeof(int));
+        hipLaunchKernelGGL(kw_count_cls2, dim3((n + 255) / 256), dim3(256), 0, 0, cls + (size_t)cur * n, n, d);
+        (void)hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        return h;
     }
 };
 

@@ -54,6 +54,8 @@ struct TopoICub {
     static constexpr int NCHAIN = 4;
     static constexpr int chain_first(int c) { return c == 0 ? 0 : (c == 1 ? 3 : (c == 2 ? 10 : 13)); }
     static constexpr int chain_last(int c) { return c == 0 ? 2 : (c == 1 ? 9 : (c == 2 ? 12 : 19)); }
+    // lanes that can own the end effector (left / right hand): the Cartesian-control code is compiled per candidate, with a static chain
+    static constexpr int ee0 = 9, ee1 = 19;
 };
 
 template <class Topo, class S>
@@ -63,6 +65,7 @@ inline bool lane_topo_matches(const TablesT<S>& T) {
         if (T.anc[0][j] != Topo::parent(j) || T.jtype[j] != Topo::jtype(j)) return false;
         for (int b = 0; b < S::NSUB; b++) if ((T.sb_m[b][j] != 0.f || T.sb_I[b][0][j] != 0.f) != (b < Topo::nsub(j))) return false;
     }
+    if (T.ee_owner != Topo::ee0 && T.ee_owner != Topo::ee1) return false;
     return true;
 }
 
@@ -129,8 +132,20 @@ struct Lane {
     // Kinematics + dynamics of the state (q, qd): bias torques tau (gravity, velocity products, Bullet's link damping, explicit joint
     // damping) and the joint-space inertia M (CRBA).  sink.put(j, i, v): entry M[j][i] = M[i][j], j >= i, i an ancestor-or-self of j;
     // sink.zero(j, i): a pair on unrelated branches.
+    // rt: the (at most NRT) robot collision spheres closest to the table within the contact margin -- contact slots in sphere order, as
+    // the lane-group kernel selects them -- with Bullet's contact frame (normal, btPlaneSpace1 tangents), friction coefficient and the
+    // Jacobian rows J[c][d][j] = dir_d . (S_l,j + S_a,j x pA) over the joints that move the sphere's link.
+    static constexpr int NRT = S::NC_RT;
+    static_assert(NRT == 2, "keep2() selects two candidates");
+    struct RtC { bool act[NRT]; float dist[NRT], mu[NRT]; float J[NRT][3][ND]; };
     template <class Sink>
-    static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau) {
+    static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau, RtC& rt) {
+        typename FX::Cand k1, k2;        // best and second-best robot-table candidate
+        k1.dist = k2.dist = 3e38f; k1.idx = k2.idx = 99; k1.mu = k2.mu = 0.f; k1.owner = k2.owner = 0;
+        k1.n = k2.n = k1.pA = k2.pA = k1.pB = k2.pB = v3(0.f, 0.f, 0.f);
+        const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
+        M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
+        const float ztop = tc.z + th.z;
         // ---- kinematics + dynamics, chain by chain (Topo::chain_*: the trunk, then every branch): forward over the chain's links
         //      (FK, joint axes, velocities, velocity-product accelerations, per-link bias force and spatial inertia; world frame, about
         //      the world origin), then backward over them (subtree forces -> bias torques, composite inertias -> rows of M, CRBA).  A
@@ -148,6 +163,16 @@ struct Lane {
             if (root) { R[j] = Rl; p[j] = pl; } else { R[j] = mm(R[pj], Rl); p[j] = add(p[pj], mv(R[pj], pl)); }
             const V3 aw = mv(R[j], ax);
             if (Topo::jtype(j) == 1) { Sa[j] = aw; Sl[j] = cross(p[j], aw); } else { Sa[j] = v3(0.f, 0.f, 0.f); Sl[j] = aw; }
+            for (int sp = 0; sp < T.nspheres; sp++) {          // robot collision spheres of this link vs the table
+                if (T.s_owner[sp] != j) continue;
+                const V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][sp], T.s_c[1][sp], T.s_c[2][sp])));
+                const float sr = T.s_r[sp];
+                if (!PBRE_ANY(!(sc.z - sr - ztop >= P.margin))) continue;       // cheap wave-wide lower bound first
+                typename FX::Cand c; c.idx = sp; c.owner = j;
+                c.dist = FX::sphere_box(sc, sr, tc, Id, th, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
+                c.mu = T.s_mu[sp] * P.tab_mu;
+                FX::keep2(c, P.margin, k1, k2);
+            }
             const V3 sa = scl(Sa[j], qd[j]), sl = scl(Sl[j], qd[j]);
             if (root) { Va[j] = sa; Vl[j] = sl; } else { Va[j] = add(Va[pj], sa); Vl[j] = add(Vl[pj], sl); }
             const V3 ca = cross(Va[j], sa), cl = add(cross(Va[j], sl), cross(Vl[j], sa));
@@ -202,6 +227,33 @@ struct Lane {
             PBRE_UNROLL for (int j = Topo::chain_last(c); j >= Topo::chain_first(c); j--) backward(j);
         }
         PBRE_UNROLL for (int j = Topo::chain_last(0); j >= Topo::chain_first(0); j--) backward(j);
+        // ---- robot-table contact slots
+        const bool two = k2.dist < 3e38f;
+        const bool swap = two && k2.idx < k1.idx;                      // slot order = sphere index order
+        const bool any_rt = PBRE_ANY(k1.dist < 3e38f);
+        PBRE_UNROLL for (int c = 0; c < NRT; c++) {
+            const typename FX::Cand cc = (c == 0) ? (swap ? k2 : k1) : (swap ? k1 : k2);
+            rt.act[c] = cc.dist < 3e38f;
+            rt.dist[c] = cc.dist; rt.mu[c] = rt.act[c] ? cc.mu : 0.f;
+            if (!any_rt) { PBRE_UNROLL for (int d = 0; d < 3; d++) PBRE_UNROLL for (int j = 0; j < ND; j++) rt.J[c][d][j] = 0.f; continue; }
+            const V3 n = cc.n;
+            V3 t1, t2;     // btPlaneSpace1
+            if (fabsf(n.z) > 0.70710678118654752f) {
+                const float a = n.y*n.y + n.z*n.z, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                t1 = v3(0.f, -n.z * kk, n.y * kk); t2 = v3(a * kk, -n.x * t1.z, n.x * t1.y);
+            } else {
+                const float a = n.x*n.x + n.y*n.y, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                t1 = v3(-n.y * kk, n.x * kk, 0.f); t2 = v3(-n.z * t1.y, n.z * t1.x, a * kk);
+            }
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                const V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                    bool onchain = false;      // joint j moves the contact link (compile-time tree, per-lane owner)
+                    PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
+                    rt.J[c][d][j] = (rt.act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                }
+            }
+        }
     }
 
     // ------------------------------------------------------------------------------------------------ the step
@@ -220,7 +272,8 @@ struct Lane {
         // ---- kinematics + dynamics -> bias torques tau and the joint-space inertia M (into the M^-1 store)
         Mat Mi; Mi.lds = mi;
         float tau[ND];
-        dynamics(T, P, q, qd, Mi, tau);
+        RtC rt;
+        dynamics(T, P, q, qd, Mi, tau, rt);
         if (P.jd_dt != 0.f) { PBRE_UNROLL for (int j = 0; j < ND; j++) Mi.set(sym(j, j), fmaf(P.jd_dt, T.jdamp[j], Mi.get(sym(j, j)))); }   // implicit joint damping: M + dt C
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle, in place
         PBRE_UNROLL for (int k = 0; k < ND; k++) {
@@ -274,6 +327,43 @@ struct Lane {
                 has_limit = has_limit || lim_any[j];
             }
         }
+
+        // ---- robot-table contact rows (setupMultiBodyContactConstraint, restitution 0): B = M^-1 J^T, 1 / (J B), positional rhs; rows
+        //      are evaluated against the running velocity
+        float rc_B[NRT][3][ND], rc_dinv[NRT][3], rc_app[NRT][3], rc_rhs[NRT];
+        bool rt_on[NRT];
+        PBRE_UNROLL for (int c = 0; c < NRT; c++) {
+            rt_on[c] = PBRE_ANY(rt.act[c]);                        // wave-uniform; the rows of a lane without the contact are exact no-ops
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                float denom = 0.f;
+                PBRE_UNROLL for (int k = 0; k < ND; k++) {
+                    float b = 0.f;
+                    if (rt_on[c]) { PBRE_UNROLL for (int j = 0; j < ND; j++) b = fmaf(Mi.get(sym(k, j)), rt.J[c][d][j], b); }
+                    rc_B[c][d][k] = b; denom = fmaf(rt.J[c][d][k], b, denom);
+                }
+                rc_dinv[c][d] = rt.act[c] ? 1.f / denom : 0.f;
+                rc_app[c][d] = 0.f;
+            }
+            const float pen = rt.dist[c] + P.slop;
+            rc_rhs[c] = rt.act[c] ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * rc_dinv[c][0] : 0.f;
+        }
+        auto rrow = [&](int c, int d) {
+            float jv = 0.f;
+            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(rt.J[c][d][j], w[j], jv);
+            float sn;
+            if (d == 0) sn = med3(rc_app[c][0] - fmaf(jv, rc_dinv[c][0], -rc_rhs[c]), 0.f, 1e10f);
+            else {
+                const float hi = rt.mu[c] * rc_app[c][0];
+                sn = med3(rc_app[c][d] - jv * rc_dinv[c][d], -hi, hi);
+                sn = hi > 0.f ? sn : rc_app[c][d];
+            }
+            const float dd = sn - rc_app[c][d]; rc_app[c][d] = sn;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) w[k] = fmaf(dd, rc_B[c][d][k], w[k]);
+        };
+        auto contacts = [&]() {      // Bullet: normals, then frictions (the object's own rows are ObjStep's: no unknown shared with these)
+            PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) rrow(c, 0);
+            PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) { rrow(c, 1); rrow(c, 2); }
+        };
 
         // ---- the object's half of the step: rows against the table only (this class has no robot-object contact)
         ObjStep ob;
@@ -330,10 +420,12 @@ struct Lane {
             for (int it = 0; it < P.iters; it += 2) {
                 motors(mrow, true);
                 if (has_limit) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) if (lim_any[j]) limit(j); }
+                contacts();
                 if (obj_on) ob.sweep();
                 if (it + 1 >= P.iters) break;
                 if (has_limit) { PBRE_UNROLL for (int j = 0; j < ND; j++) if (lim_any[j]) limit(j); }
                 motors(mrow, false);
+                contacts();
                 if (obj_on) ob.sweep();
             }
         };
@@ -359,6 +451,7 @@ struct Lane {
             if (PBRE_ANY(over)) {
 #endif
                 PBRE_UNROLL for (int j = 0; j < ND; j++) { w[j] = w0[j]; m_app[j] = 0.f; l_app[j] = 0.f; }
+                PBRE_UNROLL for (int c = 0; c < NRT; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) rc_app[c][d] = 0.f;
                 if (obj_on) ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
                 solve(motor);
             }
@@ -405,7 +498,7 @@ struct Lane {
         const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
         M3 Id; PBRE_UNROLL for (int k = 0; k < 9; k++) Id.m[k] = (k % 4 == 0) ? 1.f : 0.f;
         const float orad = sqrtf(dot(oh, oh)), ztop = tc.z + th.z;
-        int nO = 0, nT = 0;
+        int nO = 0;
         const int eo = T.ee_owner;
         t.Va = v3(0.f, 0.f, 0.f); t.Vl = v3(0.f, 0.f, 0.f); t.pe = v3(0.f, 0.f, 0.f);
         PBRE_UNROLL for (int k = 0; k < 9; k++) t.Re.m[k] = 0.f;
@@ -425,7 +518,6 @@ struct Lane {
                     const float reach = sr + P.margin + orad;
                     if (PBRE_ANY(!(dot(dd, dd) >= reach * reach)) && FX::sphere_box_dist(sc, sr, op, Ro, oh) < P.margin) nO++;
                 }
-                if (PBRE_ANY(!(sc.z - sr - ztop >= P.margin)) && FX::sphere_box_dist(sc, sr, tc, Id, th) < P.margin) nT++;
             }
             if (qd) {
                 bool anc = false;      // is j an ancestor-or-self of the EE owner?  (compile-time tree, uniform runtime owner)
@@ -438,7 +530,7 @@ struct Lane {
                 if (eo == j) { t.Re = R[j]; t.pe = p[j]; }
             }
         }
-        t.cls = (nO != 0 || nT != 0) ? 1 : 0;
+        t.cls = nO != 0 ? 1 : 0;      // complex: a robot-object contact (robot-table contacts are rows of the lane-per-env pipeline)
         return t;
     }
     static PBRE_HD int classify_state(const Tab& T, const Params& P, const float* st, int flags) {
@@ -594,6 +686,11 @@ struct Lane {
     // the chain to the end effector; same algorithm and stopping rule as Core::ik_targets / oracle orc_ik.  Writes tgt[0..ND) and
     // X[6..11].  (The reset-time targets of the home hand pose are the lane-group kernel's.)
     static PBRE_HD void ik_targets(const Tab& T, const Params& P, float* st, const float* act, float* tgt) {
+        if (T.ee_owner == Topo::ee0) ik_targets_t<Topo::ee0>(T, P, st, act, tgt); else ik_targets_t<Topo::ee1>(T, P, st, act, tgt);
+    }
+    // EO: the lane that owns the end effector; the chain base -> EO is static (T.on_chain agrees with it, lane_topo_matches)
+    template <int EO>
+    static PBRE_HD void ik_targets_t(const Tab& T, const Params& P, float* st, const float* act, float* tgt) {
         float* X = st + XO;
         V3 pos = v3(fmaf(act[0], P.ik_ps, X[6]), fmaf(act[1], P.ik_ps, X[7]), fmaf(act[2], P.ik_ps, X[8]));
         V3 eul = v3(X[9], X[10], X[11]);
@@ -606,16 +703,16 @@ struct Lane {
         if (X[14] == 0.f) { X[6] = pos.x; X[7] = pos.y; X[8] = pos.z; X[9] = eul.x; X[10] = eul.y; X[11] = eul.z; }   // (an env that left the apply_action loop keeps its pose)
         const M3 Rt = FX::quat_R(FX::euler_quat(eul));
         const V3 tp = add(pos, mv(Rt, v3(P.ik_off[0], P.ik_off[1], P.ik_off[2])));
-        const int eo = T.ee_owner;
+        constexpr int eo = EO;
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
-        float q[ND], q0[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; q0[j] = q[j]; }
+        float q[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
         for (int it = 0; it < P.ik_iters; it++) {
             // FK of the chain links only (a link off the chain has no chain link below it)
             M3 R[ND]; V3 p[ND], aw[ND];
             M3 Re = Eo; V3 po = v3(0.f, 0.f, 0.f);
             PBRE_UNROLL for (int j = 0; j < ND; j++) {
-                if (!T.on_chain[j]) continue;
+                if (!Topo::is_anc(j, EO)) continue;
                 const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
                 M3 Rl; V3 pl, ax;
                 joint_xf(T, j, q[j], Rl, pl, ax);
@@ -645,7 +742,7 @@ struct Lane {
             float A[6][6];
             PBRE_UNROLL for (int a = 0; a < 6; a++) PBRE_UNROLL for (int b = 0; b <= a; b++) A[a][b] = a == b ? P.ik_l2 : 0.f;
             PBRE_UNROLL for (int j = 0; j < ND; j++) {
-                if (!T.on_chain[j]) continue;
+                if (!Topo::is_anc(j, EO)) continue;
                 const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
                 const V3 ja = Topo::jtype(j) == 1 ? aw[j] : v3(0.f, 0.f, 0.f);
                 const float J[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
@@ -661,7 +758,7 @@ struct Lane {
             PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum / A[a][a]; }
             PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum / A[a][a]; }
             PBRE_UNROLL for (int j = 0; j < ND; j++) {
-                if (!T.on_chain[j]) continue;
+                if (!Topo::is_anc(j, EO)) continue;
                 const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
                 const V3 ja = Topo::jtype(j) == 1 ? aw[j] : v3(0.f, 0.f, 0.f);
                 const float dq = fmaf(jl.x, y[0], fmaf(jl.y, y[1], fmaf(jl.z, y[2], fmaf(ja.x, y[3], fmaf(ja.y, y[4], ja.z * y[5])))));
@@ -670,7 +767,7 @@ struct Lane {
         }
         // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
         // their current angle
-        PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = T.on_chain[j] ? q[j] : (T.blocked[j] ? T.home[j] : q0[j]);
+        PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]);
     }
 };
 

@@ -439,6 +439,33 @@ def check_obj_split(Engine, lib, n=4, steps=3, exact=True):
     return two
 
 
+def check_icub_table_contact(Engine, lib, n=2, steps=45, tol=3e-3):
+    """iCub, Cartesian control, the hand driven down onto the table: robot-table contact rows (lane-per-env pipeline: rows of kw_quad /
+    Lane::step).  Every step starts from the oracle's state (fp32), so the comparison is per step; the commanded hand pose ends up
+    below the hand itself, which the table stopped."""
+    eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=1, control_orientation=0, obj_std=0.05, tg_std=0.2)
+    eng.reset()
+    st, _ = ora.batch_reset(n)
+    xo = eng.x_off
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for k in range(steps):
+        a = rng.uniform(-0.3, 0.3, (n, 3)).astype(np.float32)
+        a[:, 2] = -1.0
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        ob, rw, dn = eng.step(a)
+        st, out = ora.batch_step(s32.astype(np.float64), a)
+        se = eng.get_state()
+        d = float(rel(se[:, :xo], st[:, :xo]).max())
+        assert d < tol, (k, d)
+        assert rel(ob, out[:, :-2]).max() < 2e-2, k
+        worst = max(worst, d)
+    hand_z, cmd_z = out[:, 2], st[:, xo + 8]
+    assert (hand_z - cmd_z > 0.01).all(), (hand_z, cmd_z)         # the table holds the hand above the commanded pose
+    return worst
+
+
 def check_icub_lane_ab(Engine, lib, monkeypatch, variant, n=64, steps=12, tol=2e-3):
     """iCub: a lane-per-env variant (PBRE_ICUB_LANE=variant) against the lane-group kernel (=0) on the same seeded free-running batch
     (joint and Cartesian control, auto-reset on and off).  The kernels round differently (M^-1 by Gauss-Jordan across a quad / by the

@@ -88,3 +88,7 @@ def test_icub_reset_snapshot(emu_lib):
 def test_icub_lane_path_matches_lane_group_kernel(emu_lib, monkeypatch):
     """CPU emulation: the lane-per-env step (pbre_lane.hpp, Lane::step / finish / ik_targets) against the lane-group core"""
     assert parity.check_icub_lane_ab(_capi.Engine, emu_lib, monkeypatch, 1, n=3, steps=8) < 2e-3
+
+
+def test_icub_hand_on_table(emu_lib):
+    print(parity.check_icub_table_contact(_capi.Engine, emu_lib, n=2, steps=45))

@@ -97,10 +97,14 @@ def test_icub_lane_pipeline_with_robot_contacts(hip_lib):
     assert info[2] == 1 and info[5] >= 1, info          # some envs were in the complex class (robot contact) at the end
 
 
-@pytest.mark.parametrize("variant", [1, 2])
-def test_icub_lane_variants_match_lane_group_kernel(hip_lib, monkeypatch, variant):
-    """free-running batches: the quad pipeline (1) and the one-kernel LDS variant (2) against the lane-group kernel, rounding level"""
-    print(parity.check_icub_lane_ab(_capi.Engine, hip_lib, monkeypatch, variant, n=96, steps=12))
+def test_icub_lane_pipeline_matches_lane_group_kernel(hip_lib, monkeypatch):
+    """free-running batches: the lane-per-env pipeline against the lane-group kernel, rounding level"""
+    print(parity.check_icub_lane_ab(_capi.Engine, hip_lib, monkeypatch, 1, n=96, steps=12))
+
+
+def test_icub_hand_on_table(hip_lib):
+    """robot-table contact rows of the lane-per-env pipeline (kw_quad) against the oracle, step by step"""
+    print(parity.check_icub_table_contact(_capi.Engine, hip_lib, n=40, steps=60))
 
 
 def test_icub_full_model_one_env_per_wave(hip_lib):

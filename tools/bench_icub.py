@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--envs", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--joint", action="store_true")
+ap.add_argument("--ik-iters", type=int, default=0, help="cap of the IK iterations (default: the reference's 100)")
 ap.add_argument("--iters", type=int, default=0, help="solver iterations (default: the reference's 150); 2 isolates everything but the solver loop")
 args = ap.parse_args()
 
@@ -28,7 +29,7 @@ import parity
 tbl, model, info = icub_table("l")
 ov = parity.icub_overrides(info, "l", 0 if args.joint else 1, 0, 1)
 eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=args.envs, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
-                   **(dict(phys={"solver_iters": args.iters}) if args.iters else {}), **ov)
+                   **(dict(phys={"solver_iters": args.iters}) if args.iters else {}), **(dict(ik_max_iters=args.ik_iters) if args.ik_iters else {}), **ov)
 t0 = time.perf_counter()
 eng.reset()
 t_reset = time.perf_counter() - t0
@@ -47,4 +48,4 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(json.dumps({"workload": "iCubPushGymEnv %s, %d envs" % ("joint control" if args.joint else "IK position control", args.envs),
                   "env_steps_per_s": args.envs * args.steps / el, "ms_per_step": el / args.steps * 1e3,
-                  "kernel_ms": eng.timing()[3], "reset_s": t_reset, "vgprs": eng.kernel_info()[1], "finite": bool(torch.isfinite(out).all())}))
+                  "kernel_ms": eng.timing()[3], "reset_s": t_reset, "vgprs": eng.kernel_info()[1], "complex_envs": eng.kernel_info()[5], "finite": bool(torch.isfinite(out).all())}))

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""iCub push, auto-reset, random actions: step time and number of envs in the complex class (robot collision sphere near table / object)
+as the batch approaches its stationary mix.   python tools/icub_steady.py [--envs 32768] [--steps 1500] [--joint] [--max-steps 500]"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ap = argparse.ArgumentParser()
+ap.add_argument("--envs", type=int, default=32768); ap.add_argument("--steps", type=int, default=1500)
+ap.add_argument("--joint", action="store_true"); ap.add_argument("--max-steps", type=int, default=500); ap.add_argument("--window", type=int, default=250)
+args = ap.parse_args()
+import numpy as np, torch
+from pybullet_robot_envs import _capi
+from pybullet_robot_envs.model.table import icub_table
+import parity
+tbl, model, info = icub_table("l")
+ov = parity.icub_overrides(info, "l", 0 if args.joint else 1, 0, 1)
+eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=args.envs, robot=_capi.ROBOT_ICUB, flags=_capi.F_AUTO_RESET, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+                   max_steps=args.max_steps, **ov)
+eng.reset()
+dev = torch.device("cuda", 0)
+act = [torch.rand((args.envs, eng.act_dim), device=dev) * 2 - 1 for _ in range(8)]
+out = torch.zeros((args.envs, eng.obs_dim + 2), device=dev)
+s = torch.cuda.Stream(device=dev); torch.cuda.set_stream(s)
+res = []
+for w in range(args.steps // args.window):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(args.window):
+        eng.step_device(act[k % 8].data_ptr(), out.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    res.append({"steps_done": (w + 1) * args.window, "ms_per_step": round(el / args.window * 1e3, 4), "M_env_steps_per_s": round(args.envs * args.window / el / 1e6, 2),
+                "complex_envs": eng.kernel_info()[5], "with_object_contact": eng.kernel_info()[6], "finite": bool(torch.isfinite(out).all())})
+print(json.dumps({"workload": "iCubPushGymEnv %s, %d envs, auto-reset, max_steps %d" % ("joint control" if args.joint else "IK position control", args.envs, args.max_steps),
+                  "lane": os.environ.get("PBRE_ICUB_LANE", "1"), "windows": res}))
