@@ -169,11 +169,25 @@ def other_configs(torch, dev, steps=10):
         from pybullet_robot_envs.envs import iCubReachGymEnv
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)   # iCubReach-v0 kwargs
         env.reset()
-        r, _ = timed(env._engine, [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(4)])
-        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs"
-        r["_envs_per_wave"] = 2
+        acts = [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(8)]
+        r, _ = timed(env._engine, acts)
+        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, right after reset()"
+        r["pipeline"] = "kw_dyn (1 thread / env) -> kw_quad (4 lanes / env) -> kw_fin; envs whose hand touches the object: lane-group kernel" if env._engine.kernel_info()[2] else "lane-group kernel"
+        r["_envs_per_wave"] = 16 if env._engine.kernel_info()[2] else 2
         # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
         roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
+        env.close()
+        # the same env in its stationary mix under random actions: auto-reset, 600 untimed steps first.  A third to a half of the
+        # envs then has a hand or forearm on the table and many IK targets are out of reach (the IK runs its 100 iterations)
+        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768, auto_reset=True)
+        env.reset()
+        o = torch.zeros((32768, env._engine.obs_dim + 2), device=dev)
+        sh = _capi.torch_stream(dev)
+        for k in range(600):
+            env._engine.step_device(acts[k % 8].data_ptr(), o.data_ptr(), sh)
+        r2, _ = timed(env._engine, acts)
+        r["steady_random_actions"] = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": 600,
+                                      "envs_with_robot_object_contact": int(env._engine.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
         out["icub_reach"] = r
         env.close()
     except Exception as e:

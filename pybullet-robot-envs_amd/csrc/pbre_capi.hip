@@ -285,7 +285,7 @@ struct pbre_ctx {
     hipEvent_t ev_k[KRING][2] = {};
     long k_steps = 0, launches = 0;
     double ms[3] = {0, 0, 0};
-    int zero_copy = 0;                 // PBRE_ZERO_COPY (A/B): pbre_step lets the kernels access page-locked host buffers directly
+    int zero_copy = 3;                 // PBRE_ZERO_COPY: pbre_step lets the kernels access page-locked host buffers directly (bit 0 actions, bit 1 rows; 0: staged copies)
     bool have_snapshot = false;        // a full pbre_reset has recorded the settled snapshot (rst_q, rst_objz)
     unsigned char* d_mask = nullptr;
     bool ext_dirty = false;            // a pbre_step_device was enqueued on a caller-supplied stream since the last quiesce()

@@ -1,22 +1,30 @@
-// pbre_lane.hpp -- lane-per-env step for robots of the wide shapes (the iCub as simulated: 20 DoF, Shape32 state records).
+// pbre_lane.hpp -- the iCub's step with one env per lane / per quad of lanes (20 DoF, Shape32 state records), against the lane-group
+// kernel of pbre_core.hpp (one env per half-wave: every scalar of a row replicated over 32 lanes, every row ending in a cross-lane
+// broadcast).
 //
-// One thread = one env, 64 envs per wavefront, as in pbre_fast.hpp for the Panda -- against the lane-group kernel of pbre_core.hpp
-// (one env per half-wave, every scalar of a row replicated over 32 lanes and every row ending in a cross-lane broadcast) a motor
-// row costs a wave ~1/8 of the issue slots per env.  What does not fit the Panda recipe is M^-1: 210 floats per env (symmetric
-// 20 x 20) cannot live in registers next to the solver state, so it lives in wave-private LDS laid out [entry][lane] (conflict
-// free, every address an immediate offset); the PBRE_LANE_MREG entries with the highest indices stay in registers so that four
-// waves -- one per SIMD -- fit a CU's 160 KB.
+// This header holds the per-env pieces, plain C++ (device: pbre_lane.hip; host: tests/host_emu):
+//   dynamics()    kinematics + dynamics of a state: bias torques, joint-space inertia M (CRBA), robot-table contact slots with their
+//                 Jacobian rows -- chain by chain over a compile-time tree (TopoICub), everything in registers;
+//   finish()      observation / reward / termination / auto-reset of the new state and its class;
+//   ik_targets()  Cartesian control: damped-least-squares IK over the (static) chain to the hand;
+//   step()        the whole step of one env in one piece: dynamics, M^-1 (sweep operator, in a caller-provided store), motor / limit /
+//                 robot-table contact rows, the object's rows (ObjStep) inside the same 150 sweeps, integration, finish.  This is the
+//                 form the CPU emulation runs and the reference the device pipeline is checked against.  As a device kernel (M^-1 in
+//                 wave-private LDS, 40 KB per wave, one wave per SIMD) it was measured SLOWER than the lane-group kernel -- 1.05 ms
+//                 against 0.74 ms per 32768-env step: a lone wave per SIMD exposes every latency -- and is no longer built.
+// The device splits the step where the data layouts want to differ (pbre_lane.hip): dynamics() with one thread per env, the solve with
+// FOUR lanes per env (each lane owns five DoF = five rows of M^-1, 100 registers, no LDS; a PGS row is one fma, a quad broadcast and
+// five fmacs), finish() with one thread per env again.
 //
-// Handled here ("simple" class of this engine): motors, joint-limit rows (frequent on the iCub under Cartesian control, where the
-// IK targets push joints into their stops) and the object's own rows against the table (ObjStep, swept inside the same loop).
-// An env with a robot collision sphere within the contact margin of the object or the table ("complex") is stepped by the
-// lane-group kernel (Core::step) and only finished here (finish(): observation, reward, termination, auto-reset, class of the
-// new state), exactly the split of k_row_list / Fast::finish on the Panda.
+// "Simple" class of this path: motors, joint-limit rows (frequent on the iCub under Cartesian control, where the IK targets push
+// joints into their stops), robot-table contacts (with random actions a third to a half of the envs has a hand or forearm on the
+// table) and the object's own rows against the table.  An env with a robot collision sphere within the contact margin of the OBJECT
+// ("complex", ~1 % of a random-action batch) is stepped by the lane-group kernel (Core::step: the coupled system) and only finished
+// here, exactly the split of k_row_list / Fast::finish on the Panda.
 //
 // Same mathematics and reference call sites as pbre_core.hpp / pbre_fast.hpp: world-frame RNEA + CRBA + explicit M^-1, Bullet's
 // row order, iCubReachGymEnv / iCubPushGymEnv / iCubPushGymGoalEnv .step (icub_reach_gym_env.py:182-259,
 // icub_push_gym_env.py:208-282), iCubEnv.apply_action / get_observation (icub_env.py:202-361).
-// Plain C++: compiled for the device in pbre_wide.hip and for the host in tests/host_emu.
 #pragma once
 #include <math.h>
 #include "pbre_fast.hpp"

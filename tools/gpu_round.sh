@@ -23,8 +23,23 @@ bash tools/pmc.sh $TAG --steps 20 --warmup 3 2>&1 | grep -E "k_fast<7>|==" | hea
 python tools/pmc_json.py $TAG 131072 2>&1 | tail -9
 bash tools/pmc_sq.sh $TAG --steps 20 --warmup 3 2>&1 | tail -30 | grep -E "valu_insts_per_wave|valu_active|wait_any" | head -8
 echo "== iCub / hands benches"
+rm -f gpurun_out/${TAG}_icub_steady.json
 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | tee gpurun_out/${TAG}_icub_bench.json | cut -c1-300
 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_icub.py --envs 65536 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_icub.py --envs 131072 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+PBRE_ICUB_LANE=0 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | sed 's/^{/{"PBRE_ICUB_LANE": 0, /' | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+echo "== iCub: stationary mix under random actions (auto-reset), lane-per-env pipeline and lane-group kernel; kernel trace of the pipeline"
+for M in "" "--joint"; do
+  timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+  PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+done
+timeout 600 python tools/icub_steady.py --envs 131072 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py --envs 32768 --steps 750 --window 250 > $ROOTDIR/gpurun_out/${TAG}_icub_rocprof.log 2>&1)
+t=$(find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_tail.py $t --last 200 | tee gpurun_out/${TAG}_icub_kernel_trace_tail.txt
+f=$(find gpurun_out/prof_icub_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_icub_kernel_stats.csv
+find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/prof_icub_$TAG -name "*.db" -delete
+bash tools/pmc_icub.sh $TAG 2>&1 | grep -E "valu_per_wave|valu_over|wait_any_over" | head -6
 timeout 300 python tools/bench_hands.py --envs 8192 --steps 20 2>&1 | tail -1 | tee gpurun_out/${TAG}_hands_bench.json | cut -c1-300
 echo "== bench N=2 on one device (control flow, gloo-staged gather)"
 PBRE_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 20 --preroll 200 2> gpurun_out/${TAG}_bench2.err | tail -1 > gpurun_out/${TAG}_bench2.json; echo rc=$?; cut -c1-300 gpurun_out/${TAG}_bench2.json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ issue counters of the iCub step kernel (kw_step<Shape32, DevLanes32, 7>, joint control) in two --pmc passes.
+# SQ issue counters of the iCub's solver kernel (kw_quad: four lanes per env, pbre_lane.hip; joint control) in two --pmc passes.
 TAG=$1; shift
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 run() { local name=$1; shift
@@ -10,14 +10,14 @@ run b SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_
 python - $TAG <<'PY'
 import csv, glob, json, sys, collections
 tag = sys.argv[1]
-out = {"source": "rocprofv3 --pmc (2 passes, tools/pmc_icub.sh), tools/bench_icub.py --envs 32768 --steps 10 --joint, 1 MI355X", "kernel": "kw_step<Shape32, DevLanes32, 7>"}
+out = {"source": "rocprofv3 --pmc (2 passes, tools/pmc_icub.sh), tools/bench_icub.py --envs 32768 --steps 10 --joint, 1 MI355X", "kernel": "kw_quad (16 envs per wave)"}
 for name in ("a", "b"):
     fs = glob.glob("gpurun_out/pmci_%s_%s/**/*counter_collection.csv" % (tag, name), recursive=True)
     if not fs: continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].split("(")[0]
-        if "kw_step" in k and "ShapeT<32" in k and k.rstrip().endswith("7>"):
+        if "kw_quad" in k:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in agg.items(): out[c] = sum(v) / len(v)
 w = out.get("SQ_WAVES", 0); wc = out.get("SQ_WAVE_CYCLES", 0)
