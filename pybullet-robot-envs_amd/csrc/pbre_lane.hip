@@ -79,18 +79,20 @@ __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __
 //            one fma for its delta, a quad broadcast folded into the five fmacs of the velocity update), integration of the joints;
 //   kw_fin   one thread per env: the object's pose from kw_obj's twist, observation / reward / termination / auto-reset / class
 //            (Lane::finish).
-// Side buffer layout: float4 chunks [chunk][env * 4 + r]: chunks 0..24 = rows 5r..5r+4 of M (element i * 20 + col), chunk 25 and the
-// first float of chunk 26 = tau[5r..5r+4]; a wave of kw_quad reads each chunk as one contiguous 1 KB block.
-constexpr int QD = 5, DCH = 37;       // + chunks 27, 28 (slot of quad lane 0): robot-table contact flags, friction, distances; 29..36: this lane's 30 Jacobian entries
+// Side buffer layout [quad lane r][element e][env]: per quad lane 148 elements -- 0..99 rows 5r..5r+4 of M (i * 20 + col), 100..104
+// tau[5r..5r+4], 108..113 (lane 0 only) robot-table contact flags / friction / distances, 116..145 this lane's 2 x 3 x 5 contact
+// Jacobian entries.  kw_dyn (one thread per env) writes 256 contiguous bytes per store, a wave of kw_quad (16 envs x 4 lanes) reads
+// four 64-byte segments per load.
+constexpr int QD = 5, DEL = 148;      // elements per quad lane (below)
 static_assert(LaneD::ND == 4 * QD, "four lanes per env, five DoF each");
 struct DynSink {
-    float* base;        // dyn + env * 16 floats (the env's four float4 slots of chunk 0)
-    size_t cs;          // floats per chunk: 16 * n_pad
-    __device__ __forceinline__ void st(int row, int col, float v) { const int e = (row % QD) * 20 + col; base[(size_t)(e / 4) * cs + (row / QD) * 4 + (e % 4)] = v; }
+    float* base;        // dyn + env
+    size_t cs;          // floats between consecutive elements: n_pad
+    __device__ __forceinline__ void f(int r, int e, float v) { base[(size_t)(r * DEL + e) * cs] = v; }      // element e of quad lane r: a wave's store is 256 contiguous bytes
+    __device__ __forceinline__ void st(int row, int col, float v) { f(row / QD, (row % QD) * 20 + col, v); }
     __device__ __forceinline__ void put(int j, int i, float v) { st(j, i, v); if (i != j) st(i, j, v); }
     __device__ __forceinline__ void zero(int, int) {}      // unrelated branch pairs: the buffer is zeroed once, nobody writes them
-    __device__ __forceinline__ void f(int r, int e, float v) { base[(size_t)(e / 4) * cs + r * 4 + (e % 4)] = v; }      // float e of quad lane r
-    __device__ __forceinline__ void tau(int j, float v) { const int e = 100 + (j % QD); base[(size_t)(e / 4) * cs + (j / QD) * 4 + (e % 4)] = v; }
+    __device__ __forceinline__ void tau(int j, float v) { f(j / QD, 100 + (j % QD), v); }
 };
 __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n,
                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __rest
     if (st[2 * Shape32::W + 14] != 0.f) return;          // left the apply_action loop: no simulation step
     float q[LaneD::ND], qd[LaneD::ND], tau[LaneD::ND];
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
-    DynSink sink; sink.base = dyn + (size_t)env * 16; sink.cs = cs;
+    DynSink sink; sink.base = dyn + env; sink.cs = cs;
     LaneD::RtC rt;
     LaneD::dynamics(*T, P, q, qd, sink, tau, rt);
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.tau(j, tau[j]);
@@ -142,15 +144,9 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
     // ---- rows 5r..5r+4 of M and the bias torques of this lane's DoF
     float A[QD][ND], tl[QD];
     {
-        const float4* d4 = reinterpret_cast<const float4*>(dyn);
-        const size_t c4s = cs / 4;
-        PBRE_UNROLL for (int c = 0; c < 25; c++) {
-            const float4 v = d4[(size_t)c * c4s + gl];
-            A[(4 * c) / ND][(4 * c) % ND] = v.x; A[(4 * c + 1) / ND][(4 * c + 1) % ND] = v.y;
-            A[(4 * c + 2) / ND][(4 * c + 2) % ND] = v.z; A[(4 * c + 3) / ND][(4 * c + 3) % ND] = v.w;
-        }
-        const float4 t0 = d4[(size_t)25 * c4s + gl];
-        tl[0] = t0.x; tl[1] = t0.y; tl[2] = t0.z; tl[3] = t0.w; tl[4] = dyn[(size_t)26 * cs + (size_t)gl * 4];
+        const float* dl = dyn + (size_t)r * DEL * cs + env;      // this lane's elements: dl[e * cs]
+        PBRE_UNROLL for (int e = 0; e < QD * ND; e++) A[e / ND][e % ND] = dl[(size_t)e * cs];
+        PBRE_UNROLL for (int i = 0; i < QD; i++) tl[i] = dl[(size_t)(100 + i) * cs];
     }
     const int d0 = QD * r;                                 // this lane's first DoF
     float q[QD], qd[QD];
@@ -220,21 +216,21 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
     float rJ[NRT][3][QD], rB[NRT][3][QD], r_dinv[NRT][3], r_app[NRT][3], r_rhs[NRT], r_mu[NRT];
     bool rt_on[NRT];
     {
-        const size_t g0 = (size_t)(gl & ~3) * 4;              // the env's quad lane 0 slot
-        const float a0 = dyn[(size_t)27 * cs + g0], a1 = dyn[(size_t)27 * cs + g0 + 1];
+        const float* d0p = dyn + env;                         // the env's quad-lane-0 elements
+        const float a0 = d0p[(size_t)108 * cs], a1 = d0p[(size_t)109 * cs];
         rt_on[0] = __any((int)(a0 != 0.f)) != 0; rt_on[1] = __any((int)(a1 != 0.f)) != 0;      // wave-uniform; rows of a quad without the contact are exact no-ops
         PBRE_UNROLL for (int c = 0; c < NRT; c++) {
             r_rhs[c] = 0.f; r_mu[c] = 0.f;
             PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = 0.f; r_app[c][d] = 0.f; PBRE_UNROLL for (int i = 0; i < QD; i++) { rJ[c][d][i] = 0.f; rB[c][d][i] = 0.f; } }
         }
         if (rt_on[0]) {
-            float jl[32];
-            const float4* d4 = reinterpret_cast<const float4*>(dyn);
-            PBRE_UNROLL for (int c = 0; c < 8; c++) { const float4 v = d4[(size_t)(29 + c) * (cs / 4) + gl]; jl[4*c] = v.x; jl[4*c+1] = v.y; jl[4*c+2] = v.z; jl[4*c+3] = v.w; }
+            float jl[30];
+            const float* dl = dyn + (size_t)r * DEL * cs + env;
+            PBRE_UNROLL for (int e = 0; e < 30; e++) jl[e] = dl[(size_t)(116 + e) * cs];
             PBRE_UNROLL for (int c = 0; c < NRT; c++) {
                 if (!rt_on[c]) continue;
                 const bool act = (c == 0 ? a0 : a1) != 0.f;
-                r_mu[c] = act ? dyn[(size_t)27 * cs + g0 + 2 + c] : 0.f;
+                r_mu[c] = act ? d0p[(size_t)(110 + c) * cs] : 0.f;
                 PBRE_UNROLL for (int d = 0; d < 3; d++) {
                     PBRE_UNROLL for (int i = 0; i < QD; i++) rJ[c][d][i] = act ? jl[(c * 3 + d) * QD + i] : 0.f;      // (stale rows of an earlier step where there is no contact)
                     float b[QD];
@@ -248,7 +244,7 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
                     den += qb_x<0xB1>(den); den += qb_x<0x4E>(den);        // sum over the quad
                     r_dinv[c][d] = act ? 1.f / den : 0.f;
                 }
-                const float pen = dyn[(size_t)28 * cs + g0 + c] + P.slop;
+                const float pen = d0p[(size_t)(112 + c) * cs] + P.slop;
                 r_rhs[c] = act ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * r_dinv[c][0] : 0.f;
             }
         }
@@ -411,9 +407,9 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         }
         {
             const size_t npad = ((size_t)n + 15) / 16 * 16;
-            dyn_cs = 16 * npad;
-            if ((e = hipMalloc(&dyn, (size_t)DCH * dyn_cs * sizeof(float))) != hipSuccess) return e;
-            if ((e = hipMemset(dyn, 0, (size_t)DCH * dyn_cs * sizeof(float))) != hipSuccess) return e;
+            dyn_cs = npad;
+            if ((e = hipMalloc(&dyn, (size_t)4 * DEL * dyn_cs * sizeof(float))) != hipSuccess) return e;
+            if ((e = hipMemset(dyn, 0, (size_t)4 * DEL * dyn_cs * sizeof(float))) != hipSuccess) return e;
         }
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, device) == hipSuccess) n_simd = pr.multiProcessorCount * 4;

@@ -28,6 +28,8 @@ timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | 
 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
 timeout 300 python tools/bench_icub.py --envs 65536 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
 timeout 300 python tools/bench_icub.py --envs 131072 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_icub.py --envs 262144 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+timeout 300 python tools/bench_icub.py --envs 16384 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
 PBRE_ICUB_LANE=0 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | sed 's/^{/{"PBRE_ICUB_LANE": 0, /' | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
 echo "== iCub: stationary mix under random actions (auto-reset), lane-per-env pipeline and lane-group kernel; kernel trace of the pipeline"
 for M in "" "--joint"; do
@@ -35,6 +37,8 @@ for M in "" "--joint"; do
   PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 done
 timeout 600 python tools/icub_steady.py --envs 131072 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py --envs 32768 --steps 750 --window 250 > $ROOTDIR/gpurun_out/${TAG}_icub_rocprof.log 2>&1)
 t=$(find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_tail.py $t --last 200 | tee gpurun_out/${TAG}_icub_kernel_trace_tail.txt
 f=$(find gpurun_out/prof_icub_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_icub_kernel_stats.csv
