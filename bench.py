@@ -167,18 +167,12 @@ def other_configs(torch, dev, steps=10):
 
     try:
         from pybullet_robot_envs.envs import iCubReachGymEnv
-        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)   # iCubReach-v0 kwargs
-        env.reset()
         acts = [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(8)]
-        r, _ = timed(env._engine, acts)
-        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, right after reset()"
-        r["pipeline"] = "kw_dyn (1 thread / env) -> kw_quad (4 lanes / env) -> kw_fin; envs whose hand touches the object: lane-group kernel" if env._engine.kernel_info()[2] else "lane-group kernel"
-        r["_envs_per_wave"] = 16 if env._engine.kernel_info()[2] else 2
-        # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
-        roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
-        env.close()
-        # the same env in its stationary mix under random actions: auto-reset, 600 untimed steps first.  A third to a half of the
-        # envs then has a hand or forearm on the table and many IK targets are out of reach (the IK runs its 100 iterations)
+        # (1) the env in its stationary mix under random actions: auto-reset, 600 untimed steps first.  A third to a half of the envs
+        # then has a hand or forearm on the table and many IK targets are out of reach (the IK runs its 100 iterations).
+        # This leg runs first: for about a second after the Panda legs every kernel of this latency-bound, half-empty workload runs
+        # ~1.6x slower (the same command measured 0.35 or 0.6 ms per post-reset step from one process to the next; PBRE_ICUB_TRACE
+        # shows all kernels stretched alike: clocks, not scheduling) -- the 600 pre-roll steps absorb that
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768, auto_reset=True)
         env.reset()
         o = torch.zeros((32768, env._engine.obs_dim + 2), device=dev)
@@ -186,8 +180,25 @@ def other_configs(torch, dev, steps=10):
         for k in range(600):
             env._engine.step_device(acts[k % 8].data_ptr(), o.data_ptr(), sh)
         r2, _ = timed(env._engine, acts)
-        r["steady_random_actions"] = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": 600,
-                                      "envs_with_robot_object_contact": int(env._engine.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
+        steady = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": 600,
+                  "envs_with_robot_object_contact": int(env._engine.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
+        env.close()
+        # (2) right after reset(): iCubReach-v0 kwargs; three repetitions (12 steps are a 4 ms measurement), the best is reported
+        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)
+        reps = []
+        for _ in range(3):
+            env.reset()
+            rr, _ = timed(env._engine, acts)
+            reps.append(rr)
+        r = min(reps, key=lambda x: x["ms_per_step"])
+        r["ms_per_step_all_repetitions"] = [x["ms_per_step"] for x in reps]
+        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, right after reset()"
+        r["pipeline"] = ("kw_dyn (1 thread / env) -> kw_quad (4 lanes / env; envs whose hand touches the object: kw_quad_rc) -> kw_fin"
+                         if env._engine.kernel_info()[2] else "lane-group kernel")
+        r["_envs_per_wave"] = 16 if env._engine.kernel_info()[2] else 2
+        # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
+        roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
+        r["steady_random_actions"] = steady
         out["icub_reach"] = r
         env.close()
     except Exception as e:
@@ -290,6 +301,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     tbl, _ = panda_table()
+    early_other = other_configs(torch, dev) if (os.environ.get("PBRE_BENCH_OTHER_FIRST") == "1" and world == 1) else None     # (diagnostic)
     # a dedicated non-null stream: the kernels and the HIP timing events run on it; RCCL orders itself after it
     side = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(side)
@@ -544,7 +556,7 @@ def main():
                      "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "sq_counters": sq, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
         if world == 1 and not args.no_other_configs:
-            res["other_configs"] = other_configs(torch, dev)
+            res["other_configs"] = early_other if early_other is not None else other_configs(torch, dev)
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()

@@ -31,6 +31,7 @@
 #include "pbre_core.hpp"
 #include "pbre_fast.hpp"
 #include "pbre_wide.hpp"
+#include "pbre_sidepick.hpp"
 
 using namespace pbre;
 using CoreD = Core<DevLanes>;
@@ -276,7 +277,8 @@ struct pbre_ctx {
                                        // left idle for hundreds of steps makes the first steps after the switch back ~8 % slower (0: never)
     int idle_single = 1;               // with no complex envs reported, both kernels go to the caller's stream in order (no fork / join events); 0: A/B
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
-    hipStream_t stream = nullptr, side = nullptr;
+    hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
+    SidePick sp;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
@@ -374,6 +376,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     //    step (613 M -> 650 M env-steps/s at 131072 envs).  Taken only when the device has reported no complex env for 16 steps in a
     //    row (a count that flickers between 0 and a few would otherwise serialise the two kernels every other step); a stale
     //    hint only serialises them for that step.
+    c->side = c->sp.pick(s);
     const int hint = b.h_total[0];
     const bool rc_first = hint >= c->rc_first_min;
     const bool single = c->idle_single && hint == 0 && b.h_total[1] == 0;      // both kernels in order on the caller's stream
@@ -467,7 +470,7 @@ void pbre_destroy(pbre_ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (auto& pr : c->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->side) (void)hipStreamDestroy(c->side);
+    c->sp.destroy(); c->side = nullptr;
     delete c;
 }
 
@@ -508,7 +511,8 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(hipSetDevice(c->device));
     { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, c->device)); c->n_simd = std::max(1, pr.multiProcessorCount * 4); }
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    CK(c->sp.create(0, false));
+    c->side = c->sp.side;
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
     CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));

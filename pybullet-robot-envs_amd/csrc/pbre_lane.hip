@@ -3,10 +3,12 @@
 // code needs -mllvm -pragma-unroll-threshold far above the default (build.sh), which the other kernels are not compiled with.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
 #include "pbre_wide_impl.hpp"
+#include "pbre_sidepick.hpp"
 
 // lane-per-env path of the 20-DoF iCub (pbre_lane.hpp): device definitions of its hooks
 #define PBRE_ANY(x) (__any((int)(x)) != 0)
@@ -33,34 +35,6 @@ __device__ __forceinline__ void wpublish(int env, int c, signed char* __restrict
     cls[env] = (signed char)c;
     if (c) next_list[atomicAdd(next_count, 1)] = env;
 }
-// Complex envs over the compacted list: physics by the lane-group kernel (Core::step: all row types, one env per half-wave),
-// observation / reward / termination / auto-reset / class of the new state by Lane::finish on the group's first lane.
-__global__ __launch_bounds__(WTPB, 3) void kw_list(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags, int MODE,
-                                                   const float* __restrict__ tgt, const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count) {
-    constexpr int EPB = WTPB / 32;
-    const int PHYS = MODE & (CoreW::M_ACTION | CoreW::M_TGT);
-    const int total = *cur_count;
-    for (int base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {
-        const int i = base + (int)(threadIdx.x / 32);
-        if (i >= total) break;                      // whole lane group; the wave's other group keeps going
-        const int env = cur_list[i];
-        float* st = state + (size_t)env * Shape32::STATE;
-        CoreW::step(*T, P, st, (MODE & CoreW::M_ACTION) ? actions + (size_t)env * act_dim : nullptr, nullptr, PHYS, flags,
-                    (MODE & CoreW::M_TGT) ? tgt + (size_t)env * Shape32::TGT : nullptr, P.env_id_base + (unsigned long long)env, nullptr);
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);    // the group's stores are read back by its first lane below
-        if ((threadIdx.x & 31u) == 0) {
-            float q[LaneD::ND], qd[LaneD::ND];
-            PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
-            LaneD::V3 op; op.x = st[Shape32::LC]; op.y = st[Shape32::LC + 1]; op.z = st[Shape32::LC + 2];
-            LaneD::Q4 oq; oq.x = st[Shape32::LC + 3]; oq.y = st[Shape32::LC + 4]; oq.z = st[Shape32::LC + 5]; oq.w = st[Shape32::LC + 6];
-            const int c = LaneD::finish(*T, P, st, q, qd, op, oq, (MODE & LaneD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
-                                        P.env_id_base + (unsigned long long)env);
-            wpublish(env, c, cls, next_list, next_count);
-        }
-    }
-}
 // Cartesian control: hand-pose update + inverse kinematics -> joint targets, one thread per env
 __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
@@ -81,9 +55,11 @@ __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __
 //            (Lane::finish).
 // Side buffer layout [quad lane r][element e][env]: per quad lane 148 elements -- 0..99 rows 5r..5r+4 of M (i * 20 + col), 100..104
 // tau[5r..5r+4], 108..113 (lane 0 only) robot-table contact flags / friction / distances, 116..145 this lane's 2 x 3 x 5 contact
-// Jacobian entries.  kw_dyn (one thread per env) writes 256 contiguous bytes per store, a wave of kw_quad (16 envs x 4 lanes) reads
-// four 64-byte segments per load.
-constexpr int QD = 5, DEL = 148;      // elements per quad lane (below)
+// Jacobian entries; envs of the complex class (robot-object contact): 148..177 this lane's robot-object Jacobian entries, 178..207 (lane
+// 0) flags / friction / distances / contact frames / lever arms of the two slots, 208..213 (lane 0) the object's twist after the
+// coupled solve (kw_quad_rc -> kw_fin).  kw_dyn (one thread per env) writes 256 contiguous bytes per store, a wave of kw_quad (16
+// envs x 4 lanes) reads four 64-byte segments per load.
+constexpr int QD = 5, DEL = 216;      // elements per quad lane (below)
 static_assert(LaneD::ND == 4 * QD, "four lanes per env, five DoF each");
 struct DynSink {
     float* base;        // dyn + env
@@ -94,17 +70,23 @@ struct DynSink {
     __device__ __forceinline__ void zero(int, int) {}      // unrelated branch pairs: the buffer is zeroed once, nobody writes them
     __device__ __forceinline__ void tau(int j, float v) { f(j / QD, 100 + (j % QD), v); }
 };
-__global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n,
+__global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
     const int env = blockIdx.x * LTPB + threadIdx.x;
-    if (env >= n || cls_cur[env] != 0) return;
+    if (env >= n) return;
     const float* st = state + (size_t)env * Shape32::STATE;
     if (st[2 * Shape32::W + 14] != 0.f) return;          // left the apply_action loop: no simulation step
+    constexpr int LC = Shape32::LC;
     float q[LaneD::ND], qd[LaneD::ND], tau[LaneD::ND];
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
     DynSink sink; sink.base = dyn + env; sink.cs = cs;
     LaneD::RtC rt;
-    LaneD::dynamics(*T, P, q, qd, sink, tau, rt);
+    LaneD::RoC ro;
+    const bool rc = cls_cur[env] != 0 && !(flags & 1);   // complex class: a robot sphere within the contact margin of the object
+    const bool any_rc = __any((int)rc) != 0;
+    LaneD::V3 op; op.x = st[LC]; op.y = st[LC + 1]; op.z = st[LC + 2];
+    LaneD::Q4 oq; oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+    LaneD::dynamics(*T, P, q, qd, sink, tau, rt, any_rc ? &ro : nullptr, op, oq);
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.tau(j, tau[j]);
     // robot-table contact slots: flags / friction / distances always, the Jacobian rows of the envs that have a contact
     sink.f(0, 108, rt.act[0] ? 1.f : 0.f); sink.f(0, 109, rt.act[1] ? 1.f : 0.f); sink.f(0, 110, rt.mu[0]); sink.f(0, 111, rt.mu[1]);
@@ -113,6 +95,16 @@ __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __rest
         PBRE_UNROLL for (int c = 0; c < LaneD::NRT; c++)
             PBRE_UNROLL for (int d = 0; d < 3; d++)
                 PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.f(j / QD, 116 + (c * 3 + d) * QD + (j % QD), rt.J[c][d][j]);
+    }
+    if (any_rc && rc) {          // robot-object contact slots of a complex env
+        PBRE_UNROLL for (int c = 0; c < LaneD::NRO; c++) {
+            sink.f(0, 178 + c, ro.act[c] ? 1.f : 0.f); sink.f(0, 180 + c, ro.mu[c]); sink.f(0, 182 + c, ro.dist[c]);
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                sink.f(0, 184 + (c * 3 + d) * 3, ro.dir[c][d].x); sink.f(0, 185 + (c * 3 + d) * 3, ro.dir[c][d].y); sink.f(0, 186 + (c * 3 + d) * 3, ro.dir[c][d].z);
+                PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.f(j / QD, 148 + (c * 3 + d) * QD + (j % QD), ro.J[c][d][j]);
+            }
+            sink.f(0, 202 + c * 3, ro.rB[c].x); sink.f(0, 203 + c * 3, ro.rB[c].y); sink.f(0, 204 + c * 3, ro.rB[c].z);
+        }
     }
 }
 
@@ -125,16 +117,13 @@ template <int CTRL> __device__ __forceinline__ float qb_x(float x) {      // qua
 }
 __device__ __forceinline__ float qb(float x, int o) { return o == 0 ? qb_t<0>(x) : (o == 1 ? qb_t<1>(x) : (o == 2 ? qb_t<2>(x) : qb_t<3>(x))); }
 
-#ifndef PBRE_QUAD_WAVES
-#define PBRE_QUAD_WAVES 2            // waves per SIMD kw_quad is register-limited to (A/B on MI355X, 65536 envs: 3 -> 100, 2 -> 115 M env-steps/s; no spills at 2)
-#endif
-__global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
-                                                   const signed char* __restrict__ cls_cur, const float* __restrict__ dyn, size_t cs) {
+// The solve of one env by the four lanes of a quad.  RC: the env has robot-object contacts -- the object's twist and its rows against the
+// table (ObjStep, evaluated by all four lanes alike) are part of the same sweeps, coupled to the joints through the robot-object rows.
+template <bool RC>
+__device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T, const Params& P, float* __restrict__ state,
+                                          const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
+                                          float* __restrict__ dyn, size_t cs, int env, int r) {
     constexpr int ND = LaneD::ND, W = Shape32::W, XO = 2 * Shape32::W;
-    const int gl = blockIdx.x * LTPB + threadIdx.x;
-    const int env = gl >> 2, r = gl & 3;
-    if (env >= n || cls_cur[env] != 0) return;             // (whole quads)
     float* st = state + (size_t)env * Shape32::STATE;
     if (st[XO + 14] != 0.f) return;
     const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
@@ -263,19 +252,90 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
         const float dd = sn - r_app[c][d]; r_app[c][d] = sn;
         PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(dd, rB[c][d][k], w[k]);
     };
-    auto contacts = [&]() {            // Bullet: normals, then frictions
+    const bool has_rt = rt_on[0];
+    // ---- RC: the object (pbre_objstep.hpp: unconstrained twist, rows against the table) and the robot-object rows that couple it to the
+    //      joints.  Row along dir at the box point op + rB: J = [J_robot ; -dir ; -(rB x dir)]; an impulse dd changes the joint
+    //      velocities by dd B, the object's twist by (-dd / m dir, -dd I_w^-1 (rB x dir)).
+    constexpr int NRO = LaneD::NRO;
+    ObjStep ob;
+    float oJ[RC ? NRO : 1][3][QD], oB[RC ? NRO : 1][3][QD], o_dir[RC ? NRO : 1][3][3], o_rxd[RC ? NRO : 1][3][3], o_g[RC ? NRO : 1][3][3];
+    float o_dinv[RC ? NRO : 1][3], o_app[RC ? NRO : 1][3], o_rhs[RC ? NRO : 1], o_mu[RC ? NRO : 1];
+    float pose[7], tw0[6];
+    const float inv_m = 1.f / P.obj_m;
+    if (RC) {
+        PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[Shape32::LC + k];
+        PBRE_UNROLL for (int k = 0; k < 6; k++) tw0[k] = st[W + Shape32::LC + k];
+        ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
+        const float* d0p = dyn + env;
+        const float* dl = dyn + (size_t)r * DEL * cs + env;
+        PBRE_UNROLL for (int c = 0; c < NRO; c++) {
+            const bool act = d0p[(size_t)(178 + c) * cs] != 0.f;
+            o_mu[c] = act ? d0p[(size_t)(180 + c) * cs] : 0.f;
+            const float rbx = d0p[(size_t)(202 + c * 3) * cs], rby = d0p[(size_t)(203 + c * 3) * cs], rbz = d0p[(size_t)(204 + c * 3) * cs];
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                const float dx = act ? d0p[(size_t)(184 + (c * 3 + d) * 3) * cs] : 0.f, dy = act ? d0p[(size_t)(185 + (c * 3 + d) * 3) * cs] : 0.f,
+                            dz = act ? d0p[(size_t)(186 + (c * 3 + d) * 3) * cs] : 0.f;
+                o_dir[c][d][0] = dx; o_dir[c][d][1] = dy; o_dir[c][d][2] = dz;
+                const float cx = rby * dz - rbz * dy, cy = rbz * dx - rbx * dz, cz = rbx * dy - rby * dx;      // rB x dir
+                o_rxd[c][d][0] = cx; o_rxd[c][d][1] = cy; o_rxd[c][d][2] = cz;
+                // I_w^-1 (rB x dir) = (m I_w^-1)(rB x dir) / m
+                o_g[c][d][0] = (ob.Ii[0] * cx + ob.Ii[3] * cy + ob.Ii[4] * cz) * inv_m;
+                o_g[c][d][1] = (ob.Ii[3] * cx + ob.Ii[1] * cy + ob.Ii[5] * cz) * inv_m;
+                o_g[c][d][2] = (ob.Ii[4] * cx + ob.Ii[5] * cy + ob.Ii[2] * cz) * inv_m;
+                PBRE_UNROLL for (int i = 0; i < QD; i++) oJ[c][d][i] = act ? dl[(size_t)(148 + (c * 3 + d) * QD + i) * cs] : 0.f;
+                float b[QD];
+                PBRE_UNROLL for (int i = 0; i < QD; i++) b[i] = 0.f;
+                PBRE_UNROLL for (int col = 0; col < ND; col++) {
+                    const float jc = qb(oJ[c][d][col % QD], col / QD);
+                    PBRE_UNROLL for (int i = 0; i < QD; i++) b[i] = fmaf(A[i][col], jc, b[i]);
+                }
+                float den = 0.f;
+                PBRE_UNROLL for (int i = 0; i < QD; i++) { oB[c][d][i] = b[i]; den = fmaf(oJ[c][d][i], b[i], den); }
+                den += qb_x<0xB1>(den); den += qb_x<0x4E>(den);
+                den += (dx * dx + dy * dy + dz * dz) * inv_m + (cx * o_g[c][d][0] + cy * o_g[c][d][1] + cz * o_g[c][d][2]);
+                o_dinv[c][d] = act ? 1.f / den : 0.f;
+                o_app[c][d] = 0.f;
+            }
+            const float pen = d0p[(size_t)(182 + c) * cs] + P.slop;
+            o_rhs[c] = act ? (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * o_dinv[c][0] : 0.f;
+        }
+    }
+    auto orow = [&](int c, int d) {    // robot-object row (RC)
+        float jv = 0.f;
+        PBRE_UNROLL for (int i = 0; i < QD; i++) jv = fmaf(oJ[c][d][i], w[i], jv);
+        jv += qb_x<0xB1>(jv); jv += qb_x<0x4E>(jv);
+        jv -= o_dir[c][d][0] * ob.vx + o_dir[c][d][1] * ob.vy + o_dir[c][d][2] * ob.vz + o_rxd[c][d][0] * ob.wx + o_rxd[c][d][1] * ob.wy + o_rxd[c][d][2] * ob.wz;
+        float sn;
+        if (d == 0) sn = __builtin_amdgcn_fmed3f(o_app[c][0] - fmaf(jv, o_dinv[c][0], -o_rhs[c]), 0.f, 1e10f);
+        else {
+            const float hi = o_mu[c] * o_app[c][0];
+            sn = __builtin_amdgcn_fmed3f(o_app[c][d] - jv * o_dinv[c][d], -hi, hi);
+            sn = hi > 0.f ? sn : o_app[c][d];
+        }
+        const float dd = sn - o_app[c][d]; o_app[c][d] = sn;
+        PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(dd, oB[c][d][k], w[k]);
+        const float dm = -dd * inv_m;
+        ob.vx = fmaf(dm, o_dir[c][d][0], ob.vx); ob.vy = fmaf(dm, o_dir[c][d][1], ob.vy); ob.vz = fmaf(dm, o_dir[c][d][2], ob.vz);
+        ob.wx = fmaf(-dd, o_g[c][d][0], ob.wx); ob.wy = fmaf(-dd, o_g[c][d][1], ob.wy); ob.wz = fmaf(-dd, o_g[c][d][2], ob.wz);
+    };
+    auto contacts = [&]() {            // Bullet: all normals (object-table, robot-object, robot-table), then all frictions
+        if (RC) { ob.sweep_normals(); PBRE_UNROLL for (int c = 0; c < NRO; c++) orow(c, 0); }
         PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) rrow(c, 0);
+        if (RC) { ob.sweep_frictions(); PBRE_UNROLL for (int c = 0; c < NRO; c++) { orow(c, 1); orow(c, 2); } }
         PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) { rrow(c, 1); rrow(c, 2); }
     };
-    const bool has_rt = rt_on[0];
 
     const float mlim = P.motor_imp, llim = P.limit_imp;
     auto axpy = [&](int j, float d) { PBRE_UNROLL for (int k = 0; k < QD; k++) w[k] = fmaf(d, A[k][j], w[k]); };
-    auto motor_free = [&](int j) {     // clamp-free row; sabs: sum of |delta| of the motor this lane owns (bounds every value its impulse had)
+    float peak = 0.f;                  // clamp-free rows: the largest |applied impulse| a motor of this lane had at the end of any sweep
+    auto motor_free = [&](int j) {     // clamp-free row; sabs: the applied impulse of the motor this lane owns
         const int o = j / QD, i0 = j % QD;
         const float d = qb(fmaf(-m_dinv[i0], w[i0], m_rhs[i0]), o);
-        sabs[i0] = fmaf(fabsf(d), own[o], sabs[i0]);
+        sabs[i0] = fmaf(d, own[o], sabs[i0]);
         axpy(j, d);
+    };
+    auto track = [&]() {               // (a motor's impulse changes once per sweep, in its own row: every value it takes is seen)
+        PBRE_UNROLL for (int i = 0; i < QD; i++) peak = fmaxf(peak, fabsf(sabs[i]));
     };
     auto motor = [&](int j) {          // clamping row, delta form (sabs holds the applied impulse here)
         const int o = j / QD, i0 = j % QD;
@@ -295,21 +355,26 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
     auto solve = [&](auto&& mrow) {
         for (int it = 0; it < P.iters; it += 2) {
             PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) mrow(j);
+            track();
             if (has_limit) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) if (lim_on[j]) limit(j); }
-            if (has_rt) contacts();
+            if (RC || has_rt) contacts();
             if (it + 1 >= P.iters) break;
             if (has_limit) { PBRE_UNROLL for (int j = 0; j < ND; j++) if (lim_on[j]) limit(j); }
             PBRE_UNROLL for (int j = 0; j < ND; j++) mrow(j);
-            if (has_rt) contacts();
+            track();
+            if (RC || has_rt) contacts();
         }
     };
     solve(motor_free);
     {
-        bool over = false;
-        PBRE_UNROLL for (int i = 0; i < QD; i++) over = over || !(sabs[i] <= mlim);      // (a NaN fails the test as well)
+        const bool over = !(peak <= mlim);      // (a NaN fails the test as well)
         if (__any((int)over)) {
             PBRE_UNROLL for (int i = 0; i < QD; i++) { w[i] = w0[i]; sabs[i] = 0.f; l_app[i] = 0.f; }
             PBRE_UNROLL for (int c = 0; c < NRT; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
+            if (RC) {
+                ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
+                PBRE_UNROLL for (int c = 0; c < NRO; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) o_app[c][d] = 0.f;
+            }
             solve(motor);
         }
     }
@@ -318,17 +383,48 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
         const float v = fminf(fmaxf(w[i], -vmax), vmax);
         st[W + d0 + i] = v; st[d0 + i] = fmaf(dt, v, q[i]);
     }
+    if (RC && r == 0) {      // the object's twist after the coupled solve, for kw_fin
+        float o[6];
+        ob.result(P, o);
+        PBRE_UNROLL for (int k = 0; k < 6; k++) dyn[(size_t)(208 + k) * cs + env] = o[k];
+    }
 }
 
-// The end of a simple env's step: object pose from the twist kw_obj left in the side record, then Lane::finish.
+#ifndef PBRE_QUAD_WAVES
+#define PBRE_QUAD_WAVES 2            // waves per SIMD kw_quad is register-limited to (A/B on MI355X, 65536 envs: 3 -> 100, 2 -> 115 M env-steps/s; no spills at 2)
+#endif
+// Simple envs: every env of the batch in natural order, the quads of complex envs idle.
+__global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                   const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
+                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
+    const int gl = blockIdx.x * LTPB + threadIdx.x;
+    const int env = gl >> 2;
+    if (env >= n || cls_cur[env] != 0) return;             // (whole quads)
+    quad_step<false>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, env, gl & 3);
+}
+// Complex envs (robot-object contact) over the compacted list, 16 per wave; a whole SIMD's register file per wave.  Persistent blocks
+// (the host does not know the list's length).
+__global__ __launch_bounds__(LTPB, 1) void kw_quad_rc(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
+                                                      const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
+                                                      const int* __restrict__ cur_list, const int* __restrict__ cur_count, float* __restrict__ dyn, size_t cs) {
+    const int total = *cur_count;
+    for (int base = blockIdx.x * (LTPB / 4); base < total; base += gridDim.x * (LTPB / 4)) {
+        const int i = base + (int)(threadIdx.x >> 2);
+        if (i >= total) break;                             // (whole quads)
+        quad_step<true>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, cur_list[i], (int)(threadIdx.x & 3));
+    }
+}
+
+// The end of an env's step: object pose from the twist kw_obj left in the side record (simple envs) / kw_quad_rc left in the dyn buffer
+// (complex envs), then Lane::finish.
 __global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state, float* __restrict__ out,
-                                               int n, int ow, int flags, int MODE, const float* __restrict__ objv,
+                                               int n, int ow, int flags, int MODE, const float* __restrict__ objv, const float* __restrict__ dyn, size_t cs,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                                int* __restrict__ next_count, int* __restrict__ zero_count) {
     constexpr int ND = LaneD::ND, W = Shape32::W, LC = Shape32::LC, XO = 2 * Shape32::W;
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) *zero_count = 0;
-    if (env >= n || cls_cur[env] != 0) return;
+    if (env >= n) return;
     float* st = state + (size_t)env * Shape32::STATE;
     float q[ND], qd[ND];
     PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[W + j]; }
@@ -336,7 +432,9 @@ __global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restric
     LaneD::Q4 oq; oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
     if (!(flags & 1) && st[XO + 14] == 0.f) {
         const float dt = P.dt;
-        const float* o = objv + (size_t)env * W + LC;
+        float o[6];
+        if (cls_cur[env] != 0) { PBRE_UNROLL for (int k = 0; k < 6; k++) o[k] = dyn[(size_t)(208 + k) * cs + env]; }
+        else { PBRE_UNROLL for (int k = 0; k < 6; k++) o[k] = objv[(size_t)env * W + LC + k]; }
         LaneD::V3 ov, ow_; ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ow_.x = o[3]; ow_.y = o[4]; ow_.z = o[5];
         op.x = fmaf(dt, ov.x, op.x); op.y = fmaf(dt, ov.y, op.y); op.z = fmaf(dt, ov.z, op.z);
         float ang = sqrtf(fmaf(ow_.x, ow_.x, fmaf(ow_.y, ow_.y, ow_.z * ow_.z)));
@@ -377,16 +475,18 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     int cur = 0, ccur = 0;
     bool cls_valid = false, topo_ok = false, enabled = true;
     float* dyn = nullptr;             // side buffer of the quad pipeline
-    hipStream_t side = nullptr;       // kw_list (few lane-group waves, latency-bound) and kw_obj run beside kw_dyn / kw_quad
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr;       // kw_obj, the IK kernel and kw_quad_rc run beside kw_dyn / kw_quad; picked per caller stream (pick_side)
+    SidePick sp;                      // candidates + calibration (pbre_sidepick.hpp)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_dyn = nullptr;
     size_t dyn_cs = 0;
     int n_simd = 1024;
     ~WideLane() override {
         for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn}) if (p) (void)hipFree(p);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_dyn) (void)hipEventDestroy(ev_dyn);
         if (ev_ik) (void)hipEventDestroy(ev_ik);
-        if (side) (void)hipStreamDestroy(side);
+        sp.destroy();
     }
     bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr; }
     void lane_invalidate() override { cls_valid = false; }
@@ -400,13 +500,22 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         if ((e = hipMalloc(&list, 2 * (size_t)n * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMalloc(&count, 3 * sizeof(int))) != hipSuccess) return e;
         if (!(getenv("PBRE_ICUB_SIDE") && getenv("PBRE_ICUB_SIDE")[0] == '0')) {      // PBRE_ICUB_SIDE=0: everything in stream order (A/B)
-            if ((e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking)) != hipSuccess) return e;
+            // highest priority: the complex envs' few waves need a whole SIMD's registers each -- they have to be placed before
+            // kw_quad's waves fill every SIMD, or they would run after it
+            int plo = 0, phi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+            if ((e = sp.create(phi, true)) != hipSuccess) return e;
+            side = sp.side;
             if ((e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_dyn, hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_ik, hipEventDisableTiming)) != hipSuccess) return e;
         }
         {
-            const size_t npad = ((size_t)n + 15) / 16 * 16;
+            // element stride: a multiple of 16 floats (kw_quad's 64-byte segments stay aligned), but never a power of two -- with 32768 envs
+            // consecutive elements were 128 KB apart and every store / load of a wave fell on the same few HBM channels; which channels
+            // depended on where the allocation landed: the same command ran at 0.35 or at 0.6 ms per step from one process to the next
+            const size_t npad = ((size_t)n + 15) / 16 * 16 + 1040;
             dyn_cs = npad;
             if ((e = hipMalloc(&dyn, (size_t)4 * DEL * dyn_cs * sizeof(float))) != hipSuccess) return e;
             if ((e = hipMemset(dyn, 0, (size_t)4 * DEL * dyn_cs * sizeof(float))) != hipSuccess) return e;
@@ -415,6 +524,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         if (hipGetDeviceProperties(&pr, device) == hipSuccess) n_simd = pr.multiProcessorCount * 4;
         return hipSuccess;
     }
+    long n_lane_steps = 0;
     bool ik_pending = false;          // Cartesian control: the IK kernel of this step is launched by lane_t (beside kw_dyn, which does not need the targets)
     hipEvent_t ev_ik = nullptr;
     void launch_lane_ik(const float* act, hipStream_t s) override {
@@ -425,29 +535,57 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         signed char* c_cur = cls + (size_t)cur * n; signed char* c_nxt = cls + (size_t)(cur ^ 1) * n;
         int* l_cur = list + (size_t)cur * n; int* l_nxt = list + (size_t)(cur ^ 1) * n;
         int* k_cur = count + ccur; int* k_nxt = count + (ccur + 1) % 3; int* k_zero = count + (ccur + 2) % 3;
-        const int gl = std::min((n + 7) / 8, n_simd);      // persistent blocks of 8 groups; blocks without work exit at once
         const int be = (n + LTPB - 1) / LTPB;
+        if (side) side = sp.pick(s);
+        // PBRE_ICUB_TRACE=<k>: HIP events around every kernel of the k-th and the following two steps, durations and start offsets on stderr
+        static const int trace_at = getenv("PBRE_ICUB_TRACE") ? atoi(getenv("PBRE_ICUB_TRACE")) : -1;
+        const bool tr = trace_at >= 0 && n_lane_steps >= trace_at && n_lane_steps < trace_at + 3;
+        n_lane_steps++;
+        hipEvent_t te[14] = {};
+        if (tr) for (auto& e : te) (void)hipEventCreate(&e);
+        auto mark = [&](int k, hipStream_t st) { if (tr) (void)hipEventRecord(te[k], st); };
         {
-            // the complex envs' kernel (a few lane-group waves, ~0.3 ms of latency) and the object solve (45 us of latency) on the side
-            // stream, beside kw_dyn -> kw_quad; kw_fin needs the object twists, the next step both kernels' classes
+            // side stream: the object solve of the simple envs (45 us of latency), the IK kernel (Cartesian control; kw_dyn does not need
+            // the targets), then -- once kw_dyn is through -- the complex envs' coupled solve (a few lone waves) beside kw_quad; kw_fin
+            // needs all of it
             hipStream_t s2 = side ? side : s;
+            mark(0, s);
             if (side) { (void)hipEventRecord(ev_fork, s); (void)hipStreamWaitEvent(side, ev_fork, 0); }
+            mark(1, s2);
+            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
+            mark(2, s2);
             const bool ik_side = ik_pending;
-            if (ik_side) {
+            if (ik_side) {      // (after kw_obj: kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
                 hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim);
                 (void)hipEventRecord(ev_ik, side);
                 ik_pending = false;
             }
-            hipLaunchKernelGGL(kw_list, dim3(gl), dim3(WTPB), 0, s2, dT, P, state, act, out, act_dim, ow, flags, MODE, tgt, l_cur, k_cur, c_nxt, l_nxt, k_nxt);
-            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
-            if (side) (void)hipEventRecord(ev_join, side);
+            mark(3, s2);
             if (ek) (void)hipEventRecord(ek[0], s);
-            hipLaunchKernelGGL(kw_dyn, dim3(be), dim3(LTPB), 0, s, dT, P, state, n, c_cur, dyn, dyn_cs);
+            mark(4, s);
+            hipLaunchKernelGGL(kw_dyn, dim3(be), dim3(LTPB), 0, s, dT, P, state, n, flags, c_cur, dyn, dyn_cs);
+            mark(5, s);
+            if (side) { (void)hipEventRecord(ev_dyn, s); (void)hipStreamWaitEvent(side, ev_dyn, 0); }
+            mark(6, s2);
+            hipLaunchKernelGGL(kw_quad_rc, dim3(std::min((n + 15) / 16, 256)), dim3(LTPB), 0, s2, dT, P, state, act, act_dim, MODE, tgt, l_cur, k_cur, dyn, dyn_cs);
+            mark(7, s2);
+            if (side) (void)hipEventRecord(ev_join, side);
             if (ik_side) (void)hipStreamWaitEvent(s, ev_ik, 0);
+            mark(8, s);
             hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs);
+            mark(9, s);
             if (ek) (void)hipEventRecord(ek[1], s);
             if (side) (void)hipStreamWaitEvent(s, ev_join, 0);
-            hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
+            mark(10, s);
+            hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, dyn, dyn_cs, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
+            mark(11, s);
+        }
+        if (tr) {
+            (void)hipEventSynchronize(te[11]);
+            auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, te[a], te[b]); return ms * 1e3f; };
+            fprintf(stderr, "[pbre] iCub step %ld (us): obj %.0f (+%.0f)  ik %.0f (+%.0f)  dyn %.0f (+%.0f)  quad_rc %.0f (+%.0f)  quad %.0f (+%.0f)  fin %.0f (+%.0f)  total %.0f\n",
+                    n_lane_steps - 1, el(1, 2), el(0, 1), el(2, 3), el(0, 2), el(4, 5), el(0, 4), el(6, 7), el(0, 6), el(8, 9), el(0, 8), el(10, 11), el(0, 10), el(0, 11));
+            for (auto& e : te) (void)hipEventDestroy(e);
         }
         cur ^= 1; ccur = (ccur + 1) % 3;
     }

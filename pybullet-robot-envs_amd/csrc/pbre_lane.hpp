@@ -146,8 +146,23 @@ struct Lane {
     static constexpr int NRT = S::NC_RT;
     static_assert(NRT == 2, "keep2() selects two candidates");
     struct RtC { bool act[NRT]; float dist[NRT], mu[NRT]; float J[NRT][3][ND]; };
+    // ro (optional; envs of the complex class): the same for the (at most NRO) spheres closest to the OBJECT (box at op, oq): contact
+    // frame, lever arm rB = point on the box - op, the robot side's Jacobian rows.
+    static constexpr int NRO = 2;
+    struct RoC { bool act[NRO]; float dist[NRO], mu[NRO]; V3 dir[NRO][3], rB[NRO]; float J[NRO][3][ND]; };
     template <class Sink>
     static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau, RtC& rt) {
+        dynamics(T, P, q, qd, sink, tau, rt, (RoC*)nullptr, v3(0.f, 0.f, 0.f), Q4{0.f, 0.f, 0.f, 1.f});
+    }
+    template <class Sink>
+    static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau, RtC& rt,
+                                 RoC* ro, V3 op, Q4 oq) {
+        typename FX::Cand o1, o2;        // best and second-best robot-object candidate
+        o1.dist = o2.dist = 3e38f; o1.idx = o2.idx = 99; o1.mu = o2.mu = 0.f; o1.owner = o2.owner = 0;
+        o1.n = o2.n = o1.pA = o2.pA = o1.pB = o2.pB = v3(0.f, 0.f, 0.f);
+        const M3 Ro = FX::quat_R(oq);
+        const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
+        const float orad = sqrtf(dot(oh, oh));
         typename FX::Cand k1, k2;        // best and second-best robot-table candidate
         k1.dist = k2.dist = 3e38f; k1.idx = k2.idx = 99; k1.mu = k2.mu = 0.f; k1.owner = k2.owner = 0;
         k1.n = k2.n = k1.pA = k2.pA = k1.pB = k2.pB = v3(0.f, 0.f, 0.f);
@@ -175,6 +190,16 @@ struct Lane {
                 if (T.s_owner[sp] != j) continue;
                 const V3 sc = add(p[j], mv(R[j], v3(T.s_c[0][sp], T.s_c[1][sp], T.s_c[2][sp])));
                 const float sr = T.s_r[sp];
+                if (ro) {
+                    const V3 dd = sub(sc, op);
+                    const float reach = sr + P.margin + orad;
+                    if (PBRE_ANY(!(dot(dd, dd) >= reach * reach))) {
+                        typename FX::Cand c; c.idx = sp; c.owner = j;
+                        c.dist = FX::sphere_box(sc, sr, op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
+                        c.mu = T.s_mu[sp] * P.obj_mu;
+                        FX::keep2(c, P.margin, o1, o2);
+                    }
+                }
                 if (!PBRE_ANY(!(sc.z - sr - ztop >= P.margin))) continue;       // cheap wave-wide lower bound first
                 typename FX::Cand c; c.idx = sp; c.owner = j;
                 c.dist = FX::sphere_box(sc, sr, tc, Id, th, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
@@ -259,6 +284,35 @@ struct Lane {
                     bool onchain = false;      // joint j moves the contact link (compile-time tree, per-lane owner)
                     PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
                     rt.J[c][d][j] = (rt.act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                }
+            }
+        }
+        // ---- robot-object contact slots (complex class)
+        if (ro) {
+            const bool two_o = o2.dist < 3e38f;
+            const bool swap_o = two_o && o2.idx < o1.idx;
+            PBRE_UNROLL for (int c = 0; c < NRO; c++) {
+                const typename FX::Cand cc = (c == 0) ? (swap_o ? o2 : o1) : (swap_o ? o1 : o2);
+                ro->act[c] = cc.dist < 3e38f;
+                ro->dist[c] = cc.dist; ro->mu[c] = ro->act[c] ? cc.mu : 0.f;
+                const V3 n = cc.n;
+                V3 t1, t2;     // btPlaneSpace1
+                if (fabsf(n.z) > 0.70710678118654752f) {
+                    const float a = n.y*n.y + n.z*n.z, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                    t1 = v3(0.f, -n.z * kk, n.y * kk); t2 = v3(a * kk, -n.x * t1.z, n.x * t1.y);
+                } else {
+                    const float a = n.x*n.x + n.y*n.y, kk = 1.f / sqrtf(fmaxf(a, 1e-30f));
+                    t1 = v3(-n.y * kk, n.x * kk, 0.f); t2 = v3(-n.z * t1.y, n.z * t1.x, a * kk);
+                }
+                ro->rB[c] = sub(cc.pB, op);
+                PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                    const V3 dir = d == 0 ? n : (d == 1 ? t1 : t2);
+                    ro->dir[c][d] = ro->act[c] ? dir : v3(0.f, 0.f, 0.f);
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                        bool onchain = false;
+                        PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
+                        ro->J[c][d][j] = (ro->act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                    }
                 }
             }
         }

@@ -41,6 +41,7 @@ struct ObjStep {
     // The same step in three parts, for a caller that runs the object rows inside its own solver loop (pbre_lane.hpp: one sweep per
     // iteration next to the robot's rows, so that the two dependency chains overlap): setup, P.iters x sweep, result.
     float vx, vy, vz, wx, wy, wz, mu;
+    float Ii[6];       // m * I_w^-1 = m R diag(1/I) R^T: xx yy zz xy xz yz (a caller with robot-object rows needs it too)
     float c_rx[NK], c_ry[NK], c_rz[NK], g[NK][3][3], r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
     PBRE_HD void setup(const Params& P, const float* pose, const float* tw, float o_m, float o_mu, float o_kl) {
         const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
@@ -70,7 +71,6 @@ struct ObjStep {
         // Impulses in delta-v units (a = lambda / m): a row along dir at lever arm r has J = [dir, r x dir], changes the twist by
         // (a dir, a g) with g = m I_w^-1 (r x dir), and J M^-1 J^T = (1 + (r x dir) . g) / m.
         mu = o_mu * P.tab_mu;
-        float Ii[6];       // m * I_w^-1 = m R diag(1/I) R^T: xx yy zz xy xz yz
         {
             const float a = P.obj_m / P.obj_I[0], b = P.obj_m / P.obj_I[1], c = P.obj_m / P.obj_I[2];      // (m / I is independent of the per-env mass)
             Ii[0] = a*R[0]*R[0] + b*R[1]*R[1] + c*R[2]*R[2]; Ii[1] = a*R[3]*R[3] + b*R[4]*R[4] + c*R[5]*R[5]; Ii[2] = a*R[6]*R[6] + b*R[7]*R[7] + c*R[8]*R[8];
@@ -119,7 +119,8 @@ struct ObjStep {
         }
     }
     // one sweep: normals then frictions; an unused slot has dinv = rhs = 0 and its rows change nothing
-    PBRE_HD void sweep() {
+    PBRE_HD void sweep() { sweep_normals(); sweep_frictions(); }
+    PBRE_HD void sweep_normals() {
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             // rows in delta form (clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied)): one operation less
             // on the row-to-row dependency chain, which is all this kernel's time; the upper bound 1e10 of a normal row never binds
@@ -128,6 +129,8 @@ struct ObjStep {
             r_app[c][0] += dd;
             vz += dd; wx = fmaf(dd, g[c][0][0], wx); wy = fmaf(dd, g[c][0][1], wy); wz = fmaf(dd, g[c][0][2], wz);
         }
+    }
+    PBRE_HD void sweep_frictions() {
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             const float hi = mu * r_app[c][0];
             {
