@@ -17,7 +17,7 @@ for name in ("a", "b"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
         k = r["Kernel_Name"].split("(")[0]
-        if "kw_quad" in k:
+        if k.rstrip().endswith("kw_quad"):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in agg.items(): out[c] = sum(v) / len(v)
 w = out.get("SQ_WAVES", 0); wc = out.get("SQ_WAVE_CYCLES", 0)
