@@ -43,14 +43,16 @@ __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __
     LaneD::ik_targets(*T, P, state + (size_t)env * Shape32::STATE, actions + (size_t)env * act_dim, tgt + (size_t)env * Shape32::TGT);
 }
 
-// ------------------------------------------------------------------ the quad pipeline: kw_dyn -> kw_quad -> kw_fin
-// The lane-per-env kernel above keeps a whole SIMD's register file and 40 KB of LDS per wave and still runs as a lone, latency-bound
-// wave per SIMD.  The pipeline below splits the step where the data layouts want to differ:
+// ------------------------------------------------------------------ the pipeline: kw_dyn -> kw_quad (+ kw_quad_rc) -> kw_fin
+// (Lane::step as ONE kernel -- M^-1 in 40 KB of LDS per wave, a whole SIMD's register file -- ran as a lone, latency-bound wave per SIMD
+// and was slower than the lane-group kernel; see pbre_lane.hpp.)  The pipeline splits the step where the data layouts want to differ:
 //   kw_dyn   one thread per env: kinematics + dynamics (Lane::dynamics) -> bias torques and the joint-space inertia M, streamed to an
 //            HBM side buffer (no LDS, no M^-1 in this kernel);
 //   kw_quad  FOUR lanes per env (a DPP quad; 16 envs per wave): lane r owns DoF 5r..5r+4, i.e. five rows of M -- 100 registers, no
-//            LDS.  Gauss-Jordan inversion across the quad, unconstrained velocities, motor / limit rows, the 150 PGS sweeps (a row is
-//            one fma for its delta, a quad broadcast folded into the five fmacs of the velocity update), integration of the joints;
+//            LDS.  Gauss-Jordan inversion across the quad, unconstrained velocities, motor / limit / robot-table contact rows, the 150
+//            PGS sweeps (a motor row is one fma for its delta, a quad broadcast and the five fmacs of the velocity update), integration
+//            of the joints; kw_quad_rc: the same for the envs with robot-object contacts (compacted list), the object's twist and
+//            table rows inside the same sweeps;
 //   kw_fin   one thread per env: the object's pose from kw_obj's twist, observation / reward / termination / auto-reset / class
 //            (Lane::finish).
 // Side buffer layout [quad lane r][element e][env]: per quad lane 148 elements -- 0..99 rows 5r..5r+4 of M (i * 20 + col), 100..104
@@ -451,12 +453,6 @@ __global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restric
     wpublish(env, c, cls, next_list, next_count);
 }
 
-// diagnostics (pbre_kernel_info[6]): envs whose class is 2 (robot-object contact)
-__global__ void kw_count_cls2(const signed char* __restrict__ cls, int n, int* __restrict__ res) {
-    const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env < n && cls[env] == 2) atomicAdd(res, 1);
-}
-
 // class of every env's current state (after reset / set_state / settle steps)
 __global__ __launch_bounds__(LTPB) void kw_lane_classify(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
                                                          signed char* __restrict__ cls, int* __restrict__ list, int* __restrict__ count) {
@@ -614,16 +610,6 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         *complex_now = 0;
         if (cls_valid) { (void)hipDeviceSynchronize(); (void)hipMemcpy(complex_now, count + ccur, sizeof(int), hipMemcpyDeviceToHost); }
         return 1;
-    }
-    int lane_cls2() override {
-        if (!cls_valid) return 0;
-        int* d = nullptr; int h = 0;
-        if (hipMalloc(&d, sizeof(int)) != hipSuccess) return -1;
-        (void)hipMemset(d, 0, sizeof(int));
-        hipLaunchKernelGGL(kw_count_cls2, dim3((n + 255) / 256), dim3(256), 0, 0, cls + (size_t)cur * n, n, d);
-        (void)hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost);
-        (void)hipFree(d);
-        return h;
     }
 };
 

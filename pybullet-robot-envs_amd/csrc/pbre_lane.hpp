@@ -19,8 +19,9 @@
 // "Simple" class of this path: motors, joint-limit rows (frequent on the iCub under Cartesian control, where the IK targets push
 // joints into their stops), robot-table contacts (with random actions a third to a half of the envs has a hand or forearm on the
 // table) and the object's own rows against the table.  An env with a robot collision sphere within the contact margin of the OBJECT
-// ("complex", ~1 % of a random-action batch) is stepped by the lane-group kernel (Core::step: the coupled system) and only finished
-// here, exactly the split of k_row_list / Fast::finish on the Panda.
+// ("complex", ~1 % of a random-action batch) needs the coupled system: on the device the quad solver with the object's twist and table
+// rows in the same sweeps (kw_quad_rc; dynamics() supplies the robot-object contact slots), in the CPU emulation the lane-group core
+// (Core::step) followed by finish().
 //
 // Same mathematics and reference call sites as pbre_core.hpp / pbre_fast.hpp: world-frame RNEA + CRBA + explicit M^-1, Bullet's
 // row order, iCubReachGymEnv / iCubPushGymEnv / iCubPushGymGoalEnv .step (icub_reach_gym_env.py:182-259,

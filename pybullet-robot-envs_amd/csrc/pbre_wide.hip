@@ -387,7 +387,7 @@ int wide_kernel_info(const WideEngine* w, int32_t* info, int32_t n) {
     const bool lane = w->lane_ok() && const_cast<WideEngine*>(w)->lane_info(&lv, &cn);
     // same slots as the Panda engine: [0] VGPRs of the lane-per-env kernel, [1] of the lane-group kernel, [2] lane-per-env path in use,
     // [3] envs in the simple class, [4] envs the lane-group kernel steps when the lane path is off, [5] complex envs
-    const int v[7] = {lane ? lv : -1, w->vgprs(), lane ? 1 : 0, lane ? w->n - cn : 0, lane ? 0 : w->n, lane ? cn : 0, lane ? const_cast<WideEngine*>(w)->lane_cls2() : -1};
+    const int v[7] = {lane ? lv : -1, w->vgprs(), lane ? 1 : 0, lane ? w->n - cn : 0, lane ? 0 : w->n, lane ? cn : 0, -1};
     for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
     return PBRE_OK;
 }

@@ -176,7 +176,6 @@ struct WideEngine {
     virtual void launch_lane_ik(const float* act, hipStream_t s) {}
     virtual hipError_t launch_lane_step(int kind, const float* act, float* out, int flags, hipStream_t s, bool timed) { return hipSuccess; }
     virtual int lane_info(int* vg, int* complex_now) { return 0; }
-    virtual int lane_cls2() { return -1; }             // diagnostics: complex envs with a robot-object contact
 };
 
 template <class S, class L>

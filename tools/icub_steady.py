@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""iCub push, auto-reset, random actions: step time and number of envs in the complex class (robot collision sphere near table / object)
+"""iCub push, auto-reset, random actions: step time and number of envs in the complex class (robot collision sphere within the contact margin of the object)
 as the batch approaches its stationary mix.   python tools/icub_steady.py [--envs 32768] [--steps 1500] [--joint] [--max-steps 500]"""
 import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +28,6 @@ for w in range(args.steps // args.window):
         eng.step_device(act[k % 8].data_ptr(), out.data_ptr(), s.cuda_stream)
     torch.cuda.synchronize(); el = time.perf_counter() - t0
     res.append({"steps_done": (w + 1) * args.window, "ms_per_step": round(el / args.window * 1e3, 4), "M_env_steps_per_s": round(args.envs * args.window / el / 1e6, 2),
-                "complex_envs": eng.kernel_info()[5], "with_object_contact": eng.kernel_info()[6], "finite": bool(torch.isfinite(out).all())})
+                "complex_envs": eng.kernel_info()[5], "finite": bool(torch.isfinite(out).all())})
 print(json.dumps({"workload": "iCubPushGymEnv %s, %d envs, auto-reset, max_steps %d" % ("joint control" if args.joint else "IK position control", args.envs, args.max_steps),
                   "lane": os.environ.get("PBRE_ICUB_LANE", "1"), "windows": res}))
