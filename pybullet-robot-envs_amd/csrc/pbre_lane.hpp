@@ -811,15 +811,17 @@ struct Lane {
                 const float J[6] = {jl.x, jl.y, jl.z, ja.x, ja.y, ja.z};
                 PBRE_UNROLL for (int a = 0; a < 6; a++) PBRE_UNROLL for (int b = 0; b <= a; b++) A[a][b] = fmaf(J[a], J[b], A[a][b]);
             }
-            float y[6];
+            // (every division by a diagonal entry of the factor is a multiplication by its reciprocal, taken once: 6 reciprocals instead
+            // of 27 divisions on this kernel's critical chain -- a lone wave per SIMD iterating up to 100 times)
+            float y[6], inv[6];
             PBRE_UNROLL for (int a = 0; a < 6; a++)
                 PBRE_UNROLL for (int b = 0; b <= a; b++) {
                     float sum = A[a][b];
                     PBRE_UNROLL for (int k = 0; k < b; k++) sum = fmaf(-A[a][k], A[b][k], sum);
-                    A[a][b] = a == b ? sqrtf(sum) : sum / A[b][b];
+                    if (a == b) { A[a][a] = sqrtf(sum); inv[a] = 1.f / A[a][a]; } else A[a][b] = sum * inv[b];
                 }
-            PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum / A[a][a]; }
-            PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum / A[a][a]; }
+            PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum * inv[a]; }
+            PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum * inv[a]; }
             PBRE_UNROLL for (int j = 0; j < ND; j++) {
                 if (!Topo::is_anc(j, EO)) continue;
                 const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
