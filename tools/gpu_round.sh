@@ -39,6 +39,12 @@ done
 timeout 600 python tools/icub_steady.py --envs 131072 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+echo "== iCub push with a scripted policy that drives the hand at the object (robot-object contacts in 10-40 % of the envs)"
+rm -f gpurun_out/${TAG}_icub_push_soak.json
+for N in 8192 32768 131072; do
+  timeout 900 python tools/icub_push_soak.py --envs $N --steps 900 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_push_soak.json | cut -c1-260
+  PBRE_ICUB_LANE=0 timeout 900 python tools/icub_push_soak.py --envs $N --steps 900 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_push_soak.json | cut -c1-260
+done
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py --envs 32768 --steps 750 --window 250 > $ROOTDIR/gpurun_out/${TAG}_icub_rocprof.log 2>&1)
 t=$(find gpurun_out/prof_icub_$TAG -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/trace_tail.py $t --last 200 | tee gpurun_out/${TAG}_icub_kernel_trace_tail.txt
 f=$(find gpurun_out/prof_icub_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_icub_kernel_stats.csv
