@@ -263,6 +263,8 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     float oJ[RC ? NRO : 1][3][QD], oB[RC ? NRO : 1][3][QD], o_dir[RC ? NRO : 1][3][3], o_rxd[RC ? NRO : 1][3][3], o_g[RC ? NRO : 1][3][3];
     float o_dinv[RC ? NRO : 1][3], o_app[RC ? NRO : 1][3], o_rhs[RC ? NRO : 1], o_mu[RC ? NRO : 1];
     float pose[7], tw0[6];
+    bool ro_on[RC ? NRO : 1];          // wave-uniform: some env of the wave uses the slot (rows of an env without it are exact no-ops)
+    PBRE_UNROLL for (int c = 0; c < (RC ? NRO : 1); c++) ro_on[c] = false;
     const float inv_m = 1.f / P.obj_m;
     if (RC) {
         PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[Shape32::LC + k];
@@ -272,6 +274,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
         const float* dl = dyn + (size_t)r * DEL * cs + env;
         PBRE_UNROLL for (int c = 0; c < NRO; c++) {
             const bool act = d0p[(size_t)(178 + c) * cs] != 0.f;
+            ro_on[c] = __any((int)act) != 0;
             o_mu[c] = act ? d0p[(size_t)(180 + c) * cs] : 0.f;
             const float rbx = d0p[(size_t)(202 + c * 3) * cs], rby = d0p[(size_t)(203 + c * 3) * cs], rbz = d0p[(size_t)(204 + c * 3) * cs];
             PBRE_UNROLL for (int d = 0; d < 3; d++) {
@@ -303,10 +306,9 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
         }
     }
     auto orow = [&](int c, int d) {    // robot-object row (RC)
-        float jv = 0.f;
-        PBRE_UNROLL for (int i = 0; i < QD; i++) jv = fmaf(oJ[c][d][i], w[i], jv);
+        float jv = fmaf(oJ[c][d][2], w[2], fmaf(oJ[c][d][1], w[1], oJ[c][d][0] * w[0])) + fmaf(oJ[c][d][4], w[4], oJ[c][d][3] * w[3]);      // (two short chains)
         jv += qb_x<0xB1>(jv); jv += qb_x<0x4E>(jv);
-        jv -= o_dir[c][d][0] * ob.vx + o_dir[c][d][1] * ob.vy + o_dir[c][d][2] * ob.vz + o_rxd[c][d][0] * ob.wx + o_rxd[c][d][1] * ob.wy + o_rxd[c][d][2] * ob.wz;
+        jv -= fmaf(o_dir[c][d][2], ob.vz, fmaf(o_dir[c][d][1], ob.vy, o_dir[c][d][0] * ob.vx)) + fmaf(o_rxd[c][d][2], ob.wz, fmaf(o_rxd[c][d][1], ob.wy, o_rxd[c][d][0] * ob.wx));
         float sn;
         if (d == 0) sn = __builtin_amdgcn_fmed3f(o_app[c][0] - fmaf(jv, o_dinv[c][0], -o_rhs[c]), 0.f, 1e10f);
         else {
@@ -321,9 +323,9 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
         ob.wx = fmaf(-dd, o_g[c][d][0], ob.wx); ob.wy = fmaf(-dd, o_g[c][d][1], ob.wy); ob.wz = fmaf(-dd, o_g[c][d][2], ob.wz);
     };
     auto contacts = [&]() {            // Bullet: all normals (object-table, robot-object, robot-table), then all frictions
-        if (RC) { ob.sweep_normals(); PBRE_UNROLL for (int c = 0; c < NRO; c++) orow(c, 0); }
+        if (RC) { ob.sweep_normals(); PBRE_UNROLL for (int c = 0; c < NRO; c++) if (ro_on[c]) orow(c, 0); }
         PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) rrow(c, 0);
-        if (RC) { ob.sweep_frictions(); PBRE_UNROLL for (int c = 0; c < NRO; c++) { orow(c, 1); orow(c, 2); } }
+        if (RC) { ob.sweep_frictions(); PBRE_UNROLL for (int c = 0; c < NRO; c++) if (ro_on[c]) { orow(c, 1); orow(c, 2); } }
         PBRE_UNROLL for (int c = 0; c < NRT; c++) if (rt_on[c]) { rrow(c, 1); rrow(c, 2); }
     };
 
