@@ -494,6 +494,37 @@ def check_icub_lane_ab(Engine, lib, monkeypatch, variant, n=64, steps=12, tol=2e
     return worst
 
 
+def check_icub_push_policy(Engine, lib, monkeypatch, n=2048, steps=300):
+    """iCub push under a scripted policy that drives the hand at the object (Cartesian control): a large share of the envs is in
+    robot-object contact, i.e. in the pipeline's coupled solve (kw_quad_rc).  Contact dynamics amplify rounding differences, so the
+    comparison with the lane-group kernel is at the level of the batch: finite states, unit quaternions, the same number of finished
+    episodes and the same mean reward to a few per cent."""
+    stats = []
+    for lane in (1, 0):
+        monkeypatch.setenv("PBRE_ICUB_LANE", str(lane))
+        eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=1, control_orientation=0, obj_std=0.05, tg_std=0.2,
+                                        max_steps=150, flags=2)
+        obs = eng.reset()
+        rng = np.random.default_rng(7)
+        o0 = 9 + (eng.obs_dim - 9 - 15)
+        dones = 0.0; rew = 0.0; cmax = 0
+        for k in range(steps):
+            d = obs[:, o0:o0 + 3] - obs[:, 0:3]; d[:, 2] += 0.02
+            a = np.clip(d / (np.linalg.norm(d, axis=1, keepdims=True) + 1e-6) + 0.3 * rng.uniform(-1, 1, (n, 3)), -1, 1).astype(np.float32)
+            obs, rw, dn = eng.step(a)
+            dones += float(dn.sum()); rew += float(rw.mean())
+            if k % 25 == 24: cmax = max(cmax, eng.kernel_info()[5])
+        st = eng.get_state(); nd = eng.ndof
+        assert np.isfinite(st).all() and np.isfinite(obs).all()
+        assert np.abs(np.linalg.norm(st[:, nd + 3:nd + 7], axis=1) - 1).max() < 1e-5
+        stats.append((dones, rew / steps, cmax))
+    monkeypatch.delenv("PBRE_ICUB_LANE")
+    (d1, r1, c1), (d0, r0, c0) = stats
+    assert c1 > n // 20, "the policy did not bring the hands to the objects: %d envs in robot-object contact at most" % c1
+    assert abs(d1 - d0) <= 0.03 * max(d0, 1.0) + 3 and abs(r1 - r0) <= 0.05 * abs(r0) + 1e-3, stats
+    return stats
+
+
 def check_icub_full_model(Engine, lib, n=2, steps=3):
     """The unpruned iCub (32 DoF with the legs: one env per 64-lane group, Shape64) against the engine's default 20-DoF model
     (Shape32): the legs cannot change any output (tests/test_golden_icub.py::test_pruned_legs_are_exact shows it for the oracle), so

@@ -102,6 +102,12 @@ def test_icub_lane_pipeline_matches_lane_group_kernel(hip_lib, monkeypatch):
     print(parity.check_icub_lane_ab(_capi.Engine, hip_lib, monkeypatch, 1, n=96, steps=12))
 
 
+def test_icub_push_policy_coupled_solve(hip_lib, monkeypatch):
+    """the pipeline's coupled robot-object solve (kw_quad_rc) with a third of the batch in contact, against the lane-group kernel at the
+    level of the batch"""
+    print(parity.check_icub_push_policy(_capi.Engine, hip_lib, monkeypatch))
+
+
 def test_icub_hand_on_table(hip_lib):
     """robot-table contact rows of the lane-per-env pipeline (kw_quad) against the oracle, step by step"""
     print(parity.check_icub_table_contact(_capi.Engine, hip_lib, n=40, steps=60))
