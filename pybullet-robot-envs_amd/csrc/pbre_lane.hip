@@ -490,7 +490,10 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");
-        enabled = !(knob && knob[0] == '0');         // PBRE_ICUB_LANE=0: every step by the lane-group kernel (A/B, validation)
+        // Default: the pipeline from 8192 envs on.  Below that its chain of lone-wave kernels (kw_dyn -> kw_quad -> kw_fin) is no
+        // shorter than the one lane-group kernel (measured, post-reset step: 4096 envs 0.44 against 0.40 ms, 8192 envs 0.48 against
+        // 0.54 ms).  PBRE_ICUB_LANE=1 / 0 forces the pipeline / the lane-group kernel (tests, A/B).
+        enabled = knob ? knob[0] != '0' : n >= 8192;
         topo_ok = lane_topo_matches<TopoICub, Shape32>(T);
         if (!enabled || !topo_ok) return hipSuccess;
         hipError_t e;

@@ -108,6 +108,18 @@ def test_icub_push_policy_coupled_solve(hip_lib, monkeypatch):
     print(parity.check_icub_push_policy(_capi.Engine, hip_lib, monkeypatch))
 
 
+def test_icub_default_path_by_batch_size(hip_lib, monkeypatch):
+    """without PBRE_ICUB_LANE: the lane-group kernel below 8192 envs, the pipeline from there on"""
+    from pybullet_robot_envs.model.table import icub_table
+    monkeypatch.delenv("PBRE_ICUB_LANE", raising=False)
+    tbl, model, info = icub_table("l")
+    ov = parity.icub_overrides(info, "l", 1, 0, 1)
+    for n, lane in ((64, 0), (8192, 1)):
+        eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=n, lib=hip_lib, robot=_capi.ROBOT_ICUB, **ov)
+        assert eng.kernel_info()[2] == lane, (n, eng.kernel_info())
+        del eng
+
+
 def test_icub_hand_on_table(hip_lib):
     """robot-table contact rows of the lane-per-env pipeline (kw_quad) against the oracle, step by step"""
     print(parity.check_icub_table_contact(_capi.Engine, hip_lib, n=40, steps=60))
