@@ -71,6 +71,10 @@ struct DynSink {
     __device__ __forceinline__ void put(int j, int i, float v) { st(j, i, v); if (i != j) st(i, j, v); }
     __device__ __forceinline__ void zero(int, int) {}      // unrelated branch pairs: the buffer is zeroed once, nobody writes them
     __device__ __forceinline__ void tau(int j, float v) { f(j / QD, 100 + (j % QD), v); }
+    // contact Jacobian rows, straight to the buffer (rows of an env without the contact are zeros; kw_quad masks them anyway)
+    __device__ __forceinline__ void rt_j(int c, int d, int j, float v) { f(j / QD, 116 + (c * 3 + d) * QD + (j % QD), v); }
+    __device__ __forceinline__ void rt_none(int) {}
+    __device__ __forceinline__ void ro_j(int c, int d, int j, float v) { f(j / QD, 148 + (c * 3 + d) * QD + (j % QD), v); }
 };
 __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __restrict__ T, const Params P, const float* __restrict__ state, int n, int flags,
                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
@@ -93,17 +97,11 @@ __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __rest
     // robot-table contact slots: flags / friction / distances always, the Jacobian rows of the envs that have a contact
     sink.f(0, 108, rt.act[0] ? 1.f : 0.f); sink.f(0, 109, rt.act[1] ? 1.f : 0.f); sink.f(0, 110, rt.mu[0]); sink.f(0, 111, rt.mu[1]);
     sink.f(0, 112, rt.dist[0]); sink.f(0, 113, rt.dist[1]);
-    if (rt.act[0]) {
-        PBRE_UNROLL for (int c = 0; c < LaneD::NRT; c++)
-            PBRE_UNROLL for (int d = 0; d < 3; d++)
-                PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.f(j / QD, 116 + (c * 3 + d) * QD + (j % QD), rt.J[c][d][j]);
-    }
     if (any_rc && rc) {          // robot-object contact slots of a complex env
         PBRE_UNROLL for (int c = 0; c < LaneD::NRO; c++) {
             sink.f(0, 178 + c, ro.act[c] ? 1.f : 0.f); sink.f(0, 180 + c, ro.mu[c]); sink.f(0, 182 + c, ro.dist[c]);
             PBRE_UNROLL for (int d = 0; d < 3; d++) {
                 sink.f(0, 184 + (c * 3 + d) * 3, ro.dir[c][d].x); sink.f(0, 185 + (c * 3 + d) * 3, ro.dir[c][d].y); sink.f(0, 186 + (c * 3 + d) * 3, ro.dir[c][d].z);
-                PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) sink.f(j / QD, 148 + (c * 3 + d) * QD + (j % QD), ro.J[c][d][j]);
             }
             sink.f(0, 202 + c * 3, ro.rB[c].x); sink.f(0, 203 + c * 3, ro.rB[c].y); sink.f(0, 204 + c * 3, ro.rB[c].z);
         }

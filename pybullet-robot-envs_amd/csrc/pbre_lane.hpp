@@ -114,6 +114,10 @@ struct Lane {
         // keep all 210 entries live in registers, which is what the LDS copy is there to avoid)
         PBRE_HD float geto(int k, int o) const { return k < MLDS ? lds[k * MS + o] : reg[k < MLDS ? 0 : k - MLDS]; }
         PBRE_HD void set(int k, float v) { if (k < MLDS) lds[k * MS] = v; else reg[k < MLDS ? 0 : k - MLDS] = v; }
+        float rtJ[2][3][ND];                          // robot-table contact Jacobian rows (dynamics() sink)
+        PBRE_HD void rt_j(int c, int d, int j, float v) { rtJ[c][d][j] = v; }
+        PBRE_HD void rt_none(int c) { PBRE_UNROLL for (int d = 0; d < 3; d++) PBRE_UNROLL for (int j = 0; j < ND; j++) rtJ[c][d][j] = 0.f; }
+        PBRE_HD void ro_j(int, int, int, float) {}     // (the one-piece step has no robot-object rows)
         PBRE_HD void put(int j, int i, float v) { set(sym(j, i), v); }      // dynamics() sink
         PBRE_HD void zero(int j, int i) { set(sym(j, i), 0.f); }
     };
@@ -146,11 +150,11 @@ struct Lane {
     // Jacobian rows J[c][d][j] = dir_d . (S_l,j + S_a,j x pA) over the joints that move the sphere's link.
     static constexpr int NRT = S::NC_RT;
     static_assert(NRT == 2, "keep2() selects two candidates");
-    struct RtC { bool act[NRT]; float dist[NRT], mu[NRT]; float J[NRT][3][ND]; };
+    struct RtC { bool act[NRT]; float dist[NRT], mu[NRT]; };          // (the Jacobian rows go to the sink: sink.rt_j(c, d, j, value))
     // ro (optional; envs of the complex class): the same for the (at most NRO) spheres closest to the OBJECT (box at op, oq): contact
     // frame, lever arm rB = point on the box - op, the robot side's Jacobian rows.
     static constexpr int NRO = 2;
-    struct RoC { bool act[NRO]; float dist[NRO], mu[NRO]; V3 dir[NRO][3], rB[NRO]; float J[NRO][3][ND]; };
+    struct RoC { bool act[NRO]; float dist[NRO], mu[NRO]; V3 dir[NRO][3], rB[NRO]; };      // (rows: sink.ro_j(c, d, j, value))
     template <class Sink>
     static PBRE_HD void dynamics(const Tab& T, const Params& P, const float* q, const float* qd, Sink& sink, float* tau, RtC& rt) {
         dynamics(T, P, q, qd, sink, tau, rt, (RoC*)nullptr, v3(0.f, 0.f, 0.f), Q4{0.f, 0.f, 0.f, 1.f});
@@ -269,7 +273,7 @@ struct Lane {
             const typename FX::Cand cc = (c == 0) ? (swap ? k2 : k1) : (swap ? k1 : k2);
             rt.act[c] = cc.dist < 3e38f;
             rt.dist[c] = cc.dist; rt.mu[c] = rt.act[c] ? cc.mu : 0.f;
-            if (!any_rt) { PBRE_UNROLL for (int d = 0; d < 3; d++) PBRE_UNROLL for (int j = 0; j < ND; j++) rt.J[c][d][j] = 0.f; continue; }
+            if (!any_rt) { sink.rt_none(c); continue; }
             const V3 n = cc.n;
             V3 t1, t2;     // btPlaneSpace1
             if (fabsf(n.z) > 0.70710678118654752f) {
@@ -284,7 +288,7 @@ struct Lane {
                 PBRE_UNROLL for (int j = 0; j < ND; j++) {
                     bool onchain = false;      // joint j moves the contact link (compile-time tree, per-lane owner)
                     PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
-                    rt.J[c][d][j] = (rt.act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                    sink.rt_j(c, d, j, (rt.act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f);
                 }
             }
         }
@@ -312,7 +316,7 @@ struct Lane {
                     PBRE_UNROLL for (int j = 0; j < ND; j++) {
                         bool onchain = false;
                         PBRE_UNROLL for (int e = 0; e < ND; e++) if (Topo::is_anc(j, e) && cc.owner == e) onchain = true;
-                        ro->J[c][d][j] = (ro->act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f;
+                        sink.ro_j(c, d, j, (ro->act[c] && onchain) ? dot(dir, add(Sl[j], cross(Sa[j], cc.pA))) : 0.f);
                     }
                 }
             }
@@ -401,8 +405,8 @@ struct Lane {
                 float denom = 0.f;
                 PBRE_UNROLL for (int k = 0; k < ND; k++) {
                     float b = 0.f;
-                    if (rt_on[c]) { PBRE_UNROLL for (int j = 0; j < ND; j++) b = fmaf(Mi.get(sym(k, j)), rt.J[c][d][j], b); }
-                    rc_B[c][d][k] = b; denom = fmaf(rt.J[c][d][k], b, denom);
+                    if (rt_on[c]) { PBRE_UNROLL for (int j = 0; j < ND; j++) b = fmaf(Mi.get(sym(k, j)), Mi.rtJ[c][d][j], b); }
+                    rc_B[c][d][k] = b; denom = fmaf(Mi.rtJ[c][d][k], b, denom);
                 }
                 rc_dinv[c][d] = rt.act[c] ? 1.f / denom : 0.f;
                 rc_app[c][d] = 0.f;
@@ -412,7 +416,7 @@ struct Lane {
         }
         auto rrow = [&](int c, int d) {
             float jv = 0.f;
-            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(rt.J[c][d][j], w[j], jv);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) jv = fmaf(Mi.rtJ[c][d][j], w[j], jv);
             float sn;
             if (d == 0) sn = med3(rc_app[c][0] - fmaf(jv, rc_dinv[c][0], -rc_rhs[c]), 0.f, 1e10f);
             else {
