@@ -76,19 +76,15 @@ class iCubEnv:
                 assert link["joint_name"] in self.initial_positions.keys()
                 self._joint_name_to_ids[link["joint_name"]] = i
 
-        # save indices of the joints to control (icub_env.py:123-143): torso + the chosen arm, in link-index order
-        if len(self._joints_to_control) == 0:
-            for joint_name in self._joint_name_to_ids.keys():
-                if joint_name in self.joint_groups['torso']:
-                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
-                elif (joint_name in self.joint_groups['l_arm'] and self._control_arm == 'l') or \
-                     (joint_name in self.joint_groups['r_arm'] and self._control_arm == 'r'):
-                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
-                else:
-                    self._joints_to_block.append(self._joint_name_to_ids[joint_name])
-                if (self._control_arm == 'l' and joint_name == 'l_wrist_yaw') or \
-                   (self._control_arm == 'r' and joint_name == 'r_wrist_yaw'):
-                    self.end_eff_idx = self._joint_name_to_ids[joint_name]
+        # Controlled joints (reference icub_env.py:123-143): the torso and the chosen arm, in link-index order; every other joint is
+        # "blocked" (held at its rest pose by the IK branch); the end effector is the chosen arm's wrist-yaw link.
+        if not self._joints_to_control:
+            side = 'l' if self._control_arm == 'l' else 'r'
+            driven = set(self.joint_groups['torso']) | set(self.joint_groups[side + '_arm'])
+            ids = self._joint_name_to_ids
+            self._joints_to_control = [i for name, i in ids.items() if name in driven]
+            self._joints_to_block = [i for name, i in ids.items() if name not in driven]
+            self.end_eff_idx = ids[side + '_wrist_yaw']
         assert self.end_eff_idx == self._full_info["ee_link"]
 
         self.ll, self.ul, self.jr, self.rs, self.jd = self.get_joint_ranges()
@@ -105,16 +101,13 @@ class iCubEnv:
         return [self.initial_positions[n] for n in self._info["dof_names"]]
 
     def get_joint_ranges(self):
-        lower_limits, upper_limits, joint_ranges, rest_poses, joint_dumping = [], [], [], [], []
-        for joint_name in self._joint_name_to_ids.keys():
-            link = self._model["links"][self._joint_name_to_ids[joint_name]]
-            ll, ul = link["lower"], link["upper"]
-            lower_limits.append(ll)
-            upper_limits.append(ul)
-            joint_ranges.append(ul - ll)
-            rest_poses.append(self.initial_positions[joint_name])
-            joint_dumping.append(0.1 if self._joint_name_to_ids[joint_name] in self._joints_to_control else 100.)
-        return lower_limits, upper_limits, joint_ranges, rest_poses, joint_dumping
+        """lower / upper limits, ranges, rest poses (= initial positions) and IK joint damping (0.1 controlled, 100 blocked) of
+        every joint, in link-index order (reference icub_env.py:157-174, from the parsed model instead of p.getJointInfo)"""
+        links = [(n, self._model["links"][i], i in self._joints_to_control) for n, i in self._joint_name_to_ids.items()]
+        lo = [l["lower"] for _, l, _ in links]
+        hi = [l["upper"] for _, l, _ in links]
+        return (lo, hi, [u - d for d, u in zip(lo, hi)], [self.initial_positions[n] for n, _, _ in links],
+                [0.1 if c else 100. for _, _, c in links])
 
     def get_workspace(self):
         return [i[:] for i in self._workspace_lim]

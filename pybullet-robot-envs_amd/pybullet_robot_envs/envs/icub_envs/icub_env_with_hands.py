@@ -81,23 +81,16 @@ class iCubHandsEnv(iCubEnv):
                 assert link["joint_name"] in self.initial_positions.keys()
                 self._joint_name_to_ids[link["joint_name"]] = i
 
-        # save indices of the joints to control (:123-146).  The reference's conditions read `a or b and c`, i.e.
-        # `in l_arm or (in l_hand and arm == 'l')`: both arms are always controlled, the hand follows control_arm
-        if len(self._joints_to_control) == 0:
-            for joint_name in self._joint_name_to_ids.keys():
-                if joint_name in self.joint_groups['torso']:
-                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
-                elif joint_name in self.joint_groups['l_arm'] or (joint_name in self.joint_groups['l_hand']
-                                                                   and self._control_arm == 'l'):
-                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
-                elif joint_name in self.joint_groups['r_arm'] or (joint_name in self.joint_groups['r_hand']
-                                                                   and self._control_arm == 'r'):
-                    self._joints_to_control.append(self._joint_name_to_ids[joint_name])
-                else:
-                    self._joints_to_block.append(self._joint_name_to_ids[joint_name])
-                if (self._control_arm == 'l' and joint_name == 'l_wrist_yaw') or \
-                   (self._control_arm == 'r' and joint_name == 'r_wrist_yaw'):
-                    self.end_eff_idx = self._joint_name_to_ids[joint_name]
+        # Controlled joints (reference :123-146; its conditions read `a or b and c`, i.e. `in l_arm or (in l_hand and arm == 'l')`):
+        # torso and BOTH arms always, the hand of control_arm; link-index order.  End effector: that arm's wrist-yaw link.
+        if not self._joints_to_control:
+            side = 'l' if self._control_arm == 'l' else 'r'
+            driven = set(self.joint_groups['torso']) | set(self.joint_groups['l_arm']) | set(self.joint_groups['r_arm']) \
+                | set(self.joint_groups[side + '_hand'])
+            ids = self._joint_name_to_ids
+            self._joints_to_control = [i for name, i in ids.items() if name in driven]
+            self._joints_to_block = [i for name, i in ids.items() if name not in driven]
+            self.end_eff_idx = ids[side + '_wrist_yaw']
         assert self.end_eff_idx == self._full_info["ee_link"]
         assert self.controlled_dofs() == self._info["controlled"]
 
