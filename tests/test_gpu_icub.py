@@ -120,6 +120,32 @@ def test_icub_default_path_by_batch_size(hip_lib, monkeypatch):
         del eng
 
 
+def test_icub_pipeline_at_size(hip_lib, monkeypatch):
+    """32768 iCub-push envs through the lane-per-env pipeline (its default size range), Cartesian control, the hand driven down and towards
+    the object so that table and object contacts occur.  Without pose randomisation and with one action for all envs every env is a
+    replica: all 32768 rows must stay bit-identical through simple and complex steps (kw_quad / kw_quad_rc place an env anywhere in a
+    wave or a list), finite, with unit quaternions.  (Agreement with the oracle is the other tests' business.)"""
+    monkeypatch.delenv("PBRE_ICUB_LANE", raising=False)           # the engine's own choice at this size
+    n = 32768
+    eng, ora, info = parity.make_icub_pair(_capi.Engine, hip_lib, n, task=1, control_arm="l", use_ik=1, control_orientation=0,
+                                           obj_std=0.0, tg_std=0.0, max_steps=60, flags=2)
+    assert eng.kernel_info()[2] == 1
+    obs = eng.reset()
+    o0 = 9 + (eng.obs_dim - 9 - 15)
+    seen_complex = 0
+    for k in range(90):
+        d = obs[0, o0:o0 + 3] - obs[0, 0:3]; d[2] -= 0.01
+        a1 = np.clip(d / (np.linalg.norm(d) + 1e-6), -1, 1).astype(np.float32)
+        obs, rw, dn = eng.step(np.broadcast_to(a1, (n, 3)).copy())
+        assert np.isfinite(obs).all() and np.isfinite(rw).all(), k
+        assert np.array_equal(obs, np.broadcast_to(obs[0], obs.shape)) and np.array_equal(rw, np.broadcast_to(rw[0], rw.shape)), "replicas diverged at step %d" % k
+        seen_complex = max(seen_complex, eng.kernel_info()[5])
+    st = eng.get_state(); nd = eng.ndof
+    assert np.abs(np.linalg.norm(st[:, nd + 3:nd + 7], axis=1) - 1).max() < 1e-5
+    assert seen_complex == n, "the hand never reached the object: the coupled solve was not exercised (%d)" % seen_complex
+    print("iCub pipeline at size: all %d replicas identical over 90 steps, robot-object contact in every env at some step" % n)
+
+
 def test_icub_hand_on_table(hip_lib):
     """robot-table contact rows of the lane-per-env pipeline (kw_quad) against the oracle, step by step"""
     print(parity.check_icub_table_contact(_capi.Engine, hip_lib, n=40, steps=60))
