@@ -199,6 +199,14 @@ def other_configs(torch, dev, steps=10):
         # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
         roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
         r["steady_random_actions"] = steady
+        env.close()
+        # (3) the same post-reset measurement at 131072 envs: the pipeline's kernels are latency chains at 32768 envs (half the SIMDs hold
+        # one wave), a bigger batch fills them
+        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=131072)
+        acts4 = [torch.rand((131072, 3), device=dev) * 2 - 1 for _ in range(4)]
+        env.reset()
+        r4, _ = timed(env._engine, acts4)
+        r["post_reset_131072_envs"] = {"value": r4["value"], "unit": "env-steps/s", "ms_per_step": r4["ms_per_step"], "outputs_finite": r4["outputs_finite"]}
         out["icub_reach"] = r
         env.close()
     except Exception as e:
