@@ -183,16 +183,17 @@ def other_configs(torch, dev, steps=10):
         steady = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": 600,
                   "envs_with_robot_object_contact": int(env._engine.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
         env.close()
-        # (2) right after reset(): iCubReach-v0 kwargs; three repetitions (12 steps are a 4 ms measurement), the best is reported
+        # (2) contact-free: iCubReach-v0 kwargs; after reset() 1500 untimed steps with ZERO actions (the hand holds its home pose, the state
+        # stays the post-reset one) so that the GPU's clocks are those of THIS half-empty, latency-bound load, then the timed steps with
+        # random actions.  (Timing 12 steps right after reset() measures the clock state the reset left behind: 0.34 ms per step after a
+        # reset done by the heavy lane-group kernel, 0.65 ms after one done by the pipeline itself.)
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)
-        reps = []
-        for _ in range(3):
-            env.reset()
-            rr, _ = timed(env._engine, acts)
-            reps.append(rr)
-        r = min(reps, key=lambda x: x["ms_per_step"])
-        r["ms_per_step_all_repetitions"] = [x["ms_per_step"] for x in reps]
-        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, right after reset()"
+        env.reset()
+        zero = torch.zeros((32768, 3), device=dev)
+        for k in range(1500):
+            env._engine.step_device(zero.data_ptr(), o.data_ptr(), sh)
+        r, _ = timed(env._engine, acts)
+        r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, hand at its home pose (1500 zero-action steps after reset())"
         r["pipeline"] = ("kw_dyn (1 thread / env) -> kw_quad (4 lanes / env; envs whose hand touches the object: kw_quad_rc) -> kw_fin"
                          if env._engine.kernel_info()[2] else "lane-group kernel")
         r["_envs_per_wave"] = 16 if env._engine.kernel_info()[2] else 2
@@ -200,13 +201,17 @@ def other_configs(torch, dev, steps=10):
         roof(r, env._engine, 4.0 * (2 * 40 + 2 * 13 + 3 + 31 + 2 + 4), "pmc_icub", "sq_insts_valu_per_wave")
         r["steady_random_actions"] = steady
         env.close()
-        # (3) the same post-reset measurement at 131072 envs: the pipeline's kernels are latency chains at 32768 envs (half the SIMDs hold
+        # (3) the same measurement at 131072 envs: the pipeline's kernels are latency chains at 32768 envs (half the SIMDs hold
         # one wave), a bigger batch fills them
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=131072)
         acts4 = [torch.rand((131072, 3), device=dev) * 2 - 1 for _ in range(4)]
         env.reset()
+        o4 = torch.zeros((131072, env._engine.obs_dim + 2), device=dev)
+        zero4 = torch.zeros((131072, 3), device=dev)
+        for k in range(600):
+            env._engine.step_device(zero4.data_ptr(), o4.data_ptr(), sh)
         r4, _ = timed(env._engine, acts4)
-        r["post_reset_131072_envs"] = {"value": r4["value"], "unit": "env-steps/s", "ms_per_step": r4["ms_per_step"], "outputs_finite": r4["outputs_finite"]}
+        r["same_at_131072_envs"] = {"value": r4["value"], "unit": "env-steps/s", "ms_per_step": r4["ms_per_step"], "outputs_finite": r4["outputs_finite"]}
         out["icub_reach"] = r
         env.close()
     except Exception as e:

@@ -488,10 +488,11 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");
-        // Default: the pipeline from 8192 envs on.  Below that its chain of lone-wave kernels (kw_dyn -> kw_quad -> kw_fin) is no
-        // shorter than the one lane-group kernel (measured, post-reset step: 4096 envs 0.44 against 0.40 ms, 8192 envs 0.48 against
-        // 0.54 ms).  PBRE_ICUB_LANE=1 / 0 forces the pipeline / the lane-group kernel (tests, A/B).
-        enabled = knob ? knob[0] != '0' : n >= 8192;
+        // Default: the pipeline from 16384 envs on.  Below that its chain of lone-wave kernels (kw_dyn -> kw_quad -> kw_fin) on a
+        // mostly idle GPU (whose clocks follow the load) is slower than the one lane-group kernel: stationary random-action mix, ms per
+        // step pipeline / lane-group: 8192 envs 1.41 / 1.32 (IK), 0.80 / 0.66 (joint); 16384 envs 1.51 / 1.92, 0.86 / 0.98; 32768 envs
+        // 1.3 / 3.2, 0.73 / 1.6.  PBRE_ICUB_LANE=1 / 0 forces the pipeline / the lane-group kernel (tests, A/B).
+        enabled = knob ? knob[0] != '0' : n >= 16384;
         topo_ok = lane_topo_matches<TopoICub, Shape32>(T);
         if (!enabled || !topo_ok) return hipSuccess;
         hipError_t e;
@@ -599,6 +600,8 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         hipEvent_t* ek = timed ? ev_k[k_steps % KRING] : nullptr;
         constexpr int OT = LaneD::M_OBS | LaneD::M_TASK;
         switch (kind) {
+            case K_SETTLE: lane_t(0, act, out, flags, s, ek); break;
+            case K_SETTLE_TGT: lane_t(LaneD::M_TGT, act, out, flags, s, ek); break;
             case K_STEP_ACT: lane_t(LaneD::M_ACTION | OT, act, out, flags, s, ek); break;
             case K_INNER_ACT: lane_t(LaneD::M_ACTION | LaneD::M_TASK | LaneD::M_INNER, act, out, flags, s, ek); break;
             case K_INNER_TGT: lane_t(LaneD::M_TGT | LaneD::M_TASK | LaneD::M_INNER, act, out, flags, s, ek); break;

@@ -57,10 +57,16 @@ static hipError_t wstep(WideEngine* w, int kind, float* st, float* tg, int cnt, 
     return hipGetLastError();
 }
 static hipError_t wsettle(WideEngine* w, float* st, float* tg, int cnt, int count, int flags, hipStream_t s) {
+    const int kind = (w->P.use_ik || w->mrec) ? WideEngine::K_SETTLE_TGT : WideEngine::K_SETTLE;
+    // settle steps of the whole batch in place: through the lane-per-env pipeline where it is the step path (pbre_lane.hip); the object's
+    // presence decides the classes, so they are recomputed for this run of steps and left invalid after it
+    const bool lane = w->lane_ok() && st == w->state && tg == w->tgt && cnt == w->n;
+    if (lane) w->lane_invalidate();
     for (int i = 0; i < count; i++) {
-        hipError_t e = wstep(w, (w->P.use_ik || w->mrec) ? WideEngine::K_SETTLE_TGT : WideEngine::K_SETTLE, st, tg, cnt, nullptr, nullptr, flags, s);
+        hipError_t e = lane ? w->launch_lane_step(kind, nullptr, nullptr, flags, s, false) : wstep(w, kind, st, tg, cnt, nullptr, nullptr, flags, s);
         if (e != hipSuccess) return e;
     }
+    if (lane) w->lane_invalidate();
     return hipSuccess;
 }
 static hipError_t wfull_step(WideEngine* w, const float* d_act, float* d_out, hipStream_t s) {

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
-    # The iCub's lane-per-env pipeline (pbre_lane.hip) is the engine's default from 8192 envs on; the tests run small batches, so they
+    # The iCub's lane-per-env pipeline (pbre_lane.hip) is the engine's default from 16384 envs on; the tests run small batches, so they
     # switch it on explicitly (tests of the lane-group kernel set PBRE_ICUB_LANE=0 themselves, the default rule has a test of its own)
     os.environ.setdefault("PBRE_ICUB_LANE", "1")
 

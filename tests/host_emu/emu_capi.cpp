@@ -245,7 +245,7 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     c->mrec = S::MREC;
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
     if constexpr (std::is_same<S, Shape16>::value) c->fast_ok = topo_matches<TopoPanda>(c->T) && fast_scene_ok(c->P);
-    if constexpr (std::is_same<S, Shape32>::value) c->lane_ok = lane_topo_matches<TopoICub, Shape32>(c->T) && (getenv("PBRE_ICUB_LANE") ? getenv("PBRE_ICUB_LANE")[0] != '0' : c->n >= 8192);      // the device's rule (pbre_lane.hip)
+    if constexpr (std::is_same<S, Shape32>::value) c->lane_ok = lane_topo_matches<TopoICub, Shape32>(c->T) && (getenv("PBRE_ICUB_LANE") ? getenv("PBRE_ICUB_LANE")[0] != '0' : c->n >= 16384);      // the device's rule (pbre_lane.hip)
     *out = c;
     return PBRE_OK;
 }

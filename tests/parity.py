@@ -409,8 +409,11 @@ def check_obj_split(Engine, lib, n=4, steps=3, exact=True):
     xo, lc = one.x_off, 20
     one.reset(); two.reset()
     s1, s2 = one.get_state(), two.get_state()
-    assert np.array_equal(s1[:, :lc], s2[:, :lc]) and np.array_equal(s1[:, 32:32 + lc], s2[:, 32:32 + lc])      # (resets: lane-group kernel in both)
-    assert np.abs(s1 - s2).max() < 1e-5
+    if exact:
+        assert np.array_equal(s1[:, :lc], s2[:, :lc]) and np.array_equal(s1[:, 32:32 + lc], s2[:, 32:32 + lc])
+        assert np.abs(s1 - s2).max() < 1e-5
+    else:       # (the pipeline also runs the settle steps of a full reset)
+        assert rel(s1[:, :xo], s2[:, :xo]).max() < 2e-4
     st, _ = ora.batch_reset(n)
     hand = two.observe()[:, :3]
     st = st.copy()

@@ -109,12 +109,12 @@ def test_icub_push_policy_coupled_solve(hip_lib, monkeypatch):
 
 
 def test_icub_default_path_by_batch_size(hip_lib, monkeypatch):
-    """without PBRE_ICUB_LANE: the lane-group kernel below 8192 envs, the pipeline from there on"""
+    """without PBRE_ICUB_LANE: the lane-group kernel below 16384 envs, the pipeline from there on"""
     from pybullet_robot_envs.model.table import icub_table
     monkeypatch.delenv("PBRE_ICUB_LANE", raising=False)
     tbl, model, info = icub_table("l")
     ov = parity.icub_overrides(info, "l", 1, 0, 1)
-    for n, lane in ((64, 0), (8192, 1)):
+    for n, lane in ((64, 0), (16384, 1)):
         eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=n, lib=hip_lib, robot=_capi.ROBOT_ICUB, **ov)
         assert eng.kernel_info()[2] == lane, (n, eng.kernel_info())
         del eng

@@ -23,26 +23,28 @@ bash tools/pmc.sh $TAG --steps 20 --warmup 3 2>&1 | grep -E "k_fast<7>|==" | hea
 python tools/pmc_json.py $TAG 131072 2>&1 | tail -9
 bash tools/pmc_sq.sh $TAG --steps 20 --warmup 3 2>&1 | tail -30 | grep -E "valu_insts_per_wave|valu_active|wait_any" | head -8
 echo "== iCub / hands benches"
-rm -f gpurun_out/${TAG}_icub_steady.json
-timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | tee gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-timeout 300 python tools/bench_icub.py --envs 65536 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-timeout 300 python tools/bench_icub.py --envs 131072 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-timeout 300 python tools/bench_icub.py --envs 262144 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-timeout 300 python tools/bench_icub.py --envs 16384 --steps 20 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
-PBRE_ICUB_LANE=0 timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 2>&1 | tail -1 | sed 's/^{/{"PBRE_ICUB_LANE": 0, /' | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-300
+rm -f gpurun_out/${TAG}_icub_steady.json gpurun_out/${TAG}_icub_bench.json
+# (bench_icub.py: 1500 zero-action steps before the timed ones, see its --warm; "--warm 0" = the burst right after reset())
+for L in 1 0; do for N in 32768 131072; do for M in "" "--joint"; do
+  PBRE_ICUB_LANE=$L timeout 300 python tools/bench_icub.py --envs $N --steps 20 $M 2>&1 | tail -1 | sed "s/^{/{\"PBRE_ICUB_LANE\": $L, /" | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
+done; done; done
+timeout 300 python tools/bench_icub.py --envs 262144 --steps 20 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
+for L in 1 0; do PBRE_ICUB_LANE=$L timeout 300 python tools/bench_icub.py --envs 16384 --steps 20 2>&1 | tail -1 | sed "s/^{/{\"PBRE_ICUB_LANE\": $L, /" | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260; done
+timeout 300 python tools/bench_icub.py --envs 32768 --steps 20 --warm 0 2>&1 | tail -1 | sed 's/^{/{"protocol": "burst right after reset()", /' | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
+timeout 300 python tools/icub_sustain.py --envs 32768 --windows 5 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
+PBRE_ICUB_LANE=0 timeout 300 python tools/icub_sustain.py --envs 32768 --windows 5 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
 echo "== iCub: stationary mix under random actions (auto-reset), lane-per-env pipeline and lane-group kernel; kernel trace of the pipeline"
-for M in "" "--joint"; do
-  timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
-  PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
-done
+for N in 16384 32768; do for M in "" "--joint"; do
+  PBRE_ICUB_LANE=1 timeout 600 python tools/icub_steady.py --envs $N --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+  PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --envs $N --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+done; done
 timeout 600 python tools/icub_steady.py --envs 131072 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 timeout 600 python tools/icub_steady.py --envs 262144 --steps 750 --window 250 --joint 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 echo "== iCub push with a scripted policy that drives the hand at the object (robot-object contacts in 10-40 % of the envs)"
 rm -f gpurun_out/${TAG}_icub_push_soak.json
 for N in 8192 32768 131072; do
-  timeout 900 python tools/icub_push_soak.py --envs $N --steps 900 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_push_soak.json | cut -c1-260
+  PBRE_ICUB_LANE=1 timeout 900 python tools/icub_push_soak.py --envs $N --steps 900 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_push_soak.json | cut -c1-260
   PBRE_ICUB_LANE=0 timeout 900 python tools/icub_push_soak.py --envs $N --steps 900 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_push_soak.json | cut -c1-260
 done
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_icub_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py --envs 32768 --steps 750 --window 250 > $ROOTDIR/gpurun_out/${TAG}_icub_rocprof.log 2>&1)
