@@ -14,7 +14,7 @@
  *
  * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
  * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 for <= 32 DoF, W = 128 for <= 60
- * (the iCub with hands: 272 floats); the Panda's robot-level engine (robot_level = 1) uses W = 32 (80 floats); nd = number of DoF:
+ * (the iCub with hands: 272 floats); the Panda's and the iCub's robot-level engines (robot_level = 1) use W = 32 (80 floats); nd = number of DoF:
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
@@ -117,10 +117,10 @@ typedef struct {
     double  ik_link_offset[3];  /* hand COM frame -> hand link frame (icub_env.py:252-258); 0 for the Panda */
     int32_t ik_absolute;        /* 1: IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-300) instead of
                                    scaled increments accumulated by the task env; set for the robot-level interfaces */
-    int32_t robot_level;        /* 1: the robot-level interface of pandaEnv / iCubHandsEnv used without a task env (R/envs/panda_envs/
-                                   panda_env.py:195-365, R/envs/icub_envs/icub_env_with_hands.py): absolute commands, persistent
+    int32_t robot_level;        /* 1: the robot-level interface of pandaEnv / iCubEnv / iCubHandsEnv used without a task env (R/envs/panda_envs/
+                                   panda_env.py:195-365, R/envs/icub_envs/icub_env.py:259-360, icub_env_with_hands.py): absolute commands, persistent
                                    POSITION_CONTROL motors (pbre_set_motors, pbre_apply_action: target | gain | force | max velocity
-                                   per joint), fingertip contact statistics appended to the observation, no episode logic.  Always
+                                   per joint), fingertip contact statistics appended to the observation (robots with fingers), no episode logic.  Always
                                    1 for PBRE_ROBOT_ICUB_HANDS; PBRE_ROBOT_PANDA with 1 = what pbre_default_config(PBRE_ROBOT_PANDA_ARM) fills */
     const double* robot_table; size_t robot_table_len;   /* number of doubles */
 } pbre_config;

@@ -22,7 +22,7 @@ namespace pbre {
 // Lane layout of one env group.  Lanes 0..NJ-1 own the robot DoF, lanes LC..LC+2 / LC+3..LC+5 the object's linear /
 // angular velocity (Q record: LC..LC+2 position, LC+3..LC+6 quaternion), lane L1 is the constant-one lane that carries
 // -rhs of a contact row through the row dot product.  State record = Q[W] | V[W] | X[16] floats.
-template <int W_, int NJ_, int NSUB_, int NLEV_, int NC_RO_ = 2, int NTIP_ = 0>
+template <int W_, int NJ_, int NSUB_, int NLEV_, int NC_RO_ = 2, int NTIP_ = 0, bool MREC_ = (NTIP_ > 0)>
 struct ShapeT {
     static constexpr int W = W_;          // lanes per env
     static constexpr int NJ = NJ_;        // robot DoF lanes
@@ -34,7 +34,7 @@ struct ShapeT {
     static constexpr int NMW = (NJ_ + 31) / 32;            // 32-bit words of an ancestor / subtree mask
     static constexpr int NC_OT = 4, NC_RO = NC_RO_, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;   // contact slots: object-table, robot-object, robot-table
     static constexpr int NTIP = NTIP_;    // fingertips whose contact force is reported (iCub hands); such a shape also keeps a
-    static constexpr bool MREC = NTIP_ > 0;   // per-env motor record target[W] | kp[W] | force scale[W] | max velocity[W] (PyBullet's persistent motors)
+    static constexpr bool MREC = MREC_;       // per-env motor record target[W] | kp[W] | force scale[W] | max velocity[W] (PyBullet's persistent motors)
     static constexpr int TGT = MREC ? 4 * W_ : NJ_;        // floats per env of the motor-target buffer
     static constexpr int TIP0 = NJ_ + 7;                   // Q lanes TIP0..TIP0+NTIP+1: tip forces, tips in contact, other robot-object contacts
     static_assert(NJ_ + 7 + (NTIP_ ? NTIP_ + 2 : 0) <= W_ && NJ_ <= 64, "lane budget");
@@ -46,6 +46,8 @@ using Shape128 = ShapeT<128, 60, 2, 4, 6, 5>;   // iCub with hands (legs pruned,
 using ShapePA = ShapeT<32, 9, 3, 4, 4, 5>;      // Panda, robot-level interface (pandaEnv alone: persistent motors, fingertip statistics -- 2 of the
                                                 // 5 fingertip slots are used; 4 robot-object contact slots: both spheres of both fingers): one env
                                                 // per half-wave, object at Q[9..15], statistics at Q[16..22]
+using ShapeIA = ShapeT<32, 20, 2, 4, 2, 0, true>;   // iCub without hands, robot-level interface (iCubEnv alone: persistent motors; the model has no
+                                                    // fingertips, so no statistics slots): one env per half-wave like Shape32
 
 // the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
 constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;

@@ -113,8 +113,9 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     const int nd = table_ndof(*cfg);
     WideEngine* w = nd > Shape64::NJ ? make_hands_engine()
                   : (cfg->robot_level && nd <= ShapePA::NJ ? static_cast<WideEngine*>(new WideImpl<ShapePA, DevLanes32>())     // pandaEnv alone
+                  : (cfg->robot_level && nd <= ShapeIA::NJ ? make_icub_arm_engine()                                             // iCubEnv alone
                   : (nd <= Shape32::NJ ? make_lane_engine()
-                                       : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>())));
+                                       : static_cast<WideEngine*>(new WideImpl<Shape64, DevLanes64>()))));
     w->cfg = *cfg;
     std::string e = w->tables(*cfg);
     if (!e.empty()) {

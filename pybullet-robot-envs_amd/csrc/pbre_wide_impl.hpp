@@ -268,5 +268,6 @@ struct WideImpl : WideEngine {
 
 WideEngine* make_hands_engine();       // pbre_hands.hip
 WideEngine* make_lane_engine();        // pbre_lane.hip
+WideEngine* make_icub_arm_engine();    // pbre_icub_arm.hip
 
 }  // namespace pbre

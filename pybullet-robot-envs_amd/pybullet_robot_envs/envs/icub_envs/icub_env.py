@@ -3,13 +3,23 @@
 Keeps the reference constructor signature and the attributes / methods the task envs use.  The SDF is parsed once by the
 engine's own model compiler (model/sdf.py -> robot_data/iCub/icub_model.json) and handed to libpbre as a flat RobotTable;
 the floating base pinned by `p.createConstraint(JOINT_FIXED)` (icub_env.py:97-103) is a fixed base at the constraint's
-rest pose (model/table.py pin_base).  All per-step work (IK, motors, dynamics, observation) runs on the GPU, one env per
-wavefront (csrc/pbre_wide.hip)."""
+rest pose (model/table.py pin_base).  All per-step work (IK, motors, dynamics, observation) runs on the GPU.
+
+Two ways of use, as in the reference:
+  * inside a task env (iCubReachGymEnv, ...): the task env owns the batched engine and fuses the robot's motor commands into its
+    step(); the robot object provides model bookkeeping, limits and `get_observation`.
+  * alone: `iCubEnv(cid, use_IK=1)` on a client from `pybullet_robot_envs.connect(n)`.  The first command or query builds the
+    robot-level engine (pbre_config.robot_level, csrc/pbre_icub_arm.hip: persistent POSITION_CONTROL motors with velocity bounds;
+    scene of the reach task -- table and object) and `apply_action(action, max_vel)` commands the whole batch;
+    `step_simulation(n)` stands for a script's `for _ in range(n): p.stepSimulation()` loops.
+
+Hand-pose commands may be 3 values (position), 6 (position + Euler angles, clipped to the arm's Euler limits as in the reference)
+or 7 (position + quaternion, used as given, as in the reference); `max_vel` is the motors' `maxVelocity`."""
 import math as m
 
 import numpy as np
 
-from pybullet_robot_envs import _client
+from pybullet_robot_envs import _capi, _client
 from pybullet_robot_envs._gym import seeding
 from pybullet_robot_envs.model.table import icub_table, ICUB_HOME
 
@@ -148,7 +158,7 @@ class iCubEnv:
     def get_observation(self):
         """Hand COM pose (3 + 3 Euler), its linear velocity (3) and the controlled joint positions (10) with their limits
         (icub_env.py:202-249).  List of 19 for a single env, [N, 19] array for a batch."""
-        eng = self._client.require_engine()
+        eng = self._engine_or_build()
         obs = eng.observe()[:, :9 + len(self._joints_to_control)].astype(np.float64)
         if self._control_eu_or_quat != 0:      # hand orientation as a quaternion (icub_env.py:219-224): converted from the engine's Euler angles
             from pybullet_robot_envs.envs.panda_envs.panda_env import pandaEnv
@@ -164,8 +174,109 @@ class iCubEnv:
             com_T_link_hand = ((-0.064768, -0.00563, -0.02266), (0., 0., 0., 1.))
         return com_T_link_hand
 
+    # ------------------------------------------------------------------ engine of the stand-alone (robot-level) use
+    def _engine_or_build(self):
+        """The task env's engine when there is one, else the robot-level engine (built and reset on first use: replaces the
+        reference reset's loadSDF + motors at the initial positions + apply_action(home hand pose) + stepSimulation,
+        icub_env.py:91-151)."""
+        c = self._client
+        if c.engine is None:
+            dofs = self.controlled_dofs()
+            home = self.sim_home()
+            c.engine = _capi.make_engine(self.robot_table, devices=c.devices, task=_capi.TASK_REACH, num_envs=c.num_envs, lib=c.lib,
+                                         robot=_capi.ROBOT_ICUB, robot_level=1, ik_absolute=1, max_steps=1 << 30, target_dist_min=-1.0,
+                                         device_id=c.device_id, env_id_base=c.env_id_base, seed=c.seed,
+                                         use_ik=1 if self._use_IK else 0, control_orientation=1 if self._control_orientation else 0,
+                                         num_controlled_joints=len(dofs), num_joints_ctrl=len(dofs), act_dof=dofs + [-1] * (16 - len(dofs)),
+                                         home=home + [0.0] * (40 - len(home)), ik_pos_scale=1.0, ik_rot_scale=1.0,
+                                         home_hand_pose=[float(x) for x in self._home_hand_pose],
+                                         eu_lim=[-1e9, 1e9] * 3,        # Euler limits are applied in apply_action: a quaternion command bypasses them
+                                         ik_link_offset=list(self._com_to_link_hand_frame()[0]),
+                                         robot_ws=[x for lim in self._workspace_lim for x in lim])
+            c.engine.reset()
+            self._own_engine = True
+        return c.engine
+
+    def _robot_level(self):
+        eng = self._engine_or_build()
+        if not getattr(self, "_own_engine", False):
+            raise RuntimeError("inside a task env the motors are commanded by the env's fused step(); robot-level commands belong "
+                               "to iCubEnv used alone (see the module docstring)")
+        return eng
+
+    @property
+    def num_envs(self):
+        return self._client.num_envs
+
+    def _batch(self, action):
+        a = np.asarray(action, dtype=np.float32)
+        if a.ndim == 1:
+            a = np.tile(a, (self.num_envs, 1))
+        return a
+
+    @staticmethod
+    def _euler_from_quat(q):
+        """pybullet.getEulerFromQuaternion for [N, 4] (x, y, z, w)."""
+        x, y, z, w = (q[:, k].astype(np.float64) for k in range(4))
+        sarg = -2.0 * (x * z - w * y)
+        roll = np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z)
+        pitch = np.arcsin(np.clip(sarg, -1.0, 1.0))
+        yaw = np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)
+        lo, hi = sarg <= -0.99999, sarg >= 0.99999
+        roll = np.where(lo | hi, 0.0, roll)
+        pitch = np.where(lo, -0.5 * m.pi, np.where(hi, 0.5 * m.pi, pitch))
+        yaw = np.where(lo, 2 * np.arctan2(x, -y), np.where(hi, 2 * np.arctan2(-x, y), yaw))
+        return np.stack([roll, pitch, yaw], axis=1)
+
+    def _hand_pose_command(self, a, eng):
+        """3 / 6 / 7 command values -> what the engine takes (x, y, z[, roll, pitch, yaw]); icub_env.py:262-300."""
+        if not (a.shape[1] == 3 or a.shape[1] == 6 or a.shape[1] == 7):
+            raise AssertionError('number of action commands must be \n- 3: (dx,dy,dz)'
+                                 '\n- 6: (dx,dy,dz,droll,dpitch,dyaw)'
+                                 '\n- 7: (dx,dy,dz,qx,qy,qz,w)'
+                                 '\ninstead it is: ', a.shape[1])
+        if eng.act_dim == 3:              # orientation not under control: the home orientation is kept (:281-283)
+            return np.ascontiguousarray(a[:, :3])
+        if a.shape[1] == 6:               # Euler angles, each `min(hi, max(lo, x))` (:289-291)
+            eu = a[:, 3:6].astype(np.float64)
+            for k in range(3):
+                eu[:, k] = np.minimum(self._eu_lim[k][1], np.maximum(self._eu_lim[k][0], eu[:, k]))
+        elif a.shape[1] == 7:             # quaternion, used as given (:296-297)
+            eu = self._euler_from_quat(a[:, 3:7])
+        else:                             # `else: use current orientation` (:299-300)
+            eu = self._current_hand_euler(eng, a.shape[0])
+        return np.concatenate([a[:, :3], eu.astype(np.float32)], axis=1)
+
+    def _current_hand_euler(self, eng, n):
+        return eng.observe()[:, 3:6].astype(np.float64)
+
     def apply_action(self, action, max_vel=-1):
-        raise NotImplementedError("IK and motor targets are applied inside the fused GPU step; use the task env's step()")
+        """Command the motors (icub_env.py:259-360); the simulation does not advance.  Joint control: one absolute target per
+        controlled joint (torso + the chosen arm), clipped to the joint limits, gain 0.5.  IK: the hand pose (x, y, z[, roll, pitch,
+        yaw | quaternion]) clipped to the workspace, solved over every joint with the other joints held at their rest poses, gain
+        0.2.  `max_vel` is the motors' maxVelocity.  A 1-D action is sent to every env, a [N, k] array per env."""
+        eng = self._robot_level()
+        a = self._batch(action)
+        if self._use_IK:
+            a = self._hand_pose_command(a, eng)
+        elif a.shape[1] != len(self._joints_to_control):
+            raise AssertionError('number of motor commands differs from number of motor to control',
+                                 a.shape[1], len(self._joints_to_control))
+        eng.apply_action(a, max_vel=float(max_vel))
+
+    def step_simulation(self, n=1):
+        """`for _ in range(n): p.stepSimulation()` of a script that drives the robot."""
+        self._robot_level().settle(int(n))
+
+    def get_object_pose(self):
+        """[N, 7] position + quaternion of the scene's object."""
+        eng = self._engine_or_build()
+        return eng.get_state_cols(eng.ndof, 7).astype(np.float64)
+
+    def get_joint_positions(self):
+        """[N, ndof] joint positions of the simulated model, `self._info['dof_names']` order."""
+        eng = self._engine_or_build()
+        return eng.get_state_cols(0, eng.ndof).astype(np.float64)
 
     def delete_simulated_robot(self):
         pass

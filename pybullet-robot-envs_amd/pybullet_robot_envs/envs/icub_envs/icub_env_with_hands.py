@@ -118,7 +118,6 @@ class iCubHandsEnv(iCubEnv):
                                 robot=_capi.ROBOT_ICUB_HANDS, **overrides)
         self._engine = c.engine
         assert self._engine.act_dim == (len(dofs) if not self._use_IK else (6 if self._control_orientation else 3)) and self._engine.state_floats == 272
-        self.num_envs = self._engine.num_envs
 
     def _com_to_link_hand_frame(self):
         if self._control_arm == 'r':
@@ -128,67 +127,18 @@ class iCubHandsEnv(iCubEnv):
         return com_T_link_hand
 
     # ------------------------------------------------------------------ commands
-    def _batch(self, action):
-        a = np.asarray(action, dtype=np.float32)
-        if a.ndim == 1:
-            a = np.tile(a, (self.num_envs, 1))
-        return a
+    # apply_action / step_simulation / the 3-6-7 hand-pose command forms are iCubEnv's (icub_env.py), on this class's own engine
+    def _engine_or_build(self):
+        return self._engine
 
-    @staticmethod
-    def _euler_from_quat(q):
-        """pybullet.getEulerFromQuaternion for [N, 4] (x, y, z, w)."""
-        x, y, z, w = (q[:, k].astype(np.float64) for k in range(4))
-        sarg = -2.0 * (x * z - w * y)
-        roll = np.arctan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z)
-        pitch = np.arcsin(np.clip(sarg, -1.0, 1.0))
-        yaw = np.arctan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z)
-        lo, hi = sarg <= -0.99999, sarg >= 0.99999
-        roll = np.where(lo | hi, 0.0, roll)
-        pitch = np.where(lo, -0.5 * m.pi, np.where(hi, 0.5 * m.pi, pitch))
-        yaw = np.where(lo, 2 * np.arctan2(x, -y), np.where(hi, 2 * np.arctan2(-x, y), yaw))
-        return np.stack([roll, pitch, yaw], axis=1)
-
-    def _hand_pose_command(self, a):
-        """3 / 6 / 7 command values -> what the engine takes (x, y, z[, roll, pitch, yaw]); icub_env.py:262-300."""
-        if not (a.shape[1] == 3 or a.shape[1] == 6 or a.shape[1] == 7):
-            raise AssertionError('number of action commands must be \n- 3: (dx,dy,dz)'
-                                 '\n- 6: (dx,dy,dz,droll,dpitch,dyaw)'
-                                 '\n- 7: (dx,dy,dz,qx,qy,qz,w)'
-                                 '\ninstead it is: ', a.shape[1])
-        ad = self._engine.act_dim         # 6 with control_orientation, else 3: the home orientation is kept (:281-283)
-        if ad == 3:
-            return np.ascontiguousarray(a[:, :3])
-        if a.shape[1] == 6:               # Euler angles, each `min(hi, max(lo, x))` (:289-291)
-            eu = a[:, 3:6].astype(np.float64)
-            for k in range(3):
-                eu[:, k] = np.minimum(self._eu_lim[k][1], np.maximum(self._eu_lim[k][0], eu[:, k]))
-        elif a.shape[1] == 7:             # quaternion, used as given (:296-297)
-            eu = self._euler_from_quat(a[:, 3:7])
-        else:                             # `else: use current orientation` (:299-300) is approximated by the home orientation
-            eu = np.tile(np.asarray(self._home_hand_pose[3:6], np.float64), (a.shape[0], 1))
-        return np.concatenate([a[:, :3], eu.astype(np.float32)], axis=1)
-
-    def apply_action(self, action, max_vel=-1):
-        """Command the motors (icub_env.py:260-361): joint control -- one absolute target per controlled joint (37: torso, both
-        arms, the hand), clipped to the joint limits; IK -- the hand pose (x, y, z[, roll, pitch, yaw]).  A 1-D action is sent to
-        every env, a [N, k] array per env.  Does not advance the simulation."""
-        a = self._batch(action)
-        if self._use_IK:
-            a = self._hand_pose_command(a)
-        elif a.shape[1] != len(self._joints_to_control):
-            raise AssertionError('number of motor commands differs from number of motor to control',
-                                 a.shape[1], len(self._joints_to_control))
-        self._engine.apply_action(a, max_vel=float(max_vel))
-
-    def step_simulation(self, n=1):
-        """`for _ in range(n): p.stepSimulation()` of the demo script."""
-        self._engine.settle(int(n))
+    def _robot_level(self):
+        return self._engine
 
     def step(self, action):
         """Fused apply_action + one simulation step + observation for the whole batch (one kernel launch)."""
         a = self._batch(action)
         if self._use_IK:
-            a = self._hand_pose_command(a)
+            a = self._hand_pose_command(a, self._engine)
         obs, rew, done = self._engine.step(a)
         self._last_out = obs
         return obs
@@ -241,16 +191,6 @@ class iCubHandsEnv(iCubEnv):
         t = self._tail()
         c = (t[:, 6] - t[:, 5]) > 0
         return bool(c[0]) if self.num_envs == 1 else c
-
-    def get_object_pose(self):
-        """[N, 7] position + quaternion of the graspable object (the demo reads it back through PyBullet)."""
-        s = self._engine.get_state()
-        nd = self._engine.ndof
-        return s[:, nd:nd + 7].astype(np.float64)
-
-    def get_joint_positions(self):
-        """[N, 60] joint positions of the simulated model, `self._info['dof_names']` order."""
-        return self._engine.get_state()[:, :self._engine.ndof].astype(np.float64)
 
     def fingertip_indices(self):
         names = self.joint_groups[self._control_arm + '_hand']

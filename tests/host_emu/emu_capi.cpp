@@ -259,6 +259,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     const int nd = table_ndof(*cfg);
     if (nd > Shape64::NJ) return create<Shape128>(cfg, out);
     if (cfg->robot_level && nd <= ShapePA::NJ) return create<ShapePA>(cfg, out);
+    if (cfg->robot_level && nd <= ShapeIA::NJ) return create<ShapeIA>(cfg, out);
     return nd > Shape32::NJ ? create<Shape64>(cfg, out) : (nd > Shape16::NJ ? create<Shape32>(cfg, out) : create<Shape16>(cfg, out));
 }
 void pbre_destroy(pbre_ctx* c) { delete c; }

@@ -259,6 +259,20 @@ def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, **kw):
     return o, tbl, info
 
 
+def icub_arm_oracle(control_arm="l", use_ik=0, control_orientation=1, **kw):
+    """Oracle + RobotTable of iCubEnv used alone (robot-level interface, reference icub_env.py:91-151, 259-360): the reach task's
+    scene, absolute hand-pose commands, no episode logic."""
+    o, tbl, info = icub_oracle(control_arm, 0, use_ik, control_orientation, **kw)
+    t = o.task
+    t.max_steps, t.target_dist_min, t.ik_absolute, t.ik_pos_scale, t.ik_rot_scale = 1 << 30, -1.0, 1, 1.0, 1.0
+    ws = [[0.1, 0.45], [-0.3, 0.3], [0.5, 1.0]]                       # iCubEnv._workspace_lim (icub_env.py:62)
+    for a in range(3):
+        for b in range(2):
+            t.robot_ws[a][b] = ws[a][b]
+            t.eu_lim[a][b] = (-1e9, 1e9)[b]                           # Euler limits are applied by the Python class
+    return o, tbl, info
+
+
 def hands_oracle(control_arm="l", use_ik=0, **kw):
     from pybullet_robot_envs.model.table import icub_hands_table
     tbl, model, info = icub_hands_table(control_arm)

@@ -974,6 +974,112 @@ def check_panda_arm(Engine, lib, use_ik=0, control_orientation=1, n=2, steps=4, 
     return eng
 
 
+# ---------------------------------------------------------------------------------------------- iCub, robot-level interface
+TOL_ICUB_ARM = dict(TOL_ICUB)      # measured on the lane emulation: q 8e-8, qd 1.2e-5, EE velocity 1e-5 m/s, everything else <= 3e-7
+
+
+def make_icub_arm_pair(Engine, lib, n, control_arm="l", use_ik=0, control_orientation=1, **kw):
+    """iCubEnv used alone (pbre_config.robot_level = 1; reference icub_env.py:91-151, 259-360): engine (built by the drop-in class)
+    + oracle, same scene."""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env import iCubEnv
+    cid = _client.connect(n, lib=lib)
+    robot = iCubEnv(cid, use_IK=use_ik, control_arm=control_arm, control_orientation=control_orientation)
+    eng = robot._robot_level()
+    ora, tbl, info = orc.icub_arm_oracle(control_arm, use_ik, control_orientation)
+    ph = eng.get_physics()
+    for f in ("table_c", "table_h", "obj_h", "obj_inertia"):
+        for k in range(3):
+            getattr(ora.params, f)[k] = getattr(ph, f)[k]
+    ora.params.obj_mass = ph.obj_mass
+    return robot, eng, ora, cid
+
+
+def check_icub_arm(Engine, lib, control_arm="l", use_ik=0, control_orientation=1, n=2, steps=4, seed=5):
+    """The iCub's robot-level engine (ShapeIA: half-wave lane groups with motor records) against the oracle: reset; fused command
+    + step from identical states; apply_action(max_vel) + stepSimulation loops, through the drop-in iCubEnv."""
+    from pybullet_robot_envs import _client
+    robot, eng, ora, cid = make_icub_arm_pair(Engine, lib, n, control_arm, use_ik, control_orientation)
+    nd = 20
+    assert eng.state_floats == ora.state_floats == 80 and eng.ndof == nd and eng.act_dim == ora.task.n_act and eng.obs_dim == ora.obs_dim == 31
+    xo = eng.x_off
+    st_o, mrec, obs_o = ora.hands_reset(n)
+    st_e = eng.get_state()
+    obs = eng.observe()
+    assert rel(st_e[:, :xo], st_o[:, :xo]).max() < 2e-3, rel(st_e[:, :xo], st_o[:, :xo]).max()
+    assert rel(obs, obs_o).max() < 2e-2
+    W = 32
+    mot = eng.get_motor_state()
+    assert mot.shape == (n, 4, W) and np.abs(mot[:, 0, :nd] - mrec[:, :nd]).max() < 2e-3 and (mot[:, 3] == 0).all()
+    rng = np.random.default_rng(seed)
+    dofs = robot.controlled_dofs()
+    home = np.array(robot.sim_home())[dofs]
+    hand = np.array(robot._home_hand_pose, np.float64)
+    worst, flips = {}, 0
+    st = st_o
+    m32 = np.zeros((n, 4, W), np.float32)
+    for k in range(steps):
+        if use_ik:
+            a = np.tile(hand[:eng.act_dim].astype(np.float32), (n, 1))
+            a[:, :3] += rng.uniform(-0.03, 0.03, (n, 3)).astype(np.float32)
+        else:
+            a = (home[None, :] + rng.uniform(-0.2, 0.2, (n, len(dofs)))).astype(np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(s32)
+        for c in range(4):
+            m32[:, c, :nd] = mrec[:, c * orc.MAXD:c * orc.MAXD + nd]
+        eng.set_motor_state(m32)
+        ob, rw, dn = eng.step(a)
+        so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+        se = eng.get_state()
+        flip = np.abs(se[:, :nd] - so[:, :nd]).max(1) > TOL_ICUB_ARM["q"] if use_ik else np.zeros(n, bool)
+        flips += int(flip.sum())
+        if (~flip).any():
+            merge_worst(worst, group_quantities(eng, se[~flip], so[~flip], ob[~flip], out[~flip]))
+        if flip.any():
+            assert_within(group_quantities(eng, se[flip], so[flip], ob[flip], out[flip]), TOL_ICUB_IK_FLIP, "(IK flip, step %d)" % k)
+        assert not dn.any()
+        st = so
+    assert flips <= max(1, n * steps // 10)
+    assert_within(worst, TOL_ICUB_ARM, "(iCub robot level, %d IK flips)" % flips)
+    # apply_action(max_vel) through the drop-in class, then the simulation advances with the motors holding the command
+    s32 = st.astype(np.float32)
+    eng.set_state(s32)
+    for c in range(4):
+        m32[:, c, :nd] = mrec[:, c * orc.MAXD:c * orc.MAXD + nd]
+    eng.set_motor_state(m32)
+    if use_ik:
+        cmd = hand[:6].copy(); cmd[:3] += [0.05, -0.04, 0.06]
+        a = np.tile(cmd[:eng.act_dim].astype(np.float32), (n, 1))
+        robot.apply_action(list(cmd[:6] if control_orientation else cmd[:3]), max_vel=0.5)
+    else:
+        a = np.tile((home + 0.5).astype(np.float32), (n, 1))
+        robot.apply_action(list(home + 0.5), max_vel=0.5)
+    so, mrec = ora.hands_apply_action(s32.astype(np.float64), mrec, a, max_vel=0.5)
+    mot = eng.get_motor_state()
+    for c in range(4):
+        assert np.abs(mot[:, c, :nd] - mrec[:, c * orc.MAXD:c * orc.MAXD + nd]).max() < (5e-3 if use_ik else 1e-6), c
+    if use_ik:
+        assert (mot[:, 3, :nd] == 0.5).all() and (mot[:, 1, :nd] == np.float32(0.2)).all()
+        for c in range(4):      # continue from identical commands (the IK may stop one iteration apart)
+            m32[:, c, :nd] = mrec[:, c * orc.MAXD:c * orc.MAXD + nd]
+        eng.set_motor_state(m32)
+    else:
+        lo, hi = np.array(robot.ll), np.array(robot.ul)
+        ctl = [j for j, idx in enumerate(robot._joint_name_to_ids.values()) if idx in robot._joints_to_control]
+        assert np.abs(mot[:, 0, dofs] - np.clip(home + 0.5, lo[ctl], hi[ctl])).max() < 1e-6       # clipped to the joint limits
+        assert (mot[:, 3, dofs] == 0.5).all() and (mot[:, 1, dofs] == np.float32(0.5)).all()
+    robot.step_simulation(12)
+    so = ora.hands_settle(so, mrec, 12)
+    se = eng.get_state()
+    assert np.abs(se[:, :nd] - so[:, :nd]).max() < 5e-5 and np.abs(se[:, 32:32 + nd] - so[:, 32:32 + nd]).max() < 5e-3
+    assert np.abs(se[:, 32:32 + nd]).max() <= 0.5 + 1e-3            # the velocity bound binds: no joint moves faster than max_vel
+    obs_r, lim = robot.get_observation()
+    assert np.asarray(obs_r).shape[-1] == 9 + len(dofs) and len(lim) == 9 + len(dofs)
+    _client.disconnect(cid)
+    return worst
+
+
 def run_panda_demo(robot, upto=4):
     """The scripted grasp of the reference's examples/helloworlds/helloworld_panda.py:89-140 on a stand-alone pandaEnv (IK control):
     pre-grasp, above the object, down to it, close the fingers, lift.  Returns the object poses [N, 7] after the phases run."""

@@ -92,3 +92,19 @@ def test_icub_lane_path_matches_lane_group_kernel(emu_lib, monkeypatch):
 
 def test_icub_hand_on_table(emu_lib):
     print(parity.check_icub_table_contact(_capi.Engine, emu_lib, n=2, steps=45))
+
+
+# ---------------------------------------------------------------------------------------------- iCubEnv used alone
+@pytest.mark.parametrize("arm,use_ik,ori", [("l", 0, 1), ("l", 1, 1), ("r", 1, 0)])
+def test_icub_env_robot_level_commands(emu_lib, arm, use_ik, ori):
+    """iCubEnv.apply_action(action, max_vel) + stepSimulation loops on the stand-alone class (reference icub_env.py:91-151, 259-360):
+    joint control, IK with (6-D) and without (3-D: the home orientation is kept) orientation control, either arm"""
+    parity.check_icub_arm(_capi.Engine, emu_lib, arm, use_ik, ori, n=1, steps=3)
+
+
+def test_icub_env_inside_a_task_env_refuses_robot_level_commands(emu_lib):
+    from pybullet_robot_envs.envs import iCubReachGymEnv
+    env = iCubReachGymEnv(use_IK=1, num_envs=1, _lib=emu_lib)
+    with pytest.raises(RuntimeError):
+        env._robot.apply_action([0.3, 0.2, 0.8])
+    env.close()

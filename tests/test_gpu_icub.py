@@ -162,3 +162,31 @@ def test_icub_wave_neighbour_independence(hip_lib):
 def test_icub_reset_snapshot(hip_lib):
     import test_emu_icub
     test_emu_icub.test_icub_reset_snapshot(hip_lib)
+
+
+# ---------------------------------------------------------------------------------------------- iCubEnv used alone
+@pytest.mark.parametrize("arm,use_ik,ori", [("l", 0, 1), ("l", 1, 1), ("r", 1, 0)])
+def test_icub_env_robot_level_commands(hip_lib, arm, use_ik, ori):
+    """iCubEnv.apply_action(action, max_vel) + stepSimulation loops on the stand-alone class (csrc/pbre_icub_arm.hip: ShapeIA, half-wave
+    lane groups with persistent motor records) through the C-ABI against the fp64 oracle"""
+    parity.check_icub_arm(_capi.Engine, hip_lib, arm, use_ik, ori, n=5, steps=4)
+
+
+def test_icub_env_robot_level_batch(hip_lib):
+    """4096 replicas driven by a script: hand to a pose above the table with a velocity bound, then back; every env reaches the poses,
+    replicas stay identical"""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env import iCubEnv
+    n = 4096
+    cid = _client.connect(n, lib=hip_lib)
+    robot = iCubEnv(cid, use_IK=1, control_arm='l', control_orientation=0)
+    robot.apply_action([0.35, 0.2, 0.85], max_vel=2.0); robot.step_simulation(300)
+    obs, lim = robot.get_observation()
+    assert obs.shape == (n, 19) and np.abs(obs[:, :3] - [0.35, 0.2, 0.85]).max() < 5e-3, np.abs(obs[:, :3] - [0.35, 0.2, 0.85]).max()
+    robot.apply_action([0.3, 0.26, 0.8]); robot.step_simulation(300)
+    obs, lim = robot.get_observation()
+    assert np.abs(obs[:, :3] - [0.3, 0.26, 0.8]).max() < 5e-3
+    st = robot._client.engine.get_state()
+    assert np.isfinite(st).all() and np.array_equal(st, np.broadcast_to(st[0], st.shape))
+    assert robot.get_object_pose().shape == (n, 7) and robot.get_joint_positions().shape == (n, 20)
+    _client.disconnect(cid)
