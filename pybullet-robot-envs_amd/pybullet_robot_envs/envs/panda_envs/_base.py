@@ -139,7 +139,12 @@ class PandaTaskBase(Env):
         return lim
 
     def apply_action(self, action):
-        raise NotImplementedError("apply_action is fused into step() on the GPU")
+        """The action half of the reference's step() (panda_push_gym_env.py:191-255, icub_reach_gym_env.py:204-259): scaled action ->
+        motors (through the IK when use_IK), then action_repeat x (stepSimulation, step counter, termination check).  Here that is the
+        fused GPU step itself; what it returns is dropped, and get_extended_observation() / _termination() / _compute_reward() called
+        afterwards -- the rest of the reference's step() -- read the state it left (without auto_reset: a finished env that restarted
+        inside the step shows its new episode)."""
+        self._raw_step(action)
 
     def _raw_step(self, action):
         a = np.asarray(action, dtype=np.float32)

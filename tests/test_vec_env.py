@@ -71,3 +71,23 @@ def test_devices_kwarg_shards_the_batch_in_one_process(emu_lib):
     two.change_physics_params([0.1, 0.2, 0.3, 0.1, 0.2, 0.3], 0.7, 0.1, 0.04)
     assert np.allclose(two._engine.get_state_cols(44)[:, 0], [0.1, 0.2, 0.3, 0.1, 0.2, 0.3])
     one.close(); two.close()
+
+
+def test_apply_action_is_the_action_half_of_step(emu_lib):
+    """The reference's step() = apply_action + get_extended_observation + _termination + _compute_reward (panda_push_gym_env.py:230-259,
+    icub_reach_gym_env.py:232-259): the same four calls on one env give what step() gives on its twin."""
+    from pybullet_robot_envs.envs.utils import scale_gym_data
+    for cls, kw, adim in ((pandaPushGymEnv, dict(obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2), 7), (iCubReachGymEnv, dict(use_IK=1), 3)):
+        a_env = cls(num_envs=2, seed=7, _lib=emu_lib, **kw)
+        b_env = cls(num_envs=2, seed=7, _lib=emu_lib, **kw)
+        a_env.reset(); b_env.reset()
+        rng = np.random.default_rng(1)
+        for t in range(3):
+            act = rng.uniform(-1, 1, (2, adim))
+            obs, rew, done, _ = a_env.step(act)
+            b_env.apply_action(act)
+            raw, lim = b_env.get_extended_observation()
+            assert np.allclose(scale_gym_data(b_env.observation_space, raw), obs, atol=1e-6)
+            assert np.array_equal(b_env._termination(), done)
+            assert np.allclose(b_env._compute_reward(), rew, rtol=2e-5, atol=2e-5)
+        a_env.close(); b_env.close()

@@ -9,7 +9,7 @@ cp gpurun_out/${TAG}_pmc_hbm.json profiles/${TAG}_pmc_hbm.json
 cp gpurun_out/pmcsq_${TAG}.json profiles/${TAG}_pmc_sq.json
 cp gpurun_out/${TAG}_icub_bench.json profiles/${TAG}_icub_bench.json
 cp gpurun_out/${TAG}_hands_bench.json profiles/${TAG}_hands_bench.json
-for f in icub_steady.json icub_push_soak.json icub_kernel_trace_tail.txt icub_kernel_stats.csv; do [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f; done
+for f in icub_steady.json icub_push_soak.json icub_kernel_trace_tail.txt icub_kernel_stats.csv tail_probe.json; do [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f; done
 [ -f gpurun_out/pmc_icub_${TAG}.json ] && cp gpurun_out/pmc_icub_${TAG}.json profiles/${TAG}_pmc_icub.json
 [ -f gpurun_out/pmc_icub_hbm_${TAG}.json ] && cp gpurun_out/pmc_icub_hbm_${TAG}.json profiles/${TAG}_pmc_icub_hbm.json
 cp gpurun_out/${TAG}_bench2.json profiles/${TAG}_bench_2ranks_one_device.json

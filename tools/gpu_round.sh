@@ -22,6 +22,8 @@ echo "== PMC HBM / SQ (separate passes, no tracing domains)"
 bash tools/pmc.sh $TAG --steps 20 --warmup 3 2>&1 | grep -E "k_fast<7>|==" | head -6
 python tools/pmc_json.py $TAG 131072 2>&1 | tail -9
 bash tools/pmc_sq.sh $TAG --steps 20 --warmup 3 2>&1 | tail -30 | grep -E "valu_insts_per_wave|valu_active|wait_any" | head -8
+echo "== Panda: stationary step time around the machine-filling batch size"
+timeout 600 python tools/tail_probe.py 2>&1 | grep "^{" | tee gpurun_out/${TAG}_tail_probe.json | cut -c1-260
 echo "== iCub / hands benches"
 rm -f gpurun_out/${TAG}_icub_steady.json gpurun_out/${TAG}_icub_bench.json
 # (bench_icub.py: 1500 zero-action steps before the timed ones, see its --warm; "--warm 0" = the burst right after reset())
