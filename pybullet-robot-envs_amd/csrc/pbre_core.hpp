@@ -861,7 +861,93 @@ struct Core {
                 PBRE_UNROLL for (int c = 0; c < NC; c++) { R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero; }
             }
         }
+        // 16-lane rows (the Panda's complex envs, k_row_list / k_step): the solver loop is one wave's serial chain -- every row waits for the
+        // previous row's update of dv -- and that chain is what a stationary batch's step waits for.  But rows that share no
+        // unknown commute exactly: motor / limit / robot-table rows only touch the robot lanes of dv, object-table rows only the object
+        // lanes (J' and B of a row are exact zeros on the other body's lanes).  So the velocity vector is kept as two registers, dvr (robot
+        // lanes) and dvo (object lanes), both with the constant-one lane, and each phase of a sweep issues a robot-only and an object-only
+        // group of rows as two independent chains that the scheduler interleaves; robot-object rows run on the merged vector in between.
+        // Bullet's order M L | OTn ROn RTn | OTf ROf RTf becomes (M L || OTn) ROn (RTn || OTf) ROf RTf: the same arithmetic on the same
+        // values row by row, bit for bit (tests: the two orders compared on contact-rich states).
+#ifndef PBRE_TWO_CHAIN
+#define PBRE_TWO_CHAIN 1
+#endif
+        constexpr bool TWO_CHAIN = PBRE_TWO_CHAIN && SH::W == 16 && !SH::MREC;
+        const bool ot_all = (on_bits & ((1u << NC_OT) - 1u)) == ((1u << NC_OT) - 1u);
         if (solved) {
+        } else if (TWO_CHAIN && ot_all && !use_objv) {
+            const unsigned ro_bits = (on_bits >> NC_OT) & ((1u << NC_RO) - 1u), rt_bits = (on_bits >> (NC_OT + NC_RO)) & ((1u << NC_RT) - 1u);
+#ifdef PBRE_TWO_CHAIN_TRACE
+            PBRE_TWO_CHAIN_TRACE(ro_bits, rt_bits, has_limit);      // (host test builds: which row patterns took this path)
+#endif
+            F dvr = dv, dvo = dv;         // 1 on the constant-one lane, 0 elsewhere
+            auto mrow2 = [&](int j) {     // motor_x on dvr
+                FR nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs);
+                FR d = LR::med3(nt, nmlim - R.m_app, R.m_lim - R.m_app);
+                R.m_app = LR::setlane(R.m_app, j, R.m_app + d);
+                dvr = L::fma_lo(LR::bcast(d, j), R.Mi[j], dvr);
+            };
+            auto limit2 = [&](int j) {
+                FR t = LR::fma(R.l_j, L::lo(dvr), zeroR - R.l_rhs);
+                FR s = LR::med3(R.l_app - t, zeroR, llim);
+                FR d = s - R.l_app;
+                R.l_app = LR::setlane(R.l_app, j, s);
+                dvr = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dvr);
+            };
+            auto ot_n = [&](int c) { row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvo); };
+            auto ot_f = [&](int c) {
+                F lim = R.mu[c] * R.an[c];
+                frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvo);
+                frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvo);
+            };
+            // one OT normal row after every second motor row: two chains of about equal length in one basic block
+            auto phase_a = [&](bool rev) {
+                PBRE_UNROLL for (int k = 0; k < NJ; k++) {
+                    mrow2(rev ? NJ - 1 - k : k);
+                    if ((k & 1) && (k >> 1) < NC_OT) ot_n(k >> 1);
+                }
+                PBRE_UNROLL for (int c = (NJ >> 1); c < NC_OT; c++) ot_n(c);
+            };
+            auto coupled = [&](bool fric) {       // robot-object rows on the merged vector
+                F dvc = L::sel(obj_lane, dvo, dvr);
+                PBRE_UNROLL for (int c = NC_OT; c < NC_OT + NC_RO; c++) if ((on_bits >> c) & 1u) {
+                    if (!fric) row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvc);
+                    else {
+                        F lim = R.mu[c] * R.an[c];
+                        frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvc);
+                        frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvc);
+                    }
+                }
+                dvr = L::sel(obj_lane, zero, dvc); dvo = L::sel(robot, zero, dvc);
+            };
+            // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
+            auto rt_n = [&]() { PBRE_UNROLL for (int c = NC_OT + NC_RO; c < NC; c++) row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvr); };
+            auto rt_f = [&]() {
+                PBRE_UNROLL for (int c = NC_OT + NC_RO; c < NC; c++) {
+                    F lim = R.mu[c] * R.an[c];
+                    frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvr);
+                    frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvr);
+                }
+            };
+            auto tail = [&]() {           // normals and frictions of a sweep after its motor / limit / OT-normal rows
+                if (ro_bits) coupled(false);
+                if (rt_bits) { rt_n(); PBRE_UNROLL for (int c = 0; c < NC_OT; c++) ot_f(c); }
+                else { PBRE_UNROLL for (int c = 0; c < NC_OT; c++) ot_f(c); }
+                if (ro_bits) coupled(true);
+                if (rt_bits) rt_f();
+            };
+            for (int it = 0; it < P.iters; it += 2) {
+                phase_a(true);
+                if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
+                tail();
+                if (it + 1 >= P.iters) break;
+                if (has_limit) {          // odd sweep: limits first, then the motors in forward order
+                    PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
+                }
+                phase_a(false);
+                tail();
+            }
+            dv = L::sel(obj_lane, dvo, dvr);
         } else if (only_ot) {
             for (int it = 0; it < P.iters; it += 2) {
                 PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
