@@ -119,6 +119,15 @@ struct DevLanes {
         x += dpp<0x140>(x);    // row_mirror
         return x;
     }
+    // one stage of sum() (k = 0..3): the solver's two-chain sweeps issue the stages of two rows in turn (pbre_core.hpp)
+    static __device__ __forceinline__ F sum_step(F x, int k) {
+        switch (k) {
+            case 0: return x + dpp<0xB1>(x);
+            case 1: return x + dpp<0x4E>(x);
+            case 2: return x + dpp<0x141>(x);
+            default: return x + dpp<0x140>(x);
+        }
+    }
     static __device__ __forceinline__ F vmin(F x) {
         x = __builtin_fminf(x, dpp<0xB1>(x));
         x = __builtin_fminf(x, dpp<0x4E>(x));

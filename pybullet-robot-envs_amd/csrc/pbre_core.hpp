@@ -23,6 +23,8 @@
 //   get_extended_observation / _termination / _compute_reward   panda_push_gym_env.py:150-187, 301-331
 #pragma once
 #include <math.h>
+#include <type_traits>
+#include <utility>
 #include "pbre_tables.hpp"
 
 #ifndef PBRE_HD
@@ -310,6 +312,13 @@ struct Core {
     // mode bits
     enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8, M_INITD = 16,
            M_INNER = 32 };   // a non-final iteration of the apply_action loop (action_repeat > 1): termination test + counter, no outputs
+
+    // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in every iteration
+    // (what `#pragma unroll` only promises up to its size threshold)
+    template <class Fn, int... Ks>
+    static PBRE_HD void for_seq_(Fn&& f, std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
+    template <int N, class Fn>
+    static PBRE_HD void for_seq(Fn&& f) { for_seq_(f, std::make_integer_sequence<int, N>{}); }
 
     struct Rows {             // register-resident solver data
         FR Mi[NJ];            // row of M^-1 (lane k: Minv[k][j])
@@ -865,48 +874,92 @@ struct Core {
         // previous row's update of dv -- and that chain is what a stationary batch's step waits for.  But rows that share no
         // unknown commute exactly: motor / limit / robot-table rows only touch the robot lanes of dv, object-table rows only the object
         // lanes (J' and B of a row are exact zeros on the other body's lanes).  So the velocity vector is kept as two registers, dvr (robot
-        // lanes) and dvo (object lanes), both with the constant-one lane, and each phase of a sweep issues a robot-only and an object-only
-        // group of rows as two independent chains that the scheduler interleaves; robot-object rows run on the merged vector in between.
-        // Bullet's order M L | OTn ROn RTn | OTf ROf RTf becomes (M L || OTn) ROn (RTn || OTf) ROf RTf: the same arithmetic on the same
-        // values row by row, bit for bit (tests: the two orders compared on contact-rich states).
+        // lanes) and dvo (object lanes), both with the constant-one lane, and a sweep runs a robot-only and an object-only group of rows
+        // as two chains whose operations are issued in turn (`zip`: the compiler keeps the source order, a lone wave then issues one
+        // chain's operation while the other's is in flight); robot-object rows run on the merged vector in between.  Bullet's order
+        //     M L | OTn ROn RTn | OTf ROf RTf        becomes        (RTf' M || OTn) L ROn (RTn || OTf) ROf
+        // (RTf': the robot-table friction rows of the previous sweep; odd sweeps: L before M): the same arithmetic on the same values row
+        // by row, bit for bit (tests: the two orders compared on contact-rich states).
 #ifndef PBRE_TWO_CHAIN
 #define PBRE_TWO_CHAIN 1
 #endif
         constexpr bool TWO_CHAIN = PBRE_TWO_CHAIN && SH::W == 16 && !SH::MREC;
+        bool solved2 = false;
+        if constexpr (TWO_CHAIN) {
         const bool ot_all = (on_bits & ((1u << NC_OT) - 1u)) == ((1u << NC_OT) - 1u);
-        if (solved) {
-        } else if (TWO_CHAIN && ot_all && !use_objv) {
+        if (!solved && ot_all && !use_objv) {
+            solved2 = true;
             const unsigned ro_bits = (on_bits >> NC_OT) & ((1u << NC_RO) - 1u), rt_bits = (on_bits >> (NC_OT + NC_RO)) & ((1u << NC_RT) - 1u);
 #ifdef PBRE_TWO_CHAIN_TRACE
             PBRE_TWO_CHAIN_TRACE(ro_bits, rt_bits, has_limit);      // (host test builds: which row patterns took this path)
 #endif
             F dvr = dv, dvo = dv;         // 1 on the constant-one lane, 0 elsewhere
-            auto mrow2 = [&](int j) {     // motor_x on dvr
-                FR nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs);
-                FR d = LR::med3(nt, nmlim - R.m_app, R.m_lim - R.m_app);
-                R.m_app = LR::setlane(R.m_app, j, R.m_app + d);
-                dvr = L::fma_lo(LR::bcast(d, j), R.Mi[j], dvr);
+            // ---- a motor row (motor_x) in 4 stages on dvr
+            FR m_nt = zeroR, m_d = zeroR, m_lo = zeroR, m_hi = zeroR;
+            F m_bc = zero;
+            auto mstage = [&](auto jc, auto sc) {
+                constexpr int j = decltype(jc)::value, st = decltype(sc)::value;
+                if constexpr (st == 0) { m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs); m_lo = nmlim - R.m_app; m_hi = R.m_lim - R.m_app; }
+                else if constexpr (st == 1) m_d = LR::med3(m_nt, m_lo, m_hi);
+                else if constexpr (st == 2) { R.m_app = LR::setlane(R.m_app, j, R.m_app + m_d); m_bc = LR::bcast(m_d, j); }
+                else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
             };
             auto limit2 = [&](int j) {
                 FR t = LR::fma(R.l_j, L::lo(dvr), zeroR - R.l_rhs);
-                FR s = LR::med3(R.l_app - t, zeroR, llim);
-                FR d = s - R.l_app;
-                R.l_app = LR::setlane(R.l_app, j, s);
+                FR s_ = LR::med3(R.l_app - t, zeroR, llim);
+                FR d = s_ - R.l_app;
+                R.l_app = LR::setlane(R.l_app, j, s_);
                 dvr = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dvr);
             };
-            auto ot_n = [&](int c) { row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvo); };
-            auto ot_f = [&](int c) {
-                F lim = R.mu[c] * R.an[c];
-                frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvo);
-                frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvo);
-            };
-            // one OT normal row after every second motor row: two chains of about equal length in one basic block
-            auto phase_a = [&](bool rev) {
-                PBRE_UNROLL for (int k = 0; k < NJ; k++) {
-                    mrow2(rev ? NJ - 1 - k : k);
-                    if ((k & 1) && (k >> 1) < NC_OT) ot_n(k >> 1);
+            // ---- a contact row (row<> / frow<>) in 9 stages on one of the vectors; Fly: the row in flight
+            struct Fly { F p, s, lo, hi; };
+            Fly fr, fo;                   // robot chain / object chain
+            // ROW: index of the row's J' in the row store (B follows); FRIC: friction row (bound +-lim, skipped while the normal impulse is 0)
+            auto cstage = [&](Fly& f, F& vec, auto rowc, F& app, auto sc, auto fricc, F lim) {
+                constexpr int ROW = decltype(rowc)::value, st = decltype(sc)::value;
+                constexpr bool FRIC = decltype(fricc)::value;
+                if constexpr (st == 0) {
+                    if (FRIC) { f.lo = zero - lim; f.hi = lim; } else { f.lo = zero; f.hi = big; }
+                    f.p = R.rs.get(ROW) * vec;
                 }
-                PBRE_UNROLL for (int c = (NJ >> 1); c < NC_OT; c++) ot_n(c);
+                else if constexpr (st <= 4) f.p = L::sum_step(f.p, st - 1);
+                else if constexpr (st == 5) f.s = app - f.p;
+                else if constexpr (st == 6) { f.s = L::med3(f.s, f.lo, f.hi); if (FRIC) f.s = L::sel(L::gt(f.hi, zero), f.s, app); }
+                else if constexpr (st == 7) { f.p = f.s - app; app = f.s; }
+                else vec = L::fma(f.p, R.rs.get(ROW + 1), vec);
+            };
+            // normal row of contact C / friction row D of contact C, stage ST
+            auto nstage = [&](Fly& f, F& vec, auto cc, auto sc) {
+                constexpr int C = decltype(cc)::value;
+                cstage(f, vec, std::integral_constant<int, 6 * C>{}, R.an[C], sc, std::false_type{}, zero);
+            };
+            auto fstage = [&](Fly& f, F& vec, auto cc, auto dc, auto sc) {
+                constexpr int C = decltype(cc)::value, D = decltype(dc)::value;
+                F lim = zero;
+                if constexpr (decltype(sc)::value == 0) lim = R.mu[C] * R.an[C];
+                cstage(f, vec, std::integral_constant<int, 6 * C + 2 + 2 * D>{}, D == 0 ? R.a1[C] : R.a2[C], sc, std::true_type{}, lim);
+            };
+            constexpr int NRT0 = NC_OT + NC_RO;
+            // (RTf' M || OTn): robot stream = [2 NC_RT friction rows of the previous sweep] + NJ motor rows, object stream = NC_OT normal rows
+            auto phase_a = [&](auto rev_c, auto e_c) {
+                constexpr bool REV = decltype(rev_c)::value, WITH_E = decltype(e_c)::value;
+                constexpr int NE = WITH_E ? 2 * NC_RT * 9 : 0, NR = NE + 4 * NJ, NO = 9 * NC_OT, NZ = NR > NO ? NR : NO;
+                for_seq<NZ>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < NE) fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{});
+                    else if constexpr (k < NR) { constexpr int r = (k - NE) / 4; mstage(std::integral_constant<int, (REV ? NJ - 1 - r : r)>{}, std::integral_constant<int, (k - NE) % 4>{}); }
+                    if constexpr (k < NO) nstage(fo, dvo, std::integral_constant<int, k / 9>{}, std::integral_constant<int, k % 9>{});
+                });
+            };
+            // (RTn || OTf)
+            auto phase_c = [&](auto rt_c) {
+                constexpr bool RT = decltype(rt_c)::value;
+                constexpr int NR = RT ? 9 * NC_RT : 0, NO = 9 * 2 * NC_OT;
+                for_seq<NO>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k < NR) nstage(fr, dvr, std::integral_constant<int, NRT0 + k / 9>{}, std::integral_constant<int, k % 9>{});
+                    fstage(fo, dvo, std::integral_constant<int, (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{});
+                });
             };
             auto coupled = [&](bool fric) {       // robot-object rows on the merged vector
                 F dvc = L::sel(obj_lane, dvo, dvr);
@@ -921,33 +974,30 @@ struct Core {
                 dvr = L::sel(obj_lane, zero, dvc); dvo = L::sel(robot, zero, dvc);
             };
             // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
-            auto rt_n = [&]() { PBRE_UNROLL for (int c = NC_OT + NC_RO; c < NC; c++) row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvr); };
-            auto rt_f = [&]() {
-                PBRE_UNROLL for (int c = NC_OT + NC_RO; c < NC; c++) {
-                    F lim = R.mu[c] * R.an[c];
-                    frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvr);
-                    frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvr);
-                }
-            };
-            auto tail = [&]() {           // normals and frictions of a sweep after its motor / limit / OT-normal rows
+            auto rt_f = [&]() { for_seq<2 * NC_RT * 9>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{}); }); };
+            const bool e_zip = rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows
+            auto mid = [&]() {            // the rest of a sweep after its motor / limit / OT-normal rows
                 if (ro_bits) coupled(false);
-                if (rt_bits) { rt_n(); PBRE_UNROLL for (int c = 0; c < NC_OT; c++) ot_f(c); }
-                else { PBRE_UNROLL for (int c = 0; c < NC_OT; c++) ot_f(c); }
+                if (rt_bits) phase_c(std::true_type{}); else phase_c(std::false_type{});
                 if (ro_bits) coupled(true);
-                if (rt_bits) rt_f();
+                if (rt_bits && !e_zip) rt_f();
             };
             for (int it = 0; it < P.iters; it += 2) {
-                phase_a(true);
+                if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
                 if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
-                tail();
+                mid();
                 if (it + 1 >= P.iters) break;
                 if (has_limit) {          // odd sweep: limits first, then the motors in forward order
                     PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
                 }
-                phase_a(false);
-                tail();
+                if (e_zip) phase_a(std::false_type{}, std::true_type{}); else phase_a(std::false_type{}, std::false_type{});
+                mid();
             }
+            if (e_zip) rt_f();            // the last sweep's
             dv = L::sel(obj_lane, dvo, dvr);
+        }
+        }
+        if (solved || solved2) {
         } else if (only_ot) {
             for (int it = 0; it < P.iters; it += 2) {
                 PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);

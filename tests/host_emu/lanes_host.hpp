@@ -100,6 +100,14 @@ struct HostLanesT {
         return x;
     }
     static F sum_obj(const F& a) { return sum(a); }
+    static F sum_step(const F& x, int k) {      // one stage of the 16-lane butterfly of sum()
+        F y;
+        for (int i = 0; i < W; i++) {
+            const int o = k == 0 ? (i ^ 1) : (k == 1 ? (i ^ 2) : (k == 2 ? ((i & ~7) | (7 - (i & 7))) : ((i & ~15) | (15 - (i & 15)))));
+            y.v[i] = x.v[i] + x.v[o];
+        }
+        return y;
+    }
     static F vmin(const F& a) { float m = a.v[0]; for (int i = 1; i < W; i++) m = std::fmin(m, a.v[i]); return F(m); }
 };
 using HostLanes = HostLanesT<16>;

@@ -191,3 +191,39 @@ def test_world_env_object_names(emu_lib):
 @pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
 def test_reset_snapshot(panda, emu_lib, flags):
     parity.check_reset_snapshot(_capi.Engine, emu_lib, panda["table"], n=5, flags=flags)
+
+
+def test_two_chain_sweeps_are_bit_identical(panda, emu_lib):
+    """Core::step for 16-lane rows runs robot-only and object-only rows of a sweep as two zipped chains (pbre_core.hpp, PBRE_TWO_CHAIN);
+    rows that share no unknown commute exactly, so every state and output must equal, bit for bit, what Bullet's sequential order
+    gives (the same library built with -DPBRE_TWO_CHAIN=0) -- on contact-rich states: robot-table, robot-object contacts, joints at
+    their limits, refreshed every third step."""
+    import os
+    import subprocess
+    import orc
+    from pybullet_robot_envs import _capi
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_emu")
+    subprocess.check_call(["make", "-s", "-C", here, "build/libpbre_emu_seq.so"])
+    seq_lib = _capi.load(os.path.join(here, "build", "libpbre_emu_seq.so"))
+    n = 24
+    engs = [_capi.Engine(panda["table"], task=1, num_envs=n, lib=l, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, flags=_capi.F_FORCE_GENERAL)
+            for l in (emu_lib, seq_lib)]
+    ora = orc.Oracle(panda["table"], task=1)
+    for e in engs:
+        e.reset()
+    base = engs[0].get_state()[0].astype(np.float64)
+    rng = np.random.default_rng(3)
+    for t in range(9):
+        if t % 3 == 0:
+            st = parity.contact_states(ora, panda, base, rng, n_table=8, n_obj=16).astype(np.float32)
+            st[::5, 6] = 2.89          # a joint at its limit
+            for e in engs:
+                e.set_state(st)
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        outs = [e.step(a) for e in engs]
+        s0, s1 = engs[0].get_state(), engs[1].get_state()
+        assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)), (t, np.abs(s0 - s1).max())
+        for x, y in zip(outs[0], outs[1]):
+            assert np.array_equal(np.asarray(x, np.float32).view(np.uint32), np.asarray(y, np.float32).view(np.uint32))
+    for e in engs:
+        e.close()

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--sizes", default="131072,130048,129024,126976,122880,98304,65536")
     ap.add_argument("--preroll", type=int, default=1000)
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--iters", type=int, default=0, help="solver iterations during the timed stationary steps only (0: unchanged, 150): what the solver loops cost")
     a = ap.parse_args()
     import torch
     from pybullet_robot_envs import _capi
@@ -44,6 +45,9 @@ def main():
             # i.i.d. actions resident in HBM, one slice per timed step (a short recycled pool biases every env's random walk and drives
             # the joints into their limits within a few hundred steps: bench.py)
             ns = a.steps if cnt else 20
+            if cnt and a.iters:
+                eng.set_physics(solver_iters=a.iters)
+                res["timed_solver_iters"] = a.iters
             pool = torch.rand((ns + 5, n, eng.act_dim), device=dev, generator=gen) * 2 - 1
             for k in range(5):
                 eng.step_device(pool[k].data_ptr(), out.data_ptr(), side.cuda_stream)
