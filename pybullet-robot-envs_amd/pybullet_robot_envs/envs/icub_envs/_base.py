@@ -57,6 +57,7 @@ class ICubTaskBase(PandaTaskBase):
         if c.engine is not None:
             c.engine.close()
         r = self._robot
+        r._own_engine = False            # the engine of this client is the task env's from now on (iCubEnv._robot_level)
         dofs = r.controlled_dofs()
         home = r.sim_home()
         ori = 1 if self._control_orientation else 0

@@ -73,6 +73,7 @@ class PandaTaskBase(Env):
                          obj_pose_rnd_std=float(self._obj_pose_rnd_std), tg_pose_rnd_std=float(self._tg_pose_rnd_std),
                          target_dist_min=float(self._target_dist_min), h_table=float(self._world.get_table_height()),
                          flags=_capi.F_AUTO_RESET if self._auto_reset else 0, use_ik=1 if self._use_IK else 0)
+        self._robot._own_engine = False      # the engine of this client is the task env's from now on (pandaEnv._robot_level)
         c.engine = _capi.make_engine(self._robot.robot_table, devices=c.devices, task=self._TASK, num_envs=c.num_envs, lib=c.lib,
                                       phys=self._world.object_physics(), **overrides)
         rws = self._robot.get_workspace()
