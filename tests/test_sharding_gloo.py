@@ -125,6 +125,61 @@ def test_two_rank_gather_icub_hands(emu_lib):
         assert np.array_equal(res[k + 1], np.concatenate([o, r[:, None], d[:, None]], 1))
 
 
+def _icub_worker(rank, world, port, total, steps, q):
+    sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("PBRE_ICUB_LANE", "1")
+    import torch.distributed as dist
+    import parity
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_table
+    from pybullet_robot_envs.sharding import ShardedEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _capi.load(os.path.join(ROOT, "tests", "host_emu", "build", "libpbre_emu.so"))
+    tbl, _, info = icub_table("l")
+    se = ShardedEngine(tbl, total, lib=lib, device_id=0, task=_capi.TASK_PUSH, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+                       **parity.icub_overrides(info, "l", 1, 0, 1))
+    acts = np.random.default_rng(13).uniform(-1, 1, (steps, total, 3)).astype(np.float32)
+    res = [se.reset()]
+    for k in range(steps):
+        r = se.step(acts[k, se.env_id_base:se.env_id_base + se.n_local])
+        res.append(None if r is None else np.concatenate([r[0], r[1][:, None], r[2][:, None]], 1))
+    dist.barrier()
+    if rank == 0:
+        q.put(res)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_icub_push(emu_lib):
+    """The iCub push env (IK control; the lane-per-env pipeline's host build) split over two ranks equals the single-process batch bit for
+    bit: per-env object / target poses are drawn from streams keyed by the global env id."""
+    import torch.multiprocessing as mp
+    import parity
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_table
+    total, steps, world = 4, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_icub_worker, args=(r, world, port, total, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tbl, _, info = icub_table("l")
+    eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=total, lib=emu_lib, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+                       **parity.icub_overrides(info, "l", 1, 0, 1))
+    acts = np.random.default_rng(13).uniform(-1, 1, (steps, total, 3)).astype(np.float32)
+    assert np.array_equal(res[0], eng.reset())
+    for k in range(steps):
+        o, r, d = eng.step(acts[k])
+        assert np.array_equal(res[k + 1], np.concatenate([o, r[:, None], d[:, None]], 1))
+
+
 def test_shard_range():
     from pybullet_robot_envs.sharding import shard_range
     assert shard_range(131072, 3, 8) == (49152, 16384)
