@@ -126,7 +126,23 @@ class WorldEnv:
         return obs, observation_lim
 
     def check_contact(self, body_id, obj_id=None):
-        raise NotImplementedError("contact queries are not exposed by the batched engine")
+        """Is the object in contact with `body_id` (world_env.py:128-134: `len(p.getContactPoints(obj_id, body_id)) > 0`)?  `body_id` is
+        this world's `table_id` or the robot's `robot_id`.  A bool for a single env, an [N] bool array for a batch.  A query on the
+        downloaded state with the step's own detection rule (distance below the contact margin): model/contacts.py."""
+        from pybullet_robot_envs.model import contacts
+        c = self._client
+        eng = c.require_engine()
+        robot = c.robot
+        if body_id == self.table_id:
+            bit = contacts.OBJECT_TABLE
+        elif robot is not None and body_id == robot.robot_id:
+            bit = contacts.ROBOT_OBJECT
+        else:
+            raise ValueError("check_contact: body_id %r is neither this world's table_id (%d) nor the robot's robot_id" % (body_id, self.table_id))
+        no_obj = bool(eng.cfg.flags & 1)
+        f = contacts.contact_flags(robot.robot_table, eng.get_state(), eng.ndof, eng.get_physics(), no_obj)
+        hit = (f & bit) != 0
+        return bool(hit[0]) if hit.shape[0] == 1 else hit
 
     def debug_gui(self):
         pass

@@ -91,3 +91,36 @@ def test_apply_action_is_the_action_half_of_step(emu_lib):
             assert np.array_equal(b_env._termination(), done)
             assert np.allclose(b_env._compute_reward(), rew, rtol=2e-5, atol=2e-5)
         a_env.close(); b_env.close()
+
+
+def test_world_check_contact_matches_the_oracle_contact_list(panda, emu_lib):
+    """WorldEnv.check_contact(body_id) (reference world_env.py:128-134) on contact-rich states: object-table and robot-object contact
+    per env as in the contact list the oracle's stepSimulation builds for the same state (types 0 / 1 of orc_step_info)."""
+    import orc
+    import parity
+    n = 24
+    env = pandaPushGymEnv(num_envs=n, _lib=emu_lib)
+    env.reset()
+    ora = orc.Oracle(panda["table"], task=1)
+    eng = env._engine
+    base = eng.get_state()[0].astype(np.float64)
+    rng = np.random.default_rng(5)
+    st = parity.contact_states(ora, panda, base, rng, n_table=8, n_obj=16).astype(np.float32)
+    st[3, 11] += 0.3                     # one object in the air: no object-table contact
+    eng.set_state(st)
+    tab = env._world.check_contact(env._world.table_id)
+    rob = env._world.check_contact(env._robot.robot_id)
+    assert tab.shape == (n,) and rob.shape == (n,)
+    home = np.array([0.0, -0.54, 0.0, -2.6, -0.30, 2.0, 1.0, 0.02, 0.02])
+    exp_tab, exp_rob = np.zeros(n, bool), np.zeros(n, bool)
+    for e in range(n):
+        _, info = ora.sim_step(st[e].astype(np.float64), home, np.full(9, 0.2), np.ones(9))
+        types = [info.type[c] for c in range(info.ncontacts)]
+        exp_tab[e], exp_rob[e] = 0 in types, 1 in types
+    assert not tab[3] and tab[:8].sum() == 7 and rob.sum() >= 8 and exp_tab.any() and exp_rob.any()
+    assert np.array_equal(tab, exp_tab), (tab, exp_tab)
+    assert np.array_equal(rob, exp_rob), (rob, exp_rob)
+    single = pandaPushGymEnv(num_envs=1, _lib=emu_lib)
+    single.reset()
+    assert single._world.check_contact(single._world.table_id) is True and single._world.check_contact(single._robot.robot_id) is False
+    env.close(); single.close()
