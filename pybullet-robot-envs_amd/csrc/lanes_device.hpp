@@ -95,7 +95,8 @@ struct DevLanes {
     // LDS crossbar.  k is a constant wherever the solver calls this (unrolled row loops), so the switch folds to one instruction.
     template <int K>
     static __device__ __forceinline__ F row_bc(F x) {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
+        // (old = the source itself: row_newbcast writes every lane, so no register has to be zeroed first)
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x150 + K, 0xF, 0xF, false));
     }
     static __device__ __forceinline__ F bcast16(F a, int k) {
         switch (k & 15) {

@@ -915,9 +915,13 @@ struct Core {
             struct Fly { F p, s, lo, hi; };
             Fly fr, fo;                   // robot chain / object chain
             // ROW: index of the row's J' in the row store (B follows); FRIC: friction row (bound +-lim, skipped while the normal impulse is 0)
-            auto cstage = [&](Fly& f, F& vec, auto rowc, F& app, auto sc, auto fricc, F lim) {
-                constexpr int ROW = decltype(rowc)::value, st = decltype(sc)::value;
-                constexpr bool FRIC = decltype(fricc)::value;
+            // OBJ: an object-table row.  Its J' is non-zero on lanes LC..L1 only, all in the upper half of the 16-lane row (LC >= 8), so
+            // three butterfly stages already leave the whole sum on those lanes (the fourth would add the lower half's exact zero); the
+            // lower lanes then carry 0 through the row -- their impulse stays 0 and B is 0 there -- which costs one stage less: NSO stages
+            auto cstage = [&](Fly& f, F& vec, auto rowc, F& app, auto sc, auto fricc, auto objc, F lim) {
+                constexpr int ROW = decltype(rowc)::value, st0 = decltype(sc)::value;
+                constexpr bool FRIC = decltype(fricc)::value, OBJ = decltype(objc)::value;
+                constexpr int st = (OBJ && st0 >= 4) ? st0 + 1 : st0;         // OBJ rows skip stage 4 (row_mirror)
                 if constexpr (st == 0) {
                     if (FRIC) { f.lo = zero - lim; f.hi = lim; } else { f.lo = zero; f.hi = big; }
                     f.p = R.rs.get(ROW) * vec;
@@ -928,37 +932,39 @@ struct Core {
                 else if constexpr (st == 7) { f.p = f.s - app; app = f.s; }
                 else vec = L::fma(f.p, R.rs.get(ROW + 1), vec);
             };
+            static_assert(LC >= 8 && L1 < 16, "object lanes in the upper half of the row");
+            constexpr int NSR = 9, NSO = 8;       // stages of a contact row on the robot chain / of an object-table row
             // normal row of contact C / friction row D of contact C, stage ST
             auto nstage = [&](Fly& f, F& vec, auto cc, auto sc) {
                 constexpr int C = decltype(cc)::value;
-                cstage(f, vec, std::integral_constant<int, 6 * C>{}, R.an[C], sc, std::false_type{}, zero);
+                cstage(f, vec, std::integral_constant<int, 6 * C>{}, R.an[C], sc, std::false_type{}, std::integral_constant<bool, (C < NC_OT)>{}, zero);
             };
             auto fstage = [&](Fly& f, F& vec, auto cc, auto dc, auto sc) {
                 constexpr int C = decltype(cc)::value, D = decltype(dc)::value;
                 F lim = zero;
                 if constexpr (decltype(sc)::value == 0) lim = R.mu[C] * R.an[C];
-                cstage(f, vec, std::integral_constant<int, 6 * C + 2 + 2 * D>{}, D == 0 ? R.a1[C] : R.a2[C], sc, std::true_type{}, lim);
+                cstage(f, vec, std::integral_constant<int, 6 * C + 2 + 2 * D>{}, D == 0 ? R.a1[C] : R.a2[C], sc, std::true_type{}, std::integral_constant<bool, (C < NC_OT)>{}, lim);
             };
             constexpr int NRT0 = NC_OT + NC_RO;
             // (RTf' M || OTn): robot stream = [2 NC_RT friction rows of the previous sweep] + NJ motor rows, object stream = NC_OT normal rows
             auto phase_a = [&](auto rev_c, auto e_c) {
                 constexpr bool REV = decltype(rev_c)::value, WITH_E = decltype(e_c)::value;
-                constexpr int NE = WITH_E ? 2 * NC_RT * 9 : 0, NR = NE + 4 * NJ, NO = 9 * NC_OT, NZ = NR > NO ? NR : NO;
+                constexpr int NE = WITH_E ? 2 * NC_RT * NSR : 0, NR = NE + 4 * NJ, NO = NSO * NC_OT, NZ = NR > NO ? NR : NO;
                 for_seq<NZ>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    if constexpr (k < NE) fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{});
+                    if constexpr (k < NE) fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{});
                     else if constexpr (k < NR) { constexpr int r = (k - NE) / 4; mstage(std::integral_constant<int, (REV ? NJ - 1 - r : r)>{}, std::integral_constant<int, (k - NE) % 4>{}); }
-                    if constexpr (k < NO) nstage(fo, dvo, std::integral_constant<int, k / 9>{}, std::integral_constant<int, k % 9>{});
+                    if constexpr (k < NO) nstage(fo, dvo, std::integral_constant<int, k / NSO>{}, std::integral_constant<int, k % NSO>{});
                 });
             };
             // (RTn || OTf)
             auto phase_c = [&](auto rt_c) {
                 constexpr bool RT = decltype(rt_c)::value;
-                constexpr int NR = RT ? 9 * NC_RT : 0, NO = 9 * 2 * NC_OT;
-                for_seq<NO>([&](auto kc) {
+                constexpr int NR = RT ? NSR * NC_RT : 0, NO = NSO * 2 * NC_OT, NZ = NR > NO ? NR : NO;
+                for_seq<NZ>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    if constexpr (k < NR) nstage(fr, dvr, std::integral_constant<int, NRT0 + k / 9>{}, std::integral_constant<int, k % 9>{});
-                    fstage(fo, dvo, std::integral_constant<int, (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{});
+                    if constexpr (k < NR) nstage(fr, dvr, std::integral_constant<int, NRT0 + k / NSR>{}, std::integral_constant<int, k % NSR>{});
+                    if constexpr (k < NO) fstage(fo, dvo, std::integral_constant<int, (k / NSO) / 2>{}, std::integral_constant<int, (k / NSO) % 2>{}, std::integral_constant<int, k % NSO>{});
                 });
             };
             auto coupled = [&](bool fric) {       // robot-object rows on the merged vector
@@ -974,7 +980,7 @@ struct Core {
                 dvr = L::sel(obj_lane, zero, dvc); dvo = L::sel(robot, zero, dvc);
             };
             // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
-            auto rt_f = [&]() { for_seq<2 * NC_RT * 9>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / 9) / 2>{}, std::integral_constant<int, (k / 9) % 2>{}, std::integral_constant<int, k % 9>{}); }); };
+            auto rt_f = [&]() { for_seq<2 * NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{}); }); };
             const bool e_zip = rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows
             auto mid = [&]() {            // the rest of a sweep after its motor / limit / OT-normal rows
                 if (ro_bits) coupled(false);
