@@ -16,14 +16,6 @@ for r in rows:
         name = "k_fast<7>" if "k_fast<7>" in k else ("k_fast_rc<7>" if "k_fast_rc<7>" in k else "k_row_list<7>")
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
-# the row kernel runs empty while no env is complex (fresh legs, most of the pre-roll): its figures are taken over the quarter of its
-# launches with the most VALU instructions (the stationary steps); its grid has spare blocks that exit at once, so per-wave averages
-# are of no use -- what counts is the total per launch (divide by the complex envs / 4 of the bench line for a working wave's share)
-if "k_row_list<7>" in agg and agg["k_row_list<7>"].get("SQ_INSTS_VALU"):
-    d = agg["k_row_list<7>"]
-    order = sorted(range(len(d["SQ_INSTS_VALU"])), key=lambda i: -d["SQ_INSTS_VALU"][i])[:max(1, len(d["SQ_INSTS_VALU"]) // 4)]
-    out["k_row_list<7> (stationary launches)"] = {c: sum(v[i] for i in order if i < len(v)) / len(order) for c, v in d.items()}
-    out["k_row_list<7> (stationary launches)"]["launches"] = len(order)
 for k, d in out.items():
     if d.get("SQ_WAVE_CYCLES"):
         d["valu_active_over_wave_cycles"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"]
