@@ -357,3 +357,9 @@ def test_force_limited_motors(hip_lib, panda):
     eng = parity.check_panda_force_limited(_capi.Engine, hip_lib, panda["table"], n=70)
     info = eng.kernel_info()
     assert info[2] == 1 and info[3] == 70, "the last step (from the unlimited arm's settled state) belongs to the lane-per-env kernel"
+
+
+def test_world_check_contact(panda, hip_lib):
+    """WorldEnv.check_contact on states downloaded from the GPU engine (host-side query, model/contacts.py) against the oracle's contact list"""
+    from test_vec_env import check_world_contacts
+    check_world_contacts(panda, hip_lib)

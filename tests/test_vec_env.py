@@ -94,12 +94,16 @@ def test_apply_action_is_the_action_half_of_step(emu_lib):
 
 
 def test_world_check_contact_matches_the_oracle_contact_list(panda, emu_lib):
+    check_world_contacts(panda, emu_lib)
+
+
+def check_world_contacts(panda, lib):
     """WorldEnv.check_contact(body_id) (reference world_env.py:128-134) on contact-rich states: object-table and robot-object contact
     per env as in the contact list the oracle's stepSimulation builds for the same state (types 0 / 1 of orc_step_info)."""
     import orc
     import parity
     n = 24
-    env = pandaPushGymEnv(num_envs=n, _lib=emu_lib)
+    env = pandaPushGymEnv(num_envs=n, _lib=lib)
     env.reset()
     ora = orc.Oracle(panda["table"], task=1)
     eng = env._engine
@@ -120,7 +124,7 @@ def test_world_check_contact_matches_the_oracle_contact_list(panda, emu_lib):
     assert not tab[3] and tab[:8].sum() == 7 and rob.sum() >= 8 and exp_tab.any() and exp_rob.any()
     assert np.array_equal(tab, exp_tab), (tab, exp_tab)
     assert np.array_equal(rob, exp_rob), (rob, exp_rob)
-    single = pandaPushGymEnv(num_envs=1, _lib=emu_lib)
+    single = pandaPushGymEnv(num_envs=1, _lib=lib)
     single.reset()
     assert single._world.check_contact(single._world.table_id) is True and single._world.check_contact(single._robot.robot_id) is False
     env.close(); single.close()
