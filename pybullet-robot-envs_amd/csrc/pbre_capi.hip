@@ -514,9 +514,15 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(c->sp.create(0, false));
     c->side = c->sp.side;
     for (auto& ev : c->ev) CK(hipEventCreate(&ev));
-    CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    for (auto& pr : c->ev_k) for (auto& ev : pr) CK(hipEventCreate(&ev));
+    {   // fork / join of the two step kernels: both ends are on this GPU, so the events need no system-scope fence (cache write-back
+        // and invalidate at every marker); PBRE_EVENT_FENCE=1 keeps it (A/B)
+        const char* ef = getenv("PBRE_EVENT_FENCE");
+        const unsigned fl = hipEventDisableTiming | ((ef && ef[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+        CK(hipEventCreateWithFlags(&c->ev_fork, fl));
+        CK(hipEventCreateWithFlags(&c->ev_join, fl));
+    }
+    // (timing-only events around the dominant kernel: no system-scope fence at the markers)
+    for (auto& pr : c->ev_k) for (auto& ev : pr) CK(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     CK(hipMalloc(&c->dT, sizeof(Tables)));
     CK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
     CK(alloc_buf(c->main, c->npad));

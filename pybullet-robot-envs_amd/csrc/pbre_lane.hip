@@ -506,10 +506,12 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
             if ((e = sp.create(phi, true)) != hipSuccess) return e;
             side = sp.side;
-            if ((e = hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&ev_join, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&ev_dyn, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&ev_ik, hipEventDisableTiming)) != hipSuccess) return e;
+            const char* ef = getenv("PBRE_EVENT_FENCE");      // (see pbre_capi.hip: device-only dependencies need no system-scope fence)
+            const unsigned efl = hipEventDisableTiming | ((ef && ef[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+            if ((e = hipEventCreateWithFlags(&ev_fork, efl)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_join, efl)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_dyn, efl)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev_ik, efl)) != hipSuccess) return e;
         }
         {
             // element stride: a multiple of 16 floats (kw_quad's 64-byte segments stay aligned), but never a power of two -- with 32768 envs

@@ -132,7 +132,8 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     CK(hipSetDevice(w->device));
     CK(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     for (auto& ev : w->ev) CK(hipEventCreate(&ev));
-    for (auto& pr : w->ev_k) for (auto& ev : pr) CK(hipEventCreate(&ev));
+    // (timing-only events around the dominant kernel: no system-scope fence at the markers)
+    for (auto& pr : w->ev_k) for (auto& ev : pr) CK(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
     const size_t n = (size_t)w->n, sf = (size_t)w->sf, nj = (size_t)w->tgs;
     CK(w->upload_tables());
     CK(hipMalloc(&w->state, n * sf * sizeof(float)));
