@@ -59,7 +59,11 @@ enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE co
        /* Envs with robot contacts / joints at a limit ("complex") are stepped by one of two kernels; the engine picks by
         * their number (row kernel while they are few: lowest latency; lane-per-env k_fast_rc when many: highest throughput).
         * These two flags pin the choice (validation, A/B): */
-       PBRE_F_COMPLEX_ROWS = 8, PBRE_F_COMPLEX_LANES = 16 };
+       PBRE_F_COMPLEX_ROWS = 8, PBRE_F_COMPLEX_LANES = 16,
+       /* Panda, envs without robot contact: the 9 joint-motor rows (p.setJointMotorControl2, panda_env.py:305-310) are a linear
+        * iteration there and their `solver_iters` sweeps are evaluated in closed form (a matrix power); this flag runs
+        * them as Bullet does, row by row (validation, A/B) */
+       PBRE_F_SEQ_MOTORS = 32 };
 
 typedef struct pbre_ctx pbre_ctx;
 

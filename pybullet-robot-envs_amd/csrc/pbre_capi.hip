@@ -25,7 +25,6 @@
 #define PBRE_ANY(x) (__any((int)(x)) != 0)
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
-#define PBRE_PARK_STRIDE 64          // Fast::step parks the solver start values in wave-private LDS laid out [k][lane]
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -83,7 +82,6 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 }
 
 // Simple envs: every env of the batch in natural order, lanes of complex envs idle.  Block = one wave.
-// LDS (wave-private, no barriers): the solver start values of the clamp-free rows' fall-back (Fast::step `park`, [k][lane]).
 // (Staging the wave's 64 output rows through LDS and streaming them out as one contiguous block with coalesced 256-byte stores was
 // measured too -- profiles/r02_pmc_hbm.json: WRITE_SIZE 62.1 MB against 63.3 MB with each lane writing its own 140-byte row, and the
 // same step time -- the L2 already merges the lanes' 4-byte stores into full lines; what WRITE_SIZE carries beyond the records and
@@ -93,13 +91,12 @@ __global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                                int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
-    __shared__ float lds_park[FastD::PARK * FTPB];
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                               (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, lds_park + threadIdx.x);
+                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
     publish_class(env, c, cls, next_list, next_count, cap);
 }
 
@@ -362,6 +359,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         c->k_steps++;
         return hipGetLastError();
     }
+    flags |= c->cfg.flags & PBRE_F_SEQ_MOTORS;
     const int cur = b.cur, nxt = cur ^ 1;
     const int cc = b.ccur, cn = (cc + 1) % 3, cz = (cc + 2) % 3;      // counters: current, next (zero on entry), the one after
     const int blocks = (n + FTPB - 1) / FTPB;

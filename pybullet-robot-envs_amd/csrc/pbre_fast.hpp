@@ -245,16 +245,60 @@ struct Fast {
     //   1  complex: robot contacts and/or active joint-limit rows -> step_t<true> (adds dense 9-DoF contact rows and the
     //               limit rows; needs the whole register file, launched only over the list of complex envs)
     // Both variants return the class of the state they produced.
-    // park: PARK floats of scratch per env with stride PBRE_PARK_STRIDE (the device passes wave-private LDS laid out [k][lane], the
-    // host build a local array): the solver's start values while the clamp-free motor rows are tried (see step_t)
-    static constexpr int PARK = ND + 6;
-#ifndef PBRE_PARK_STRIDE
-#define PBRE_PARK_STRIDE 1
-#endif
+    // Closed form of `ds` double sweeps (rows ND-1..0, then 0..ND-1) of the clamp-free motor rows on the error e = w - t (see step_t).
+    // A: M^-1 (triangle), dinv[j] = 1 / A_jj.  A row j is e <- e - (e_j / A_jj) A_j, which zeroes e_j: the second visit of row 0 in a
+    // double sweep is the identity, and after the first double sweep e_{ND-1} = 0 for good, so the remaining ds - 1 double sweeps act on
+    // the first NH = ND - 1 components through one NH x NH matrix H (built column by column from the same row operations), and
+    // H^(ds-1) e is evaluated by binary powering: ~4.2 k FMAs for 150 sweeps of 9 rows instead of ~15 k dependent ones.
+    static constexpr int NH = ND - 1;
+    static PBRE_HD void motor_closed(const float* A, const float* dinv, float* e, int ds) {
+        auto rowop = [&](float* v, int j) {
+            const float s = v[j] * dinv[j];
+            PBRE_UNROLL for (int k = 0; k < ND; k++) if (k != j) v[k] = fmaf(-s, A[sym(k, j)], v[k]);
+            v[j] = 0.f;
+        };
+        PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) rowop(e, j);
+        PBRE_UNROLL for (int j = 1; j < ND; j++) rowop(e, j);
+        int r = ds - 1;
+        if (r <= 0) return;
+        float H[NH][NH], G[NH][NH];
+        PBRE_UNROLL for (int c = 0; c < NH; c++) {
+            float v[ND];
+            PBRE_UNROLL for (int k = 0; k < ND; k++) v[k] = k == c ? 1.f : 0.f;
+            PBRE_UNROLL for (int j = NH - 1; j >= 0; j--) if (j <= c) rowop(v, j);     // (rows j > c find v_j = 0: identity)
+            PBRE_UNROLL for (int j = 1; j < ND; j++) rowop(v, j);
+            PBRE_UNROLL for (int k = 0; k < NH; k++) H[k][c] = v[k];
+        }
+        auto apply = [&](const float (*X)[NH]) {
+            float y[NH];
+            PBRE_UNROLL for (int i = 0; i < NH; i++) {
+                float a = 0.f;
+                PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(X[i][k], e[k], a);
+                y[i] = a;
+            }
+            PBRE_UNROLL for (int i = 0; i < NH; i++) e[i] = y[i];
+        };
+        auto square = [&](const float (*X)[NH], float (*Y)[NH]) {
+            PBRE_UNROLL for (int i = 0; i < NH; i++)
+                PBRE_UNROLL for (int c = 0; c < NH; c++) {
+                    float a = 0.f;
+                    PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(X[i][k], X[k][c], a);
+                    Y[i][c] = a;
+                }
+        };
+        for (;;) {
+            if (r & 1) apply(H);
+            r >>= 1; if (!r) break;
+            square(H, G);
+            if (r & 1) apply(G);
+            r >>= 1; if (!r) break;
+            square(G, H);
+        }
+    }
     static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                            unsigned long long env_id, const float* tgt, float* park) {
+                            unsigned long long env_id, const float* tgt) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt, park);
+        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
     // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (`if self._termination():
     // break`, panda_push_gym_env.py:239-240; flag X[14]): no simulation step, only the evaluation of the state it is in
@@ -268,11 +312,11 @@ struct Fast {
     static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                                unsigned long long env_id = 0, const float* tgt = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr);
+        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
     template <bool RC>
     static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                              unsigned long long env_id, const float* tgt, float* park) {
+                              unsigned long long env_id, const float* tgt) {
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
@@ -391,6 +435,9 @@ struct Fast {
                 PBRE_UNROLL for (int k = 0; k < 6; k++) CI[pp][k] += CI[j][k];
             }
         }
+        // (simple class: M itself is needed once more, for the impulse bound of the motor rows' closed form)
+        float M0[RC ? 1 : ND * (ND + 1) / 2];
+        if (!RC) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle
         PBRE_UNROLL for (int k = 0; k < ND; k++) {
             const float pv = 1.f / Mi[sym(k, k)];
@@ -409,15 +456,9 @@ struct Fast {
         // ---- unconstrained joint velocities w = v*; motor rows (btMultiBodyJointMotor) written against the running
         //      velocity w = v* + dv:  t = dinv*w - rhs2 with rhs2 = (kp (q_des - q)/dt + (1 - kd) v*) dinv
         const float vmax = P.vmax;
-        // Mc[j] = column j of M^-1 in the pair layout (entry ND of the padded vectors stays 0).  The complex-env variant keeps the
-        // 45-entry triangle instead: it is register-bound (dense robot-contact rows), 90 more live values cost more than they save.
-        WV w, Mc[RC ? 1 : ND];
+        WV w;
         PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) wset(w, k, 0.f);
-        if (!RC) {
-            PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) PBRE_UNROLL for (int j = 0; j < ND; j++) wset(Mc[j], k, 0.f);
-            PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_UNROLL for (int k = 0; k < ND; k++) wset(Mc[j], k, Mi[sym(k, j)]);
-        }
-        float m_dinv[ND], m_rhs[ND], m_app[ND];
+        float m_dinv[ND], m_rhs[ND], m_app[ND], m_t[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
@@ -430,7 +471,8 @@ struct Fast {
                 if (j < T.n_act) qdes = clampf(fmaf(act[j], P.act_scale, q[j]), T.lower[j], T.upper[j]);
             }
             m_dinv[j] = 1.f / Mi[sym(j, j)];
-            m_rhs[j] = (kp * (qdes - q[j]) * inv_dt + (1.f - kd) * wj) * m_dinv[j];
+            m_t[j] = kp * (qdes - q[j]) * inv_dt + (1.f - kd) * wj;      // the motor's target velocity (btMultiBodyJointMotor)
+            m_rhs[j] = m_t[j] * m_dinv[j];
             m_app[j] = 0.f;
         }
 
@@ -600,16 +642,14 @@ struct Fast {
             const float nt = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
             const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
             m_app[j] += d;
-            if (RC) { PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k))); }
-            else waxpy(w, d, Mc[RC ? 0 : j]);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
         const float llim = P.limit_imp;
         auto limit = [&](int j) {
             const float t = fmaf(m_dinv[j] * l_dir[j], wget(w, j), -l_rhs[j]);
             const float s = med3(l_app[j] - t, 0.f, llim);
             const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
-            if (RC) { PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k))); }
-            else waxpy(w, d, Mc[RC ? 0 : j]);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
         auto orow = [&](int c, int d) {
             const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
@@ -658,97 +698,64 @@ struct Fast {
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
             if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) { rrow(c, 1); rrow(c, 2); } }
         };
-        // The usual wave of the simple-env kernel has all four object-table slots in use (the cube rests on the table in every
-        // env): that case gets its own copy of the loop without the per-slot "does any lane use it" branches, which cost two
-        // VALU + two SALU instructions per slot and iteration (rows of a lane without the contact are exact no-ops either way).
-        bool all_slots = !RC;
-        PBRE_UNROLL for (int c = 0; c < NK; c++) all_slots = all_slots && any_c[c];
-        if (all_slots) {
-            // One sweep = the ND motor rows (reversed on even sweeps) and the 12 object rows (4 normals, then the friction pairs).  In
-            // this class the two blocks share no unknown, so any interleaving of the two sequences gives each block bit for bit the
-            // iterates of Bullet's order (motors, normals, frictions).  The rows are ISSUED interleaved -- motor, object, motor, ... --
-            // because each block is one dependent chain (a row waits for the previous row's update) and the scheduler keeps source
-            // order: back to back they cost a lone wave the sum of both chains' latencies, interleaved the longer of the two
-            // (PBRE_INTERLEAVE=0 restores the sequential order for A/B runs).
-#ifndef PBRE_INTERLEAVE
-#define PBRE_INTERLEAVE 1
-#endif
-            constexpr bool IL = PBRE_INTERLEAVE != 0 && ND == 9 && NK == 4;
-            auto obj_k = [&](int k) {           // k-th object row of a sweep in Bullet's order
-                if (k < NK) orow(k, 0); else orow((k - NK) / 2, 1 + ((k - NK) & 1));
-            };
-            auto sweep_rows = [&](auto&& mrow, bool rev) {
-                if (IL) {
-                    // 9 motor rows and 12 object rows: m o m o m o m o m o m o m o m o m o o o o
-                    PBRE_UNROLL for (int k = 0; k < ND; k++) { mrow(rev ? ND - 1 - k : k); obj_k(k); }
-                    PBRE_UNROLL for (int k = ND; k < 3 * NK; k++) obj_k(k);
-                } else {
-                    if (rev) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) mrow(j); } else { PBRE_UNROLL for (int j = 0; j < ND; j++) mrow(j); }
-                    PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
-                    PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+        if (!RC) {
+            // ---- simple class.  The motor rows and the object rows share no unknown, so Bullet's interleaved sweeps give each block
+            // exactly the iterates it would get alone: the two blocks are solved one after the other.
+            // (1) Motor block.  While no motor reaches its impulse bound, a motor row is the linear map e <- (I - A_j e_j^T / A_jj) e on the
+            // error e = w - t (A = M^-1, t = the motors' target velocities, the fixed point), so the `iters` sweeps are a power of one
+            // matrix: w = t + G^(iters/2) (w0 - t) with G = one reversed + one forward sweep -- evaluated by repeated squaring
+            // (motor_closed) instead of 150 x 9 dependent row updates.  Same numbers as the sequential sweeps up to rounding (the
+            // correction term G^k e decays geometrically, so its rounding errors are far below those of 1350 sequential row updates);
+            // PBRE_F_SEQ_MOTORS (flags bit 5) runs Bullet's sequential rows instead (validation, A/B).
+            // Validity: the rows are clamp-free only while every applied impulse stays within +-motor_imp.  Every row update minimises the
+            // energy 1/2 l^T A l - b^T l along one coordinate, so |l_k - l*|_A never grows: |l_k,j| <= |l*_j| + |l*|_A sqrt(M_jj) with
+            // l* = M (t - w0), |l*|_A^2 = (t - w0)^T l*.  A lane that fails the bound (a NaN fails it too) takes the sequential clamping rows;
+            // what a lane computes does not depend on the lanes it shares a wave with.
+            const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
+            bool over = true;
+            float wc[ND];
+            if (want_closed) {
+                float e[ND];
+                PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
+                float en = 0.f, lam[ND];
+                PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                    float l = 0.f;
+                    PBRE_UNROLL for (int k = 0; k < ND; k++) l = fmaf(M0[sym(j, k)], e[k], l);
+                    lam[j] = l; en = fmaf(l, e[j], en);
                 }
-            };
-            // Clamp-free motor rows first (the kernel is VALU-issue bound: fma + |.|-accumulate instead of fma, 2 sub, med3, add per row).
-            // No motor comes near PyBullet's default force bound (1e5 N dt = 417 against impulses of a few units), and
-            // sum |delta_j| over the solve bounds every value the applied impulse of motor j ever had, so one test after the loop
-            // decides; a wave in which it fails starts over with the clamping rows from the solver's initial values, which were
-            // parked in `park` (wave-private LDS on the device: no HBM traffic).
-            bool solved = false;
-            {
-                PBRE_UNROLL for (int j = 0; j < ND; j++) park[j * PBRE_PARK_STRIDE] = wget(w, j);
-                park[(ND + 0) * PBRE_PARK_STRIDE] = ov.x; park[(ND + 1) * PBRE_PARK_STRIDE] = ov.y; park[(ND + 2) * PBRE_PARK_STRIDE] = ov.z;
-                park[(ND + 3) * PBRE_PARK_STRIDE] = ow.x; park[(ND + 4) * PBRE_PARK_STRIDE] = ow.y; park[(ND + 5) * PBRE_PARK_STRIDE] = ow.z;
-                auto motor_free = [&](int j) {       // (m_app[j] accumulates |delta| here; the clamping rows start from 0 again)
-                    const float d = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
-                    m_app[j] += fabsf(d);
-                    waxpy(w, d, Mc[RC ? 0 : j]);
-                };
-#ifdef PBRE_FIXPOINT_PROBE
-                // host-only instrumentation (tools/fixpoint_probe.py): the first sweep after which a whole sweep leaves the object
-                // block (ov, ow, applied impulses) / a double sweep leaves the motor block (w) bit-unchanged
-                {
-                    int fo = -1, fm = -1, po = -1;
-                    float pw[ND], po6[6], pa[NK][3], qo6[6], qa[NK][3];
-                    auto snap_o = [&](float* o6, float (*a)[3]) { o6[0] = ov.x; o6[1] = ov.y; o6[2] = ov.z; o6[3] = ow.x; o6[4] = ow.y; o6[5] = ow.z;
-                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) a[c][d] = r_app[c][d]; };
-                    auto same_o = [&](const float* o6, float (*a)[3]) { bool s = o6[0] == ov.x && o6[1] == ov.y && o6[2] == ov.z && o6[3] == ow.x && o6[4] == ow.y && o6[5] == ow.z;
-                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) s = s && a[c][d] == r_app[c][d]; return s; };
-                    snap_o(qo6, qa);
-                    for (int it = 0; it < P.iters; it++) {
-                        if ((it & 1) == 0) for (int j = 0; j < ND; j++) pw[j] = wget(w, j);
-                        snap_o(po6, pa);
-                        sweep_rows(motor_free, (it & 1) == 0);
-                        if (fo < 0 && same_o(po6, pa)) fo = it;
-                        if (po < 0 && fo < 0 && it >= 1 && same_o(qo6, qa)) po = it;      // period 2
-                        for (int k = 0; k < 6; k++) qo6[k] = po6[k];
-                        for (int c = 0; c < NK; c++) for (int d = 0; d < 3; d++) qa[c][d] = pa[c][d];
-                        if ((it & 1) == 1 && fm < 0) { bool s = true; for (int j = 0; j < ND; j++) s = s && pw[j] == wget(w, j); if (s) fm = it - 1; }
-                    }
-                    pbre_fixpoint_record(fo, fm, po);
-                }
-#else
+                bool ov_ = !(en >= 0.f);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) ov_ = ov_ || !(fabsf(lam[j]) + sqrtf(en * M0[sym(j, j)]) <= mlim);
+                over = ov_;
+                motor_closed(Mi, m_dinv, e, P.iters >> 1);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) wc[j] = m_t[j] + e[j];
+            }
+            if (PBRE_ANY(over)) {
                 for (int it = 0; it < P.iters; it += 2) {
-                    sweep_rows(motor_free, true);
+                    PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
                     if (it + 1 >= P.iters) break;
-                    sweep_rows(motor_free, false);
-                }
-#endif
-                bool over = false;
-                PBRE_UNROLL for (int j = 0; j < ND; j++) over = over || !(m_app[j] <= mlim);      // (a NaN fails the test as well)
-                solved = !PBRE_ANY(over);
-                if (!solved) {
-                    PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, park[j * PBRE_PARK_STRIDE]);
-                    ov = v3(park[(ND + 0) * PBRE_PARK_STRIDE], park[(ND + 1) * PBRE_PARK_STRIDE], park[(ND + 2) * PBRE_PARK_STRIDE]);
-                    ow = v3(park[(ND + 3) * PBRE_PARK_STRIDE], park[(ND + 4) * PBRE_PARK_STRIDE], park[(ND + 5) * PBRE_PARK_STRIDE]);
-                    PBRE_UNROLL for (int c = 0; c < NK; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
-                    PBRE_UNROLL for (int j = 0; j < ND; j++) m_app[j] = 0.f;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
                 }
             }
-            if (!solved)
-            for (int it = 0; it < P.iters; it += 2) {
-                sweep_rows(motor, true);
-                if (it + 1 >= P.iters) break;
-                sweep_rows(motor, false);
+            if (want_closed) { PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, over ? wget(w, j) : wc[j]); }
+            // (2) Object block: 4 normal rows, then the friction pairs.  The usual wave has all four object-table slots in use (the
+            // cube rests on the table in every env): that case gets its own copy of the loop without the per-slot "does any lane use
+            // it" branches (rows of a lane without the contact are exact no-ops either way).
+            bool all_slots = true, no_slot = true;
+            PBRE_UNROLL for (int c = 0; c < NK; c++) { all_slots = all_slots && any_c[c]; no_slot = no_slot && !any_c[c]; }
+            if (all_slots) {
+                auto osweep = [&]() {
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+                };
+                // (two sweeps per trip: a row's new applied impulse lands in a fresh register, with one sweep per trip every row pays a
+                // register move at the back edge)
+                for (int it = 0; it < P.iters; it += 2) {
+                    osweep();
+                    if (it + 1 >= P.iters) break;
+                    osweep();
+                }
+            } else if (!no_slot) {
+                for (int it = 0; it < P.iters; it++) contacts();
             }
         } else
         for (int it = 0; it < P.iters; it += 2) {

@@ -64,7 +64,7 @@ struct Emu : pbre_ctx {
         if constexpr (PANDA) {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
-                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; float park[FastH::PARK]; FastH::step(T, P, st, act, out, mode, flags, env_id, tg, park); }
+                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
@@ -122,6 +122,7 @@ struct Emu : pbre_ctx {
         }
     }
     void settle(int e, int cnt, int flags) {
+        flags |= cfg.flags & PBRE_F_SEQ_MOTORS;
         const int mode = (P.use_ik || S::MREC) ? CoreH::M_TGT : 0;
         for (int i = 0; i < cnt; i++) step_env(&state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &tgt[(size_t)e * TG]);
     }
@@ -184,7 +185,7 @@ struct Emu : pbre_ctx {
             const int tail = last ? (CoreH::M_OBS | CoreH::M_TASK) : (CoreH::M_TASK | CoreH::M_INNER);
             for (int e = 0; e < n; e++) {
                 float* st = &state[(size_t)e * STATE];
-                const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET);
+                const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET | PBRE_F_SEQ_MOTORS);
                 const unsigned long long id = P.env_id_base + (unsigned long long)e;
                 float* o = last ? out + (size_t)e * ow : nullptr;
                 if (P.use_ik) {
