@@ -171,7 +171,12 @@ int pbre_step(pbre_ctx* ctx, const float* actions, float* out);
  *   NULL                the ctx's own NON-BLOCKING stream: it is not ordered against any other stream (not even the legacy
  *                       default stream); the caller orders inputs / outputs with events or pbre_sync().
  * Every host-synchronous entry point (pbre_reset, pbre_get_state, pbre_set_state, pbre_observe, pbre_settle, pbre_set_physics,
- * pbre_step, pbre_sync, ...) first waits for all steps enqueued this way, whatever stream they went to. */
+ * pbre_step, pbre_sync, ...) first waits for all steps enqueued this way, whatever stream they went to.
+ * One-time host synchronisation: the FIRST step enqueued on a stream the ctx has not seen before calibrates which of its internal
+ * side streams overlaps with that stream (two ~150 us probe kernels and a host wait on an event; up to four caller streams are
+ * remembered, PBRE_SIDE_PROBE=0 disables the probe).  A stream that is being captured into a hipGraph is never probed.
+ * Returns PBRE_E_ARG when PBRE_F_AUTO_RESET is set and pbre_set_physics changed the scene since the last full pbre_reset (the settled
+ * snapshot the in-kernel restart uses is stale). */
 #define PBRE_STREAM_LEGACY ((void*)1)
 int pbre_step_device(pbre_ctx* ctx, const float* d_actions, float* d_out, void* stream);
 int pbre_sync(pbre_ctx* ctx);

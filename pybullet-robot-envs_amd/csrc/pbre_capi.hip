@@ -86,8 +86,13 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 // measured too -- profiles/r02_pmc_hbm.json: WRITE_SIZE 62.1 MB against 63.3 MB with each lane writing its own 140-byte row, and the
 // same step time -- the L2 already merges the lanes' 4-byte stores into full lines; what WRITE_SIZE carries beyond the records and
 // rows is the register spill traffic.  The direct per-lane row writes stayed.)
-template <int MODE>
-__global__ __launch_bounds__(FTPB, PBRE_FAST_WAVES) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+// WPS: the waves per SIMD the register allocation is limited to.  2 (256 VGPRs) is the fast one; 3 (168 VGPRs, the setup phase
+// spills ~0.8 KB per lane) leaves room for the complex envs' waves beside a batch that fills every wave slot of the 2-wave variant
+// (131072 envs = 2048 waves = 1024 SIMDs x 2): there the displaced k_fast waves of the 2-wave variant run in a second round
+// (0.249 ms per stationary step against 0.220 ms with this variant; right after reset(), without complex envs, 0.157 against 0.187).
+// launch_step picks per step.
+template <int MODE, int WPS = PBRE_FAST_WAVES>
+__global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                                int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
@@ -274,10 +279,12 @@ struct pbre_ctx {
                                        // left idle for hundreds of steps makes the first steps after the switch back ~8 % slower (0: never)
     int idle_single = 1;               // with no complex envs reported, both kernels go to the caller's stream in order (no fork / join events); 0: A/B
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
+    int fast3 = 2;                     // k_fast variant limited to 3 waves per SIMD: 0 never, 1 whenever complex envs are reported, 2 when they would displace k_fast waves (PBRE_FAST3)
     hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
     SidePick sp;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_sys = nullptr;   // ev_join_sys: with the system-scope fence (see pbre_step)
+    bool rows_to_host = false;         // the step in flight writes its output rows straight into page-locked host memory
     static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
     static constexpr int KSAMPLE = 8;          // (every KSAMPLE-th launch is sampled) recorded on the stream that kernel runs on
     int ksample = KSAMPLE;                     // PBRE_KSAMPLE: A/B of the sampling interval
@@ -286,11 +293,12 @@ struct pbre_ctx {
     double ms[3] = {0, 0, 0};
     int zero_copy = 3;                 // PBRE_ZERO_COPY: pbre_step lets the kernels access page-locked host buffers directly (bit 0 actions, bit 1 rows; 0: staged copies)
     bool have_snapshot = false;        // a full pbre_reset has recorded the settled snapshot (rst_q, rst_objz)
+    bool stale_snapshot = false;       // ... and a later pbre_set_physics changed the scene it was recorded in
     unsigned char* d_mask = nullptr;
     bool ext_dirty = false;            // a pbre_step_device was enqueued on a caller-supplied stream since the last quiesce()
     std::string err;
 };
-static std::string g_err;
+static thread_local std::string g_err;      // errors without a ctx (pbre_create): per calling thread (MultiEngine creates its shards from one thread per device)
 
 #define HIPCHK(call)                                                                                   \
     do {                                                                                               \
@@ -407,13 +415,26 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
     hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
     if (timed) (void)hipEventRecord(ek[0], s_fast);
-    hipLaunchKernelGGL(k_fast<MODE>, dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
-                       b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
+    // the 3-waves-per-SIMD variant when the complex envs' waves would push k_fast waves of the 2-wave variant into an extra round
+    bool fast3 = false;
+    if (!single && c->fast3 != 0) {
+        const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 : (hint + FTPB - 1) / FTPB * 2) + 8;
+        fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
+    }
+    if (fast3)
+        hipLaunchKernelGGL((k_fast<MODE, 3>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                           b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
+    else
+        hipLaunchKernelGGL((k_fast<MODE, 2>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                           b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed) { (void)hipEventRecord(ek[1], s_fast); c->k_steps++; }
     if (!single || touch_side) {
-        if ((e = hipEventRecord(c->ev_join, c->side)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(s, c->ev_join, 0)) != hipSuccess) return e;
+        // (round-2 advice) the side stream's kernel may have written rows into host memory: join through the event that keeps its
+        // system-scope release, so the host sees them once the caller's stream is synchronised, whatever the buffer's coherence mode
+        hipEvent_t ej = c->rows_to_host ? c->ev_join_sys : c->ev_join;
+        if ((e = hipEventRecord(ej, c->side)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(s, ej, 0)) != hipSuccess) return e;
     }
     b.ccur = cn;
     b.cur = nxt;
@@ -466,6 +487,7 @@ void pbre_destroy(pbre_ctx* c) {
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join_sys) (void)hipEventDestroy(c->ev_join_sys);
     for (auto& pr : c->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->sp.destroy(); c->side = nullptr;
@@ -497,6 +519,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_KSAMPLE")) c->ksample = std::max(1, atoi(ev));
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
+    if (const char* ev = getenv("PBRE_FAST3")) c->fast3 = atoi(ev);
     if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -518,6 +541,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
         const unsigned fl = hipEventDisableTiming | ((ef && ef[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
         CK(hipEventCreateWithFlags(&c->ev_fork, fl));
         CK(hipEventCreateWithFlags(&c->ev_join, fl));
+        CK(hipEventCreateWithFlags(&c->ev_join_sys, hipEventDisableTiming));
     }
     // (timing-only events around the dominant kernel: no system-scope fence at the markers)
     for (auto& pr : c->ev_k) for (auto& ev : pr) CK(hipEventCreateWithFlags(&ev, hipEventDisableSystemFence));
@@ -646,7 +670,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             for (int k = 0; k < NJ; k++) { c->P.rst_q[k] = rec[k]; c->T.rst_q[k] = rec[k]; }
             c->P.rst_objz = rec[11];
             HIPCHK(hipMemcpy(c->dT, &c->T, sizeof(Tables), hipMemcpyHostToDevice));
-            c->have_snapshot = true;
+            c->have_snapshot = true; c->stale_snapshot = false;
             // end-effector pose of the settled robot (the first 6 observation entries of env 0) for the in-kernel restart
             hipLaunchKernelGGL(k_observe, dim3(c->npad / EPB), dim3(TPB), 0, c->stream, c->dT, c->P, c->main.state, c->d_out, c->d_scratch, c->n, c->ow);
             HIPCHK(hipGetLastError());
@@ -667,7 +691,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
 int pbre_reset_snapshot(pbre_ctx* c, const uint8_t* mask, float* obs) {
     if (!c || !mask) return PBRE_E_ARG;
     if (c->wide) return wide_reset_snapshot(c->wide, mask, obs);
-    if (!c->have_snapshot) { c->err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+    if (!c->have_snapshot) { c->err = c->stale_snapshot ? stale_snapshot_msg() : "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(quiesce(c));
     if (!c->d_mask) HIPCHK(hipMalloc(&c->d_mask, (size_t)c->npad));
@@ -688,6 +712,7 @@ int pbre_step_device(pbre_ctx* c, const float* d_actions, float* d_out, void* st
     // hipStreamLegacy handle, so it is passed as stream 0)
     hipStream_t s = stream == PBRE_STREAM_LEGACY ? (hipStream_t) nullptr : (stream ? (hipStream_t)stream : c->stream);
     if (stream) c->ext_dirty = true;
+    if (c->stale_snapshot && (c->cfg.flags & PBRE_F_AUTO_RESET)) { c->err = stale_snapshot_msg(); return PBRE_E_ARG; }
     HIPCHK(full_step(c, d_actions, d_out, s));
     return PBRE_OK;
 }
@@ -697,6 +722,7 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (c->wide) return wide_step(c->wide, actions, out);
     HIPCHK(hipSetDevice(c->device));
     if (c->ext_dirty) HIPCHK(quiesce(c));
+    if (c->stale_snapshot && (c->cfg.flags & PBRE_F_AUTO_RESET)) { c->err = stale_snapshot_msg(); return PBRE_E_ARG; }
     // zero-copy (PBRE_ZERO_COPY bit 0: actions, bit 1: rows): a page-locked buffer (pbre_host_alloc) is accessed by the kernels
     // themselves, over PCIe, instead of being staged through HBM with a copy
     bool za = false, zo = false;
@@ -709,7 +735,10 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
     if (!za) HIPCHK(hipMemcpyAsync(c->d_act, actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(full_step(c, za ? actions : c->d_act, zo ? out : c->d_out, c->stream));
+    c->rows_to_host = zo;
+    const hipError_t fe = full_step(c, za ? actions : c->d_act, zo ? out : c->d_out, c->stream);
+    c->rows_to_host = false;
+    HIPCHK(fe);
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     if (!zo) HIPCHK(hipMemcpyAsync(out, c->d_out, (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
@@ -793,6 +822,10 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need explicit joint damping"; return PBRE_E_UNSUPPORTED; }
+    if (snapshot_relevant_change(c->cfg.phys, *phys)) {      // (round-2 advice) restarts would put the object at the old scene's rest height
+        c->stale_snapshot = c->stale_snapshot || c->have_snapshot;
+        c->have_snapshot = false; P2.rst_ok = 0;
+    }
     c->cfg = cfg; c->P = P2;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(quiesce(c));
@@ -855,7 +888,7 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (c->wide) return wide_kernel_info(c->wide, info, n);
     hipFuncAttributes fa;
     int rf = -1, rg = -1, rr = -1;
-    if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP>) == hipSuccess) rf = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 2>) == hipSuccess) rf = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
     int complex_now = 0, complex_sum = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)

@@ -129,6 +129,20 @@ inline int default_config(pbre_config* c, int robot, int task) {
 }
 
 // pbre_physics -> the device parameter block (the robot tables do not depend on pbre_physics); false on bad values
+// Does a pbre_set_physics call change what the settled snapshot of the last full reset depends on (scene geometry, contact margin /
+// slop / ERP, gravity, time step)?  Then the snapshot -- settled robot pose, object rest height, cached end-effector pose -- describes a
+// scene that no longer exists: pbre_reset_snapshot and the in-kernel auto-reset must not use it (mass, friction, damping and the
+// solver's impulse bounds leave the rest pose alone: domain randomisation keeps the snapshot).
+inline bool snapshot_relevant_change(const pbre_physics& a, const pbre_physics& b) {
+    bool ch = a.dt != b.dt || a.gravity_z != b.gravity_z || a.erp != b.erp || a.linear_slop != b.linear_slop || a.contact_margin != b.contact_margin ||
+              a.ground_z != b.ground_z;
+    for (int k = 0; k < 3; k++) ch = ch || a.table_c[k] != b.table_c[k] || a.table_h[k] != b.table_h[k] || a.obj_h[k] != b.obj_h[k];
+    return ch;
+}
+inline const char* stale_snapshot_msg() {
+    return "the scene changed (pbre_set_physics: geometry / contact parameters) since the last full pbre_reset: the settled snapshot that "
+           "pbre_reset_snapshot and PBRE_F_AUTO_RESET restart from is stale -- call pbre_reset for the whole batch first";
+}
 inline bool apply_physics(const pbre_physics& p, Params& P2) {
     if (p.solver_iters <= 0 || p.dt <= 0 || p.obj_mass <= 0) return false;
     P2.dt = (float)p.dt; P2.inv_dt = (float)(1.0 / p.dt); P2.gz = (float)p.gravity_z; P2.iters = p.solver_iters;

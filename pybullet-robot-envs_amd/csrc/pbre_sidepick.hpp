@@ -54,6 +54,11 @@ struct SidePick {
         side = cand[0];
         const char* knob = getenv("PBRE_SIDE_PROBE");
         if (knob && knob[0] == '0') return side;
+        // (round-2 advice) the probe launches busy-wait kernels and waits for an event on the host: never on a stream that is being
+        // captured into a graph (it would invalidate the capture) -- such a caller gets the first candidate, uncalibrated
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return side;
+        (void)hipGetLastError();
         probes++;
         for (int k = 0; k < NCAND; k++) {
             (void)hipEventRecord(t0, s);

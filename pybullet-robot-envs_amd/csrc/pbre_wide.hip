@@ -250,7 +250,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
             WCHK(hipMemcpy(rec.data(), w->state, (size_t)w->sf * sizeof(float), hipMemcpyDeviceToHost));
             w->snapshot(rec.data());
             WCHK(w->upload_tables());
-            w->have_snapshot = true;
+            w->have_snapshot = true; w->stale_snapshot = false;
         }
     }
     if (obs) return wide_observe(w, obs);
@@ -258,7 +258,7 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
 }
 int wide_reset_snapshot(WideEngine* w, const uint8_t* mask, float* obs) {
     if (w->mrec) { w->err = "pbre_reset_snapshot: task envs only (the robot-level interfaces have no episodes)"; return PBRE_E_UNSUPPORTED; }
-    if (!w->have_snapshot) { w->err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+    if (!w->have_snapshot) { w->err = w->stale_snapshot ? stale_snapshot_msg() : "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
     if (!w->d_mask) WCHK(hipMalloc(&w->d_mask, (size_t)w->n));
@@ -273,12 +273,14 @@ int wide_reset_snapshot(WideEngine* w, const uint8_t* mask, float* obs) {
 int wide_step_device(WideEngine* w, const float* d_actions, float* d_out, void* stream) {
     WCHK(hipSetDevice(w->device));
     if (stream) w->ext_dirty = true;
+    if (w->stale_snapshot && (w->cfg.flags & PBRE_F_AUTO_RESET)) { w->err = stale_snapshot_msg(); return PBRE_E_ARG; }
     WCHK(wfull_step(w, d_actions, d_out, stream == PBRE_STREAM_LEGACY ? (hipStream_t) nullptr : (stream ? (hipStream_t)stream : w->stream)));
     return PBRE_OK;
 }
 int wide_step(WideEngine* w, const float* actions, float* out) {
     WCHK(hipSetDevice(w->device));
     if (w->ext_dirty) WCHK(wquiesce(w));
+    if (w->stale_snapshot && (w->cfg.flags & PBRE_F_AUTO_RESET)) { w->err = stale_snapshot_msg(); return PBRE_E_ARG; }
     hipStream_t s = w->stream;
     WCHK(hipEventRecord(w->ev[0], s));
     WCHK(hipMemcpyAsync(w->d_act, actions, (size_t)w->n * w->act_dim * 4, hipMemcpyHostToDevice, s));
@@ -368,6 +370,7 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     if (!apply_physics(*p, P2)) { w->err = "bad physics parameters"; return PBRE_E_ARG; }
     WCHK(hipSetDevice(w->device));
     WCHK(wquiesce(w));
+    if (snapshot_relevant_change(w->cfg.phys, *p)) { w->stale_snapshot = w->stale_snapshot || w->have_snapshot; w->have_snapshot = false; P2.rst_ok = 0; }
     w->cfg.phys = *p; w->P = P2;
     w->lane_invalidate();          // the contact margin may have changed
     return PBRE_OK;

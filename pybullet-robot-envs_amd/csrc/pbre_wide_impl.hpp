@@ -160,7 +160,7 @@ struct WideEngine {
     virtual void launch_observe(bool initd, float* st, float* out, int cnt, hipStream_t s) = 0;
     virtual void launch_init(float* st, int cnt, hipStream_t s) = 0;
     virtual void launch_snapshot_reset(const unsigned char* mask, hipStream_t s) = 0;
-    bool have_snapshot = false;
+    bool have_snapshot = false, stale_snapshot = false;   // stale: pbre_set_physics changed the scene the snapshot was recorded in
     virtual void launch_target(float* st, int cnt, hipStream_t s) = 0;
     virtual void launch_mrec_init(float* tg, int cnt, hipStream_t s) = 0;
     virtual void launch_set_motors(const MotorCmd& cmd, const unsigned char* mask, hipStream_t s) = 0;

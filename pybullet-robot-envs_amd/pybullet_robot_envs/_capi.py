@@ -366,9 +366,9 @@ class MultiEngine(object):
         return np.concatenate(parts, axis=0)
 
     def close(self):
+        self._pool.shutdown(wait=True)         # shard calls still in flight finish before their contexts are destroyed
         for e in self.shards:
             e.close()
-        self._pool.shutdown(wait=False)
 
     def obs_limits(self):
         return self.shards[0].obs_limits()

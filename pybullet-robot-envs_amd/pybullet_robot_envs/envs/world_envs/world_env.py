@@ -78,7 +78,9 @@ class WorldEnv:
         return object_physics(self._obj_name)
 
     def load_object(self, obj_name):
-        """(world_env.py:76-84) switch the object; takes effect in the engine at once when the task env has built it"""
+        """(world_env.py:76-84) switch the object; takes effect in the engine at once when the task env has built it.  In the reference
+        load_object is part of WorldEnv.reset(): the new object only exists after a reset.  Here the engine refuses snapshot restarts
+        (pbre_reset_snapshot, in-kernel auto-reset) until the next full reset() has settled the new object (its rest height differs)."""
         self._obj_name = obj_name
         ph = self.object_physics()
         if self._client.engine is not None:

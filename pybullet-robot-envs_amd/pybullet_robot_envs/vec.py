@@ -8,14 +8,17 @@ seed(), get_attr/set_attr/env_method`.  Like `DummyVecEnv`, a finished env is re
 observation is the first one of the next episode and `infos[i]["terminal_observation"]` keeps the last one of the finished episode
 (what SB-style libraries bootstrap from on a time-limit truncation): the adapter restarts the finished envs with a masked
 SNAPSHOT reset (`env.reset(mask, snapshot=True)` -> pbre_reset_snapshot: one small kernel, not the 201 settle launches of the
-explicit reset).  A task env constructed with `auto_reset=True` restarts finished envs inside the step kernel itself (fastest;
+explicit reset; within 2e-5 / 5e-5 of it).  `snapshot_reset=False` asks for the explicit masked reset instead; the adapter also falls
+back to it when the engine has no valid settled snapshot (no full reset yet, e.g. after a set_state restore; or the scene was
+changed by set_physics / load_object since) or when the wrapped env's reset() does not take the `snapshot` keyword.  A task env constructed with `auto_reset=True` restarts finished envs inside the step kernel itself (fastest;
 for device-resident rollouts through `step_tensor`); the terminal observation is then not available, and the infos say so."""
 import numpy as np
 
 
 class BatchedVecEnv(object):
-    def __init__(self, env):
+    def __init__(self, env, snapshot_reset=True):
         self.env = env
+        self._snapshot_reset = bool(snapshot_reset)
         self.num_envs = int(env.num_envs)
         self.observation_space = env.observation_space
         self.action_space = env.action_space
@@ -57,13 +60,24 @@ class BatchedVecEnv(object):
             idx = np.nonzero(done)[0]
             for i in idx:
                 infos[i]["terminal_observation"] = dict((k, v[i].copy()) for k, v in obs.items()) if self._goal else obs[i].copy()
-            fresh = self.env.reset(mask=done.astype(np.uint8), snapshot=True)
+            fresh = self._masked_reset(done.astype(np.uint8))
             if self._goal:
                 for k in obs:
                     obs[k][idx] = self._batch(np.asarray(fresh[k]))[idx]
             else:
                 obs[idx] = self._batch(np.asarray(fresh))[idx]
         return obs, rew, done, infos
+
+    def _masked_reset(self, mask):
+        if self._snapshot_reset:
+            try:
+                return self.env.reset(mask=mask, snapshot=True)
+            except TypeError:                     # a wrapped env whose reset() has no `snapshot` keyword
+                self._snapshot_reset = False
+            except RuntimeError as e:             # the engine has no valid settled snapshot (PBRE_E_ARG): explicit reset this time
+                if "snapshot" not in str(e):
+                    raise
+        return self.env.reset(mask=mask)
 
     def step(self, actions):
         self.step_async(actions)

@@ -41,7 +41,7 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     virtual ~pbre_ctx() {}
     virtual void reset(const uint8_t* mask) = 0;
     virtual int reset_snapshot(const uint8_t* mask) = 0;
-    bool have_snapshot = false;
+    bool have_snapshot = false, stale_snapshot = false;
     virtual void step(const float* actions, float* out) = 0;
     virtual void observe(float* obs) = 0;
     virtual void settle_all(int n, int flags) = 0;
@@ -150,7 +150,7 @@ struct Emu : pbre_ctx {
             }
         }
         if (!mask) {
-            for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; have_snapshot = true;
+            for (int k = 0; k < NJ; k++) { P.rst_q[k] = state[k]; T.rst_q[k] = state[k]; } P.rst_objz = state[S::LC + 2]; have_snapshot = true; stale_snapshot = false;
             std::vector<float> row(obs_dim + 2);
             float* st = &state[0];
             auto Q = L::load(st), V = L::load(st + W), X = L::loadm(st + 2 * W, L::lti(L::lane(), 16));
@@ -161,7 +161,7 @@ struct Emu : pbre_ctx {
     }
     int reset_snapshot(const uint8_t* mask) override {
         if (S::MREC) { err = "pbre_reset_snapshot: task envs only"; return PBRE_E_UNSUPPORTED; }
-        if (!have_snapshot) { err = "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
+        if (!have_snapshot) { err = stale_snapshot ? stale_snapshot_msg() : "pbre_reset_snapshot: no settled snapshot yet (call pbre_reset for the whole batch first)"; return PBRE_E_ARG; }
         for (int e = 0; e < n; e++) {
             if (!mask[e]) continue;
             float* st = &state[(size_t)e * STATE];
@@ -295,6 +295,7 @@ int pbre_reset_snapshot(pbre_ctx* c, const uint8_t* mask, float* obs) {
 }
 int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     if (!c || !actions || !out) return PBRE_E_ARG;
+    if (c->stale_snapshot && (c->cfg.flags & PBRE_F_AUTO_RESET)) { c->err = stale_snapshot_msg(); return PBRE_E_ARG; }
     c->step(actions, out);
     return PBRE_OK;
 }
@@ -353,6 +354,7 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     Params P2 = c->P;
     if (!apply_physics(*phys, P2)) { c->err = "bad physics parameters"; return PBRE_E_ARG; }
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need explicit joint damping"; return PBRE_E_UNSUPPORTED; }
+    if (snapshot_relevant_change(c->cfg.phys, *phys)) { c->stale_snapshot = c->stale_snapshot || c->have_snapshot; c->have_snapshot = false; P2.rst_ok = 0; }
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;
 }

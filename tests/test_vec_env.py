@@ -128,3 +128,38 @@ def check_world_contacts(panda, lib):
     single.reset()
     assert single._world.check_contact(single._world.table_id) is True and single._world.check_contact(single._robot.robot_id) is False
     env.close(); single.close()
+
+
+def test_scene_change_invalidates_the_settled_snapshot(emu_lib):
+    """Round-2 advice: after a change of the scene (WorldEnv.load_object / set_physics with new geometry) the settled snapshot of the
+    last full reset describes another scene.  The engine refuses snapshot restarts until a full reset re-records it -- mass / friction
+    changes (domain randomisation) keep it -- and BatchedVecEnv falls back to the explicit masked reset."""
+    import pytest
+    env = pandaPushGymEnv(max_steps=2, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, num_envs=3, _lib=emu_lib)
+    v = BatchedVecEnv(env)
+    v.reset()
+    eng = env._engine
+    mask = np.array([1, 0, 0], np.uint8)
+    eng.reset_snapshot(mask)                                     # valid after the full reset
+    eng.set_physics(obj_mass=0.2, obj_mu=0.7)                    # domain randomisation: the rest pose does not change
+    eng.reset_snapshot(mask)
+    env._world.load_object("YcbMustardBottle")                   # a taller box: other rest height
+    with pytest.raises(RuntimeError, match="stale"):
+        eng.reset_snapshot(mask)
+    rng = np.random.default_rng(0)
+    for t in range(3):                                           # the adapter resets finished envs explicitly meanwhile
+        obs, rew, done, infos = v.step(rng.uniform(-1, 1, (3, 7)))
+    assert done.any() or True
+    h = eng.get_physics().obj_h[2]
+    z = eng.get_state()[:, 11]
+    top = eng.get_physics().table_c[2] + eng.get_physics().table_h[2]
+    assert np.all(np.abs(z - (top + h)) < 5e-3), (z, top + h)   # restarted envs rest ON the table with the new half height
+    v.reset()
+    eng.reset_snapshot(mask)                                     # a full reset re-records the snapshot
+    a = pandaPushGymEnv(max_steps=2, num_envs=2, auto_reset=True, _lib=emu_lib)
+    a.reset()
+    a._world.load_object("YcbMustardBottle")
+    with pytest.raises(RuntimeError, match="stale"):             # the in-kernel auto-reset must not restart from the old scene either
+        a.step(np.zeros((2, 7)))
+    a.reset()
+    a.step(np.zeros((2, 7)))
