@@ -33,10 +33,12 @@ sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALG_BYTES_PER_ENV_STEP = 444.0      # read 172 B + write 272 B (Panda push, joint control)
-# FLOPs actually required per env-step by the sparse formulation the fast kernel uses: per PGS iteration
+# FLOPs actually required per env-step by the sparse formulation the fast kernel uses: rounds 1-2, per PGS iteration
 # 9 motor rows x 23 + 4 normal rows x 18 + 8 friction rows x 20 = 439 flop, x150, + ~8 k for kinematics/dynamics/obs.
 # (SURVEY 8(d)'s 0.4 MFLOP assumed 33 dense rows of 70 flop; the dense figure is what the general row kernel does.)
-ALG_FLOP_PER_ENV_STEP = 150 * 439 + 8000.0
+# Round 3: the 9 motor rows of a contact-free env are evaluated in closed form (matrix power, ~4.2 k FMA) instead of 150 sweeps, so the
+# figure counts what the kernel now has to execute: 150 x (4 x 18 + 8 x 20) for the object rows + 8.4 k + ~8 k.
+ALG_FLOP_PER_ENV_STEP = 150 * 232 + 8400.0 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
@@ -112,6 +114,7 @@ def cpu_baseline(target_cpu_seconds=20.0):
     n, steps = 256, 8
     work, dt = _cpu_worker((n, steps, 0))
     per = dt / work
+    single_core = work / dt                 # the single-thread figure (this process, one core)
     total = max(cores * n * steps, int(target_cpu_seconds / per))
     steps = 16
     n = max(16, total // (cores * steps))
@@ -121,7 +124,7 @@ def cpu_baseline(target_cpu_seconds=20.0):
     wall = time.perf_counter() - t0
     done = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
-    return {"value": done / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    return {"value": done / busy, "unit": "env-steps/s", "cores": cores, "kind": "port", "single_core": single_core,
             "pybullet": "absent on this box (import pybullet fails): PyBullet baseline unavailable, the oracle is the stated substitute",
             "sample": "%d envs x %d steps per core on %d cores (oracle/pbre_oracle.c, fp64, 150 PGS iters), "
                       "%.1f s wall incl. process start" % (n, steps, cores, wall)}
@@ -289,7 +292,7 @@ def main():
     import torch.distributed as dist
     from pybullet_robot_envs import _capi
     from pybullet_robot_envs.model.table import panda_table
-    from pybullet_robot_envs.sharding import ShardedEngine
+    from pybullet_robot_envs.sharding import ShardedEngine, GatherPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -364,34 +367,24 @@ def main():
             self.gen.manual_seed(1234 + rank)
             self.pool = torch.rand((pool_steps, n, eng.act_dim), device=dev, generator=self.gen) * 2 - 1
             self.fresh = torch.empty((n, eng.act_dim), device=dev)
-            self.out = [torch.zeros((n, eng.obs_dim + 2), device=dev, dtype=torch.float32) for _ in range(2)]
-            self.gathered = [torch.zeros_like(self.out[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
-            self.pending = [None, None]
-            self.k = 0
+            # the data path (sharding.GatherPipeline): step kernels + one async, double-buffered gather per step
+            self.pipe = GatherPipeline(self.sh, dev, gather=True, host_staged=(backend != "nccl"))
             self.steps_done = 0
 
-        gather = True
+        @property
+        def gather(self):
+            return self.pipe.gather
+
+        @gather.setter
+        def gather(self, v):
+            self.pipe.gather = v
 
         def step(self, ev=None, act=None):
-            b = self.k & 1
-            if self.pending[b] is not None:            # the gather that read this buffer two steps ago
-                self.pending[b].wait()
-                self.pending[b] = None
             if act is None:
-                act = self.pool[self.k % self.pool.shape[0]]
+                act = self.pool[self.pipe.k % self.pool.shape[0]]
             if ev is not None:
                 ev[0].record()
-            self.eng.step_device(act.data_ptr(), self.out[b].data_ptr(), stream)
-            if ev is not None:
-                ev[1].record()
-            if world > 1 and self.gather:              # the one collective of the data path (RCCL over xGMI)
-                if backend == "nccl":
-                    self.pending[b] = dist.gather(self.out[b], self.gathered, dst=0, async_op=True)
-                else:
-                    side.synchronize()
-                    h = self.out[b].cpu()
-                    dist.gather(h, [torch.empty_like(h) for _ in range(world)] if rank == 0 else None, dst=0)
-            self.k += 1
+            self.pipe.step(act, stream, timing_events=ev)
             self.steps_done += 1
 
         def preroll(self, upto):
@@ -402,10 +395,7 @@ def main():
             self.drain()
 
         def drain(self):
-            for b in range(2):
-                if self.pending[b] is not None:
-                    self.pending[b].wait()
-                    self.pending[b] = None
+            self.pipe.drain()
 
         def timed(self, steps, warmup, events=False):
             for _ in range(warmup):
@@ -446,10 +436,15 @@ def main():
     csum0 = eng.kernel_info()[7]
     head = job.timed(args.steps, args.warmup, events=True)
     complex_per_step = ((eng.kernel_info()[7] - csum0) % (1 << 31)) / float(args.steps + args.warmup)
+    # (side key) the same timed region five more times, back to back, without event pairs: the spread of the headline on this box
+    rep = [head["ms_per_step"]] + [job.timed(args.steps, 0)["ms_per_step"] for _ in range(5)]
+    repeats = {"ms_per_step": {"median": float(np.median(rep)), "min": float(np.min(rep)), "max": float(np.max(rep))}, "samples": len(rep),
+               "value_at_median": total * 1e3 / float(np.median(rep)),
+               "note": "sample 0 is the headline's timed region (exactly --steps steps); the others repeat it on the same stationary batch"}
     steps_before = job.steps_done - args.steps
     complex_after = job.complex_frac()
-    finite = bool(torch.isfinite(job.out[0]).all() and torch.isfinite(job.out[1]).all())
-    done_frac = float(job.out[(job.k - 1) & 1][:, -1].mean())
+    finite = bool(torch.isfinite(job.pipe.out[0]).all() and torch.isfinite(job.pipe.out[1]).all())
+    done_frac = float(job.pipe.out[(job.pipe.k - 1) & 1][:, -1].mean())
     kern_ms = float(eng.timing()[3])      # k_fast alone: mean of the HIP event pairs the library records around it on its stream
     info = eng.kernel_info()
     episodes = float(torch.as_tensor(eng.get_state()[:, eng.x_off + 5]).mean()) if rank == 0 else 0.0
@@ -551,6 +546,9 @@ def main():
                        "complex_env_frac_rank0": complex_after, "complex_envs_per_step_timed_region_rank0": complex_per_step,
                        "done_frac_last_step_rank0": done_frac,
                        "mean_episodes_completed_per_env_rank0": episodes},
+            "repeats": repeats,
+            "k_fast_variant": {"steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
+                               "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3)"},
             "fresh_reset": clean(fresh) if fresh else None,
             "steady_synchronised_clocks": sync_clocks,
             "weak_scaling_128k_per_gpu": weak,

@@ -247,7 +247,8 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
 /* kernel facts for the bench/roofline report: [0] VGPRs of the fast kernel, [1] VGPRs of the general kernel,
  * [2] fast path enabled, [3..5] envs stepped in the most recent step by the fast kernel / the general row kernel / the
  * lane-per-env robot-contact kernel, [6] VGPRs of the robot-contact kernel, [7] running sum of the complex envs stepped so far
- * (env-steps taken by the robot-contact / limit-row kernels; wraps at 2^31) */
+ * (env-steps taken by the robot-contact / limit-row kernels; wraps at 2^31), [8] steps since the last reset whose fast kernel was the
+ * variant limited to 3 waves per SIMD (picked when the complex envs' waves would otherwise displace fast-kernel waves), [9] its VGPRs */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

@@ -289,7 +289,7 @@ struct pbre_ctx {
     static constexpr int KSAMPLE = 8;          // (every KSAMPLE-th launch is sampled) recorded on the stream that kernel runs on
     int ksample = KSAMPLE;                     // PBRE_KSAMPLE: A/B of the sampling interval
     hipEvent_t ev_k[KRING][2] = {};
-    long k_steps = 0, launches = 0;
+    long k_steps = 0, launches = 0, launches3 = 0;      // launches3: steps whose k_fast was the 3-waves-per-SIMD variant
     double ms[3] = {0, 0, 0};
     int zero_copy = 3;                 // PBRE_ZERO_COPY: pbre_step lets the kernels access page-locked host buffers directly (bit 0 actions, bit 1 rows; 0: staged copies)
     bool have_snapshot = false;        // a full pbre_reset has recorded the settled snapshot (rst_q, rst_objz)
@@ -421,6 +421,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 : (hint + FTPB - 1) / FTPB * 2) + 8;
         fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
     }
+    if (fast3) c->launches3++;
     if (fast3)
         hipLaunchKernelGGL((k_fast<MODE, 3>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
@@ -683,7 +684,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_ok = nc == 0 ? 1 : 0;         // every env of the freshly reset batch is in the simple class
         }
     }
-    c->k_steps = 0; c->launches = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
+    c->k_steps = 0; c->launches = 0; c->launches3 = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -887,7 +888,8 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
     if (c->wide) return wide_kernel_info(c->wide, info, n);
     hipFuncAttributes fa;
-    int rf = -1, rg = -1, rr = -1;
+    int rf = -1, rg = -1, rr = -1, rf3 = -1;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 3>) == hipSuccess) rf3 = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 2>) == hipSuccess) rf = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
@@ -900,8 +902,9 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
         (void)hipMemcpy(&complex_sum, c->main.count + 3 * NB + 1, sizeof(int), hipMemcpyDeviceToHost);
         for (int k = 0; k < NB; k++) complex_now += cnt[k];
     }
-    const int v[8] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum};
-    for (int i = 0; i < n; i++) info[i] = i < 8 ? v[i] : 0;
+    const int v[10] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
+                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1};
+    for (int i = 0; i < n; i++) info[i] = i < 10 ? v[i] : 0;
     return PBRE_OK;
 }
 

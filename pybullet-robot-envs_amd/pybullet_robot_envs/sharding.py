@@ -72,3 +72,66 @@ class ShardedEngine(object):
         self.engine.step_device(actions.data_ptr(), out.data_ptr(), stream)
         if self.distributed:
             self.dist.gather(out, gathered if self.rank == 0 else None, dst=0)
+
+
+class GatherPipeline(object):
+    """The per-step data path of a sharded rollout, device resident: step kernels on torch's current stream, then ONE gather of
+    the [n_local, obs_dim + 2] rows to rank 0 (RCCL over xGMI with the "nccl" backend), asynchronous and double buffered -- the
+    gather of step k overlaps with the kernels of step k + 1, and an output buffer is reused only after the gather that read it
+    has completed.  `bench.py --gpus N` times exactly this loop; tests/test_gpu_rccl.py runs it against an unsharded engine.
+      gather=False     every rank's consumer reads its own rows (no collective at all);
+      host_staged=True the rows go through host memory (gloo; single-GPU test boxes where RCCL refuses two ranks on one device)."""
+
+    def __init__(self, sharded, device, gather=True, host_staged=False):
+        import torch
+        self.torch, self.sh, self.dev = torch, sharded, device
+        self.gather, self.host_staged = gather, host_staged
+        eng = sharded.engine
+        n = sharded.n_local
+        self.out = [torch.zeros((n, eng.obs_dim + 2), device=device, dtype=torch.float32) for _ in range(2)]
+        self.gathered = None
+        if sharded.distributed and sharded.rank == 0:
+            self.gathered = [[torch.zeros_like(self.out[0]) for _ in range(sharded.world)] for _ in range(2)]
+        self.pending = [None, None]
+        self.k = 0
+
+    def step(self, actions, stream=None, timing_events=None):
+        """enqueue one step of the local shard on `actions` [n_local, act_dim] (CUDA tensor) and its gather; returns the buffer index b:
+        rank 0 finds the stacked rows of this step in self.gathered[b] after wait(b) (self.out[b] with one rank).  timing_events: a pair
+        of torch events; the second is recorded between the step kernels and the gather (bench.py's kernel-only figure)"""
+        sh, b = self.sh, self.k & 1
+        self.wait(b)                                   # the gather that read this buffer two steps ago
+        if stream is None:
+            stream = _capi.torch_stream(actions.device)
+        sh.engine.step_device(actions.data_ptr(), self.out[b].data_ptr(), stream)
+        if timing_events is not None:
+            timing_events[1].record()
+        if sh.distributed and self.gather:
+            if self.host_staged:
+                self.torch.cuda.current_stream(self.dev).synchronize()
+                h = self.out[b].cpu()
+                outs = [self.torch.empty_like(h) for _ in range(sh.world)] if sh.rank == 0 else None
+                sh.dist.gather(h, outs, dst=0)
+                if sh.rank == 0:
+                    for g, o in zip(self.gathered[b], outs):
+                        g.copy_(o)
+            else:
+                self.pending[b] = sh.dist.gather(self.out[b], self.gathered[b] if sh.rank == 0 else None, dst=0, async_op=True)
+        self.k += 1
+        return b
+
+    def wait(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def drain(self):
+        self.wait(0)
+        self.wait(1)
+
+    def rows(self, b):
+        """stacked [total_envs, obs_dim + 2] rows of the step that returned b (rank 0; None elsewhere)"""
+        self.wait(b)
+        if not self.sh.distributed or not self.gather:
+            return self.out[b]
+        return self.torch.cat(self.gathered[b], 0) if self.sh.rank == 0 else None

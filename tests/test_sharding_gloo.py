@@ -37,11 +37,26 @@ def _worker(rank, world, port, total, steps, q):
     for k in range(steps):
         r = se.step(acts[k, se.env_id_base:se.env_id_base + se.n_local])
         res.append(None if r is None else np.concatenate([r[0], r[1][:, None], r[2][:, None]], 1))
+    # the asynchronous, double-buffered gather loop bench.py --gpus N times (sharding.GatherPipeline), on CPU tensors over gloo: the
+    # host emulation's pbre_step_device takes host pointers, the `stream` argument is ignored
+    import torch
+    from pybullet_robot_envs.sharding import GatherPipeline
+    pipe = GatherPipeline(se, torch.device("cpu"), gather=True, host_staged=False)
+    got = []
+    for k in range(steps):
+        a = torch.from_numpy(np.ascontiguousarray(acts[k, se.env_id_base:se.env_id_base + se.n_local]))
+        b = pipe.step(a, stream=1)
+        if k >= 1:
+            r = pipe.rows(b ^ 1)
+            got.append(None if r is None else r.clone().numpy())
+    pipe.drain()
+    r = pipe.rows((steps - 1) & 1)
+    got.append(None if r is None else r.clone().numpy())
     dist.barrier()
     if rank == 0:
-        q.put(res)
+        q.put(res + got)
     else:
-        assert all(r is None for r in res)
+        assert all(r is None for r in res) and all(g is None for g in got)
     dist.destroy_process_group()
 
 
@@ -65,6 +80,9 @@ def test_two_rank_gather_equals_single_process(panda, emu_lib):
     for k in range(steps):
         o, r, d = eng.step(acts[k])
         assert np.array_equal(res[k + 1], np.concatenate([o, r[:, None], d[:, None]], 1))
+    for k in range(steps):                 # the pipelined loop continued from the same state with the same actions again
+        o, r, d = eng.step(acts[k])
+        assert np.array_equal(res[steps + 1 + k], np.concatenate([o, r[:, None], d[:, None]], 1))
 
 
 def _hands_worker(rank, world, port, total, steps, q):
