@@ -171,7 +171,9 @@ struct Fast {
             }
             const bool c01 = R.m[0] < R.m[4], c12 = R.m[4] < R.m[8], c02 = R.m[0] < R.m[8];
             const bool use2 = (c01 && c12) || (!c01 && c02), use1 = c01 && !c12;
-            q = use2 ? c[2] : (use1 ? c[1] : c[0]);
+            // (component-wise selects: `use2 ? c[2] : ...` on the structs became an indexed load from an LDS copy of c[], 3 KB per wave)
+            q.x = use2 ? c[2].x : (use1 ? c[1].x : c[0].x); q.y = use2 ? c[2].y : (use1 ? c[1].y : c[0].y);
+            q.z = use2 ? c[2].z : (use1 ? c[1].z : c[0].z); q.w = use2 ? c[2].w : (use1 ? c[1].w : c[0].w);
         }
         return q;
     }

@@ -7,7 +7,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ev = []
 for r in rows:
     k = r["Kernel_Name"]
-    name = "k_fast" if "k_fast<7>" in k else ("k_row_list" if "k_row_list<7>" in k else ("k_fast_rc" if "k_fast_rc<7>" in k else None))
+    name = "k_fast" if ("k_fast<7>" in k or "k_fast<7," in k) else ("k_row_list" if "k_row_list<7>" in k else ("k_fast_rc" if "k_fast_rc<7>" in k else None))
     if name:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 ev.sort()
