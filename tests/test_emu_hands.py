@@ -65,3 +65,8 @@ def test_hands_apply_action_max_vel(emu_lib):
     nd, vo = eng.ndof, eng.v_off
     assert np.abs(se[:, :nd] - so[:, :nd]).max() < 5e-6 and np.abs(se[:, vo:vo + nd] - so[:, vo:vo + nd]).max() < 1e-3
     assert np.abs(so[:, vo:vo + nd]).max() <= 0.4 + 1e-3 and np.abs(so[0, vo + np.array(info["controlled"])]).max() > 0.39     # the bound binds
+
+
+def test_hands_five_fingertips_on_the_object(emu_lib):
+    w = parity.check_hands_five_fingertips(_capi.Engine, emu_lib, "r")
+    assert w["fingertips_in_contact"] == 5

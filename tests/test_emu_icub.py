@@ -108,3 +108,14 @@ def test_icub_env_inside_a_task_env_refuses_robot_level_commands(emu_lib):
     with pytest.raises(RuntimeError):
         env._robot.apply_action([0.3, 0.2, 0.8])
     env.close()
+
+
+def test_icub_crafted_contact_states(emu_lib):
+    """hand on the object / on the table / both / a joint beyond its limit: one step each against the oracle, per quantity"""
+    rep = parity.check_icub_contact_states(_capi.Engine, emu_lib, n_each=3)
+    assert rep["states"] == 12
+
+
+def test_icub_push_closed_loop_against_oracle(emu_lib):
+    rep = parity.check_icub_push_closed_loop(_capi.Engine, emu_lib, n=2)
+    assert rep["touched_envs"] == 2

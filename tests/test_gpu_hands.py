@@ -162,3 +162,10 @@ def test_config5_at_size(hip_lib):
     obs, _ = robot.get_observation()
     assert obs.shape == (n, 46) and np.isfinite(obs).all()
     _client.disconnect(cid)
+
+
+@pytest.mark.parametrize("arm", ["r", "l"])
+def test_hands_five_fingertips_on_the_object(hip_lib, arm):
+    w = parity.check_hands_five_fingertips(_capi.Engine, hip_lib, arm)
+    print("five fingertips (%s):" % arm, w)
+    assert w["fingertips_in_contact"] == 5

@@ -190,3 +190,19 @@ def test_icub_env_robot_level_batch(hip_lib):
     assert np.isfinite(st).all() and np.array_equal(st, np.broadcast_to(st[0], st.shape))
     assert robot.get_object_pose().shape == (n, 7) and robot.get_joint_positions().shape == (n, 20)
     _client.disconnect(cid)
+
+
+@pytest.mark.parametrize("lane", ["1", "0"])
+def test_icub_crafted_contact_states(hip_lib, monkeypatch, lane):
+    """48 crafted contact states (hand on the object, on the table, both, a joint beyond its limit) through the lane-per-env pipeline
+    (kw_quad / kw_quad_rc; lane = 1) and the lane-group kernel (lane = 0): one step each against the oracle, per-quantity bounds."""
+    monkeypatch.setenv("PBRE_ICUB_LANE", lane)
+    rep = parity.check_icub_contact_states(_capi.Engine, hip_lib, n_each=12)
+    print("iCub crafted contact states (PBRE_ICUB_LANE=%s):" % lane, rep)
+    assert rep["states"] == 48
+
+
+def test_icub_push_closed_loop_against_oracle(hip_lib):
+    rep = parity.check_icub_push_closed_loop(_capi.Engine, hip_lib, n=8)
+    print("iCub closed-loop push:", rep)
+    assert rep["touched_envs"] == 8

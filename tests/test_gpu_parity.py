@@ -363,3 +363,11 @@ def test_world_check_contact(panda, hip_lib):
     """WorldEnv.check_contact on states downloaded from the GPU engine (host-side query, model/contacts.py) against the oracle's contact list"""
     from test_vec_env import check_world_contacts
     check_world_contacts(panda, hip_lib)
+
+
+def test_scripted_push_closed_loop_against_oracle(panda, hip_lib):
+    """Long horizon WITH pushing: the scripted push, closed loop in the engine (GPU) and in the oracle, free running for 280 steps; the
+    cubes' final displacements compared per env."""
+    rep = parity.check_panda_push_closed_loop(_capi.Engine, hip_lib, panda["table"], n=16)
+    print("closed-loop push:", rep)
+    assert rep["touched_envs"] == 16
