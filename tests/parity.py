@@ -339,11 +339,14 @@ def make_icub_pair(Engine, lib, n, task=0, control_arm="l", use_ik=1, control_or
 # Contact steps of the iCub engines (hand on the table / on the object: stiff motor-vs-contact conflicts, 150 sweeps amplify fp32
 # rounding as on the Panda, TOL_CONTACT), per quantity; measured values: profiles/r03_parity_report_hip.json (GPU) and the lane
 # emulation, bounds ~4x the worst of the two
-TOL_ICUB_CONTACT = {"q": 1e-5, "qd": 2.5e-3, "obj_pos": 1e-6, "obj_quat": 5e-6, "obj_v": 2e-4, "obj_w": 5e-3,
-                    "obs_ee_pos": 3e-6, "obs_ee_eul": 1e-5, "obs_ee_vel": 5e-4, "obs_rest": 2e-5}
+# (worst measured, GPU: q 9.3e-7, qd 2.2e-4, obj_pos 5.1e-6 / obj_v 1.2e-3 -- the object squeezed between hand and table --, obj_quat
+# 6.3e-7, obj_w 3.0e-4, EE position 2.3e-7, EE Euler angles 7.8e-7, EE velocity 3.3e-5 m/s)
+TOL_ICUB_CONTACT = {"q": 4e-6, "qd": 1e-3, "obj_pos": 2e-5, "obj_quat": 3e-6, "obj_v": 5e-3, "obj_w": 1.5e-3,
+                    "obs_ee_pos": 1e-6, "obs_ee_eul": 3e-6, "obs_ee_vel": 1.5e-4, "obs_rest": 2e-5}
 # after reset(): 201-202 free-running settle steps in the engine and in the oracle (no re-synchronisation in between)
-TOL_ICUB_RESET = {"q": 2e-5, "qd": 2e-4, "obj_pos": 2e-6, "obj_quat": 2e-6, "obj_v": 1e-4, "obj_w": 1e-3,
-                  "obs_ee_pos": 2e-5, "obs_ee_eul": 5e-5, "obs_ee_vel": 2e-4, "obs_rest": 5e-5}
+# (worst measured: q 2.2e-7, qd 1.1e-5, obj_pos 1.6e-7, EE position 2.0e-7, EE Euler angles 3.8e-7, EE velocity 3.0e-6)
+TOL_ICUB_RESET = {"q": 1e-6, "qd": 5e-5, "obj_pos": 6e-7, "obj_quat": 4e-7, "obj_v": 3e-5, "obj_w": 1e-6,
+                  "obs_ee_pos": 8e-7, "obs_ee_eul": 1.5e-6, "obs_ee_vel": 1.5e-5, "obs_rest": 1.5e-6}
 
 
 def compare_groups(eng, se, so, ob, out, tol, use_ik, worst, context="", tail=0, sel=None):
@@ -676,10 +679,12 @@ def make_hands_pair(Engine, lib, n, control_arm="r", use_ik=0, obj_std=0.0, **kw
 # iCub with hands (one env per wavefront), one step from identical fp32 states; measured on the lane emulation: joint control q 6e-8,
 # qd 5e-6; IK control q 6e-7, qd 1.4e-4, EE velocity 9e-6 m/s
 # hands, fingertip / palm contacts on the object and after reset (202 free-running settle steps of 60 joints): per quantity
-TOL_HANDS_CONTACT = {"q": 2e-5, "qd": 5e-3, "obj_pos": 1e-6, "obj_quat": 5e-6, "obj_v": 5e-4, "obj_w": 1e-2,
-                     "obs_ee_pos": 3e-6, "obs_ee_eul": 1e-5, "obs_ee_vel": 5e-4, "obs_rest": 2e-5}
-TOL_HANDS_RESET = {"q": 5e-5, "qd": 5e-4, "obj_pos": 2e-6, "obj_quat": 2e-6, "obj_v": 1e-4, "obj_w": 1e-3,
-                   "obs_ee_pos": 2e-5, "obs_ee_eul": 5e-5, "obs_ee_vel": 2e-4, "obs_rest": 1e-4}
+# (worst measured, contacts: q 1.4e-7, qd 3.0e-5, obj_quat 1.0e-6, obj_v 1.5e-5, obj_w 4.9e-4, observation tail entries 2.0e-6; reset: q 1.0e-5
+# and qd 1.0e-4 with IK control -- 202 settle steps towards an IK target that differs by the IK's own stopping tolerance --, else <= 4e-7)
+TOL_HANDS_CONTACT = {"q": 6e-7, "qd": 1.5e-4, "obj_pos": 2e-7, "obj_quat": 4e-6, "obj_v": 6e-5, "obj_w": 2e-3,
+                     "obs_ee_pos": 4e-7, "obs_ee_eul": 1.2e-6, "obs_ee_vel": 3e-5, "obs_rest": 8e-6}
+TOL_HANDS_RESET = {"q": 4e-5, "qd": 4e-4, "obj_pos": 6e-7, "obj_quat": 4e-7, "obj_v": 3e-5, "obj_w": 1e-6,
+                   "obs_ee_pos": 2e-7, "obs_ee_eul": 1.5e-6, "obs_ee_vel": 6e-6, "obs_rest": 4e-5}
 TOL_HANDS = {"q": 5e-6, "qd": 1e-3, "obj_pos": 3e-7, "obj_quat": 8e-7, "obj_v": 5e-5, "obj_w": 5e-6,
              "obs_ee_pos": 1e-6, "obs_ee_eul": 3e-6, "obs_ee_vel": 1e-4, "obs_rest": 5e-6}
 
@@ -1502,7 +1507,8 @@ def check_panda_push_closed_loop(Engine, lib, table, n=8, seed=5):
     loop -- every side tracks the joint targets from its OWN joint angles -- in the engine and in the oracle, free running for 280
     steps from the same reset.  The robot-object contact is contact-chaotic in detail (a 1e-7 difference decides which sphere touches
     first), but the push is a robust macroscopic event: per env, the cube's final displacement agrees within 1.5 cm (and 25 % of its
-    length), every cube moved more than 3 cm in both, and the arm -- position controlled -- ends within 2e-3 rad."""
+    length; measured on the GPU, 16 envs pushed 11 - 28 cm: 12 of them within 0.2 mm, the worst 2.8 cm on a 21 cm push), every cube moved
+    more than 3 cm in both, and the arm -- position controlled -- ends within 2e-3 rad."""
     eng, ora = make_pair(Engine, lib, table, n, obj_std=0.03, tg_std=0.0, max_steps=10 ** 6)
     ora.task.max_steps = 10 ** 6
     st = check_reset(eng, ora, n)
@@ -1536,7 +1542,8 @@ def check_icub_push_closed_loop(Engine, lib, n=8, steps=330, seed=6):
     (joint control: with Cartesian control the restated IK closed loop is itself chaotic -- two branches of the damped-least-squares
     solution a rounding apart whip the arm differently, section 2 of DESIGN.md -- so a per-env comparison is only meaningful in joint
     space; the joint targets of the sweep come from the oracle's IK once, before the rollout).  Engine and oracle run free from the same
-    reset; per env the cube's final displacement agrees within 1 cm (and 15 % of its length), every cube was pushed > 2 cm in both."""
+    reset; per env the cube's final displacement agrees within 3 mm (and 5 % of its length; measured: 0.5 mm on pushes of 2.5 - 8.6 cm),
+    every cube was pushed > 2 cm in both."""
     eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm="l", use_ik=0, obj_std=0.03, tg_std=0.0, max_steps=10 ** 6)
     ora.task.max_steps = 10 ** 6
     eng.reset()
@@ -1578,5 +1585,5 @@ def check_icub_push_closed_loop(Engine, lib, n=8, steps=330, seed=6):
            "worst_disp_diff_cm": float(100 * np.linalg.norm(de - do, axis=1).max()), "arm_q_diff": float(np.abs(se[:, :nd] - st[:, :nd]).max())}
     if not MEASURE:
         assert rep["touched_envs"] == n and (le > 0.02).all() and (lo_ > 0.02).all(), rep
-        assert (np.linalg.norm(de - do, axis=1) <= 0.01 + 0.15 * lo_).all(), rep
+        assert (np.linalg.norm(de - do, axis=1) <= 0.003 + 0.05 * lo_).all(), rep
     return rep

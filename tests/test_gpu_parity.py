@@ -65,18 +65,22 @@ def test_device_glue_only(panda, hip_lib):
 
 
 def test_matches_host_lane_emulation(panda, hip_lib, emu_lib):
-    # same algorithm, same fp32 arithmetic order: GPU vs CPU lane emulation agree to a few ulp
+    """The CPU lane emulation compiles the same source (csrc/pbre_fast.hpp, pbre_core.hpp) without FMA contraction and with libm's
+    division / square root, so it is not bit-identical to the device; one step from the same state agrees per quantity within a
+    quarter of the single-step bounds against the oracle (parity.TOL), the 201-step reset within 1e-5 (positions, angles)."""
     n = 20
     kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2)
     g = _capi.Engine(panda["table"], lib=hip_lib, **kw)
     e = _capi.Engine(panda["table"], lib=emu_lib, **kw)
     og, oe = g.reset(), e.reset()
-    assert np.abs(og - oe).max() < 1e-4
+    assert np.abs(g.get_state()[:, :16] - e.get_state()[:, :16]).max() < 1e-5 and np.abs(og - oe).max() < 1e-4
     e.set_state(g.get_state())
     a = np.random.default_rng(6).uniform(-1, 1, (n, 7)).astype(np.float32)
-    rg, re_ = g.step(a), e.step(a)
-    assert np.abs(g.get_state() - e.get_state()).max() < 1e-4
-    assert np.abs(rg[0] - re_[0]).max() < 1e-3
+    (obg, rwg, dng), (obe, rwe, dne) = g.step(a), e.step(a)
+    out_e = np.concatenate([obe, rwe[:, None], dne[:, None]], 1).astype(np.float64)
+    q = parity.panda_quantities(g.get_state(), e.get_state().astype(np.float64), obg, out_e, rwg)
+    parity.assert_within(q, dict((k, 0.25 * v) for k, v in parity.TOL.items()), "(GPU against the CPU lane emulation)")
+    assert np.array_equal(dng, dne)
 
 
 def test_sharding_invariance(panda, hip_lib):
