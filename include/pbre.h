@@ -19,7 +19,8 @@
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
  *   X[12], X[13] hand-object / object-target distance at reset (iCub push reward)   X[14] left the apply_action loop (action_repeat > 1)
- *   Panda task envs: X[12], X[13], X[15] per-env object mass / lateral friction / 1 + linear damping (pbre_set_physics_per_env; 0 = batch value)
+ *   Panda task envs: X[12], X[13], X[15] per-env object mass / lateral friction / 1 + linear damping, V[15] 1 + the robot links' linear damping
+ *   (pbre_set_physics_per_env; 0 = batch value)
  * Robot-level engines (iCub with hands: W = 128, nd = 60; Panda: W = 32, nd = 9, fingertip slots 0 / 1 = left / right finger): additionally Q[nd+7..nd+12) mean normal force on each fingertip of the controlled hand,
  *   Q[nd+12] fingertips in contact with the object, Q[nd+13] robot-object contact points (check_contact_fingertips /
  *   check_collision, icub_env_with_hands.py:246-318); these 7 values are also the tail of the observation.
@@ -232,10 +233,11 @@ int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
  * linearDamping=) of change_physics_params, R/envs/panda_envs/panda_push_gym_env.py:362-364, as the reference's Dyn-Rand training
  * calls it once per env).  Arrays are host [num_envs] float32 or NULL (unchanged); env_mask NULL = all envs.  The values live in the
  * env's state record (X[12] mass, X[13] lateral friction, X[15] 1 + linear damping; 0 = the batch value of pbre_physics), survive
- * resets and travel with pbre_get_state / pbre_set_state; the (cube) object's inertia scales with its mass.  The robot links' linear
- * damping (`robot_damping`, :366-367) is the batch-uniform pbre_physics.lin_damping.  Panda task envs only. */
+ * resets and travel with pbre_get_state / pbre_set_state; the (cube) object's inertia scales with its mass.  robot_lin_damping: the
+ * robot links' linear damping (`robot_damping`, :366-367: p.changeDynamics(robot_id, i, linearDamping=...)), per env as well, in
+ * V[15] (1 + damping; 0 = the batch value pbre_physics.lin_damping).  Panda task envs only. */
 int pbre_set_physics_per_env(pbre_ctx* ctx, const uint8_t* env_mask, const float* obj_mass, const float* obj_mu,
-                             const float* obj_lin_damping);
+                             const float* obj_lin_damping, const float* robot_lin_damping);
 
 /* observation limits used by the Gym Box space / scale_gym_data (create_gym_spaces, :83-103) */
 int pbre_obs_limits(const pbre_ctx* ctx, float* low, float* high);

@@ -517,6 +517,8 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
         if (X[12] > 0) { for (int k = 0; k < 3; k++) pp.obj_inertia[k] *= (double)X[12] / pp.obj_mass; pp.obj_mass = (double)X[12]; }
         if (X[13] > 0) pp.obj_mu = (double)X[13];
         if (X[15] > 0) okl = X[15] - 1;
+        /* ... and V[15]: 1 + linear damping of the robot's links (the `robot_damping` argument, :365-367), 0 = the batch value */
+        if (st[OV(m) + 15] > 0) pp.lin_damping = (double)st[OV(m) + 15] - 1;
     }
     const orc_params* prm = &pp;
     const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : (m->ntip > 0 ? 4 : ORC_NC_RO);      /* robot-level Panda: both spheres of both fingers */

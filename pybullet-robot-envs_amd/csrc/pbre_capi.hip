@@ -240,7 +240,7 @@ __global__ void k_next_episode(const float* __restrict__ state, const int* __res
     if (i >= cpad) return;
     const float* src = state + (size_t)idx[i < cnt ? i : cnt - 1] * STATE;
     ep[i] = (unsigned)((int)src[37] + 1);
-    if (work != state) { float* dst = work + (size_t)i * STATE; dst[44] = src[44]; dst[45] = src[45]; dst[47] = src[47]; }
+    if (work != state) { float* dst = work + (size_t)i * STATE; dst[44] = src[44]; dst[45] = src[45]; dst[47] = src[47]; dst[31] = src[31]; }
 }
 // dst[idx[i]] <- src[i], 48 floats per record
 __global__ void k_scatter(float* __restrict__ dst, const float* __restrict__ src, const int* __restrict__ idx, int cnt) {
@@ -835,25 +835,28 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     return PBRE_OK;
 }
 
-int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping) {
+int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping,
+                             const float* robot_lin_damping) {
     if (!c) return PBRE_E_ARG;
     if (c->wide) { c->err = "pbre_set_physics_per_env: implemented for the Panda task envs (change_physics_params, panda_push_gym_env.py:362-368)"; return PBRE_E_UNSUPPORTED; }
     for (int e = 0; e < c->n; e++) {
         if (mask && !mask[e]) continue;
-        if ((obj_mass && !(obj_mass[e] > 0.f)) || (obj_mu && !(obj_mu[e] > 0.f)) || (obj_lin_damping && !(obj_lin_damping[e] >= 0.f))) {
+        if ((obj_mass && !(obj_mass[e] > 0.f)) || (obj_mu && !(obj_mu[e] > 0.f)) || (obj_lin_damping && !(obj_lin_damping[e] >= 0.f)) ||
+            (robot_lin_damping && !(robot_lin_damping[e] >= 0.f))) {
             c->err = "pbre_set_physics_per_env: mass and friction must be > 0, damping >= 0"; return PBRE_E_ARG;
         }
     }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(quiesce(c));
-    // three strided columns of the state records: X[12] mass, X[13] lateral friction, X[15] 1 + linear damping (0 = batch value)
+    // strided columns of the state records: X[12] mass, X[13] lateral friction, X[15] 1 + linear damping of the object, V[15] 1 + linear
+    // damping of the robot's links (0 = batch value)
     std::vector<float> col((size_t)c->n);
-    const float* src[3] = {obj_mass, obj_mu, obj_lin_damping};
-    const int slot[3] = {44, 45, 47};
-    for (int k = 0; k < 3; k++) {
+    const float* src[4] = {obj_mass, obj_mu, obj_lin_damping, robot_lin_damping};
+    const int slot[4] = {44, 45, 47, 31};
+    for (int k = 0; k < 4; k++) {
         if (!src[k]) continue;
         HIPCHK(hipMemcpy2D(col.data(), 4, c->main.state + slot[k], (size_t)STATE * 4, 4, c->n, hipMemcpyDeviceToHost));
-        for (int e = 0; e < c->n; e++) if (!mask || mask[e]) col[e] = src[k][e] + (k == 2 ? 1.f : 0.f);
+        for (int e = 0; e < c->n; e++) if (!mask || mask[e]) col[e] = src[k][e] + (k >= 2 ? 1.f : 0.f);
         HIPCHK(hipMemcpy2D(c->main.state + slot[k], (size_t)STATE * 4, col.data(), 4, 4, c->n, hipMemcpyHostToDevice));
     }
     return PBRE_OK;

@@ -445,7 +445,10 @@ struct Core {
             V3 w = Vs.a;
             V3 vc = add(Vs.l, cross(w, c));
             V3 ac = add(add(As.l, cross(As.a, c)), cross(w, vc));
-            F sl = L::fma(L::c(P.kl), norm(vc), L::c(P.kl));           // Bullet velocity damping K1 + K2|v|
+            // (Panda task envs: V[15] = 1 + this env's robot link damping, 0 = the batch value; pbre_set_physics_per_env)
+            F r_kl = L::c(P.kl);
+            if (W == 16 && !SH::MREC) { const F v15 = L::bcast(Vr, 15); r_kl = L::sel(L::gt(v15, zero), v15 - one, r_kl); }
+            F sl = L::fma(r_kl, norm(vc), r_kl);           // Bullet velocity damping K1 + K2|v|
             V3 f = scl(add(ac, scl(vc, sl)), m);
             V3 Iww = mv(Iw, w);
             F sa = L::fma(L::c(P.ka), norm(w), L::c(P.ka));
@@ -1363,9 +1366,9 @@ struct Core {
         float* ob = st + LC;                       // object position (3) + quaternion (4) inside the Q record
         float* X = st + 2 * W;
         // (the per-env object parameters X[12], X[13], X[15] of a Panda task env are not part of the episode: a reset keeps them)
-        const float k12 = st[2 * W + 12], k13 = st[2 * W + 13], k15 = st[2 * W + 15];
+        const float k12 = st[2 * W + 12], k13 = st[2 * W + 13], k15 = st[2 * W + 15], v15 = st[W + 15];      // (V[15]: the robot's per-env link damping)
         for (int k = 0; k < STATE; k++) st[k] = 0.f;
-        if (W == 16) { st[2 * W + 12] = k12; st[2 * W + 13] = k13; st[2 * W + 15] = k15; }
+        if (W == 16) { st[2 * W + 12] = k12; st[2 * W + 13] = k13; st[2 * W + 15] = k15; st[W + 15] = v15; }
         for (int k = 0; k < T.ndof; k++) st[k] = T.home[k];
         const float x_min = P.ws[0][0] + 0.05f, x_max = P.ws[0][1] - 0.1f;
         const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;

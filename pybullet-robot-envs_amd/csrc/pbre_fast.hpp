@@ -354,6 +354,8 @@ struct Fast {
         // per-env object parameters (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral friction,
         // X[15] 1 + linear damping; 0 = the batch value.  The inertia of the (cube) object scales with its mass.
         const float o_m = st[44] > 0.f ? st[44] : P.obj_m, o_mu = st[45] > 0.f ? st[45] : P.obj_mu, o_kl = st[47] > 0.f ? st[47] - 1.f : P.kl;
+        // ... and the robot links' linear damping (change_physics_params' robot_damping, panda_push_gym_env.py:365-367): V[15] = 1 + damping
+        const float r_kl = st[31] > 0.f ? st[31] - 1.f : P.kl;
 
         // ---- one forward sweep over the links: FK, joint axes, velocities, velocity-product accelerations,
         //      collision-sphere distances, per-link bias force and spatial inertia (world frame, about the world origin)
@@ -425,7 +427,7 @@ struct Fast {
                     V3 w = Va[j];
                     V3 vc = add(Vl[j], cross(w, c));
                     V3 ac = add(add(Al[j], cross(Aa[j], c)), cross(w, vc));
-                    float sl_ = fmaf(P.kl, norm(vc), P.kl);
+                    float sl_ = fmaf(r_kl, norm(vc), r_kl);
                     V3 f = scl(add(ac, scl(vc, sl_)), m);
                     V3 Iww = mv(Iw, w);
                     float sa_ = fmaf(P.ka, norm(w), P.ka);

@@ -309,18 +309,18 @@ class Engine:
                 setattr(ph, k, v)
         self._chk(self.lib.pbre_set_physics(self._ctx, C.byref(ph)))
 
-    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None):
-        """Per-env object mass / lateral friction / linear damping ([N] arrays or None = unchanged): domain randomisation of the
-        Panda task envs (reference change_physics_params, called per env and episode by the Dyn-Rand training)."""
+    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None, robot_lin_damping=None):
+        """Per-env object mass / lateral friction / linear damping and robot link damping ([N] arrays or None = unchanged): domain
+        randomisation of the Panda task envs (reference change_physics_params, called per env and episode by the Dyn-Rand training)."""
         def arr(x):
             if x is None:
                 return None
             a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, np.float32), (self.num_envs,)))
             return a
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        a, b, c = arr(obj_mass), arr(obj_mu), arr(obj_lin_damping)
+        a, b, c, d = arr(obj_mass), arr(obj_mu), arr(obj_lin_damping), arr(robot_lin_damping)
         self._chk(self.lib.pbre_set_physics_per_env(self._ctx, None if m is None else _fp(m), None if a is None else _fp(a),
-                                                    None if b is None else _fp(b), None if c is None else _fp(c)))
+                                                    None if b is None else _fp(b), None if c is None else _fp(c), None if d is None else _fp(d)))
 
     def timing(self):
         ms = (C.c_double * 4)()
@@ -418,11 +418,12 @@ class MultiEngine(object):
         for e in self.shards:
             e.set_physics(**fields)
 
-    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None):
+    def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None, robot_lin_damping=None):
         def part(x, k):
             return None if x is None else np.broadcast_to(np.asarray(x, np.float32), (self.num_envs,))[self._sl(k)]
         for k, e in enumerate(self.shards):
-            e.set_physics_per_env(part(obj_mass, k), part(obj_mu, k), part(obj_lin_damping, k), None if mask is None else np.asarray(mask)[self._sl(k)])
+            e.set_physics_per_env(part(obj_mass, k), part(obj_mu, k), part(obj_lin_damping, k), None if mask is None else np.asarray(mask)[self._sl(k)],
+                                  part(robot_lin_damping, k))
 
     def get_motor_state(self):
         return self._cat(self._map(lambda k: self.shards[k].get_motor_state()))

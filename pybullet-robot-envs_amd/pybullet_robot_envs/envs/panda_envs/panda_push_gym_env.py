@@ -29,14 +29,13 @@ class pandaPushGymEnv(PandaTaskBase):
     def change_physics_params(self, obj_mass, obj_friction, obj_dumping, robot_damping):
         """Domain randomisation hook of the reference (panda_push_gym_env.py:362-368: p.changeDynamics on the object's mass /
         lateral friction / linear damping, then on the arm links' linear damping).  Scalars apply to every env of the batch, [N]
-        arrays give every env its own object (the reference calls this per env and episode); the values persist across resets.
-        `robot_damping` is one constant for the batch (a scalar).  The reference's own loop over the arm links reads a
-        non-existent attribute (`_num_dof_no_fingers`, :366) and raises after the object was changed; here both parts are applied.
-        The cube's inertia is rescaled with its mass."""
-        if np.ndim(robot_damping) != 0:
-            raise ValueError("robot_damping is batch-uniform (a scalar)")
-        self._engine.set_physics(lin_damping=float(robot_damping))
-        self._engine.set_physics_per_env(obj_mass=obj_mass, obj_mu=obj_friction, obj_lin_damping=obj_dumping)
+        arrays give every env its own object and its own arm damping (the reference calls this per env and episode); the values persist
+        across resets.  The reference's own loop over the arm links reads a non-existent attribute (`_num_dof_no_fingers`, :366) and
+        raises after the object was changed; here both parts are applied (every robot link gets `robot_damping`).  The cube's inertia is
+        rescaled with its mass."""
+        n = self._engine.num_envs
+        rd = np.broadcast_to(np.asarray(robot_damping, np.float32), (n,))
+        self._engine.set_physics_per_env(obj_mass=obj_mass, obj_mu=obj_friction, obj_lin_damping=obj_dumping, robot_lin_damping=rd)
         return 0
 
     # host-side restatements of the reference helpers on the current state (the GPU step already returns them)

@@ -358,7 +358,8 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     c->cfg = cfg; c->P = P2;
     return PBRE_OK;
 }
-int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping) {
+int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping,
+                             const float* robot_lin_damping) {
     if (!c) return PBRE_E_ARG;
     if (c->sf != 48) { c->err = "pbre_set_physics_per_env: implemented for the Panda task envs"; return PBRE_E_UNSUPPORTED; }
     for (int e = 0; e < c->n; e++) {
@@ -367,6 +368,7 @@ int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_
         if (obj_mass) X[12] = obj_mass[e];
         if (obj_mu) X[13] = obj_mu[e];
         if (obj_lin_damping) X[15] = obj_lin_damping[e] + 1.f;
+        if (robot_lin_damping) c->state[(size_t)e * 48 + 31] = robot_lin_damping[e] + 1.f;
     }
     return PBRE_OK;
 }

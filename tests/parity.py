@@ -1222,9 +1222,10 @@ def check_per_env_physics(Engine, lib, table, n=8, flags=0):
     mass = rng.uniform(0.05, 0.4, n).astype(np.float32)
     mu = rng.uniform(0.3, 1.2, n).astype(np.float32)
     damp = rng.uniform(0.0, 0.3, n).astype(np.float32)
-    eng.set_physics_per_env(obj_mass=mass, obj_mu=mu, obj_lin_damping=damp)
+    rdamp = rng.uniform(0.0, 0.5, n).astype(np.float32)     # the arm links' linear damping, per env (robot_damping, :365-367)
+    eng.set_physics_per_env(obj_mass=mass, obj_mu=mu, obj_lin_damping=damp, robot_lin_damping=rdamp)
     se = eng.get_state()
-    assert np.array_equal(se[:, 44], mass) and np.array_equal(se[:, 45], mu) and np.array_equal(se[:, 47], damp + 1)
+    assert np.array_equal(se[:, 44], mass) and np.array_equal(se[:, 45], mu) and np.array_equal(se[:, 47], damp + 1) and np.array_equal(se[:, 31], rdamp + 1)
     st = se.astype(np.float64)
     st[:, 25:28] = [0.3, -0.2, 0.0]                        # sliding cubes: friction, mass and damping all matter
     # (a cube sliding on four saturated friction rows: its angular velocity carries the rounding of the contact impulses divided by
@@ -1238,13 +1239,32 @@ def check_per_env_physics(Engine, lib, table, n=8, flags=0):
     eng.step(a); s0 = eng.get_state()
     eng.set_state(st.astype(np.float32)); eng.step(a); s1 = eng.get_state()
     assert np.abs(s0[:, 25:27] - s1[:, 25:27]).max() > 1e-4
-    assert np.array_equal(s0[:, :9], s1[:, :9])            # the robot does not touch the object: unaffected
+    assert np.array_equal(s0[:, :9], s1[:, :9])            # the robot does not touch the object: unaffected by the object's parameters
+    # ... the robot's own damping: with the default (practically unbounded) motors a POSITION_CONTROL joint reaches its target velocity
+    # whatever the damping, so the check runs with force-limited motors (max_motor_impulse 0.02, as check_panda_force_limited): there
+    # the damping changes the arm's motion, the engine follows the oracle, and the untouched object is unaffected
+    e2, o2 = make_pair(Engine, lib, table, n, flags=flags, phys={"max_motor_impulse": 0.02})
+    o2.params.max_motor_impulse = 0.02
+    e2.reset()
+    e2.set_physics_per_env(robot_lin_damping=rdamp)
+    sd = e2.get_state().astype(np.float64)
+    assert np.array_equal(sd[:, 31], rdamp + 1)
+    sd[:, 16:23] = 1.0                                     # moving arm: the damping acts on the links' velocities
+    s32 = sd.astype(np.float32)
+    base = s32.copy(); base[:, 31] = 0
+    e2.set_state(base); e2.step(a); s2 = e2.get_state()
+    e2.set_state(s32); e2.step(a); s3 = e2.get_state()
+    big = rdamp > 0.2
+    assert np.abs(s2[big, 16:25] - s3[big, 16:25]).max() > 1e-4 and np.array_equal(s2[:, 9:16], s3[:, 9:16])
+    so3, _ = o2.batch_step(s32.astype(np.float64), a)
+    assert np.abs(s3[:, :9] - so3[:, :9]).max() < TOL_CONTACT["q"] and np.abs(s3[:, 16:25] - so3[:, 16:25]).max() < TOL_CONTACT["qd"]
+    e2.close()
     # resets (full, masked) keep the per-env values; a masked set changes only the selected envs
     eng.reset()
-    assert np.array_equal(eng.get_state()[:, [44, 45, 47]], np.stack([mass, mu, damp + 1], 1))
+    assert np.array_equal(eng.get_state()[:, [44, 45, 47, 31]], np.stack([mass, mu, damp + 1, rdamp + 1], 1))
     m = np.zeros(n, np.uint8); m[[1, n - 1]] = 1
     eng.reset(mask=m)
-    assert np.array_equal(eng.get_state()[:, [44, 45, 47]], np.stack([mass, mu, damp + 1], 1))
+    assert np.array_equal(eng.get_state()[:, [44, 45, 47, 31]], np.stack([mass, mu, damp + 1, rdamp + 1], 1))
     eng.set_physics_per_env(obj_mass=np.full(n, 0.2, np.float32), mask=m)
     want = mass.copy(); want[[1, n - 1]] = 0.2
     assert np.array_equal(eng.get_state()[:, 44], want)

@@ -161,7 +161,9 @@ def test_change_physics_params_env_class(emu_lib):
     assert env.change_physics_params([0.1, 0.2, 0.3], 0.7, [0.0, 0.1, 0.2], 0.05) == 0      # per-env object, separate robot damping
     s = env._engine.get_state()
     assert np.allclose(s[:, 44], [0.1, 0.2, 0.3]) and np.allclose(s[:, 45], 0.7) and np.allclose(s[:, 47], [1.0, 1.1, 1.2])
-    assert env._engine.get_physics().lin_damping == 0.05
+    assert np.allclose(s[:, 31], 1.05)                           # the arm links' damping lives in the record too (V[15] = 1 + damping)
+    assert env.change_physics_params(0.1, 0.7, 0.0, [0.0, 0.1, 0.3]) == 0                   # ... and may differ per env
+    assert np.allclose(env._engine.get_state()[:, 31], [1.0, 1.1, 1.3])
     env.close()
 
 
