@@ -52,6 +52,7 @@ enum { PBRE_ROBOT_PANDA_ARM = 3,   /* pbre_default_config only: the Panda with t
        PBRE_ROBOT_ICUB_HANDS = 2 };   /* icub_model_with_hands.sdf (R/envs/icub_envs/icub_env_with_hands.py): robot-level interface --
                                      absolute joint / hand-pose commands, persistent finger motors (pbre_set_motors), fingertip
                                      contact forces appended to the observation */
+enum { PBRE_SHAPE_BOX = 0, PBRE_SHAPE_SPHERE = 1, PBRE_SHAPE_CYLINDER = 2 };   /* pbre_physics.obj_shape (reference world_env.py:18-25, 179-216: obj_name) */
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
@@ -84,6 +85,10 @@ typedef struct {
                                          by the iCub's finger joints (c = 1 on links of inertia 1e-3) once their motors are force-limited
                                          (grasp, force 10) -- default for PBRE_ROBOT_ICUB_HANDS only.  Not available on the Panda's
                                          lane-per-env kernels (PBRE_E_UNSUPPORTED). */
+    int32_t obj_shape;                /* PBRE_SHAPE_*: the object's collision primitive.  BOX: half extents obj_h.  SPHERE: radius obj_h[0]
+                                         (YcbTennisBall, pear, strawberry stand-ins: they roll).  CYLINDER: about the object's local z,
+                                         radius obj_h[0], half height obj_h[2] (the cans, duck_vhacd).  Round objects are stepped by the
+                                         per-env object solver / the lane-group kernels (every engine), never by k_fast's in-line cube rows. */
 } pbre_physics;
 
 typedef struct {

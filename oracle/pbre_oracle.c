@@ -433,6 +433,69 @@ static real sphere_box(const real* sc, real sr, const real* bc, const real* Rb, 
     return dist;
 }
 
+/* sphere vs the object primitive (orc_params.obj_shape; stand-ins of the reference's round objects -- YcbTennisBall, the cans, pear,
+ * duck_vhacd: world_env.py:18-25, 179-216).  Same contract as sphere_box: signed distance, n = world normal object -> sphere, pb = point
+ * on the object.  shape 1: sphere of radius h[0]; shape 2: capped cylinder about the object's local z, radius h[0], half height h[2]. */
+static real sphere_shape(int shape, const real* sc, real sr, const real* bc, const real* Rb, const real* h, real* n, real* pb) {
+    if (shape == 0) return sphere_box(sc, sr, bc, Rb, h, n, pb);
+    real d[3];
+    for (int k = 0; k < 3; k++) d[k] = sc[k] - bc[k];
+    if (shape == 1) {
+        real len = norm3(d);
+        if (len < (real)1e-9) { n[0] = 0; n[1] = 0; n[2] = 1; } else for (int k = 0; k < 3; k++) n[k] = d[k] / len;
+        for (int k = 0; k < 3; k++) pb[k] = bc[k] + n[k] * h[0];
+        return len - h[0] - sr;
+    }
+    real dl[3], cl[3], nl[3], dist;
+    m3T_v(Rb, d, dl);
+    const real rho = (real)sqrt((double)(dl[0] * dl[0] + dl[1] * dl[1]));
+    const real ux = rho > (real)1e-12 ? dl[0] / rho : 1, uy = rho > (real)1e-12 ? dl[1] / rho : 0;      /* radial unit vector */
+    const real rc = rho > h[0] ? h[0] : rho, zc = dl[2] < -h[2] ? -h[2] : (dl[2] > h[2] ? h[2] : dl[2]);
+    cl[0] = ux * rc; cl[1] = uy * rc; cl[2] = zc;
+    real df[3] = {dl[0] - cl[0], dl[1] - cl[1], dl[2] - cl[2]};
+    real len = norm3(df);
+    if (len >= (real)1e-9) {                            /* centre outside the solid */
+        for (int k = 0; k < 3; k++) nl[k] = df[k] / len;
+        dist = len - sr;
+    } else {                                            /* inside: leave through the nearer of the lateral surface and the caps */
+        const real er = h[0] - rho, ez = h[2] - (real)fabs((double)dl[2]);
+        if (er <= ez) { nl[0] = ux; nl[1] = uy; nl[2] = 0; cl[0] = ux * h[0]; cl[1] = uy * h[0]; cl[2] = dl[2]; dist = -er - sr; }
+        else { nl[0] = 0; nl[1] = 0; nl[2] = dl[2] >= 0 ? (real)1 : (real)-1; cl[0] = dl[0]; cl[1] = dl[1]; cl[2] = nl[2] * h[2]; dist = -ez - sr; }
+    }
+    m3_v(Rb, nl, n);
+    real t[3]; m3_v(Rb, cl, t);
+    for (int k = 0; k < 3; k++) pb[k] = bc[k] + t[k];
+    return dist;
+}
+
+/* The object's candidate contact points against its support surface, as offsets from its centre in WORLD axes (8 slots; returns 0 for
+ * a slot the shape does not use).  box: the 8 vertices.  sphere: the lowest point.  cylinder: per cap three rim points at 0 / 120 /
+ * 240 degrees (slots 0-2 bottom cap, 4-6 top cap; an upright can stands on a tripod) and the rim's lowest point (slots 3 / 7: the
+ * generator a lying can rolls on; undefined -- unused -- while the axis is vertical). */
+static int shape_candidate(int shape, const real* h, const real* Ro, int v, real* r) {
+    if (shape == 0) {
+        real l[3] = {(v & 1 ? h[0] : -h[0]), (v & 2 ? h[1] : -h[1]), (v & 4 ? h[2] : -h[2])};
+        m3_v(Ro, l, r);
+        return 1;
+    }
+    if (shape == 1) { if (v != 0) return 0; r[0] = 0; r[1] = 0; r[2] = -h[0]; return 1; }
+    const real s = v < 4 ? (real)-1 : (real)1;
+    const int k = v & 3;
+    real l[3];
+    if (k < 3) {
+        static const double cs[3] = {1.0, -0.5, -0.5}, sn[3] = {0.0, 0.86602540378443865, -0.86602540378443865};
+        l[0] = h[0] * (real)cs[k]; l[1] = h[0] * (real)sn[k]; l[2] = s * h[2];
+    } else {
+        /* lowest point of the rim: the direction of -z (world) projected into the cap's plane, in local axes (-R^T z)_xy */
+        const real dx = -Ro[6], dy = -Ro[7];
+        const real len = (real)sqrt((double)(dx * dx + dy * dy));
+        if (len < (real)1e-6) return 0;
+        l[0] = h[0] * dx / len; l[1] = h[0] * dy / len; l[2] = s * h[2];
+    }
+    m3_v(Ro, l, r);
+    return 1;
+}
+
 /* support height under a world point: table top inside the footprint (unless the point is below the slab), else ground */
 static real support_height(const orc_params* p, const real* x) {
     real top = (real)(p->table_c[2] + p->table_h[2]);
@@ -546,8 +609,9 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
     if (obj_on) {
         cand_t c[8];
         for (int v = 0; v < 8; v++) {
-            real l[3] = {(v & 1 ? oh[0] : -oh[0]), (v & 2 ? oh[1] : -oh[1]), (v & 4 ? oh[2] : -oh[2])}, x[3];
-            m3_v(Ro, l, x);
+            real x[3];
+            const int used = shape_candidate(prm->obj_shape, oh, Ro, v, x);
+            if (!used) { x[0] = 0; x[1] = 0; x[2] = (real)1e6; }      /* unused slot: far above any support */
             for (int k = 0; k < 3; k++) x[k] += op[k];
             real hs = support_height(prm, x);
             c[v].idx = v; c[v].dist = x[2] - hs; c[v].n[0] = 0; c[v].n[1] = 0; c[v].n[2] = 1;
@@ -558,7 +622,7 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
         cand_t cs[ORC_MAXS];
         for (int s = 0; s < m->ns; s++) {
             cs[s].idx = s; cs[s].link = m->s_link[s]; cs[s].mu = (real)(m->s_mu[s] * prm->obj_mu);
-            cs[s].dist = sphere_box(sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
+            cs[s].dist = sphere_shape(prm->obj_shape, sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
             for (int k = 0; k < 3; k++) cs[s].pA[k] = cs[s].pB[k] + cs[s].n[k] * cs[s].dist;
         }
         n_ro = select_contacts(cs, m->ns, nc_ro, margin, sel + n_ot);

@@ -72,6 +72,8 @@ typedef struct {
     double obj_h[3], obj_mass, obj_inertia[3], obj_mu;
     int flags;                     /* ORC_F_* */
     int implicit_joint_damping;    /* 1: (M + dt C) dv = dt (tau - C v) instead of the explicit damping torque (include/pbre.h) */
+    int obj_shape;                 /* object primitive (include/pbre.h PBRE_SHAPE_*): 0 box (half extents obj_h), 1 sphere (radius obj_h[0]),
+                                      2 cylinder about its local z axis (radius obj_h[0], half height obj_h[2]) */
 } orc_params;
 
 #define ORC_F_NO_OBJECT 1   /* object frozen and contact-free (reset phase 1; reach config 2) */

@@ -396,7 +396,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     bool rows = NB == 1 && hint <= c->row_max;
     if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
     if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
-    if (!c->P.obj_iso) rows = NB == 1;                 // a box with unequal principal inertias: k_fast_rc's object rows assume a cube
+    if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB == 1;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
     if constexpr (NB == 1) {
         if (rows) {
             const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));

@@ -257,6 +257,67 @@ struct Core {
         return L::sel(inside, zero - best - sr, len - sr);
     }
 
+    // sphere vs the round object primitives (Params::obj_shape 1 sphere / 2 cylinder about local z; pbre_objstep.hpp: Shapes, oracle:
+    // sphere_shape): same contract as sphere_box.  Branch-free per lane (the shape itself is a batch constant).
+    static PBRE_HD F sphere_round(int shape, const V3& sc, F sr, const V3& bc, const M3& Rb, const V3& h, V3& n, V3& pb) {
+        const F one = L::c(1.f), zero = L::c(0.f);
+        V3 d = sub(sc, bc);
+        if (shape == 1) {
+            F len = norm(d);
+            B deg = L::lt(len, L::c(1e-9f));
+            F il = one / L::max(len, L::c(1e-30f));
+            n = v3(L::sel(deg, zero, d.x * il), L::sel(deg, zero, d.y * il), L::sel(deg, one, d.z * il));
+            pb = add(bc, scl(n, h.x));
+            return len - h.x - sr;
+        }
+        V3 dl = mtv(Rb, d);
+        F rho = L::sqrt(L::fma(dl.x, dl.x, dl.y * dl.y));
+        B ax0 = L::bnot(L::gt(rho, L::c(1e-12f)));
+        F ir = one / L::max(rho, L::c(1e-30f));
+        F ux = L::sel(ax0, one, dl.x * ir), uy = L::sel(ax0, zero, dl.y * ir);
+        F rc = L::min(rho, h.x), zc = clampf(dl.z, zero - h.z, h.z);
+        V3 cl = v3(ux * rc, uy * rc, zc);
+        V3 df = sub(dl, cl);
+        F len = norm(df);
+        B inside = L::lt(len, L::c(1e-9f));
+        F il = one / L::max(len, L::c(1e-30f));
+        V3 n_out = scl(df, il);
+        F er = h.x - rho, ez = h.z - L::abs(dl.z);
+        B lat = L::le(er, ez);                         // leave through the lateral surface rather than a cap
+        F sz = L::sel(L::ge(dl.z, zero), one, zero - one);
+        V3 n_in = v3(L::sel(lat, ux, zero), L::sel(lat, uy, zero), L::sel(lat, zero, sz));
+        V3 cl_in = v3(L::sel(lat, ux * h.x, dl.x), L::sel(lat, uy * h.x, dl.y), L::sel(lat, dl.z, sz * h.z));
+        V3 nl = selv(inside, n_in, n_out);
+        V3 c2 = selv(inside, cl_in, cl);
+        n = mv(Rb, nl);
+        pb = add(bc, mv(Rb, c2));
+        return L::sel(inside, zero - L::sel(lat, er, ez) - sr, len - sr);
+    }
+    // Candidate contact point of the object against its support surface owned by lane v = 0..7 (offset from the centre, world axes) and
+    // whether the shape uses that slot (pbre_objstep.hpp: Shapes::candidate, same rules)
+    static PBRE_HD V3 shape_candidate(int shape, const V3& oh, const M3& Ro, I lane, B& used) {
+        const F one = L::c(1.f), zero = L::c(0.f);
+        if (shape == 0) {
+            F sgx = L::sel(L::bit(lane, 0), one, zero - one), sgy = L::sel(L::bit(lane, 1), one, zero - one), sgz = L::sel(L::bit(lane, 2), one, zero - one);
+            used = L::lti(lane, 8);
+            return mv(Ro, v3(sgx * oh.x, sgy * oh.y, sgz * oh.z));
+        }
+        if (shape == 1) { used = L::eqi(lane, 0); return v3(zero, zero, zero - oh.x); }
+        const F s = L::sel(L::bit(lane, 2), one, zero - one);
+        const B b0 = L::bit(lane, 0), b1 = L::bit(lane, 1);          // rim slot k = lane & 3: 0, 1, 2 fixed points, 3 the lowest point
+        const B k0 = L::band(L::bnot(b0), L::bnot(b1)), k1 = L::band(b0, L::bnot(b1));
+        const F cs = L::sel(k0, one, L::c(-0.5f));
+        const F sn = L::sel(k0, zero, L::sel(k1, L::c(0.86602540378443865f), L::c(-0.86602540378443865f)));
+        const F dx = zero - Ro.m[6], dy = zero - Ro.m[7];
+        const F len = L::sqrt(L::fma(dx, dx, dy * dy));
+        const B low_ok = L::ge(len, L::c(1e-6f));
+        const F il = one / L::max(len, L::c(1e-30f));
+        const B is_low = L::band(b0, b1);
+        const F lx = L::sel(is_low, oh.x * dx * il, oh.x * cs), ly = L::sel(is_low, oh.x * dy * il, oh.x * sn);
+        used = L::band(L::lti(lane, 8), L::bor(L::bnot(is_low), low_ok));
+        return mv(Ro, v3(lx, ly, s * oh.z));
+    }
+
     // Select the `cap` smallest-distance candidates (dist < margin) among lanes with `valid`;
     // returns the per-lane rank (0..cap-1 in lane order) or -1.  Ties resolve to the lowest lane.
     static PBRE_HD I select_k(F dist, B valid, F margin, int cap, I lane) {
@@ -592,9 +653,9 @@ struct Core {
             F sr = L::load(T.s_r);
             smu = L::load(T.s_mu);
             V3 oh = v3(L::c(P.obj_h[0]), L::c(P.obj_h[1]), L::c(P.obj_h[2]));
-            // object vertices
-            F sgx = L::sel(L::bit(lane, 0), one, zero - one), sgy = L::sel(L::bit(lane, 1), one, zero - one), sgz = L::sel(L::bit(lane, 2), one, zero - one);
-            vx = add(op, mv(Ro, v3(sgx * oh.x, sgy * oh.y, sgz * oh.z)));
+            // object vertices (box) / candidate points of a round object
+            B cand_used;
+            vx = add(op, shape_candidate(P.obj_shape, oh, Ro, lane, cand_used));
             F top = L::c(P.tab_c[2] + P.tab_h[2]), bot = L::c(P.tab_c[2] - P.tab_h[2]);
             B infoot = L::band(L::le(L::abs(vx.x - L::c(P.tab_c[0])), L::c(P.tab_h[0])), L::le(L::abs(vx.y - L::c(P.tab_c[1])), L::c(P.tab_h[1])));
             F hs = L::sel(L::band(infoot, L::gt(vx.z, bot)), top, L::c(P.ground_z));
@@ -604,8 +665,8 @@ struct Core {
             rk_ot = none; rk_ro = none;
             d_ro = L::c(1.f);
             if (obj_on) {
-                rk_ot = select_k(vd, L::lti(lane, 8), margin, NC_OT, lane);
-                d_ro = sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro);
+                rk_ot = select_k(vd, cand_used, margin, NC_OT, lane);
+                d_ro = P.obj_shape == 0 ? sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro) : sphere_round(P.obj_shape, sc, sr, op, Ro, oh, n_ro, pB_ro);
                 pA_ro = add(pB_ro, scl(n_ro, d_ro));
                 rk_ro = select_k(d_ro, sv, margin, NC_RO, lane);
             } else { n_ro = up; pB_ro = up; pA_ro = up; }

@@ -233,6 +233,14 @@ struct Fast {
         return len < 1e-9f ? -best - sr : len - sr;
     }
 
+    // ... to the object, whatever its primitive (Params::obj_shape; round objects: Shapes::sphere_round)
+    static PBRE_HD float sphere_obj_dist(const Params& P, V3 sc, float sr, V3 bc, const M3& Rb, V3 h) {
+        if (P.obj_shape == 0) return sphere_box_dist(sc, sr, bc, Rb, h);
+        const float s_[3] = {sc.x, sc.y, sc.z}, c_[3] = {bc.x, bc.y, bc.z}, h_[3] = {h.x, h.y, h.z};
+        float n_[3], pb_[3];
+        return Shapes::sphere_round(P.obj_shape, s_, sr, c_, Rb.m, h_, n_, pb_);
+    }
+
     enum { M_ACTION = 1, M_OBS = 2, M_TASK = 4, M_TGT = 8,     // M_TGT: motor targets come from the IK target buffer
            M_INNER = 32 };   // a non-final iteration of the apply_action loop (action_repeat > 1): termination test + counter, no outputs
 
@@ -544,7 +552,7 @@ struct Fast {
         // I_w^-1 = 1/I, so the object's half of the step -- it shares no unknown with the robot rows in this class -- is done by
         // ObjStep (pbre_objstep.hpp: same rows, any principal inertia) and the solver loop runs the robot rows alone.  The envs with
         // robot contacts of such a scene are stepped by the row kernel (launch_step), never by step_t<true>.
-        const bool obj_inline = obj_on && (P.obj_iso != 0);
+        const bool obj_inline = obj_on && (P.obj_iso != 0) && P.obj_shape == 0;      // (round objects -- sphere, cylinder -- are ObjStep's too)
         float o_tw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (obj_on && !obj_inline) {
             const float pose[7] = {op.x, op.y, op.z, oq.x, oq.y, oq.z, oq.w};
@@ -887,7 +895,7 @@ struct Fast {
                 if (obj_on) {
                     const V3 dd = sub(sc, op);
                     const float reach = sr + P.margin + orad;
-                    if ((!bounds || PBRE_ANY(!(dot(dd, dd) >= reach * reach))) && sphere_box_dist(sc, sr, op, Ro, oh) < P.margin) nO++;
+                    if ((!bounds || PBRE_ANY(!(dot(dd, dd) >= reach * reach))) && sphere_obj_dist(P, sc, sr, op, Ro, oh) < P.margin) nO++;
                 }
                 if ((!bounds || PBRE_ANY(!(sc.z - sr - ztop >= P.margin))) && sphere_box_dist(sc, sr, tc, Id, th) < P.margin) nT++;
             }

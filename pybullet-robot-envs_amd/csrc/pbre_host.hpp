@@ -137,6 +137,7 @@ inline bool snapshot_relevant_change(const pbre_physics& a, const pbre_physics& 
     bool ch = a.dt != b.dt || a.gravity_z != b.gravity_z || a.erp != b.erp || a.linear_slop != b.linear_slop || a.contact_margin != b.contact_margin ||
               a.ground_z != b.ground_z;
     for (int k = 0; k < 3; k++) ch = ch || a.table_c[k] != b.table_c[k] || a.table_h[k] != b.table_h[k] || a.obj_h[k] != b.obj_h[k];
+    ch = ch || a.obj_shape != b.obj_shape;
     return ch;
 }
 inline const char* stale_snapshot_msg() {
@@ -153,6 +154,8 @@ inline bool apply_physics(const pbre_physics& p, Params& P2) {
     for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
     P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
     P2.obj_iso = (P2.obj_I[0] == P2.obj_I[1] && P2.obj_I[1] == P2.obj_I[2]) ? 1 : 0;
+    if (p.obj_shape < 0 || p.obj_shape > 2) return false;
+    P2.obj_shape = p.obj_shape;
     return true;
 }
 
@@ -190,6 +193,8 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     for (int k = 0; k < 3; k++) { P.tab_c[k] = (float)p.table_c[k]; P.tab_h[k] = (float)p.table_h[k]; P.obj_h[k] = (float)p.obj_h[k]; P.obj_I[k] = (float)p.obj_inertia[k]; }
     P.tab_mu = (float)p.table_mu; P.ground_z = (float)p.ground_z; P.obj_m = (float)p.obj_mass; P.obj_mu = (float)p.obj_mu;
     P.obj_iso = (P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]) ? 1 : 0;
+    if (p.obj_shape < 0 || p.obj_shape > 2) return "bad physics parameters (obj_shape)";
+    P.obj_shape = p.obj_shape;
     P.task = c.task; P.max_steps = c.max_steps; P.flags = c.flags;
     P.dist_min = (float)c.target_dist_min; P.act_scale = (float)c.act_scale;
     P.obj_std = (float)c.obj_pose_rnd_std; P.tg_std = (float)c.tg_pose_rnd_std;

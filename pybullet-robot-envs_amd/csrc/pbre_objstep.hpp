@@ -18,6 +18,74 @@
 
 namespace pbre {
 
+// The object's collision primitive (Params::obj_shape, include/pbre.h PBRE_SHAPE_*): the reference's object list (world_env.py:18-25,
+// 179-216) has round members -- YcbTennisBall, the cans, pear, duck_vhacd -- that a box stand-in makes slide where they roll.
+// Candidate contact points against the support surface, as offsets from the centre in WORLD axes, 8 slots like the box's vertices:
+//   box       the 8 vertices;
+//   sphere    slot 0: the lowest point (0, 0, -r);
+//   cylinder  (axis = local z, radius h[0], half height h[2]) per cap three rim points at 0 / 120 / 240 degrees (slots 0-2 bottom cap,
+//             4-6 top cap: an upright can stands on a tripod) and the rim's lowest point (slots 3 / 7: the generator a lying can rolls
+//             on; unused while the axis is vertical).
+// Same rules as oracle/pbre_oracle.c: shape_candidate().
+struct Shapes {
+    // R: row-major rotation object -> world; returns false for a slot the shape does not use
+    static PBRE_HD bool candidate(int shape, const float* h, const float* R, int v, float& rx, float& ry, float& rz) {
+        float lx, ly, lz;
+        if (shape == 0) { lx = (v & 1) ? h[0] : -h[0]; ly = (v & 2) ? h[1] : -h[1]; lz = (v & 4) ? h[2] : -h[2]; }
+        else if (shape == 1) { rx = 0.f; ry = 0.f; rz = -h[0]; return v == 0; }
+        else {
+            const float s = v < 4 ? -1.f : 1.f;
+            const int k = v & 3;
+            if (k < 3) {
+                const float cs = k == 0 ? 1.f : -0.5f, sn = k == 0 ? 0.f : (k == 1 ? 0.86602540378443865f : -0.86602540378443865f);
+                lx = h[0] * cs; ly = h[0] * sn; lz = s * h[2];
+            } else {
+                const float dx = -R[6], dy = -R[7];
+                const float len = sqrtf(fmaf(dx, dx, dy * dy));
+                if (!(len >= 1e-6f)) { rx = 0.f; ry = 0.f; rz = 0.f; return false; }
+                lx = h[0] * dx / len; ly = h[0] * dy / len; lz = s * h[2];
+            }
+        }
+        rx = fmaf(R[0], lx, fmaf(R[1], ly, R[2] * lz)); ry = fmaf(R[3], lx, fmaf(R[4], ly, R[5] * lz)); rz = fmaf(R[6], lx, fmaf(R[7], ly, R[8] * lz));
+        return true;
+    }
+    // signed distance of a sphere (centre s, radius sr) to a round object at c with rotation R (shape 1 or 2; the box has its own code
+    // in the callers); n: world normal object -> sphere, pb: point on the object.  oracle: sphere_shape().
+    static PBRE_HD float sphere_round(int shape, const float* s, float sr, const float* c, const float* R, const float* h, float* n, float* pb) {
+        const float d[3] = {s[0] - c[0], s[1] - c[1], s[2] - c[2]};
+        if (shape == 1) {
+            const float len = sqrtf(fmaf(d[0], d[0], fmaf(d[1], d[1], d[2] * d[2])));
+            const bool deg = len < 1e-9f;
+            const float il = 1.f / fmaxf(len, 1e-30f);
+            n[0] = deg ? 0.f : d[0] * il; n[1] = deg ? 0.f : d[1] * il; n[2] = deg ? 1.f : d[2] * il;
+            pb[0] = fmaf(n[0], h[0], c[0]); pb[1] = fmaf(n[1], h[0], c[1]); pb[2] = fmaf(n[2], h[0], c[2]);
+            return len - h[0] - sr;
+        }
+        const float dl[3] = {fmaf(R[0], d[0], fmaf(R[3], d[1], R[6] * d[2])), fmaf(R[1], d[0], fmaf(R[4], d[1], R[7] * d[2])),
+                             fmaf(R[2], d[0], fmaf(R[5], d[1], R[8] * d[2]))};
+        const float rho = sqrtf(fmaf(dl[0], dl[0], dl[1] * dl[1]));
+        const bool ax0 = !(rho > 1e-12f);
+        const float ir = 1.f / fmaxf(rho, 1e-30f);
+        const float ux = ax0 ? 1.f : dl[0] * ir, uy = ax0 ? 0.f : dl[1] * ir;
+        const float rc = fminf(rho, h[0]), zc = fminf(fmaxf(dl[2], -h[2]), h[2]);
+        float cl[3] = {ux * rc, uy * rc, zc};
+        const float df[3] = {dl[0] - cl[0], dl[1] - cl[1], dl[2] - cl[2]};
+        const float len = sqrtf(fmaf(df[0], df[0], fmaf(df[1], df[1], df[2] * df[2])));
+        float nl[3], dist;
+        if (len >= 1e-9f) { const float il = 1.f / len; nl[0] = df[0] * il; nl[1] = df[1] * il; nl[2] = df[2] * il; dist = len - sr; }
+        else {
+            const float er = h[0] - rho, ez = h[2] - fabsf(dl[2]);
+            if (er <= ez) { nl[0] = ux; nl[1] = uy; nl[2] = 0.f; cl[0] = ux * h[0]; cl[1] = uy * h[0]; cl[2] = dl[2]; dist = -er - sr; }
+            else { nl[0] = 0.f; nl[1] = 0.f; nl[2] = dl[2] >= 0.f ? 1.f : -1.f; cl[0] = dl[0]; cl[1] = dl[1]; cl[2] = nl[2] * h[2]; dist = -ez - sr; }
+        }
+        PBRE_UNROLL for (int k = 0; k < 3; k++) {
+            n[k] = fmaf(R[3 * k], nl[0], fmaf(R[3 * k + 1], nl[1], R[3 * k + 2] * nl[2]));
+            pb[k] = c[k] + fmaf(R[3 * k], cl[0], fmaf(R[3 * k + 1], cl[1], R[3 * k + 2] * cl[2]));
+        }
+        return dist;
+    }
+};
+
 struct ObjStep {
     static constexpr int NK = 4;      // object-table contact slots (ShapeT::NC_OT of every shape)
     static PBRE_HD float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -84,12 +152,15 @@ struct ObjStep {
             float vd[8], rx[8], ry[8], rz[8];
             const float top = P.tab_c[2] + P.tab_h[2], bot = P.tab_c[2] - P.tab_h[2];
             PBRE_UNROLL for (int v = 0; v < 8; v++) {
-                const float lx = (v & 1) ? P.obj_h[0] : -P.obj_h[0], ly = (v & 2) ? P.obj_h[1] : -P.obj_h[1], lz = (v & 4) ? P.obj_h[2] : -P.obj_h[2];
-                rx[v] = fmaf(R[0], lx, fmaf(R[1], ly, R[2] * lz)); ry[v] = fmaf(R[3], lx, fmaf(R[4], ly, R[5] * lz));
-                rz[v] = fmaf(R[6], lx, fmaf(R[7], ly, R[8] * lz));
+                bool used = true;
+                if (P.obj_shape == 0) {
+                    const float lx = (v & 1) ? P.obj_h[0] : -P.obj_h[0], ly = (v & 2) ? P.obj_h[1] : -P.obj_h[1], lz = (v & 4) ? P.obj_h[2] : -P.obj_h[2];
+                    rx[v] = fmaf(R[0], lx, fmaf(R[1], ly, R[2] * lz)); ry[v] = fmaf(R[3], lx, fmaf(R[4], ly, R[5] * lz));
+                    rz[v] = fmaf(R[6], lx, fmaf(R[7], ly, R[8] * lz));
+                } else used = Shapes::candidate(P.obj_shape, P.obj_h, R, v, rx[v], ry[v], rz[v]);      // (wave-uniform branch: the shape is a batch constant)
                 const float X = px + rx[v], Y = py + ry[v], Z = pz + rz[v];
                 const bool in = fabsf(X - P.tab_c[0]) <= P.tab_h[0] && fabsf(Y - P.tab_c[1]) <= P.tab_h[1];
-                vd[v] = Z - ((in && Z > bot) ? top : P.ground_z);
+                vd[v] = used ? Z - ((in && Z > bot) ? top : P.ground_z) : 3e38f;
             }
             int slot = 0;
             PBRE_UNROLL for (int v = 0; v < 8; v++) {

@@ -91,6 +91,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     float tab_c[3], tab_h[3], tab_mu, ground_z;
     float obj_h[3], obj_m, obj_I[3], obj_mu;
     int   obj_iso;                // the object's principal inertias are equal (a cube): the lane-per-env kernels' in-line object rows apply
+    int   obj_shape;              // PBRE_SHAPE_*: 0 box (half extents obj_h), 1 sphere (radius obj_h[0]), 2 cylinder about local z (radius obj_h[0], half height obj_h[2])
     int   task, max_steps, flags;
     float dist_min, act_scale;
     float obj_std, tg_std, ws[3][2], h_table;

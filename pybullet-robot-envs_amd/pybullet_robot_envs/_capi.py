@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "c
 STATE_FLOATS = 48
 ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS, ROBOT_PANDA_ARM = 0, 1, 2, 3
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
 F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES, F_SEQ_MOTORS = 1, 2, 4, 8, 16, 32
 
 
@@ -26,7 +27,7 @@ class Physics(C.Structure):
                 ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
-                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("implicit_joint_damping", C.c_int32)]
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("implicit_joint_damping", C.c_int32), ("obj_shape", C.c_int32)]
 
 
 class Config(C.Structure):

@@ -87,9 +87,17 @@ class WorldEnv:
             self._client.engine.set_physics(**ph)
 
     def get_object_shape_info(self):
-        """(world_env.py:95-98) geometry type 3 = box, dimensions = full extents"""
-        h = self.object_physics()["obj_h"]
-        return [self.obj_id, -1, 3, [2 * x for x in h], "", [0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
+        """(world_env.py:95-98) one p.getCollisionShapeData row of the stand-in: geometry type 3 = GEOM_BOX with the full extents, 2 =
+        GEOM_SPHERE with the radius (x3), 4 = GEOM_CYLINDER with [height, radius, 0] (pybullet's conventions)"""
+        ph = self.object_physics()
+        h, shape = ph["obj_h"], ph.get("obj_shape", 0)
+        if shape == 1:
+            geom, dims = 2, [h[0]] * 3
+        elif shape == 2:
+            geom, dims = 4, [2 * h[2], h[0], 0.0]
+        else:
+            geom, dims = 3, [2 * x for x in h]
+        return [self.obj_id, -1, geom, dims, "", [0.0, 0.0, 0.0], [0.0, 0.0, 0.0, 1.0]]
 
     def get_table_height(self):
         return self._h_table

@@ -60,6 +60,45 @@ def _sphere_box_dist(sc, sr, bc, Rb, h):
     return np.where(ln < 1e-9, -best - sr, ln - sr)
 
 
+def _sphere_round_dist(shape, sc, sr, bc, Rb, h):
+    """signed distance of spheres to a round object (shape 1 sphere of radius h[0], 2 cylinder about local z: radius h[0], half height
+    h[2]) -- csrc/pbre_objstep.hpp: Shapes::sphere_round"""
+    d = sc - bc
+    if shape == 1:
+        return np.linalg.norm(d, axis=1) - h[0] - sr
+    dl = np.einsum("nji,nj->ni", Rb, d)
+    rho = np.hypot(dl[:, 0], dl[:, 1])
+    rc, zc = np.minimum(rho, h[0]), np.clip(dl[:, 2], -h[2], h[2])
+    ln = np.hypot(rho - rc, dl[:, 2] - zc)
+    inside = -np.minimum(h[0] - rho, h[2] - np.abs(dl[:, 2]))
+    return np.where(ln < 1e-9, inside - sr, ln - sr)
+
+
+def _shape_candidates(shape, h, Ro):
+    """[N, 8, 3] candidate contact points of the object against its support (offsets, world axes) and [N, 8] validity"""
+    n = Ro.shape[0]
+    r = np.zeros((n, 8, 3)); ok = np.zeros((n, 8), bool)
+    for v in range(8):
+        if shape == 0:
+            l = np.array([h[0] if v & 1 else -h[0], h[1] if v & 2 else -h[1], h[2] if v & 4 else -h[2]])
+            r[:, v] = np.einsum("nij,j->ni", Ro, l); ok[:, v] = True
+        elif shape == 1:
+            if v == 0:
+                r[:, v] = [0.0, 0.0, -h[0]]; ok[:, v] = True
+        else:
+            s, k = (-1.0 if v < 4 else 1.0), v & 3
+            if k < 3:
+                l = np.array([h[0] * np.cos(2 * np.pi * k / 3), h[0] * np.sin(2 * np.pi * k / 3), s * h[2]])
+                r[:, v] = np.einsum("nij,j->ni", Ro, l); ok[:, v] = True
+            else:
+                dx, dy = -Ro[:, 2, 0], -Ro[:, 2, 1]
+                ln = np.hypot(dx, dy)
+                good = ln >= 1e-6
+                l = np.stack([h[0] * dx / np.maximum(ln, 1e-30), h[0] * dy / np.maximum(ln, 1e-30), np.full(n, s * h[2])], 1)
+                r[:, v] = np.einsum("nij,nj->ni", Ro, l); ok[:, v] = good
+    return r, ok
+
+
 def contact_flags(table, state, ndof, phys, no_object=False):
     """[N] uint8 of OBJECT_TABLE | ROBOT_OBJECT | ROBOT_TABLE for the batch state records state[N, F] (Q | V | X layout of
     include/pbre.h: joints at [0, ndof), object position / quaternion behind them); phys = pbre_physics (Engine.get_physics())."""
@@ -71,6 +110,7 @@ def contact_flags(table, state, ndof, phys, no_object=False):
     margin = float(phys.contact_margin)
     tc, th = np.array(list(phys.table_c), float), np.array(list(phys.table_h), float)
     oh = np.array(list(phys.obj_h), float)
+    shape = int(getattr(phys, "obj_shape", 0))
     op, Ro = st[:, ndof:ndof + 3], _quat_R(st[:, ndof + 3:ndof + 7])
     eye = np.broadcast_to(np.eye(3), (n, 3, 3))
     flags = np.zeros(n, np.uint8)
@@ -80,13 +120,14 @@ def contact_flags(table, state, ndof, phys, no_object=False):
         li, c, rad = int(s[0]), s[1:4], float(s[4])
         sc = p[:, li] + np.einsum("nij,j->ni", R[:, li], c)
         if not no_object:
-            flags |= np.where(_sphere_box_dist(sc, rad, op, Ro, oh) < margin, ROBOT_OBJECT, 0).astype(np.uint8)
+            d_ro = _sphere_box_dist(sc, rad, op, Ro, oh) if shape == 0 else _sphere_round_dist(shape, sc, rad, op, Ro, oh)
+            flags |= np.where(d_ro < margin, ROBOT_OBJECT, 0).astype(np.uint8)
         flags |= np.where(_sphere_box_dist(sc, rad, np.broadcast_to(tc, (n, 3)), eye, th) < margin, ROBOT_TABLE, 0).astype(np.uint8)
-    if not no_object:                     # the box's vertices against the table top (pbre_fast.hpp: the object rows' candidates)
+    if not no_object:                     # the object's candidate points (box vertices / round primitives) against the table top
         top, bot = tc[2] + th[2], tc[2] - th[2]
+        cand, ok = _shape_candidates(shape, oh, Ro)
         for v in range(8):
-            l = np.array([oh[0] if v & 1 else -oh[0], oh[1] if v & 2 else -oh[1], oh[2] if v & 4 else -oh[2]])
-            x = op + np.einsum("nij,j->ni", Ro, l)
-            on = (np.abs(x[:, 0] - tc[0]) <= th[0]) & (np.abs(x[:, 1] - tc[1]) <= th[1]) & (x[:, 2] > bot)
+            x = op + cand[:, v]
+            on = (np.abs(x[:, 0] - tc[0]) <= th[0]) & (np.abs(x[:, 1] - tc[1]) <= th[1]) & (x[:, 2] > bot) & ok[:, v]
             flags |= np.where(on & (x[:, 2] - top < margin), OBJECT_TABLE, 0).astype(np.uint8)
     return flags

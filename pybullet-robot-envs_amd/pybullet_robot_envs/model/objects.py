@@ -2,8 +2,9 @@
 
 The reference's objects are meshes of packages that are not part of its checkout (`pybullet_data`: duck_vhacd, teddy_vhacd,
 domino, cube_small; `pybullet_object_models`: the YCB set and its superquadric approximations) and not available to this build.
-Every `obj_name` is simulated as a BOX with the object's approximate bounding dimensions and mass, so that `obj_name` changes the
-dynamics (size, mass, principal inertias, lateral friction) instead of being ignored:
+Every `obj_name` is simulated as a collision PRIMITIVE with the object's approximate dimensions and mass -- a box, or for the round
+members (ROUND_OBJECTS: tennis ball, pear, strawberry, the cans, the duck) a sphere / an upright cylinder -- so that `obj_name` changes
+the dynamics (shape, size, mass, principal inertias, lateral friction) instead of being ignored:
   * YCB objects: dimensions (m) and masses (kg) as published with the YCB object and model set (Calli et al., "Benchmarking in
     Manipulation Research", 2015, object table); box axes = the published x, y, z extents;
   * pybullet_data objects: approximate extents of the meshes at the scale their URDFs load them with [EXT-UNVERIFIED: the package is
@@ -39,12 +40,37 @@ YCB_OBJECTS = {
 }
 
 
+# Round members of the object list (reference world_env.py:18-25, 179-216): collision primitive instead of the bounding box, so that they
+# roll where the reference's meshes roll.  name -> ("sphere", radius) | ("cylinder", radius, half height); the cylinder's axis is the
+# object's z (the cans stand upright after reset, as their URDFs load them).  Radii / heights from the same published extents;
+# a sphere that stands in for an ellipsoid (pear, strawberry) has the volume-equivalent radius.  [EXT-UNVERIFIED like the boxes.]
+ROUND_OBJECTS = {
+    "YcbTennisBall": ("sphere", 0.0325),
+    "YcbPear": ("sphere", 0.038),
+    "YcbStrawberry": ("sphere", 0.024),
+    "YcbChipsCan": ("cylinder", 0.0375, 0.125),
+    "YcbMasterChefCan": ("cylinder", 0.051, 0.0695),
+    "YcbTomatoSoupCan": ("cylinder", 0.033, 0.0505),
+    "duck_vhacd": ("cylinder", 0.04, 0.04),        # a rounded body on a flat base: slides on its base, rolls on its side
+}
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
+
+
 def object_physics(obj_name):
-    """pbre_physics fields of the box stand-in: half extents, mass, principal inertias of a uniform box, lateral friction."""
+    """pbre_physics fields of the stand-in: collision primitive (obj_shape), its dimensions (obj_h: half extents | radius x 3 | radius,
+    radius, half height), mass, principal inertias of the uniform solid, lateral friction."""
     key = obj_name[:-5] if obj_name.endswith(".urdf") else obj_name
     ent = PYBULLET_DATA_OBJECTS.get(key) or YCB_OBJECTS.get(key)
     if ent is None:
         raise ValueError("unknown obj_name %r; known: %s" % (obj_name, sorted(list(PYBULLET_DATA_OBJECTS) + list(YCB_OBJECTS))))
     (x, y, z), mass, mu = ent
-    return {"obj_h": [x / 2, y / 2, z / 2], "obj_mass": mass, "obj_mu": mu,
-            "obj_inertia": [mass * (y * y + z * z) / 12.0, mass * (x * x + z * z) / 12.0, mass * (x * x + y * y) / 12.0]}
+    rnd = ROUND_OBJECTS.get(key)
+    if rnd is None:
+        return {"obj_shape": SHAPE_BOX, "obj_h": [x / 2, y / 2, z / 2], "obj_mass": mass, "obj_mu": mu,
+                "obj_inertia": [mass * (y * y + z * z) / 12.0, mass * (x * x + z * z) / 12.0, mass * (x * x + y * y) / 12.0]}
+    if rnd[0] == "sphere":
+        r = rnd[1]
+        return {"obj_shape": SHAPE_SPHERE, "obj_h": [r, r, r], "obj_mass": mass, "obj_mu": mu, "obj_inertia": [0.4 * mass * r * r] * 3}
+    r, hh = rnd[1], rnd[2]
+    it = mass * (3.0 * r * r + 4.0 * hh * hh) / 12.0
+    return {"obj_shape": SHAPE_CYLINDER, "obj_h": [r, r, hh], "obj_mass": mass, "obj_mu": mu, "obj_inertia": [it, it, 0.5 * mass * r * r]}

@@ -65,7 +65,7 @@ struct Emu : pbre_ctx {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
                 if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
-                else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso) {
+                else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
                     CoreH::step(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg);
@@ -81,7 +81,7 @@ struct Emu : pbre_ctx {
         }
         if constexpr (std::is_same<S, Shape32>::value) {
             // the device's kw_lane / kw_list pair (pbre_wide.hip): task-env steps of the whole batch; settle steps stay on the lane-group kernel
-            if (lane_ok && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
+            if (lane_ok && P.obj_shape == 0 && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
                 if (LaneH::classify_state(T, P, st, flags) == 0) {
                     n_fast++;
                     float mi[LaneH::NM];
@@ -117,7 +117,7 @@ struct Emu : pbre_ctx {
     void ik(float* st, const float* act, float* tg, bool rst) {
         if constexpr (PANDA) FastH::ik_targets(T, P, st, act, tg, rst);
         else {
-            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && !rst) { LaneH::ik_targets(T, P, st, act, tg); return; } }
+            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && P.obj_shape == 0 && !rst) { LaneH::ik_targets(T, P, st, act, tg); return; } }
             CoreH::ik_targets(T, P, st, act, tg, rst);
         }
     }

@@ -42,7 +42,8 @@ class Params(C.Structure):
                 ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
-                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int), ("implicit_joint_damping", C.c_int)]
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int), ("implicit_joint_damping", C.c_int),
+                ("obj_shape", C.c_int)]
 
 
 class Task(C.Structure):
@@ -249,6 +250,7 @@ def set_object(o, ph):
         o.params.obj_h[k] = ph["obj_h"][k]
         o.params.obj_inertia[k] = ph["obj_inertia"][k]
     o.params.obj_mass, o.params.obj_mu = ph["obj_mass"], ph["obj_mu"]
+    o.params.obj_shape = int(ph.get("obj_shape", 0))
 
 
 def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, **kw):

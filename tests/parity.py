@@ -1310,6 +1310,99 @@ def check_other_objects(Engine, lib, table, names=("YcbGelatinBox", "domino/domi
     return out
 
 
+def contacts_flags_of(eng, table, states):
+    from pybullet_robot_envs.model import contacts
+    return contacts.contact_flags(table, np.asarray(states, np.float64), eng.ndof, eng.get_physics())
+
+
+def check_round_objects(Engine, lib, table, names=("YcbTennisBall", "YcbTomatoSoupCan", "duck_vhacd"), n=6, flags=0):
+    """The round members of the object list (reference world_env.py:18-25, 179-216; model/objects.py: ROUND_OBJECTS) as sphere / cylinder
+    primitives, against the oracle with the same primitive:
+      * reset: the object drops onto the table and settles (ball on its lowest point, can on its base);
+      * a ROLLING object, free running for 120 steps from the same state in both: a ball given a push ends up rolling without
+        slipping (|v - omega x r| -> 0: the property a box stand-in cannot have), a can lying on its side rolls along, an upright can
+        slides on its base; single steps from identical states on the way, per quantity;
+      * robot-object contact: the object placed against the fingers (sphere-vs-sphere / sphere-vs-cylinder rows)."""
+    from pybullet_robot_envs.model.objects import object_physics
+    out = {}
+    for name in names:
+        ph = object_physics(name)
+        shape, r, hh = ph["obj_shape"], ph["obj_h"][0], ph["obj_h"][2]
+        eng, ora = make_pair(Engine, lib, table, n, flags=flags, phys=ph)
+        orc.set_object(ora, ph)
+        assert eng.get_physics().obj_shape == shape and ora.params.obj_shape == shape and shape in (1, 2)
+        ora32 = orc.Oracle(table, f32=True, task=1)
+        ora32.task.obj_pose_rnd_std, ora32.task.tg_pose_rnd_std = ora.task.obj_pose_rnd_std, ora.task.tg_pose_rnd_std
+        orc.set_object(ora32, ph)
+        eng.reset()
+        st, _ = ora.batch_reset(n)
+        se = eng.get_state()
+        assert np.isfinite(se).all()
+        assert rel(se[:, :31], st[:, :31]).max() < 5e-4, (name, rel(se[:, :31], st[:, :31]).max())
+        assert np.abs(se[:, 11] - (0.625 + hh)).max() < 2e-3, (name, se[:, 11])
+        rng = np.random.default_rng(15)
+        # ---- rolling / sliding, free running
+        s = st.copy()
+        s[:, 32:35] = [0.9, 0.9, 0.65]                                       # far target: no success on the way
+        lying = shape == 2 and name != "duck_vhacd"
+        if lying:                                                            # can on its side: axis along world x, resting on the table
+            s[:, 12:16] = [0.0, np.sqrt(0.5), 0.0, np.sqrt(0.5)]
+            s[:, 11] = 0.625 + r
+        s[:, 25:28] = [0.0, 0.25, 0.0]                                       # pushed along +y (a lying can: across its axis)
+        s32 = s.astype(np.float32)
+        eng.set_state(s32)
+        so = s32.astype(np.float64)
+        zero = np.zeros((n, 7), np.float32)
+        worst = {}
+        for k in range(120):
+            eng.step(zero)
+            so, _ = ora.batch_step(so, zero)
+        se = eng.get_state().astype(np.float64)
+        v, w = so[:, 25:28], so[:, 28:31]
+        rep = {"free_run_obj_pos_diff": float(np.abs(se[:, 9:12] - so[:, 9:12]).max()), "travel_cm": float(100 * (so[:, 10] - s[:, 10]).mean())}
+        if shape == 1 or lying:
+            slip = v[:, 1] + w[:, 0] * r                                    # contact-point velocity of a body rolling along +y: v_y - (omega x (0,0,-r))_y
+            rep["slip_over_speed"] = float(np.abs(slip).max() / max(np.abs(v[:, 1]).max(), 1e-9))
+            assert np.abs(v[:, 1]).min() > 0.05 and rep["slip_over_speed"] < 0.02, (name, rep, v[0], w[0])      # still moving, rolling without slipping
+            assert np.abs(se[:, 28] * r + se[:, 26]).max() < 0.02 * np.abs(se[:, 26]).max() + 1e-4                # ... in the engine as well
+        else:
+            assert np.abs(v[:, :2]).max() < 1e-3 and np.abs(so[:, 12:14]).max() < 1e-3, (name, v[0], so[0, 12:16])     # friction stopped the upright can; it did not tip
+        assert rep["free_run_obj_pos_diff"] < 2e-4, (name, rep)
+        # ---- single steps from identical states while it moves
+        # (from the rolling / resting states the free run ended in, nudged a little: a ball with an arbitrary spin sits on the edge of
+        # its friction cone -- sticking in one tangent direction, sliding in the other -- where a rounding decides the regime; the
+        # conditioning probe of check_single_steps would skip most of such states)
+        s2 = so.copy()
+        s2[:, 25:28] += rng.uniform(-0.01, 0.01, (n, 3)) * [1, 1, 0]
+        tol = dict(TOL_CONTACT, obj_pos=2e-6, obs_obj_pos=2e-6, obj_v=5e-4)
+        r1 = check_single_steps(eng, ora, s2, rng, steps=3, tol=tol, skip_ambiguous=True, max_skip=0.5, ora32=ora32, max_outliers=0.1)
+        rep.update(dict(r1["worst"], skipped=r1["skipped_ambiguous"], outliers=r1.get("outliers", 0), compared=r1["compared"]))
+        # ---- robot-object contact: the object under the fingers (complex env -> the row kernel's sphere-vs-round rows)
+        from pybullet_robot_envs.model.table import panda_table, PANDA_SPHERES
+        _, model = panda_table()
+        s3 = st.copy()
+        for e in range(n):                                                   # one hand / finger sphere ~2 mm inside the object, from above or from the side
+            q = s3[e, :9]
+            cs, rs = scenarios.sphere_centres(ora, model, PANDA_SPHERES, q)[-1 - (e % 4)]
+            pen = 0.002
+            if shape == 1:
+                d = rng.normal(size=3); d[2] = -abs(d[2]) - 0.5; d /= np.linalg.norm(d)
+                s3[e, 9:12] = cs + d * (rs + r - pen)
+            elif e % 2 == 0:
+                s3[e, 9:12] = cs + np.array([0.0, 0.0, -(rs + hh - pen)])     # the sphere on the can's top cap
+            else:
+                d = np.array([np.cos(0.7 * e), np.sin(0.7 * e), 0.0])
+                s3[e, 9:12] = cs + d * (rs + r - pen)                          # ... on its lateral surface
+            s3[e, 12:16] = [0, 0, 0, 1]
+        f3 = contacts_flags_of(eng, table, s3)
+        assert (f3 & 2).all(), ("the crafted states have no robot-object contact", f3)
+        r2 = check_single_steps(eng, ora, s3, rng, steps=1, tol=TOL_CONTACT, skip_ambiguous=True, max_skip=0.5, ora32=ora32, max_outliers=0.1)
+        rep["robot_contact_compared"] = r2["compared"]
+        out[name] = rep
+        eng.close()
+    return out
+
+
 def check_reset_snapshot(Engine, lib, table, n=8, **over):
     """pbre_reset_snapshot against an explicit masked pbre_reset of the same envs and episodes: the same sampled object pose and target
     (bit-identical: same Philox streams), the settled heights / robot pose within 5e-5, zero velocities, cleared counters; the other

@@ -239,3 +239,11 @@ def test_scripted_push_closed_loop_against_oracle(panda, emu_lib):
     displacement compared (bounds in parity.check_panda_push_closed_loop)."""
     rep = parity.check_panda_push_closed_loop(_capi.Engine, emu_lib, panda["table"], n=3)
     assert rep["touched_envs"] == 3
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_FORCE_GENERAL])
+def test_round_objects(panda, emu_lib, flags):
+    """sphere / cylinder stand-ins of the round objects (tennis ball, cans, duck): they roll; against the oracle with the same primitive
+    (lane-per-env kernel + ObjStep with the row kernel for robot contacts, and the general row kernel)"""
+    rep = parity.check_round_objects(_capi.Engine, emu_lib, panda["table"], n=3, flags=flags)
+    assert rep["YcbTennisBall"]["travel_cm"] > 5 and rep["YcbTomatoSoupCan"]["travel_cm"] > 5
