@@ -368,7 +368,11 @@ struct Fast {
         // ---- one forward sweep over the links: FK, joint axes, velocities, velocity-product accelerations,
         //      collision-sphere distances, per-link bias force and spatial inertia (world frame, about the world origin)
         V3 Sa[ND], Sl[ND];
-        V3 Fa[ND], Fl[ND];
+        // bias torques tau_i = -S_i . (bias wrench of i's subtree): accumulated link by link in the forward sweep (link j's wrench projected
+        // on the axes of j and of its ancestors: 44 pairs, ~160 more FMAs than summing subtree wrenches backwards) -- so that no per-link
+        // wrench (54 floats) has to stay alive until the backward sweep
+        float tau[ND];
+        PBRE_UNROLL for (int j = 0; j < ND; j++) tau[j] = 0.f;
         float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
         Cand k1[2], k2[2];       // [0] robot-object, [1] robot-table: best and second best
         PBRE_UNROLL for (int g = 0; g < 2; g++) {
@@ -420,7 +424,7 @@ struct Fast {
                         keep2(c, P.margin, k1[1], k2[1]);
                     }
                 }
-                Fa[j] = v3(0.f, 0.f, 0.f); Fl[j] = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
+                V3 Faj = v3(0.f, 0.f, 0.f), Flj = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
                 PBRE_UNROLL for (int k = 0; k < 6; k++) CI[j][k] = 0.f;
                 PBRE_UNROLL for (int b = 0; b < NSUB; b++) {
                     if (b >= Topo::nsub(j)) continue;
@@ -440,20 +444,20 @@ struct Fast {
                     V3 Iww = mv(Iw, w);
                     float sa_ = fmaf(P.ka, norm(w), P.ka);
                     V3 nc = add(add(mv(Iw, Aa[j]), cross(w, Iww)), scl(Iww, sa_));
-                    Fa[j] = add(Fa[j], add(nc, cross(c, f))); Fl[j] = add(Fl[j], f);
+                    Faj = add(Faj, add(nc, cross(c, f))); Flj = add(Flj, f);
                     Cm[j] += m; Ch[j] = add(Ch[j], scl(c, m));
                     const float cc = dot(c, c);
                     CI[j][0] += fmaf(m, cc - c.x*c.x, Iw.m[0]); CI[j][1] += fmaf(m, cc - c.y*c.y, Iw.m[4]); CI[j][2] += fmaf(m, cc - c.z*c.z, Iw.m[8]);
                     CI[j][3] += fmaf(-m, c.x*c.y, Iw.m[1]); CI[j][4] += fmaf(-m, c.x*c.z, Iw.m[2]); CI[j][5] += fmaf(-m, c.y*c.z, Iw.m[5]);
                 }
+                PBRE_UNROLL for (int i = 0; i < ND; i++)
+                    if (Topo::is_anc(i, j)) tau[i] -= dot(Sa[i], Faj) + dot(Sl[i], Flj);
             }
         }
 
-        // ---- backward sweep: subtree forces -> bias torques, composite inertias -> mass matrix (CRBA)
+        // ---- backward sweep: composite inertias -> mass matrix (CRBA)
         float Mi[ND * (ND + 1) / 2];       // symmetric storage, becomes M^-1
-        float tau[ND];
         PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) {
-            tau[j] = -(dot(Sa[j], Fa[j]) + dot(Sl[j], Fl[j]));
             M3 Io; Io.m[0] = CI[j][0]; Io.m[1] = CI[j][3]; Io.m[2] = CI[j][4]; Io.m[3] = CI[j][3]; Io.m[4] = CI[j][1]; Io.m[5] = CI[j][5];
             Io.m[6] = CI[j][4]; Io.m[7] = CI[j][5]; Io.m[8] = CI[j][2];
             V3 Ga = add(mv(Io, Sa[j]), cross(Ch[j], Sl[j]));
@@ -465,7 +469,6 @@ struct Fast {
             }
             if (Topo::parent(j) >= 0) {
                 const int pp = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
-                Fa[pp] = add(Fa[pp], Fa[j]); Fl[pp] = add(Fl[pp], Fl[j]);
                 Cm[pp] += Cm[j]; Ch[pp] = add(Ch[pp], Ch[j]);
                 PBRE_UNROLL for (int k = 0; k < 6; k++) CI[pp][k] += CI[j][k];
             }
@@ -494,6 +497,12 @@ struct Fast {
         WV w;
         PBRE_UNROLL for (int k = ND; k < 2 * ((ND + 1) / 2); k++) wset(w, k, 0.f);
         float m_dinv[ND], m_rhs[ND], m_app[ND], m_t[ND];
+        // (simple class: joint angles / velocities are re-read from the state record here rather than kept in registers across the
+        // kinematic sweeps and the inversion -- the barrier stops the compiler from reusing the earlier loads)
+        if (!RC) {
+            PBRE_REG_BARRIER();
+            PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+        }
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
@@ -509,6 +518,45 @@ struct Fast {
             m_t[j] = kp * (qdes - q[j]) * inv_dt + (1.f - kd) * wj;      // the motor's target velocity (btMultiBodyJointMotor)
             m_rhs[j] = m_t[j] * m_dinv[j];
             m_app[j] = 0.f;
+        }
+
+        const float mlim = P.motor_imp;
+        // motor row in delta form: clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied), so a row whose clamp
+        // does not bind returns Bullet's delta = rhs' - dinv w_j bit for bit -- the same value the closed form reproduces
+        auto motor = [&](int j) {
+            const float nt = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
+            const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
+            m_app[j] += d;
+            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
+        };
+        if (!RC) {
+            // ---- simple class, motor block (see the solver section below for the why and the validity bound)
+            const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
+            bool over = true;
+            float wc[ND];
+            if (want_closed) {
+                float e[ND];
+                PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
+                float en = 0.f, lam[ND];
+                PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                    float l = 0.f;
+                    PBRE_UNROLL for (int k = 0; k < ND; k++) l = fmaf(M0[sym(j, k)], e[k], l);
+                    lam[j] = l; en = fmaf(l, e[j], en);
+                }
+                bool ov_ = !(en >= 0.f);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) ov_ = ov_ || !(fabsf(lam[j]) + sqrtf(en * M0[sym(j, j)]) <= mlim);
+                over = ov_;
+                motor_closed(Mi, m_dinv, e, P.iters >> 1);
+                PBRE_UNROLL for (int j = 0; j < ND; j++) wc[j] = m_t[j] + e[j];
+            }
+            if (PBRE_ANY(over)) {
+                for (int it = 0; it < P.iters; it += 2) {
+                    PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
+                    if (it + 1 >= P.iters) break;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
+                }
+            }
+            if (want_closed) { PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, over ? wget(w, j) : wc[j]); }
         }
 
         // joint-limit rows (btMultiBodyJointLimitConstraint; complex class only): a row exists while the joint is at/over
@@ -670,15 +718,6 @@ struct Fast {
 
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
         ow = scl(ow, inv_sk);                 // scaled angular velocity u inside the solver loop
-        const float mlim = P.motor_imp;
-        // motor row in delta form: clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied), so a row whose clamp
-        // does not bind returns Bullet's delta = rhs' - dinv w_j bit for bit -- the same value the clamp-free rows below produce
-        auto motor = [&](int j) {
-            const float nt = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
-            const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
-            m_app[j] += d;
-            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
-        };
         const float llim = P.limit_imp;
         auto limit = [&](int j) {
             const float t = fmaf(m_dinv[j] * l_dir[j], wget(w, j), -l_rhs[j]);
@@ -735,7 +774,8 @@ struct Fast {
         };
         if (!RC) {
             // ---- simple class.  The motor rows and the object rows share no unknown, so Bullet's interleaved sweeps give each block
-            // exactly the iterates it would get alone: the two blocks are solved one after the other.
+            // exactly the iterates it would get alone: the two blocks are solved one after the other -- the motor block earlier, right
+            // after the motors' targets were formed (motor_block above: its matrices are dead before the object's rows are built).
             // (1) Motor block.  While no motor reaches its impulse bound, a motor row is the linear map e <- (I - A_j e_j^T / A_jj) e on the
             // error e = w - t (A = M^-1, t = the motors' target velocities, the fixed point), so the `iters` sweeps are a power of one
             // matrix: w = t + G^(iters/2) (w0 - t) with G = one reversed + one forward sweep -- evaluated by repeated squaring
@@ -746,32 +786,6 @@ struct Fast {
             // energy 1/2 l^T A l - b^T l along one coordinate, so |l_k - l*|_A never grows: |l_k,j| <= |l*_j| + |l*|_A sqrt(M_jj) with
             // l* = M (t - w0), |l*|_A^2 = (t - w0)^T l*.  A lane that fails the bound (a NaN fails it too) takes the sequential clamping rows;
             // what a lane computes does not depend on the lanes it shares a wave with.
-            const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
-            bool over = true;
-            float wc[ND];
-            if (want_closed) {
-                float e[ND];
-                PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
-                float en = 0.f, lam[ND];
-                PBRE_UNROLL for (int j = 0; j < ND; j++) {
-                    float l = 0.f;
-                    PBRE_UNROLL for (int k = 0; k < ND; k++) l = fmaf(M0[sym(j, k)], e[k], l);
-                    lam[j] = l; en = fmaf(l, e[j], en);
-                }
-                bool ov_ = !(en >= 0.f);
-                PBRE_UNROLL for (int j = 0; j < ND; j++) ov_ = ov_ || !(fabsf(lam[j]) + sqrtf(en * M0[sym(j, j)]) <= mlim);
-                over = ov_;
-                motor_closed(Mi, m_dinv, e, P.iters >> 1);
-                PBRE_UNROLL for (int j = 0; j < ND; j++) wc[j] = m_t[j] + e[j];
-            }
-            if (PBRE_ANY(over)) {
-                for (int it = 0; it < P.iters; it += 2) {
-                    PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j);
-                    if (it + 1 >= P.iters) break;
-                    PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j);
-                }
-            }
-            if (want_closed) { PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, over ? wget(w, j) : wc[j]); }
             // (2) Object block: 4 normal rows, then the friction pairs.  The usual wave has all four object-table slots in use (the
             // cube rests on the table in every env): that case gets its own copy of the loop without the per-slot "does any lane use
             // it" branches (rows of a lane without the contact are exact no-ops either way).

@@ -381,5 +381,5 @@ def test_scripted_push_closed_loop_against_oracle(panda, hip_lib):
 def test_round_objects(panda, hip_lib, flags):
     """sphere / cylinder stand-ins of the round objects (YcbTennisBall, the cans, duck_vhacd): reset, rolling without slipping, single
     steps and robot-object contacts against the oracle (k_fast + ObjStep / k_row_list, and the general row kernel)"""
-    rep = parity.check_round_objects(_capi.Engine, hip_lib, panda["table"], names=("YcbTennisBall", "YcbTomatoSoupCan", "YcbChipsCan", "duck_vhacd", "YcbPear"), n=24, flags=flags)
+    rep = parity.check_round_objects(_capi.Engine, hip_lib, panda["table"], names=("YcbTennisBall", "YcbTomatoSoupCan", "YcbMasterChefCan", "duck_vhacd", "YcbPear"), n=24, flags=flags)
     print("round objects:", {k: {kk: v[kk] for kk in ("travel_cm", "free_run_obj_pos_diff", "obj_w", "skipped", "compared", "robot_contact_compared") if kk in v} for k, v in rep.items()})
