@@ -42,11 +42,11 @@ ALG_FLOP_PER_ENV_STEP = 150 * 232 + 8400.0 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
-PROFILE_TAG = "r02"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
+PROFILE_TAG = "r03"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
 
 
 def _profile(name, key=None):
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG,):             # this round's counter passes only (round-2 verdict: no stale profiles behind the line)
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))))
             return (d[key] if key else d), "profiles/%s_%s.json" % (tag, name)
@@ -514,13 +514,16 @@ def main():
         # per-env summary of the counter passes over this same command, scaled to this launch's env count.
         traffic, traffic_src = None, None
         pmc, src = _profile("pmc_hbm", "k_fast<7>")
+        traffic_note = None
         if pmc:
             traffic, traffic_src = pmc["hbm_bytes_per_env_step"] * n_local, src
+            traffic_note = ("counters of the variant that steps the stationary batch (%s: 168 VGPRs, its setup phase spills ~380 B per lane); the "
+                            "256-VGPR variant that runs while no env is complex is spill-free and moves 553 B per env-step (same file)" % pmc.get("variant"))
         sq = None
         d, src = _profile("pmc_sq", "k_fast<7>")
         if d:
             sq = {"valu_insts_per_wave": d["valu_insts_per_wave"], "valu_active_over_wave_cycles": d["valu_active_over_wave_cycles"],
-                  "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "waves_per_simd": 2, "source": src}
+                  "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "variant": d.get("variant"), "source": src}
         rccl = None
         if world > 1:
             try:
@@ -555,7 +558,7 @@ def main():
             "sharded_consumers_no_gather": no_gather,
             "host_inclusive": host,
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU/dependency bound (AI ~166 FLOP/B of the sparse formulation >> 25 FLOP/B machine "

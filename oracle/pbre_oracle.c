@@ -1094,7 +1094,9 @@ static void env_reset_impl(const orc_model* m, const orc_params* prm, const orc_
     real x_min = (real)t->ws_lim[0][0] + (real)0.05, x_max = (real)t->ws_lim[0][1] - (real)0.1;
     real y_min = (real)t->ws_lim[1][0] + (real)0.05, y_max = (real)t->ws_lim[1][1] - (real)0.05;
     real px = x_min + (real)0.5 * (x_max - x_min), py = y_min + (real)0.5 * (y_max - y_min);
-    real pz = (real)t->h_table + (real)0.07, yaw = (real)(0.25 * PI);
+    /* (the robot-level scenes -- ik_absolute: helloworld_icub.py:51, helloworld_panda.py:78 -- load their object with p.loadURDF(path,
+     * position): identity orientation, not WorldEnv's yaw of pi/4) */
+    real pz = (real)t->h_table + (real)0.07, yaw = t->ik_absolute ? (real)0 : (real)(0.25 * PI);
     uint32_t r[4];
     orc_philox4x32((uint32_t)env_id, (uint32_t)(env_id >> 32), episode, 0u, (uint32_t)t->seed, (uint32_t)(t->seed >> 32), r);
     if (t->obj_pose_rnd_std > 0) {

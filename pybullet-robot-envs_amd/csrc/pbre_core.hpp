@@ -1435,7 +1435,9 @@ struct Core {
         const float y_min = P.ws[1][0] + 0.05f, y_max = P.ws[1][1] - 0.05f;
         float px = x_min + 0.5f * (x_max - x_min), py = y_min + 0.5f * (y_max - y_min);
         const float pz = P.h_table + 0.07f;
-        float yaw = 0.78539816339744831f;
+        // (the robot-level scenes -- shapes with a motor record: helloworld_icub.py:51, helloworld_panda.py:78 -- load their object with
+        // p.loadURDF(path, position): identity orientation, not WorldEnv's yaw of pi/4)
+        float yaw = SH::MREC ? 0.f : 0.78539816339744831f;
         if (P.obj_std > 0.f) {
             unsigned r[4];
             philox((unsigned)env_id, (unsigned)(env_id >> 32), episode, 0u, P.seed_lo, P.seed_hi, r);

@@ -70,3 +70,28 @@ def test_hands_apply_action_max_vel(emu_lib):
 def test_hands_five_fingertips_on_the_object(emu_lib):
     w = parity.check_hands_five_fingertips(_capi.Engine, emu_lib, "r")
     assert w["fingertips_in_contact"] == 5
+
+
+def test_helloworld_icub_demo_grasps_and_lifts_the_brick(emu_lib):
+    """The reference's scripted grasp (examples/helloworlds/helloworld_icub.py:61-125) on the stand-alone class, one env on the CPU lane
+    emulation: the fingers close on the brick (>= 3 fingertips in contact), the brick is lifted with the hand (>= 5 cm; the demo raises
+    the hand by 18 cm), carried to the right and dropped back onto the table when the hand opens."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import demo_icub_hands
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+    cid = _client.connect(1, lib=emu_lib)
+    robot = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+    obj, tips = [], []
+
+    def log(line):
+        obj.append(robot.get_object_pose()[0, :3].copy())
+        tips.append(int(np.atleast_1d(robot.check_contact_fingertips()[0])[0]))
+    demo_icub_hands.run(robot, log=log)
+    # after reset, 1 above, 2 turned, 3 closed, 4 up, 5 right, 6 open
+    assert tips[3] >= 3 and tips[4] >= 3, tips
+    assert obj[4][2] - obj[2][2] >= 0.05, obj
+    assert np.hypot(obj[5][0] - 0.3, obj[5][1] + 0.2) < 0.08 and obj[5][2] > obj[2][2] + 0.05, obj
+    assert abs(obj[6][2] - obj[2][2]) < 0.01 and tips[6] == 0, (obj, tips)
+    _client.disconnect(cid)

@@ -134,8 +134,10 @@ def test_hands_force_limited_reset(hip_lib):
 def test_config5_at_size(hip_lib):
     """BASELINE config 5 at its per-GPU size (8192 = 65536 / 8 envs of the 60-DoF iCub with hands): reset and the reference demo's
     scripted phases (pre-grasp -> approach -> grasp -> lift -> move -> open, helloworld_icub.py:61-125) on the whole batch.
-    Size-independent properties: everything finite, unit quaternions, the closing fingers are in contact with the object in every
-    env during the grasp phase, and -- the object pose is not randomised here -- all 8192 replicas are bit-identical."""
+    Size-independent properties: everything finite, unit quaternions, the grasp HOLDS -- at least three fingertips on the brick after
+    the closing phase, the brick goes up with the hand (>= 5 cm above its rest height at the end of the lift; measured 19 cm), is
+    carried to the right and falls back onto the table when the hand opens -- and, the object pose not being randomised here, all
+    8192 replicas are bit-identical."""
     import os, sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import demo_icub_hands
@@ -157,8 +159,11 @@ def test_config5_at_size(hip_lib):
         seen["obj"].append(st[0, nd:nd + 3].copy())
     demo_icub_hands.run(robot, log=log)
     print("config 5 at size:", seen["tips"], "fingertips /", seen["points"], "robot-object contact points seen at the phase ends")
-    moved = np.abs(seen["obj"][3] - seen["obj"][2]).max()
-    assert seen["points"] >= 1 or moved > 5e-3, seen                # the closing fingers reached the object (contacts exercised)
+    obj = seen["obj"]            # after reset, 1 above, 2 turned, 3 closed, 4 up, 5 right, 6 open
+    assert seen["tips"] >= 3, seen
+    assert obj[4][2] - obj[2][2] >= 0.05, ("the grasp did not lift the brick", obj)
+    assert np.hypot(obj[5][0] - 0.3, obj[5][1] + 0.2) < 0.08 and obj[5][2] > obj[2][2] + 0.05, ("the brick was not carried with the hand", obj)
+    assert abs(obj[6][2] - obj[2][2]) < 0.01, ("the released brick did not come to rest on the table", obj)
     obs, _ = robot.get_observation()
     assert obs.shape == (n, 46) and np.isfinite(obs).all()
     _client.disconnect(cid)
