@@ -7,6 +7,10 @@
 // barrier and a workgroup never needs LDS.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef PBRE_HD
+#define PBRE_HD __device__ __forceinline__
+#endif
+#include "pbre_math.hpp"
 
 namespace pbre {
 
@@ -55,6 +59,7 @@ struct DevLanes {
     static __device__ __forceinline__ F sin(F x) { return sinf(x); }
     static __device__ __forceinline__ F cos(F x) { return cosf(x); }
     static __device__ __forceinline__ F asin(F x) { return asinf(x); }
+    static __device__ __forceinline__ void sincos(F x, F& s, F& c) { pbre::sincos_f(x, s, c); }      // shared range reduction (pbre_math.hpp)
     static __device__ __forceinline__ F atan2(F a, F b) { return atan2f(a, b); }
     static __device__ __forceinline__ F fma(F a, F b, F c_) { return __builtin_fmaf(a, b, c_); }
     static __device__ __forceinline__ F min(F a, F b) { return __builtin_fminf(a, b); }
@@ -327,6 +332,7 @@ struct DevLanes128 {
 #define PBRE_U1(name, fn) static __device__ __forceinline__ F name(F x) { return F{fn(x.a), fn(x.b)}; }
     PBRE_U1(abs, __builtin_fabsf) PBRE_U1(sqrt, sqrtf) PBRE_U1(sin, sinf) PBRE_U1(cos, cosf) PBRE_U1(asin, asinf)
 #undef PBRE_U1
+    static __device__ __forceinline__ void sincos(F x, F& s, F& c) { pbre::sincos_f(x.a, s.a, c.a); pbre::sincos_f(x.b, s.b, c.b); }
     static __device__ __forceinline__ F atan2(F x, F y) { return F{atan2f(x.a, y.a), atan2f(x.b, y.b)}; }
     static __device__ __forceinline__ F fma(F x, F y, F z) { return F{__builtin_fmaf(x.a, y.a, z.a), __builtin_fmaf(x.b, y.b, z.b)}; }
     static __device__ __forceinline__ F min(F x, F y) { return F{__builtin_fminf(x.a, y.a), __builtin_fminf(x.b, y.b)}; }

@@ -146,7 +146,8 @@ struct Core {
     // pybullet getQuaternionFromEuler / getEulerFromQuaternion
     static PBRE_HD Q4 euler_quat(const V3& e) {
         F h = L::c(.5f);
-        F cr = L::cos(e.x * h), sr = L::sin(e.x * h), cp = L::cos(e.y * h), sp = L::sin(e.y * h), cy = L::cos(e.z * h), sy = L::sin(e.z * h);
+        F cr, sr, cp, sp, cy, sy;
+        L::sincos(e.x * h, sr, cr); L::sincos(e.y * h, sp, cp); L::sincos(e.z * h, sy, cy);
         Q4 q; q.x = sr*cp*cy - cr*sp*sy; q.y = cr*sp*cy + sr*cp*sy; q.z = cr*cp*sy - sr*sp*cy; q.w = cr*cp*cy + sr*sp*sy;
         return q;
     }
@@ -183,7 +184,9 @@ struct Core {
         V3 p0 = v3(L::load(T.p0[0]), L::load(T.p0[1]), L::load(T.p0[2]));
         // Rodrigues rotation about the joint axis (identity for non-revolute lanes)
         F th = L::sel(rev, q, L::c(0.f));
-        F c = L::cos(th), s = L::sin(th), C = L::c(1.f) - c;
+        F c, s;
+        L::sincos(th, s, c);
+        F C = L::c(1.f) - c;
         M3 Rj;
         Rj.m[0] = c + ax.x*ax.x*C;      Rj.m[1] = ax.x*ax.y*C - ax.z*s; Rj.m[2] = ax.x*ax.z*C + ax.y*s;
         Rj.m[3] = ax.y*ax.x*C + ax.z*s; Rj.m[4] = c + ax.y*ax.y*C;      Rj.m[5] = ax.y*ax.z*C - ax.x*s;
@@ -1138,8 +1141,10 @@ struct Core {
             F cap = L::c(0.78539816339744831f) * inv_dt;
             ang = L::sel(L::gt(ang * dt, L::c(0.78539816339744831f)), cap, ang);
             F small = L::c(0.5f) * dt - dt * dt * dt * L::c(0.020833333333f) * ang * ang;
-            F sc_ = L::sel(L::lt(ang, L::c(0.001f)), small, L::sin(L::c(0.5f) * ang * dt) / L::max(ang, L::c(1e-30f)));
-            Q4 dq; dq.x = wn.x * sc_; dq.y = wn.y * sc_; dq.z = wn.z * sc_; dq.w = L::cos(ang * dt * L::c(0.5f));
+            F sh_, ch_;
+            L::sincos(L::c(0.5f) * ang * dt, sh_, ch_);
+            F sc_ = L::sel(L::lt(ang, L::c(0.001f)), small, sh_ / L::max(ang, L::c(1e-30f)));
+            Q4 dq; dq.x = wn.x * sc_; dq.y = wn.y * sc_; dq.z = wn.z * sc_; dq.w = ch_;
             Q4 nq = qmul(dq, oq);
             F in = one / L::sqrt(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
             F qc = L::sel(L::eqi(lane, LC + 3), nq.x, L::sel(L::eqi(lane, LC + 4), nq.y, L::sel(L::eqi(lane, LC + 5), nq.z, nq.w)));

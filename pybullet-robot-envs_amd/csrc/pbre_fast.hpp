@@ -17,6 +17,7 @@
 #pragma once
 #include <math.h>
 #include "pbre_tables.hpp"
+#include "pbre_math.hpp"
 
 #ifndef PBRE_HD
 #define PBRE_HD
@@ -118,27 +119,7 @@ struct Fast {
 #endif
     static constexpr int sym(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-    // sin and cos of one argument with one shared range reduction (Cody-Waite, pi/2 in three parts) and degree-7 / degree-8 minimax
-    // polynomials on [-pi/4, pi/4]: absolute error <= 1.3e-7 for |x| < 1e3 (joint angles, Euler half-angles and yaw samples are all below 2 pi), ~28
-    // instructions for the pair against ~240 (with a Payne-Hanek slow path each) for separate sinf() and cosf() calls -- a step
-    // evaluates 23 pairs, and the straight-line setup code of the kernel shrinks by a fifth.  Plain C++: the host emulation runs
-    // the same arithmetic.
-    static PBRE_HD void sincos_(float x, float& sn, float& cs) {
-        const float kf = rintf(x * 0.63661977236758134f);
-        float r = fmaf(-kf, 1.5707855224609375f, x);          // pi/2 = 1.5707855224609375 + 1.0804334124e-5 + 6.0770999344e-11 (fdlibm's split)
-        r = fmaf(-kf, 1.0804334124e-5f, r);
-        r = fmaf(-kf, 6.0770999344e-11f, r);
-        const float z = r * r;
-        const float ps = fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
-        const float s0 = fmaf(r * z, ps, r);                   // r + r^3 (...)
-        const float pc = fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
-        const float c0 = fmaf(z * z, pc, fmaf(-0.5f, z, 1.f));
-        const int k = (int)kf;
-        const bool swap = (k & 1) != 0;
-        const float sv = swap ? c0 : s0, cv = swap ? s0 : c0;
-        sn = (k & 2) ? -sv : sv;
-        cs = ((k + 1) & 2) ? -cv : cv;
-    }
+    static PBRE_HD void sincos_(float x, float& sn, float& cs) { sincos_f(x, sn, cs); }      // pbre_math.hpp
 
     struct Q4 { float x, y, z, w; };
     static PBRE_HD M3 quat_R(Q4 q) {

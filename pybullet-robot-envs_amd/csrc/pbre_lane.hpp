@@ -129,7 +129,7 @@ struct Lane {
         const V3 p0 = v3(T.p0[0][j], T.p0[1][j], T.p0[2][j]);
         if (Topo::jtype(j) == 1) {
             float c, sn;
-            sincosf(qj, &sn, &c);                     // one range reduction for both
+            FX::sincos_(qj, sn, c);                   // shared-reduction sin / cos (pbre_fast.hpp: ~28 instructions, no slow path)
             const float C = 1.f - c;
             M3 Rj;
             Rj.m[0] = c + ax.x*ax.x*C;       Rj.m[1] = ax.x*ax.y*C - ax.z*sn; Rj.m[2] = ax.x*ax.z*C + ax.y*sn;
@@ -540,8 +540,10 @@ struct Lane {
             op = v3(fmaf(dt, ov.x, op.x), fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
             float ang = norm(ow);
             if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * inv_dt;
-            const float sc_ = ang < 0.001f ? 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang : sinf(0.5f * ang * dt) / ang;
-            Q4 dq; dq.x = ow.x * sc_; dq.y = ow.y * sc_; dq.z = ow.z * sc_; dq.w = cosf(ang * dt * 0.5f);
+            float sh_, ch_;
+            FX::sincos_(0.5f * ang * dt, sh_, ch_);
+            const float sc_ = ang < 0.001f ? 0.5f * dt - dt * dt * dt * 0.020833333333f * ang * ang : sh_ / ang;
+            Q4 dq; dq.x = ow.x * sc_; dq.y = ow.y * sc_; dq.z = ow.z * sc_; dq.w = ch_;
             const Q4 nq = FX::qmul(dq, oq);
             const float in = 1.f / sqrtf(nq.x*nq.x + nq.y*nq.y + nq.z*nq.z + nq.w*nq.w);
             oq.x = nq.x * in; oq.y = nq.y * in; oq.z = nq.z * in; oq.w = nq.w * in;

@@ -4,6 +4,7 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include "../../pybullet-robot-envs_amd/csrc/pbre_math.hpp"
 
 namespace pbre_emu {
 
@@ -49,6 +50,7 @@ struct HostLanesT {
 #define U1(name, expr) static F name(const F& a) { F r; for (int i = 0; i < W; i++) { float x = a.v[i]; r.v[i] = (expr); } return r; }
     U1(abs, std::fabs(x)) U1(sqrt, std::sqrt(x)) U1(sin, std::sin(x)) U1(cos, std::cos(x)) U1(asin, std::asin(x))
 #undef U1
+    static void sincos(const F& a, F& s, F& c) { for (int i = 0; i < W; i++) pbre::sincos_f(a.v[i], s.v[i], c.v[i]); }      // same arithmetic as the device
     static F fma(const F& a, const F& b, const F& c_) { F r; for (int i = 0; i < W; i++) r.v[i] = std::fma(a.v[i], b.v[i], c_.v[i]); return r; }
     static F min(const F& a, const F& b) { F r; for (int i = 0; i < W; i++) r.v[i] = std::fmin(a.v[i], b.v[i]); return r; }
     static F max(const F& a, const F& b) { F r; for (int i = 0; i < W; i++) r.v[i] = std::fmax(a.v[i], b.v[i]); return r; }

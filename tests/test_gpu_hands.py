@@ -163,7 +163,7 @@ def test_config5_at_size(hip_lib):
     assert seen["tips"] >= 3, seen
     assert obj[4][2] - obj[2][2] >= 0.05, ("the grasp did not lift the brick", obj)
     assert np.hypot(obj[5][0] - 0.3, obj[5][1] + 0.2) < 0.08 and obj[5][2] > obj[2][2] + 0.05, ("the brick was not carried with the hand", obj)
-    assert abs(obj[6][2] - obj[2][2]) < 0.01, ("the released brick did not come to rest on the table", obj)
+    assert 0.625 + 0.02 < obj[6][2] < 0.625 + 0.045, ("the released brick did not come to rest on the table (on one of its faces)", obj)
     obs, _ = robot.get_observation()
     assert obs.shape == (n, 46) and np.isfinite(obs).all()
     _client.disconnect(cid)
