@@ -367,19 +367,28 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
             if (RC || has_rt) contacts();
         }
     };
-    solve(motor_free);
-    {
+    // The clamp-free attempt is only worth making in a wave without contact rows: a hand pressed on the table or on the object is
+    // exactly where a position motor runs into its impulse bound (the contact stops what the motor drives), the attempt then fails
+    // and the solve runs twice -- in the stationary random-action mix that was most waves.  Either way an env's result is the same
+    // (a clamping row whose clamp does not bind returns the free row's delta bit for bit).  PBRE_QUAD_FREE_ALWAYS=1: round 2's rule (A/B).
+#ifndef PBRE_QUAD_FREE_ALWAYS
+#define PBRE_QUAD_FREE_ALWAYS 0
+#endif
+    bool again = true;
+    if (PBRE_QUAD_FREE_ALWAYS || !(RC || has_rt)) {
+        solve(motor_free);
         const bool over = !(peak <= mlim);      // (a NaN fails the test as well)
-        if (__any((int)over)) {
+        again = __any((int)over) != 0;
+        if (again) {
             PBRE_UNROLL for (int i = 0; i < QD; i++) { w[i] = w0[i]; sabs[i] = 0.f; l_app[i] = 0.f; }
             PBRE_UNROLL for (int c = 0; c < NRT; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
             if (RC) {
                 ob.setup(P, pose, tw0, P.obj_m, P.obj_mu, P.kl);
                 PBRE_UNROLL for (int c = 0; c < NRO; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) o_app[c][d] = 0.f;
             }
-            solve(motor);
         }
     }
+    if (again) solve(motor);
     // ---- integrate the joints (semi-implicit Euler)
     PBRE_UNROLL for (int i = 0; i < QD; i++) {
         const float v = fminf(fmaxf(w[i], -vmax), vmax);
@@ -555,10 +564,15 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             mark(0, s);
             if (side) { (void)hipEventRecord(ev_fork, s); (void)hipStreamWaitEvent(side, ev_fork, 0); }
             mark(1, s2);
-            if (!(flags & 1)) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
-            mark(2, s2);
+            // (Cartesian control: the IK kernel is the head of the step's critical path -- IK -> kw_quad_rc -> kw_fin -- so it goes first
+            // on the side stream and the object solve moves to the caller's stream behind kw_quad, which is done before kw_quad_rc on the
+            // side stream anyway (measured: beside the IK kernel -- right behind kw_dyn -- it stretched that kernel from 0.41 to 0.66 ms);
+            // joint control: the object solve stays on the side stream, beside kw_dyn)
             const bool ik_side = ik_pending;
-            if (ik_side) {      // (after kw_obj: kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
+            const bool obj_main = ik_side && side != nullptr;
+            if (!(flags & 1) && !obj_main) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
+            mark(2, s2);
+            if (ik_side) {      // (kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
                 hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim);
                 (void)hipEventRecord(ev_ik, side);
                 ik_pending = false;
@@ -578,6 +592,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs);
             mark(9, s);
             if (ek) (void)hipEventRecord(ek[1], s);
+            if (!(flags & 1) && obj_main) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s, P, state, objv, n);
             if (side) (void)hipStreamWaitEvent(s, ev_join, 0);
             mark(10, s);
             hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, dyn, dyn_cs, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
