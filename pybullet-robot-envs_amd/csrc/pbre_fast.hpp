@@ -243,6 +243,16 @@ struct Fast {
         n = mv(Rb, nl); pb = add(bc, mv(Rb, c2));
         return inside ? -best - sr : len - sr;
     }
+
+    // full test against the object, whatever its primitive: signed distance, world normal object -> sphere, point on the object
+    static PBRE_HD float sphere_obj(const Params& P, V3 sc, float sr, V3 bc, const M3& Rb, V3 h, V3& n, V3& pb) {
+        if (P.obj_shape == 0) return sphere_box(sc, sr, bc, Rb, h, n, pb);
+        const float s_[3] = {sc.x, sc.y, sc.z}, c_[3] = {bc.x, bc.y, bc.z}, h_[3] = {h.x, h.y, h.z};
+        float n_[3], pb_[3];
+        const float d = Shapes::sphere_round(P.obj_shape, s_, sr, c_, Rb.m, h_, n_, pb_);
+        n = v3(n_[0], n_[1], n_[2]); pb = v3(pb_[0], pb_[1], pb_[2]);
+        return d;
+    }
     struct Cand { float dist; int idx; V3 n, pA, pB; float mu; int owner; };
     static PBRE_HD bool better(const Cand& x, const Cand& y) { return x.dist < y.dist || (x.dist == y.dist && x.idx < y.idx); }
     // keep the two best (smallest distance, ties -> lowest sphere index) candidates below the margin

@@ -493,8 +493,8 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         if (ev_ik) (void)hipEventDestroy(ev_ik);
         sp.destroy();
     }
-    // (the pipeline's collision code is the box's: a round object -- pbre_physics.obj_shape -- is stepped by the lane-group kernel)
-    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr && this->P.obj_shape == 0; }
+    // (round objects -- pbre_physics.obj_shape -- included: the object's own rows are ObjStep's, the robot-object test is Fast::sphere_obj)
+    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr; }
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");

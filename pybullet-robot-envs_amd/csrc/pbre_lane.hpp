@@ -200,7 +200,7 @@ struct Lane {
                     const float reach = sr + P.margin + orad;
                     if (PBRE_ANY(!(dot(dd, dd) >= reach * reach))) {
                         typename FX::Cand c; c.idx = sp; c.owner = j;
-                        c.dist = FX::sphere_box(sc, sr, op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
+                        c.dist = FX::sphere_obj(P, sc, sr, op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
                         c.mu = T.s_mu[sp] * P.obj_mu;
                         FX::keep2(c, P.margin, o1, o2);
                     }
@@ -585,7 +585,7 @@ struct Lane {
                 if (obj_on) {
                     const V3 dd = sub(sc, op);
                     const float reach = sr + P.margin + orad;
-                    if (PBRE_ANY(!(dot(dd, dd) >= reach * reach)) && FX::sphere_box_dist(sc, sr, op, Ro, oh) < P.margin) nO++;
+                    if (PBRE_ANY(!(dot(dd, dd) >= reach * reach)) && FX::sphere_obj_dist(P, sc, sr, op, Ro, oh) < P.margin) nO++;
                 }
             }
             if (qd) {

@@ -81,7 +81,7 @@ struct Emu : pbre_ctx {
         }
         if constexpr (std::is_same<S, Shape32>::value) {
             // the device's kw_lane / kw_list pair (pbre_wide.hip): task-env steps of the whole batch; settle steps stay on the lane-group kernel
-            if (lane_ok && P.obj_shape == 0 && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
+            if (lane_ok && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
                 if (LaneH::classify_state(T, P, st, flags) == 0) {
                     n_fast++;
                     float mi[LaneH::NM];
@@ -117,7 +117,7 @@ struct Emu : pbre_ctx {
     void ik(float* st, const float* act, float* tg, bool rst) {
         if constexpr (PANDA) FastH::ik_targets(T, P, st, act, tg, rst);
         else {
-            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && P.obj_shape == 0 && !rst) { LaneH::ik_targets(T, P, st, act, tg); return; } }
+            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && !rst) { LaneH::ik_targets(T, P, st, act, tg); return; } }
             CoreH::ik_targets(T, P, st, act, tg, rst);
         }
     }

@@ -1480,12 +1480,46 @@ def icub_contact_states(ora, info, base, rng, n_obj=12, n_table=12, n_both=12, n
                 return q
         raise RuntimeError("no table-contact configuration found")
 
+    shape = int(ora.params.obj_shape)
+
+    def clear_of_object(q, s):
+        from pybullet_robot_envs.model import contacts as _ct
+        cs = centres(q)
+        C = np.array([c for c, _ in cs]); Rr = np.array([r for _, r in cs])
+        oc = np.asarray(s[nd:nd + 3], float)
+        qo = np.asarray(s[nd + 3:nd + 7], float)
+        Ro = np.broadcast_to(_ct._quat_R(qo[None])[0], (len(cs), 3, 3))
+        dist = (_ct._sphere_box_dist(C, Rr, oc[None], Ro, oh) if shape == 0 else _ct._sphere_round_dist(shape, C, Rr, oc[None], Ro, oh))
+        return dist.min() > 0.005
+
     def put_object(s, q, pen=0.002):
-        c, r = centres(q)[rng.integers(0, len(sph))]
-        d = rng.normal(size=3); d[2] = -abs(d[2]); d /= np.linalg.norm(d)           # the object lies below / beside the hand
-        k = int(np.argmax(np.abs(d)))                                               # face the sphere with the box's nearest face
-        dd = np.zeros(3); dd[k] = np.sign(d[k])
-        s[nd:nd + 3] = c + dd * (r + oh[k] - pen)
+        """the object against one arm sphere, ~pen deep; no other sphere deeper than that, the object not sunk into the table"""
+        from pybullet_robot_envs.model import contacts as _ct
+        cs = centres(q)
+        C = np.array([c for c, _ in cs]); Rr = np.array([r for _, r in cs])
+        I3 = np.broadcast_to(np.eye(3), (len(cs), 3, 3))
+        for _ in range(4000):
+            i = rng.integers(0, len(sph))
+            c, r = cs[i]
+            d = rng.normal(size=3); d[2] = -abs(d[2]); d /= np.linalg.norm(d)       # the object lies below / beside the hand
+            k = int(np.argmax(np.abs(d)))                                           # face the sphere with the box's nearest face
+            dd = np.zeros(3); dd[k] = np.sign(d[k])
+            ext = oh[k]
+            if shape == 1:                                                          # ball: any direction, radius oh[0]
+                dd, ext = d, oh[0]
+            elif shape == 2 and k < 2:                                              # upright cylinder touched on its side: radial direction
+                dd = np.array([d[0], d[1], 0.0]) / np.hypot(d[0], d[1]); ext = oh[0]
+            oc = c + dd * (r + ext - pen)
+            if shape != 1 and k < 2 and oc[2] - oh[2] < ztop and abs(ztop + oh[2] + 2e-4 - c[2]) < oh[2] - 1e-3:
+                oc[2] = ztop + oh[2] + 2e-4                                          # touched on its side: stand it on the table
+            dist = (_ct._sphere_box_dist(C, Rr, oc[None], I3, oh) if shape == 0 else _ct._sphere_round_dist(shape, C, Rr, oc[None], I3, oh))
+            bottom = oc[2] - (oh[0] if shape == 1 else oh[2])
+            over_table = abs(oc[0] - ora.params.table_c[0]) < ora.params.table_h[0] and abs(oc[1] - ora.params.table_c[1]) < ora.params.table_h[1]
+            if dist.min() >= -(pen + 5e-4) and (not over_table or bottom >= ztop - 1e-3):
+                break
+        else:
+            raise RuntimeError("no object placement found")
+        s[nd:nd + 3] = oc
         s[nd + 3:nd + 7] = [0, 0, 0, 1]
         s[vo + nd:vo + nd + 6] = rng.normal(0, 0.1, 6)
 
@@ -1493,10 +1527,15 @@ def icub_contact_states(ora, info, base, rng, n_obj=12, n_table=12, n_both=12, n
     for kind, cnt in (("object", n_obj), ("table", n_table), ("both", n_both), ("limit", n_limit)):
         for _ in range(cnt):
             s = np.array(base, float)
-            q = table_config() if kind in ("table", "both") else arm_config(0.3)
-            if kind == "limit":
-                j = ctrl[rng.integers(0, len(ctrl))]
-                q[j] = (lo[j] - rng.uniform(0.005, 0.02)) if rng.random() < 0.5 else (hi[j] + rng.uniform(0.005, 0.02))
+            for _ in range(200):
+                q = table_config() if kind in ("table", "both") else arm_config(0.3)
+                if kind == "limit":
+                    j = ctrl[rng.integers(0, len(ctrl))]
+                    q[j] = (lo[j] - rng.uniform(0.005, 0.02)) if rng.random() < 0.5 else (hi[j] + rng.uniform(0.005, 0.02))
+                if kind in ("object", "both") or clear_of_object(q, s):
+                    break                                                           # (a big object at its reset pose: the arm must not be inside it)
+            else:
+                raise RuntimeError("no arm configuration clear of the object found")
             s[:nd] = q
             s[vo:vo + nd] = 0.0
             s[vo + np.array(ctrl)] = rng.normal(0, 0.3, len(ctrl))
@@ -1506,15 +1545,27 @@ def icub_contact_states(ora, info, base, rng, n_obj=12, n_table=12, n_both=12, n
     return np.array(out), kinds
 
 
-def check_icub_contact_states(Engine, lib, n_each=12, steps=1, seed=21, control_arm="l"):
+def check_icub_contact_states(Engine, lib, n_each=12, steps=1, seed=21, control_arm="l", obj_name=None):
     """>= 48 crafted contact states of the iCub push env (joint control), one step each against the oracle with per-quantity bounds
-    (TOL_ICUB_CONTACT); states whose contact set flips under a +-3 um nudge of the margin are skipped and counted."""
-    eng0, ora, info = make_icub_pair(Engine, lib, 1, task=1, control_arm=control_arm, use_ik=0, obj_std=0.0, tg_std=0.2)
+    (TOL_ICUB_CONTACT); states whose contact set flips under a +-3 um nudge of the margin are skipped and counted.
+    obj_name: a member of the object list instead of the cube (model/objects.py; the round ones: sphere / cylinder primitives)."""
+    kw = {}
+    ph = None
+    if obj_name is not None:
+        from pybullet_robot_envs.model.objects import object_physics
+        ph = object_physics(obj_name)
+        kw["phys"] = ph
+    eng0, ora, info = make_icub_pair(Engine, lib, 1, task=1, control_arm=control_arm, use_ik=0, obj_std=0.0, tg_std=0.2, **kw)
+    if ph is not None:
+        orc.set_object(ora, ph)
     base, _ = ora.batch_reset(1)
     rng = np.random.default_rng(seed)
     S, kinds = icub_contact_states(ora, info, base[0], rng, n_each, n_each, n_each, n_each, control_arm)
     n = len(S)
-    eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm=control_arm, use_ik=0, obj_std=0.0, tg_std=0.2, max_steps=10 ** 6)
+    eng, ora, info = make_icub_pair(Engine, lib, n, task=1, control_arm=control_arm, use_ik=0, obj_std=0.0, tg_std=0.2, max_steps=10 ** 6, **kw)
+    if ph is not None:
+        orc.set_object(ora, ph)
+        assert eng.get_physics().obj_shape == ph["obj_shape"] == ora.params.obj_shape
     ora.task.max_steps = 10 ** 6
     eng.reset()
     kinds = np.array(kinds)

@@ -116,6 +116,15 @@ def test_icub_crafted_contact_states(emu_lib):
     assert rep["states"] == 12
 
 
+@pytest.mark.parametrize("obj_name", ["YcbTennisBall", "duck_vhacd"])
+def test_icub_crafted_contact_states_round_objects(emu_lib, monkeypatch, obj_name):
+    """the same with a round object (sphere / upright cylinder primitive), through the lane-per-env code (PBRE_ICUB_LANE=1: the device
+    pipeline's dynamics and classifier; complex envs by the lane-group code) -- iCubReach-v0's default object is the duck"""
+    monkeypatch.setenv("PBRE_ICUB_LANE", "1")
+    rep = parity.check_icub_contact_states(_capi.Engine, emu_lib, n_each=2, obj_name=obj_name)
+    assert rep["states"] == 8
+
+
 def test_icub_push_closed_loop_against_oracle(emu_lib):
     rep = parity.check_icub_push_closed_loop(_capi.Engine, emu_lib, n=2)
     assert rep["touched_envs"] == 2

@@ -202,6 +202,26 @@ def test_icub_crafted_contact_states(hip_lib, monkeypatch, lane):
     assert rep["states"] == 48
 
 
+@pytest.mark.parametrize("obj_name,lane", [("YcbTennisBall", "1"), ("YcbMasterChefCan", "1"), ("duck_vhacd", "1"), ("YcbMasterChefCan", "0")])
+def test_icub_crafted_contact_states_round_objects(hip_lib, monkeypatch, obj_name, lane):
+    """the crafted contact states with a round object (sphere / cylinder primitive) through the pipeline (lane = 1: hand on the ball /
+    can / duck is kw_quad_rc's coupled solve with Fast::sphere_obj rows, the object's own rows are ObjStep's shape candidates) and
+    through the lane-group kernel (lane = 0: what batches below 16384 envs run)"""
+    monkeypatch.setenv("PBRE_ICUB_LANE", lane)
+    rep = parity.check_icub_contact_states(_capi.Engine, hip_lib, n_each=12, obj_name=obj_name)
+    print("iCub crafted contact states, %s (PBRE_ICUB_LANE=%s):" % (obj_name, lane), rep)
+    assert rep["states"] == 48 and (rep["complex_envs_stepped"] > 0) == (lane == "1")
+
+
+def test_icub_reach_default_object_runs_the_pipeline(hip_lib):
+    """iCubReach-v0's default object (the duck: a round primitive) must not push the batch back to the lane-group kernel"""
+    from pybullet_robot_envs.envs import iCubReachGymEnv
+    env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=16384, _lib=hip_lib)
+    env.reset()
+    assert env._engine.get_physics().obj_shape != 0 and env._engine.kernel_info()[2] == 1
+    env.close()
+
+
 def test_icub_push_closed_loop_against_oracle(hip_lib):
     rep = parity.check_icub_push_closed_loop(_capi.Engine, hip_lib, n=8)
     print("iCub closed-loop push:", rep)
