@@ -1397,7 +1397,12 @@ struct Core {
             PBRE_UNROLL for (int a = 5; a >= 0; a--) { F sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = sum - G[k][a] * y[k]; y[a] = sum / G[a][a]; }
             F dq = zero;
             PBRE_UNROLL for (int a = 0; a < 6; a++) dq = L::fma(J[a], y[a], dq);
-            q = L::sel(L::band(go, chain), q + dq, q);
+            const F qn = L::sel(L::band(go, chain), q + dq, q);
+            const bool moved = L::any(L::ne(qn, q));
+            q = qn;
+            // no joint angle of any group of the wave changed (targets out of reach: the damped step is below half an ulp): every further
+            // iteration would repeat this one, leaving gives the same targets bit for bit
+            if (!moved) break;
         }
         // joints off the chain: the iCub sends them to their rest pose (icub_env.py:316-317), PyBullet returns the Panda's
         // current finger positions

@@ -1005,11 +1005,17 @@ struct Fast {
                 }
             PBRE_UNROLL for (int a = 0; a < 6; a++) { float sum = e[a]; PBRE_UNROLL for (int k = 0; k < a; k++) sum = fmaf(-A[a][k], y[k], sum); y[a] = sum / A[a][a]; }
             PBRE_UNROLL for (int a = 5; a >= 0; a--) { float sum = y[a]; PBRE_UNROLL for (int k = a + 1; k < 6; k++) sum = fmaf(-A[k][a], y[k], sum); y[a] = sum / A[a][a]; }
+            bool moved = false;
             PBRE_UNROLL for (int j = 0; j < ND; j++) {
                 float dq = 0.f;
                 PBRE_UNROLL for (int a = 0; a < 6; a++) dq = fmaf(J[a][j], y[a], dq);
-                q[j] = done ? q[j] : q[j] + dq;
+                const float qn = done ? q[j] : q[j] + dq;
+                moved = moved || qn != q[j];
+                q[j] = qn;
             }
+            // no joint angle of any env of the wave changed (targets out of reach: the damped step is below half an ulp): every further
+            // iteration would repeat this one, leaving gives the same targets bit for bit
+            if (!PBRE_ANY(moved)) break;
         }
     }
     // apply_action, IK branch (panda_push_gym_env.py:197-222 + panda_env.py:229-291): accumulate the scaled Cartesian action into

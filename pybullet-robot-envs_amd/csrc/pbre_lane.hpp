@@ -819,6 +819,7 @@ struct Lane {
             }
             // (every division by a diagonal entry of the factor is a multiplication by its reciprocal, taken once: 6 reciprocals instead
             // of 27 divisions on this kernel's critical chain -- a lone wave per SIMD iterating up to 100 times)
+            bool moved = false;
             float y[6], inv[6];
             PBRE_UNROLL for (int a = 0; a < 6; a++)
                 PBRE_UNROLL for (int b = 0; b <= a; b++) {
@@ -833,8 +834,13 @@ struct Lane {
                 const V3 jl = Topo::jtype(j) == 1 ? cross(aw[j], sub(pe, p[j])) : aw[j];
                 const V3 ja = Topo::jtype(j) == 1 ? aw[j] : v3(0.f, 0.f, 0.f);
                 const float dq = fmaf(jl.x, y[0], fmaf(jl.y, y[1], fmaf(jl.z, y[2], fmaf(ja.x, y[3], fmaf(ja.y, y[4], ja.z * y[5])))));
-                q[j] = go ? q[j] + dq : q[j];
+                const float qn = go ? q[j] + dq : q[j];
+                moved = moved || qn != q[j];
+                q[j] = qn;
             }
+            // an iteration that changes no joint angle of any env of the wave (targets out of reach: the damped step has shrunk below half
+            // an ulp of every angle) would be repeated unchanged until the iteration cap: leaving here gives the same targets bit for bit
+            if (!PBRE_ANY(moved)) break;
         }
         // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
         // their current angle
