@@ -254,10 +254,10 @@ def other_configs(torch, dev, steps=10):
         r["mean_robot_object_contact_points"] = float(o[:, -3].mean())
         r["_envs_per_wave"] = 1
         roof(r, robot._engine, 1750.0, "pmc_hands", "valu_insts_per_wave")      # ~1.75 KB per env-step
-        out["icub_hands_config5_standin"] = r
+        out["icub_hands_config5"] = r
         _client.disconnect(cid)
     except Exception as e:
-        out["icub_hands_config5_standin"] = {"error": repr(e)}
+        out["icub_hands_config5"] = {"error": repr(e)}
     return out
 
 

@@ -840,7 +840,9 @@ struct Lane {
             }
             // an iteration that changes no joint angle of any env of the wave (targets out of reach: the damped step has shrunk below half
             // an ulp of every angle) would be repeated unchanged until the iteration cap: leaving here gives the same targets bit for bit
+#ifndef PBRE_IK_NO_FIXPOINT_EXIT
             if (!PBRE_ANY(moved)) break;
+#endif
         }
         // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
         // their current angle

@@ -247,3 +247,24 @@ def test_round_objects(panda, emu_lib, flags):
     (lane-per-env kernel + ObjStep with the row kernel for robot contacts, and the general row kernel)"""
     rep = parity.check_round_objects(_capi.Engine, emu_lib, panda["table"], n=3, flags=flags)
     assert rep["YcbTennisBall"]["travel_cm"] > 5 and rep["YcbTomatoSoupCan"]["travel_cm"] > 5
+
+
+def test_closed_form_motor_rows_match_the_sequential_rows(panda, emu_lib):
+    """The simple class applies its 150 sweeps over the clamp-free motor rows in closed form (a matrix power, Fast::motor_closed);
+    PBRE_F_SEQ_MOTORS runs Bullet's sequential rows instead.  Same states, one step each: the object (which the motor rows do not
+    touch) bit for bit, everything else within a quarter of the single-step bounds against the oracle."""
+    n = 12
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=emu_lib)
+    c = _capi.Engine(panda["table"], **kw)
+    s = _capi.Engine(panda["table"], flags=_capi.F_SEQ_MOTORS, **kw)
+    c.reset(); s.reset()
+    rng = np.random.default_rng(8)
+    for _ in range(4):
+        a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        s.set_state(c.get_state())
+        (obc, rwc, dnc), (obs_, rws, dns) = c.step(a), s.step(a)
+        sc, ss = c.get_state(), s.get_state()
+        assert np.array_equal(sc[:, 9:16], ss[:, 9:16]) and np.array_equal(sc[:, 25:31], ss[:, 25:31]) and np.array_equal(dnc, dns)
+        out_s = np.concatenate([obs_, rws[:, None], dns[:, None]], 1).astype(np.float64)
+        q = parity.panda_quantities(sc, ss.astype(np.float64), obc, out_s, rwc)
+        parity.assert_within(q, dict((k, 0.25 * v) for k, v in parity.TOL.items()), "(closed-form motor rows against the sequential rows)")

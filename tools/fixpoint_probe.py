@@ -1,4 +1,7 @@
-"""After how many PGS sweeps do the solver blocks of the simple-env step (Fast::step_t<false>) stop changing a single bit?
+"""(Round-3 note: the probe's hook lived in the sequential motor / object loop of Fast::step_t as of commit f21640c; the closed-form
+motor rows of the following commit removed that loop, so `make build/libpbre_emu_probe.so` reproduces the committed histogram only at
+f21640c -- `git worktree add /tmp/probe f21640c` -- and builds a probe-less library at HEAD.)
+After how many PGS sweeps do the solver blocks of the simple-env step (Fast::step_t<false>) stop changing a single bit?
 
 Runs the CPU lane-emulation build with -DPBRE_FIXPOINT_PROBE (tests/host_emu: build/libpbre_emu_probe.so) on a Panda-push batch in
 bench.py's stationary protocol (de-synchronised episode clocks, i.i.d. U(-1,1) actions, in-kernel auto-reset) and prints, per
