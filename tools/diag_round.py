@@ -1,3 +1,6 @@
+"""Crafted iCub contact states (tests/parity.py: check_icub_contact_states) per object primitive and kernel path, in measurement mode:
+prints the worst difference to the oracle per contact kind (hand on the object / on the table / both / joint limit).  GPU box.
+    python tools/diag_round.py"""
 import os, sys, json
 sys.path.insert(0, "tests"); sys.path.insert(0, "pybullet-robot-envs_amd")
 os.environ["PBRE_PARITY_MEASURE"] = "1"
