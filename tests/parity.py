@@ -1754,3 +1754,132 @@ def check_icub_push_closed_loop(Engine, lib, n=8, steps=330, seed=6):
         assert rep["touched_envs"] == n and (le > 0.02).all() and (lo_ > 0.02).all(), rep
         assert (np.linalg.norm(de - do, axis=1) <= 0.003 + 0.05 * lo_).all(), rep
     return rep
+
+
+def check_hands_demo_against_oracle(lib, n=1):
+    """BASELINE config 5 closed loop: the reference's scripted grasp (examples/helloworlds/helloworld_icub.py:61-125) through the drop-in
+    iCubHandsEnv on the engine AND, command by command, on the fp64 oracle (every pbre_apply_action / pbre_set_motors / pbre_settle the
+    class issues is mirrored by orc_hands_apply_action / orc_hands_set_motors / orc_hands_settle): ~370 free-running steps with the
+    fingers closing on the brick, lifting, carrying and releasing it.  Compared per phase: the brick's position.  Bounds (measured on the
+    lane emulation / the GPU -> bound): fingers closed 0.3 mm -> 2 mm; lifted (19.5 cm up in both) 1.3 mm -> 5 mm; carried 5 mm -> 2 cm;
+    after the release the brick tumbles onto the table: both at rest height of some face, landing spots within 8 cm."""
+    import math as m
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.icub_envs.icub_env_with_hands import iCubHandsEnv
+    cid = _client.connect(n, lib=lib)
+    robot = iCubHandsEnv(cid, use_IK=1, control_arm='r')
+    eng = robot._engine
+    ora, tbl, info = orc.hands_oracle('r', use_ik=1)
+    ph = eng.get_physics()
+    for f in ("table_c", "table_h", "obj_h", "obj_inertia"):
+        for k in range(3):
+            getattr(ora.params, f)[k] = getattr(ph, f)[k]
+    ora.params.obj_mass = ph.obj_mass
+    ora.params.implicit_joint_damping = ph.implicit_joint_damping
+    st_o, mrec, _ = ora.hands_reset(n)
+    nd = eng.ndof
+    se = eng.get_state()
+    assert np.abs(se[:, :nd] - st_o[:, :nd]).max() < 5e-4 and np.abs(se[:, nd:nd + 7] - st_o[:, nd:nd + 7]).max() < 1e-6      # same scene, same settled pose
+    S = {"st": st_o, "mr": mrec}
+    e_apply, e_motors, e_settle = eng.apply_action, eng.set_motors, eng.settle
+
+    def apply_action(a, max_vel=-1.0):
+        e_apply(a, max_vel=max_vel)
+        S["st"], S["mr"] = ora.hands_apply_action(S["st"], S["mr"], np.asarray(a, np.float64), max_vel)
+
+    def set_motors(dofs, targets, kp, max_force=0.0, mask=None, max_vel=0.0):
+        e_motors(dofs, targets, kp, max_force, mask)
+        S["mr"] = ora.hands_set_motors(S["mr"], dofs, targets, kp, max_force)
+
+    def settle(k, *a):
+        e_settle(k)
+        S["st"] = ora.hands_settle(S["st"], S["mr"], k)
+
+    eng.apply_action, eng.set_motors, eng.settle = apply_action, set_motors, settle
+
+    def quat(e):
+        cr, sr, cp, sp, cy, sy = m.cos(e[0] / 2), m.sin(e[0] / 2), m.cos(e[1] / 2), m.sin(e[1] / 2), m.cos(e[2] / 2), m.sin(e[2] / 2)
+        return [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy]
+
+    def brick():
+        return eng.get_state()[:, nd:nd + 3].astype(np.float64), S["st"][:, nd:nd + 3].copy()
+
+    rep = {}
+    q2 = quat([m.pi / 2, m.pi / 3, -m.pi])
+    pos_cl = [0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 0, 0.6, 0.8, 1.0, 1.57, 0.8, 0.5, 0.8]
+    robot.pre_grasp(); robot.step_simulation(10)
+    robot.apply_action([0.49, 0.0, 0.8] + quat([0, 0, m.pi / 2]), max_vel=5); robot.pre_grasp(); robot.step_simulation(60)
+    robot.apply_action([0.485, 0.0, 0.72] + q2, max_vel=5); robot.pre_grasp(); robot.step_simulation(60)
+    be, bo = brick(); rest = bo[:, 2].copy()
+    rep["untouched_diff_m"] = float(np.abs(be - bo).max())
+    assert rep["untouched_diff_m"] < 1e-6
+    robot.grasp(pos_cl); robot.step_simulation(60)
+    be, bo = brick(); rep["closed_diff_m"] = float(np.abs(be - bo).max())
+    assert rep["closed_diff_m"] < 2e-3, rep
+    robot.apply_action([0.45, 0, 0.9] + q2, max_vel=5); robot.grasp(pos_cl); robot.step_simulation(60)
+    be, bo = brick(); rep["lifted_diff_m"] = float(np.abs(be - bo).max())
+    rep["lift_engine_m"], rep["lift_oracle_m"] = float((be[:, 2] - rest).min()), float((bo[:, 2] - rest).min())
+    assert rep["lift_engine_m"] > 0.05 and rep["lift_oracle_m"] > 0.05 and rep["lifted_diff_m"] < 5e-3, rep
+    robot.apply_action([0.3, -0.2, 0.9] + quat([0.0, 0.0, m.pi / 2]), max_vel=5); robot.grasp(pos_cl); robot.step_simulation(60)
+    be, bo = brick(); rep["carried_diff_m"] = float(np.abs(be - bo).max())
+    assert rep["carried_diff_m"] < 2e-2 and (be[:, 2] - rest).min() > 0.05 and (bo[:, 2] - rest).min() > 0.05, rep
+    robot.pre_grasp(); robot.step_simulation(50)
+    be, bo = brick(); rep["released_xy_diff_m"] = float(np.abs(be[:, :2] - bo[:, :2]).max())
+    hmax = float(max(ph.obj_h[k] for k in range(3))) + 0.02
+    assert (be[:, 2] < rest + hmax).all() and (bo[:, 2] < rest + hmax).all() and rep["released_xy_diff_m"] < 8e-2, rep
+    eng.apply_action, eng.set_motors, eng.settle = e_apply, e_motors, e_settle
+    _client.disconnect(cid)
+    return rep
+
+
+def check_panda_demo_against_oracle(lib, n=1):
+    """The Panda counterpart: the reference's scripted grasp (examples/helloworlds/helloworld_panda.py:89-140) through the drop-in pandaEnv
+    on the engine and, command by command, on the fp64 oracle (pbre_apply_action / pbre_set_motors / pbre_set_motor_state / pbre_settle
+    mirrored): above the object, down to it, fingers closed on it, lifted.  ~620 free-running steps; the object's position per phase."""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.panda_envs.panda_env import pandaEnv
+    cid = _client.connect(n, lib=lib)
+    robot = pandaEnv(cid, use_IK=1)
+    eng = robot._robot_level()
+    ora, tbl = orc.panda_arm_oracle(1, 1)
+    ph = eng.get_physics()
+    for f in ("table_c", "table_h", "obj_h", "obj_inertia"):
+        for k in range(3):
+            getattr(ora.params, f)[k] = getattr(ph, f)[k]
+    ora.params.obj_mass = ph.obj_mass
+    st_o, mrec, _ = ora.hands_reset(n)
+    nd = eng.ndof
+    se = eng.get_state()
+    assert np.abs(se[:, :nd] - st_o[:, :nd]).max() < 5e-5 and np.abs(se[:, nd:nd + 7] - st_o[:, nd:nd + 7]).max() < 1e-6
+    S = {"st": st_o, "mr": mrec}
+    e_apply, e_motors, e_settle, e_setm = eng.apply_action, eng.set_motors, eng.settle, eng.set_motor_state
+
+    def apply_action(a, max_vel=-1.0):
+        e_apply(a, max_vel=max_vel)
+        S["st"], S["mr"] = ora.hands_apply_action(S["st"], S["mr"], np.asarray(a, np.float64), max_vel)
+
+    def set_motors(dofs, targets, kp, max_force=0.0, mask=None, max_vel=0.0):
+        e_motors(dofs, targets, kp, max_force, mask, max_vel=max_vel)
+        S["mr"] = ora.hands_set_motors(S["mr"], dofs, targets, kp, max_force, max_vel=max_vel)
+
+    def set_motor_state(mot):
+        e_setm(mot)
+        for c in range(4):
+            S["mr"][:, c * orc.MAXD:c * orc.MAXD + nd] = mot[:, c, :nd]
+
+    def settle(k, *a):
+        e_settle(k)
+        S["st"] = ora.hands_settle(S["st"], S["mr"], k)
+
+    eng.apply_action, eng.set_motors, eng.settle, eng.set_motor_state = apply_action, set_motors, settle, set_motor_state
+    rep = {}
+    poses = run_panda_demo(robot, upto=4)
+    bo = S["st"][:, nd:nd + 3]
+    be = np.atleast_2d(np.asarray(poses[3]))[:, :3]
+    rest = np.atleast_2d(np.asarray(poses[0]))[:, 2]
+    rep["lifted_diff_m"] = float(np.abs(be - bo).max())
+    rep["lift_engine_m"], rep["lift_oracle_m"] = float((be[:, 2] - rest).min()), float((bo[:, 2] - rest).min())
+    eng.apply_action, eng.set_motors, eng.settle, eng.set_motor_state = e_apply, e_motors, e_settle, e_setm
+    _client.disconnect(cid)
+    assert rep["lift_engine_m"] > 0.1 and rep["lift_oracle_m"] > 0.1 and rep["lifted_diff_m"] < 5e-3, rep
+    return rep

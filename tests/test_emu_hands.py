@@ -96,3 +96,12 @@ def test_helloworld_icub_demo_grasps_and_lifts_the_brick(emu_lib):
     # (released 25 cm above the table it tumbles: it comes to rest on one of its faces, 2.5 or 3.75 cm half height)
     assert 0.625 + 0.02 < obj[6][2] < 0.625 + 0.045 and tips[6] == 0, (obj, tips)
     _client.disconnect(cid)
+
+
+def test_scripted_grasp_against_the_oracle(emu_lib):
+    """config 5 closed loop: the reference's grasp demo on the engine and, command by command, on the fp64 oracle -- both close on the
+    brick, lift it ~19 cm, carry and release it; the brick's position is compared per phase (parity.check_hands_demo_against_oracle)"""
+    rep = parity.check_hands_demo_against_oracle(emu_lib, n=1)
+    print("scripted grasp, engine vs oracle:", rep)
+    assert rep["lift_oracle_m"] > 0.15 and rep["lift_engine_m"] > 0.15
+

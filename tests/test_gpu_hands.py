@@ -174,3 +174,12 @@ def test_hands_five_fingertips_on_the_object(hip_lib, arm):
     w = parity.check_hands_five_fingertips(_capi.Engine, hip_lib, arm)
     print("five fingertips (%s):" % arm, w)
     assert w["fingertips_in_contact"] == 5
+
+
+def test_scripted_grasp_against_the_oracle(hip_lib):
+    """config 5 closed loop: the reference's grasp demo on the engine and, command by command, on the fp64 oracle -- both close on the
+    brick, lift it ~19 cm, carry and release it; the brick's position is compared per phase (parity.check_hands_demo_against_oracle)"""
+    rep = parity.check_hands_demo_against_oracle(hip_lib, n=2)
+    print("scripted grasp, engine vs oracle:", rep)
+    assert rep["lift_oracle_m"] > 0.15 and rep["lift_engine_m"] > 0.15
+
