@@ -1,15 +1,17 @@
 // pbre_capi.hip -- libpbre.so: HIP kernels (gfx950) + the C-ABI of include/pbre.h.
 //
-// Three stepping kernels:
-//   k_fast     lane-per-env (one thread = one env, 64 envs per wave), everything in VGPRs, 2 waves/SIMD.  Steps the
-//              "simple" envs (class 0: no robot contact, no joint-limit row): 9 motor rows + <= 4 object-table contacts.
-//   k_fast_rc  lane-per-env with dense robot-contact rows and limit rows (class 1), whole register file (1 wave/SIMD),
-//              launched over the compacted list of complex envs, concurrently with k_fast on a second stream.
-//   k_step     general 16-lane-row kernel (pbre_core.hpp): one env per DPP row, 4 envs per wave.  Any robot the
-//              RobotTable describes (<= 9 DoF); used when the table does not match the compiled-in Panda topology
-//              or when PBRE_F_FORCE_GENERAL is set (validation).
-// Every lane-per-env kernel ends by classifying the state it produced and appends complex envs to the list the next
-// step's k_fast_rc consumes, so there is no classification pre-pass on the hot path.
+// Four stepping kernels:
+//   k_fast      lane-per-env (one thread = one env, 64 envs per wave), everything in VGPRs.  Steps the "simple" envs (class 0: no robot
+//               contact, no joint-limit row): 9 motor rows (in closed form) + <= 4 object-table contacts.  Two builds: 256 VGPRs / 2 waves
+//               per SIMD, and 168 VGPRs / 3 per SIMD for the steps in which the complex envs' waves need room (launch_step picks).
+//   k_row_list  complex envs (class 1), few of them: the 16-lane row physics of k_step over the compacted list + Fast::finish,
+//               concurrently with k_fast on a second stream.
+//   k_fast_rc   complex envs, many of them: lane-per-env with dense robot-contact rows and limit rows, whole register file (1 wave/SIMD).
+//   k_step      general 16-lane-row kernel (pbre_core.hpp): one env per DPP row, 4 envs per wave.  Any robot the
+//               RobotTable describes (<= 9 DoF); used when the table does not match the compiled-in Panda topology
+//               or when PBRE_F_FORCE_GENERAL is set (validation).
+// Every step kernel ends by classifying the state it produced and appends complex envs to the list the next step's complex-env
+// kernel consumes, so there is no classification pre-pass on the hot path.
 //
 // State lives in HBM as one 192-byte record per env (three 64-byte lane records).  No kernel uses LDS or barriers; blocks
 // are independent, so the block -> XCD mapping is irrelevant (there is no inter-block reuse to be XCD-aware about).
@@ -40,7 +42,8 @@ constexpr int EPB = 16;              // envs per block of the row kernel
 constexpr int TPB = EPB * W;         // 256 threads
 constexpr int FTPB = 64;             // lane-per-env kernels: one wave per block
 #ifndef PBRE_FAST_WAVES
-#define PBRE_FAST_WAVES 2            // waves per SIMD k_fast is register-limited to (A/B on MI355X: 1 -> 404, 2 -> 495, 3 -> 325 M env-steps/s)
+#define PBRE_FAST_WAVES 2            // default waves per SIMD k_fast is register-limited to (round-1 A/B on MI355X: 1 -> 404, 2 -> 495, 3 -> 325 M env-steps/s;
+                                     // since round 3 launch_step also instantiates <MODE, 3> and picks per step)
 #endif
 #ifndef PBRE_RC_PRIO
 #define PBRE_RC_PRIO 3               // wave priority (s_setprio) of the complex-env kernels, 0: leave it (A/B)
