@@ -404,3 +404,35 @@ def test_closed_form_motor_rows_match_the_sequential_rows(panda, hip_lib):
         out_s = np.concatenate([obs_, rws[:, None], dns[:, None]], 1).astype(np.float64)
         q = parity.panda_quantities(sc, ss.astype(np.float64), obc, out_s, rwc)
         parity.assert_within(q, dict((k, 0.25 * v) for k, v in parity.TOL.items()), "(closed-form motor rows against the sequential rows)")
+
+
+def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch):
+    """k_fast exists in two builds -- 256 VGPRs / two waves per SIMD and 168 VGPRs / three (spills in its setup phase) -- and launch_step
+    picks per step; at the headline batch the 168-register build steps the stationary mix, at a test's batch sizes it is never picked.
+    PBRE_FAST3=1 takes it whenever complex envs are reported: same states (contact-rich ones among them, so that the complex-env kernel
+    runs beside it), several steps, results bit for bit those of the 256-register build (PBRE_FAST3=0)."""
+    n = 4096
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40)
+    monkeypatch.setenv("PBRE_FAST3", "1")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_FAST3", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    # a few contact-rich states so that complex envs exist from the first step on
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 8, 8).astype(np.float32)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(9)
+    for _ in range(60):
+        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    assert np.array_equal(a.get_state(), b.get_state())
+    ia, ib = a.kernel_info(), b.kernel_info()
+    assert ia[8] > 0 and ib[8] == 0, (ia, ib)          # steps whose k_fast was the three-waves-per-SIMD build
+    assert ia[9] <= 168 and ia[0] > 168, ia            # its register count / the default build's
+
