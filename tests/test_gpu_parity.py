@@ -436,3 +436,28 @@ def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch
     assert ia[8] > 0 and ib[8] == 0, (ia, ib)          # steps whose k_fast was the three-waves-per-SIMD build
     assert ia[9] <= 168 and ia[0] > 168, ia            # its register count / the default build's
 
+
+def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch):
+    """pbre_step with page-locked buffers: by default the kernels read the actions from and write the rows to host memory themselves
+    (PBRE_ZERO_COPY=3); =0 stages them through device buffers with hipMemcpyAsync.  Same rows, bit for bit, complex envs included
+    (their rows are written by the side stream's kernel)."""
+    n = 512
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib)
+    monkeypatch.setenv("PBRE_ZERO_COPY", "3")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_ZERO_COPY", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(2), 6, 6).astype(np.float32)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(10)
+    for _ in range(6):
+        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        for x, y in zip(a.step(act), b.step(act)):
+            assert np.array_equal(x, y)
+    assert a.kernel_info()[7] > 0          # complex env-steps were among them
+
