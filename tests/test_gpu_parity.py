@@ -406,13 +406,15 @@ def test_closed_form_motor_rows_match_the_sequential_rows(panda, hip_lib):
         parity.assert_within(q, dict((k, 0.25 * v) for k, v in parity.TOL.items()), "(closed-form motor rows against the sequential rows)")
 
 
-def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch):
+@pytest.mark.parametrize("use_ik,action_repeat", [(0, 1), (1, 1), (0, 2)])
+def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch, use_ik, action_repeat):
     """k_fast exists in two builds -- 256 VGPRs / two waves per SIMD and 168 VGPRs / three (spills in its setup phase) -- and launch_step
     picks per step; at the headline batch the 168-register build steps the stationary mix, at a test's batch sizes it is never picked.
     PBRE_FAST3=1 takes it whenever complex envs are reported: same states (contact-rich ones among them, so that the complex-env kernel
     runs beside it), several steps, results bit for bit those of the 256-register build (PBRE_FAST3=0)."""
     n = 4096
-    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40)
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40,
+              use_ik=use_ik, action_repeat=action_repeat)           # (joint control, IK control, the inner iterations of action_repeat: all k_fast modes)
     monkeypatch.setenv("PBRE_FAST3", "1")
     a = _capi.Engine(panda["table"], **kw)
     monkeypatch.setenv("PBRE_FAST3", "0")
@@ -427,7 +429,7 @@ def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch
     a.set_state(st); b.set_state(st)
     rng = np.random.default_rng(9)
     for _ in range(60):
-        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
         ra, rb = a.step(act), b.step(act)
         for x, y in zip(ra, rb):
             assert np.array_equal(x, y)
