@@ -140,18 +140,19 @@ def other_configs(torch, dev, steps=10):
     from pybullet_robot_envs import _capi
     out = {}
 
-    def timed(eng, acts):
+    def timed(eng, acts, nsteps=None):
+        nsteps = nsteps or steps
         o = torch.zeros((eng.num_envs, eng.obs_dim + 2), device=dev)
         s = _capi.torch_stream(dev)
         for k in range(2):
             eng.step_device(acts[k % len(acts)].data_ptr(), o.data_ptr(), s)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for k in range(steps):
+        for k in range(nsteps):
             eng.step_device(acts[k % len(acts)].data_ptr(), o.data_ptr(), s)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        return {"envs": eng.num_envs, "value": eng.num_envs * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3,
+        return {"envs": eng.num_envs, "value": eng.num_envs * nsteps / el, "unit": "env-steps/s", "ms_per_step": el / nsteps * 1e3,
                 "outputs_finite": bool(torch.isfinite(o).all())}, o
 
     def roof(r, eng, alg_bytes, pmc_name, valu_key):
@@ -170,29 +171,69 @@ def other_configs(torch, dev, steps=10):
         r.pop("_envs_per_wave", None)
 
     try:
+        # BASELINE configs 2 and 3 (parity-test cases, reported here for completeness): Panda reach, 4096 envs, object frozen and
+        # contact-free; Panda push, 32768 envs, joint control.  Both in their stationary mix (600 untimed steps, auto-reset on).
+        from pybullet_robot_envs.model.table import panda_table
+        tblp, _ = panda_table()
+        for key, n_, task, fl, label in (("panda_reach_config2", 4096, _capi.TASK_REACH, _capi.F_NO_OBJECT | _capi.F_AUTO_RESET,
+                                          "pandaReachGymEnv-style reach, 4096 envs, object frozen and contact-free (free-space dynamics only)"),
+                                         ("panda_push_config3", 32768, _capi.TASK_PUSH, _capi.F_AUTO_RESET,
+                                          "pandaPushGymEnv joint-control step, 32768 envs, box-on-table contact + 150 PGS sweeps")):
+            eng = _capi.Engine(tblp, task=task, num_envs=n_, flags=fl, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, device_id=dev.index or 0)
+            eng.reset()
+            op = torch.zeros((n_, eng.obs_dim + 2), device=dev)
+            sp = _capi.torch_stream(dev)
+            fresh = torch.empty((n_, 7), device=dev)
+            for k in range(600):                   # i.i.d. actions per (step, env): a fresh draw per pre-roll step (a short recycled pool
+                fresh.uniform_(-1.0, 1.0)          # biases every env's random walk and drives the joints into their limits)
+                eng.step_device(fresh.data_ptr(), op.data_ptr(), sp)
+            actp = [torch.rand((n_, 7), device=dev) * 2 - 1 for _ in range(100)]
+            rp, _ = timed(eng, actp, 100)
+            rp["workload"] = label + "; stationary mix (600 untimed steps first)"
+            rp["complex_envs"] = int(eng.kernel_info()[5])
+            out[key] = rp
+            eng.close()
+    except Exception as e:
+        out["panda_configs_2_3"] = {"error": repr(e)}
+    try:
         from pybullet_robot_envs.envs import iCubReachGymEnv
         acts = [torch.rand((32768, 3), device=dev) * 2 - 1 for _ in range(8)]
-        # (1) the env in its stationary mix under random actions: auto-reset, 600 untimed steps first.  A third to a half of the envs
-        # then has a hand or forearm on the table and many IK targets are out of reach (the IK runs its 100 iterations).
+        # (1) the env in its stationary mix under random actions, the headline's protocol: auto-reset, episode clocks de-synchronised (step
+        # counters U{0..max_steps-1}), max_steps + 500 untimed steps with fresh i.i.d. actions, then the timed ones.  (Rounds 1-2 recycled a pool
+        # of 8 action tensors -- a constant mean action per env, the commanded hand pose drifts into a workspace corner -- and kept the
+        # clocks synchronised, which measures one phase of the episode.)  With IK control a wave's IK runs until its slowest env has
+        # converged or given up after 100 iterations; far into an episode some env of nearly every wave is at an out-of-reach target.
         # This leg runs first: for about a second after the Panda legs every kernel of this latency-bound, half-empty workload runs
-        # ~1.6x slower (the same command measured 0.35 or 0.6 ms per post-reset step from one process to the next; PBRE_ICUB_TRACE
-        # shows all kernels stretched alike: clocks, not scheduling) -- the 600 pre-roll steps absorb that
-        env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768, auto_reset=True)
-        env.reset()
-        o = torch.zeros((32768, env._engine.obs_dim + 2), device=dev)
+        # ~1.6x slower (PBRE_ICUB_TRACE shows all kernels stretched alike: clocks, not scheduling) -- the pre-roll absorbs that
+        steady = {}
         sh = _capi.torch_stream(dev)
-        for k in range(600):
-            env._engine.step_device(acts[k % 8].data_ptr(), o.data_ptr(), sh)
-        r2, _ = timed(env._engine, acts)
-        steady = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": 600,
-                  "envs_with_robot_object_contact": int(env._engine.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
-        env.close()
+        for key, use_ik, adim in (("ik_control", 1, 3), ("joint_control", 0, None)):
+            env = iCubReachGymEnv(use_IK=use_ik, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768, auto_reset=True)
+            env.reset()
+            eng = env._engine
+            adim = eng.act_dim
+            st = eng.get_state()
+            st[:, eng.x_off + 3] = np.random.default_rng(4321).integers(0, int(env._max_steps), 32768).astype(np.float32)
+            eng.set_state(st)
+            o = torch.zeros((32768, eng.obs_dim + 2), device=dev)
+            fresh = torch.empty((32768, adim), device=dev)
+            pre = int(env._max_steps) + 500
+            for k in range(pre):
+                fresh.uniform_(-1.0, 1.0)
+                eng.step_device(fresh.data_ptr(), o.data_ptr(), sh)
+            r2, _ = timed(eng, [torch.rand((32768, adim), device=dev) * 2 - 1 for _ in range(40)], 40)
+            steady[key] = {"value": r2["value"], "unit": "env-steps/s", "ms_per_step": r2["ms_per_step"], "preroll_steps": pre, "max_steps": int(env._max_steps),
+                           "episode_clocks": "de-synchronised", "actions": "i.i.d. U(-1,1) per (step, env)",
+                           "envs_with_robot_object_contact": int(eng.kernel_info()[5]), "outputs_finite": r2["outputs_finite"]}
+            env.close()
+        steady.update(steady["ik_control"])        # (the keys of rounds 1-2: the IK-control figure)
         # (2) contact-free: iCubReach-v0 kwargs; after reset() 1500 untimed steps with ZERO actions (the hand holds its home pose, the state
         # stays the post-reset one) so that the GPU's clocks are those of THIS half-empty, latency-bound load, then the timed steps with
         # random actions.  (Timing 12 steps right after reset() measures the clock state the reset left behind: 0.34 ms per step after a
         # reset done by the heavy lane-group kernel, 0.65 ms after one done by the pipeline itself.)
         env = iCubReachGymEnv(use_IK=1, control_arm='l', control_orientation=0, obj_pose_rnd_std=0, num_envs=32768)
         env.reset()
+        o = torch.zeros((32768, env._engine.obs_dim + 2), device=dev)
         zero = torch.zeros((32768, 3), device=dev)
         for k in range(1500):
             env._engine.step_device(zero.data_ptr(), o.data_ptr(), sh)
