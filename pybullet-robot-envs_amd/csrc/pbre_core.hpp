@@ -37,6 +37,14 @@
 #define PBRE_OPAQUE(p)       // device builds: hide a pointer's value from the optimiser (no instruction)
 #endif
 
+// No implicit FMA contraction in this file.  Core::step solves the same rows through different code paths chosen per WAVE (two zipped chains,
+// the plain loop, the object-table-only loop, ...), and which envs share a wave of the complex-env list depends on the order in which
+// kernels appended them -- on timing.  The paths are the same arithmetic row by row; with the compiler free to fuse a multiply and an add
+// here but not there they differed in the last bit, and a complex env's result depended on its wave-mates (found by running two
+// identical engines side by side: tools/diag_fast3.py).  Every fused operation in this file is an explicit L::fma.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 namespace pbre {
 
 template <class L, class SH = Shape16>
@@ -1489,3 +1497,6 @@ struct Core {
 };
 
 }  // namespace pbre
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

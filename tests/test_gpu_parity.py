@@ -463,3 +463,30 @@ def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch)
             assert np.array_equal(x, y)
     assert a.kernel_info()[7] > 0          # complex env-steps were among them
 
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_complex_env_results_do_not_depend_on_their_wave_mates(panda, hip_lib, use_ik):
+    """Two identical engines side by side, contact-rich envs among 4096, 60 steps with auto-reset: bit-identical throughout.  The
+    complex envs of a step are appended to their list by atomics, so which of them share a wave of the row kernel differs from run to
+    run -- and Core::step picks its solver path per wave.  The paths are the same arithmetic; implicit FMA contraction made them differ
+    in the last bit (round 3: found by tools/diag_fast3.py, fixed by `#pragma clang fp contract(off)` in pbre_core.hpp)."""
+    n = 4096
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40, use_ik=use_ik)
+    a = _capi.Engine(panda["table"], **kw)
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 8, 8).astype(np.float32)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    for trial in range(3):
+        rng = np.random.default_rng(11 + trial)
+        for _ in range(60):
+            act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+            for x, y in zip(a.step(act), b.step(act)):
+                assert np.array_equal(x, y)
+        assert np.array_equal(a.get_state(), b.get_state())
+    assert a.kernel_info()[7] > 0
+

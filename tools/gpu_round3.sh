@@ -36,10 +36,10 @@ for L in 1 0; do for N in 32768 131072; do for M in "" "--joint"; do
   PBRE_ICUB_LANE=$L timeout 300 python tools/bench_icub.py --envs $N --steps 20 $M 2>&1 | tail -1 | sed "s/^{/{\"PBRE_ICUB_LANE\": $L, /" | tee -a gpurun_out/${TAG}_icub_bench.json | cut -c1-260
 done; done; done
 for N in 16384 32768; do for M in "" "--joint"; do
-  PBRE_ICUB_LANE=1 timeout 600 python tools/icub_steady.py --envs $N --steps 1000 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+  PBRE_ICUB_LANE=1 timeout 600 python tools/icub_steady.py --desync --envs $N --steps 1500 --window 250 $M 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 done; done
-PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --envs 32768 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
-timeout 600 python tools/icub_steady.py --envs 131072 --steps 1000 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+PBRE_ICUB_LANE=0 timeout 600 python tools/icub_steady.py --desync --envs 32768 --steps 1500 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
+timeout 600 python tools/icub_steady.py --desync --envs 131072 --steps 1500 --window 250 2>&1 | tail -1 | tee -a gpurun_out/${TAG}_icub_steady.json | cut -c1-400
 bash tools/prof_icub_steady.sh $TAG 2>&1 | tail -9; cp gpurun_out/icubs_${TAG}_kernels.json gpurun_out/${TAG}_icub_steady_kernels.json
 bash tools/pmc_icub.sh $TAG 2>&1 | grep -E "valu_per_wave|valu_over|wait_any_over" | head -6
 bash tools/pmc_icub_hbm.sh $TAG 2>&1 | tail -6

@@ -4,7 +4,7 @@
 TAG=$1; shift
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 rm -rf gpurun_out/prof_icubs_$TAG
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $ROOTDIR/gpurun_out/prof_icubs_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py "$@" > $ROOTDIR/gpurun_out/icubs_$TAG.log 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $ROOTDIR/gpurun_out/prof_icubs_$TAG -o run -- python $ROOTDIR/tools/icub_steady.py --desync "$@" > $ROOTDIR/gpurun_out/icubs_$TAG.log 2>&1)
 tail -1 gpurun_out/icubs_$TAG.log | cut -c1-600
 t=$(find gpurun_out/prof_icubs_$TAG -name "*kernel_trace.csv" | head -1)
 [ -n "$t" ] && python - "$t" gpurun_out/icubs_${TAG}_kernels.json <<'PY'
