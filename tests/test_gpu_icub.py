@@ -226,3 +226,30 @@ def test_icub_push_closed_loop_against_oracle(hip_lib):
     rep = parity.check_icub_push_closed_loop(_capi.Engine, hip_lib, n=8)
     print("iCub closed-loop push:", rep)
     assert rep["touched_envs"] == 8
+
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_two_identical_pipelines_stay_bit_identical(hip_lib, monkeypatch, use_ik):
+    """two identical iCub push engines side by side (pipeline, crafted contact states among 4096 envs, auto-reset): the envs with
+    robot-object contact are stepped from a list whose order depends on timing (atomic appends); their results must not"""
+    monkeypatch.setenv("PBRE_ICUB_LANE", "1")
+    n = 4096
+    eng0, ora, info = parity.make_icub_pair(_capi.Engine, hip_lib, 1, task=1, use_ik=0, obj_std=0.0, tg_std=0.2)
+    base, _ = ora.batch_reset(1)
+    S, kinds = parity.icub_contact_states(ora, info, base[0], np.random.default_rng(21), 12, 12, 12, 12, "l")
+    kw = dict(task=1, use_ik=use_ik, obj_std=0.05, tg_std=0.2, max_steps=60, flags=_capi.F_AUTO_RESET)
+    a, _, _ = parity.make_icub_pair(_capi.Engine, hip_lib, n, **kw)
+    b, _, _ = parity.make_icub_pair(_capi.Engine, hip_lib, n, **kw)
+    a.reset(); b.reset()
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S.astype(np.float32)
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(3)
+    seen = 0
+    for k in range(80):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        for x, y in zip(a.step(act), b.step(act)):
+            assert np.array_equal(x, y)
+        seen = max(seen, a.kernel_info()[5])
+    assert np.array_equal(a.get_state(), b.get_state()) and seen > 0
+
