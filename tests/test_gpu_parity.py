@@ -490,3 +490,28 @@ def test_complex_env_results_do_not_depend_on_their_wave_mates(panda, hip_lib, u
         assert np.array_equal(a.get_state(), b.get_state())
     assert a.kernel_info()[7] > 0
 
+
+def test_simple_env_results_do_not_depend_on_their_wave_mates(panda, hip_lib):
+    """k_fast has a second copy of its solver loop for the usual wave (all four object-table slots in use in every lane) and a per-lane
+    fallback for clamping motors; which copy a wave runs must not change a lane's result: one wave of 64 envs, in the second engine
+    env 1 has a tilted cube (fewer table contacts) and env 2 a sliding one -- the other 62 envs bit-identical over 40 steps."""
+    n = 64
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib)
+    a, b = _capi.Engine(panda["table"], **kw), _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    st = a.get_state()
+    sb = st.copy()
+    ang = np.deg2rad(20.0)
+    sb[1, 12:16] = [np.sin(ang / 2), 0, 0, np.cos(ang / 2)]
+    sb[1, 11] += 0.01
+    sb[2, 25:28] = [0.3, -0.2, 0.0]
+    a.set_state(st); b.set_state(sb)
+    others = np.ones(n, bool); others[[1, 2]] = False
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        (oa, ra, da), (ob, rb, db) = a.step(act), b.step(act)
+        assert np.array_equal(oa[others], ob[others]) and np.array_equal(ra[others], rb[others])
+        assert np.array_equal(a.get_state()[others], b.get_state()[others])
+    assert not np.array_equal(a.get_state()[1], b.get_state()[1])
+
