@@ -1883,3 +1883,68 @@ def check_panda_demo_against_oracle(lib, n=1):
     _client.disconnect(cid)
     assert rep["lift_engine_m"] > 0.1 and rep["lift_oracle_m"] > 0.1 and rep["lifted_diff_m"] < 5e-3, rep
     return rep
+
+
+def sliding_cube_reference(v0, mu, g, kl, dt, pyramid=1.0):
+    """1-D restatement of a cube sliding along a friction-pyramid axis on the table under Coulomb friction and Bullet's velocity damping,
+    with the step's own discretisation (semi-implicit Euler: the damped, friction-limited velocity first, then the position):
+    v <- max(0, v - dt (pyramid mu g + kl (1 + |v|) v)), x <- x + dt v.  Returns the stopping distance."""
+    v, x = float(v0), 0.0
+    while v > 0.0:
+        v = max(0.0, v - dt * (pyramid * mu * g + kl * (1.0 + abs(v)) * v))
+        x += dt * v
+    return x
+
+
+def check_sliding_cube_kat(step_fn, st0, params, v0s=(0.3, 0.6)):
+    """Analytic contact KAT (no PyBullet needed): the cube, given a horizontal velocity, must stop after the distance Coulomb friction
+    mu = obj_mu * table_mu predicts (sliding_cube_reference), straight, without turning or lifting.  Along a world axis -- the axes of
+    Bullet's friction pyramid on a horizontal plane (btPlaneSpace1 of n = +z) -- and along the diagonal, where the two clamped axis rows
+    decelerate it sqrt(2) times harder (the pyramid approximation Bullet makes).  step_fn(state) -> next state under zero actions."""
+    mu, g, kl, dt = params["mu"], params["g"], params["kl"], params["dt"]
+    rep = {}
+    for v0 in v0s:
+        for name, d, pyr in (("axis", np.array([1.0, 0.0]), 1.0), ("diagonal", np.array([1.0, 1.0]) / np.sqrt(2.0), np.sqrt(2.0))):
+            s = np.array(st0, np.float64).copy()
+            s[:, 25:27] = v0 * d
+            s[:, 27:31] = 0.0
+            x0, q0 = s[0, 9:12].copy(), s[0, 12:16].copy()
+            for k in range(600):
+                s = np.asarray(step_fn(s), np.float64)
+                if np.abs(s[0, 25:28]).max() < 1e-7 and k > 3:
+                    break
+            dist = float((s[0, 9:11] - x0[:2]) @ d)
+            ref = sliding_cube_reference(v0, mu, g, kl, dt, pyr)
+            rep["%s_v%.1f" % (name, v0)] = {"distance_m": dist, "reference_m": ref}
+            assert abs(dist - ref) < 0.01 * ref + 2e-5, (name, v0, dist, ref)
+            side = float((s[0, 9:11] - x0[:2]) @ np.array([-d[1], d[0]]))
+            assert abs(side) < 1e-4 and abs(s[0, 11] - x0[2]) < 2e-4, (name, side, s[0, 11] - x0[2])          # straight, stays down
+            assert np.abs(s[0, 12:16] - q0).max() < 2e-4, (name, s[0, 12:16], q0)                             # does not turn
+    return rep
+
+
+def check_rolling_onset_kat(make_step, v0=0.5):
+    """Analytic contact KAT for the round primitives: a body set sliding without spin on a plane with Coulomb friction ends up rolling at
+    v0 / (1 + I / (m r^2)) -- 5/7 v0 for a solid sphere, 2/3 v0 for a solid cylinder rolling on its side -- whatever the friction
+    coefficient (angular momentum about the contact point is conserved).  Bullet's velocity damping (0.04 per second on both twists) takes
+    ~1 % off during the 20-40 steps of the sliding phase: the bound is [-3.5 %, +0.5 %].  make_step(name) -> (st0, radius, step_fn)."""
+    rep = {}
+    for name, ratio, lying in (("YcbTennisBall", 5.0 / 7.0, False), ("YcbTomatoSoupCan", 2.0 / 3.0, True)):
+        st0, r, step_fn = make_step(name)
+        s = np.array(st0, np.float64).copy()
+        s[:, 25:28] = [0.0, v0, 0.0]
+        s[:, 28:31] = 0.0
+        if lying:                                             # axis along world x, resting on the table
+            s[:, 12:16] = [0.0, np.sqrt(0.5), 0.0, np.sqrt(0.5)]
+            s[:, 11] = 0.625 + r
+        onset = None
+        for k in range(120):
+            s = np.asarray(step_fn(s), np.float64)
+            v, w = s[0, 26], s[0, 28]
+            if abs(v + w * r) < 2e-4 * v0:                   # contact-point velocity of a body rolling along +y
+                onset = (k, v / v0)
+                break
+        assert onset is not None, name
+        rep[name] = {"steps_to_rolling": onset[0], "v_over_v0": float(onset[1]), "analytic": ratio}
+        assert -0.035 * ratio < onset[1] - ratio < 0.005 * ratio, (name, onset, ratio)
+    return rep

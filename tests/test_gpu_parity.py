@@ -515,3 +515,41 @@ def test_simple_env_results_do_not_depend_on_their_wave_mates(panda, hip_lib):
         assert np.array_equal(a.get_state()[others], b.get_state()[others])
     assert not np.array_equal(a.get_state()[1], b.get_state()[1])
 
+
+def test_sliding_cube_stops_where_coulomb_friction_says(panda, hip_lib):
+    """analytic contact KAT through the engine (parity.check_sliding_cube_kat): a cube given a horizontal velocity stops after the
+    distance Coulomb friction predicts -- along a pyramid axis and, sqrt(2) harder, along the diagonal -- straight, without turning"""
+    eng = _capi.Engine(panda["table"], task=1, num_envs=1, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0.0, lib=hip_lib)
+    eng.reset()
+    st = eng.get_state()
+    ph = eng.get_physics()
+    zero = np.zeros((1, 7), np.float32)
+
+    def step(s):
+        eng.set_state(np.asarray(s, np.float32))
+        eng.step(zero)
+        return eng.get_state()
+    rep = parity.check_sliding_cube_kat(step, st, {"mu": ph.obj_mu * ph.table_mu, "g": -ph.gravity_z, "kl": ph.lin_damping, "dt": ph.dt})
+    print("sliding cube:", rep)
+
+
+def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda, hip_lib):
+    """analytic KAT for the round primitives through the engine (parity.check_rolling_onset_kat): 5/7 v0 for the ball, 2/3 v0 for the
+    lying can, whatever the friction coefficient"""
+    from pybullet_robot_envs.model.objects import object_physics
+    keep = []
+
+    def make(name):
+        ph = object_physics(name)
+        eng = _capi.Engine(panda["table"], task=1, num_envs=1, obj_pose_rnd_std=0.0, tg_pose_rnd_std=0.0, lib=hip_lib, phys=ph)
+        keep.append(eng)
+        eng.reset()
+        zero = np.zeros((1, 7), np.float32)
+
+        def step(s):
+            eng.set_state(np.asarray(s, np.float32))
+            eng.step(zero)
+            return eng.get_state()
+        return eng.get_state(), ph["obj_h"][0], step
+    print("rolling onset:", parity.check_rolling_onset_kat(make))
+

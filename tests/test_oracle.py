@@ -149,3 +149,34 @@ def test_object_stays_on_table_and_is_pushable(ora):
         assert 0.64 < st[0, 11] < 0.67                    # stays on the table top (rest height 0.650), may tilt a little
     assert st[0, 9] - x0[0] > 0.03                       # pushed forward (the joint-space sweep also turns it)
     assert abs(st[0, 10] - x0[1]) < 0.08
+
+
+def test_sliding_cube_stops_where_coulomb_friction_says(ora):
+    """analytic contact KAT: stopping distance of a sliding cube (parity.check_sliding_cube_kat) -- pins the oracle's friction rows,
+    normal force and damping against first principles, not against PyBullet"""
+    import parity
+    ora.task.tg_pose_rnd_std = 0.0; ora.task.obj_pose_rnd_std = 0.0
+    st, _ = ora.batch_reset(1)
+    P = ora.params
+    zero = np.zeros((1, 7))
+    rep = parity.check_sliding_cube_kat(lambda s: ora.batch_step(s, zero)[0], st,
+                                        {"mu": P.obj_mu * P.table_mu, "g": -P.gravity_z, "kl": P.lin_damping, "dt": P.dt})
+    assert rep["axis_v0.6"]["distance_m"] > 0.03
+
+
+def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda):
+    """analytic KAT for the round primitives (parity.check_rolling_onset_kat): 5/7 v0 for the ball, 2/3 v0 for the lying can"""
+    import parity
+    from pybullet_robot_envs.model.objects import object_physics
+
+    def make(name):
+        ph = object_physics(name)
+        o = orc.Oracle(panda["table"], task=1)
+        orc.set_object(o, ph)
+        o.task.tg_pose_rnd_std = 0.0; o.task.obj_pose_rnd_std = 0.0
+        st, _ = o.batch_reset(1)
+        zero = np.zeros((1, 7))
+        return st, ph["obj_h"][0], (lambda s: o.batch_step(s, zero)[0])
+    rep = parity.check_rolling_onset_kat(make)
+    assert rep["YcbTennisBall"]["steps_to_rolling"] > 5
+
