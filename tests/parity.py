@@ -1948,3 +1948,22 @@ def check_rolling_onset_kat(make_step, v0=0.5):
         rep[name] = {"steps_to_rolling": onset[0], "v_over_v0": float(onset[1]), "analytic": ratio}
         assert -0.035 * ratio < onset[1] - ratio < 0.005 * ratio, (name, onset, ratio)
     return rep
+
+
+def check_free_fall_kat(step_fn, st0, params, lift=0.12, steps=30):
+    """Analytic KAT: the cube released `lift` above its rest height falls under gravity and Bullet's velocity damping exactly as the step's
+    discretisation says -- v <- v + dt (-g - kl (1 + |v|) v), z <- z + dt v -- until it comes within the contact margin of the table."""
+    g, kl, dt = params["g"], params["kl"], params["dt"]
+    s = np.array(st0, np.float64).copy()
+    s[:, 11] += lift
+    s[:, 25:31] = 0.0
+    z, v, worst = float(s[0, 11]), 0.0, 0.0
+    for k in range(steps):
+        s = np.asarray(step_fn(s), np.float64)
+        v = v + dt * (-g - kl * (1.0 + abs(v)) * v)
+        z = z + dt * v
+        worst = max(worst, abs(s[0, 11] - z), abs(s[0, 27] - v) * dt)
+    assert z > st0[0, 11] + 0.02, "the reference run reached the table: shorten it"
+    assert worst < 2e-6, worst
+    assert np.abs(s[0, 9:11] - st0[0, 9:11]).max() < 1e-7 and np.abs(s[0, 12:16] - st0[0, 12:16]).max() < 1e-6      # straight down, no spin
+    return {"steps": steps, "fall_m": float(st0[0, 11] + lift - s[0, 11]), "max_abs_error_m": worst}

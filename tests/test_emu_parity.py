@@ -285,6 +285,7 @@ def test_sliding_cube_stops_where_coulomb_friction_says(panda, emu_lib):
         return eng.get_state()
     rep = parity.check_sliding_cube_kat(step, st, {"mu": ph.obj_mu * ph.table_mu, "g": -ph.gravity_z, "kl": ph.lin_damping, "dt": ph.dt})
     print("sliding cube:", rep)
+    print("free fall:", parity.check_free_fall_kat(step, st, {"g": -ph.gravity_z, "kl": ph.lin_damping, "dt": ph.dt}))
 
 
 def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda, emu_lib):

@@ -162,6 +162,8 @@ def test_sliding_cube_stops_where_coulomb_friction_says(ora):
     rep = parity.check_sliding_cube_kat(lambda s: ora.batch_step(s, zero)[0], st,
                                         {"mu": P.obj_mu * P.table_mu, "g": -P.gravity_z, "kl": P.lin_damping, "dt": P.dt})
     assert rep["axis_v0.6"]["distance_m"] > 0.03
+    ff = parity.check_free_fall_kat(lambda s: ora.batch_step(s, zero)[0], st, {"g": -P.gravity_z, "kl": P.lin_damping, "dt": P.dt})
+    assert ff["fall_m"] > 0.05
 
 
 def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda):
