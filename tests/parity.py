@@ -1967,3 +1967,24 @@ def check_free_fall_kat(step_fn, st0, params, lift=0.12, steps=30):
     assert worst < 2e-6, worst
     assert np.abs(s[0, 9:11] - st0[0, 9:11]).max() < 1e-7 and np.abs(s[0, 12:16] - st0[0, 12:16]).max() < 1e-6      # straight down, no spin
     return {"steps": steps, "fall_m": float(st0[0, 11] + lift - s[0, 11]), "max_abs_error_m": worst}
+
+
+def check_finger_force_kat(lib, n=1):
+    """Analytic KAT for the robot-object contact rows and the force-limited motors: in the closed grasp of the reference's Panda demo
+    (helloworld_panda.py: fingers commanded shut with force 10 N on a rigid object) each finger's motor sits at its force bound, so the
+    normal forces of the finger's contact points must add up to exactly that bound -- static equilibrium of the prismatic finger joint,
+    whose axis is horizontal with the hand pointing down.  (Two collision spheres per finger touch the object: 2 x 5.000 N.)"""
+    from pybullet_robot_envs import _client
+    from pybullet_robot_envs.envs.panda_envs.panda_env import pandaEnv
+    cid = _client.connect(n, lib=lib)
+    robot = pandaEnv(cid, use_IK=1)
+    run_panda_demo(robot, upto=3)
+    robot.step_simulation(40)
+    eng = robot._robot_level()
+    tail = eng.observe()[:, -7:].astype(np.float64)        # mean normal force finger 1 / 2, -, -, -, fingers in contact, contact points
+    assert (tail[:, 5] == 2).all() and (tail[:, 6] % 2 == 0).all(), tail
+    per_finger = tail[:, 6:7] / 2.0
+    total = tail[:, :2] * per_finger
+    _client.disconnect(cid)
+    assert np.abs(total - 10.0).max() < 5e-3, total
+    return {"contact_points": tail[0, 6], "normal_force_per_finger_N": total[0].tolist()}

@@ -43,3 +43,8 @@ def test_scripted_grasp_against_the_oracle(hip_lib):
     print("Panda scripted grasp, engine vs oracle:", rep)
     assert rep["lift_oracle_m"] > 0.2 and rep["lift_engine_m"] > 0.2
 
+
+def test_closed_fingers_press_with_exactly_their_force_limit(hip_lib):
+    """analytic KAT (parity.check_finger_force_kat): the contact forces on a force-limited finger add up to its 10 N bound"""
+    print("finger forces:", parity.check_finger_force_kat(hip_lib, n=4))
+
