@@ -255,7 +255,9 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
  * [2] fast path enabled, [3..5] envs stepped in the most recent step by the fast kernel / the general row kernel / the
  * lane-per-env robot-contact kernel, [6] VGPRs of the robot-contact kernel, [7] running sum of the complex envs stepped so far
  * (env-steps taken by the robot-contact / limit-row kernels; wraps at 2^31), [8] steps since the last reset whose fast kernel was the
- * variant limited to 3 waves per SIMD (picked when the complex envs' waves would otherwise displace fast-kernel waves), [9] its VGPRs */
+ * variant limited to 3 waves per SIMD (picked when the complex envs' waves would otherwise displace fast-kernel waves), [9] its VGPRs,
+ * [10] steps since the last reset whose simple envs were stepped by the pair kernel (robot wave + object wave per 64 envs: the mapping
+ * for batches that leave most SIMDs without a wave), [11] its VGPRs */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

@@ -27,6 +27,13 @@
 #define PBRE_ANY(x) (__any((int)(x)) != 0)
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
+#define PBRE_PAIR_SYNC() __syncthreads()
+#ifdef PBRE_PHASE_PROBE      // tools/phase_probe.py: cycles per phase of lane 0 of block 0's waves, summed over the launches since the last reset of the counters
+__device__ unsigned long long g_probe[32];
+#define PBRE_PROBE_DECL unsigned long long pb_t_ = __builtin_readcyclecounter();
+#define PBRE_PROBE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_probe[k], t_ - pb_t_); pb_t_ = t_; } while (0)
+#endif
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -108,6 +115,44 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
     publish_class(env, c, cls, next_list, next_count, cap);
 }
 
+// Simple envs of a batch that leaves most SIMDs without a wave (a per-GPU shard of a strongly scaled batch, BASELINE configs 2 and 3):
+// the same step as k_fast, spread over two waves per 64 envs.  In the simple class the robot's rows and the object's rows share no
+// unknown, so wave 0 of a block does the robot's half (kinematics, dynamics, M^-1, the motor rows' closed form, integration, kinematics
+// of the new state) while wave 1 does the object's (contact candidates, the 150 sweeps over its <= 12 rows, integration) on another SIMD
+// of the CU; one block barrier, behind which wave 0 finds the object's new pose in LDS and writes observation, reward, done and the
+// class.  A lone wave issues one instruction per ~5.4 cycles whatever its dependencies (profiles/r01_ubench_pkfma.txt), so a batch of
+// lone waves steps in the LONGER half + the observation instead of the sum of both.  Same operations on the same operands as k_fast:
+// bit-identical results (tests/test_gpu_parity.py), so which kernel a shard size selects is invisible in the data (sharding invariance).
+constexpr int PTPB = 2 * FTPB;
+template <int MODE>
+__global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
+    __shared__ PairX px;
+    const int ln = threadIdx.x & (FTPB - 1);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: 0 robot, 1 object
+    const int env = blockIdx.x * FTPB + ln;
+    if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;
+    const bool live = env < n && cls_cur[env] == 0;
+    if (!PBRE_ANY(live)) return;              // the same decision in both waves of the block (same envs): no barrier is left waiting
+    if (!live) return;
+    float* st = state + (size_t)env * STATE;
+    const bool sim = st[46] == 0.f;           // (action_repeat > 1 only: the env already left this env.step()'s apply_action loop)
+    if (role == 0) {
+        const float* a = (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr;
+        float* o = (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr;
+        const unsigned long long id = P.env_id_base + (unsigned long long)env;
+        int c;
+        if (sim) c = FastD::step_t<false, 1>(*T, P, st, a, o, MODE, flags, id, (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, &px, ln);
+        else c = FastD::skipped(*T, P, st, o, MODE, flags, id);
+        publish_class(env, c, cls, next_list, next_count, cap);
+    } else {
+        if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
+        __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
+    }
+}
+
 // Complex envs (robot contacts and/or limit rows), compacted per class.  Persistent blocks (the host does not know the
 // list lengths): work item w = (bucket, 64-env chunk); block b takes items b, b + gridDim.x, ...  The grid is one block
 // per SIMD (the kernel needs a whole SIMD's register file), blocks without work exit at once.
@@ -173,6 +218,7 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
         CoreD::step(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
                     (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
         __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
+        PBRE_PROBE_DECL
         if (real && (threadIdx.x & 15u) == 0) {
             float q[NJ], qd[NJ];
             PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
@@ -182,6 +228,7 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
                                         P.env_id_base + (unsigned long long)env);
             publish_class(env, c, cls, next_list, next_count, cap);
         }
+        PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
     }
 }
 
@@ -282,6 +329,8 @@ struct pbre_ctx {
                                        // left idle for hundreds of steps makes the first steps after the switch back ~8 % slower (0: never)
     int idle_single = 1;               // with no complex envs reported, both kernels go to the caller's stream in order (no fork / join events); 0: A/B
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
+    int pair = 2;                      // k_fast_pair (robot wave + object wave per 64 envs): 0 never, 1 whenever it applies, 2 while its waves fit two per SIMD (PBRE_PAIR)
+    long launches_pair = 0;
     int fast3 = 2;                     // k_fast variant limited to 3 waves per SIMD: 0 never, 1 whenever complex envs are reported, 2 when they would displace k_fast waves (PBRE_FAST3)
     hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
     SidePick sp;
@@ -424,6 +473,16 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 : (hint + FTPB - 1) / FTPB * 2) + 8;
         fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
     }
+    // small batches: the pair kernel (two waves per 64 envs) while all of its waves are resident at once, two per SIMD at most
+    bool pair = false;
+    if (c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
+        pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
+    if (pair) {
+        c->launches_pair++;
+        if constexpr (!(MODE & FastD::M_INNER))      // (the inner iterations of action_repeat > 1 stay on k_fast: not instantiated)
+        hipLaunchKernelGGL((k_fast_pair<MODE>), dim3(blocks), dim3(PTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+                           b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
+    } else {
     if (fast3) c->launches3++;
     if (fast3)
         hipLaunchKernelGGL((k_fast<MODE, 3>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
@@ -431,6 +490,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     else
         hipLaunchKernelGGL((k_fast<MODE, 2>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
+    }
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (timed) { (void)hipEventRecord(ek[1], s_fast); c->k_steps++; }
     if (!single || touch_side) {
@@ -524,6 +584,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     if (const char* ev = getenv("PBRE_FAST3")) c->fast3 = atoi(ev);
+    if (const char* ev = getenv("PBRE_PAIR")) c->pair = atoi(ev);
     if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -687,7 +748,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_ok = nc == 0 ? 1 : 0;         // every env of the freshly reset batch is in the simple class
         }
     }
-    c->k_steps = 0; c->launches = 0; c->launches3 = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
+    c->k_steps = 0; c->launches = 0; c->launches3 = 0; c->launches_pair = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -894,8 +955,9 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
     if (c->wide) return wide_kernel_info(c->wide, info, n);
     hipFuncAttributes fa;
-    int rf = -1, rg = -1, rr = -1, rf3 = -1;
+    int rf = -1, rg = -1, rr = -1, rf3 = -1, rp = -1;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 3>) == hipSuccess) rf3 = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fast_pair<MODE_STEP>) == hipSuccess) rp = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 2>) == hipSuccess) rf = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
@@ -908,10 +970,19 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
         (void)hipMemcpy(&complex_sum, c->main.count + 3 * NB + 1, sizeof(int), hipMemcpyDeviceToHost);
         for (int k = 0; k < NB; k++) complex_now += cnt[k];
     }
-    const int v[10] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
-                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1};
-    for (int i = 0; i < n; i++) info[i] = i < 10 ? v[i] : 0;
+    const int v[12] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
+                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1};
+    for (int i = 0; i < n; i++) info[i] = i < 12 ? v[i] : 0;
     return PBRE_OK;
 }
+
+#ifdef PBRE_PHASE_PROBE
+int pbre_debug_probe(unsigned long long* out, int reset) {      // (probe builds only; not part of include/pbre.h)
+    unsigned long long z[32] = {0};
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof z) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof z) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 }  // extern "C"

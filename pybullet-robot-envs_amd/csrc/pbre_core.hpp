@@ -36,6 +36,10 @@
 #ifndef PBRE_OPAQUE
 #define PBRE_OPAQUE(p)       // device builds: hide a pointer's value from the optimiser (no instruction)
 #endif
+#ifndef PBRE_PROBE           // phase timing of one wave (tools/phase_probe.py builds with -DPBRE_PHASE_PROBE); nothing otherwise
+#define PBRE_PROBE(k)
+#define PBRE_PROBE_DECL
+#endif
 
 // No implicit FMA contraction in this file.  Core::step solves the same rows through different code paths chosen per WAVE (two zipped chains,
 // the plain loop, the object-table-only loop, ...), and which envs share a wave of the complex-env list depends on the order in which
@@ -443,6 +447,7 @@ struct Core {
         const bool obj_on = !(flags & 1);
         const F dt = L::c(P.dt), inv_dt = L::c(P.inv_dt);
 
+        PBRE_PROBE_DECL
         F Qr = L::load(st), Vr = L::load(st + W), Xr = L::loadm(st + 2 * W, L::lti(lane, 16));
         F q = L::sel(robot, Qr, zero);
 
@@ -489,7 +494,9 @@ struct Core {
         M3 Ro = quat_R(oq);
 
         // ---- kinematics at q_t
+        PBRE_PROBE(0);      // loads, motor targets
         Kin K; fk(T, q, K);
+        PBRE_PROBE(1);      // forward kinematics
         F qd = L::sel(robot, Vr, zero);
 
         // ---- rigid-body quantities of this lane's sub-bodies, velocities, bias forces (world-frame RNEA)
@@ -534,6 +541,7 @@ struct Core {
             cI[0] = cI[0] + L::fma(m, cc - c.x*c.x, Iw.m[0]); cI[1] = cI[1] + L::fma(m, cc - c.y*c.y, Iw.m[4]); cI[2] = cI[2] + L::fma(m, cc - c.z*c.z, Iw.m[8]);
             cI[3] = cI[3] + L::fma(zero - m, c.x*c.y, Iw.m[1]); cI[4] = cI[4] + L::fma(zero - m, c.x*c.z, Iw.m[2]); cI[5] = cI[5] + L::fma(zero - m, c.y*c.z, Iw.m[5]);
         }
+        PBRE_PROBE(2);      // velocities, bias forces, inertias (RNEA)
         // ---- subtree sums (bias force + composite inertia): broadcast loop with descendant masks
         const Mask dmask = loadmask(T.dmask);
         Sp Fs; Fs.a = v3(zero, zero, zero); Fs.l = v3(zero, zero, zero);
@@ -548,6 +556,7 @@ struct Core {
         }
         F tau = zero - (dot(K.S.a, Fs.a) + dot(K.S.l, Fs.l)) - L::load(T.jdamp) * qd;   // -bias - joint damping
 
+        PBRE_PROBE(3);      // subtree sums
         // ---- CRBA: G = Ic S (own), H[row=lane][i]
         M3 Io; Io.m[0] = CI[0]; Io.m[1] = CI[3]; Io.m[2] = CI[4]; Io.m[3] = CI[3]; Io.m[4] = CI[1]; Io.m[5] = CI[5]; Io.m[6] = CI[4]; Io.m[7] = CI[5]; Io.m[8] = CI[2];
         Sp G; G.a = add(mv(Io, K.S.a), cross(Ch, K.S.l)); G.l = add(scl(K.S.l, Cm), cross(K.S.a, Ch));
@@ -572,6 +581,7 @@ struct Core {
             PBRE_UNROLL for (int i = 0; i < NJ; i++) R.Mi[i] = LR::sel(LR::band(LR::eqi(laneR, i), nojoint), oneR, R.Mi[i]);
         }
 
+        PBRE_PROBE(4);      // CRBA
         // ---- M^-1 by in-place Gauss-Jordan (SPD, no pivoting), one matrix row per lane
         if (NJ > 40) {
             // 60 x 60: a rolled pivot loop (fully unrolled it is ~20k instructions and beyond the compiler's unroll budget, which
@@ -604,6 +614,7 @@ struct Core {
             R.Mi[c] = LR::sel(isc, inv, zeroR - f * inv);
         }
 
+        PBRE_PROBE(5);      // M^-1
         // ---- unconstrained velocities v* (ABA equivalent): qdd = M^-1 tau
         F qdd;
         {
@@ -647,6 +658,7 @@ struct Core {
         }
         vstar = L::sel(robot, vstar, vobj);                 // generalized v* of all 15 DoF (lane 15: 0)
 
+        PBRE_PROBE(6);      // v*, object dynamics
         // ---- collision detection at q_t
         // Per-lane candidates stay alive through the row setup; the group-uniform Contact of a slot is fetched where its
         // rows are built (all NC of them at once would be 13 values x NC of register pressure on top of the M^-1 rows).
@@ -688,6 +700,7 @@ struct Core {
             rk_rt = select_k(d_rt, sv, margin, NC_RT, lane);
             vB = v3(vx.x, vx.y, hs);
         }
+        PBRE_PROBE(7);      // collision detection
         auto contact_of = [&](int c) -> Contact {
             if (c < NC_OT) return fetch(rk_ot, c, up, vx, vB, vd, o_mu * L::c(P.tab_mu), L::ci(0), lane);
             if (c < NC_OT + NC_RO) return fetch(rk_ro, c - NC_OT, n_ro, pA_ro, pB_ro, d_ro, smu * o_mu, so, lane);
@@ -806,6 +819,7 @@ struct Core {
             }
         }
 
+        PBRE_PROBE(8);      // constraint rows
         // ---- projected Gauss-Seidel (Bullet order: non-contact rows alternate direction, normals, frictions)
         F dv = L::sel(L::eqi(lane, L1), one, zero);
         const F big = L::c(1e10f);
@@ -1110,6 +1124,7 @@ struct Core {
             contacts();
         }
 
+        PBRE_PROBE(9);      // the sweeps
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
         if (use_objv) vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew);
@@ -1163,6 +1178,7 @@ struct Core {
             Qn = L::sel(skip, Qr, Qn); Vn = L::sel(skip, Vr, Vn);
         }
         L::store(st, Qn); L::store(st + W, Vn);
+        PBRE_PROBE(10);     // integration, store
 
         if (mode & (M_OBS | M_TASK)) {
             // the observation re-reads the tables through a pointer the optimiser cannot identify with T: otherwise the table

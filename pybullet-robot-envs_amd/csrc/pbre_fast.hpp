@@ -34,9 +34,24 @@
 #ifndef PBRE_ANY            // wave-uniform "any lane" on the device; identity on the host (one env per call)
 #define PBRE_ANY(x) (x)
 #endif
+#ifndef PBRE_PROBE           // phase timing of one wave (tools/phase_probe.py builds with -DPBRE_PHASE_PROBE); nothing otherwise
+#define PBRE_PROBE(k)
+#define PBRE_PROBE_DECL
+#endif
+#ifndef PBRE_PAIR_SYNC      // block barrier between the two waves of the pair kernel (device build; never reached on the host)
+#define PBRE_PAIR_SYNC() do {} while (0)
+#endif
 #include "pbre_objstep.hpp"
 
 namespace pbre {
+
+// LDS exchange area of one block of the pair kernel (k_fast_pair, pbre_capi.hip): 64 envs, the robot's half of the step on wave 0, the
+// object's half on wave 1.  [value][lane] so that a wave's accesses are conflict-free.
+struct PairX {
+    float o[7][64];          // object wave -> robot wave: the object's new position (3) and quaternion (4)
+    float sc[3 * W][64];     // robot wave, for itself: collision-sphere centres of the new state (tested against the new object pose
+                             // once the object wave has delivered it)
+};
 
 // Franka Panda as flattened by build_tables(): 7-revolute chain, two prismatic fingers on lane 6,
 // lane 6 carries 3 rigid sub-bodies (link7, hand, grasptarget).
@@ -338,17 +353,28 @@ struct Fast {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
         return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
     }
-    template <bool RC>
+    // ROLE (simple class only): 0 the whole step on one lane (k_fast); 1 / 2 the pair kernel's split of the same step over two waves of
+    // a block -- the robot's half (kinematics, dynamics, motor rows, integration, then the observation of the new state) and the
+    // object's half (contact candidates, the 150 sweeps over its rows, integration).  In this class the two halves share no unknown, so
+    // the split changes no operand of any operation: the results are those of ROLE 0 bit for bit (GPU test).  The object wave hands the
+    // new object pose over in LDS (px, lane ln); small batches -- every wave alone on its SIMD -- step in max(robot, object) + the
+    // observation instead of their sum.
+    template <bool RC, int ROLE = 0>
     static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                              unsigned long long env_id, const float* tgt) {
+                              unsigned long long env_id, const float* tgt, PairX* px = nullptr, int ln = 0) {
+        static_assert(ROLE == 0 || !RC, "the pair kernel steps the simple class");
+        constexpr bool ROBOT = ROLE != 2, OBJECT = ROLE != 1;
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
         const bool obj_on = !(flags & 1);
         const float dt = P.dt, inv_dt = P.inv_dt;
+        PBRE_PROBE_DECL
+        constexpr int PB = ROLE == 2 ? 24 : 16;      // probe slots: 16.. one-lane step / robot wave, 24.. object wave
         float q[ND], qd[ND];
-        PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
-        V3 op = v3(st[9], st[10], st[11]);
-        Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+        if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; } }
+        V3 op = v3(0.f, 0.f, 0.f);
+        Q4 oq; oq.x = 0.f; oq.y = 0.f; oq.z = 0.f; oq.w = 1.f;
+        if (OBJECT) { op = v3(st[9], st[10], st[11]); oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15]; }     // (the robot wave gets the NEW pose, from the object wave)
         M3 Ro = quat_R(oq);
         // per-env object parameters (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral friction,
         // X[15] 1 + linear damping; 0 = the batch value.  The inertia of the (cube) object scales with its mass.
@@ -370,7 +396,7 @@ struct Fast {
             k1[g].dist = k2[g].dist = 3e38f; k1[g].idx = k2[g].idx = 99; k1[g].mu = k2[g].mu = 0.f; k1[g].owner = k2[g].owner = 0;
             k1[g].n = k2[g].n = k1[g].pA = k2[g].pA = k1[g].pB = k2[g].pB = v3(0.f, 0.f, 0.f);
         }
-        {
+        if (ROBOT) {
             M3 R[ND]; V3 p[ND]; V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
             const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
             const V3 tc = v3(P.tab_c[0], P.tab_c[1], P.tab_c[2]), th = v3(P.tab_h[0], P.tab_h[1], P.tab_h[2]);
@@ -446,9 +472,10 @@ struct Fast {
             }
         }
 
+        PBRE_PROBE(PB + 0);      // forward sweep
         // ---- backward sweep: composite inertias -> mass matrix (CRBA)
         float Mi[ND * (ND + 1) / 2];       // symmetric storage, becomes M^-1
-        PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) {
+        if (ROBOT) PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) {
             M3 Io; Io.m[0] = CI[j][0]; Io.m[1] = CI[j][3]; Io.m[2] = CI[j][4]; Io.m[3] = CI[j][3]; Io.m[4] = CI[j][1]; Io.m[5] = CI[j][5];
             Io.m[6] = CI[j][4]; Io.m[7] = CI[j][5]; Io.m[8] = CI[j][2];
             V3 Ga = add(mv(Io, Sa[j]), cross(Ch[j], Sl[j]));
@@ -466,9 +493,9 @@ struct Fast {
         }
         // (simple class: M itself is needed once more, for the impulse bound of the motor rows' closed form)
         float M0[RC ? 1 : ND * (ND + 1) / 2];
-        if (!RC) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
+        if (!RC && ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle
-        PBRE_UNROLL for (int k = 0; k < ND; k++) {
+        if (ROBOT) PBRE_UNROLL for (int k = 0; k < ND; k++) {
             const float pv = 1.f / Mi[sym(k, k)];
             float b[ND];
             PBRE_UNROLL for (int i = 0; i < ND; i++) b[i] = Mi[sym(i, k)];
@@ -480,8 +507,9 @@ struct Fast {
             }
             Mi[sym(k, k)] = -pv;
         }
-        PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) Mi[i] = -Mi[i];
+        if (ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) Mi[i] = -Mi[i]; }
 
+        PBRE_PROBE(PB + 1);      // CRBA, M^-1
         // ---- unconstrained joint velocities w = v*; motor rows (btMultiBodyJointMotor) written against the running
         //      velocity w = v* + dv:  t = dinv*w - rhs2 with rhs2 = (kp (q_des - q)/dt + (1 - kd) v*) dinv
         const float vmax = P.vmax;
@@ -490,11 +518,11 @@ struct Fast {
         float m_dinv[ND], m_rhs[ND], m_app[ND], m_t[ND];
         // (simple class: joint angles / velocities are re-read from the state record here rather than kept in registers across the
         // kinematic sweeps and the inversion -- the barrier stops the compiler from reusing the earlier loads)
-        if (!RC) {
+        if (!RC && ROBOT) {
             PBRE_REG_BARRIER();
             PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
         }
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+        if (ROBOT) PBRE_UNROLL for (int j = 0; j < ND; j++) {
             float a = 0.f;
             PBRE_UNROLL for (int k = 0; k < ND; k++) a = fmaf(Mi[sym(j, k)], tau[k], a);
             const float wj = clampf(fmaf(dt, a, qd[j]), -vmax, vmax);
@@ -520,7 +548,7 @@ struct Fast {
             m_app[j] += d;
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
-        if (!RC) {
+        if (!RC && ROBOT) {
             // ---- simple class, motor block (see the solver section below for the why and the validity bound)
             const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
             bool over = true;
@@ -550,6 +578,7 @@ struct Fast {
             if (want_closed) { PBRE_UNROLL for (int j = 0; j < ND; j++) wset(w, j, over ? wget(w, j) : wc[j]); }
         }
 
+        PBRE_PROBE(PB + 2);      // motor targets, motor block (closed form)
         // joint-limit rows (btMultiBodyJointLimitConstraint; complex class only): a row exists while the joint is at/over
         // the limit; J = dir e_j, positional rhs -pen*erp/dt, impulse in [0, limit_imp]
         float l_dir[ND], l_rhs[ND], l_app[ND];
@@ -569,7 +598,8 @@ struct Fast {
         }
 
         // ---- object: unconstrained velocity, object-table contacts (normal +z, friction directions -y and +x)
-        V3 ov = v3(st[25], st[26], st[27]), ow = v3(st[28], st[29], st[30]);
+        V3 ov = v3(0.f, 0.f, 0.f), ow = v3(0.f, 0.f, 0.f);
+        if (OBJECT) { ov = v3(st[25], st[26], st[27]); ow = v3(st[28], st[29], st[30]); }
         constexpr int NK = NC_OT;
         float c_rx[NK], c_ry[NK], c_rz[NK];
         bool c_act[NK];
@@ -591,9 +621,9 @@ struct Fast {
         // I_w^-1 = 1/I, so the object's half of the step -- it shares no unknown with the robot rows in this class -- is done by
         // ObjStep (pbre_objstep.hpp: same rows, any principal inertia) and the solver loop runs the robot rows alone.  The envs with
         // robot contacts of such a scene are stepped by the row kernel (launch_step), never by step_t<true>.
-        const bool obj_inline = obj_on && (P.obj_iso != 0) && P.obj_shape == 0;      // (round objects -- sphere, cylinder -- are ObjStep's too)
+        const bool obj_inline = OBJECT && obj_on && (P.obj_iso != 0) && P.obj_shape == 0;      // (round objects -- sphere, cylinder -- are ObjStep's too)
         float o_tw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (obj_on && !obj_inline) {
+        if (OBJECT && obj_on && !obj_inline) {
             const float pose[7] = {op.x, op.y, op.z, oq.x, oq.y, oq.z, oq.w};
             const float tw0[6] = {ov.x, ov.y, ov.z, ow.x, ow.y, ow.z};
             ObjStep::run_p(P, pose, tw0, o_tw, o_m, o_mu, o_kl);
@@ -707,6 +737,7 @@ struct Fast {
             }
         }
 
+        PBRE_PROBE(PB + 3);      // object: unconstrained velocity, candidates, rows (+ robot-contact rows)
         // ---- projected Gauss-Seidel, Bullet order (motors reversed on even iterations, forward on odd; normals; frictions)
         ow = scl(ow, inv_sk);                 // scaled angular velocity u inside the solver loop
         const float llim = P.limit_imp;
@@ -763,7 +794,8 @@ struct Fast {
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
             if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) { rrow(c, 1); rrow(c, 2); } }
         };
-        if (!RC) {
+        if (!RC && !OBJECT) {
+        } else if (!RC) {
             // ---- simple class.  The motor rows and the object rows share no unknown, so Bullet's interleaved sweeps give each block
             // exactly the iterates it would get alone: the two blocks are solved one after the other -- the motor block earlier, right
             // after the motors' targets were formed (motor_block above: its matrices are dead before the object's rows are built).
@@ -808,17 +840,18 @@ struct Fast {
             contacts();
         }
 
+        PBRE_PROBE(PB + 4);      // the sweeps
         ow = scl(ow, sk);
-        if (obj_on && !obj_inline) { ov = v3(o_tw[0], o_tw[1], o_tw[2]); ow = v3(o_tw[3], o_tw[4], o_tw[5]); }
+        if (OBJECT && obj_on && !obj_inline) { ov = v3(o_tw[0], o_tw[1], o_tw[2]); ow = v3(o_tw[3], o_tw[4], o_tw[5]); }
         // ---- integrate.  Positions are re-read from the state record (still the old values) rather than kept in
         //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
         PBRE_REG_BARRIER();
-        PBRE_UNROLL for (int j = 0; j < ND; j++) {
+        if (ROBOT) PBRE_UNROLL for (int j = 0; j < ND; j++) {
             const float v = clampf(wget(w, j), -vmax, vmax);
             qd[j] = v; q[j] = fmaf(dt, v, st[j]);
             st[j] = q[j]; st[16 + j] = v;
         }
-        if (obj_on) {
+        if (OBJECT && obj_on) {
             op = v3(st[9], st[10], st[11]);
             oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
             ov = v3(clampf(ov.x, -vmax, vmax), clampf(ov.y, -vmax, vmax), clampf(ov.z, -vmax, vmax));
@@ -836,11 +869,17 @@ struct Fast {
             st[9] = op.x; st[10] = op.y; st[11] = op.z; st[12] = oq.x; st[13] = oq.y; st[14] = oq.z; st[15] = oq.w;
             st[25] = ov.x; st[26] = ov.y; st[27] = ov.z; st[28] = ow.x; st[29] = ow.y; st[30] = ow.z;
         }
+        PBRE_PROBE(PB + 5);      // integration
+        if (ROLE == 2) {         // the object's new pose for the robot wave's observation
+            px->o[0][ln] = op.x; px->o[1][ln] = op.y; px->o[2][ln] = op.z;
+            px->o[3][ln] = oq.x; px->o[4][ln] = oq.y; px->o[5][ln] = oq.z; px->o[6][ln] = oq.w;
+            return 0;
+        }
         // observation / reward / termination of the new state, and its class for the next step.  The model constants
         // are re-read after the solver loop instead of keeping ~130 of them live across it.
         const Tables* T2 = &T;
         PBRE_LAUNDER(T2);
-        return finish(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC);
+        return finish<ROLE>(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC, px, ln);
     }
 
     // Class of a state (same distance arithmetic as the contact candidates of step_t<true>):
@@ -853,13 +892,24 @@ struct Fast {
 #endif                       //    mid-episode); 6: one list per class above (pays off only when k_fast_rc is throughput-bound)
     static constexpr int NCLASS = PBRE_NCLASS;
     static_assert(NCLASS == 2 || NCLASS == 6, "supported class layouts");
-    struct Tail { int cls; M3 Re; V3 pe, Va, Vl; };   // class + end-effector owner frame and spatial velocity
+    struct Tail { int cls; M3 Re; V3 pe, Va, Vl; int nT; bool lim; };   // class + end-effector owner frame and spatial velocity (nT, lim: what the class was made of)
+    static PBRE_HD int cls_of(int nO, int nT, bool lim) {
+        if (nO == 0 && nT == 0) return lim ? 1 : 0;
+        if (NCLASS == 2) return 1;
+        if (!lim && nO == 0) return nT == 1 ? 2 : 3;
+        if (!lim && nT == 0 && nO == 1) return 4;
+        return 5;
+    }
 
     // One streaming sweep over the links (a link's frame is dropped as soon as its children are done): kinematics, the
     // class of the state, and -- when qd is given -- the frame and spatial velocity of the end-effector's owner link.
     // `bounds`: try cheap wave-wide lower bounds before the exact sphere-box distances (the simple-env kernel, where every lane is
     // normally far from any contact; on the few waves of the complex-env kernels the extra tests would only add latency)
-    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags, bool bounds = false) {
+    // ROLE 1 (robot wave of the pair kernel): the new object pose is not known yet -- the sphere centres are parked in LDS and tested
+    // against the object by sweep_object() once the object wave has delivered it; cls then only counts the table and the limits.
+    template <int ROLE = 0>
+    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags, bool bounds = false,
+                              PairX* px = nullptr, int ln = 0) {
         const bool obj_on = !(flags & 1);
         Tail t;
         bool lim = false;
@@ -897,7 +947,8 @@ struct Fast {
                 // cheap lower bounds on the two distances first (bounding sphere of the object; height above the table top); the
                 // exact sphere-box tests (a square root each) only run if some lane of the wave is not clearly far
                 const float sr = T.s_r[s];
-                if (obj_on) {
+                if (ROLE == 1) { px->sc[3 * s][ln] = sc.x; px->sc[3 * s + 1][ln] = sc.y; px->sc[3 * s + 2][ln] = sc.z; }
+                else if (obj_on) {
                     const V3 dd = sub(sc, op);
                     const float reach = sr + P.margin + orad;
                     if ((!bounds || PBRE_ANY(!(dot(dd, dd) >= reach * reach))) && sphere_obj_dist(P, sc, sr, op, Ro, oh) < P.margin) nO++;
@@ -915,12 +966,23 @@ struct Fast {
                 if (eo == j) { t.Re = R[j]; t.pe = p[j]; }
             }
         }
-        if (nO == 0 && nT == 0) t.cls = lim ? 1 : 0;
-        else if (NCLASS == 2) t.cls = 1;
-        else if (!lim && nO == 0) t.cls = nT == 1 ? 2 : 3;
-        else if (!lim && nT == 0 && nO == 1) t.cls = 4;
-        else t.cls = 5;
+        t.cls = cls_of(nO, nT, lim); t.nT = nT; t.lim = lim;
         return t;
+    }
+    // the object half of sweep<1>'s classification: the parked sphere centres against the object pose (same tests, same operands)
+    static PBRE_HD int sweep_object(const Tables& T, const Params& P, V3 op, Q4 oq, bool bounds, const PairX* px, int ln) {
+        const M3 Ro = quat_R(oq);
+        const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
+        const float orad = sqrtf(dot(oh, oh));
+        int nO = 0;
+        for (int s = 0; s < T.nspheres; s++) {
+            const V3 sc = v3(px->sc[3 * s][ln], px->sc[3 * s + 1][ln], px->sc[3 * s + 2][ln]);
+            const float sr = T.s_r[s];
+            const V3 dd = sub(sc, op);
+            const float reach = sr + P.margin + orad;
+            if ((!bounds || PBRE_ANY(!(dot(dd, dd) >= reach * reach))) && sphere_obj_dist(P, sc, sr, op, Ro, oh) < P.margin) nO++;
+        }
+        return nO;
     }
     // class of the state stored in `st` (after reset / set_state)
     static PBRE_HD int classify_state(const Tables& T, const Params& P, const float* st, int flags) {
@@ -1051,15 +1113,32 @@ struct Fast {
     // Observation / reward / termination of the new state and its class.  With PBRE_F_AUTO_RESET a finished env is
     // re-initialised right here (snapshot reset): the transition's reward and done flag are returned
     // together with the first observation of the next episode.
+    template <int ROLE = 0>
     static PBRE_HD int finish(const Tables& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
-                              float* out, int mode, int flags, unsigned long long env_id, bool bounds = false) {
+                              float* out, int mode, int flags, unsigned long long env_id, bool bounds = false, PairX* px = nullptr, int ln = 0) {
         const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
+        PBRE_PROBE_DECL
         float reward = 0.f, done = 0.f;
         // end-effector pose / velocity of the state (q, qd) and its class, by the streaming sweep
         V3 ee, eul, vee;
         int cls;
+        bool first = true;
         auto kin = [&]() {
-            const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds);
+            Tail tl;
+            if (ROLE == 1 && first) {
+                // robot wave of the pair kernel: everything of the sweep that does not involve the object, then the block barrier behind
+                // which the object wave's new pose is in LDS, then the sphere-object tests
+                tl = sweep<1>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds, px, ln);
+                if (ROLE == 1) PBRE_PROBE(22);      // robot wave: kinematics of the new state
+                PBRE_PAIR_SYNC();
+                if (ROLE == 1) PBRE_PROBE(23);      // robot wave: waiting for the object wave
+                if (!(flags & 1)) {
+                    op = v3(px->o[0][ln], px->o[1][ln], px->o[2][ln]);
+                    oq.x = px->o[3][ln]; oq.y = px->o[4][ln]; oq.z = px->o[5][ln]; oq.w = px->o[6][ln];
+                    tl.cls = cls_of(sweep_object(T, P, op, oq, bounds, px, ln), tl.nT, tl.lim);
+                }
+            } else tl = sweep<0>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds);
+            first = false;
             cls = tl.cls;
             if (!want_obs) return;
             M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
@@ -1164,6 +1243,7 @@ struct Fast {
             if (P.task >= 1) { out[o++] = tg.x; out[o++] = tg.y; out[o++] = tg.z; }
             out[o++] = reward; out[o++] = done;
         }
+        if (ROLE == 1) PBRE_PROBE(20);      // robot wave: object tests, observation, reward, row
         return cls;
     }
 };

@@ -329,8 +329,8 @@ class Engine:
         return list(ms)
 
     def kernel_info(self):
-        info = (C.c_int32 * 10)()
-        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(10)))
+        info = (C.c_int32 * 16)()
+        self._chk(self.lib.pbre_kernel_info(self._ctx, info, C.c_int32(16)))
         return list(info)
 
 

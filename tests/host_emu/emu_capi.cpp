@@ -36,7 +36,8 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     std::string err;
     bool fast_ok = false;
     bool lane_ok = false;                // the iCub's lane-per-env path (pbre_lane.hpp; PBRE_ICUB_LANE=0 switches it off as on the device)
-    long n_fast = 0, n_rc = 0, n_general = 0;
+    long n_fast = 0, n_rc = 0, n_general = 0, n_pair = 0;
+    bool pair = getenv("PBRE_PAIR") && getenv("PBRE_PAIR")[0] == '1';
     bool obj_split = !(getenv("PBRE_OBJ_SPLIT") && getenv("PBRE_OBJ_SPLIT")[0] == '0');
     virtual ~pbre_ctx() {}
     virtual void reset(const uint8_t* mask) = 0;
@@ -64,7 +65,17 @@ struct Emu : pbre_ctx {
         if constexpr (PANDA) {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
-                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; FastH::step(T, P, st, act, out, mode, flags, env_id, tg); }
+                if (FastH::classify_state(T, P, st, flags) == 0) {
+                    n_fast++;
+                    // PBRE_PAIR=1: the device's pair kernel (k_fast_pair) -- the object's half of the step (ROLE 2), then the robot's half with
+                    // the observation (ROLE 1), handing the object's new pose over through the exchange area as the two waves do in LDS
+                    if (pair && !(flags & 1) && !(mode & FastH::M_INNER) && st[46] == 0.f) {
+                        PairX px;
+                        (void)FastH::step_t<false, 2>(T, P, st, nullptr, nullptr, mode, flags, 0ull, nullptr, &px, 0);
+                        (void)FastH::step_t<false, 1>(T, P, st, act, out, mode, flags, env_id, tg, &px, 0);
+                        n_pair++;
+                    } else FastH::step(T, P, st, act, out, mode, flags, env_id, tg);
+                }
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
@@ -375,8 +386,8 @@ int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; const_cast<pbre_ctx*>(c)->limits(lo, hi); return PBRE_OK; }
 int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
-    const long v[7] = {0, 0, (c->fast_ok || c->lane_ok) ? 1 : 0, c->n_fast, c->n_general, c->n_rc, 0};
-    for (int i = 0; i < n; i++) info[i] = i < 7 ? (int32_t)v[i] : 0;
+    const long v[11] = {0, 0, (c->fast_ok || c->lane_ok) ? 1 : 0, c->n_fast, c->n_general, c->n_rc, 0, 0, 0, 0, c->n_pair};      // ([10]: env-steps taken by the pair split, PBRE_PAIR=1)
+    for (int i = 0; i < n; i++) info[i] = i < 11 ? (int32_t)v[i] : 0;
     return PBRE_OK;
 }
 

@@ -32,8 +32,19 @@ TOL_CONTACT = {
     "obs_ee_pos": 2e-6, "obs_ee_eul": 4e-6, "obs_ee_vel": 5e-3, "obs_q": 1e-5, "obs_obj_pos": 5e-7, "obs_obj_eul": 1e-5,
     "obs_rel_pos": 2.5e-6, "obs_rel_eul": 1e-5, "obs_target": 1e-7, "reward": 2e-6,
 }
-TOL_STATE = 2e-4      # lumped |a-b| / (1 + |b|) bounds, kept for the free-running / multi-step checks
-TOL_OBS = 2e-3
+# reset(): 201 free-running settle steps from the same initial record in engine and oracle (the arm relaxes onto its hold targets, the
+# cube drops 4.5 cm onto the table and comes to rest); measured on the lane emulation / the GPU: see CALIBRATION below
+TOL_RESET = {       # measured (emulation / GPU): q 9.5e-8, obj_pos 1.6e-7, obj_quat 8e-8, obj_v 6.4e-6, EE pos 1.7e-7, rel pos 4e-7
+    "q": 8e-7, "qd": 1e-5, "obj_pos": 8e-7, "obj_quat": 5e-7, "obj_v": 4e-5, "obj_w": 2e-6,
+    "obs_ee_pos": 1e-6, "obs_ee_eul": 1.5e-6, "obs_ee_vel": 1e-4, "obs_q": 8e-7, "obs_obj_pos": 8e-7, "obs_obj_eul": 5e-7,
+    "obs_rel_pos": 2.5e-6, "obs_rel_eul": 2e-6, "obs_target": 8e-7,
+}
+# ... with force-limited motors (max_motor_impulse 0.02: the arm sags onto the bound and creeps; measured q 2.2e-5, EE Euler 1.8e-5)
+TOL_RESET_LIMITED = dict(TOL_RESET, q=1e-4, qd=6e-4, obs_q=1e-4, obs_ee_pos=2.5e-5, obs_ee_eul=8e-5, obs_ee_vel=6e-3, obs_rel_pos=2e-5, obs_rel_eul=5e-5)
+# 40 - 60 free-running steps after the reset (no re-synchronisation; random actions, no env reaches a contact): the object's bounds are
+# the reset's, the arm drifts (measured q 9e-7, qd 1.3e-5, normalised EE velocity 1.6e-4)
+TOL_ROLLOUT60 = dict(TOL_RESET, q=1e-5, qd=1e-4, obs_q=1e-5, obs_ee_pos=5e-6, obs_ee_eul=1e-5, obs_ee_vel=1.5e-3, obs_rel_pos=7e-6, obs_rel_eul=1e-5,
+                     reward=4e-6)       # GPU, 60 steps: q 2.1e-6, qd 1.4e-5, EE pos 9.6e-7, EE Euler 2.1e-6, EE velocity 2.3e-4, reward 7e-7
 TOL_REWARD = 1e-4
 
 
@@ -114,14 +125,14 @@ def merge_worst(worst, q):
     return worst
 
 
-MEASURE = __import__("os").environ.get("PBRE_PARITY_MEASURE") == "1"     # tools/parity_report.py: print the measured values, assert nothing
+MEASURE = __import__("os").environ.get("PBRE_PARITY_MEASURE") == "1"     # tools/parity_measured.py: also print the measured values
 
 
 def assert_within(worst, tol=None, context=""):
+    """PBRE_PARITY_MEASURE=1 (tools/parity_measured.py) additionally PRINTS the measured values; it never switches an assertion off."""
     tol = TOL if tol is None else tol
     if MEASURE:
         print("MEASURED %s: %s" % (context, dict((k, float("%.3g" % v)) for k, v in worst.items() if not isinstance(v, str))))
-        return
     bad = dict((k, (v, tol[k])) for k, v in worst.items() if k in tol and not v <= tol[k])
     assert not bad, "per-quantity tolerance exceeded (measured, bound): %r %s" % (bad, context)
 
@@ -138,12 +149,13 @@ def make_pair(Engine, lib, table, n, task=1, obj_std=0.05, tg_std=0.2, **kw):
     return eng, ora
 
 
-def check_reset(eng, ora, n):
+def check_reset(eng, ora, n, tol=None):
     obs = eng.reset()
     st_o, obs_o = ora.batch_reset(n)
     st_e = eng.get_state()
-    assert rel(st_e, st_o).max() < TOL_STATE, rel(st_e, st_o).max()
-    assert rel(obs, obs_o).max() < TOL_OBS
+    task = ora.task.task if hasattr(ora.task, "task") else 1
+    out_o = np.concatenate([obs_o, np.zeros((n, 2))], 1)
+    assert_within(panda_quantities(st_e, st_o, obs, out_o, task=task), TOL_RESET if tol is None else tol, "(reset: 201 free-running settle steps)")
     return st_o
 
 
@@ -795,7 +807,7 @@ def check_panda_force_limited(Engine, lib, table, n=6, imp=0.02):
     eng, ora = make_pair(Engine, lib, table, n, phys={"max_motor_impulse": imp})
     ref, _ = make_pair(Engine, lib, table, n)
     ora.params.max_motor_impulse = imp
-    st = check_reset(eng, ora, n)
+    st = check_reset(eng, ora, n, TOL_RESET_LIMITED)
     ref.reset()
     assert rel(ref.get_state()[:, :9], eng.get_state()[:, :9]).max() > 1e-3, "the bound does not bind: nothing tested"
     check_single_steps(eng, ora, st, np.random.default_rng(13), steps=3)
@@ -805,7 +817,7 @@ def check_panda_force_limited(Engine, lib, table, n=6, imp=0.02):
     eng.set_state(s0)
     ob, rw, dn = eng.step(a)
     so, out = ora.batch_step(s0.astype(np.float64), a)
-    assert rel(eng.get_state()[:, :31], so[:, :31]).max() < TOL_STATE and rel(ob, out[:, :-2]).max() < TOL_OBS
+    assert_within(panda_quantities(eng.get_state(), so, ob, out, rw), TOL, "(force-limited motors, one step from the unlimited arm's settled state)")
     ref.set_state(s0)
     ref.step(a)
     assert rel(ref.get_state()[:, :9], eng.get_state()[:, :9]).max() > 1e-4      # the bound changed that step too
@@ -1988,3 +2000,45 @@ def check_finger_force_kat(lib, n=1):
     _client.disconnect(cid)
     assert np.abs(total - 10.0).max() < 5e-3, total
     return {"contact_points": tail[0, 6], "normal_force_per_finger_N": total[0].tolist()}
+
+
+def check_pair_split_is_bit_identical(Engine, lib, table, panda, setenv, n=256, steps=40, use_ik=0, phys=None, task=1):
+    """The pair mapping of the simple class (csrc/pbre_capi.hip: k_fast_pair -- the robot's half of the step on one wave, the object's
+    half on a second one, the object's new pose handed over in LDS; Fast::step_t<false, 1 / 2>) against the one-lane-per-env step
+    (k_fast, ROLE 0): a full reset through each (201 settle launches in each mapping), contact-rich states among the envs so that the
+    complex-env kernel runs beside it, `steps` steps with auto-reset and a short episode, per-env object parameters -- rows, states and
+    classes bit for bit.  `setenv(name, value)` sets an environment variable for the engines created after it (the mapping is read at
+    pbre_create: PBRE_PAIR=1 always, 0 never, default by batch size)."""
+    kw = dict(task=task, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=lib, flags=2, max_steps=25, use_ik=use_ik)
+    if phys:
+        kw["phys"] = phys
+    setenv("PBRE_PAIR", "1")
+    a = Engine(table, **kw)
+    setenv("PBRE_PAIR", "0")
+    b = Engine(table, **kw)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob) and np.array_equal(a.get_state(), b.get_state()), "reset through the pair mapping differs"
+    st = a.get_state()
+    if phys is None:
+        ora = orc.Oracle(table, task=1)
+        ora.task.obj_pose_rnd_std, ora.task.tg_pose_rnd_std = 0.05, 0.2
+        base, _ = ora.batch_reset(1)
+        S = contact_states(ora, panda, base[0], np.random.default_rng(1), 6, 6).astype(np.float32)
+        st[:len(S), :S.shape[1]] = S
+    rng = np.random.default_rng(21)
+    st[:, 28:31] += rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32) * (rng.random((n, 1)) < 0.3)      # some objects spinning / sliding
+    st[:, 25:27] += rng.uniform(-0.3, 0.3, (n, 2)).astype(np.float32) * (rng.random((n, 1)) < 0.3)
+    a.set_state(st); b.set_state(st)
+    if task >= 1 and phys is None:
+        m = rng.uniform(0.05, 0.3, n).astype(np.float32); mu = rng.uniform(0.3, 1.2, n).astype(np.float32)
+        for e in (a, b):
+            e.set_physics_per_env(obj_mass=m, obj_mu=mu)
+    for k in range(steps):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), "step %d: rows differ between the pair mapping and the one-lane step" % k
+    assert np.array_equal(a.get_state(), b.get_state())
+    ia, ib = a.kernel_info(), b.kernel_info()
+    assert ia[10] > 0 and ib[10] == 0, (ia, ib)
+    return ia, ib

@@ -9,6 +9,15 @@ from pybullet_robot_envs import _capi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["pair", "lane"])
+def simple_env_mapping(request, monkeypatch):
+    """Every test of this module runs under both mappings of the simple class: the pair kernel (k_fast_pair: robot wave + object wave per
+    64 envs -- what launch_step picks by itself for batches of up to 65536 envs, i.e. for every per-GPU shard of BASELINE's split) and
+    the one-lane-per-env kernel k_fast (what the full 131072-env batch gets).  PBRE_PAIR is read at pbre_create."""
+    monkeypatch.setenv("PBRE_PAIR", "1" if request.param == "pair" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("task", [0, 1])
 def test_reset_and_steps(panda, hip_lib, task):
     n = 50                                   # not a multiple of 16: exercises the padding rows
@@ -49,8 +58,7 @@ def test_free_running_rollout(panda, hip_lib):
         a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
         ob, rw, dn = eng.step(a)
         st, out = ora.batch_step(st, a)
-    assert parity.rel(eng.get_state(), st).max() < 2e-3
-    assert parity.rel(ob, out[:, :-2]).max() < 1e-2
+    parity.assert_within(parity.panda_quantities(eng.get_state(), st, ob, out, rw), parity.TOL_ROLLOUT60, "(60 free-running steps after reset)")
 
 
 def test_full_episode_rollout(panda, hip_lib):
@@ -295,13 +303,14 @@ def test_config2_reach_without_object(panda, hip_lib):
     ora.params.flags = _orc.F_NO_OBJECT
     eng.reset()
     st0 = eng.get_state()
-    sub = np.arange(0, n, 64)
     rng = np.random.default_rng(8)
     a = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
     ob, rw, dn = eng.step(a)
     st1 = eng.get_state()
-    so, out = ora.batch_step(st0[sub].astype(np.float64), a[sub])
-    assert parity.rel(st1[sub], so).max() < parity.TOL_STATE and parity.rel(ob[sub], out[:, :-2]).max() < parity.TOL_OBS
+    so, out = ora.batch_step(st0.astype(np.float64), a)          # every env of the batch against the oracle, per quantity
+    q = parity.panda_quantities(st1, so, ob, out, rw, task=0)
+    parity.assert_within(q, parity.TOL, "(config 2: one step of all 4096 reach envs)")
+    assert np.array_equal(dn, out[:, -1])
     assert np.array_equal(st1[:, 9:16], st0[:, 9:16])                           # the object did not move
     assert np.abs((st1[:, :7] - st0[:, :7]) - 0.025 * a).max() < 2e-5          # K2 motor law
 
@@ -415,6 +424,7 @@ def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch
     n = 4096
     kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40,
               use_ik=use_ik, action_repeat=action_repeat)           # (joint control, IK control, the inner iterations of action_repeat: all k_fast modes)
+    monkeypatch.setenv("PBRE_PAIR", "0")            # (the two builds of k_fast: not the pair kernel, whatever the module's mapping fixture says)
     monkeypatch.setenv("PBRE_FAST3", "1")
     a = _capi.Engine(panda["table"], **kw)
     monkeypatch.setenv("PBRE_FAST3", "0")
@@ -554,3 +564,30 @@ def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda, hip_li
         return eng.get_state(), ph["obj_h"][0], step
     print("rolling onset:", parity.check_rolling_onset_kat(make))
 
+
+
+@pytest.mark.parametrize("use_ik,obj", [(0, None), (1, None), (0, "YcbTennisBall"), (0, "YcbMustardBottle")])
+def test_pair_kernel_is_bit_identical_to_k_fast(panda, hip_lib, monkeypatch, use_ik, obj):
+    """k_fast_pair (the small-batch mapping: two waves per 64 envs) against k_fast on the same states -- a full reset through each, contact-rich
+    envs among them (k_row_list beside it), 60 steps with auto-reset, per-env object parameters: rows, states and classes bit for bit.
+    That is what keeps the sharding invariance bitwise although shard sizes select different kernels."""
+    phys = None
+    if obj:
+        from pybullet_robot_envs.model.objects import object_physics
+        phys = object_physics(obj)
+    ia, ib = parity.check_pair_split_is_bit_identical(_capi.Engine, hip_lib, panda["table"], panda, monkeypatch.setenv, n=2048, steps=60,
+                                                      use_ik=use_ik, phys=phys)
+    assert 0 < ia[11] <= 256, ia          # the pair kernel's register count
+    print("steps taken by the pair kernel:", ia[10])
+
+
+def test_pair_kernel_is_the_default_of_small_batches(panda, hip_lib, monkeypatch):
+    """launch_step's rule (PBRE_PAIR unset): the pair kernel while its waves fit two per SIMD (<= 65536 envs on an MI355X)."""
+    monkeypatch.delenv("PBRE_PAIR", raising=False)
+    for n, want in ((4096, True), (65536, True), (131072, False)):
+        eng = _capi.Engine(panda["table"], task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib)
+        eng.reset()
+        eng.step(np.zeros((n, 7), np.float32))
+        info = eng.kernel_info()
+        assert (info[10] > 0) == want, (n, info)
+        eng.close()
