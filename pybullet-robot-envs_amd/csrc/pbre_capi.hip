@@ -28,6 +28,9 @@
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
 #define PBRE_PAIR_SYNC() __syncthreads()
+#ifndef PBRE_CONST_AS        // (-DPBRE_CONST_AS= builds the A/B variant with the model constants re-read through a plain pointer)
+#define PBRE_CONST_AS __attribute__((address_space(4)))
+#endif
 #ifdef PBRE_PHASE_PROBE      // tools/phase_probe.py: cycles per phase of lane 0 of block 0's waves, summed over the launches since the last reset of the counters
 __device__ unsigned long long g_probe[32];
 #define PBRE_PROBE_DECL unsigned long long pb_t_ = __builtin_readcyclecounter();
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ 
             PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
             FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
             FastD::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-            const int c = FastD::finish(*T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
+            // (the tables through the constant address space: scalar loads although the row's stores precede them -- Fast::finish)
+            const int c = FastD::finish(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
                                         P.env_id_base + (unsigned long long)env);
             publish_class(env, c, cls, next_list, next_count, cap);
         }

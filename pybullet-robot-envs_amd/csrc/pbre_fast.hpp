@@ -31,6 +31,9 @@
 #ifndef PBRE_LAUNDER        // hide a (uniform) pointer's provenance from the optimiser (device build)
 #define PBRE_LAUNDER(p) do {} while (0)
 #endif
+#ifndef PBRE_CONST_AS       // device build: the constant address space -- wave-uniform loads from it are scalar loads (s_load), whatever stores
+#define PBRE_CONST_AS       // precede them; nothing on the host.  See step_t's call of finish().
+#endif
 #ifndef PBRE_ANY            // wave-uniform "any lane" on the device; identity on the host (one env per call)
 #define PBRE_ANY(x) (x)
 #endif
@@ -82,6 +85,8 @@ inline bool topo_matches(const Tables& T) {
     }
     return true;
 }
+
+typedef PBRE_CONST_AS Tables CTables;
 
 template <class Topo>
 struct Fast {
@@ -879,7 +884,8 @@ struct Fast {
         // are re-read after the solver loop instead of keeping ~130 of them live across it.
         const Tables* T2 = &T;
         PBRE_LAUNDER(T2);
-        return finish<ROLE>(*T2, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC, px, ln);
+        const CTables* T4 = (const CTables*)T2;
+        return finish<ROLE>(*T4, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC, px, ln);
     }
 
     // Class of a state (same distance arithmetic as the contact candidates of step_t<true>):
@@ -907,8 +913,8 @@ struct Fast {
     // normally far from any contact; on the few waves of the complex-env kernels the extra tests would only add latency)
     // ROLE 1 (robot wave of the pair kernel): the new object pose is not known yet -- the sphere centres are parked in LDS and tested
     // against the object by sweep_object() once the object wave has delivered it; cls then only counts the table and the limits.
-    template <int ROLE = 0>
-    static PBRE_HD Tail sweep(const Tables& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags, bool bounds = false,
+    template <int ROLE = 0, class TT = Tables>
+    static PBRE_HD Tail sweep(const TT& T, const Params& P, const float* q, const float* qd, V3 op, Q4 oq, int flags, bool bounds = false,
                               PairX* px = nullptr, int ln = 0) {
         const bool obj_on = !(flags & 1);
         Tail t;
@@ -970,7 +976,8 @@ struct Fast {
         return t;
     }
     // the object half of sweep<1>'s classification: the parked sphere centres against the object pose (same tests, same operands)
-    static PBRE_HD int sweep_object(const Tables& T, const Params& P, V3 op, Q4 oq, bool bounds, const PairX* px, int ln) {
+    template <class TT>
+    static PBRE_HD int sweep_object(const TT& T, const Params& P, V3 op, Q4 oq, bool bounds, const PairX* px, int ln) {
         const M3 Ro = quat_R(oq);
         const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
         const float orad = sqrtf(dot(oh, oh));
@@ -1113,8 +1120,13 @@ struct Fast {
     // Observation / reward / termination of the new state and its class.  With PBRE_F_AUTO_RESET a finished env is
     // re-initialised right here (snapshot reset): the transition's reward and done flag are returned
     // together with the first observation of the next episode.
-    template <int ROLE = 0>
-    static PBRE_HD int finish(const Tables& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
+    // TT: `Tables`, or the same struct in the constant address space (CTables).  The second half of a step re-reads the model constants
+    // (they are not kept live across the solver loop); through a plain pointer those re-reads come after the step's stores and behind an
+    // opaque pointer, so the compiler issued them as per-lane FLAT loads of a uniform address -- ~200 vector loads with a full memory
+    // round trip each, 45 k of the robot wave's 138 k cycles on a lone wave (tools/phase_probe.py) -- and even the `owner == link` scan
+    // over the collision spheres ran on vector compares.  From the constant address space they are scalar loads again.
+    template <int ROLE = 0, class TT = Tables>
+    static PBRE_HD int finish(const TT& T, const Params& P, float* st, float* q, float* qd, V3 op, Q4 oq,
                               float* out, int mode, int flags, unsigned long long env_id, bool bounds = false, PairX* px = nullptr, int ln = 0) {
         const bool want_obs = (mode & (M_OBS | M_TASK)) != 0;
         PBRE_PROBE_DECL

@@ -71,6 +71,10 @@ class Oracle:
 
     def __init__(self, table, f32=False, task=1):
         so = os.path.join(ROOT, "oracle", "build", "liborc_f32.so" if f32 else "liborc.so")
+        if os.environ.get("ORC_SANITIZED") == "1":      # the ASan / UBSan build (oracle/Makefile: asan); needs the sanitizer runtime preloaded
+            so = so.replace(".so", "_asan.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"])
         if not os.path.exists(so):
             build()
         self.lib = C.CDLL(so)

@@ -182,3 +182,27 @@ def test_sliding_ball_and_can_end_up_rolling_at_the_analytic_speed(panda):
     rep = parity.check_rolling_onset_kat(make)
     assert rep["YcbTennisBall"]["steps_to_rolling"] > 5
 
+
+
+def test_oracle_under_asan_ubsan():
+    """SURVEY section 5 (race / memory-error detection: the reference has none): the oracle's own tests once more against its
+    AddressSanitizer + UndefinedBehaviorSanitizer build (`make -C oracle asan`), in a subprocess with the sanitizer runtime preloaded.
+    Any out-of-bounds access, use of an uninitialised stack slot through a wild index, signed overflow or misaligned access in the
+    restatement aborts that run."""
+    import os, subprocess, sys
+    if os.environ.get("ORC_SANITIZED") == "1":
+        return                                   # (we ARE the sanitized re-run)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"])
+    rt = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ub = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    if not (os.path.isabs(rt) and os.path.exists(rt)):
+        import pytest
+        pytest.skip("no libasan in this image")
+    env = dict(os.environ, ORC_SANITIZED="1", LD_PRELOAD=rt + (":" + ub if os.path.exists(ub) else ""),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "AddressSanitizer" not in tail and "runtime error" not in tail, tail
