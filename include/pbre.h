@@ -257,7 +257,10 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
  * (env-steps taken by the robot-contact / limit-row kernels; wraps at 2^31), [8] steps since the last reset whose fast kernel was the
  * variant limited to 3 waves per SIMD (picked when the complex envs' waves would otherwise displace fast-kernel waves), [9] its VGPRs,
  * [10] steps since the last reset whose simple envs were stepped by the pair kernel (robot wave + object wave per 64 envs: the mapping
- * for batches that leave most SIMDs without a wave), [11] its VGPRs */
+ * for batches that leave most SIMDs without a wave), [11] its VGPRs, [12] NaN / Inf guard: env-steps since pbre_create whose state was
+ * not finite (NaN or +-Inf in a joint angle / velocity or in the object's pose / twist, on input or after the step).  Such an env-step is
+ * returned with reward 0 and done 1; with PBRE_F_AUTO_RESET the env restarts from the settled snapshot in the same step, without it the
+ * env keeps its NaN state (and is counted again every step) until the caller resets it.  The reference has no such guard. */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 #ifdef __cplusplus

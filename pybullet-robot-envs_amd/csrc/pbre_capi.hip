@@ -28,6 +28,8 @@
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
 #define PBRE_PAIR_SYNC() __syncthreads()
+#define PBRE_COUNT_BAD(p) atomicAdd((p), 1)
+#define PBRE_OBJV_SYNC() __syncthreads()
 #ifndef PBRE_CONST_AS        // (-DPBRE_CONST_AS= builds the A/B variant with the model constants re-read through a plain pointer)
 #define PBRE_CONST_AS __attribute__((address_space(4)))
 #endif
@@ -83,7 +85,9 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     float* o = nullptr;
     if (MODE & CoreD::M_ACTION) a = actions + (size_t)(real ? env : 0) * act_dim;
     if (MODE & CoreD::M_OBS) o = real ? out + (size_t)env * ow : scratch_row;
-    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, P.env_id_base + (unsigned long long)env);
+    // (padding rows: pristine dummy record in, scratch record out -- see k_row_list)
+    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, P.env_id_base + (unsigned long long)env, nullptr,
+                real ? nullptr : st + (size_t)EPB * STATE);
 }
 
 // Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
@@ -199,40 +203,76 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
 // state is the lane-per-env kernels' Fast::finish run by lane 0 of the row, so both complex-env kernels are interchangeable.
 // A row spreads an env over 16 lanes, so a wave's latency is ~1/3 of a k_fast_rc wave's: with few complex envs the step is
 // no longer gated by that latency.  Grid-stride over the list (the host only has a hint of its length).
+// The object of a complex env WITHOUT robot-object contact (95 % of them) shares no unknown with the robot's rows, so its half of the
+// step is not the row waves' business: a fifth wave of the block steps the objects of the block's 16 envs, one lane per env (ObjStep,
+// pbre_objstep.hpp: the same rows, 150 sweeps, as a lane-per-env chain of ~45 us), and leaves the new twists in LDS.  A row wave none
+// of whose four envs has such a contact neither builds nor sweeps the object-table rows -- its sweep is the robot's rows alone, about
+// half the instructions -- and picks the twist up at the end (Core::step's `objv`, the mechanism of the iCub's kw_obj); an env WITH a
+// robot-object contact solves the coupled system as before (zipped sweeps), and so do its wave-mates, whose own object result is then
+// dropped in favour of the side record's: what an env computes never depends on the envs it shares a wave with.
+// The block is four waves -- three row waves (12 envs) and the object wave -- so that each has a SIMD of the CU to itself: as a fifth
+// wave the object wave shared its SIMD with a row wave and both ran at little more than half their lone speed (measured, phase probe).
+constexpr int REPB = 12;             // envs per block of k_row_list
+constexpr int RTPB = REPB * W + FTPB;
 template <int MODE>
-__global__ __launch_bounds__(TPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
                                                   const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
     static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
+    __shared__ float objv[REPB][W];
     // These few waves are the tail of the step: each shares its SIMD with a k_fast wave, and a row wave is latency-bound (it leaves
     // most issue slots to its neighbour anyway), so it gets the higher wave priority and runs at its lone-wave speed.
     if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);
     const int total = cur_count[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
-    const int row = threadIdx.x >> 4;
+    const bool obj_on = !(flags & 1);
+    const bool obj_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= REPB * W)) != 0;
+    const int row = obj_wave ? (int)threadIdx.x - REPB * W : (int)(threadIdx.x >> 4);
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
-    for (int base = blockIdx.x * EPB; base < total; base += gridDim.x * EPB) {
+    for (int base = blockIdx.x * REPB; base < total; base += gridDim.x * REPB) {
         const int i = base + row;
-        const bool real = i < total;
-        const int env = real ? cur_list[i] : dummy_base + row;           // idle rows step a dummy record in lockstep
+        const bool real = i < total && row < REPB;
+        // Idle rows run in lockstep with the real ones and the wave pays for the rows of its heaviest group, so what they step must be the
+        // cheapest state there is -- and stay it: they READ a pristine dummy record (the un-settled reset pose pbre_create wrote: arm at
+        // home, object in the air, no contact, no joint at a limit) and WRITE their result to a scratch record EPB further on.  (Until
+        // round 4 they stepped the dummy record in place, with env 0's actions, launch after launch and without ever being reset: a
+        // random walk into joint limits and table contacts that made every partially filled wave carry the longest chain of the step.)
+        const int env = real ? cur_list[i] : dummy_base + (row < REPB ? row : 0);
         float* st = state + (size_t)env * STATE;
-        CoreD::step(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
-                    (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
-        PBRE_PROBE_DECL
-        if (real && (threadIdx.x & 15u) == 0) {
-            float q[NJ], qd[NJ];
-            PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
-            FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
-            FastD::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-            // (the tables through the constant address space: scalar loads although the row's stores precede them -- Fast::finish)
-            const int c = FastD::finish(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
-                                        P.env_id_base + (unsigned long long)env);
-            publish_class(env, c, cls, next_list, next_count, cap);
+        float* st_idle = real ? nullptr : st + (size_t)EPB * STATE;
+        if (obj_wave) {
+            if (obj_on) {
+                if (row < REPB) {
+                    float pose[7], tw[6], o[6];
+                    PBRE_UNROLL for (int k = 0; k < 7; k++) pose[k] = st[CoreD::LC + k];
+                    PBRE_UNROLL for (int k = 0; k < 6; k++) tw[k] = st[W + CoreD::LC + k];
+                    // per-env object parameters (pbre_set_physics_per_env): X[12] mass, X[13] lateral friction, X[15] 1 + linear damping
+                    const float o_m = st[44] > 0.f ? st[44] : P.obj_m, o_mu = st[45] > 0.f ? st[45] : P.obj_mu, o_kl = st[47] > 0.f ? st[47] - 1.f : P.kl;
+                    ObjStep::run_p(P, pose, tw, o, o_m, o_mu, o_kl);
+                    PBRE_UNROLL for (int k = 0; k < 6; k++) objv[row][CoreD::LC + k] = o[k];
+                }
+                __syncthreads();                                                 // pairs with PBRE_OBJV_SYNC in the row waves' Core::step
+            }
+        } else {
+            CoreD::step(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
+                        (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull, obj_on ? &objv[row][0] : nullptr, st_idle);
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
+            PBRE_PROBE_DECL
+            if (real && (threadIdx.x & 15u) == 0) {
+                float q[NJ], qd[NJ];
+                PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+                FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
+                FastD::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+                // (the tables through the constant address space: scalar loads although the row's stores precede them -- Fast::finish)
+                const int c = FastD::finish(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
+                                            P.env_id_base + (unsigned long long)env);
+                publish_class(env, c, cls, next_list, next_count, cap);
+            }
+            PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
         }
-        PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
+        if (obj_on && base + gridDim.x * REPB < total) __syncthreads();          // the side records are rewritten by the next trip
     }
 }
 
@@ -325,6 +365,7 @@ struct pbre_ctx {
     Tables* dT = nullptr;
     EnvBuf main, tmp;
     float *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr;
+    int* d_bad = nullptr;              // NaN / Inf guard: env-steps that met a non-finite state (Params::bad_count)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
     int n_simd = 1024;
@@ -384,8 +425,9 @@ static bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->cfg.flag
 static hipError_t alloc_buf(EnvBuf& b, int cap) {
     b.cap = cap;
     hipError_t e;
-    if ((e = hipMalloc(&b.state, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;
-    if ((e = hipMemset(b.state, 0, (size_t)(cap + EPB) * STATE * sizeof(float))) != hipSuccess) return e;     // k_init keeps X[12], X[13], X[15]
+    // cap records + EPB pristine dummy records (read by the idle rows of the row kernels) + EPB scratch records (written by them)
+    if ((e = hipMalloc(&b.state, (size_t)(cap + 2 * EPB) * STATE * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMemset(b.state, 0, (size_t)(cap + 2 * EPB) * STATE * sizeof(float))) != hipSuccess) return e;     // k_init keeps X[12], X[13], X[15]
     if ((e = hipMalloc(&b.cls, (size_t)2 * cap)) != hipSuccess) return e;
     if ((e = hipMalloc(&b.tgt, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.tgt, 0, (size_t)(cap + EPB) * NJ * sizeof(float))) != hipSuccess) return e;
@@ -455,8 +497,8 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB == 1;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
     if constexpr (NB == 1) {
         if (rows) {
-            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + EPB - 1) / EPB + 8));
-            hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(TPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + 8));
+            hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
     }
@@ -474,7 +516,7 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     // the 3-waves-per-SIMD variant when the complex envs' waves would push k_fast waves of the 2-wave variant into an extra round
     bool fast3 = false;
     if (!single && c->fast3 != 0) {
-        const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 : (hint + FTPB - 1) / FTPB * 2) + 8;
+        const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 + (hint + REPB - 1) / REPB : (hint + FTPB - 1) / FTPB * 2) + 8;
         fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
     }
     // small batches: the pair kernel (two waves per 64 envs) while all of its waves are resident at once, two per SIMD at most
@@ -550,7 +592,7 @@ void pbre_destroy(pbre_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     free_buf(c->main); free_buf(c->tmp);
-    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask})
+    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask, (void*)c->d_bad})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -621,6 +663,9 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(hipMalloc(&c->d_act, (size_t)c->npad * c->act_dim * sizeof(float)));
     CK(hipMalloc(&c->d_out, (size_t)c->npad * c->ow * sizeof(float)));
     CK(hipMalloc(&c->d_scratch, 64 * sizeof(float)));
+    CK(hipMalloc(&c->d_bad, 2 * sizeof(int)));
+    CK(hipMemset(c->d_bad, 0, 2 * sizeof(int)));
+    c->P.bad_count = c->d_bad;
     CK(hipMalloc(&c->d_ids, (size_t)(c->npad + EPB) * sizeof(unsigned long long)));
     CK(hipMalloc(&c->d_ep, (size_t)(c->npad + EPB) * sizeof(unsigned)));
     CK(hipMalloc(&c->d_idx, (size_t)c->npad * sizeof(int)));
@@ -965,7 +1010,7 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 2>) == hipSuccess) rf = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_step<MODE_STEP>) == hipSuccess) rg = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_rc<MODE_STEP>) == hipSuccess) rr = fa.numRegs;
-    int complex_now = 0, complex_sum = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
+    int complex_now = 0, complex_sum = 0, bad = 0;       // envs whose current state is "complex" (what the next step's k_fast_rc will take)
     const bool lpe = lane_per_env(c);
     if (lpe) {
         int cnt[NB] = {0};
@@ -974,9 +1019,13 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
         (void)hipMemcpy(&complex_sum, c->main.count + 3 * NB + 1, sizeof(int), hipMemcpyDeviceToHost);
         for (int k = 0; k < NB; k++) complex_now += cnt[k];
     }
-    const int v[12] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
-                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1};
-    for (int i = 0; i < n; i++) info[i] = i < 12 ? v[i] : 0;
+    if (c->d_bad) {
+        (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
+        (void)hipMemcpy(&bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    }
+    const int v[13] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
+                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1, bad};
+    for (int i = 0; i < n; i++) info[i] = i < 13 ? v[i] : 0;
     return PBRE_OK;
 }
 

@@ -36,6 +36,12 @@
 #ifndef PBRE_OPAQUE
 #define PBRE_OPAQUE(p)       // device builds: hide a pointer's value from the optimiser (no instruction)
 #endif
+#ifndef PBRE_COUNT_BAD       // ++*p from any number of lanes (device: atomicAdd)
+#define PBRE_COUNT_BAD(p) (++*(p))
+#endif
+#ifndef PBRE_OBJV_SYNC       // a kernel whose `objv` side record is produced by a sibling wave of the same block (k_row_list): the block barrier
+#define PBRE_OBJV_SYNC()     // behind which it is complete; nothing where a kernel of its own produced it earlier (kw_obj) and on the host
+#endif
 #ifndef PBRE_PROBE           // phase timing of one wave (tools/phase_probe.py builds with -DPBRE_PHASE_PROBE); nothing otherwise
 #define PBRE_PROBE(k)
 #define PBRE_PROBE_DECL
@@ -436,8 +442,10 @@ struct Core {
     // act: pointer to this env's action row or nullptr.  out: this env's [obs_dim+2] row or nullptr.
     // objv: nullptr, or this group's W-float side record whose object-twist lanes hold the object's twist after a step without
     // robot-object contact (pbre_objstep.hpp); used by the groups that have no such contact.
+    // st_out: where the new state goes (default: back into st).  The row kernels' idle rows read a pristine record and write a scratch one,
+    // so that what they compute in lockstep with the real rows stays the cheapest step there is (see k_row_list).
     static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                             const float* tgt = nullptr, unsigned long long env_id = 0, const float* objv = nullptr) {
+                             const float* tgt = nullptr, unsigned long long env_id = 0, const float* objv = nullptr, float* st_out = nullptr) {
         const I lane = L::lane();
         const F zero = L::c(0.f), one = L::c(1.f);
         const B robot = L::lti(lane, NJ);
@@ -972,11 +980,21 @@ struct Core {
 #ifndef PBRE_TWO_CHAIN
 #define PBRE_TWO_CHAIN 1
 #endif
+#ifndef PBRE_ROBOT_ONLY_CHAIN      // (0: A/B -- such waves take the loops with per-slot tests below, as before round 4)
+#define PBRE_ROBOT_ONLY_CHAIN 1
+#endif
         constexpr bool TWO_CHAIN = PBRE_TWO_CHAIN && SH::W == 16 && !SH::MREC;
         bool solved2 = false;
         if constexpr (TWO_CHAIN) {
         const bool ot_all = (on_bits & ((1u << NC_OT) - 1u)) == ((1u << NC_OT) - 1u);
-        if (!solved && ot_all && !use_objv) {
+        // (with `objv`: a wave none of whose groups has a robot-object contact has not built the object-table rows -- ot_all is false and it
+        // sweeps its robot rows alone below; a wave with such a group runs the zipped sweeps over everything, as without `objv`)
+        // robot_only: no object row of any kind in the wave -- the object is another wave's (k_row_list's object wave: every group of this
+        // wave is free of robot-object contact) or absent (PBRE_F_NO_OBJECT).  The sweep is then the robot chain alone, M L RTn RTf, as
+        // straight-line code from the same stage functions (the loop with per-slot tests spent a third of its time in its branches: a
+        // lone wave's dependent instruction takes ~4.5 cycles, a scalar test + branch between two rows ~15).
+        const bool robot_only = !solved && (on_bits & ((1u << (NC_OT + NC_RO)) - 1u)) == 0u && PBRE_ROBOT_ONLY_CHAIN;
+        if (!solved && (ot_all || robot_only)) {
             solved2 = true;
             const unsigned ro_bits = (on_bits >> NC_OT) & ((1u << NC_RO) - 1u), rt_bits = (on_bits >> (NC_OT + NC_RO)) & ((1u << NC_RT) - 1u);
 #ifdef PBRE_TWO_CHAIN_TRACE
@@ -1070,6 +1088,23 @@ struct Core {
             };
             // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
             auto rt_f = [&]() { for_seq<2 * NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{}); }); };
+            if (robot_only) {
+                auto motors = [&](auto rev_c) {
+                    constexpr bool REV = decltype(rev_c)::value;
+                    for_seq<4 * NJ>([&](auto kc) { constexpr int k = decltype(kc)::value; mstage(std::integral_constant<int, (REV ? NJ - 1 - k / 4 : k / 4)>{}, std::integral_constant<int, k % 4>{}); });
+                };
+                auto rt_n = [&]() { for_seq<NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; nstage(fr, dvr, std::integral_constant<int, NRT0 + k / NSR>{}, std::integral_constant<int, k % NSR>{}); }); };
+                for (int it = 0; it < P.iters; it += 2) {
+                    motors(std::true_type{});
+                    if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
+                    if (rt_bits) { rt_n(); rt_f(); }
+                    if (it + 1 >= P.iters) break;
+                    if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j); }
+                    motors(std::false_type{});
+                    if (rt_bits) { rt_n(); rt_f(); }
+                }
+                dv = dvr;
+            } else {
             const bool e_zip = rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows
             auto mid = [&]() {            // the rest of a sweep after its motor / limit / OT-normal rows
                 if (ro_bits) coupled(false);
@@ -1090,6 +1125,7 @@ struct Core {
             }
             if (e_zip) rt_f();            // the last sweep's
             dv = L::sel(obj_lane, dvo, dvr);
+            }
         }
         }
         if (solved || solved2) {
@@ -1127,7 +1163,7 @@ struct Core {
         PBRE_PROBE(9);      // the sweeps
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
-        if (use_objv) vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew);
+        if (use_objv) { PBRE_OBJV_SYNC(); vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew); }
         B dyn = obj_on ? L::bor(robot, obj_lane) : robot;
         F Vn = L::sel(dyn, vnew, Vr);
         B posl = obj_on ? L::lti(lane, LC + 3) : robot;
@@ -1173,11 +1209,17 @@ struct Core {
             F qc = L::sel(L::eqi(lane, LC + 3), nq.x, L::sel(L::eqi(lane, LC + 4), nq.y, L::sel(L::eqi(lane, LC + 5), nq.z, nq.w)));
             Qn = L::sel(L::band(L::gei(lane, LC + 3), L::lti(lane, LC + 7)), qc * in, Qn);
         }
+        {   // NaN / Inf guard: a non-finite entry of the incoming state (x * 0 is NaN for x = NaN, +-Inf) -- which the solver's
+            // clamps would otherwise turn into finite garbage -- is added to every position of the new state: 0 normally, NaN then.
+            // observe() / Fast::finish find it there, count the env-step and (PBRE_F_AUTO_RESET) restart the env.
+            const F finv = L::sum(L::fma(Qr, zero, Vr * zero));
+            Qn = L::sel(posl, Qn + finv, Qn);
+        }
         {   // action_repeat > 1: a group that left the apply_action loop earlier in this env.step() (X[14]) does not simulate
             const B skip = L::ne(L::bcast(Xr, 14), zero);
             Qn = L::sel(skip, Qr, Qn); Vn = L::sel(skip, Vr, Vn);
         }
-        L::store(st, Qn); L::store(st + W, Vn);
+        { float* so = st_out ? st_out : st; L::store(so, Qn); L::store(so + W, Vn); }
         PBRE_PROBE(10);     // integration, store
 
         if (mode & (M_OBS | M_TASK)) {
@@ -1185,7 +1227,7 @@ struct Core {
             // values both phases use (joint frames, ancestor tables, ...) stay in registers across the whole solver loop
             const Tables* Tp = &T;
             PBRE_OPAQUE(Tp);
-            observe(*Tp, P, st, Qn, Vn, Xr, out, mode, flags, env_id);
+            observe(*Tp, P, st_out ? st_out : st, Qn, Vn, Xr, out, mode, flags, env_id);
         }
     }
 
@@ -1235,6 +1277,11 @@ struct Core {
         const V3 ee = o.ee, op = o.op, tg = o.tg;
 
         F reward = zero, done = zero;
+        // NaN / Inf guard: a non-finite position of the new state (see step()): counted, returned as reward 0 / done 1, restarted with
+        // PBRE_F_AUTO_RESET
+        const B posn = (flags & 1) ? L::lti(lane, NJ) : L::lti(lane, LC + 7);
+        const B bad = L::ne(L::sum(L::sel(posn, Qn * zero, zero)), zero);
+        if (L::any(bad)) { if (L::first(L::sel(bad, one, zero)) != 0.f && L::lane0() && P.bad_count) PBRE_COUNT_BAD(P.bad_count); }
         if (mode & M_INITD) {
             // iCubPushGymEnv.reset (icub_push_gym_env.py:124-127): distances the normalised reward divides by
             F d1 = norm(sub(ee, op)), d2 = norm(sub(op, tg));
@@ -1278,6 +1325,7 @@ struct Core {
                 } else
                 reward = L::sel(succ, L::c(1000.f) + (L::c(100.f) - dsucc * L::c(80.f)), base);
             }
+            done = L::sel(bad, one, done); reward = L::sel(bad, zero, reward);
             const F lf = (mode & M_INNER) ? L::sel(left, one, zero) : zero;      // consumed by the remaining iterations, cleared by the last one
             F Xn = L::sel(L::eqi(lane, 3), cnt, L::sel(L::eqi(lane, 4), term, L::sel(L::eqi(lane, 14), lf, Xr)));
             L::storem(st + 2 * W, Xn, L::lti(lane, 16));

@@ -41,6 +41,9 @@
 #define PBRE_PROBE(k)
 #define PBRE_PROBE_DECL
 #endif
+#ifndef PBRE_COUNT_BAD      // ++*p from any number of lanes (device: atomicAdd)
+#define PBRE_COUNT_BAD(p) (++*(p))
+#endif
 #ifndef PBRE_PAIR_SYNC      // block barrier between the two waves of the pair kernel (device build; never reached on the host)
 #define PBRE_PAIR_SYNC() do {} while (0)
 #endif
@@ -380,6 +383,16 @@ struct Fast {
         V3 op = v3(0.f, 0.f, 0.f);
         Q4 oq; oq.x = 0.f; oq.y = 0.f; oq.z = 0.f; oq.w = 1.f;
         if (OBJECT) { op = v3(st[9], st[10], st[11]); oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15]; }     // (the robot wave gets the NEW pose, from the object wave)
+        // NaN / Inf guard.  fin_r / fin_o: 0 while every entry of the robot's / the object's part of the incoming state
+        // is finite, NaN otherwise (x * 0 is NaN for x = NaN or +-Inf).  They are ADDED to one position of the new state, so a
+        // non-finite input -- which the solver's clamps (v_med3, v_max: they return the other operand) would otherwise turn into
+        // finite garbage -- leaves a NaN that finish() finds, counts and, with PBRE_F_AUTO_RESET, restarts the env from.
+        float fin_r = 0.f, fin_o = 0.f;
+        if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) { fin_r = fmaf(q[j], 0.f, fin_r); fin_r = fmaf(qd[j], 0.f, fin_r); } }
+        if (OBJECT) {
+            fin_o = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, oq.w * 0.f))))));
+            PBRE_UNROLL for (int k = 25; k < 31; k++) fin_o = fmaf(st[k], 0.f, fin_o);
+        }
         M3 Ro = quat_R(oq);
         // per-env object parameters (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral friction,
         // X[15] 1 + linear damping; 0 = the batch value.  The inertia of the (cube) object scales with its mass.
@@ -854,6 +867,7 @@ struct Fast {
         if (ROBOT) PBRE_UNROLL for (int j = 0; j < ND; j++) {
             const float v = clampf(wget(w, j), -vmax, vmax);
             qd[j] = v; q[j] = fmaf(dt, v, st[j]);
+            if (j == 0) q[j] += fin_r;
             st[j] = q[j]; st[16 + j] = v;
         }
         if (OBJECT && obj_on) {
@@ -861,7 +875,7 @@ struct Fast {
             oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
             ov = v3(clampf(ov.x, -vmax, vmax), clampf(ov.y, -vmax, vmax), clampf(ov.z, -vmax, vmax));
             ow = v3(clampf(ow.x, -vmax, vmax), clampf(ow.y, -vmax, vmax), clampf(ow.z, -vmax, vmax));
-            op = v3(fmaf(dt, ov.x, op.x), fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
+            op = v3(fmaf(dt, ov.x, op.x) + fin_o, fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
             float ang = norm(ow);
             if (ang * dt > 0.78539816339744831f) ang = 0.78539816339744831f * inv_dt;
             float sh, ch;
@@ -1160,6 +1174,15 @@ struct Fast {
             eul = quat_euler(R_quat(Ree));
         };
         kin();
+        // NaN / Inf guard: the new state's positions (a non-finite input left its mark there, see step_t; a velocity that diverged to
+        // Inf / NaN reaches them through the integration).  Such an env-step is counted (pbre_kernel_info[12]); its transition is
+        // returned as reward 0, done 1 and, with PBRE_F_AUTO_RESET, the env restarts from the settled snapshot in this same step --
+        // a single diverged env can neither poison a whole rollout silently nor stay dead.
+        float fin = 0.f;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) fin = fmaf(q[j], 0.f, fin);
+        if (!(flags & 1)) fin = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, fmaf(oq.w, 0.f, fin)))))));
+        const bool bad = !(fin == 0.f);
+        if (PBRE_ANY(bad)) { if (bad && P.bad_count) PBRE_COUNT_BAD(P.bad_count); }
         if (!want_obs) return cls;
         V3 tg = v3(st[32], st[33], st[34]);
         bool again = false;
@@ -1184,6 +1207,7 @@ struct Fast {
                 const float base = P.task == 1 ? -d1 - d2 : -d1;
                 reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
             }
+            if (bad) { reward = 0.f; done = 1.f; }
             st[35] = cnt; st[36] = term;
             st[46] = ((mode & M_INNER) && left) ? 1.f : 0.f;      // consumed by the remaining iterations of this env.step(), cleared by its last one
             again = (flags & 2) && !(mode & M_INNER) && done != 0.f;

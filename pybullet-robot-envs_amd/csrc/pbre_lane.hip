@@ -81,11 +81,18 @@ __global__ __launch_bounds__(LTPB, 1) void kw_dyn(const TablesT<Shape32>* __rest
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (env >= n) return;
     const float* st = state + (size_t)env * Shape32::STATE;
-    if (st[2 * Shape32::W + 14] != 0.f) return;          // left the apply_action loop: no simulation step
     constexpr int LC = Shape32::LC;
     float q[LaneD::ND], qd[LaneD::ND], tau[LaneD::ND];
     PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { q[j] = st[j]; qd[j] = st[Shape32::W + j]; }
     DynSink sink; sink.base = dyn + env; sink.cs = cs;
+    {   // NaN / Inf guard (Fast::step_t): 0 while the incoming state is finite, NaN otherwise; element 214 of quad lane 0, which kw_fin adds to
+        // a position of the new state (the clamps of the solve in between would turn a non-finite velocity into finite garbage)
+        float fin_in = 0.f;
+        PBRE_UNROLL for (int j = 0; j < LaneD::ND; j++) { fin_in = fmaf(q[j], 0.f, fin_in); fin_in = fmaf(qd[j], 0.f, fin_in); }
+        if (!(flags & 1)) { PBRE_UNROLL for (int k = 0; k < 7; k++) fin_in = fmaf(st[LC + k], 0.f, fin_in); PBRE_UNROLL for (int k = 0; k < 6; k++) fin_in = fmaf(st[Shape32::W + LC + k], 0.f, fin_in); }
+        sink.f(0, 214, fin_in);
+    }
+    if (st[2 * Shape32::W + 14] != 0.f) return;          // left the apply_action loop: no simulation step
     LaneD::RtC rt;
     LaneD::RoC ro;
     const bool rc = cls_cur[env] != 0 && !(flags & 1);   // complex class: a robot sphere within the contact margin of the object
@@ -457,6 +464,10 @@ __global__ __launch_bounds__(LTPB) void kw_fin(const TablesT<Shape32>* __restric
         oq.x = nq.x * in; oq.y = nq.y * in; oq.z = nq.z * in; oq.w = nq.w * in;
         st[LC] = op.x; st[LC + 1] = op.y; st[LC + 2] = op.z; st[LC + 3] = oq.x; st[LC + 4] = oq.y; st[LC + 5] = oq.z; st[LC + 6] = oq.w;
         PBRE_UNROLL for (int k = 0; k < 6; k++) st[W + LC + k] = o[k];
+    }
+    {   // NaN / Inf guard: what kw_dyn found in the incoming state
+        const float fin_in = dyn[(size_t)214 * cs + env];
+        if (!(fin_in == 0.f)) { q[0] += fin_in; st[0] = q[0]; }
     }
     const int c = LaneD::finish(*T, P, st, q, qd, op, oq, (MODE & LaneD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env);
     wpublish(env, c, cls, next_list, next_count);

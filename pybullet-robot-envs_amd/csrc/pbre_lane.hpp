@@ -34,6 +34,9 @@
 #ifndef PBRE_LANE_MSTRIDE      // floats between consecutive M^-1 entries of one env (device: 64 = [entry][lane]; host: 1)
 #define PBRE_LANE_MSTRIDE 1
 #endif
+#ifndef PBRE_COUNT_BAD       // ++*p from any number of lanes (device: atomicAdd)
+#define PBRE_COUNT_BAD(p) (++*(p))
+#endif
 #ifndef PBRE_OPAQUE_I          // device: the optimiser must assume the (per-lane) int changed (asm volatile("" : "+v"(x))); host: nothing
 #define PBRE_OPAQUE_I(x) do {} while (0)
 #endif
@@ -335,6 +338,10 @@ struct Lane {
         // (its lane runs along and stores nothing), only the evaluation of the state it is in
         const bool skip = st[XO + 14] != 0.f;
         const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
+        // NaN / Inf guard (see Fast::step_t): 0 while the incoming state is finite, NaN otherwise; added to one position of the new state
+        float fin_in = 0.f;
+        PBRE_UNROLL for (int j = 0; j < ND; j++) { fin_in = fmaf(q[j], 0.f, fin_in); fin_in = fmaf(qd[j], 0.f, fin_in); }
+        if (obj_on) { PBRE_UNROLL for (int k = 0; k < 7; k++) fin_in = fmaf(st[LC + k], 0.f, fin_in); PBRE_UNROLL for (int k = 0; k < 6; k++) fin_in = fmaf(st[W + LC + k], 0.f, fin_in); }
 
         // ---- kinematics + dynamics -> bias torques tau and the joint-space inertia M (into the M^-1 store)
         Mat Mi; Mi.lds = mi;
@@ -529,6 +536,7 @@ struct Lane {
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             const float v = clampf(w[j], -vmax, vmax);
             qd[j] = skip ? st[W + j] : v; q[j] = skip ? st[j] : fmaf(dt, v, st[j]);
+            if (j == 0) q[j] += fin_in;
             st[j] = q[j]; st[W + j] = qd[j];
         }
         V3 op = v3(st[LC], st[LC + 1], st[LC + 2]);
@@ -624,10 +632,19 @@ struct Lane {
         float* X = st + XO;
         V3 tg = v3(X[0], X[1], X[2]);
         V3 ee0 = v3(0.f, 0.f, 0.f), eul0 = ee0, vee0 = ee0, op0 = op, tg0 = tg; Q4 oq0 = oq; int cls0 = 0;
-        bool again = false;
+        bool again = false, bad = false;
         PBRE_NOUNROLL for (int pass = 0; pass < 2; pass++) {
             const Tail tl = sweep(T, P, q, want_obs ? qd : nullptr, op, oq, flags);
             cls = tl.cls;
+            if (pass == 0) {
+                // NaN / Inf guard (see Fast::finish): a non-finite position of the new state is counted, returned as reward 0 / done 1 and
+                // restarted with PBRE_F_AUTO_RESET
+                float fin = 0.f;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) fin = fmaf(q[j], 0.f, fin);
+                if (!(flags & 1)) fin = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, fmaf(oq.w, 0.f, fin)))))));
+                bad = !(fin == 0.f);
+                if (PBRE_ANY(bad)) { if (bad && P.bad_count) PBRE_COUNT_BAD(P.bad_count); }
+            }
             if (!want_obs) return cls;
             {
                 M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
@@ -675,6 +692,7 @@ struct Lane {
                     } else
                         reward = succ ? 1000.f + (100.f - dsucc * 80.f) : base;
                 }
+                if (bad) { reward = 0.f; done = 1.f; }
                 X[3] = cnt; X[4] = term;
                 X[14] = ((mode & M_INNER) && left) ? 1.f : 0.f;
                 again = (flags & 2) && !(mode & M_INNER) && done != 0.f;

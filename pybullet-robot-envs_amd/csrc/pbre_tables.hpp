@@ -107,6 +107,7 @@ struct Params {                  // float copies of pbre_physics + task constant
     int   ik_abs;                                   // IK actions are absolute hand poses (robot-level apply_action, icub_env.py:262-330) instead of scaled increments
     float cmd_vmax, cmd_kp;                         // robot-level apply_action(max_vel): maxVelocity of the commanded motors (0: none) and their
     int   cmd_nj;                                   // positionGain (0: the hold gain); cmd_nj > 0: only the first cmd_nj DoF are commanded (pandaEnv, panda_env.py:284-290)
+    int*  bad_count;                                // device counter of env-steps that met a non-finite state (NaN / Inf guard); may be null
 };
 
 namespace detail {

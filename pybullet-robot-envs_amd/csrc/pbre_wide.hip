@@ -101,7 +101,7 @@ void wide_destroy(WideEngine* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     w->free_tables();
     for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
-                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv})
+                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv, (void*)w->d_bad})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : w->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
@@ -152,6 +152,9 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     }
     CK(hipMalloc(&w->d_act, n * w->act_dim * sizeof(float)));
     CK(hipMalloc(&w->d_out, n * w->ow * sizeof(float)));
+    CK(hipMalloc(&w->d_bad, 2 * sizeof(int)));
+    CK(hipMemset(w->d_bad, 0, 2 * sizeof(int)));
+    w->P.bad_count = w->d_bad;
     CK(w->lane_alloc());
     CK(hipMalloc(&w->d_ids, n * sizeof(unsigned long long)));
     CK(hipMalloc(&w->d_ep, n * sizeof(unsigned)));
@@ -398,8 +401,10 @@ int wide_kernel_info(const WideEngine* w, int32_t* info, int32_t n) {
     const bool lane = w->lane_ok() && const_cast<WideEngine*>(w)->lane_info(&lv, &cn);
     // same slots as the Panda engine: [0] VGPRs of the lane-per-env kernel, [1] of the lane-group kernel, [2] lane-per-env path in use,
     // [3] envs in the simple class, [4] envs the lane-group kernel steps when the lane path is off, [5] complex envs
-    const int v[7] = {lane ? lv : -1, w->vgprs(), lane ? 1 : 0, lane ? w->n - cn : 0, lane ? 0 : w->n, lane ? cn : 0, -1};
-    for (int i = 0; i < n; i++) info[i] = i < 7 ? v[i] : 0;
+    int bad = 0;                      // [12] env-steps that met a non-finite state (NaN / Inf guard)
+    if (w->d_bad) { (void)hipSetDevice(w->device); (void)hipDeviceSynchronize(); (void)hipMemcpy(&bad, w->d_bad, sizeof(int), hipMemcpyDeviceToHost); }
+    const int v[13] = {lane ? lv : -1, w->vgprs(), lane ? 1 : 0, lane ? w->n - cn : 0, lane ? 0 : w->n, lane ? cn : 0, -1, 0, 0, 0, 0, 0, bad};
+    for (int i = 0; i < n; i++) info[i] = i < 13 ? v[i] : 0;
     return PBRE_OK;
 }
 

@@ -8,6 +8,7 @@
 #define PBRE_HD __device__ __forceinline__
 #define PBRE_UNROLL _Pragma("unroll")
 #define PBRE_OPAQUE(p) asm volatile("" : "+s"(p))
+#define PBRE_COUNT_BAD(p) atomicAdd((p), 1)
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
 #include "pbre_core.hpp"
@@ -139,6 +140,7 @@ struct WideEngine {
     unsigned char* d_mask = nullptr;
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
+    int* d_bad = nullptr;                     // NaN / Inf guard counter (Params::bad_count)
     float* objv = nullptr;                    // [n][W] side records of kw_obj, or nullptr: object rows always solved in kw_step
     const float* obj_done = nullptr;          // state buffer whose object solve rode along with the last kw_ik launch (consumed by the next step)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;

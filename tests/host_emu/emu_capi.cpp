@@ -37,6 +37,7 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     bool fast_ok = false;
     bool lane_ok = false;                // the iCub's lane-per-env path (pbre_lane.hpp; PBRE_ICUB_LANE=0 switches it off as on the device)
     long n_fast = 0, n_rc = 0, n_general = 0, n_pair = 0;
+    int n_bad = 0;                       // NaN / Inf guard counter (Params::bad_count points here)
     bool pair = getenv("PBRE_PAIR") && getenv("PBRE_PAIR")[0] == '1';
     bool obj_split = !(getenv("PBRE_OBJ_SPLIT") && getenv("PBRE_OBJ_SPLIT")[0] == '0');
     virtual ~pbre_ctx() {}
@@ -79,7 +80,19 @@ struct Emu : pbre_ctx {
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
                     n_rc++;
-                    CoreH::step(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg);
+                    // (as on the device: the object's half of the step by ObjStep, one lane per env -- the row kernel's fifth wave --, used by
+                    // Core::step for an env without robot-object contact)
+                    float objv[W] = {0};
+                    const bool obj_on = !(flags & 1);
+                    if (obj_on) {
+                        float pose[7], tw[6], o[6];
+                        for (int k = 0; k < 7; k++) pose[k] = st[S::LC + k];
+                        for (int k = 0; k < 6; k++) tw[k] = st[W + S::LC + k];
+                        const float o_m = st[44] > 0.f ? st[44] : P.obj_m, o_mu = st[45] > 0.f ? st[45] : P.obj_mu, o_kl = st[47] > 0.f ? st[47] - 1.f : P.kl;
+                        ObjStep::run_p(P, pose, tw, o, o_m, o_mu, o_kl);
+                        for (int k = 0; k < 6; k++) objv[S::LC + k] = o[k];
+                    }
+                    CoreH::step(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg, 0ull, obj_on ? objv : nullptr);
                     float q[NJ], qd[NJ];
                     for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
                     FastH::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
@@ -259,6 +272,7 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     std::string e = make_tables<S>(*cfg, c->T, c->P);
     if (!e.empty()) { g_err = e; delete c; return e.find("robot_table") == 0 ? PBRE_E_TABLE : (e.find("not implemented") != std::string::npos ? PBRE_E_UNSUPPORTED : PBRE_E_ARG); }
     c->cfg.robot_table = nullptr;
+    c->P.bad_count = &c->n_bad;
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg); c->sf = S::STATE; c->nj = S::NJ;
     c->state.assign((size_t)c->n * S::STATE, 0.f);
     c->tgt.assign((size_t)c->n * S::TGT, 0.f);
@@ -386,8 +400,8 @@ int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_
 int pbre_obs_limits(const pbre_ctx* c, float* lo, float* hi) { if (!c || !lo || !hi) return PBRE_E_ARG; const_cast<pbre_ctx*>(c)->limits(lo, hi); return PBRE_OK; }
 int pbre_timing(const pbre_ctx*, double* ms, int32_t n) { for (int i = 0; i < n; i++) ms[i] = 0; return PBRE_OK; }
 int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
-    const long v[11] = {0, 0, (c->fast_ok || c->lane_ok) ? 1 : 0, c->n_fast, c->n_general, c->n_rc, 0, 0, 0, 0, c->n_pair};      // ([10]: env-steps taken by the pair split, PBRE_PAIR=1)
-    for (int i = 0; i < n; i++) info[i] = i < 11 ? (int32_t)v[i] : 0;
+    const long v[13] = {0, 0, (c->fast_ok || c->lane_ok) ? 1 : 0, c->n_fast, c->n_general, c->n_rc, 0, 0, 0, 0, c->n_pair, 0, c->n_bad};      // ([10]: env-steps taken by the pair split, PBRE_PAIR=1; [12]: NaN / Inf guard)
+    for (int i = 0; i < n; i++) info[i] = i < 13 ? (int32_t)v[i] : 0;
     return PBRE_OK;
 }
 

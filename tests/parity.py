@@ -2042,3 +2042,86 @@ def check_pair_split_is_bit_identical(Engine, lib, table, panda, setenv, n=256, 
     ia, ib = a.kernel_info(), b.kernel_info()
     assert ia[10] > 0 and ib[10] == 0, (ia, ib)
     return ia, ib
+
+
+def check_nan_guard(Engine, lib, table, panda, n=64, flags_extra=0, use_ik=0):
+    """NaN / Inf guard (pbre_kernel_info[12]): non-finite entries injected into the state of a few envs -- a joint
+    angle, a joint velocity (Inf), the object's position, the object's angular velocity, and a joint velocity of an env with robot
+    contacts (the complex-env kernel's path) -- are counted, returned as reward 0 / done 1, and with PBRE_F_AUTO_RESET the envs restart
+    from the settled snapshot in the same step (finite state, next episode); every other env's row and state are bit for bit those of
+    an engine that never saw the NaNs.  Without auto-reset the env keeps its non-finite state and is counted again."""
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=lib, use_ik=use_ik)
+    ora = orc.Oracle(table, task=1)
+    ora.task.obj_pose_rnd_std, ora.task.tg_pose_rnd_std = 0.05, 0.2
+    base, _ = ora.batch_reset(1)
+    S = scenarios.table_contact_states(ora, panda["model"], panda["spheres"], base[0], 4, np.random.default_rng(1)).astype(np.float32)      # 4 envs with robot-table contacts
+    rep = {}
+    for auto in (True, False):
+        a = Engine(table, flags=(2 if auto else 0) | flags_extra, **kw)
+        b = Engine(table, flags=(2 if auto else 0) | flags_extra, **kw)
+        a.reset(); b.reset()
+        st = a.get_state()
+        st[:len(S), :S.shape[1]] = S
+        b.set_state(st)
+        bad = [1, 9, 17, 23, 40]
+        sa = st.copy()
+        sa[9, 2] = np.nan             # a joint angle
+        sa[17, 16 + 4] = np.inf       # a joint velocity
+        sa[23, 10] = np.nan           # the object's position
+        sa[40, 29] = -np.inf          # the object's angular velocity
+        sa[1, 16 + 1] = np.nan        # a joint velocity of a complex env (robot-table contact: the row kernel's path)
+        a.set_state(sa)
+        c0 = a.kernel_info()[12]
+        assert b.kernel_info()[12] == 0
+        rng = np.random.default_rng(5)
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        (oa, ra, da), (ob, rb, db) = a.step(act), b.step(act)
+        ok = np.ones(n, bool); ok[bad] = False
+        assert a.kernel_info()[12] - c0 == len(bad), (a.kernel_info()[12], c0)
+        assert np.all(da[bad] == 1) and np.all(ra[bad] == 0)
+        assert np.array_equal(oa[ok], ob[ok]) and np.array_equal(ra[ok], rb[ok]) and np.array_equal(da[ok], db[ok]), "a healthy env's row changed"
+        s1, s1b = a.get_state(), b.get_state()
+        assert np.array_equal(s1[ok], s1b[ok]), "a healthy env's state changed"
+        if auto:
+            assert np.isfinite(s1).all() and np.isfinite(oa).all(), "restarted envs must be finite"
+            assert np.all(s1[bad, 37] == st[bad, 37] + 1), "restarted envs are in their next episode"
+            assert np.all(s1[bad, 35] == 0)
+            a.step(act)
+            assert a.kernel_info()[12] - c0 == len(bad)         # no env is bad any more
+        else:
+            assert not np.isfinite(s1[bad]).all(axis=1).any(), "without auto-reset a non-finite env stays non-finite"
+            a.step(act)
+            assert a.kernel_info()[12] - c0 == 2 * len(bad)     # ... and is counted again
+        rep["auto_reset" if auto else "count_only"] = int(a.kernel_info()[12] - c0)
+        a.close(); b.close()
+    return rep
+
+
+def check_icub_nan_guard(Engine, lib, n=32, use_ik=0):
+    """NaN / Inf guard on the iCub engines (the lane-group kernel's Core::observe, or the pipeline's kw_dyn -> kw_fin / Lane::finish,
+    whichever PBRE_ICUB_LANE selects): non-finite joint angle / joint velocity / object position in three envs -- counted, reward 0,
+    done 1, restarted under PBRE_F_AUTO_RESET; the other envs bit for bit those of an engine that never saw them."""
+    mk = lambda: make_icub_pair(Engine, lib, n, 1, "l", use_ik, 0, obj_std=0.05, tg_std=0.2, flags=2)[0]
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    st = a.get_state()
+    nd, vo = a.ndof, a.v_off
+    bad = [1, n // 2, n - 2]
+    sa = st.copy()
+    sa[bad[0], 5] = np.nan; sa[bad[1], vo + 2] = np.inf; sa[bad[2], nd + 1] = np.nan
+    a.set_state(sa); b.set_state(st)
+    c0 = a.kernel_info()[12]
+    act = np.random.default_rng(5).uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+    (oa, ra, da), (ob, rb, db) = a.step(act), b.step(act)
+    ok = np.ones(n, bool); ok[bad] = False
+    assert a.kernel_info()[12] - c0 == len(bad), (a.kernel_info(), c0)
+    assert np.all(da[bad] == 1) and np.all(ra[bad] == 0)
+    assert np.array_equal(oa[ok], ob[ok]) and np.array_equal(ra[ok], rb[ok]) and np.array_equal(da[ok], db[ok])
+    s1 = a.get_state()
+    assert np.array_equal(s1[ok], b.get_state()[ok])
+    assert np.isfinite(s1).all() and np.isfinite(oa).all()
+    xo = a.x_off
+    assert np.all(s1[bad, xo + 5] == st[bad, xo + 5] + 1)
+    a.step(act)
+    assert a.kernel_info()[12] - c0 == len(bad)
+    a.close(); b.close()

@@ -128,3 +128,8 @@ def test_icub_crafted_contact_states_round_objects(emu_lib, monkeypatch, obj_nam
 def test_icub_push_closed_loop_against_oracle(emu_lib):
     rep = parity.check_icub_push_closed_loop(_capi.Engine, emu_lib, n=2)
     assert rep["touched_envs"] == 2
+
+
+def test_icub_nan_inf_guard(emu_lib):
+    """NaN / Inf guard through Lane::step / Lane::finish and (complex envs, masked paths) Core::step / Core::observe on the lane emulation"""
+    parity.check_icub_nan_guard(_capi.Engine, emu_lib, n=8)

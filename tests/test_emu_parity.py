@@ -320,3 +320,9 @@ def test_pair_split_of_the_simple_class_is_bit_identical(panda, emu_lib, monkeyp
     ia, ib = parity.check_pair_split_is_bit_identical(_capi.Engine, emu_lib, panda["table"], panda, monkeypatch.setenv, n=24, steps=30,
                                                       use_ik=use_ik, phys=phys)
     print("env-steps through the pair split:", ia[10])
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_FORCE_GENERAL])
+def test_nan_inf_guard(panda, emu_lib, flags):
+    """lane-per-env kernels (Fast::finish), the row kernel's complex envs, the general 16-lane kernel (Core::observe)"""
+    print(parity.check_nan_guard(_capi.Engine, emu_lib, panda["table"], panda, flags_extra=flags))

@@ -253,3 +253,11 @@ def test_two_identical_pipelines_stay_bit_identical(hip_lib, monkeypatch, use_ik
         seen = max(seen, a.kernel_info()[5])
     assert np.array_equal(a.get_state(), b.get_state()) and seen > 0
 
+
+
+@pytest.mark.parametrize("lane,use_ik", [("1", 0), ("1", 1), ("0", 0)])
+def test_icub_nan_inf_guard(hip_lib, monkeypatch, lane, use_ik):
+    """NaN / Inf guard on the iCub: the pipeline (kw_dyn records what the incoming state held, kw_fin / Lane::finish count, flag and restart)
+    and the lane-group kernel (Core::step / Core::observe)"""
+    monkeypatch.setenv("PBRE_ICUB_LANE", lane)
+    parity.check_icub_nan_guard(_capi.Engine, hip_lib, use_ik=use_ik)

@@ -591,3 +591,11 @@ def test_pair_kernel_is_the_default_of_small_batches(panda, hip_lib, monkeypatch
         info = eng.kernel_info()
         assert (info[10] > 0) == want, (n, info)
         eng.close()
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
+def test_nan_inf_guard(panda, hip_lib, flags):
+    """SURVEY section 5 (failure detection): NaN / Inf injected into the state of five envs -- counted (pbre_kernel_info[12]), returned
+    as reward 0 / done 1, restarted under PBRE_F_AUTO_RESET; every other env bit-unchanged.  flags: which kernels see them (k_fast /
+    k_fast_pair + k_row_list, k_fast_rc, the general 16-lane kernel)."""
+    print(parity.check_nan_guard(_capi.Engine, hip_lib, panda["table"], panda, flags_extra=flags))

@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 600 python tools/tail_probe.py --sizes 4096,16384,32768,65536,131072 --preroll 1100 --steps 600 2>&1 | grep "^{" | tee gpurun_out/r04j_shards.json | cut -c1-330
+PBRE_LIB=$(pwd)/pybullet-robot-envs_amd/csrc/libpbre_nocas.so timeout 600 python tools/tail_probe.py --sizes 4096,16384,32768,65536,131072 --preroll 1100 --steps 600 2>&1 | grep "^{" | sed "s/^{/{\"lib\": \"round-3 row kernel\", /" | tee -a gpurun_out/r04j_shards.json | cut -c1-330
