@@ -34,10 +34,13 @@
 #define PBRE_CONST_AS __attribute__((address_space(4)))
 #endif
 #ifdef PBRE_PHASE_PROBE      // tools/phase_probe.py: cycles per phase of lane 0 of block 0's waves, summed over the launches since the last reset of the counters
-__device__ unsigned long long g_probe[32];
+__device__ unsigned long long g_probe[64];
 #define PBRE_PROBE_DECL unsigned long long pb_t_ = __builtin_readcyclecounter();
 #define PBRE_PROBE(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
         if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_probe[k], t_ - pb_t_); pb_t_ = t_; } while (0)
+// (path k of a row wave: its count in slot 32 + k, the ticks of its sweeps in slot 48 + k)
+#define PBRE_PROBE_PATH(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { atomicAdd(&g_probe[32 + (k)], 1ull); atomicAdd(&g_probe[48 + (k)], t_ - pb_t_); } } while (0)
 #endif
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"
@@ -220,26 +223,34 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
                                                   signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
                                                   const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
-    static_assert(NB == 1 || MODE < 0, "the row kernel walks a single complex list (PBRE_NCLASS=2)");
+    static_assert(NB <= 2 || MODE < 0, "the row kernel walks one complex list (PBRE_NCLASS=2) or two (3: uncoupled / coupled)");
     __shared__ float objv[REPB][W];
     // These few waves are the tail of the step: each shares its SIMD with a k_fast wave, and a row wave is latency-bound (it leaves
     // most issue slots to its neighbour anyway), so it gets the higher wave priority and runs at its lone-wave speed.
     if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);
-    const int total = cur_count[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total, recent, host_total);
+    // Work items of REPB rows: bucket 0 (complex envs without robot-object contact) fills every row, four envs per wave; bucket 1 (the
+    // coupled ones, PBRE_NCLASS=3) gets ONE env per wave -- rows 1..3 of the wave idle on the pristine dummy record -- so that the long
+    // coupled sweep runs over that env's own row slots only and slows nobody else down.
+    const int total0 = cur_count[0], total1 = NB > 1 ? cur_count[NB > 1 ? 1 : 0] : 0;
+    const int items0 = (total0 + REPB - 1) / REPB, items1 = (total1 + REPB / 4 - 1) / (REPB / 4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total0 + total1, recent, host_total);
     const bool obj_on = !(flags & 1);
     const bool obj_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= REPB * W)) != 0;
     const int row = obj_wave ? (int)threadIdx.x - REPB * W : (int)(threadIdx.x >> 4);
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
-    for (int base = blockIdx.x * REPB; base < total; base += gridDim.x * REPB) {
-        const int i = base + row;
-        const bool real = i < total && row < REPB;
+    // (the coupled envs' items come first: theirs are the longest waves of the step)
+    for (int item = blockIdx.x; item < items0 + items1; item += gridDim.x) {
+        const bool coupled = item < items1;
+        const int* __restrict__ lst = coupled ? cur_list + cap : cur_list;
+        const int total = coupled ? total1 : total0;
+        const int i = coupled ? item * (REPB / 4) + (row >> 2) : (item - items1) * REPB + row;
+        const bool real = i < total && row < REPB && !(coupled && (row & 3) != 0);
         // Idle rows run in lockstep with the real ones and the wave pays for the rows of its heaviest group, so what they step must be the
         // cheapest state there is -- and stay it: they READ a pristine dummy record (the un-settled reset pose pbre_create wrote: arm at
         // home, object in the air, no contact, no joint at a limit) and WRITE their result to a scratch record EPB further on.  (Until
         // round 4 they stepped the dummy record in place, with env 0's actions, launch after launch and without ever being reset: a
         // random walk into joint limits and table contacts that made every partially filled wave carry the longest chain of the step.)
-        const int env = real ? cur_list[i] : dummy_base + (row < REPB ? row : 0);
+        const int env = real ? lst[i] : dummy_base + (row < REPB ? row : 0);
         float* st = state + (size_t)env * STATE;
         float* st_idle = real ? nullptr : st + (size_t)EPB * STATE;
         if (obj_wave) {
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
             }
             PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
         }
-        if (obj_on && base + gridDim.x * REPB < total) __syncthreads();          // the side records are rewritten by the next trip
+        if (obj_on && item + (int)gridDim.x < items0 + items1) __syncthreads();   // the side records are rewritten by the next trip
     }
 }
 
@@ -491,13 +502,14 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
         if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     }
     // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
-    bool rows = NB == 1 && hint <= c->row_max;
-    if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB == 1;
+    bool rows = NB <= 2 && hint <= c->row_max;
+    if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB <= 2;
     if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
-    if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB == 1;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
-    if constexpr (NB == 1) {
+    if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB <= 2;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
+    if constexpr (NB <= 2) {
         if (rows) {
-            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + 8));
+            // (the host knows the complex envs' total, not how many of them are coupled -- one env per wave: about a tenth, generously)
+            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
             hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
@@ -1031,7 +1043,7 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
 
 #ifdef PBRE_PHASE_PROBE
 int pbre_debug_probe(unsigned long long* out, int reset) {      // (probe builds only; not part of include/pbre.h)
-    unsigned long long z[32] = {0};
+    unsigned long long z[64] = {0};
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof z) != hipSuccess) return -1;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof z) != hipSuccess) return -1;
     return 0;

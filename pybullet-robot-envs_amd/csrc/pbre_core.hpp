@@ -46,6 +46,9 @@
 #define PBRE_PROBE(k)
 #define PBRE_PROBE_DECL
 #endif
+#ifndef PBRE_PROBE_PATH      // (probe builds: which solver path a wave took)
+#define PBRE_PROBE_PATH(k)
+#endif
 
 // No implicit FMA contraction in this file.  Core::step solves the same rows through different code paths chosen per WAVE (two zipped chains,
 // the plain loop, the object-table-only loop, ...), and which envs share a wave of the complex-env list depends on the order in which
@@ -984,7 +987,7 @@ struct Core {
 #define PBRE_ROBOT_ONLY_CHAIN 1
 #endif
         constexpr bool TWO_CHAIN = PBRE_TWO_CHAIN && SH::W == 16 && !SH::MREC;
-        bool solved2 = false;
+        bool solved2 = false, robot_only_path = false;
         if constexpr (TWO_CHAIN) {
         const bool ot_all = (on_bits & ((1u << NC_OT) - 1u)) == ((1u << NC_OT) - 1u);
         // (with `objv`: a wave none of whose groups has a robot-object contact has not built the object-table rows -- ot_all is false and it
@@ -1089,6 +1092,7 @@ struct Core {
             // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
             auto rt_f = [&]() { for_seq<2 * NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{}); }); };
             if (robot_only) {
+                robot_only_path = true;
                 auto motors = [&](auto rev_c) {
                     constexpr bool REV = decltype(rev_c)::value;
                     for_seq<4 * NJ>([&](auto kc) { constexpr int k = decltype(kc)::value; mstage(std::integral_constant<int, (REV ? NJ - 1 - k / 4 : k / 4)>{}, std::integral_constant<int, k % 4>{}); });
@@ -1160,6 +1164,7 @@ struct Core {
             contacts();
         }
 
+        PBRE_PROBE_PATH(solved ? 12 : (solved2 ? (robot_only_path ? 13 : 14) : 15));      // clamp-free / robot-only chain / two zipped chains / loops with per-slot tests
         PBRE_PROBE(9);      // the sweeps
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);

@@ -907,15 +907,20 @@ struct Fast {
     //   5 any other combination.
     // Classes 1..5 are all stepped by step_t<true>; they exist so that a wave of the compacted complex list is homogeneous
     // and the wave-uniform "any lane uses this row slot" tests skip the row slots nobody in the wave needs.
+    // NCLASS = 3 (default since round 4): class 1 = complex without, class 2 = complex WITH a robot collision sphere within the margin of
+    // the object.  The second kind (~5 % of the complex envs) solves the coupled system -- ~390 instead of ~150 instructions per sweep
+    // in the row kernel -- and a row wave pays for the rows of its heaviest group: listed apart they get waves of their own
+    // (k_row_list) instead of slowing three cheap wave-mates down, and their own wave sweeps only the row slots THEY use.
 #ifndef PBRE_NCLASS
-#define PBRE_NCLASS 2        // 2: all complex envs share one list (best at <= 131072 envs/GPU on MI355X: 308 vs 282 M env-steps/s
-#endif                       //    mid-episode); 6: one list per class above (pays off only when k_fast_rc is throughput-bound)
+#define PBRE_NCLASS 3        // 2: all complex envs share one list; 3: see above; 6: one list per class of the table above (pays off only when
+#endif                       //    k_fast_rc is throughput-bound)
     static constexpr int NCLASS = PBRE_NCLASS;
-    static_assert(NCLASS == 2 || NCLASS == 6, "supported class layouts");
+    static_assert(NCLASS == 2 || NCLASS == 3 || NCLASS == 6, "supported class layouts");
     struct Tail { int cls; M3 Re; V3 pe, Va, Vl; int nT; bool lim; };   // class + end-effector owner frame and spatial velocity (nT, lim: what the class was made of)
     static PBRE_HD int cls_of(int nO, int nT, bool lim) {
         if (nO == 0 && nT == 0) return lim ? 1 : 0;
         if (NCLASS == 2) return 1;
+        if (NCLASS == 3) return nO > 0 ? 2 : 1;
         if (!lim && nO == 0) return nT == 1 ? 2 : 3;
         if (!lim && nT == 0 && nO == 1) return 4;
         return 5;

@@ -9,6 +9,6 @@ rm -rf gpurun_out/prof_$TAG
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 s=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$s" ] && python tools/compact_stats.py $s gpurun_out/${TAG}_kernel_stats.csv && head -8 gpurun_out/${TAG}_kernel_stats.csv
-[ -n "$t" ] && python tools/trace_steps.py $t 40 | tail -9
+[ -n "$t" ] && python tools/trace_steps.py $t 250 | tail -6
 tail -1 gpurun_out/${TAG}_rocprof.log | cut -c1-200
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/prof_$TAG -name "*.db" -delete

@@ -7,7 +7,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ev = []
 for r in rows:
     k = r["Kernel_Name"]
-    name = "k_fast" if ("k_fast<7>" in k or "k_fast<7," in k) else ("k_row_list" if "k_row_list<7>" in k else ("k_fast_rc" if "k_fast_rc<7>" in k else None))
+    name = "k_fast" if ("k_fast<7>" in k or "k_fast<7," in k or "k_fast_pair<7>" in k) else ("k_row_list" if "k_row_list<7>" in k else ("k_fast_rc" if "k_fast_rc<7>" in k else None))
     if name:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 ev.sort()
@@ -27,3 +27,6 @@ for i in fast:
         dur["span"].append((max(e0, c[1]) - t0) / 1e3)
     print(line)
 print({k: round(sum(v) / len(v), 1) for k, v in dur.items()})
+for k, v in dur.items():      # distribution over the listed steps (us): min, quartiles, max
+    v = sorted(v)
+    print(k, "min %.1f  p25 %.1f  median %.1f  p75 %.1f  max %.1f  (n = %d)" % (v[0], v[len(v) // 4], v[len(v) // 2], v[3 * len(v) // 4], v[-1], len(v)))
