@@ -317,6 +317,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-weak", action="store_true", help="skip the extra 131072-envs-per-GPU measurement at N>1")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-inclusive pbre_step measurement (N=1 only)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the informative iCub / iCub-with-hands lines (N=1 only)")
+    ap.add_argument("--no-shards", action="store_true", help="skip the per-GPU shard sizes of the strong-scaling split measured on this one GPU (N=1 only)")
     return ap.parse_args(argv)
 
 
@@ -551,6 +552,34 @@ def main():
         except Exception as e:
             sync_clocks = {"error": repr(e)}
 
+    # extra at N=1: the per-GPU shards of BASELINE's strong-scaling split (131072 envs over 2 / 4 / 8 GPUs) measured on THIS GPU, fresh and
+    # stationary (the headline's protocol: de-synchronised clocks, pre-roll, auto-reset counted; 200 timed steps -- below the
+    # machine-filling batch a step's time depends on whether one of its few complex envs has a robot-object contact).  With the
+    # driver's own SCALE runs absent (no 8-GPU node) this is what the 1 -> 8 curve can be projected from: N GPUs step the batch in the
+    # time one GPU needs for its 131072 / N shard (+ the gather, which is overlapped).
+    shards = None
+    if world == 1 and not args.no_shards and total == TOTAL_ENVS:
+        shards = {}
+        try:
+            for n_sh in (65536, 32768, 16384):
+                js = Job(n_sh, 256)
+                fr = clean(js.timed(100, 5))
+                js.preroll(max(args.preroll, 1000))
+                c0 = js.eng.kernel_info()[7]
+                stt = clean(js.timed(200, 5))
+                inf = js.eng.kernel_info()
+                shards[str(n_sh)] = {"gpus_in_the_split": TOTAL_ENVS // n_sh, "fresh_ms_per_step": fr["ms_per_step"], "stationary_ms_per_step": stt["ms_per_step"],
+                                     "fresh_env_steps_per_s": fr["value"], "stationary_env_steps_per_s": stt["value"],
+                                     "complex_envs_per_step": ((inf[7] - c0) % (1 << 31)) / 205.0,
+                                     "simple_env_kernel": "k_fast_pair (robot wave + object wave per 64 envs)" if inf[10] > 0 else "k_fast"}
+                del js
+            one = head["ms_per_step"]
+            shards["projection"] = {"stationary_speedup_vs_one_gpu": {str(TOTAL_ENVS // int(k)): one / v["stationary_ms_per_step"] for k, v in shards.items() if k.isdigit()},
+                                    "fresh_speedup_vs_one_gpu": ({str(TOTAL_ENVS // int(k)): fresh["ms_per_step"] / v["fresh_ms_per_step"] for k, v in shards.items() if k.isdigit()} if fresh else None),
+                                    "note": "single-GPU measurements of the shard sizes, before the (overlapped) gather; not a multi-GPU run"}
+        except Exception as e:
+            shards["error"] = repr(e)
+
     # extra at N>1: weak scaling -- every GPU keeps the 131072-env shard (131072 x N envs in total), same gather
     weak = None
     if world > 1 and not args.no_weak:
@@ -609,7 +638,10 @@ def main():
                        "mean_episodes_completed_per_env_rank0": episodes},
             "repeats": repeats,
             "k_fast_variant": {"steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
-                               "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3)"},
+                               "steps_with_the_pair_kernel_since_reset": info[10], "vgprs_pair_kernel": info[11],
+                               "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3), and the pair kernel (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
+            "nan_inf_guard": {"bad_env_steps_since_create": info[12], "note": "env-steps whose state was not finite (pbre_kernel_info[12]); such envs are returned with done = 1 and restarted"},
+            "shards": shards,
             "fresh_reset": clean(fresh) if fresh else None,
             "steady_synchronised_clocks": sync_clocks,
             "weak_scaling_128k_per_gpu": weak,

@@ -461,7 +461,13 @@ static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_classify, dim3((n + FTPB - 1) / FTPB), dim3(FTPB), 0, s, c->dT, c->P, b.state, n, flags, b.cls + (size_t)b.cur * b.cap, b.list[b.cur], b.count + b.ccur * NB, b.cap);
     hipLaunchKernelGGL(k_total, dim3(1), dim3(1), 0, s, b.count + b.ccur * NB, b.h_total, b.count + 3 * NB);
-    return hipGetLastError();
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return le;
+    // The complex-env count k_total just wrote is what the next launch_step sizes its complex-env kernel by.  Every caller is a
+    // host-synchronous entry point off the hot path (reset, set_state, settle, set_physics), so wait for it: launched against the count
+    // of an EARLIER state, a batch that has just become entirely complex (IK control: the home hand pose's IK solution lies beyond
+    // joint 4's limit) was walked by an 8-block row kernel -- 11 ms per launch at 16384 envs, 19 s per reset at 131072.
+    return hipStreamSynchronize(s);
 }
 
 // one batched step of the first n envs of b on stream s
@@ -509,7 +515,10 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     if constexpr (NB <= 2) {
         if (rows) {
             // (the host knows the complex envs' total, not how many of them are coupled -- one env per wave: about a tenth, generously)
-            const int rblocks = std::max(8, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
+            // At least 64 blocks whatever the hint says: the hint is the count of a step the DEVICE has finished, and a host that runs ahead
+            // of it (the 201 launches of a reset are enqueued in ~1 ms) sizes every launch by a count that may be a hundred steps old --
+            // 16384 envs that had all become complex meanwhile were walked by 8 blocks, 11 ms per launch.  Blocks without work exit at once.
+            const int rblocks = std::max(64, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
             hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
@@ -568,6 +577,9 @@ static hipError_t settle_steps(pbre_ctx* c, EnvBuf& b, int n, int count, int fla
     for (int i = 0; i < count; i++) {
         hipError_t e = c->P.use_ik ? launch_step<MODE_SETTLE_IK>(c, b, n, nullptr, nullptr, flags, s) : launch_step<0>(c, b, n, nullptr, nullptr, flags, s);
         if (e != hipSuccess) return e;
+        // (a settle loop is host-synchronous anyway: every 16 launches let the device catch up, so that the complex-env count the next
+        // launches are sized and scheduled by is at most 16 steps old)
+        if ((i & 15) == 15 && (e = hipStreamSynchronize(s)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
