@@ -584,7 +584,9 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
         if (st[OV(m) + 15] > 0) pp.lin_damping = (double)st[OV(m) + 15] - 1;
     }
     const orc_params* prm = &pp;
-    const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : (m->ntip > 0 ? 4 : ORC_NC_RO);      /* robot-level Panda: both spheres of both fingers */
+    /* robot-object contact slots: the Panda (task envs: SURVEY a6 "<= 4 cube-robot points"; robot-level interface: both spheres of both
+     * fingers) keeps the 4 deepest, the 20-DoF iCub the 2 deepest (six stand-in spheres, three per arm), the iCub with hands 6 */
+    const int nc_ro = m->ndof > 32 ? ORC_NC_RO_HANDS : ((m->ntip > 0 || m->ndof <= 9) ? ORC_NC_RO_PANDA : ORC_NC_RO);
     const real dt = (real)prm->dt;
     real* q = st; real* qd = st + OV(m);
     real* op = st + OQ(m); real* oq = op + 3; real* ov = qd + nd; real* ow = ov + 3;

@@ -34,6 +34,7 @@ typedef double real;
 #define ORC_NC_OT 4      /* object-table contact slots */
 #define ORC_NC_RO 2      /* robot-object contact slots (6 for the iCub with hands: 5 fingertips + palm) */
 #define ORC_NC_RO_HANDS 6
+#define ORC_NC_RO_PANDA 4 /* the Panda (<= 9 DoF) */
 #define ORC_NC_RT 2      /* robot-table contact slots */
 #define ORC_NC (ORC_NC_OT + ORC_NC_RO_HANDS + ORC_NC_RT)
 #define ORC_NTIP 5       /* fingertips of the controlled hand (icub_env_with_hands.py:248) */

@@ -278,10 +278,21 @@ struct Fast {
     }
     struct Cand { float dist; int idx; V3 n, pA, pB; float mu; int owner; };
     static PBRE_HD bool better(const Cand& x, const Cand& y) { return x.dist < y.dist || (x.dist == y.dist && x.idx < y.idx); }
-    // keep the two best (smallest distance, ties -> lowest sphere index) candidates below the margin
+    // keep the N best (smallest distance, ties -> lowest sphere index) candidates below the margin, best first: an insertion into
+    // a sorted register array with compile-time indices (selects, no dynamic indexing)
+    // (two candidates, best and second best: the iCub's lane-per-env code, pbre_lane.hpp)
     static PBRE_HD void keep2(const Cand& c, float margin, Cand& a, Cand& b) {
         if (c.dist < margin) {
             if (better(c, a)) { b = a; a = c; } else if (better(c, b)) b = c;
+        }
+    }
+    template <int N>
+    static PBRE_HD void keepn(const Cand& c, float margin, Cand (&k)[N]) {
+        if (c.dist < margin) {
+            Cand cur = c;
+            PBRE_UNROLL for (int i = 0; i < N; i++) {
+                if (better(cur, k[i])) { const Cand t = k[i]; k[i] = cur; cur = t; }
+            }
         }
     }
 
@@ -373,7 +384,7 @@ struct Fast {
         static_assert(ROLE == 0 || !RC, "the pair kernel steps the simple class");
         constexpr bool ROBOT = ROLE != 2, OBJECT = ROLE != 1;
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
-        static_assert(NC_RO == 2 && NC_RT == 2, "keep2() selects two candidates per category");
+        constexpr int NKO = RC ? NC_RO : 1, NKT = RC ? NC_RT : 1;
         const bool obj_on = !(flags & 1);
         const float dt = P.dt, inv_dt = P.inv_dt;
         PBRE_PROBE_DECL
@@ -409,11 +420,10 @@ struct Fast {
         float tau[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) tau[j] = 0.f;
         float Cm[ND]; V3 Ch[ND]; float CI[ND][6];
-        Cand k1[2], k2[2];       // [0] robot-object, [1] robot-table: best and second best
-        PBRE_UNROLL for (int g = 0; g < 2; g++) {
-            k1[g].dist = k2[g].dist = 3e38f; k1[g].idx = k2[g].idx = 99; k1[g].mu = k2[g].mu = 0.f; k1[g].owner = k2[g].owner = 0;
-            k1[g].n = k2[g].n = k1[g].pA = k2[g].pA = k1[g].pB = k2[g].pB = v3(0.f, 0.f, 0.f);
-        }
+        Cand kO[NKO], kT[NKT];   // the NC_RO robot-object / NC_RT robot-table candidates closest to contact, best first
+        auto none = [&](Cand& k) { k.dist = 3e38f; k.idx = 99; k.mu = 0.f; k.owner = 0; k.n = k.pA = k.pB = v3(0.f, 0.f, 0.f); };
+        PBRE_UNROLL for (int i = 0; i < NKO; i++) none(kO[i]);
+        PBRE_UNROLL for (int i = 0; i < NKT; i++) none(kT[i]);
         if (ROBOT) {
             M3 R[ND]; V3 p[ND]; V3 Va[ND], Vl[ND], Aa[ND], Al[ND];
             const V3 oh = v3(P.obj_h[0], P.obj_h[1], P.obj_h[2]);
@@ -452,11 +462,11 @@ struct Fast {
                         if (obj_on) {
                             c.dist = sphere_box(sc, T.s_r[s], op, Ro, oh, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
                             c.mu = T.s_mu[s] * o_mu;
-                            keep2(c, P.margin, k1[0], k2[0]);
+                            keepn(c, P.margin, kO);
                         }
                         c.dist = sphere_box(sc, T.s_r[s], tc, Id, th, c.n, c.pB); c.pA = add(c.pB, scl(c.n, c.dist));
                         c.mu = T.s_mu[s] * P.tab_mu;
-                        keep2(c, P.margin, k1[1], k2[1]);
+                        keepn(c, P.margin, kT);
                     }
                 }
                 V3 Faj = v3(0.f, 0.f, 0.f), Flj = v3(0.f, 0.f, 0.f); Cm[j] = 0.f; Ch[j] = v3(0.f, 0.f, 0.f);
@@ -711,11 +721,22 @@ struct Fast {
         PBRE_UNROLL for (int c = 0; c < NR; c++) rc_act[c] = false;
         if (RC) {
             PBRE_UNROLL for (int c = 0; c < NR; c++) {
-                const int g = c < NC_RO ? 0 : 1, k = c < NC_RO ? c : c - NC_RO;
-                // slot order = sphere index order among the (at most two) selected candidates
-                const bool two = k2[g].dist < 3e38f;
-                const bool swap = two && k2[g].idx < k1[g].idx;
-                const Cand cc = (k == 0) ? (swap ? k2[g] : k1[g]) : (swap ? k1[g] : k2[g]);
+                // slot order = sphere index order among the selected candidates (Bullet walks its manifolds in creation order; the row
+                // kernel's select_k ranks them in lane order): slot k is the candidate with the k-th lowest sphere index
+                Cand cc; none(cc);
+                if (c < NC_RO) {
+                    PBRE_UNROLL for (int i = 0; i < NKO; i++) {
+                        int below = 0;
+                        PBRE_UNROLL for (int j = 0; j < NKO; j++) below += (j != i && kO[j].idx < kO[i].idx) ? 1 : 0;       // (free slots carry idx 99, distinct real ones differ)
+                        if (below == c && kO[i].dist < 3e38f) cc = kO[i];
+                    }
+                } else {
+                    PBRE_UNROLL for (int i = 0; i < NKT; i++) {
+                        int below = 0;
+                        PBRE_UNROLL for (int j = 0; j < NKT; j++) below += (j != i && kT[j].idx < kT[i].idx) ? 1 : 0;
+                        if (below == c - NC_RO && kT[i].dist < 3e38f) cc = kT[i];
+                    }
+                }
                 rc_act[c] = cc.dist < 3e38f;
                 rc_mu[c] = rc_act[c] ? cc.mu : 0.f;
                 const V3 n = cc.n;

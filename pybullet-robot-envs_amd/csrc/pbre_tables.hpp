@@ -39,7 +39,10 @@ struct ShapeT {
     static constexpr int TIP0 = NJ_ + 7;                   // Q lanes TIP0..TIP0+NTIP+1: tip forces, tips in contact, other robot-object contacts
     static_assert(NJ_ + 7 + (NTIP_ ? NTIP_ + 2 : 0) <= W_ && NJ_ <= 64, "lane budget");
 };
-using Shape16 = ShapeT<16, 9, 3, 4>;      // Panda (<= 9 DoF): one env per 16-lane DPP row, 4 envs per wave
+#ifndef PBRE_PANDA_NC_RO
+#define PBRE_PANDA_NC_RO 4                // robot-object contact slots of the Panda task envs ("<= 4 cube-robot points")
+#endif
+using Shape16 = ShapeT<16, 9, 3, 4, PBRE_PANDA_NC_RO>;      // Panda (<= 9 DoF): one env per 16-lane DPP row, 4 envs per wave
 using Shape32 = ShapeT<32, 20, 2, 4>;     // iCub as simulated (legs pruned, 20 DoF): one env per half-wave, 2 envs per wave
 using Shape64 = ShapeT<64, 32, 2, 4>;     // <= 32 DoF: one env per wave
 using Shape128 = ShapeT<128, 60, 2, 4, 6, 5>;   // iCub with hands (legs pruned, 60 DoF): one env per wave, two virtual lanes per physical lane
@@ -51,7 +54,7 @@ using ShapeIA = ShapeT<32, 20, 2, 4, 2, 0, true>;   // iCub without hands, robot
 
 // the Panda shape's constants at namespace scope (lane-per-env kernels, C-ABI of the 48-float record)
 constexpr int W = Shape16::W, NJ = Shape16::NJ, LC = Shape16::LC, L1 = Shape16::L1, NSUB = Shape16::NSUB, NLEV = Shape16::NLEV;
-constexpr int NC_OT = 4, NC_RO = 2, NC_RT = 2, NC = NC_OT + NC_RO + NC_RT;
+constexpr int NC_OT = Shape16::NC_OT, NC_RO = Shape16::NC_RO, NC_RT = Shape16::NC_RT, NC = NC_OT + NC_RO + NC_RT;
 constexpr int STATE = Shape16::STATE;
 constexpr int MAXJ = 64;     // DoF bound of any shape
 

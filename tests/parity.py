@@ -2125,3 +2125,26 @@ def check_icub_nan_guard(Engine, lib, n=32, use_ik=0):
     a.step(act)
     assert a.kernel_info()[12] - c0 == len(bad)
     a.close(); b.close()
+
+
+def check_four_robot_object_slots(Engine, lib, table, panda, flags=0, n=24, seed=31):
+    """SURVEY a6 ("<= 4 cube-robot points"): the cube pinched between the fingers -- both spheres of both fingers on it, in a quarter of the
+    states the palm sphere as a fifth candidate -- one step against the oracle with the same four slots, per quantity at TOL_CONTACT.
+    Every state has >= 3 robot-object contacts in the oracle (the round-3 engine kept two)."""
+    ora = orc.Oracle(table, task=1)
+    ora.task.obj_pose_rnd_std, ora.task.tg_pose_rnd_std = 0.05, 0.2
+    base, _ = ora.batch_reset(1)
+    rng = np.random.default_rng(seed)
+    S = scenarios.multi_sphere_object_states(ora, panda["model"], panda["spheres"], base[0], n, rng, want=3)
+    assert len(S) == n
+    counts = []
+    for s in S:
+        _, info = ora.sim_step(s, s[:9].copy(), np.full(9, 0.1), np.full(9, 1.0))
+        counts.append(sum(1 for c in range(info.ncontacts) if info.type[c] == 1))
+    assert min(counts) >= 3 and max(counts) == 4, counts
+    eng, ora = make_pair(Engine, lib, table, len(S), flags=flags)
+    ora32 = orc.Oracle(table, f32=True, task=1)
+    ora32.task.obj_pose_rnd_std, ora32.task.tg_pose_rnd_std = 0.05, 0.2
+    rep = check_single_steps(eng, ora, S, rng, steps=1, tol=TOL_CONTACT, skip_ambiguous=True, max_skip=0.3, ora32=ora32)
+    rep["robot_object_contacts_per_state"] = counts
+    return rep

@@ -326,3 +326,10 @@ def test_pair_split_of_the_simple_class_is_bit_identical(panda, emu_lib, monkeyp
 def test_nan_inf_guard(panda, emu_lib, flags):
     """lane-per-env kernels (Fast::finish), the row kernel's complex envs, the general 16-lane kernel (Core::observe)"""
     print(parity.check_nan_guard(_capi.Engine, emu_lib, panda["table"], panda, flags_extra=flags))
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_FORCE_GENERAL])
+def test_four_robot_object_contact_slots(panda, emu_lib, flags):
+    """the lane-per-env complex kernel's path (Fast::step_t<true>), the row kernel's (Core::step + Fast::finish) and the general kernel"""
+    rep = parity.check_four_robot_object_slots(_capi.Engine, emu_lib, panda["table"], panda, flags=flags)
+    print({k: v for k, v in rep.items() if k != "robot_object_contacts_per_state"})

@@ -599,3 +599,11 @@ def test_nan_inf_guard(panda, hip_lib, flags):
     as reward 0 / done 1, restarted under PBRE_F_AUTO_RESET; every other env bit-unchanged.  flags: which kernels see them (k_fast /
     k_fast_pair + k_row_list, k_fast_rc, the general 16-lane kernel)."""
     print(parity.check_nan_guard(_capi.Engine, hip_lib, panda["table"], panda, flags_extra=flags))
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
+def test_four_robot_object_contact_slots(panda, hip_lib, flags):
+    """four robot-object slots -- the cube pinched between the fingers (both spheres of both fingers, sometimes the palm as a fifth
+    candidate), one step against the four-slot oracle; k_row_list, k_fast_rc and the general kernel"""
+    rep = parity.check_four_robot_object_slots(_capi.Engine, hip_lib, panda["table"], panda, flags=flags)
+    print({k: v for k, v in rep.items() if k != "robot_object_contacts_per_state"})
