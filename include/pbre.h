@@ -240,7 +240,12 @@ int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
  * env's state record (X[12] mass, X[13] lateral friction, X[15] 1 + linear damping; 0 = the batch value of pbre_physics), survive
  * resets and travel with pbre_get_state / pbre_set_state; the (cube) object's inertia scales with its mass.  robot_lin_damping: the
  * robot links' linear damping (`robot_damping`, :366-367: p.changeDynamics(robot_id, i, linearDamping=...)), per env as well, in
- * V[15] (1 + damping; 0 = the batch value pbre_physics.lin_damping).  Panda task envs only. */
+ * V[15] (1 + damping; 0 = the batch value pbre_physics.lin_damping).  Panda task envs only.
+ * Restarts from the settled snapshot (pbre_reset_snapshot, PBRE_F_AUTO_RESET) place every env at env 0's settled robot pose and object
+ * height: per-env values do not move where the object rests, and the hold motors bring the arm to the same pose whatever its links'
+ * velocity damping, so the approximation (< 5e-5 against an explicit reset with uniform values) carries over to heterogeneous damping
+ * only approximately -- an env whose robot damping differs from env 0's by a factor settles a few 1e-4 rad elsewhere within the 201
+ * settle steps; callers that randomise robot damping and need the exact settled pose use pbre_reset(mask). */
 int pbre_set_physics_per_env(pbre_ctx* ctx, const uint8_t* env_mask, const float* obj_mass, const float* obj_mu,
                              const float* obj_lin_damping, const float* robot_lin_damping);
 

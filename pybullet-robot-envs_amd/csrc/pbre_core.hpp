@@ -26,6 +26,10 @@
 #include <type_traits>
 #include <utility>
 #include "pbre_tables.hpp"
+#ifndef PBRE_HD
+#define PBRE_HD
+#endif
+#include "pbre_math.hpp"
 
 #ifndef PBRE_HD
 #define PBRE_HD
@@ -56,6 +60,7 @@
 // here but not there they differed in the last bit, and a complex env's result depended on its wave-mates (found by running two
 // identical engines side by side: tools/diag_fast3.py).  Every fused operation in this file is an explicit L::fma.
 #if defined(__clang__)
+#pragma float_control(push)
 #pragma clang fp contract(off)
 #endif
 namespace pbre {
@@ -1533,7 +1538,7 @@ struct Core {
             yaw = -0.78539816339744831f + 1.57079632679489662f * u01(r[2]);
         }
         ob[0] = clamps(px, x_min, x_max); ob[1] = clamps(py, y_min, y_max); ob[2] = pz;
-        ob[3] = 0.f; ob[4] = 0.f; ob[5] = sinf(0.5f * yaw); ob[6] = cosf(0.5f * yaw);
+        ob[3] = 0.f; ob[4] = 0.f; sincos_f(0.5f * yaw, ob[5], ob[6]);      // (pbre_math.hpp: the same values as Fast::finish's in-kernel restart)
         X[5] = (float)(int)episode;       // 0xFFFFFFFF marks a record that was never reset (episode -1)
         if (P.use_ik) for (int k = 0; k < 6; k++) X[6 + k] = P.home_hand[k];
     }
@@ -1549,8 +1554,10 @@ struct Core {
             philox((unsigned)env_id, (unsigned)(env_id >> 32), episode, 1u, P.seed_lo, P.seed_hi, r);
             const float u1 = (float)((r[0] >> 8) + 1u) * (1.0f / 16777216.0f), u2 = u01(r[1]);
             const float rad = sqrtf(-2.f * logf(u1)) * P.tg_std;
-            tx = ob[0] + rad * cosf(6.28318530717958648f * u2);
-            ty = ob[1] + rad * sinf(6.28318530717958648f * u2);
+            float su, cu;
+            sincos_f(6.28318530717958648f * u2, su, cu);          // (as Fast::finish: every restart path samples identical values)
+            tx = ob[0] + rad * cu;
+            ty = ob[1] + rad * su;
         }
         X[0] = clamps(tx, tx_min, tx_max); X[1] = clamps(ty, P.ws[1][0], P.ws[1][1]); X[2] = ob[2];
         X[3] = 0.f; X[4] = 0.f;
@@ -1567,5 +1574,5 @@ struct Core {
 
 }  // namespace pbre
 #if defined(__clang__)
-#pragma clang fp contract(fast)
+#pragma float_control(pop)      // back to whatever the including translation unit compiles with (hipcc: fast; clang++ -ffp-contract=off stays off)
 #endif

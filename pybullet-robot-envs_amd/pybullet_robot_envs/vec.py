@@ -18,7 +18,8 @@ import numpy as np
 class BatchedVecEnv(object):
     def __init__(self, env, snapshot_reset=True):
         self.env = env
-        self._snapshot_reset = bool(snapshot_reset)
+        self._snapshot_reset = None if snapshot_reset else False     # None: look the `snapshot` keyword of env.reset up on first use
+        self._warned_explicit = False
         self.num_envs = int(env.num_envs)
         self.observation_space = env.observation_space
         self.action_space = env.action_space
@@ -69,14 +70,29 @@ class BatchedVecEnv(object):
         return obs, rew, done, infos
 
     def _masked_reset(self, mask):
+        """Restart the finished envs: one small kernel from the settled snapshot (pbre_reset_snapshot) when the wrapped env's reset() takes
+        `snapshot=` and the engine holds a valid snapshot, else the explicit masked reset (201 settle launches on a compacted copy --
+        ~200x the cost, hence the one-time warning).  Whether reset() has the keyword is looked up once (inspect.signature), not
+        guessed from a TypeError -- a genuine TypeError inside reset() is not swallowed."""
+        if self._snapshot_reset is None:
+            import inspect
+            try:
+                self._snapshot_reset = "snapshot" in inspect.signature(self.env.reset).parameters
+            except (TypeError, ValueError):
+                self._snapshot_reset = False
         if self._snapshot_reset:
             try:
                 return self.env.reset(mask=mask, snapshot=True)
-            except TypeError:                     # a wrapped env whose reset() has no `snapshot` keyword
-                self._snapshot_reset = False
-            except RuntimeError as e:             # the engine has no valid settled snapshot (PBRE_E_ARG): explicit reset this time
+            except RuntimeError as e:
+                # PBRE_E_ARG from pbre_reset_snapshot: no settled snapshot (yet, or a pbre_set_physics change made it stale) -> explicit
+                # reset this time; the next full reset() records a new snapshot
                 if "snapshot" not in str(e):
                     raise
+                if not self._warned_explicit:
+                    import warnings
+                    warnings.warn("BatchedVecEnv: no valid settled snapshot (%s); finished envs are restarted by the explicit masked reset "
+                                  "(201 settle launches) until the next full reset() records one" % e, RuntimeWarning)
+                    self._warned_explicit = True
         return self.env.reset(mask=mask)
 
     def step(self, actions):

@@ -1709,10 +1709,18 @@ def check_panda_push_closed_loop(Engine, lib, table, n=8, seed=5):
     le, lo_ = np.linalg.norm(de[:, :2], axis=1), np.linalg.norm(do[:, :2], axis=1)
     rep = {"touched_envs": int((lo_ > 1e-3).sum()), "disp_engine_cm": np.round(100 * le, 2).tolist(), "disp_oracle_cm": np.round(100 * lo_, 2).tolist(),
            "worst_disp_diff_cm": float(100 * np.linalg.norm(de - do, axis=1).max()), "arm_q_diff": float(np.abs(se[:, :7] - st[:, :7]).max())}
-    if not MEASURE:
-        assert rep["touched_envs"] == n and (le > 0.03).all() and (lo_ > 0.03).all(), rep
-        assert (np.linalg.norm(de - do, axis=1) <= 0.015 + 0.25 * lo_).all(), rep
-        assert rep["arm_q_diff"] < 1.5e-2, rep
+    dd = np.linalg.norm(de - do, axis=1)
+    rep["median_disp_diff_mm"] = float(1e3 * np.median(dd))
+    rep["envs_within_1mm"] = int((dd < 1e-3).sum())
+    if MEASURE:
+        print("MEASURED (closed-loop push):", rep)
+    assert rep["touched_envs"] == n and (le > 0.03).all() and (lo_ > 0.03).all(), rep
+    # every env: the loose stick-slip bound (an env whose first touch falls one step apart in fp32 and fp64 integrates that difference) ...
+    assert (dd <= 0.015 + 0.25 * lo_).all(), rep
+    assert rep["arm_q_diff"] < 1.5e-2, rep
+    # ... and (round-3 advice) the MAJORITY tightly: the median env ends within 1 mm of the oracle's cube, which a 10 % error in the
+    # friction or contact rows -- 1 to 3 cm on these pushes -- could not pass
+    assert rep["median_disp_diff_mm"] < 1.0 and rep["envs_within_1mm"] >= (n + 1) // 2, rep
     return rep
 
 
@@ -1762,9 +1770,10 @@ def check_icub_push_closed_loop(Engine, lib, n=8, steps=330, seed=6):
     le, lo_ = np.linalg.norm(de[:, :2], axis=1), np.linalg.norm(do[:, :2], axis=1)
     rep = {"touched_envs": int((lo_ > 1e-3).sum()), "disp_engine_cm": np.round(100 * le, 2).tolist(), "disp_oracle_cm": np.round(100 * lo_, 2).tolist(),
            "worst_disp_diff_cm": float(100 * np.linalg.norm(de - do, axis=1).max()), "arm_q_diff": float(np.abs(se[:, :nd] - st[:, :nd]).max())}
-    if not MEASURE:
-        assert rep["touched_envs"] == n and (le > 0.02).all() and (lo_ > 0.02).all(), rep
-        assert (np.linalg.norm(de - do, axis=1) <= 0.003 + 0.05 * lo_).all(), rep
+    if MEASURE:
+        print("MEASURED (iCub closed-loop push):", rep)
+    assert rep["touched_envs"] == n and (le > 0.02).all() and (lo_ > 0.02).all(), rep
+    assert (np.linalg.norm(de - do, axis=1) <= 0.003 + 0.05 * lo_).all(), rep
     return rep
 
 
