@@ -351,7 +351,7 @@ def main():
     import torch.distributed as dist
     from pybullet_robot_envs import _capi
     from pybullet_robot_envs.model.table import panda_table
-    from pybullet_robot_envs.sharding import ShardedEngine, GatherPipeline
+    from pybullet_robot_envs.sharding import ShardedEngine, GatherPipeline, CtxGatherPipeline
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -426,8 +426,23 @@ def main():
             self.gen.manual_seed(1234 + rank)
             self.pool = torch.rand((pool_steps, n, eng.act_dim), device=dev, generator=self.gen) * 2 - 1
             self.fresh = torch.empty((n, eng.act_dim), device=dev)
-            # the data path (sharding.GatherPipeline): step kernels + one async, double-buffered gather per step
-            self.pipe = GatherPipeline(self.sh, dev, gather=True, host_staged=(backend != "nccl"))
+            # the data path: step kernels + one asynchronous, double-buffered gather per step.  With several GPUs the gather is the
+            # context's own (include/pbre.h: pbre_comm_init / pbre_step_gather_device -- ncclSend / ncclRecv into rank 0 enqueued from C on
+            # the ctx's communication stream; sharding.CtxGatherPipeline); should its communicator not come up on EVERY rank, all ranks
+            # fall back to torch.distributed's gather (sharding.GatherPipeline).  PBRE_BENCH_CTX_COMM=0 pins the fallback.
+            self.pipe, self.comm_kind, self.comm_note = None, "torch.distributed.gather", None
+            if world > 1 and backend == "nccl" and os.environ.get("PBRE_BENCH_CTX_COMM", "1") == "1":
+                ok, pipe = 1.0, None
+                try:
+                    pipe = CtxGatherPipeline(self.sh, dev)
+                except Exception as e:
+                    ok, self.comm_note = 0.0, repr(e)
+                if min(max_over_ranks([-ok])) > -1.0 + 1e-9:      # (max of -ok = -min of ok) some rank failed
+                    pipe = None
+                if pipe is not None:
+                    self.pipe, self.comm_kind = pipe, "context-owned RCCL communicator (pbre_step_gather_device)"
+            if self.pipe is None:
+                self.pipe = GatherPipeline(self.sh, dev, gather=True, host_staged=(backend != "nccl"))
             self.steps_done = 0
 
         @property
@@ -503,6 +518,8 @@ def main():
     steps_before = job.steps_done - args.steps
     complex_after = job.complex_frac()
     finite = bool(torch.isfinite(job.pipe.out[0]).all() and torch.isfinite(job.pipe.out[1]).all())
+    comm_kind, comm_note = job.comm_kind, job.comm_note
+    comm_info = job.pipe.info() if hasattr(job.pipe, "info") else None
     done_frac = float(job.pipe.out[(job.pipe.k - 1) & 1][:, -1].mean())
     kern_ms = float(eng.timing()[3])      # k_fast alone: mean of the HIP event pairs the library records around it on its stream
     info = eng.kernel_info()
@@ -614,7 +631,8 @@ def main():
         rccl = None
         if world > 1:
             try:
-                rccl = {"backend": backend, "ranks_seen": dist.get_world_size(), "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+                rccl = {"backend": backend, "ranks_seen": (comm_info or {}).get("ranks_seen", dist.get_world_size()), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                        "gather": comm_kind, "context_communicator": comm_info, "note": comm_note}
             except Exception as e:
                 rccl = {"backend": backend, "ranks_seen": dist.get_world_size(), "version": repr(e)}
         res = {

@@ -268,6 +268,34 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
  * env keeps its NaN state (and is counted again every step) until the caller resets it.  The reference has no such guard. */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
+/* ---- The sharded batch's per-step gather, owned by the context (no counterpart in the reference: it is one env per physics client
+ * and process, R/envs/panda_envs/panda_push_gym_env.py:56-62; BASELINE north_star: "shards the env batch across the 8 GPUs of one node
+ * with a single RCCL gather over xGMI per step to return stacked observations / rewards"; SURVEY 8(b): "one RCCL communicator per
+ * ctx", 8(e): "gather-to-root emulated with ncclGroupStart + ncclSend / ncclRecv").  One process per GPU; the ctx of rank r was created
+ * with num_envs = N / G and env_id_base = r N / G.  RCCL is loaded with dlopen on first use (PBRE_RCCL_LIB, else librccl.so.1 /
+ * librccl.so): libpbre.so does not link against it.
+ *   pbre_comm_unique_id   rank 0: the 128-byte ncclUniqueId every rank's pbre_comm_init needs (hand it over by any out-of-band channel);
+ *   pbre_comm_init        collective over the G ranks: this ctx's communicator (ncclCommInitRank on the ctx's device) and its
+ *                         communication stream; released by pbre_destroy;
+ *   pbre_step_gather_device  = pbre_step_device(d_actions -> d_rows_local) on `stream`, then -- on the communication stream, ordered
+ *                         behind the step by an event -- ONE grouped exchange: every rank sends its [num_envs, obs_dim + 2] rows to
+ *                         rank 0, which receives them into d_rows_all [G * num_envs, obs_dim + 2] (rank order; its own rows by a
+ *                         device copy; d_rows_all is ignored on the other ranks).  Asynchronous.  The caller alternates between TWO
+ *                         (d_rows_local, d_rows_all) buffer pairs: the exchange of step k overlaps the kernels of step k + 1, and a
+ *                         buffer is stepped into again only after the exchange that read it (the stream waits for that event);
+ *   pbre_gather_wait      makes `stream` (and, host_too != 0, the host) wait for every exchange enqueued so far: then rank 0 may
+ *                         read d_rows_all;
+ *   pbre_comm_info        [0] ranks in the communicator (ncclCommCount), [1] this rank, [2] RCCL version code, [3] exchanges enqueued;
+ *   pbre_comm_last_error  message of the last failed call above (borrowed pointer).
+ * PBRE_COMM_SELF_P2P=1 (read at pbre_comm_init): rank 0's own rows travel through ncclSend / ncclRecv too (single-GPU tests execute
+ * the RCCL point-to-point path that way). */
+int pbre_comm_unique_id(void* id128);
+int pbre_comm_init(pbre_ctx* ctx, const void* id128, int32_t rank, int32_t world);
+int pbre_step_gather_device(pbre_ctx* ctx, const float* d_actions, float* d_rows_local, float* d_rows_all, void* stream);
+int pbre_gather_wait(pbre_ctx* ctx, void* stream, int32_t host_too);
+int pbre_comm_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
+const char* pbre_comm_last_error(const pbre_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

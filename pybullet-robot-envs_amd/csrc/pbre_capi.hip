@@ -609,8 +609,11 @@ extern "C" {
 
 int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return default_config(cfg, robot, task); }
 
+__attribute__((visibility("hidden"))) void pbre_comm_release(const pbre_ctx* c);      // pbre_comm.hip: the ctx's RCCL communicator, if any
+
 void pbre_destroy(pbre_ctx* c) {
     if (!c) return;
+    pbre_comm_release(c);
     if (c->wide) { wide_destroy(c->wide); delete c; return; }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);

@@ -75,8 +75,11 @@ def load(path=None):
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
-                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot"):
+                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot",
+                 "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info"):
         getattr(lib, name).restype = C.c_int
+    lib.pbre_comm_last_error.restype = C.c_char_p
+    lib.pbre_comm_last_error.argtypes = [C.c_void_p]
     lib.pbre_host_alloc.restype = C.c_void_p
     lib.pbre_host_alloc.argtypes = [C.c_size_t]
     lib.pbre_host_free.restype = None
@@ -84,6 +87,21 @@ def load(path=None):
     if path is None:
         _LIB = lib
     return lib
+
+
+def _set_rccl_lib(path=None):
+    """PBRE_RCCL_LIB for csrc/pbre_comm.hip's dlopen: an explicit path, else (unless already set) the librccl.so torch bundles -- the
+    copy torch.distributed's "nccl" backend has loaded or will load -- so that one process never holds two RCCLs."""
+    if path:
+        os.environ["PBRE_RCCL_LIB"] = path
+    elif not os.environ.get("PBRE_RCCL_LIB"):
+        try:
+            import torch
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(cand):
+                os.environ["PBRE_RCCL_LIB"] = cand
+        except Exception:
+            pass
 
 
 def _fp(a):
@@ -230,6 +248,44 @@ class Engine:
         None = the engine's own non-blocking stream (NOT ordered against torch streams: the caller orders inputs / outputs)."""
         self._chk(self.lib.pbre_step_device(self._ctx, C.c_void_p(d_actions_ptr), C.c_void_p(d_out_ptr),
                                             C.c_void_p(stream or 0)))
+
+    # ---- the sharded batch's gather, owned by the context (include/pbre.h: pbre_comm_*; csrc/pbre_comm.hip) ----
+    @staticmethod
+    def comm_unique_id(lib=None, rccl_lib=None):
+        """rank 0: the 128-byte id every rank's comm_init needs.  rccl_lib: path of the RCCL library to dlopen (default: torch's bundled
+        copy when torch is importable, so that a process which also uses torch.distributed holds ONE RCCL)."""
+        _set_rccl_lib(rccl_lib)
+        lib = lib or load()
+        buf = (C.c_ubyte * 128)()
+        rc = lib.pbre_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("pbre_comm_unique_id failed (%d): %s" % (rc, lib.pbre_comm_last_error(None).decode()))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world, rccl_lib=None):
+        _set_rccl_lib(rccl_lib)
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        rc = self.lib.pbre_comm_init(self._ctx, buf, C.c_int32(rank), C.c_int32(world))
+        if rc != 0:
+            raise RuntimeError("pbre_comm_init failed (%d): %s" % (rc, self.lib.pbre_comm_last_error(None).decode()))
+
+    def comm_info(self):
+        info = (C.c_int32 * 4)()
+        self._chk_comm(self.lib.pbre_comm_info(self._ctx, info, C.c_int32(4)))
+        return {"ranks_seen": info[0], "rank": info[1], "rccl_version_code": info[2], "exchanges": info[3]}
+
+    def step_gather_device(self, d_actions_ptr, d_rows_local_ptr, d_rows_all_ptr, stream=None):
+        """pbre_step_device + the one grouped RCCL exchange of the step's rows into rank 0's stacked buffer, all enqueued from C
+        (asynchronous; alternate between two buffer pairs, gather_wait before reading)."""
+        self._chk_comm(self.lib.pbre_step_gather_device(self._ctx, C.c_void_p(d_actions_ptr), C.c_void_p(d_rows_local_ptr),
+                                                        C.c_void_p(d_rows_all_ptr or 0), C.c_void_p(stream or 0)))
+
+    def gather_wait(self, stream=None, host=False):
+        self._chk_comm(self.lib.pbre_gather_wait(self._ctx, C.c_void_p(stream or 0), C.c_int32(1 if host else 0)))
+
+    def _chk_comm(self, rc):
+        if rc != 0:
+            raise RuntimeError("libpbre communicator error %d: %s" % (rc, self.lib.pbre_comm_last_error(self._ctx).decode()))
 
     def sync(self):
         self._chk(self.lib.pbre_sync(self._ctx))

@@ -135,3 +135,53 @@ class GatherPipeline(object):
         if not self.sh.distributed or not self.gather:
             return self.out[b]
         return self.torch.cat(self.gathered[b], 0) if self.sh.rank == 0 else None
+
+
+class CtxGatherPipeline(object):
+    """GatherPipeline's loop with the gather owned by the engine's context (include/pbre.h: pbre_comm_init / pbre_step_gather_device;
+    csrc/pbre_comm.hip): step kernels on the caller's stream, then ONE grouped RCCL exchange (ncclSend of every rank's rows, matching
+    ncclRecv's on rank 0) on the context's communication stream, double buffered -- all enqueued by one C call per step, no torch
+    collective and no Python between the kernels and the exchange.  torch.distributed (any backend) is used once, to hand rank 0's
+    ncclUniqueId to the other ranks.  Same interface as GatherPipeline (step / wait / drain / rows / out / k)."""
+
+    def __init__(self, sharded, device, rccl_lib=None):
+        import torch
+        self.torch, self.sh, self.dev = torch, sharded, device
+        eng = sharded.engine
+        n, w = sharded.n_local, sharded.world
+        uid = [_capi.Engine.comm_unique_id(eng.lib, rccl_lib) if sharded.rank == 0 else None]
+        if sharded.distributed:
+            sharded.dist.broadcast_object_list(uid, src=0)
+        eng.comm_init(uid[0], sharded.rank, w, rccl_lib)
+        self.out = [torch.zeros((n, eng.obs_dim + 2), device=device, dtype=torch.float32) for _ in range(2)]
+        self.all = [torch.zeros((n * w, eng.obs_dim + 2), device=device, dtype=torch.float32) for _ in range(2)] if sharded.rank == 0 else [None, None]
+        self.gather = True
+        self.k = 0
+
+    def step(self, actions, stream=None, timing_events=None):
+        b = self.k & 1
+        if stream is None:
+            stream = _capi.torch_stream(actions.device)
+        eng = self.sh.engine
+        if self.gather:
+            eng.step_gather_device(actions.data_ptr(), self.out[b].data_ptr(), self.all[b].data_ptr() if self.all[b] is not None else 0, stream)
+        else:
+            eng.step_device(actions.data_ptr(), self.out[b].data_ptr(), stream)
+        if timing_events is not None:
+            timing_events[1].record()
+        self.k += 1
+        return b
+
+    def wait(self, b=None):
+        self.sh.engine.gather_wait(_capi.torch_stream(self.dev), host=False)
+
+    def drain(self):
+        self.sh.engine.gather_wait(_capi.torch_stream(self.dev), host=True)
+
+    def rows(self, b):
+        """stacked [total_envs, obs_dim + 2] rows of the step that returned b (rank 0; None elsewhere)"""
+        self.wait(b)
+        return self.all[b] if self.gather else self.out[b]
+
+    def info(self):
+        return self.sh.engine.comm_info()

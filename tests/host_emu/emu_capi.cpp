@@ -405,4 +405,12 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     return PBRE_OK;
 }
 
+// the context-owned RCCL gather (pbre_comm.hip): no communicator in the CPU emulation
+int pbre_comm_unique_id(void*) { return PBRE_E_UNSUPPORTED; }
+int pbre_comm_init(pbre_ctx*, const void*, int32_t, int32_t) { return PBRE_E_UNSUPPORTED; }
+int pbre_step_gather_device(pbre_ctx*, const float*, float*, float*, void*) { return PBRE_E_UNSUPPORTED; }
+int pbre_gather_wait(pbre_ctx*, void*, int32_t) { return PBRE_E_UNSUPPORTED; }
+int pbre_comm_info(const pbre_ctx*, int32_t*, int32_t) { return PBRE_E_UNSUPPORTED; }
+const char* pbre_comm_last_error(const pbre_ctx*) { return "the CPU lane emulation has no RCCL communicator"; }
+
 }  // extern "C"

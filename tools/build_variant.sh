@@ -10,8 +10,8 @@ EXTRA=""
 [ $TU = pbre_lane ] && EXTRA="-mllvm -pragma-unroll-threshold=1000000"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -fno-slp-vectorize $EXTRA $FL -c -o obj/${TU}_$SUF.o $TU.hip
 OBJS=""
-for t in pbre_capi pbre_wide pbre_hands pbre_lane pbre_icub_arm; do
+for t in pbre_capi pbre_wide pbre_hands pbre_lane pbre_icub_arm pbre_comm; do
     if [ $t = $TU ]; then OBJS="$OBJS obj/${TU}_$SUF.o"; else OBJS="$OBJS obj/$t.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o libpbre_$SUF.so $OBJS
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o libpbre_$SUF.so $OBJS -ldl
 echo built libpbre_$SUF.so
