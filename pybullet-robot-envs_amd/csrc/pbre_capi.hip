@@ -96,7 +96,10 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
 // Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
 // k_fast_rc are homogeneous.  lists: [NB][cap] ints, counts: [NB] ints.
 constexpr int NB = FastD::NCLASS - 1;
-__device__ __forceinline__ void publish_class(int env, int c, signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap) {
+// (c: what Fast::step / finish returned -- the class, with BAD_BIT when the NaN / Inf guard fired: counted here, pbre_kernel_info[12])
+__device__ __forceinline__ void publish_class(int env, int c, signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                              int* __restrict__ bad_count = nullptr) {
+    if (c & FastD::BAD_BIT) { if (bad_count) atomicAdd(bad_count, 1); c &= FastD::BAD_BIT - 1; }
     cls[env] = (signed char)c;
     if (c) next_list[(size_t)(c - 1) * cap + atomicAdd(next_count + (c - 1), 1)] = env;
 }
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
     const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                               (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                               (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
-    publish_class(env, c, cls, next_list, next_count, cap);
+    publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
 }
 
 // Simple envs of a batch that leaves most SIMDs without a wave (a per-GPU shard of a strongly scaled batch, BASELINE configs 2 and 3):
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict_
         int c;
         if (sim) c = FastD::step_t<false, 1>(*T, P, st, a, o, MODE, flags, id, (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, &px, ln);
         else c = FastD::skipped(*T, P, st, o, MODE, flags, id);
-        publish_class(env, c, cls, next_list, next_count, cap);
+        publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
     } else {
         if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
         __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
             const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                                          (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                                          (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
-            publish_class(env, c, cls, next_list, next_count, cap);
+            publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
         }
     }
 }
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
                 // (the tables through the constant address space: scalar loads although the row's stores precede them -- Fast::finish)
                 const int c = FastD::finish(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
                                             P.env_id_base + (unsigned long long)env);
-                publish_class(env, c, cls, next_list, next_count, cap);
+                publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
             }
             PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
         }

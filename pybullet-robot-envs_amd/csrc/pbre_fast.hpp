@@ -41,6 +41,9 @@
 #define PBRE_PROBE(k)
 #define PBRE_PROBE_DECL
 #endif
+#ifndef PBRE_NAN_GUARD      // 0: build without the NaN / Inf guard (A/B of its cost)
+#define PBRE_NAN_GUARD 1
+#endif
 #ifndef PBRE_COUNT_BAD      // ++*p from any number of lanes (device: atomicAdd)
 #define PBRE_COUNT_BAD(p) (++*(p))
 #endif
@@ -394,16 +397,6 @@ struct Fast {
         V3 op = v3(0.f, 0.f, 0.f);
         Q4 oq; oq.x = 0.f; oq.y = 0.f; oq.z = 0.f; oq.w = 1.f;
         if (OBJECT) { op = v3(st[9], st[10], st[11]); oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15]; }     // (the robot wave gets the NEW pose, from the object wave)
-        // NaN / Inf guard.  fin_r / fin_o: 0 while every entry of the robot's / the object's part of the incoming state
-        // is finite, NaN otherwise (x * 0 is NaN for x = NaN or +-Inf).  They are ADDED to one position of the new state, so a
-        // non-finite input -- which the solver's clamps (v_med3, v_max: they return the other operand) would otherwise turn into
-        // finite garbage -- leaves a NaN that finish() finds, counts and, with PBRE_F_AUTO_RESET, restarts the env from.
-        float fin_r = 0.f, fin_o = 0.f;
-        if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) { fin_r = fmaf(q[j], 0.f, fin_r); fin_r = fmaf(qd[j], 0.f, fin_r); } }
-        if (OBJECT) {
-            fin_o = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, oq.w * 0.f))))));
-            PBRE_UNROLL for (int k = 25; k < 31; k++) fin_o = fmaf(st[k], 0.f, fin_o);
-        }
         M3 Ro = quat_R(oq);
         // per-env object parameters (domain randomisation, pbre_set_physics_per_env): X[12] mass, X[13] lateral friction,
         // X[15] 1 + linear damping; 0 = the batch value.  The inertia of the (cube) object scales with its mass.
@@ -885,15 +878,27 @@ struct Fast {
         // ---- integrate.  Positions are re-read from the state record (still the old values) rather than kept in
         //      registers across the solver loop; the barrier stops the compiler from reusing the earlier loads.
         PBRE_REG_BARRIER();
+        // NaN / Inf guard.  fin_r / fin_o: 0 while every entry of the robot's / the object's part of the INCOMING state
+        // (re-read here: still the old values) is finite, NaN otherwise (x * 0 is NaN for x = NaN or +-Inf).  They are ADDED to one
+        // position of the new state, so a non-finite input -- which the solver's clamps (v_med3, v_max: they return the other
+        // operand) would otherwise turn into finite garbage -- leaves a NaN that finish() finds, flags and, with PBRE_F_AUTO_RESET,
+        // restarts the env from.
+        float fin_r = 0.f, fin_o = 0.f;
         if (ROBOT) PBRE_UNROLL for (int j = 0; j < ND; j++) {
             const float v = clampf(wget(w, j), -vmax, vmax);
-            qd[j] = v; q[j] = fmaf(dt, v, st[j]);
-            if (j == 0) q[j] += fin_r;
-            st[j] = q[j]; st[16 + j] = v;
+            const float q0 = st[j];
+            if (PBRE_NAN_GUARD) { fin_r = fmaf(q0, 0.f, fin_r); fin_r = fmaf(st[16 + j], 0.f, fin_r); }
+            qd[j] = v; q[j] = fmaf(dt, v, q0);
+            st[16 + j] = v;
         }
+        if (ROBOT) { q[0] += fin_r; PBRE_UNROLL for (int j = 0; j < ND; j++) st[j] = q[j]; }
         if (OBJECT && obj_on) {
             op = v3(st[9], st[10], st[11]);
             oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+            if (PBRE_NAN_GUARD) {
+                fin_o = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, oq.w * 0.f))))));
+                PBRE_UNROLL for (int k = 25; k < 31; k++) fin_o = fmaf(st[k], 0.f, fin_o);
+            }
             ov = v3(clampf(ov.x, -vmax, vmax), clampf(ov.y, -vmax, vmax), clampf(ov.z, -vmax, vmax));
             ow = v3(clampf(ow.x, -vmax, vmax), clampf(ow.y, -vmax, vmax), clampf(ow.z, -vmax, vmax));
             op = v3(fmaf(dt, ov.x, op.x) + fin_o, fmaf(dt, ov.y, op.y), fmaf(dt, ov.z, op.z));
@@ -936,6 +941,7 @@ struct Fast {
 #define PBRE_NCLASS 3        // 2: all complex envs share one list; 3: see above; 6: one list per class of the table above (pays off only when
 #endif                       //    k_fast_rc is throughput-bound)
     static constexpr int NCLASS = PBRE_NCLASS;
+    static constexpr int BAD_BIT = 256;      // step() / finish() return value: class | BAD_BIT when the NaN / Inf guard fired (the caller counts)
     static_assert(NCLASS == 2 || NCLASS == 3 || NCLASS == 6, "supported class layouts");
     struct Tail { int cls; M3 Re; V3 pe, Va, Vl; int nT; bool lim; };   // class + end-effector owner frame and spatial velocity (nT, lim: what the class was made of)
     static PBRE_HD int cls_of(int nO, int nT, bool lim) {
@@ -1207,9 +1213,10 @@ struct Fast {
         float fin = 0.f;
         PBRE_UNROLL for (int j = 0; j < ND; j++) fin = fmaf(q[j], 0.f, fin);
         if (!(flags & 1)) fin = fmaf(op.x, 0.f, fmaf(op.y, 0.f, fmaf(op.z, 0.f, fmaf(oq.x, 0.f, fmaf(oq.y, 0.f, fmaf(oq.z, 0.f, fmaf(oq.w, 0.f, fin)))))));
-        const bool bad = !(fin == 0.f);
-        if (PBRE_ANY(bad)) { if (bad && P.bad_count) PBRE_COUNT_BAD(P.bad_count); }
-        if (!want_obs) return cls;
+        // (the count itself is the CALLER's: finish() returns the class with BAD_BIT set -- an atomic in the middle of this function made
+        // the compiler duplicate the rest of it, +57 % static instructions and +14 % executed VALU in k_fast)
+        const bool bad = PBRE_NAN_GUARD && !(fin == 0.f);
+        if (!want_obs) return cls | (bad ? BAD_BIT : 0);
         V3 tg = v3(st[32], st[33], st[34]);
         bool again = false;
         if (mode & M_TASK) {
@@ -1306,7 +1313,7 @@ struct Fast {
             out[o++] = reward; out[o++] = done;
         }
         if (ROLE == 1) PBRE_PROBE(20);      // robot wave: object tests, observation, reward, row
-        return cls;
+        return cls | (bad ? BAD_BIT : 0);
     }
 };
 

@@ -643,6 +643,12 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         hipFuncAttributes fa;
         *vg = hipFuncGetAttributes(&fa, (const void*)kw_quad) == hipSuccess ? fa.numRegs : -1;
         *complex_now = 0;
+        if (!cls_valid && lane_ok()) {        // (e.g. right after a reset done by the lane-group kernel: classify the batch as the next lane step would)
+            cur = 0; ccur = 0;
+            (void)hipMemsetAsync(count, 0, 3 * sizeof(int), stream);
+            hipLaunchKernelGGL(kw_lane_classify, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, stream, dT, P, state, n, cfg.flags & PBRE_F_NO_OBJECT, cls, list, count);
+            cls_valid = hipGetLastError() == hipSuccess;
+        }
         if (cls_valid) { (void)hipDeviceSynchronize(); (void)hipMemcpy(complex_now, count + ccur, sizeof(int), hipMemcpyDeviceToHost); }
         return 1;
     }

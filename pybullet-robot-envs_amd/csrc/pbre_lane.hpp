@@ -698,6 +698,23 @@ struct Lane {
                 again = (flags & 2) && !(mode & M_INNER) && done != 0.f;
             }
             if (!PBRE_ANY(again)) break;
+            if (P.rst_ok) {
+                // The settled robot pose is the same in every env, so its end-effector pose was recorded with the snapshot (P.rst_ee) and the
+                // robot is at rest: the first observation of the next episode needs no second kinematic sweep -- which the whole wave would
+                // otherwise run whenever one of its 64 envs finishes (every step of a 32768-env batch: kw_fin 0.10 instead of 0.05 ms).
+                // As in Fast::finish; P.rst_ok = 0 (no snapshot yet, or its pose is not a simple-class state) takes the second pass below.
+                if (again) {
+                    snapshot_reset(T, P, env_id, st);
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = 0.f; }
+                    op = v3(st[LC], st[LC + 1], st[LC + 2]);
+                    oq.x = st[LC + 3]; oq.y = st[LC + 4]; oq.z = st[LC + 5]; oq.w = st[LC + 6];
+                    tg = v3(X[0], X[1], X[2]);
+                    ee = v3(P.rst_ee[0], P.rst_ee[1], P.rst_ee[2]); eul = v3(P.rst_ee[3], P.rst_ee[4], P.rst_ee[5]); vee = v3(0.f, 0.f, 0.f);
+                    cls = 0;
+                    if (P.robot >= 1 && P.task >= 1) { X[12] = norm(sub(ee, op)); X[13] = norm(sub(op, tg)); }     // icub_push_gym_env.py:124-127
+                }
+                break;
+            }
             // snapshot reset of the finished envs (settled robot pose and object height of the last full reset, freshly sampled object
             // pose and target), then the first observation of the new episode in the second pass
             ee0 = ee; eul0 = eul; vee0 = vee; op0 = op; tg0 = tg; oq0 = oq; cls0 = cls;

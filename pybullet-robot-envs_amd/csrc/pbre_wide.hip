@@ -254,6 +254,18 @@ int wide_reset(WideEngine* w, const uint8_t* mask, float* obs) {
             w->snapshot(rec.data());
             WCHK(w->upload_tables());
             w->have_snapshot = true; w->stale_snapshot = false;
+            // end-effector pose of the settled robot (the first 6 observation entries of env 0) for the lane-per-env pipeline's in-kernel
+            // restart (Lane::finish): valid while the settled state is in the simple class (no robot sphere at the object)
+            w->P.rst_ok = 0;
+            if (w->lane_ok() && !w->mrec) {
+                w->launch_observe(false, w->state, w->d_out, w->n, s);
+                WCHK(hipGetLastError());
+                WCHK(hipStreamSynchronize(s));
+                float row[6]; int vg = 0, cn = 1;
+                WCHK(hipMemcpy(row, w->d_out, sizeof row, hipMemcpyDeviceToHost));
+                for (int k = 0; k < 6; k++) w->P.rst_ee[k] = row[k];
+                if (w->lane_info(&vg, &cn) && cn == 0) w->P.rst_ok = 1;
+            }
         }
     }
     if (obs) return wide_observe(w, obs);

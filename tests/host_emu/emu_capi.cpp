@@ -62,6 +62,7 @@ struct Emu : pbre_ctx {
     TablesT<S> T;
 
     // same dispatch as the device: lane-per-env fast path first (Panda), general lane-group kernel otherwise
+    void count_bad(int c) { if (c & FastH::BAD_BIT) n_bad++; }      // (as the device's publish_class: the NaN / Inf guard's counter)
     void step_env(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tg = nullptr) {
         if constexpr (PANDA) {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
@@ -73,9 +74,9 @@ struct Emu : pbre_ctx {
                     if (pair && !(flags & 1) && !(mode & FastH::M_INNER) && st[46] == 0.f) {
                         PairX px;
                         (void)FastH::step_t<false, 2>(T, P, st, nullptr, nullptr, mode, flags, 0ull, nullptr, &px, 0);
-                        (void)FastH::step_t<false, 1>(T, P, st, act, out, mode, flags, env_id, tg, &px, 0);
+                        count_bad(FastH::step_t<false, 1>(T, P, st, act, out, mode, flags, env_id, tg, &px, 0));
                         n_pair++;
-                    } else FastH::step(T, P, st, act, out, mode, flags, env_id, tg);
+                    } else count_bad(FastH::step(T, P, st, act, out, mode, flags, env_id, tg));
                 }
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
                     // the device's k_row_list: physics by the row kernel, observation / reward / done / auto-reset by Fast::finish
@@ -97,9 +98,9 @@ struct Emu : pbre_ctx {
                     for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
                     FastH::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
                     FastH::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-                    FastH::finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id);
+                    count_bad(FastH::finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id));
                 }
-                else { n_rc++; FastH::step_rc(T, P, st, act, out, mode, flags, env_id, tg); }
+                else { n_rc++; count_bad(FastH::step_rc(T, P, st, act, out, mode, flags, env_id, tg)); }
                 return;
             }
         }

@@ -134,7 +134,7 @@ def test_action_repeat(panda, emu_lib, use_ik, flags):
 
 
 def test_force_limited_motors(emu_lib, panda):
-    parity.check_panda_force_limited(_capi.Engine, emu_lib, panda["table"], n=3)
+    parity.check_panda_force_limited(_capi.Engine, emu_lib, panda["table"], n=int(__import__("os").environ.get("PBRE_FL_N", "3")))
 
 
 def test_device_glue_only(panda, emu_lib):
