@@ -16,6 +16,10 @@
 #include <math.h>
 #include "pbre_tables.hpp"
 
+#if defined(__clang__)     // (see pbre_fast.hpp: contraction is stated per header)
+#pragma float_control(push)
+#pragma clang fp contract(fast)
+#endif
 namespace pbre {
 
 // The object's collision primitive (Params::obj_shape, include/pbre.h PBRE_SHAPE_*): the reference's object list (world_env.py:18-25,
@@ -228,3 +232,6 @@ struct ObjStep {
 };
 
 }  // namespace pbre
+#if defined(__clang__)
+#pragma float_control(pop)
+#endif
