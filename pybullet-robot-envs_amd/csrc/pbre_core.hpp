@@ -59,10 +59,7 @@
 // kernels appended them -- on timing.  The paths are the same arithmetic row by row; with the compiler free to fuse a multiply and an add
 // here but not there they differed in the last bit, and a complex env's result depended on its wave-mates (found by running two
 // identical engines side by side: tools/diag_fast3.py).  Every fused operation in this file is an explicit L::fma.
-#if defined(__clang__)
-#pragma float_control(push)
-#pragma clang fp contract(off)
-#endif
+PBRE_FP_CONTRACT_OFF
 namespace pbre {
 
 template <class L, class SH = Shape16>
@@ -1573,6 +1570,4 @@ struct Core {
 };
 
 }  // namespace pbre
-#if defined(__clang__)
-#pragma float_control(pop)      // back to whatever the including translation unit compiles with (hipcc: fast; clang++ -ffp-contract=off stays off)
-#endif
+PBRE_FP_CONTRACT_FAST       // (pbre_math.hpp: the setting the other sources of csrc/ are written for; the amdgcn target has no push / pop of it)

@@ -52,15 +52,10 @@
 #endif
 #include "pbre_objstep.hpp"
 
-// Floating-point contraction is stated per header, not inherited from whatever was included before (pbre_core.hpp switches it off
-// for the row kernels and restores the translation unit's setting, which under -fno-fast-math is "on": within one expression only).
-// The lane-per-env code is written as plain a * b + c across statements and is meant to be fused wherever the compiler can:
-// 33.4 k instead of 38.1 k VALU instructions per k_fast wave (profiles/r04_fp_contract_bisect.txt).  The host emulation (g++
-// -ffp-contract=off) never fuses; device and emulation are compared within tolerances, variants of one build bit for bit.
-#if defined(__clang__)
-#pragma float_control(push)
-#pragma clang fp contract(fast)
-#endif
+// The lane-per-env code is written as plain a * b + c across statements and is meant to be fused wherever the compiler can (pbre_math.hpp:
+// contraction is stated per header): 32.6 k instead of 38.1 k VALU instructions per k_fast wave (profiles/r04_fp_contract_bisect.txt).
+// Device and emulation are compared within tolerances, variants of one build bit for bit.
+PBRE_FP_CONTRACT_FAST
 namespace pbre {
 
 // LDS exchange area of one block of the pair kernel (k_fast_pair, pbre_capi.hip): 64 envs, the robot's half of the step on wave 0, the
@@ -1327,6 +1322,3 @@ struct Fast {
 };
 
 }  // namespace pbre
-#if defined(__clang__)
-#pragma float_control(pop)
-#endif

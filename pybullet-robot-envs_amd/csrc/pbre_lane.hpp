@@ -50,10 +50,7 @@
 #define PBRE_LANE_MREG 0
 #endif
 
-#if defined(__clang__)     // (see pbre_fast.hpp: contraction is stated per header)
-#pragma float_control(push)
-#pragma clang fp contract(fast)
-#endif
+PBRE_FP_CONTRACT_FAST      // (pbre_math.hpp: contraction is stated per header)
 namespace pbre {
 
 // The iCub as flattened by build_tables() from model/table.py: icub_table (legs pruned): torso 0-1-2, left arm 3..9, head 10..12,
@@ -890,6 +887,3 @@ struct Lane {
 };
 
 }  // namespace pbre
-#if defined(__clang__)
-#pragma float_control(pop)
-#endif

@@ -5,6 +5,19 @@
 #define PBRE_HD
 #endif
 
+// Floating-point contraction is stated by every header that cares, at its top, and never inherited from whatever was included before
+// ('#pragma float_control(push / pop)' is ignored by the amdgcn target, so there is no "restore"): pbre_core.hpp compiles with contraction
+// off (its fused operations are explicit L::fma: results must not depend on which solver path a wave takes), the lane-per-env headers
+// (pbre_fast.hpp, pbre_objstep.hpp, pbre_lane.hpp) with contraction fast.  pbre_core.hpp ends by switching back to fast, the setting
+// every other source of csrc/ is written for.  g++ builds of the host emulation use -ffp-contract=off throughout.
+#if defined(__clang__)
+#define PBRE_FP_CONTRACT_OFF _Pragma("clang fp contract(off)")
+#define PBRE_FP_CONTRACT_FAST _Pragma("clang fp contract(fast)")
+#else
+#define PBRE_FP_CONTRACT_OFF
+#define PBRE_FP_CONTRACT_FAST
+#endif
+
 namespace pbre {
 
 // sin and cos of one argument with one shared range reduction (Cody-Waite, pi/2 in three parts) and degree-7 / degree-8 minimax

@@ -15,11 +15,12 @@
 #pragma once
 #include <math.h>
 #include "pbre_tables.hpp"
-
-#if defined(__clang__)     // (see pbre_fast.hpp: contraction is stated per header)
-#pragma float_control(push)
-#pragma clang fp contract(fast)
+#ifndef PBRE_HD
+#define PBRE_HD
 #endif
+#include "pbre_math.hpp"
+
+PBRE_FP_CONTRACT_FAST      // (pbre_math.hpp: contraction is stated per header)
 namespace pbre {
 
 // The object's collision primitive (Params::obj_shape, include/pbre.h PBRE_SHAPE_*): the reference's object list (world_env.py:18-25,
@@ -232,6 +233,3 @@ struct ObjStep {
 };
 
 }  // namespace pbre
-#if defined(__clang__)
-#pragma float_control(pop)
-#endif

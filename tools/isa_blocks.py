@@ -42,7 +42,7 @@ def main():
         sys.exit("no kernel matches %r" % pat)
     for i0, name in sel:
         print("==", dm[name][:120])
-        end = next(j for j in range(i0, len(lines)) if lines[j].strip().startswith("s_endpgm"))
+        end = next(j for j in range(i0, len(lines)) if lines[j].startswith(".Lfunc_end"))      # (a kernel may hold several s_endpgm)
         # walk: labels and instructions
         blocks, cur, pos = [], None, {}
         idx = 0

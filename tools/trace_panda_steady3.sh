@@ -5,7 +5,7 @@ N=${1:-131072}; TAG=${2:-tp3}; shift 2
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 rm -rf gpurun_out/prof_$TAG
-(cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --envs $N --no-cpu-baseline --no-other-configs --no-host-path --no-fresh > $ROOTDIR/gpurun_out/${TAG}_rocprof.log 2>&1)
+(cd /tmp && env "$@" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --envs $N --no-cpu-baseline --no-other-configs --no-host-path --no-fresh --no-shards > $ROOTDIR/gpurun_out/${TAG}_rocprof.log 2>&1)
 t=$(find gpurun_out/prof_$TAG -name "*kernel_trace.csv" | head -1)
 s=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1)
 [ -n "$s" ] && python tools/compact_stats.py $s gpurun_out/${TAG}_kernel_stats.csv && head -8 gpurun_out/${TAG}_kernel_stats.csv
