@@ -622,7 +622,7 @@ def main():
         if pmc:
             traffic, traffic_src = pmc["hbm_bytes_per_env_step"] * n_local, src
             traffic_note = ("counters of the variant that steps the stationary batch (%s: 168 VGPRs, its setup phase spills ~380 B per lane); the "
-                            "256-VGPR variant that runs while no env is complex is spill-free and moves 553 B per env-step (same file)" % pmc.get("variant"))
+                            "256-VGPR variant that runs while no env is complex is spill-free and moves ~550 B per env-step (same file)" % pmc.get("variant"))
         sq = None
         d, src = _profile("pmc_sq", "k_fast<7>")
         if d:
@@ -669,8 +669,8 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
-                         "note": "path is fp32-VALU/dependency bound (AI ~166 FLOP/B of the sparse formulation >> 25 FLOP/B machine "
-                                 "balance); HBM fraction is small by construction, see valu"},
+                         "note": "path is fp32-VALU issue bound (%.0f FLOP per algorithmic byte against a machine balance of ~20 FLOP/B); the HBM "
+                                 "fraction is small by construction, see valu" % (ALG_FLOP_PER_ENV_STEP / ALG_BYTES_PER_ENV_STEP)},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
                      # the 157.3 TF peak assumes v_pk_fma_f32 at full rate; measured on this chip (profiles/r01_ubench_pkfma.txt) a
                      # packed FMA takes ~2 passes, so the scalar-FMA peak (78.6 TF) is the practical ceiling of fp32 FMA code

@@ -1274,7 +1274,7 @@ struct Core {
     static PBRE_HD V3 selv3(B c, const V3& a, const V3& b) { return selv(c, a, b); }
 
     // Observation / reward / termination of the current state (Qn, Vn, Xr = the three state records).  With
-    // PBRE_F_AUTO_RESET (flags & 2) a finished env is re-initialised right here (snapshot reset, DESIGN.md section 5): the
+    // PBRE_F_AUTO_RESET (flags & 2) a finished env is re-initialised right here (snapshot reset, DESIGN.md section 6): the
     // transition's reward and done flag are returned together with the first observation of the next episode.
     static PBRE_HD void observe(const Tables& T, const Params& P, float* st, F Qn, F Vn, F Xr, float* out, int mode,
                                 int flags = 0, unsigned long long env_id = 0) {

@@ -1168,7 +1168,7 @@ struct Fast {
     static PBRE_HD float u01(unsigned x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
     // Observation / reward / termination of the new state and its class.  With PBRE_F_AUTO_RESET a finished env is
-    // re-initialised right here (snapshot reset, DESIGN.md section 5): the transition's reward and done flag are returned
+    // re-initialised right here (snapshot reset, DESIGN.md section 6): the transition's reward and done flag are returned
     // together with the first observation of the next episode.
     // TT: `Tables`, or the same struct in the constant address space (CTables).  The second half of a step re-reads the model constants
     // (they are not kept live across the solver loop); through a plain pointer those re-reads come after the step's stores and behind an

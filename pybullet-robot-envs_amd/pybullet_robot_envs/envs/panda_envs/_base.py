@@ -5,7 +5,7 @@ Each public class keeps the reference constructor signature and Gym surface
 action_space, _robot, _world, _env_step_counter, terminated) and adds optional trailing kwargs
 `num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False` (auto_reset: a finished env is re-initialised
 inside the step that finished it -- the step returns that transition's reward/done with the first observation of the
-next episode, Isaac-Gym style -- using the snapshot reset of DESIGN.md section 5).  With num_envs == 1 the return shapes are the
+next episode, Isaac-Gym style -- using the snapshot reset of DESIGN.md section 6).  With num_envs == 1 the return shapes are the
 reference's ((obs_dim,) float64, 0-d reward, 0-d float32 done, {}); with num_envs = N everything is
 stacked [N, ...].  All per-step work is one fused HIP kernel behind the C-ABI (include/pbre.h)."""
 import numpy as np
