@@ -1,7 +1,8 @@
 #!/bin/bash
+# iCub: step latency of the two engines at batch sizes that leave most SIMDs empty (a wave's chain, not throughput), hold protocol and stationary mix
 export TMPDIR=/tmp
-for L in 0 1; do for N in 128 2048; do for M in "" "--joint"; do
-  PBRE_ICUB_LANE=$L timeout 300 python tools/bench_icub.py --envs $N --steps 20 $M 2>&1 | tail -1 | python -c "
+for L in 0 1; do for N in 2048 8192; do for M in "" "--joint"; do
+  PBRE_ICUB_LANE=$L timeout 300 python tools/icub_steady.py --desync --envs $N --steps 1000 --window 250 $M 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('LANE=$L', d['workload'][:55], 'ms/step %.3f kernel_ms %.3f' % (d['ms_per_step'], d['kernel_ms']), {k:d[k] for k in d if 'complex' in k or 'contact' in k})"
+d=json.loads(sys.stdin.read()); print('LANE=$L', d['workload'][:60], [(w['steps_done'], w['ms_per_step'], w['complex_envs']) for w in d['windows']])"
 done; done; done
