@@ -812,7 +812,15 @@ struct Lane {
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
         float q[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
+#ifdef PBRE_IK_PROBE      // host emulation only (tools/ik_cycle_probe.py): at which iteration does this env's iteration become periodic?
+        float q_m2[ND]; int probe_at = -1, probe_kind = 3;      // kind 0 converged (residual), 1 fixed point, 2 two-cycle, 3 neither within the cap
+        PBRE_UNROLL for (int j = 0; j < ND; j++) q_m2[j] = 3.0e38f;
+#endif
         for (int it = 0; it < P.ik_iters; it++) {
+#ifdef PBRE_IK_PROBE
+            float q_m1[ND];
+            PBRE_UNROLL for (int j = 0; j < ND; j++) q_m1[j] = q[j];
+#endif
             // FK of the chain links only (a link off the chain has no chain link below it)
             M3 R[ND]; V3 p[ND], aw[ND];
             M3 Re = Eo; V3 po = v3(0.f, 0.f, 0.f);
@@ -829,6 +837,9 @@ struct Lane {
             float e[6];
             e[0] = tp.x - pe.x; e[1] = tp.y - pe.y; e[2] = tp.z - pe.z;
             const bool go = sqrtf(fmaf(e[0], e[0], fmaf(e[1], e[1], e[2] * e[2]))) >= P.ik_res;
+#ifdef PBRE_IK_PROBE
+            if (!go && probe_at < 0) { probe_at = it; probe_kind = 0; }
+#endif
             if (!PBRE_ANY(go)) break;
             {   // orientation error as a world-frame rotation vector: axis-angle of Rt (Re Eo)^T
                 const M3 Ree = mm(Re, Eo);
@@ -876,10 +887,23 @@ struct Lane {
             }
             // an iteration that changes no joint angle of any env of the wave (targets out of reach: the damped step has shrunk below half
             // an ulp of every angle) would be repeated unchanged until the iteration cap: leaving here gives the same targets bit for bit
+#ifdef PBRE_IK_PROBE
+            {
+                bool two = true;
+                PBRE_UNROLL for (int j = 0; j < ND; j++) two = two && q[j] == q_m2[j];
+                if (probe_at < 0 && !moved) { probe_at = it; probe_kind = 1; }
+                if (probe_at < 0 && two) { probe_at = it; probe_kind = 2; }
+                PBRE_UNROLL for (int j = 0; j < ND; j++) q_m2[j] = q_m1[j];
+            }
+#else
 #ifndef PBRE_IK_NO_FIXPOINT_EXIT
             if (!PBRE_ANY(moved)) break;
 #endif
+#endif
         }
+#ifdef PBRE_IK_PROBE
+        pbre_ik_probe_record(probe_kind, probe_at);
+#endif
         // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
         // their current angle
         PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]);

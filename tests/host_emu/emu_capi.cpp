@@ -16,6 +16,15 @@ extern "C" void pbre_fixpoint_hist(long* o, long* m, long* p2, int clear) {
     for (int i = 0; i < 152; i++) { o[i] = g_fix_obj[i]; m[i] = g_fix_mot[i]; p2[i] = g_fix_per2[i]; if (clear) g_fix_obj[i] = g_fix_mot[i] = g_fix_per2[i] = 0; }
 }
 #endif
+#ifdef PBRE_IK_PROBE
+// instrumented build (make build/libpbre_emu_ikprobe.so, tools/ik_cycle_probe.py): per call of Lane::ik_targets, the iteration at which the
+// env's IK sequence converged (kind 0), reached a bitwise fixed point (1), a two-cycle (2), or none of these within the cap (3)
+static long g_ik_hist[4][128];
+static void pbre_ik_probe_record(int kind, int at) { g_ik_hist[kind & 3][at < 0 ? 127 : (at > 126 ? 126 : at)]++; }
+extern "C" void pbre_ik_probe_hist(long* h, int clear) {
+    for (int k = 0; k < 4; k++) for (int i = 0; i < 128; i++) { h[k * 128 + i] = g_ik_hist[k][i]; if (clear) g_ik_hist[k][i] = 0; }
+}
+#endif
 #include "../../pybullet-robot-envs_amd/csrc/pbre_host.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
