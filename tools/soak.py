@@ -38,7 +38,8 @@ def soak(name, eng, steps, chunk, act_dim, lim_lo, lim_hi):
         episodes = int(st[:, xo + 5].sum())
     el = time.perf_counter() - t0
     print(json.dumps({"soak": name, "envs": n, "steps": steps, "env_steps_per_s": n * steps / el, "episodes_completed": episodes,
-                      "max_abs_object_height_dev_m": worst, "complex_envs_at_end": eng.kernel_info()[5]}))
+                      "max_abs_object_height_dev_m": worst, "complex_envs_at_end": eng.kernel_info()[5],
+                      "nan_inf_guard_bad_env_steps": eng.kernel_info()[12]}))
 
 
 tbl, _ = panda_table()
