@@ -162,6 +162,7 @@ void orc_default_params(orc_params* p) {
     p->dt = 1.0 / 240.0;            /* panda_push_gym_env.py:39 */
     p->gravity_z = -9.8;            /* :126 */
     p->solver_iters = 150;          /* :122 */
+    p->solver_residual_threshold = 0;   /* all sweeps (pbre_oracle.h); PyBullet's documented default would be 1e-7 [EXT-UNVERIFIED] */
     p->erp = 0.2;                   /* Bullet contact/joint ERP default [EXT-UNVERIFIED] */
     p->linear_slop = 1e-5;          /* [EXT-UNVERIFIED] */
     p->contact_margin = 1e-3;       /* ~ contact breaking threshold of a 5 cm cube [EXT-UNVERIFIED] */
@@ -528,6 +529,7 @@ typedef struct {
     int fidx;
 } row_t;
 
+static __thread int g_last_sweeps[2];      /* sweeps_used, sweeps_to_1e7 of this thread's last simulation step (orc_batch_step_sweeps) */
 static real resolve_row(row_t* r, real* dvA, real* dvB, int nd) {
     /* btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric, cfm = 0 */
     real delta = r->rhs, dot = 0;
@@ -774,17 +776,29 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
     /* 5. projected Gauss-Seidel, Bullet row order (btMultiBodyConstraintSolver::solveSingleIteration):
      *    non-contact rows (order alternates with iteration parity), all normals, all frictions */
     real dvA[ORC_MAXD] = {0}, dvB[6] = {0};
+    /* Least-squares residual of a sweep as Bullet keeps it (btMultiBodyConstraintSolver::solveSingleIteration: the maximum over the rows
+     * of (deltaImpulse / jacDiagABInv)^2, i.e. of the squared velocity-level change of the row) and the loop's exit test
+     * (btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations: residual <= m_leastSquaresResidualThreshold) [EXT-UNVERIFIED].
+     * With the threshold at 0 the loop ends early only after a sweep that changed nothing, which leaves the result as it is. */
+    info->sweeps_used = prm->solver_iters; info->sweeps_to_1e7 = prm->solver_iters + 1; info->last_sq_residual = 0;
+#define ORC_RES(row) do { real d_ = resolve_row((row), dvA, dvB, nd) / (row)->dinv; d_ *= d_; if (d_ > lsr) lsr = d_; } while (0)
     for (int it = 0; it < prm->solver_iters; it++) {
+        real lsr = 0;
         for (int j = 0; j < n_nc; j++) {
             int idx = (it & 1) ? j : n_nc - 1 - j;
-            resolve_row(&nc[idx], dvA, dvB, nd);
+            ORC_RES(&nc[idx]);
         }
-        for (int c = 0; c < nsel; c++) resolve_row(&rn[c], dvA, dvB, nd);
+        for (int c = 0; c < nsel; c++) ORC_RES(&rn[c]);
         for (int f = 0; f < 2 * nsel; f++) {
             real tot = rn[rf[f].fidx].app;
-            if (tot > 0) { rf[f].lo = -rf[f].mu * tot; rf[f].hi = rf[f].mu * tot; resolve_row(&rf[f], dvA, dvB, nd); }
+            if (tot > 0) { rf[f].lo = -rf[f].mu * tot; rf[f].hi = rf[f].mu * tot; ORC_RES(&rf[f]); }
         }
+        info->last_sq_residual = lsr;
+        if (lsr <= (real)1e-7 && info->sweeps_to_1e7 > prm->solver_iters) info->sweeps_to_1e7 = it + 1;
+        if (lsr <= (real)prm->solver_residual_threshold) { info->sweeps_used = it + 1; break; }
     }
+#undef ORC_RES
+    g_last_sweeps[0] = info->sweeps_used; g_last_sweeps[1] = info->sweeps_to_1e7;
 
     /* 6. velocity update + position integration (stepPositionsMultiDof) */
     for (int k = 0; k < nd; k++) {
@@ -1307,6 +1321,18 @@ void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* 
                      real* states, real* obs) {
     const int od = orc_obs_dim(t, m), sf = orc_state_floats(m);
     for (int e = 0; e < n; e++) orc_env_reset(m, prm, t, env_id0 + (uint64_t)e, 0, states + (size_t)e * sf, obs ? obs + (size_t)e * od : NULL);
+}
+/* orc_batch_step that also reports, per env, how many sweeps the solver ran and after how many Bullet's residual test with PyBullet's
+ * documented default threshold (1e-7) would have ended the loop (orc_step_info.sweeps_used / sweeps_to_1e7) */
+void orc_batch_step_sweeps(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
+                           const real* actions, real* out, int* sweeps_used, int* sweeps_to_1e7) {
+    const int od = orc_obs_dim(t, m), sf = orc_state_floats(m);
+    for (int e = 0; e < n; e++) {
+        real* o = out + (size_t)e * (od + 2);
+        g_last_sweeps[0] = g_last_sweeps[1] = 0;
+        orc_env_step(m, prm, t, states + (size_t)e * sf, actions + (size_t)e * t->n_act, o, o + od, o + od + 1);
+        sweeps_used[e] = g_last_sweeps[0]; sweeps_to_1e7[e] = g_last_sweeps[1];
+    }
 }
 void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
                     const real* actions, real* out) {

@@ -75,6 +75,10 @@ typedef struct {
     int implicit_joint_damping;    /* 1: (M + dt C) dv = dt (tau - C v) instead of the explicit damping torque (include/pbre.h) */
     int obj_shape;                 /* object primitive (include/pbre.h PBRE_SHAPE_*): 0 box (half extents obj_h), 1 sphere (radius obj_h[0]),
                                       2 cylinder about its local z axis (radius obj_h[0], half height obj_h[2]) */
+    double solver_residual_threshold;  /* Bullet's btContactSolverInfo::m_leastSquaresResidualThreshold: the sweep loop is left once the
+                                      largest squared velocity-level change of a row within one sweep is <= this value.  0 (the default here,
+                                      and what the engine implements): all solver_iters sweeps unless a sweep changes nothing at all.
+                                      [EXT-UNVERIFIED] PyBullet documents solverResidualThreshold with default 1e-7; see orc_step_info.sweeps_* */
 } orc_params;
 
 #define ORC_F_NO_OBJECT 1   /* object frozen and contact-free (reset phase 1; reach config 2) */
@@ -89,6 +93,10 @@ typedef struct {
     real qdd[ORC_MAXD];          /* unconstrained joint accelerations (ABA) */
     real obj_acc[6];
     real residual;
+    int  sweeps_used;            /* sweeps the solver ran (= solver_iters unless solver_residual_threshold ended it) */
+    int  sweeps_to_1e7;          /* first sweep after which the largest squared velocity-level row change was <= 1e-7 (PyBullet's documented
+                                    default threshold), solver_iters + 1 if never: how early real PyBullet would presumably leave the loop */
+    real last_sq_residual;       /* that quantity for the last sweep run */
 } orc_step_info;
 
 #ifdef __cplusplus
@@ -165,6 +173,8 @@ void orc_env_step(const orc_model* m, const orc_params* prm, const orc_task* t, 
 /* batched convenience loops (tests, cpu_baseline) */
 void orc_batch_reset(const orc_model* m, const orc_params* prm, const orc_task* t, int n, uint64_t env_id0,
                      real* states, real* obs);
+void orc_batch_step_sweeps(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
+                           const real* actions, real* out, int* sweeps_used, int* sweeps_to_1e7);
 void orc_batch_step(const orc_model* m, const orc_params* prm, const orc_task* t, int n, real* states,
                     const real* actions, real* out /*[n][obs_dim+2]*/);
 

@@ -31,7 +31,8 @@ def _mk(real):
         _fields_ = [("ncontacts", C.c_int), ("type", C.c_int * NC), ("link", C.c_int * NC), ("idx", C.c_int * NC),
                     ("n", real * 3 * NC), ("pA", real * 3 * NC), ("pB", real * 3 * NC), ("dist", real * NC),
                     ("mu", real * NC), ("lambda_n", real * NC), ("lambda_f1", real * NC), ("lambda_f2", real * NC),
-                    ("motor_impulse", real * MAXD), ("qdd", real * MAXD), ("obj_acc", real * 6), ("residual", real)]
+                    ("motor_impulse", real * MAXD), ("qdd", real * MAXD), ("obj_acc", real * 6), ("residual", real),
+                    ("sweeps_used", C.c_int), ("sweeps_to_1e7", C.c_int), ("last_sq_residual", real)]
     return Model, StepInfo
 
 
@@ -43,7 +44,7 @@ class Params(C.Structure):
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
                 ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int), ("implicit_joint_damping", C.c_int),
-                ("obj_shape", C.c_int)]
+                ("obj_shape", C.c_int), ("solver_residual_threshold", C.c_double)]
 
 
 class Task(C.Structure):
@@ -241,6 +242,18 @@ class Oracle:
         self.lib.orc_batch_step(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_int(n),
                                 self._p(st), self._p(act), self._p(out))
         return st, out
+
+    def batch_step_sweeps(self, states, actions):
+        """batch_step + per env: sweeps the solver ran, sweeps after which Bullet's residual test with PyBullet's documented default
+        threshold (1e-7) would have ended the loop (solver_iters + 1: never)"""
+        st = self._a(states).copy()
+        n = st.shape[0]
+        act = self._a(actions)
+        out = np.zeros((n, self.obs_dim + 2), self.np_real)
+        used = np.zeros(n, np.int32); to7 = np.zeros(n, np.int32)
+        self.lib.orc_batch_step_sweeps(C.byref(self.model), C.byref(self.params), C.byref(self.task), C.c_int(n), self._p(st), self._p(act),
+                                       self._p(out), used.ctypes.data_as(C.c_void_p), to7.ctypes.data_as(C.c_void_p))
+        return st, out, used, to7
 
     def philox(self, c, k):
         out = (C.c_uint32 * 4)()

@@ -206,3 +206,28 @@ def test_oracle_under_asan_ubsan():
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "AddressSanitizer" not in tail and "runtime error" not in tail, tail
+
+
+def test_solver_residual_threshold_option():
+    """Bullet's exit test of the sweep loop (orc_params.solver_residual_threshold; PyBullet documents solverResidualThreshold with default
+    1e-7 [EXT-UNVERIFIED]): off by default -- all solver_iters sweeps, which is what the engine implements --, and when it is on the loop
+    ends exactly where orc_step_info.sweeps_to_1e7 says, with a result close to the full solve's (tools/residual_exit_probe.py)."""
+    import orc
+    ora, _ = orc.panda_oracle()
+    ora.task.obj_pose_rnd_std = 0.05; ora.task.tg_pose_rnd_std = 0.2
+    n = 6
+    st, _ = ora.batch_reset(n)
+    act = np.random.default_rng(3).uniform(-1, 1, (n, 7))
+    assert ora.params.solver_residual_threshold == 0.0
+    full, out_full, used, to7 = ora.batch_step_sweeps(st, act)
+    assert (used == ora.params.solver_iters).all() and (to7 >= 1).all()
+    ora.params.solver_residual_threshold = 1e-7
+    early, out_early, used_e, to7_e = ora.batch_step_sweeps(st, act)
+    ora.params.solver_residual_threshold = 0.0
+    assert (used_e == np.minimum(to7, ora.params.solver_iters)).all() and (to7_e == to7).all()
+    assert (used_e < ora.params.solver_iters).any(), "the test never fires on free-space steps: nothing tested"
+    nd = ora.ndof
+    assert np.abs(early[:, :nd] - full[:, :nd]).max() < 1e-5 and np.abs(early[:, 16:16 + nd] - full[:, 16:16 + nd]).max() < 2e-3
+    # bit-identical to the default when nothing ends the loop early
+    again, _, _, _ = ora.batch_step_sweeps(st, act)
+    assert np.array_equal(again, full)
