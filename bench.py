@@ -524,6 +524,21 @@ def main():
     kern_ms = float(eng.timing()[3])      # k_fast alone: mean of the HIP event pairs the library records around it on its stream
     info = eng.kernel_info()
     episodes = float(torch.as_tensor(eng.get_state()[:, eng.x_off + 5]).mean()) if rank == 0 else 0.0
+    # (side key, SURVEY section 5 "metrics": contact-count histogram) which contact kinds the envs of the stationary batch are in, from the
+    # downloaded state of rank 0's first 16384 envs through the host-side restatement of the step's detection rule (model/contacts.py)
+    contact_hist = None
+    if rank == 0:
+        try:
+            from pybullet_robot_envs.model import contacts as _ct
+            from pybullet_robot_envs.model.table import panda_table as _pt
+            st_s = eng.get_state()[:16384]
+            fl = _ct.contact_flags(_pt()[0], st_s, eng.ndof, eng.get_physics())
+            nm = {_ct.OBJECT_TABLE: "object_table", _ct.ROBOT_OBJECT: "robot_object", _ct.ROBOT_TABLE: "robot_table"}
+            contact_hist = {"envs_sampled": int(st_s.shape[0]),
+                            "envs_by_contact_kinds": {("+".join(n for b, n in nm.items() if k & b) or "none"): int(c) for k, c in zip(*np.unique(fl, return_counts=True))},
+                            "note": "contact = distance below the contact margin (the step's own detection rule) in the state after the timed region"}
+        except Exception as e:      # informative only
+            contact_hist = {"error": repr(e)}
 
     # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows)
     no_gather = None
@@ -658,6 +673,7 @@ def main():
             "k_fast_variant": {"steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
                                "steps_with_the_pair_kernel_since_reset": info[10], "vgprs_pair_kernel": info[11],
                                "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3), and the pair kernel (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
+            "contact_histogram_rank0": contact_hist,
             "nan_inf_guard": {"bad_env_steps_since_create": info[12], "note": "env-steps whose state was not finite (pbre_kernel_info[12]); such envs are returned with done = 1 and restarted"},
             "shards": shards,
             "fresh_reset": clean(fresh) if fresh else None,
