@@ -295,6 +295,44 @@ def test_step_tensor_is_ordered_with_the_producing_stream(hip_lib):
     env.close(); ref.close()
 
 
+def test_sharding_invariance_at_the_headline_size(panda, hip_lib, simple_env_mapping, monkeypatch):
+    """BASELINE config 4 as a size-independent property: 131072 envs in ONE engine (k_fast, 2- and 3-wave builds, k_row_list) against the
+    same envs in two 65536-env shards with env_id_base 0 / 65536 (k_fast_pair steps their simple envs), the bench's stationary protocol
+    (de-synchronised episode clocks, i.i.d. actions, in-kernel auto-reset), 600 steps: output rows and final states bit for bit
+    (tools/diag_sharding_at_scale.py runs the same for 1500 steps)."""
+    import torch
+    if simple_env_mapping == "lane":
+        pytest.skip("one run: this test leaves the choice of the simple envs' kernel to the library")
+    monkeypatch.setenv("PBRE_PAIR", "2")          # the default: the pair kernel while its waves fit two per SIMD
+    n, h, steps = 131072, 65536, 600
+    kw = dict(task=1, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, flags=_capi.F_AUTO_RESET, seed=1234, lib=hip_lib)
+    whole = _capi.Engine(panda["table"], num_envs=n, **kw)
+    parts = [_capi.Engine(panda["table"], num_envs=h, env_id_base=k * h, **kw) for k in range(2)]
+    clocks = np.random.default_rng(4321).integers(0, 1000, n).astype(np.float32)
+    for e, sl in [(whole, slice(0, n))] + [(parts[k], slice(k * h, (k + 1) * h)) for k in range(2)]:
+        e.reset()
+        st = e.get_state(); st[:, e.x_off + 3] = clocks[sl]; e.set_state(st)
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(device=dev)
+    ow = whole.obs_dim + 2
+    out_w = torch.zeros((n, ow), device=dev); out_p = torch.zeros((n, ow), device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    with torch.cuda.stream(s):
+        for k in range(steps):
+            act = torch.rand((n, 7), device=dev, generator=gen) * 2 - 1
+            whole.step_device(act.data_ptr(), out_w.data_ptr(), s.cuda_stream)
+            for j in range(2):
+                parts[j].step_device(act[j * h:(j + 1) * h].data_ptr(), out_p[j * h:(j + 1) * h].data_ptr(), s.cuda_stream)
+            if k % 100 == 99:
+                s.synchronize()
+                assert torch.equal(out_w, out_p), "output rows differ at step %d" % k
+    assert np.array_equal(whole.get_state(), np.concatenate([p.get_state() for p in parts]))
+    iw, ip = whole.kernel_info(), parts[0].kernel_info()
+    assert ip[10] >= steps and iw[10] == 0, "the shards are stepped by the pair kernel, the whole batch by k_fast"
+    assert iw[7] > 2 * steps and iw[12] == 0 and ip[12] == 0       # complex envs throughout (8.4 k env-steps of them in the run of record); no NaN / Inf
+    print("sharding at scale: complex env-steps %d, 3-wave steps %d, pair steps per shard %d" % (iw[7], iw[8], ip[10]))
+
+
 def test_config2_reach_without_object(panda, hip_lib):
     """BASELINE config 2: Panda reach, 4096 envs, object frozen and contact-free (free-space dynamics only)."""
     n = 4096
