@@ -42,7 +42,7 @@ ALG_FLOP_PER_ENV_STEP = 150 * 232 + 8400.0 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
-PROFILE_TAG = "r04"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
+PROFILE_TAG = "r05"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
 
 
 def _profile(name, key=None):
@@ -400,6 +400,9 @@ def main():
                 t = tc
         return [float(v) for v in t]
 
+    def clean(d):
+        return dict((k, v) for k, v in d.items() if not k.startswith("_"))
+
     class Job(object):
         """One sharded batch: engine, resident action pool for the timed steps, double-buffered output rows, pipelined gather."""
 
@@ -492,8 +495,25 @@ def main():
         def complex_frac(self):
             return self.eng.kernel_info()[5] / float(self.n_local)
 
-    def clean(d):
-        return dict((k, v) for k, v in d.items() if not k.startswith("_"))
+        def timed_with_residual_threshold(self, steps, thr=1e-7, settle=100):
+            """(side key) the same stationary batch stepped with Bullet's exit test of the sweep loop on (pbre_physics.solver_residual_threshold
+            = PyBullet's documented solverResidualThreshold default; the engine's default is 0 = all 150 sweeps): `settle` untimed steps, the
+            timed ones, the per-env sweep counts of the last step; then the threshold is switched off again."""
+            self.drain()
+            self.eng.set_physics(solver_residual_threshold=thr)
+            try:
+                for _ in range(settle):
+                    self.fresh.uniform_(-1, 1, generator=self.gen)
+                    self.step(act=self.fresh)
+                self.drain()
+                r = clean(self.timed(steps, 5))
+                sw = self.eng.get_sweeps()
+                r.update({"solver_residual_threshold": thr, "sweeps_last_step": {"median": float(np.median(sw)), "mean": float(sw.mean()), "p90": float(np.percentile(sw, 90)),
+                                                                               "frac_at_the_cap": float((sw >= 150).mean())}})
+            finally:
+                self.drain()
+                self.eng.set_physics(solver_residual_threshold=0.0)
+            return r
 
     total = args.envs
     job = Job(total, 2 * (args.steps + args.warmup))
@@ -514,7 +534,11 @@ def main():
     rep = [head["ms_per_step"]] + [job.timed(args.steps, 0)["ms_per_step"] for _ in range(5)]
     repeats = {"ms_per_step": {"median": float(np.median(rep)), "min": float(np.min(rep)), "max": float(np.max(rep))}, "samples": len(rep),
                "value_at_median": total * 1e3 / float(np.median(rep)),
-               "note": "sample 0 is the headline's timed region (exactly --steps steps); the others repeat it on the same stationary batch"}
+               "note": "six timed regions of exactly --steps steps each on the same stationary batch, back to back (sample 0 with HIP event pairs around every 8th step); `value` is the median's"}
+    # `value` / `ms_per_step`: the MEDIAN of these six timed regions of exactly --steps steps each (the driver's 20 steps are a 4 ms region; a
+    # single one carries the box's scheduling noise); the first region alone is kept as `first_timed_region`
+    first_region = {"ms_per_step": head["ms_per_step"], "value": head["value"]}
+    head["ms_per_step"] = float(np.median(rep)); head["value"] = total * 1e3 / head["ms_per_step"]
     steps_before = job.steps_done - args.steps
     complex_after = job.complex_frac()
     finite = bool(torch.isfinite(job.pipe.out[0]).all() and torch.isfinite(job.pipe.out[1]).all())
@@ -540,6 +564,14 @@ def main():
         except Exception as e:      # informative only
             contact_hist = {"error": repr(e)}
 
+    # (side key, N = 1) Bullet's residual exit on: the stationary batch at the headline size
+    rt_side = None
+    if world == 1 and os.environ.get("PBRE_BENCH_NO_RT") != "1":
+        try:
+            rt_side = {str(total): job.timed_with_residual_threshold(max(args.steps, 50))}
+        except Exception as e:
+            rt_side = {"error": repr(e)}
+
     # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows)
     no_gather = None
     if world > 1:
@@ -564,7 +596,7 @@ def main():
             ms = eng.timing()
             host = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3,
                     "h2d_ms": ms[0], "kernels_ms": ms[1], "d2h_ms": ms[2],
-                    "note": "Engine.step(): numpy actions in, [obs|reward|done] rows out through pinned staging buffers (PCIe-bound); never `value`"}
+                    "note": "SURVEY 8(d) literal metric: Engine.step(), numpy actions in, [obs|reward|done] rows out through page-locked host buffers (PCIe-bound); never `value`, which is device-resident stepping (pbre_step_device)"}
         except Exception as e:
             host = {"error": repr(e)}
     del job
@@ -604,6 +636,8 @@ def main():
                                      "fresh_env_steps_per_s": fr["value"], "stationary_env_steps_per_s": stt["value"],
                                      "complex_envs_per_step": ((inf[7] - c0) % (1 << 31)) / 205.0,
                                      "simple_env_kernel": "k_fast_pair (robot wave + object wave per 64 envs)" if inf[10] > 0 else "k_fast"}
+                if n_sh == 16384 and isinstance(rt_side, dict) and "error" not in rt_side:
+                    rt_side[str(n_sh)] = js.timed_with_residual_threshold(200)
                 del js
             one = head["ms_per_step"]
             shards["projection"] = {"stationary_speedup_vs_one_gpu": {str(TOTAL_ENVS // int(k)): one / v["stationary_ms_per_step"] for k, v in shards.items() if k.isdigit()},
@@ -669,7 +703,10 @@ def main():
                        "complex_env_frac_rank0": complex_after, "complex_envs_per_step_timed_region_rank0": complex_per_step,
                        "done_frac_last_step_rank0": done_frac,
                        "mean_episodes_completed_per_env_rank0": episodes},
-            "repeats": repeats,
+            "repeats": repeats, "first_timed_region": first_region,
+            "solver_residual_threshold_1e-7": ({"stationary": rt_side,
+                                                "note": "side key: pbre_physics.solver_residual_threshold = 1e-7 (PyBullet's documented solverResidualThreshold default "
+                                                        "[EXT-UNVERIFIED]); `value` is measured with the engine's default 0 = all 150 sweeps (DESIGN.md section 2)"} if rt_side else None),
             "k_fast_variant": {"steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
                                "steps_with_the_pair_kernel_since_reset": info[10], "vgprs_pair_kernel": info[11],
                                "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3), and the pair kernel (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
@@ -680,7 +717,7 @@ def main():
             "steady_synchronised_clocks": sync_clocks,
             "weak_scaling_128k_per_gpu": weak,
             "sharded_consumers_no_gather": no_gather,
-            "host_inclusive": host,
+            "host_inclusive": host,      # SURVEY 8(d) literal: upload + kernels + download through the host-buffer entry point; `value` is device-resident stepping
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                          "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],

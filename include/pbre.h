@@ -89,6 +89,16 @@ typedef struct {
                                          (YcbTennisBall, pear, strawberry stand-ins: they roll).  CYLINDER: about the object's local z,
                                          radius obj_h[0], half height obj_h[2] (the cans, duck_vhacd).  Round objects are stepped by the
                                          per-env object solver / the lane-group kernels (every engine), never by k_fast's in-line cube rows. */
+    double  solver_residual_threshold; /* PyBullet's setPhysicsEngineParameter(solverResidualThreshold=...), Bullet's
+                                         btContactSolverInfo::m_leastSquaresResidualThreshold: an env leaves the sweep loop after the first
+                                         sweep whose largest squared velocity-level row change, max over the rows of (delta impulse /
+                                         jacDiagABInv)^2, is <= this value.  0 (default): all `solver_iters` sweeps -- the strict reading of
+                                         `numSolverIterations=150` (R/envs/panda_envs/panda_push_gym_env.py:122), which leaves the threshold
+                                         at PyBullet's default; PyBullet documents that default as 1e-7 [EXT-UNVERIFIED: no PyBullet on any
+                                         box so far], so a PyBullet-pinned comparison may need 1e-7 here.  With a value > 0 every env's
+                                         constraint system is swept as ONE system (no closed form of the motor block, no split of an env
+                                         over two waves, no lane-per-env iCub pipeline): the exit test is a maximum over all of its rows.
+                                         The sweeps each env ran in the last step: pbre_get_sweeps. */
 } pbre_physics;
 
 typedef struct {
@@ -233,6 +243,9 @@ int pbre_set_motor_state(pbre_ctx* ctx, const float* motors);
  * episodes; batch-uniform).  The object must stay a cube (isotropic inertia) for the lane-per-env kernels. */
 int pbre_set_physics(pbre_ctx* ctx, const pbre_physics* phys);
 int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
+/* pbre_physics.solver_residual_threshold > 0: the number of sweeps every env's solver ran in the most recent simulation step
+ * (1..solver_iters; solver_iters when the test never fired), host [num_envs] int32.  PBRE_E_UNSUPPORTED while the threshold is 0. */
+int pbre_get_sweeps(pbre_ctx* ctx, int32_t* sweeps);
 
 /* Per-env domain randomisation of the object (replaces the per-env, per-episode p.changeDynamics(obj_id, mass=, lateralFriction=,
  * linearDamping=) of change_physics_params, R/envs/panda_envs/panda_push_gym_env.py:362-364, as the reference's Dyn-Rand training

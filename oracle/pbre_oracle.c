@@ -530,6 +530,7 @@ typedef struct {
 } row_t;
 
 static __thread int g_last_sweeps[2];      /* sweeps_used, sweeps_to_1e7 of this thread's last simulation step (orc_batch_step_sweeps) */
+void orc_last_sweeps(int out[2]) { out[0] = g_last_sweeps[0]; out[1] = g_last_sweeps[1]; }
 static real resolve_row(row_t* r, real* dvA, real* dvB, int nd) {
     /* btMultiBodyConstraintSolver::resolveSingleConstraintRowGeneric, cfm = 0 */
     real delta = r->rhs, dot = 0;

@@ -185,6 +185,9 @@ void orc_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
 /* Bullet pure-math helpers used by the observation code */
 void orc_quat_from_euler(const real e[3], real q[4]);
 void orc_euler_from_quat(const real q[4], real e[3]);
+/* sweeps_used, sweeps_to_1e7 (orc_step_info) of the calling thread's most recent simulation step */
+void orc_last_sweeps(int out[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,7 +74,8 @@ static_assert((int)CoreD::M_INNER == (int)FastD::M_INNER && (int)CoreD::M_TGT ==
 // ------------------------------------------------------------------ kernels
 // General row kernel.  n = real env count; state has ceil16(n) + 16 records (the last 16 are valid dummy records for the
 // padding rows of a partially filled block); actions/out rows of padding rows are redirected to env 0 / a scratch row.
-template <int MODE>
+// RT (all step kernels): pbre_physics.solver_residual_threshold > 0 -- the variants with Bullet's exit test of the sweep loop
+template <int MODE, bool RT = false>
 __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                               const float* __restrict__ actions, float* __restrict__ out,
                                               float* __restrict__ scratch_row, int n, int dummy_base, int act_dim, int ow, int flags,
@@ -89,8 +90,8 @@ __global__ __launch_bounds__(TPB) void k_step(const Tables* __restrict__ T, cons
     if (MODE & CoreD::M_ACTION) a = actions + (size_t)(real ? env : 0) * act_dim;
     if (MODE & CoreD::M_OBS) o = real ? out + (size_t)env * ow : scratch_row;
     // (padding rows: pristine dummy record in, scratch record out -- see k_row_list)
-    CoreD::step(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, P.env_id_base + (unsigned long long)env, nullptr,
-                real ? nullptr : st + (size_t)EPB * STATE);
+    CoreD::step<RT>(*T, P, st, a, o, MODE, flags, (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, P.env_id_base + (unsigned long long)env, nullptr,
+                    real ? nullptr : st + (size_t)EPB * STATE, (RT && real && P.sweeps) ? P.sweeps + env : nullptr);
 }
 
 // Complex envs are kept in NB = NCLASS - 1 bucket lists (one per class, see Fast::classify) so that the waves of
@@ -114,7 +115,7 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 // (131072 envs = 2048 waves = 1024 SIMDs x 2): there the displaced k_fast waves of the 2-wave variant run in a second round
 // (0.249 ms per stationary step against 0.220 ms with this variant; right after reset(), without complex envs, 0.157 against 0.187).
 // launch_step picks per step.
-template <int MODE, int WPS = PBRE_FAST_WAVES>
+template <int MODE, int WPS = PBRE_FAST_WAVES, bool RT = false>
 __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
     const int env = blockIdx.x * FTPB + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
-    const int c = FastD::step(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+    const int c = FastD::step<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                                  (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                                  (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
     publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
 }
 
@@ -180,7 +181,7 @@ static __device__ __forceinline__ void report_hint(int total, int* __restrict__ 
     host_total[0] = total; host_total[1] = r;
 }
 
-template <int MODE>
+template <int MODE, bool RT = false>
 __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
@@ -196,9 +197,9 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
         const int i = k * FTPB + threadIdx.x;
         if (i < cur_count[b]) {
             const int env = cur_list[(size_t)b * cap + i];
-            const int c = FastD::step_rc(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                         (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                                         (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr);
+            const int c = FastD::step_rc<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                                             (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                                             (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
             publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
         }
     }
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
 // wave the object wave shared its SIMD with a row wave and both ran at little more than half their lone speed (measured, phase probe).
 constexpr int REPB = 12;             // envs per block of k_row_list
 constexpr int RTPB = REPB * W + FTPB;
-template <int MODE>
+// (RT: the object wave idles -- Bullet's exit test is a maximum over ALL rows of an env, so the object's rows stay in the row wave's solve)
+template <int MODE, bool RT = false>
 __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                   const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
                                                   const int* __restrict__ cur_list, const int* __restrict__ cur_count,
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
     const int total0 = cur_count[0], total1 = NB > 1 ? cur_count[NB > 1 ? 1 : 0] : 0;
     const int items0 = (total0 + REPB - 1) / REPB, items1 = (total1 + REPB / 4 - 1) / (REPB / 4);
     if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total0 + total1, recent, host_total);
-    const bool obj_on = !(flags & 1);
+    const bool obj_on = !(flags & 1) && !RT;      // (here: "the object wave solves the objects of the block's envs")
     const bool obj_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= REPB * W)) != 0;
     const int row = obj_wave ? (int)threadIdx.x - REPB * W : (int)(threadIdx.x >> 4);
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
@@ -270,8 +272,9 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
                 __syncthreads();                                                 // pairs with PBRE_OBJV_SYNC in the row waves' Core::step
             }
         } else {
-            CoreD::step(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
-                        (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull, obj_on ? &objv[row][0] : nullptr, st_idle);
+            CoreD::step<RT>(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
+                            (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull, obj_on ? &objv[row][0] : nullptr, st_idle,
+                            (RT && real && P.sweeps) ? P.sweeps + env : nullptr);
             __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
             PBRE_PROBE_DECL
             if (real && (threadIdx.x & 15u) == 0) {
@@ -380,6 +383,7 @@ struct pbre_ctx {
     EnvBuf main, tmp;
     float *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     int* d_bad = nullptr;              // NaN / Inf guard: env-steps that met a non-finite state (Params::bad_count)
+    int* d_sweeps = nullptr;           // [npad] sweeps every env's solver ran in the last step (Params::sweeps; pbre_physics.solver_residual_threshold > 0)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
     int n_simd = 1024;
@@ -474,12 +478,12 @@ static hipError_t classify(pbre_ctx* c, EnvBuf& b, int n, int flags, hipStream_t
 }
 
 // one batched step of the first n envs of b on stream s
-template <int MODE>
-static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
+template <int MODE, bool RT>
+static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
     if (!lane_per_env(c)) {
         hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
         (void)hipEventRecord(ek[0], s);
-        hipLaunchKernelGGL(k_step<MODE>, dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
+        hipLaunchKernelGGL((k_step<MODE, RT>), dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
                            c->act_dim, c->ow, flags, b.tgt);
         (void)hipEventRecord(ek[1], s);
         c->k_steps++;
@@ -522,12 +526,12 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
             // of it (the 201 launches of a reset are enqueued in ~1 ms) sizes every launch by a count that may be a hundred steps old --
             // 16384 envs that had all become complex meanwhile were walked by 8 blocks, 11 ms per launch.  Blocks without work exit at once.
             const int rblocks = std::max(64, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
-            hipLaunchKernelGGL(k_row_list<MODE>, dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+            hipLaunchKernelGGL((k_row_list<MODE, RT>), dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
     }
     if (!rows)
-        hipLaunchKernelGGL(k_fast_rc<MODE>, dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast_rc<MODE, RT>), dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                            b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.count + 3 * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
@@ -545,20 +549,20 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     }
     // small batches: the pair kernel (two waves per 64 envs) while all of its waves are resident at once, two per SIMD at most
     bool pair = false;
-    if (c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
+    if (!RT && c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
         pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
     if (pair) {
         c->launches_pair++;
-        if constexpr (!(MODE & FastD::M_INNER))      // (the inner iterations of action_repeat > 1 stay on k_fast: not instantiated)
+        if constexpr (!(MODE & FastD::M_INNER) && !RT)      // (the inner iterations of action_repeat > 1 stay on k_fast: not instantiated; RT: one lane per env)
         hipLaunchKernelGGL((k_fast_pair<MODE>), dim3(blocks), dim3(PTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     } else {
     if (fast3) c->launches3++;
     if (fast3)
-        hipLaunchKernelGGL((k_fast<MODE, 3>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast<MODE, 3, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     else
-        hipLaunchKernelGGL((k_fast<MODE, 2>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast<MODE, 2, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -573,6 +577,11 @@ static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, f
     b.ccur = cn;
     b.cur = nxt;
     return hipSuccess;
+}
+
+template <int MODE>
+static hipError_t launch_step(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
+    return c->P.res_lim > 0.f ? launch_step_t<MODE, true>(c, b, n, act, out, flags, s) : launch_step_t<MODE, false>(c, b, n, act, out, flags, s);
 }
 
 // settle steps (hold motors; IK mode: hold the IK targets)
@@ -622,7 +631,7 @@ void pbre_destroy(pbre_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     free_buf(c->main); free_buf(c->tmp);
-    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask, (void*)c->d_bad})
+    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask, (void*)c->d_bad, (void*)c->d_sweeps})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -696,6 +705,9 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     CK(hipMalloc(&c->d_bad, 2 * sizeof(int)));
     CK(hipMemset(c->d_bad, 0, 2 * sizeof(int)));
     c->P.bad_count = c->d_bad;
+    CK(hipMalloc(&c->d_sweeps, (size_t)c->npad * sizeof(int)));
+    CK(hipMemset(c->d_sweeps, 0, (size_t)c->npad * sizeof(int)));
+    c->P.sweeps = c->d_sweeps;
     CK(hipMalloc(&c->d_ids, (size_t)(c->npad + EPB) * sizeof(unsigned long long)));
     CK(hipMalloc(&c->d_ep, (size_t)(c->npad + EPB) * sizeof(unsigned)));
     CK(hipMalloc(&c->d_idx, (size_t)c->npad * sizeof(int)));
@@ -956,6 +968,15 @@ int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
     if (c->wide) return wide_get_physics(c->wide, phys);
     *phys = c->cfg.phys;
+    return PBRE_OK;
+}
+int pbre_get_sweeps(pbre_ctx* c, int32_t* sweeps) {
+    if (!c || !sweeps) return PBRE_E_ARG;
+    if (c->wide) return wide_get_sweeps(c->wide, sweeps);
+    if (!(c->P.res_lim > 0.f)) { c->err = "pbre_get_sweeps: pbre_physics.solver_residual_threshold is 0 (every env runs all solver_iters sweeps)"; return PBRE_E_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
+    HIPCHK(hipMemcpy(sweeps, c->d_sweeps, (size_t)c->n * sizeof(int), hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
 int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {

@@ -425,22 +425,25 @@ struct Core {
     // app / lim are group-uniform; L::uni tells a backend that stores a value in more than one register per lane so
     // OBJ: the row only touches the object (object-table contacts): its J' is zero on every robot lane, which lets a backend
     // use a cheaper all-reduce (L::sum_obj; same value bit for bit)
+    // (both return the row's impulse change, group-uniform: what the residual test of step<RT> looks at)
     template <bool OBJ = false>
-    static PBRE_HD void row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
+    static PBRE_HD F row(F Jp, F Bv, F& app, F lo, F hi, F& dv) {
         app = L::uni(app);
         F t = (OBJ && LC >= 16) ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);      // (sum_obj: the object lanes lie in the upper 16-lane row)
         F s = L::med3(app - t, lo, hi);
         F d = s - app; app = s;
         dv = L::fma(d, Bv, dv);
+        return d;
     }
     template <bool OBJ = false>
-    static PBRE_HD void frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
+    static PBRE_HD F frow(F Jp, F Bv, F& app, F lim, F& dv) {   // friction row, skipped when normal impulse <= 0
         app = L::uni(app); lim = L::uni(lim);
         F t = (OBJ && LC >= 16) ? L::sum_obj(Jp * dv) : L::sum(Jp * dv);      // (sum_obj: the object lanes lie in the upper 16-lane row)
         F s = L::med3(app - t, L::c(0.f) - lim, lim);
         s = L::sel(L::gt(lim, L::c(0.f)), s, app);
         F d = s - app; app = s;
         dv = L::fma(d, Bv, dv);
+        return d;
     }
 
     // One simulation step for one env group.  st: pointer to the env's 48-float record.
@@ -449,8 +452,15 @@ struct Core {
     // robot-object contact (pbre_objstep.hpp); used by the groups that have no such contact.
     // st_out: where the new state goes (default: back into st).  The row kernels' idle rows read a pristine record and write a scratch one,
     // so that what they compute in lockstep with the real rows stays the cheapest step there is (see k_row_list).
+    // RT (pbre_physics.solver_residual_threshold > 0; Bullet's m_leastSquaresResidualThreshold [EXT-UNVERIFIED], oracle:
+    // orc_params.solver_residual_threshold): a group leaves the sweep loop after the first sweep whose largest velocity-level row change
+    // |delta impulse / jacDiagABInv|, over all of its rows, is <= P.res_lim.  Its velocity vector is snapshotted there; the wave goes on
+    // until its last group is through, and what a group computes does not depend on its wave-mates.  sw: where the group's sweep count
+    // goes (or null).  Callers pass objv = nullptr: the test is over ALL rows of an env, so the object's rows stay in this solve.
+    template <bool RT = false>
     static PBRE_HD void step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                             const float* tgt = nullptr, unsigned long long env_id = 0, const float* objv = nullptr, float* st_out = nullptr) {
+                             const float* tgt = nullptr, unsigned long long env_id = 0, const float* objv = nullptr, float* st_out = nullptr,
+                             int* sw = nullptr) {
         const I lane = L::lane();
         const F zero = L::c(0.f), one = L::c(1.f);
         const B robot = L::lti(lane, NJ);
@@ -734,11 +744,14 @@ struct Core {
         }
 
         // ---- constraint rows
+        FR m_diag = oneR;            // RT: (M^-1)_jj on lane j = 1 / dinv of joint j's motor and limit rows
+        F r_den[NC][3];              // RT: 1 / dinv of the contact rows (group-uniform; dead code without RT)
         // motors (btMultiBodyJointMotor, POSITION_CONTROL): velocity error kp (q_des - q)/dt - kd v*
         {
             FR diag = oneR;                                 // this lane's diagonal entry of M^-1 (1 on lanes without a joint)
             PBRE_UNROLL for (int j = 0; j < NJ; j++) diag = LR::sel(LR::eqi(laneR, j), R.Mi[j], diag);
             F dinv = L::wide(oneR / diag);
+            if (RT) m_diag = diag;
             B live = L::band(robot, L::nei(L::loadI(T.jtype), 0));
             R.m_dinv = L::lo(L::sel(live, dinv, zero));
             F verr = kp * (qdes - q) * inv_dt - kd * vstar;
@@ -766,6 +779,7 @@ struct Core {
         PBRE_UNROLL for (int c = 0; c < NC; c++) {
             const int type = c < NC_OT ? 0 : (c < NC_OT + NC_RO ? 1 : 2);
             R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero;
+            PBRE_UNROLL for (int d = 0; d < 3; d++) r_den[c][d] = zero;
             if (type == 0 && split_all) {
                 R.act[c] = L::lti(lane, 0); R.mu[c] = L::uni(zero);
                 PBRE_UNROLL for (int k = 0; k < 6; k++) R.rs.put(6 * c + k, zero);
@@ -818,6 +832,7 @@ struct Core {
                 F denom = L::sum(J * Bv);
                 F rel = L::sum(J * vstar);
                 F dinv = L::sel(cc.act, one / L::sel(cc.act, denom, one), zero);
+                r_den[c][d] = L::uni(L::sel(cc.act, denom, zero));
                 F rhs;
                 if (d == 0) {   // setupMultiBodyContactConstraint, restitution 0
                     F pen = cc.dist + L::c(P.slop);
@@ -840,11 +855,16 @@ struct Core {
         // a motor / limit row touches one DoF only: every lane evaluates the row it owns, lane j's update is the one
         // applied (Gauss-Seidel order is kept by the sequence of calls)
         constexpr bool FREE_ROWS = SH::W == 32 || SH::MREC;       // iCub shapes: clamp-free motor rows first, see below (16-lane Panda rows: no gain)
+        // RT bookkeeping: lane j of m_dsw / l_dsw holds the impulse change of joint j's motor / limit row in the current sweep, lsr the
+        // largest |impulse change / dinv| of its contact rows so far (group-uniform)
+        FR m_dsw = zeroR, l_dsw = zeroR;
+        F lsr = zero;
         auto motor = [&](int j) {
             FR t = LR::fma(R.m_dinv, L::lo(dv), zeroR - R.m_rhs);
             FR s = LR::med3(R.m_app - t, nmlim, R.m_lim);
             FR d = s - R.m_app;
             R.m_app = LR::setlane(R.m_app, j, s);
+            if constexpr (RT) m_dsw = LR::setlane(m_dsw, j, d);
             dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
         auto limit = [&](int j) {
@@ -852,24 +872,26 @@ struct Core {
             FR s = LR::med3(R.l_app - t, zeroR, llim);
             FR d = s - R.l_app;
             R.l_app = LR::setlane(R.l_app, j, s);
+            if constexpr (RT) l_dsw = LR::setlane(l_dsw, j, d);
             dv = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dv);      // (bcast_row here: no gain with IK control, where limit rows are frequent)
         };
+        auto res_of = [&](int c, int d, F dd) { if constexpr (RT) lsr = L::max(lsr, L::abs(dd * r_den[c][d])); };
         bool on[NC];                         // some group of the wave has contact c
         unsigned on_bits = 0u;               // the same as a scalar bit mask: tested with one SALU instruction per slot inside the loop
         PBRE_UNROLL for (int c = 0; c < NC; c++) { on[c] = L::any(R.act[c]); on_bits |= on[c] ? (1u << c) : 0u; }
         auto contacts = [&]() {
             PBRE_UNROLL for (int c = 0; c < NC; c++) if ((on_bits >> c) & 1u) {
-                if (c < NC_OT) row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
-                else row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+                if (c < NC_OT) res_of(c, 0, row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv));
+                else res_of(c, 0, row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv));
             }
             PBRE_UNROLL for (int c = 0; c < NC; c++) if ((on_bits >> c) & 1u) {
                 F lim = R.mu[c] * R.an[c];
                 if (c < NC_OT) {
-                    frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
-                    frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                    res_of(c, 1, frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv));
+                    res_of(c, 2, frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv));
                 } else {
-                    frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
-                    frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                    res_of(c, 1, frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv));
+                    res_of(c, 2, frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv));
                 }
             }
         };
@@ -901,12 +923,34 @@ struct Core {
         bool only_ot = true;
         PBRE_UNROLL for (int c = 0; c < NC; c++) only_ot = only_ot && (on[c] == (c < NC_OT));
         auto contacts_ot = [&]() {
-            PBRE_UNROLL for (int c = 0; c < NC_OT; c++) row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv);
+            PBRE_UNROLL for (int c = 0; c < NC_OT; c++) res_of(c, 0, row<true>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dv));
             PBRE_UNROLL for (int c = 0; c < NC_OT; c++) {
                 F lim = R.mu[c] * R.an[c];
-                frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv);
-                frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv);
+                res_of(c, 1, frow<true>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dv));
+                res_of(c, 2, frow<true>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dv));
             }
+        };
+        // RT: end of sweep `it` (cur: the velocity vector as it stands).  Bullet's test, btSequentialImpulseConstraintSolver::
+        // solveGroupCacheFriendlyIterations: leastSquaresResidual <= m_leastSquaresResidualThreshold (both squared there).  A group that
+        // passes keeps a snapshot of its vector (and, where fingertip forces are reported, of its robot-object normal impulses); true once
+        // every group of the wave is through.
+        B rt_done = L::bfalse();
+        F rt_dv = zero, rt_used = L::c((float)P.iters);
+        F rt_an[NC_RO];
+        PBRE_UNROLL for (int c = 0; c < NC_RO; c++) rt_an[c] = zero;
+        auto sweep_end = [&](int it, F cur) -> bool {
+            const FR mres = LR::max(LR::abs(m_dsw * m_diag), LR::abs(l_dsw * m_diag));
+            const F res = L::max(L::sel(robot, L::wide(mres), zero), L::uni(lsr));
+            const F g = zero - L::vmin(zero - res);
+            const B newly = L::band(L::bnot(rt_done), L::le(g, L::c(P.res_lim)));
+            if (L::any(newly)) {
+                rt_dv = L::sel(newly, cur, rt_dv);
+                rt_used = L::sel(newly, L::c((float)(it + 1)), rt_used);
+                if (NTIP > 0) { PBRE_UNROLL for (int c = 0; c < NC_RO; c++) rt_an[c] = L::sel(newly, R.an[NC_OT + c], rt_an[c]); }
+                rt_done = L::bor(rt_done, newly);
+            }
+            m_dsw = zeroR; l_dsw = zeroR; lsr = zero;
+            return !L::any(L::bnot(rt_done));
         };
         // iCub shapes: in waves without robot contact rows the motor rows first run WITHOUT their clamp.  While a motor stays
         // inside its impulse bound (PyBullet's default force of 1e5 N is far out of these robots' reach) Bullet's row is
@@ -923,13 +967,14 @@ struct Core {
             FR nt = LR::fma(m_ndinv_x, L::lo(dv), R.m_rhs);
             FR d = LR::med3(nt, nmlim - R.m_app, R.m_lim - R.m_app);
             R.m_app = LR::setlane(R.m_app, j, R.m_app + d);
+            if constexpr (RT) m_dsw = LR::setlane(m_dsw, j, d);
             dv = L::fma_lo(LR::bcast(d, j), R.Mi[j], dv);
         };
         // (a shape with one env per wave has no neighbour to be independent of: its clamping rows stay the plain ones)
         auto mrow = [&](int j) { if (SH::W <= 32) motor_x(j); else motor(j); };
         bool solved = false;
         // (not attempted while some motor of the wave is force-limited -- grasping fingers, force 10: those do reach their bound)
-        if (FREE_ROWS && (only_ot || on_bits == 0u) && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
+        if (!RT && FREE_ROWS && (only_ot || on_bits == 0u) && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
             const FR m_ndinv = zeroR - R.m_dinv;
             bool over = false;
             FR dsel = zeroR;              // lane j: the delta of row j in the current sweep
@@ -1013,7 +1058,7 @@ struct Core {
                 constexpr int j = decltype(jc)::value, st = decltype(sc)::value;
                 if constexpr (st == 0) { m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs); m_lo = nmlim - R.m_app; m_hi = R.m_lim - R.m_app; }
                 else if constexpr (st == 1) m_d = LR::med3(m_nt, m_lo, m_hi);
-                else if constexpr (st == 2) { R.m_app = LR::setlane(R.m_app, j, R.m_app + m_d); m_bc = LR::bcast(m_d, j); }
+                else if constexpr (st == 2) { R.m_app = LR::setlane(R.m_app, j, R.m_app + m_d); m_bc = LR::bcast(m_d, j); if constexpr (RT) m_dsw = LR::setlane(m_dsw, j, m_d); }
                 else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
             };
             auto limit2 = [&](int j) {
@@ -1021,11 +1066,13 @@ struct Core {
                 FR s_ = LR::med3(R.l_app - t, zeroR, llim);
                 FR d = s_ - R.l_app;
                 R.l_app = LR::setlane(R.l_app, j, s_);
+                if constexpr (RT) l_dsw = LR::setlane(l_dsw, j, d);
                 dvr = L::fma_lo(LR::bcast(d * R.l_dir, j), R.Mi[j], dvr);
             };
             // ---- a contact row (row<> / frow<>) in 9 stages on one of the vectors; Fly: the row in flight
-            struct Fly { F p, s, lo, hi; };
+            struct Fly { F p, s, lo, hi, res; };      // (res, RT: the chain's largest |impulse change / dinv| of the sweep)
             Fly fr, fo;                   // robot chain / object chain
+            fr.res = zero; fo.res = zero;
             // ROW: index of the row's J' in the row store (B follows); FRIC: friction row (bound +-lim, skipped while the normal impulse is 0)
             // OBJ: an object-table row.  Its J' is non-zero on lanes LC..L1 only, all in the upper half of the 16-lane row (LC >= 8), so
             // three butterfly stages already leave the whole sum on those lanes (the fourth would add the lower half's exact zero); the
@@ -1041,7 +1088,7 @@ struct Core {
                 else if constexpr (st <= 4) f.p = L::sum_step(f.p, st - 1);
                 else if constexpr (st == 5) f.s = app - f.p;
                 else if constexpr (st == 6) { f.s = L::med3(f.s, f.lo, f.hi); if (FRIC) f.s = L::sel(L::gt(f.hi, zero), f.s, app); }
-                else if constexpr (st == 7) { f.p = f.s - app; app = f.s; }
+                else if constexpr (st == 7) { f.p = f.s - app; app = f.s; if constexpr (RT) f.res = L::max(f.res, L::abs(f.p * r_den[ROW / 6][(ROW % 6) / 2])); }
                 else vec = L::fma(f.p, R.rs.get(ROW + 1), vec);
             };
             static_assert(LC >= 8 && L1 < 16, "object lanes in the upper half of the row");
@@ -1071,8 +1118,8 @@ struct Core {
             };
             // (RTn || OTf)
             auto phase_c = [&](auto rt_c) {
-                constexpr bool RT = decltype(rt_c)::value;
-                constexpr int NR = RT ? NSR * NC_RT : 0, NO = NSO * 2 * NC_OT, NZ = NR > NO ? NR : NO;
+                constexpr bool RTAB = decltype(rt_c)::value;
+                constexpr int NR = RTAB ? NSR * NC_RT : 0, NO = NSO * 2 * NC_OT, NZ = NR > NO ? NR : NO;
                 for_seq<NZ>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k < NR) nstage(fr, dvr, std::integral_constant<int, NRT0 + k / NSR>{}, std::integral_constant<int, k % NSR>{});
@@ -1082,16 +1129,21 @@ struct Core {
             auto coupled = [&](bool fric) {       // robot-object rows on the merged vector
                 F dvc = L::sel(obj_lane, dvo, dvr);
                 PBRE_UNROLL for (int c = NC_OT; c < NC_OT + NC_RO; c++) if ((on_bits >> c) & 1u) {
-                    if (!fric) row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvc);
+                    if (!fric) res_of(c, 0, row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvc));
                     else {
                         F lim = R.mu[c] * R.an[c];
-                        frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvc);
-                        frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvc);
+                        res_of(c, 1, frow<false>(R.rs.get(6 * c + 2), R.rs.get(6 * c + 3), R.a1[c], lim, dvc));
+                        res_of(c, 2, frow<false>(R.rs.get(6 * c + 4), R.rs.get(6 * c + 5), R.a2[c], lim, dvc));
                     }
                 }
                 dvr = L::sel(obj_lane, zero, dvc); dvo = L::sel(robot, zero, dvc);
             };
             // (the rows of a robot-table slot no group of the wave uses are exact no-ops: J' = B = 0)
+            // RT: end of a sweep of the two chains (their residuals merged into lsr, the vector as it stands: object lanes from dvo)
+            auto chains_end = [&](int it) -> bool {
+                lsr = L::max(lsr, L::max(fr.res, fo.res)); fr.res = zero; fo.res = zero;
+                return sweep_end(it, L::sel(obj_lane, dvo, dvr));
+            };
             auto rt_f = [&]() { for_seq<2 * NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{}); }); };
             if (robot_only) {
                 robot_only_path = true;
@@ -1104,14 +1156,16 @@ struct Core {
                     motors(std::true_type{});
                     if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
                     if (rt_bits) { rt_n(); rt_f(); }
+                    if constexpr (RT) { if (chains_end(it)) break; }
                     if (it + 1 >= P.iters) break;
                     if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j); }
                     motors(std::false_type{});
                     if (rt_bits) { rt_n(); rt_f(); }
+                    if constexpr (RT) { if (chains_end(it + 1)) break; }
                 }
                 dv = dvr;
             } else {
-            const bool e_zip = rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows
+            const bool e_zip = !RT && rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows (RT: a sweep ends where Bullet's does)
             auto mid = [&]() {            // the rest of a sweep after its motor / limit / OT-normal rows
                 if (ro_bits) coupled(false);
                 if (rt_bits) phase_c(std::true_type{}); else phase_c(std::false_type{});
@@ -1122,12 +1176,14 @@ struct Core {
                 if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
                 if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
                 mid();
+                if constexpr (RT) { if (chains_end(it)) break; }
                 if (it + 1 >= P.iters) break;
                 if (has_limit) {          // odd sweep: limits first, then the motors in forward order
                     PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
                 }
                 if (e_zip) phase_a(std::false_type{}, std::true_type{}); else phase_a(std::false_type{}, std::false_type{});
                 mid();
+                if constexpr (RT) { if (chains_end(it + 1)) break; }
             }
             if (e_zip) rt_f();            // the last sweep's
             dv = L::sel(obj_lane, dvo, dvr);
@@ -1140,18 +1196,22 @@ struct Core {
                 PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
                 if (has_limit) limits_bwd();
                 contacts_ot();
+                if constexpr (RT) { if (sweep_end(it, dv)) break; }
                 if (it + 1 >= P.iters) break;
                 if (has_limit) limits_fwd();
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
                 contacts_ot();
+                if constexpr (RT) { if (sweep_end(it + 1, dv)) break; }
             }
         } else if (on_bits == 0u) {      // no contact row in the wave (the object rows are kw_obj's, or there is no object)
             for (int it = 0; it < P.iters; it += 2) {
                 PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
                 if (has_limit) limits_bwd();
+                if constexpr (RT) { if (sweep_end(it, dv)) break; }
                 if (it + 1 >= P.iters) break;
                 if (has_limit) limits_fwd();
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
+                if constexpr (RT) { if (sweep_end(it + 1, dv)) break; }
             }
         } else
         for (int it = 0; it < P.iters; it += 2) {
@@ -1159,11 +1219,18 @@ struct Core {
             PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) mrow(j);
             if (has_limit) limits_bwd();
             contacts();
+            if constexpr (RT) { if (sweep_end(it, dv)) break; }
             if (it + 1 >= P.iters) break;
             // odd iteration: forward order
             if (has_limit) limits_fwd();
             PBRE_UNROLL for (int j = 0; j < NJ; j++) mrow(j);
             contacts();
+            if constexpr (RT) { if (sweep_end(it + 1, dv)) break; }
+        }
+        if constexpr (RT) {           // a group that left the loop early: its snapshot
+            dv = L::sel(rt_done, rt_dv, dv);
+            if (NTIP > 0) { PBRE_UNROLL for (int c = 0; c < NC_RO; c++) R.an[NC_OT + c] = L::sel(rt_done, rt_an[c], R.an[NC_OT + c]); }
+            if (sw && L::lane0()) *sw = (int)L::first(rt_used);
         }
 
         PBRE_PROBE_PATH(solved ? 12 : (solved2 ? (robot_only_path ? 13 : 14) : 15));      // clamp-free / robot-only chain / two zipped chains / loops with per-slot tests

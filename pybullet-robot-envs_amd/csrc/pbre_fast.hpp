@@ -360,10 +360,13 @@ struct Fast {
             square(G, H);
         }
     }
+    // RT: pbre_physics.solver_residual_threshold > 0 (Bullet's exit test of the sweep loop, see step_t); sw: where the number of sweeps the
+    // env ran goes (Params::sweeps + the env's local index), or null
+    template <bool RT = false>
     static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                            unsigned long long env_id, const float* tgt) {
+                            unsigned long long env_id, const float* tgt, int* sw = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<false>(T, P, st, act, out, mode, flags, env_id, tgt);
+        return step_t<false, 0, RT>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr, 0, sw);
     }
     // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (`if self._termination():
     // break`, panda_push_gym_env.py:239-240; flag X[14]): no simulation step, only the evaluation of the state it is in
@@ -374,10 +377,11 @@ struct Fast {
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
         return finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id);
     }
+    template <bool RT = false>
     static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                               unsigned long long env_id = 0, const float* tgt = nullptr) {
+                               unsigned long long env_id = 0, const float* tgt = nullptr, int* sw = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
-        return step_t<true>(T, P, st, act, out, mode, flags, env_id, tgt);
+        return step_t<true, 0, RT>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr, 0, sw);
     }
     // ROLE (simple class only): 0 the whole step on one lane (k_fast); 1 / 2 the pair kernel's split of the same step over two waves of
     // a block -- the robot's half (kinematics, dynamics, motor rows, integration, then the observation of the new state) and the
@@ -385,10 +389,17 @@ struct Fast {
     // the split changes no operand of any operation: the results are those of ROLE 0 bit for bit (GPU test).  The object wave hands the
     // new object pose over in LDS (px, lane ln); small batches -- every wave alone on its SIMD -- step in max(robot, object) + the
     // observation instead of their sum.
-    template <bool RC, int ROLE = 0>
+    // RT (pbre_physics.solver_residual_threshold > 0; PyBullet's solverResidualThreshold, Bullet's m_leastSquaresResidualThreshold
+    // [EXT-UNVERIFIED], oracle: orc_params.solver_residual_threshold): the env leaves the sweep loop after the first sweep whose largest
+    // velocity-level row change |delta impulse / jacDiagABInv| -- over ALL of its rows: motors, limits, normals, frictions -- is
+    // <= P.res_lim.  The test couples the blocks of the simple class, so the motor rows run sequentially next to the object's rows (no
+    // closed form, no split over two waves); a lane that has left the loop keeps a snapshot of its velocities while its wave-mates go on
+    // (what an env computes does not depend on the lanes it shares a wave with).  The sweeps run are reported through `sw`.
+    template <bool RC, int ROLE = 0, bool RT = false>
     static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
-                              unsigned long long env_id, const float* tgt, PairX* px = nullptr, int ln = 0) {
+                              unsigned long long env_id, const float* tgt, PairX* px = nullptr, int ln = 0, int* sw = nullptr) {
         static_assert(ROLE == 0 || !RC, "the pair kernel steps the simple class");
+        static_assert(ROLE == 0 || !RT, "the residual test is a maximum over all rows of an env: one lane steps the whole env");
         constexpr bool ROBOT = ROLE != 2, OBJECT = ROLE != 1;
         constexpr int NR = RC ? NC_RO + NC_RT : 1;      // robot-contact slots: [0, NC_RO) object, [NC_RO, NR) table
         constexpr int NKO = RC ? NC_RO : 1, NKT = RC ? NC_RT : 1;
@@ -517,8 +528,8 @@ struct Fast {
             }
         }
         // (simple class: M itself is needed once more, for the impulse bound of the motor rows' closed form)
-        float M0[RC ? 1 : ND * (ND + 1) / 2];
-        if (!RC && ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
+        float M0[(RC || RT) ? 1 : ND * (ND + 1) / 2];
+        if (!RC && !RT && ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle
         if (ROBOT) PBRE_UNROLL for (int k = 0; k < ND; k++) {
             const float pv = 1.f / Mi[sym(k, k)];
@@ -565,15 +576,17 @@ struct Fast {
         }
 
         const float mlim = P.motor_imp;
+        float lsr = 0.f;      // RT: the sweep's largest |delta impulse / jacDiagABInv| so far (a motor / limit row on joint j: / dinv = * (M^-1)_jj)
         // motor row in delta form: clamp(applied + delta) - applied = clamp(delta, lo - applied, hi - applied), so a row whose clamp
         // does not bind returns Bullet's delta = rhs' - dinv w_j bit for bit -- the same value the closed form reproduces
         auto motor = [&](int j) {
             const float nt = fmaf(-m_dinv[j], wget(w, j), m_rhs[j]);
             const float d = med3(nt, -mlim - m_app[j], mlim - m_app[j]);
             m_app[j] += d;
+            if constexpr (RT) lsr = fmaxf(lsr, fabsf(d * Mi[sym(j, j)]));
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
-        if (!RC && ROBOT) {
+        if (!RC && !RT && ROBOT) {
             // ---- simple class, motor block (see the solver section below for the why and the validity bound)
             const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
             bool over = true;
@@ -631,9 +644,10 @@ struct Fast {
         // per row: 1/(J M^-1 J^T) and the accumulated impulse; the normal row also carries its positional rhs.  The object's
         // inertia is isotropic (checked at create time, fast_eligible()), so M^-1 J^T = [dir/m ; (r x dir)/I] needs no storage.
         float r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
+        float r_den[RT ? NK : 1][3];      // RT: 1 / dinv of the row (in the scaled units the object rows work in)
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             c_act[c] = false; c_rx[c] = c_ry[c] = c_rz[c] = 0.f; r_rhs[c] = 0.f;
-            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = r_app[c][d] = 0.f; }
+            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = r_app[c][d] = 0.f; if (RT) r_den[RT ? c : 0][d] = 0.f; }
         }
         // The object is solved in scaled coordinates in which it has unit mass and unit (isotropic) inertia: lever arms
         // r' = sk r and angular velocity u = omega / sk with sk = sqrt(m / I), object-table impulses in delta-v units (a = lambda / m).
@@ -648,10 +662,12 @@ struct Fast {
         // robot contacts of such a scene are stepped by the row kernel (launch_step), never by step_t<true>.
         const bool obj_inline = OBJECT && obj_on && (P.obj_iso != 0) && P.obj_shape == 0;      // (round objects -- sphere, cylinder -- are ObjStep's too)
         float o_tw[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        ObjStep os;           // RT: the object's rows are swept inside the solver loop below, next to the robot's
         if (OBJECT && obj_on && !obj_inline) {
             const float pose[7] = {op.x, op.y, op.z, oq.x, oq.y, oq.z, oq.w};
             const float tw0[6] = {ov.x, ov.y, ov.z, ow.x, ow.y, ow.z};
-            ObjStep::run_p(P, pose, tw0, o_tw, o_m, o_mu, o_kl);
+            if constexpr (RT) os.setup(P, pose, tw0, o_m, o_mu, o_kl);
+            else ObjStep::run_p(P, pose, tw0, o_tw, o_m, o_mu, o_kl);
         }
         if (obj_inline) {
             const float isc = o_m / P.obj_m;
@@ -702,8 +718,10 @@ struct Fast {
             PBRE_UNROLL for (int c = 0; c < NK; c++) {
                 const float rx = c_rx[c], ry = c_ry[c], rz = c_rz[c];
                 const V3 Ja[3] = {v3(ry, -rx, 0.f), v3(rz, 0.f, -rx), v3(0.f, rz, -ry)};   // r x dir for dir = +z, -y, +x
-                PBRE_UNROLL for (int d = 0; d < 3; d++)
+                PBRE_UNROLL for (int d = 0; d < 3; d++) {
                     r_dinv[c][d] = c_act[c] ? 1.f / (1.f + dot(Ja[d], Ja[d])) : 0.f;
+                    if (RT) r_den[RT ? c : 0][d] = c_act[c] ? 1.f + dot(Ja[d], Ja[d]) : 0.f;
+                }
                 // setupMultiBodyContactConstraint, restitution 0: only the positional part remains in the rhs because the
                 // row is evaluated against the running velocity
                 const float pen = c_dist[c] + P.slop;
@@ -713,6 +731,7 @@ struct Fast {
 
         // ---- robot contacts (RC): dense rows J_r (9 joint DoF) [+ object part for robot-object], B_r = M^-1 J_r^T
         float rc_J[NR][3][ND], rc_B[NR][3][ND], rc_dinv[NR][3], rc_app[NR][3], rc_rhs[NR], rc_mu[NR];
+        float rc_den[RT ? NR : 1][3];
         V3 rc_dir[NC_RO][3], rc_rxd[NC_RO][3];
         bool rc_act[NR];
         PBRE_UNROLL for (int c = 0; c < NR; c++) rc_act[c] = false;
@@ -766,6 +785,7 @@ struct Fast {
                         denom += fmaf(dot(rxd, rxd), inv_I, inv_m);
                     }
                     rc_dinv[c][d] = rc_act[c] ? 1.f / denom : 0.f;
+                    if (RT) rc_den[RT ? c : 0][d] = rc_act[c] ? denom : 0.f;
                     rc_app[c][d] = 0.f;
                 }
                 const float pen = cc.dist + P.slop;
@@ -781,6 +801,7 @@ struct Fast {
             const float t = fmaf(m_dinv[j] * l_dir[j], wget(w, j), -l_rhs[j]);
             const float s = med3(l_app[j] - t, 0.f, llim);
             const float d = (s - l_app[j]) * l_dir[j]; l_app[j] = s;
+            if constexpr (RT) lsr = fmaxf(lsr, fabsf(d * Mi[sym(j, j)]));
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
         auto orow = [&](int c, int d) {
@@ -797,6 +818,7 @@ struct Fast {
                 s = hi > 0.f ? s : r_app[c][d];
             }
             const float dd = s - r_app[c][d]; r_app[c][d] = s;
+            if constexpr (RT) lsr = fmaxf(lsr, fabsf(dd * r_den[RT ? c : 0][d]));
             if (d == 0) { ov.z += dd; ow.x = fmaf(dd, ry, ow.x); ow.y = fmaf(-dd, rx, ow.y); }
             else if (d == 1) { ov.y -= dd; ow.x = fmaf(dd, rz, ow.x); ow.z = fmaf(-dd, rx, ow.z); }
             else { ov.x += dd; ow.y = fmaf(dd, rz, ow.y); ow.z = fmaf(-dd, ry, ow.z); }
@@ -813,6 +835,7 @@ struct Fast {
                 s = hi > 0.f ? s : rc_app[c][d];
             }
             const float dd = s - rc_app[c][d]; rc_app[c][d] = s;
+            if constexpr (RT) lsr = fmaxf(lsr, fabsf(dd * rc_den[RT ? c : 0][d]));
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(dd, rc_B[c][d][k], wget(w, k)));
             if (c < NC_RO) {
                 const int co = c < NC_RO ? c : 0;
@@ -830,6 +853,56 @@ struct Fast {
             PBRE_UNROLL for (int c = 0; c < NK; c++) if (any_c[c]) { orow(c, 1); orow(c, 2); }
             if (RC) { PBRE_UNROLL for (int c = 0; c < NR; c++) if (any_r[c]) { rrow(c, 1); rrow(c, 2); } }
         };
+        int used = P.iters;
+        if constexpr (RT) {
+            const bool obj_sep = OBJECT && obj_on && !obj_inline;
+            bool done = false;
+            WV w_k = w; V3 ov_k = ov, ow_k = ow;
+            float os_k[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // end of sweep `it`: Bullet's test (btSequentialImpulseConstraintSolver::solveGroupCacheFriendlyIterations: leastSquaresResidual
+            // <= m_leastSquaresResidualThreshold, both squared there); true once every lane of the wave has left the loop
+            auto sweep_end = [&](int it) -> bool {
+                const bool newly = !done && lsr <= P.res_lim;
+                if (PBRE_ANY(newly)) {
+                    PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w_k, k, newly ? wget(w, k) : wget(w_k, k));
+                    ov_k = v3(newly ? ov.x : ov_k.x, newly ? ov.y : ov_k.y, newly ? ov.z : ov_k.z);
+                    ow_k = v3(newly ? ow.x : ow_k.x, newly ? ow.y : ow_k.y, newly ? ow.z : ow_k.z);
+                    if (obj_sep) {
+                        os_k[0] = newly ? os.vx : os_k[0]; os_k[1] = newly ? os.vy : os_k[1]; os_k[2] = newly ? os.vz : os_k[2];
+                        os_k[3] = newly ? os.wx : os_k[3]; os_k[4] = newly ? os.wy : os_k[4]; os_k[5] = newly ? os.wz : os_k[5];
+                    }
+                    used = newly ? it + 1 : used;
+                    done = done || newly;
+                }
+                return !PBRE_ANY(!done);
+            };
+            auto rows_c = [&]() {         // the contact rows of a sweep: the object's own (in line, or ObjStep's), the robot's (RC)
+                if (obj_sep) lsr = fmaxf(lsr, os.sweep_res());
+                else contacts();
+            };
+            for (int it = 0; it < P.iters; it += 2) {
+                lsr = 0.f;
+                if (ROBOT) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j); }
+                if (RC && any_lim) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) limit(j); }
+                rows_c();
+                if (sweep_end(it)) break;
+                if (it + 1 >= P.iters) break;
+                lsr = 0.f;
+                if (RC && any_lim) { PBRE_UNROLL for (int j = 0; j < ND; j++) limit(j); }
+                if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j); }
+                rows_c();
+                if (sweep_end(it + 1)) break;
+            }
+            PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, done ? wget(w_k, k) : wget(w, k));
+            ov = v3(done ? ov_k.x : ov.x, done ? ov_k.y : ov.y, done ? ov_k.z : ov.z);
+            ow = v3(done ? ow_k.x : ow.x, done ? ow_k.y : ow.y, done ? ow_k.z : ow.z);
+            if (obj_sep) {
+                os.vx = done ? os_k[0] : os.vx; os.vy = done ? os_k[1] : os.vy; os.vz = done ? os_k[2] : os.vz;
+                os.wx = done ? os_k[3] : os.wx; os.wy = done ? os_k[4] : os.wy; os.wz = done ? os_k[5] : os.wz;
+                os.result(P, o_tw);
+            }
+            if (sw) *sw = used;
+        } else
         if (!RC && !OBJECT) {
         } else if (!RC) {
             // ---- simple class.  The motor rows and the object rows share no unknown, so Bullet's interleaved sweeps give each block

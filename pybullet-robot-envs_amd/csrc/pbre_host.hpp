@@ -156,6 +156,8 @@ inline bool apply_physics(const pbre_physics& p, Params& P2) {
     P2.obj_iso = (P2.obj_I[0] == P2.obj_I[1] && P2.obj_I[1] == P2.obj_I[2]) ? 1 : 0;
     if (p.obj_shape < 0 || p.obj_shape > 2) return false;
     P2.obj_shape = p.obj_shape;
+    if (!(p.solver_residual_threshold >= 0)) return false;
+    P2.res_lim = (float)std::sqrt(p.solver_residual_threshold);
     return true;
 }
 
@@ -195,6 +197,8 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     P.obj_iso = (P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]) ? 1 : 0;
     if (p.obj_shape < 0 || p.obj_shape > 2) return "bad physics parameters (obj_shape)";
     P.obj_shape = p.obj_shape;
+    if (!(p.solver_residual_threshold >= 0)) return "bad physics parameters (solver_residual_threshold)";
+    P.res_lim = (float)std::sqrt(p.solver_residual_threshold);
     P.task = c.task; P.max_steps = c.max_steps; P.flags = c.flags;
     P.dist_min = (float)c.target_dist_min; P.act_scale = (float)c.act_scale;
     P.obj_std = (float)c.obj_pose_rnd_std; P.tg_std = (float)c.tg_pose_rnd_std;

@@ -505,7 +505,9 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
         sp.destroy();
     }
     // (round objects -- pbre_physics.obj_shape -- included: the object's own rows are ObjStep's, the robot-object test is Fast::sphere_obj)
-    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr; }
+    // (not with Bullet's residual exit, pbre_physics.solver_residual_threshold > 0: the pipeline splits an env's rows over kernels, the
+    // test is a maximum over all of them -- such a batch is stepped by the lane-group kernel, Core::step<RT>)
+    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr && !(P.res_lim > 0.f); }
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");

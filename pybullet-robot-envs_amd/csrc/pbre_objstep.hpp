@@ -116,6 +116,7 @@ struct ObjStep {
     float vx, vy, vz, wx, wy, wz, mu;
     float Ii[6];       // m * I_w^-1 = m R diag(1/I) R^T: xx yy zz xy xz yz (a caller with robot-object rows needs it too)
     float c_rx[NK], c_ry[NK], c_rz[NK], g[NK][3][3], r_dinv[NK][3], r_app[NK][3], r_rhs[NK];
+    float r_den[NK][3];      // 1 / r_dinv (0 for an unused slot): only sweep_res() reads it
     PBRE_HD void setup(const Params& P, const float* pose, const float* tw, float o_m, float o_mu, float o_kl) {
         const float dt = P.dt, inv_dt = P.inv_dt, vmax = P.vmax;
         const float isc = o_m / P.obj_m;
@@ -151,7 +152,7 @@ struct ObjStep {
         }
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             c_rx[c] = c_ry[c] = c_rz[c] = 0.f; r_rhs[c] = 0.f;
-            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = 0.f; r_app[c][d] = 0.f; g[c][d][0] = g[c][d][1] = g[c][d][2] = 0.f; }
+            PBRE_UNROLL for (int d = 0; d < 3; d++) { r_dinv[c][d] = 0.f; r_den[c][d] = 0.f; r_app[c][d] = 0.f; g[c][d][0] = g[c][d][1] = g[c][d][2] = 0.f; }
         }
         {
             float vd[8], rx[8], ry[8], rz[8];
@@ -184,7 +185,8 @@ struct ObjStep {
                             g[c][d][0] = Ii[0] * Ja[d][0] + Ii[3] * Ja[d][1] + Ii[4] * Ja[d][2];
                             g[c][d][1] = Ii[3] * Ja[d][0] + Ii[1] * Ja[d][1] + Ii[5] * Ja[d][2];
                             g[c][d][2] = Ii[4] * Ja[d][0] + Ii[5] * Ja[d][1] + Ii[2] * Ja[d][2];
-                            r_dinv[c][d] = 1.f / (1.f + Ja[d][0] * g[c][d][0] + Ja[d][1] * g[c][d][1] + Ja[d][2] * g[c][d][2]);
+                            r_den[c][d] = 1.f + Ja[d][0] * g[c][d][0] + Ja[d][1] * g[c][d][1] + Ja[d][2] * g[c][d][2];
+                            r_dinv[c][d] = 1.f / r_den[c][d];
                         }
                         const float pen = vd[v] + P.slop;     // setupMultiBodyContactConstraint, restitution 0
                         r_rhs[c] = (pen > 0.f ? -pen * inv_dt : -pen * P.erp * inv_dt) * r_dinv[c][0];
@@ -224,6 +226,38 @@ struct ObjStep {
                 vx += dd; wx = fmaf(dd, g[c][2][0], wx); wy = fmaf(dd, g[c][2][1], wy); wz = fmaf(dd, g[c][2][2], wz);
             }
         }
+    }
+    // one sweep as sweep(), returning the largest |delta impulse / jacDiagABInv| of its rows: the object's contribution to Bullet's
+    // least-squares residual (pbre_physics.solver_residual_threshold; callers compare against Params::res_lim = its square root)
+    PBRE_HD float sweep_res() {
+        float lsr = 0.f;
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            const float jv = vz + c_ry[c] * wx - c_rx[c] * wy;
+            const float dd = fmaxf(fmaf(-jv, r_dinv[c][0], r_rhs[c]), -r_app[c][0]);
+            r_app[c][0] += dd;
+            lsr = fmaxf(lsr, fabsf(dd * r_den[c][0]));
+            vz += dd; wx = fmaf(dd, g[c][0][0], wx); wy = fmaf(dd, g[c][0][1], wy); wz = fmaf(dd, g[c][0][2], wz);
+        }
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            const float hi = mu * r_app[c][0];
+            {
+                const float jv = -vy + c_rz[c] * wx - c_rx[c] * wz;
+                float dd = med3(-jv * r_dinv[c][1], -hi - r_app[c][1], hi - r_app[c][1]);
+                dd = hi > 0.f ? dd : 0.f;
+                r_app[c][1] += dd;
+                lsr = fmaxf(lsr, fabsf(dd * r_den[c][1]));
+                vy -= dd; wx = fmaf(dd, g[c][1][0], wx); wy = fmaf(dd, g[c][1][1], wy); wz = fmaf(dd, g[c][1][2], wz);
+            }
+            {
+                const float jv = vx + c_rz[c] * wy - c_ry[c] * wz;
+                float dd = med3(-jv * r_dinv[c][2], -hi - r_app[c][2], hi - r_app[c][2]);
+                dd = hi > 0.f ? dd : 0.f;
+                r_app[c][2] += dd;
+                lsr = fmaxf(lsr, fabsf(dd * r_den[c][2]));
+                vx += dd; wx = fmaf(dd, g[c][2][0], wx); wy = fmaf(dd, g[c][2][1], wy); wz = fmaf(dd, g[c][2][2], wz);
+            }
+        }
+        return lsr;
     }
     PBRE_HD void result(const Params& P, float* o) const {
         const float vmax = P.vmax;

@@ -111,6 +111,9 @@ struct Params {                  // float copies of pbre_physics + task constant
     float cmd_vmax, cmd_kp;                         // robot-level apply_action(max_vel): maxVelocity of the commanded motors (0: none) and their
     int   cmd_nj;                                   // positionGain (0: the hold gain); cmd_nj > 0: only the first cmd_nj DoF are commanded (pandaEnv, panda_env.py:284-290)
     int*  bad_count;                                // device counter of env-steps that met a non-finite state (NaN / Inf guard); may be null
+    float res_lim;                                  // sqrt(pbre_physics.solver_residual_threshold): an env leaves the sweep loop after the first sweep whose largest
+                                                    // velocity-level row change |delta impulse / jacDiagABInv| is <= res_lim (Bullet compares the squares); 0: never
+    int*  sweeps;                                   // res_lim > 0: per-env count of the sweeps run in the step ([num_envs], this ctx's local env index); may be null
 };
 
 namespace detail {

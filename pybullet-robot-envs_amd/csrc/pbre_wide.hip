@@ -101,7 +101,7 @@ void wide_destroy(WideEngine* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     w->free_tables();
     for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
-                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv, (void*)w->d_bad})
+                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv, (void*)w->d_bad, (void*)w->d_sweeps})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : w->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
@@ -155,6 +155,9 @@ int wide_create(const pbre_config* cfg, WideEngine** out, std::string& err) {
     CK(hipMalloc(&w->d_bad, 2 * sizeof(int)));
     CK(hipMemset(w->d_bad, 0, 2 * sizeof(int)));
     w->P.bad_count = w->d_bad;
+    CK(hipMalloc(&w->d_sweeps, (size_t)w->n * sizeof(int)));
+    CK(hipMemset(w->d_sweeps, 0, (size_t)w->n * sizeof(int)));
+    w->P.sweeps = w->d_sweeps;
     CK(w->lane_alloc());
     CK(hipMalloc(&w->d_ids, n * sizeof(unsigned long long)));
     CK(hipMalloc(&w->d_ep, n * sizeof(unsigned)));
@@ -388,6 +391,13 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     if (snapshot_relevant_change(w->cfg.phys, *p)) { w->stale_snapshot = w->stale_snapshot || w->have_snapshot; w->have_snapshot = false; P2.rst_ok = 0; }
     w->cfg.phys = *p; w->P = P2;
     w->lane_invalidate();          // the contact margin may have changed
+    return PBRE_OK;
+}
+int wide_get_sweeps(WideEngine* w, int32_t* sweeps) {
+    if (!(w->P.res_lim > 0.f)) { w->err = "pbre_get_sweeps: pbre_physics.solver_residual_threshold is 0 (every env runs all solver_iters sweeps)"; return PBRE_E_UNSUPPORTED; }
+    WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
+    WCHK(hipMemcpy(sweeps, w->d_sweeps, (size_t)w->n * sizeof(int), hipMemcpyDeviceToHost));
     return PBRE_OK;
 }
 int wide_obs_limits(const WideEngine* w, float* lo, float* hi) { w->limits(lo, hi); return PBRE_OK; }

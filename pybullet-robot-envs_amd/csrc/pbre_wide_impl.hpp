@@ -23,7 +23,8 @@ template <class S> constexpr int phys_lanes() { return S::W > 64 ? 64 : S::W; }
 static_assert(Shape32::LC >= 16, "DevLanes32::sum_obj assumes the object lanes lie in the upper 16-lane row of the half-wave");   // physical lanes of one env group (Shape128: two virtual lanes each)
 struct MotorCmd { int n; int dof[64]; float target[64]; float kp, fscale, vmax; };     // pbre_set_motors, by value
 
-template <class S, class L, int MODE>
+// RT: pbre_physics.solver_residual_threshold > 0 (Core::step<RT>; objv is null then: the exit test is over all rows of an env)
+template <class S, class L, int MODE, bool RT = false>
 __global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT<S>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow,
                                                    int flags, const float* __restrict__ tgt, const float* __restrict__ objv) {
@@ -31,9 +32,9 @@ __global__ __launch_bounds__(WTPB, S::W > 64 ? 2 : 3) void kw_step(const TablesT
     constexpr int EPB = WTPB / phys_lanes<S>();
     const int env = blockIdx.x * EPB + (int)(threadIdx.x / phys_lanes<S>());
     if (env >= n) return;                           // whole lane group; a partially filled wave keeps running its other group
-    C::step(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+    C::template step<RT>(*T, P, state + (size_t)env * S::STATE, (MODE & C::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
             (MODE & C::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, ((MODE & C::M_TGT) || S::MREC) ? tgt + (size_t)env * S::TGT : nullptr,
-            P.env_id_base + (unsigned long long)env, objv ? objv + (size_t)env * S::W : nullptr);
+            P.env_id_base + (unsigned long long)env, objv ? objv + (size_t)env * S::W : nullptr, nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
 }
 // The object's half of the step for every env, one thread per env (pbre_objstep.hpp): twist after a step without robot-object contact,
 // into the object lanes of the env's side record.  kw_step takes it where its collision detection finds no such contact.
@@ -141,6 +142,7 @@ struct WideEngine {
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
     int* d_bad = nullptr;                     // NaN / Inf guard counter (Params::bad_count)
+    int* d_sweeps = nullptr;                  // [n] sweeps every env's solver ran in the last step (Params::sweeps; pbre_physics.solver_residual_threshold > 0)
     float* objv = nullptr;                    // [n][W] side records of kw_obj, or nullptr: object rows always solved in kw_step
     const float* obj_done = nullptr;          // state buffer whose object solve rode along with the last kw_ik launch (consumed by the next step)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
@@ -199,6 +201,11 @@ struct WideImpl : WideEngine {
     void free_tables() override { if (dT) (void)hipFree(dT); dT = nullptr; }
     template <int MODE>
     void step_t(float* st, float* tg, int cnt, const float* act, float* out, int flags, hipStream_t s) {
+        if (P.res_lim > 0.f) {         // Bullet's residual exit: one solve over all rows of an env, no side solve of the object
+            obj_done = nullptr;
+            hipLaunchKernelGGL((kw_step<S, L, MODE, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg, (const float*)nullptr);
+            return;
+        }
         const float* ov = (objv && !(flags & 1)) ? objv : nullptr;
         const bool done = ov && obj_done == st;
         obj_done = nullptr;
@@ -221,7 +228,7 @@ struct WideImpl : WideEngine {
         const int ikb = blocks_of(cnt);
         if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(ikb), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim, ikb, (float*)nullptr);
         else {
-            const bool ride = step_follows && objv != nullptr && !(cfg.flags & PBRE_F_NO_OBJECT);
+            const bool ride = step_follows && objv != nullptr && !(cfg.flags & PBRE_F_NO_OBJECT) && !(P.res_lim > 0.f);
             hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(ikb + (ride ? (cnt + WTPB - 1) / WTPB : 0)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim,
                                ikb, ride ? objv : nullptr);
             obj_done = ride ? st : nullptr;

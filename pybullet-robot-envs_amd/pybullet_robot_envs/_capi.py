@@ -27,7 +27,8 @@ class Physics(C.Structure):
                 ("max_motor_impulse", C.c_double), ("limit_max_impulse", C.c_double),
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
-                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("implicit_joint_damping", C.c_int32), ("obj_shape", C.c_int32)]
+                ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("implicit_joint_damping", C.c_int32), ("obj_shape", C.c_int32),
+                ("solver_residual_threshold", C.c_double)]
 
 
 class Config(C.Structure):
@@ -75,7 +76,7 @@ def load(path=None):
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
-                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot",
+                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot", "pbre_get_sweeps",
                  "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_comm_last_error.restype = C.c_char_p
@@ -366,6 +367,13 @@ class Engine:
                 setattr(ph, k, v)
         self._chk(self.lib.pbre_set_physics(self._ctx, C.byref(ph)))
 
+    def get_sweeps(self):
+        """[N] int32: the sweeps every env's solver ran in the last simulation step -- only with set_physics(solver_residual_threshold=...)
+        > 0 (PyBullet's solverResidualThreshold; the reference leaves it at PyBullet's default, panda_push_gym_env.py:122)."""
+        sw = np.empty(self.num_envs, np.int32)
+        self._chk(self.lib.pbre_get_sweeps(self._ctx, sw.ctypes.data_as(C.POINTER(C.c_int32))))
+        return sw
+
     def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None, robot_lin_damping=None):
         """Per-env object mass / lateral friction / linear damping and robot link damping ([N] arrays or None = unchanged): domain
         randomisation of the Panda task envs (reference change_physics_params, called per env and episode by the Dyn-Rand training)."""
@@ -474,6 +482,9 @@ class MultiEngine(object):
     def set_physics(self, **fields):
         for e in self.shards:
             e.set_physics(**fields)
+
+    def get_sweeps(self):
+        return self._cat(self._map(lambda k: self.shards[k].get_sweeps()))
 
     def set_physics_per_env(self, obj_mass=None, obj_mu=None, obj_lin_damping=None, mask=None, robot_lin_damping=None):
         def part(x, k):

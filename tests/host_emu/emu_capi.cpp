@@ -47,6 +47,7 @@ struct pbre_ctx {                       // shape-independent part + the virtual 
     bool lane_ok = false;                // the iCub's lane-per-env path (pbre_lane.hpp; PBRE_ICUB_LANE=0 switches it off as on the device)
     long n_fast = 0, n_rc = 0, n_general = 0, n_pair = 0;
     int n_bad = 0;                       // NaN / Inf guard counter (Params::bad_count points here)
+    std::vector<int> sweeps;             // pbre_get_sweeps (pbre_physics.solver_residual_threshold > 0)
     bool pair = getenv("PBRE_PAIR") && getenv("PBRE_PAIR")[0] == '1';
     bool obj_split = !(getenv("PBRE_OBJ_SPLIT") && getenv("PBRE_OBJ_SPLIT")[0] == '0');
     virtual ~pbre_ctx() {}
@@ -73,6 +74,7 @@ struct Emu : pbre_ctx {
     // same dispatch as the device: lane-per-env fast path first (Panda), general lane-group kernel otherwise
     void count_bad(int c) { if (c & FastH::BAD_BIT) n_bad++; }      // (as the device's publish_class: the NaN / Inf guard's counter)
     void step_env(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tg = nullptr) {
+        if (P.res_lim > 0.f) { step_env_rt(st, act, out, mode, flags, env_id, tg); return; }
         if constexpr (PANDA) {
             if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
                 // the class is recomputed here instead of being carried from the previous step
@@ -148,10 +150,33 @@ struct Emu : pbre_ctx {
         }
         CoreH::step(T, P, st, act, out, mode, flags, tg, env_id);
     }
+    // pbre_physics.solver_residual_threshold > 0: the device's RT kernel variants -- one solve over all rows of an env (no pair kernel,
+    // no side solve of the object, no lane-per-env iCub pipeline), same choice of kernel otherwise
+    void step_env_rt(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id, const float* tg) {
+        int* sw = &sweeps[(size_t)(st - state.data()) / STATE];
+        if constexpr (PANDA) {
+            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
+                if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; count_bad(FastH::template step<true>(T, P, st, act, out, mode, flags, env_id, tg, sw)); }
+                else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
+                    n_rc++;
+                    CoreH::template step<true>(T, P, st, act, nullptr, mode & (CoreH::M_ACTION | CoreH::M_TGT), flags, tg, 0ull, nullptr, nullptr, sw);
+                    float q[NJ], qd[NJ];
+                    for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
+                    FastH::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
+                    FastH::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
+                    count_bad(FastH::finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id));
+                }
+                else { n_rc++; count_bad(FastH::template step_rc<true>(T, P, st, act, out, mode, flags, env_id, tg, sw)); }
+                return;
+            }
+        }
+        n_general++;
+        CoreH::template step<true>(T, P, st, act, out, mode, flags, tg, env_id, nullptr, nullptr, sw);
+    }
     void ik(float* st, const float* act, float* tg, bool rst) {
         if constexpr (PANDA) FastH::ik_targets(T, P, st, act, tg, rst);
         else {
-            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && !rst) { LaneH::ik_targets(T, P, st, act, tg); return; } }
+            if constexpr (std::is_same<S, Shape32>::value) { if (lane_ok && !rst && !(P.res_lim > 0.f)) { LaneH::ik_targets(T, P, st, act, tg); return; } }
             CoreH::ik_targets(T, P, st, act, tg, rst);
         }
     }
@@ -285,6 +310,7 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     c->P.bad_count = &c->n_bad;
     c->n = cfg->num_envs; c->obs_dim = obs_dim_of(c->T, c->P); c->act_dim = act_dim_of(*cfg); c->sf = S::STATE; c->nj = S::NJ;
     c->state.assign((size_t)c->n * S::STATE, 0.f);
+    c->sweeps.assign((size_t)c->n, 0);
     c->tgt.assign((size_t)c->n * S::TGT, 0.f);
     c->mrec = S::MREC;
     for (int e = 0; e < c->n; e++) c->state[(size_t)e * S::STATE + 2 * S::W + 5] = -1.f;      // never reset
@@ -380,6 +406,12 @@ int pbre_set_motor_state(pbre_ctx* c, const float* m) {
 int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     if (!c || !phys) return PBRE_E_ARG;
     *phys = c->cfg.phys;
+    return PBRE_OK;
+}
+int pbre_get_sweeps(pbre_ctx* c, int32_t* sweeps) {
+    if (!c || !sweeps) return PBRE_E_ARG;
+    if (!(c->P.res_lim > 0.f)) { c->err = "pbre_get_sweeps: pbre_physics.solver_residual_threshold is 0 (every env runs all solver_iters sweeps)"; return PBRE_E_UNSUPPORTED; }
+    for (int e = 0; e < c->n; e++) sweeps[e] = c->sweeps[e];
     return PBRE_OK;
 }
 int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {

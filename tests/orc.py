@@ -129,10 +129,14 @@ class Oracle:
         act = self._a(actions)
         n = st.shape[0]
         out = np.zeros((n, self.obs_dim + 2), self.np_real)
+        self.last_sweeps = np.zeros(n, np.int32)       # sweeps the solver ran per env (orc_params.solver_residual_threshold)
+        sw2 = (C.c_int * 2)()
         for e in range(n):
             o = out[e]
             self.lib.orc_hands_step(C.byref(self.model), C.byref(self.params), C.byref(self.task), self._p(st[e]), self._p(mr[e]),
                                     self._p(act[e]), self._p(o), self._p(o[self.obs_dim:]), self._p(o[self.obs_dim + 1:]))
+            self.lib.orc_last_sweeps(sw2)
+            self.last_sweeps[e] = sw2[0]
         return st, mr, out
 
     def hands_settle(self, states, mrec, n_steps):

@@ -2158,3 +2158,171 @@ def check_four_robot_object_slots(Engine, lib, table, panda, flags=0, n=24, seed
     rep = check_single_steps(eng, ora, S, rng, steps=1, tol=TOL_CONTACT, skip_ambiguous=True, max_skip=0.3, ora32=ora32)
     rep["robot_object_contacts_per_state"] = counts
     return rep
+
+
+# ---- pbre_physics.solver_residual_threshold (PyBullet's solverResidualThreshold; Bullet's exit test of the sweep loop) ----------------
+# Engine and oracle run the same test on the same quantity -- the sweep's largest squared velocity-level row change against the threshold --
+# in fp32 and fp64.  Where both leave the loop after the same sweep the results are held to the usual bounds (TOL / TOL_CONTACT).  Where
+# the residual of a sweep lies within rounding of the threshold the two may leave one sweep apart; the results then differ by what that one
+# sweep still changes, at most sqrt(threshold) = 3.2e-4 rad/s in the worst row of the env: those env-steps are counted, their fraction is
+# bounded, and they are held to TOL_RT_FLIP (one sweep's worth, not a parity bound).
+TOL_RT_FLIP = dict(TOL_CONTACT, q=5e-6, qd=1.2e-3, obj_v=4e-4, obj_w=4e-3, obs_q=5e-6, obs_ee_pos=5e-6, obs_ee_eul=1e-5, obs_ee_vel=2e-2, obs_rel_pos=8e-6,
+                   obs_rel_eul=2e-5, obs_obj_pos=2e-6, obs_obj_eul=1e-5, obj_pos=2e-6, reward=8e-6)
+
+
+def check_residual_threshold(Engine, lib, table, states=None, n=48, steps=3, thr=1e-7, flags=0, tol=None, seed=41, max_flip=0.05, report=None,
+                             skip_ambiguous=False, max_skip=0.15, expect_early=True, **over):
+    """One step each from identical fp32 states with the threshold on in engine and oracle.  Asserts: the engine's per-env sweep counts
+    (pbre_get_sweeps) equal the oracle's except for a bounded fraction of one-sweep flips; equal-count env-steps within `tol`; flips within
+    TOL_RT_FLIP; the test actually fires (some env leaves before solver_iters) and changes the result against a full solve."""
+    rng = np.random.default_rng(seed)
+    if states is None:
+        eng, ora = make_pair(Engine, lib, table, n, flags=flags, **over)
+        if over.get("use_ik"):
+            eng.reset(); st, _ = ora.batch_reset(n)         # (IK control: the reset's own bounds are check_ik_mode's)
+        else:
+            st = check_reset(eng, ora, n)                   # threshold 0: the usual reset, the usual bounds
+    else:
+        st = np.asarray(states, np.float64)
+        n = st.shape[0]
+        eng, ora = make_pair(Engine, lib, table, n, flags=flags, **over)
+    with_thr = lambda e: e.set_physics(solver_residual_threshold=thr)
+    try:
+        eng.get_sweeps()
+        raise AssertionError("pbre_get_sweeps must refuse while the threshold is 0")
+    except RuntimeError:
+        pass
+    iters = int(ora.params.solver_iters)
+    rep = report if report is not None else {}
+    rep.update({"envs": n, "steps": steps, "flips": 0, "compared": 0, "early": 0, "skipped_ambiguous": 0})
+    worst, worst_flip = {}, {}
+    tt = TOL if tol is None else tol
+    for k in range(steps):
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+        s32 = st.astype(np.float32)
+        # the full solve of the same step (threshold 0), for the "it changes something" assertion
+        eng.set_physics(solver_residual_threshold=0.0)
+        eng.set_state(s32); eng.step(a); s_full = eng.get_state()
+        with_thr(eng); ora.params.solver_residual_threshold = thr
+        try:
+            eng.set_state(s32)
+            ob, rw, dn = eng.step(a)
+            se = eng.get_state()
+            sw = eng.get_sweeps()
+            so, out, used, to7 = ora.batch_step_sweeps(s32.astype(np.float64), a)
+            ok = np.ones(n, bool)
+            if skip_ambiguous:
+                ok = ~ambiguous_envs(ora, s32.astype(np.float64), a)
+        finally:
+            ora.params.solver_residual_threshold = 0.0
+        rep["skipped_ambiguous"] += int((~ok).sum())
+        assert (~ok).mean() <= max_skip, "threshold-ambiguous contact sets: %d of %d skipped" % ((~ok).sum(), n)
+        assert sw.min() >= 1 and sw.max() <= iters
+        same = (sw == used) & ok
+        flip = (sw != used) & ok
+        rep["flips"] += int(flip.sum()); rep["compared"] += int(same.sum()); rep["early"] += int((used < iters).sum())
+        rep.setdefault("max_sweep_gap", 0)
+        if flip.any():
+            rep["max_sweep_gap"] = max(rep["max_sweep_gap"], int(np.abs(sw[flip].astype(int) - used[flip]).max()))
+        dflip = (dn != out[:, -1]) & ok
+        assert dflip.sum() <= max(1, n // 50), "done flags differ in %d of %d envs" % (dflip.sum(), n)
+        if same.any():
+            merge_worst(worst, panda_quantities(se[same], so[same], ob[same], out[same]))
+            k2 = same & ~dflip
+            if k2.any():
+                merge_worst(worst, {"reward": rel(rw[k2], out[k2, -2]).max()})
+        if flip.any():
+            merge_worst(worst_flip, panda_quantities(se[flip], so[flip], ob[flip], out[flip]))
+        # an env that left the loop early is NOT where the full solve ends (else the option would be a no-op)
+        early = used < iters - 20
+        if early.any():
+            rep["max_effect_qd"] = max(rep.get("max_effect_qd", 0.0), float(np.abs(se[early, 16:25] - s_full[early, 16:25]).max()))
+        st = so
+    eng.set_physics(solver_residual_threshold=0.0)
+    rep["worst"], rep["worst_flip"] = worst, worst_flip
+    total = max(1, rep["flips"] + rep["compared"])
+    assert rep["flips"] <= max(1, int(max_flip * total)), "exit sweeps differ in %d of %d env-steps (bound %.0f %%)" % (rep["flips"], total, 100 * max_flip)
+    assert rep["max_sweep_gap"] <= 2, "engine and oracle leave the loop %d sweeps apart" % rep["max_sweep_gap"]
+    if expect_early:
+        assert rep["early"] > 0, "the residual test never fired: nothing tested"
+        assert rep.get("max_effect_qd", 0.0) > 1e-6, "leaving the loop early changed nothing"
+    assert_within(worst, tt, "(residual threshold %g: %d env-steps with equal sweep counts, %d flips, %d ambiguous skipped)" % (thr, rep["compared"], rep["flips"], rep["skipped_ambiguous"]))
+    assert_within(worst_flip, TOL_RT_FLIP, "(residual threshold %g: the %d env-steps that left the loop a sweep apart)" % (thr, rep["flips"]))
+    return rep
+
+
+TOL_RT_FLIP_GROUP = {"q": 5e-6, "qd": 1.2e-3, "obj_pos": 2e-6, "obj_quat": 3e-6, "obj_v": 5e-3, "obj_w": 4e-3,
+                     "obs_ee_pos": 5e-6, "obs_ee_eul": 1e-5, "obs_ee_vel": 8e-4, "obs_rest": 2e-5}
+
+
+def check_group_residual_threshold(eng, ora, st, rng, tol, steps=3, thr=1e-7, max_flip=0.1, report=None, tail=0, context=""):
+    """The lane-group engines (iCub, iCub with hands, robot-level Panda: Core::step<RT>) with pbre_physics.solver_residual_threshold on,
+    one step each from identical fp32 states against the oracle with the same threshold: equal per-env sweep counts except for a bounded
+    fraction of one-sweep flips (TOL_RT_FLIP_GROUP), everything else within `tol`."""
+    n = st.shape[0]
+    iters = int(ora.params.solver_iters)
+    rep = report if report is not None else {}
+    rep.update({"flips": 0, "compared": 0, "early": 0, "max_sweep_gap": 0})
+    worst, worst_flip = {}, {}
+    eng.set_physics(solver_residual_threshold=thr); ora.params.solver_residual_threshold = thr
+    try:
+        for k in range(steps):
+            a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
+            s32 = st.astype(np.float32)
+            eng.set_state(s32)
+            ob, rw, dn = eng.step(a)
+            se = eng.get_state(); sw = eng.get_sweeps()
+            so, out, used, to7 = ora.batch_step_sweeps(s32.astype(np.float64), a)
+            same, flip = sw == used, sw != used
+            rep["flips"] += int(flip.sum()); rep["compared"] += int(same.sum()); rep["early"] += int((used < iters).sum())
+            if flip.any():
+                rep["max_sweep_gap"] = max(rep["max_sweep_gap"], int(np.abs(sw[flip].astype(int) - used[flip]).max()))
+                merge_worst(worst_flip, group_quantities(eng, se[flip], so[flip], ob[flip], out[flip], tail=tail))
+            if same.any():
+                merge_worst(worst, group_quantities(eng, se[same], so[same], ob[same], out[same], tail=tail))
+            st = so
+    finally:
+        eng.set_physics(solver_residual_threshold=0.0); ora.params.solver_residual_threshold = 0.0
+    rep["worst"], rep["worst_flip"] = worst, worst_flip
+    total = max(1, rep["flips"] + rep["compared"])
+    assert rep["early"] > 0, "the residual test never fired: nothing tested " + context
+    assert rep["flips"] <= max(1, int(max_flip * total)), "exit sweeps differ in %d of %d env-steps %s" % (rep["flips"], total, context)
+    assert rep["max_sweep_gap"] <= 2
+    assert_within(worst, tol, "(residual threshold %g, %d env-steps with equal sweep counts, %d flips) %s" % (thr, rep["compared"], rep["flips"], context))
+    assert_within(worst_flip, TOL_RT_FLIP_GROUP, "(residual threshold %g: one-sweep flips) %s" % (thr, context))
+    return rep
+
+
+def check_hands_residual_threshold(Engine, lib, n=1, steps=2, thr=1e-7, seed=9):
+    """iCub with hands (Core::step<RT> on the 128-virtual-lane shape, rows in LDS): joint-control steps with the threshold on, against the
+    oracle's hands_step with the same threshold -- equal sweep counts (one-sweep flips bounded), results within TOL_HANDS."""
+    eng, ora, info = make_hands_pair(Engine, lib, n, "r", 0)
+    eng.reset()
+    st, mrec, _ = ora.hands_reset(n)
+    rng = np.random.default_rng(seed)
+    home = np.asarray(info["home"])[info["controlled"]]
+    iters = int(ora.params.solver_iters)
+    worst, flips, early, same_n = {}, 0, 0, 0
+    eng.set_physics(solver_residual_threshold=thr); ora.params.solver_residual_threshold = thr
+    try:
+        for k in range(steps):
+            a = (home[None, :] + rng.uniform(-0.2, 0.2, (n, len(home)))).astype(np.float32)
+            s32 = st.astype(np.float32)
+            eng.set_state(s32)
+            ob, rw, dn = eng.step(a)
+            so, mrec, out = ora.hands_step(s32.astype(np.float64), mrec, a)
+            se, sw, used = eng.get_state(), eng.get_sweeps(), ora.last_sweeps
+            same = sw == used
+            flips += int((~same).sum()); same_n += int(same.sum()); early += int((used < iters).sum())
+            assert np.abs(sw.astype(int) - used).max() <= 2
+            if same.any():
+                merge_worst(worst, group_quantities(eng, se[same], so[same], ob[same], out[same], tail=7))
+            if (~same).any():
+                assert_within(group_quantities(eng, se[~same], so[~same], ob[~same], out[~same], tail=7), TOL_RT_FLIP_GROUP, "(hands, one-sweep flip)")
+            st = so
+    finally:
+        eng.set_physics(solver_residual_threshold=0.0); ora.params.solver_residual_threshold = 0.0
+    assert early > 0, "the residual test never fired"
+    assert flips <= max(1, (flips + same_n) // 4)
+    assert_within(worst, TOL_HANDS, "(hands, residual threshold %g, %d env-steps, %d flips)" % (thr, same_n, flips))
+    return eng

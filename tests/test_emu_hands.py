@@ -105,3 +105,7 @@ def test_scripted_grasp_against_the_oracle(emu_lib):
     print("scripted grasp, engine vs oracle:", rep)
     assert rep["lift_oracle_m"] > 0.15 and rep["lift_engine_m"] > 0.15
 
+
+
+def test_hands_solver_residual_threshold(emu_lib):
+    parity.check_hands_residual_threshold(_capi.Engine, emu_lib, n=1, steps=2)

@@ -133,3 +133,12 @@ def test_icub_push_closed_loop_against_oracle(emu_lib):
 def test_icub_nan_inf_guard(emu_lib):
     """NaN / Inf guard through Lane::step / Lane::finish and (complex envs, masked paths) Core::step / Core::observe on the lane emulation"""
     parity.check_icub_nan_guard(_capi.Engine, emu_lib, n=8)
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_icub_solver_residual_threshold(emu_lib, task):
+    """pbre_physics.solver_residual_threshold on the iCub's lane-group kernel (Core::step<RT>, half-wave shape): joint-control steps against
+    the oracle with the same threshold, equal per-env sweep counts."""
+    eng, ora, info = parity.make_icub_pair(_capi.Engine, emu_lib, 4, task, "l", 0, 0, obj_std=0.05, tg_std=0.2)
+    eng.reset(); st, _ = ora.batch_reset(4)
+    parity.check_group_residual_threshold(eng, ora, st, np.random.default_rng(5), parity.TOL_ICUB, steps=3)

@@ -333,3 +333,36 @@ def test_four_robot_object_contact_slots(panda, emu_lib, flags):
     """the lane-per-env complex kernel's path (Fast::step_t<true>), the row kernel's (Core::step + Fast::finish) and the general kernel"""
     rep = parity.check_four_robot_object_slots(_capi.Engine, emu_lib, panda["table"], panda, flags=flags)
     print({k: v for k, v in rep.items() if k != "robot_object_contacts_per_state"})
+
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_solver_residual_threshold_free_space(panda, emu_lib, use_ik):
+    """pbre_physics.solver_residual_threshold = 1e-7 (PyBullet's documented solverResidualThreshold default; the reference only sets
+    numSolverIterations, panda_push_gym_env.py:122): reset, then single steps of the simple-env kernel (Fast::step_t<RT>: sequential motor rows
+    next to the object's rows, per-lane exit) against the oracle with the same threshold -- equal per-env sweep counts."""
+    rep = parity.check_residual_threshold(_capi.Engine, emu_lib, panda["table"], n=24, steps=3, use_ik=use_ik)
+    assert rep["early"] >= rep["compared"] // 2        # most free-space steps leave the loop well before sweep 150
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_FORCE_GENERAL])
+def test_solver_residual_threshold_contact_rich_states(panda, emu_lib, flags):
+    """... on crafted contact-rich states, with each of the kernels that step them: lane-per-env (step_t<true, 0, RT>), 16-lane rows
+    (Core::step<RT>: the robot-only chain, the two zipped chains with robot-object rows) and the general row kernel."""
+    _, ora = parity.make_pair(_capi.Engine, emu_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 24, 24)
+    parity.check_residual_threshold(_capi.Engine, emu_lib, panda["table"], states=S, steps=1, flags=flags, tol=parity.TOL_CONTACT, skip_ambiguous=True)
+
+
+def test_solver_residual_threshold_is_off_by_default_and_validated(panda, emu_lib):
+    eng = _capi.Engine(panda["table"], task=1, num_envs=2, lib=emu_lib)
+    assert eng.get_physics().solver_residual_threshold == 0.0
+    with pytest.raises(RuntimeError):
+        eng.get_sweeps()
+    with pytest.raises(RuntimeError):
+        eng.set_physics(solver_residual_threshold=-1.0)
+    eng.reset()
+    eng.set_physics(solver_residual_threshold=1e-7)
+    eng.step(np.zeros((2, 7), np.float32))
+    sw = eng.get_sweeps()
+    assert sw.shape == (2,) and (sw >= 1).all() and (sw < 150).all()       # a hold step at rest converges in a few sweeps

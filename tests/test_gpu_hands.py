@@ -183,3 +183,7 @@ def test_scripted_grasp_against_the_oracle(hip_lib):
     print("scripted grasp, engine vs oracle:", rep)
     assert rep["lift_oracle_m"] > 0.15 and rep["lift_engine_m"] > 0.15
 
+
+
+def test_hands_solver_residual_threshold(hip_lib):
+    parity.check_hands_residual_threshold(_capi.Engine, hip_lib, n=2, steps=2)

@@ -261,3 +261,13 @@ def test_icub_nan_inf_guard(hip_lib, monkeypatch, lane, use_ik):
     and the lane-group kernel (Core::step / Core::observe)"""
     monkeypatch.setenv("PBRE_ICUB_LANE", lane)
     parity.check_icub_nan_guard(_capi.Engine, hip_lib, use_ik=use_ik)
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_icub_solver_residual_threshold(hip_lib, task):
+    """pbre_physics.solver_residual_threshold on the iCub (kw_step<.., RT>: the lane-group kernel steps the batch, the lane-per-env pipeline
+    splits an env's rows over kernels and is switched off): joint-control steps against the oracle with the same threshold."""
+    eng, ora, info = parity.make_icub_pair(_capi.Engine, hip_lib, 8, task, "l", 0, 0, obj_std=0.05, tg_std=0.2)
+    eng.reset(); st, _ = ora.batch_reset(8)
+    parity.check_group_residual_threshold(eng, ora, st, np.random.default_rng(5), parity.TOL_ICUB, steps=3)
+    assert eng.kernel_info()[2] == 0          # the lane-group kernel stepped the batch

@@ -645,3 +645,53 @@ def test_four_robot_object_contact_slots(panda, hip_lib, flags):
     candidate), one step against the four-slot oracle; k_row_list, k_fast_rc and the general kernel"""
     rep = parity.check_four_robot_object_slots(_capi.Engine, hip_lib, panda["table"], panda, flags=flags)
     print({k: v for k, v in rep.items() if k != "robot_object_contacts_per_state"})
+
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_solver_residual_threshold_free_space(panda, hip_lib, use_ik):
+    """pbre_physics.solver_residual_threshold = 1e-7 on the device (k_fast<MODE, WPS, RT>): reset, then single steps against the oracle
+    with the same threshold; per-env sweep counts (pbre_get_sweeps) equal the oracle's except for a bounded fraction of one-sweep flips."""
+    rep = parity.check_residual_threshold(_capi.Engine, hip_lib, panda["table"], n=192, steps=3, use_ik=use_ik)
+    assert rep["early"] >= rep["compared"] // 2
+
+
+@pytest.mark.parametrize("flags", [0, _capi.F_COMPLEX_ROWS, _capi.F_COMPLEX_LANES, _capi.F_FORCE_GENERAL])
+def test_solver_residual_threshold_contact_rich_states(panda, hip_lib, flags):
+    """... crafted contact-rich states on k_row_list<MODE, RT> (default for few complex envs; F_COMPLEX_ROWS pins it), k_fast_rc<MODE, RT>
+    (F_COMPLEX_LANES) and k_step<MODE, RT> (F_FORCE_GENERAL)."""
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 24, 24)
+    parity.check_residual_threshold(_capi.Engine, hip_lib, panda["table"], states=S, steps=1, flags=flags, tol=parity.TOL_CONTACT, skip_ambiguous=True)
+
+
+def test_solver_residual_threshold_results_do_not_depend_on_wave_mates_or_sharding(panda, hip_lib):
+    """With the threshold on an env leaves the sweep loop on its own while its wave goes on: two engines side by side (complex envs land in
+    different row-kernel waves from run to run) and a 2-shard split of the same batch are bit-identical over 40 steps with auto-reset."""
+    n = 4096
+    kw = dict(task=1, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=30)
+    a = _capi.Engine(panda["table"], num_envs=n, **kw)
+    b = _capi.Engine(panda["table"], num_envs=n, **kw)
+    h0 = _capi.Engine(panda["table"], num_envs=n // 2, env_id_base=0, **kw)
+    h1 = _capi.Engine(panda["table"], num_envs=n // 2, env_id_base=n // 2, **kw)
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 8, 8).astype(np.float32)
+    for e in (a, b, h0, h1):
+        e.reset()
+        e.set_physics(solver_residual_threshold=1e-7)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st); h0.set_state(st[:n // 2]); h1.set_state(st[n // 2:])
+    rng = np.random.default_rng(12)
+    early = 0
+    for _ in range(40):
+        act = rng.uniform(-1, 1, (n, 7)).astype(np.float32)
+        ra, rb, r0, r1 = a.step(act), b.step(act), h0.step(act[:n // 2]), h1.step(act[n // 2:])
+        for x, y, z0, z1 in zip(ra, rb, r0, r1):
+            assert np.array_equal(x, y) and np.array_equal(x, np.concatenate([z0, z1]))
+        sw = a.get_sweeps()
+        assert np.array_equal(sw, b.get_sweeps()) and np.array_equal(sw, np.concatenate([h0.get_sweeps(), h1.get_sweeps()]))
+        early += int((sw < 150).sum())
+    assert np.array_equal(a.get_state(), b.get_state())
+    assert a.kernel_info()[7] > 0 and early > 20 * n
