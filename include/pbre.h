@@ -295,17 +295,31 @@ int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
  *                         rank 0, which receives them into d_rows_all [G * num_envs, obs_dim + 2] (rank order; its own rows by a
  *                         device copy; d_rows_all is ignored on the other ranks).  Asynchronous.  The caller alternates between TWO
  *                         (d_rows_local, d_rows_all) buffer pairs: the exchange of step k overlaps the kernels of step k + 1, and a
- *                         buffer is stepped into again only after the exchange that read it (the stream waits for that event);
+ *                         row buffer is stepped into again only after the exchange that last read it (tracked per d_rows_local
+ *                         pointer, up to four: the stream waits for that exchange's event).  A step into such a buffer through plain
+ *                         pbre_step_device is NOT protected: call pbre_gather_wait(stream) first;
  *   pbre_gather_wait      makes `stream` (and, host_too != 0, the host) wait for every exchange enqueued so far: then rank 0 may
  *                         read d_rows_all;
- *   pbre_comm_info        [0] ranks in the communicator (ncclCommCount), [1] this rank, [2] RCCL version code, [3] exchanges enqueued;
+ *   pbre_scatter_actions_device  the way back of a CLOSED loop (policy on rank 0: a(t + 1) = pi(obs(t)) needs the gathered rows of step
+ *                         t before step t + 1 can start, so that gather cannot be overlapped): rank 0 holds d_actions_all
+ *                         [G * num_envs, act_dim] (rank order), every rank receives its [num_envs, act_dim] slice into
+ *                         d_actions_local -- ONE grouped exchange (ncclSend x (G - 1) on rank 0, one ncclRecv elsewhere; rank 0's own
+ *                         slice by a device copy) on the communication stream, ordered behind what `stream` holds on entry (the
+ *                         policy) and ahead of what is enqueued on `stream` afterwards (the step).  d_actions_all is ignored on the
+ *                         other ranks;
+ *   pbre_comm_info        [0] ranks in the communicator (ncclCommCount), [1] this rank, [2] RCCL version code, [3] gathers enqueued,
+ *                         [4] action scatters enqueued;
  *   pbre_comm_last_error  message of the last failed call above (borrowed pointer).
+ * stream: as for pbre_step_device -- a hipStream_t; PBRE_STREAM_LEGACY (HIP's legacy default stream, torch's default) is a stream like any
+ * other here; NULL = the ctx's own stream, ordered through the host (every call then synchronises; pbre_scatter_actions_device refuses it).
+ * An exchange that fails inside its ncclGroup closes the group and marks the communicator unusable (every later call returns the error).
  * PBRE_COMM_SELF_P2P=1 (read at pbre_comm_init): rank 0's own rows travel through ncclSend / ncclRecv too (single-GPU tests execute
  * the RCCL point-to-point path that way). */
 int pbre_comm_unique_id(void* id128);
 int pbre_comm_init(pbre_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int pbre_step_gather_device(pbre_ctx* ctx, const float* d_actions, float* d_rows_local, float* d_rows_all, void* stream);
 int pbre_gather_wait(pbre_ctx* ctx, void* stream, int32_t host_too);
+int pbre_scatter_actions_device(pbre_ctx* ctx, const float* d_actions_all, float* d_actions_local, void* stream);
 int pbre_comm_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 const char* pbre_comm_last_error(const pbre_ctx* ctx);
 

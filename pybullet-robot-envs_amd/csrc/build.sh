@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-fast-math -fno-slp-vectorize -Rpass-analysis=kernel-resource-usage"
 mkdir -p obj
-HDRS="pbre_math.hpp pbre_sidepick.hpp pbre_core.hpp pbre_objstep.hpp pbre_fast.hpp pbre_lane.hpp pbre_host.hpp pbre_tables.hpp pbre_wide.hpp pbre_wide_impl.hpp lanes_device.hpp ../../include/pbre.h build.sh"
+HDRS="pbre_math.hpp pbre_sidepick.hpp pbre_core.hpp pbre_objstep.hpp pbre_fast.hpp pbre_lane.hpp pbre_host.hpp pbre_tables.hpp pbre_wide.hpp pbre_wide_impl.hpp lanes_device.hpp pbre_comm_impl.hpp ../../include/pbre.h build.sh"
 pids=()
 for tu in pbre_capi pbre_wide pbre_hands pbre_lane pbre_icub_arm pbre_comm; do
     stale=0

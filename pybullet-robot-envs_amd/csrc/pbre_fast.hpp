@@ -876,23 +876,32 @@ struct Fast {
                 }
                 return !PBRE_ANY(!done);
             };
-            auto rows_c = [&]() {         // the contact rows of a sweep: the object's own (in line, or ObjStep's), the robot's (RC)
-                if (obj_sep) lsr = fmaxf(lsr, os.sweep_res());
-                else contacts();
+            // the sweeps, with the contact rows of a sweep as `rows`: the usual wave (simple class, cube resting on all four object-table slots
+            // in every lane) gets straight-line rows, as in the loop without the exit test -- the per-slot "does any lane use it" branches made
+            // the compiler duplicate the loop body per branch combination (16 k instructions, spills inside the loop)
+            auto run = [&](auto&& rows) {
+                for (int it = 0; it < P.iters; it += 2) {
+                    lsr = 0.f;
+                    if (ROBOT) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j); }
+                    if (RC && any_lim) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) limit(j); }
+                    rows();
+                    if (sweep_end(it)) break;
+                    if (it + 1 >= P.iters) break;
+                    lsr = 0.f;
+                    if (RC && any_lim) { PBRE_UNROLL for (int j = 0; j < ND; j++) limit(j); }
+                    if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j); }
+                    rows();
+                    if (sweep_end(it + 1)) break;
+                }
             };
-            for (int it = 0; it < P.iters; it += 2) {
-                lsr = 0.f;
-                if (ROBOT) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) motor(j); }
-                if (RC && any_lim) { PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) limit(j); }
-                rows_c();
-                if (sweep_end(it)) break;
-                if (it + 1 >= P.iters) break;
-                lsr = 0.f;
-                if (RC && any_lim) { PBRE_UNROLL for (int j = 0; j < ND; j++) limit(j); }
-                if (ROBOT) { PBRE_UNROLL for (int j = 0; j < ND; j++) motor(j); }
-                rows_c();
-                if (sweep_end(it + 1)) break;
-            }
+            bool all_slots = true;
+            PBRE_UNROLL for (int c = 0; c < NK; c++) all_slots = all_slots && any_c[c];
+            if (obj_sep) run([&]() { lsr = fmaxf(lsr, os.sweep_res()); });
+            else if (!RC && all_slots) run([&]() {
+                PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
+                PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+            });
+            else run([&]() { contacts(); });
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, done ? wget(w_k, k) : wget(w, k));
             ov = v3(done ? ov_k.x : ov.x, done ? ov_k.y : ov.y, done ? ov_k.z : ov.z);
             ow = v3(done ? ow_k.x : ow.x, done ? ow_k.y : ow.y, done ? ow_k.z : ow.z);

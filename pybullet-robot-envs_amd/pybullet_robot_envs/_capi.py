@@ -77,7 +77,7 @@ def load(path=None):
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
                  "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot", "pbre_get_sweeps",
-                 "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info"):
+                 "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info", "pbre_scatter_actions_device"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_comm_last_error.restype = C.c_char_p
     lib.pbre_comm_last_error.argtypes = [C.c_void_p]
@@ -271,9 +271,14 @@ class Engine:
             raise RuntimeError("pbre_comm_init failed (%d): %s" % (rc, self.lib.pbre_comm_last_error(None).decode()))
 
     def comm_info(self):
-        info = (C.c_int32 * 4)()
-        self._chk_comm(self.lib.pbre_comm_info(self._ctx, info, C.c_int32(4)))
-        return {"ranks_seen": info[0], "rank": info[1], "rccl_version_code": info[2], "exchanges": info[3]}
+        info = (C.c_int32 * 5)()
+        self._chk_comm(self.lib.pbre_comm_info(self._ctx, info, C.c_int32(5)))
+        return {"ranks_seen": info[0], "rank": info[1], "rccl_version_code": info[2], "exchanges": info[3], "action_scatters": info[4]}
+
+    def scatter_actions_device(self, d_actions_all_ptr, d_actions_local_ptr, stream=None):
+        """The way back of a closed loop: rank 0's [G * num_envs, act_dim] actions -> every rank's [num_envs, act_dim] slice, one grouped
+        RCCL exchange in `stream` order (pbre_scatter_actions_device)."""
+        self._chk_comm(self.lib.pbre_scatter_actions_device(self._ctx, C.c_void_p(d_actions_all_ptr or 0), C.c_void_p(d_actions_local_ptr), C.c_void_p(stream or 0)))
 
     def step_gather_device(self, d_actions_ptr, d_rows_local_ptr, d_rows_all_ptr, stream=None):
         """pbre_step_device + the one grouped RCCL exchange of the step's rows into rank 0's stacked buffer, all enqueued from C

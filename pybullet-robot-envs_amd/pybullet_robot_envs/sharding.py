@@ -149,14 +149,42 @@ class CtxGatherPipeline(object):
         self.torch, self.sh, self.dev = torch, sharded, device
         eng = sharded.engine
         n, w = sharded.n_local, sharded.world
-        uid = [_capi.Engine.comm_unique_id(eng.lib, rccl_lib) if sharded.rank == 0 else None]
+        # Setup is failure-SYMMETRIC: every rank probes that the RCCL library loads (pbre_comm_unique_id dlopens it) and the ranks agree on
+        # the outcome before anything blocking -- a rank that failed alone (rank 0 before its broadcast, any rank before the collective
+        # ncclCommInitRank) would leave the others waiting in a collective it never joins.  Either every rank has a communicator on
+        # return or every rank raises (and the caller falls back to torch.distributed's gather on all of them).
+        uid, err = None, None
+        try:
+            uid = _capi.Engine.comm_unique_id(eng.lib, rccl_lib)       # (ranks other than 0 discard theirs)
+        except Exception as e:
+            err = repr(e)
+        if not self._all_ok(err is None):
+            raise RuntimeError("CtxGatherPipeline: RCCL did not load on every rank (this rank: %s)" % (err or "ok"))
+        box = [uid if sharded.rank == 0 else None]
         if sharded.distributed:
-            sharded.dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(uid[0], sharded.rank, w, rccl_lib)
+            sharded.dist.broadcast_object_list(box, src=0)
+        try:
+            eng.comm_init(box[0], sharded.rank, w, rccl_lib)
+        except Exception as e:
+            err = repr(e)
+        if not self._all_ok(err is None):      # (ncclCommInitRank itself is collective: it fails or succeeds on all ranks; this catches what precedes it)
+            raise RuntimeError("CtxGatherPipeline: pbre_comm_init failed on some rank (this rank: %s)" % (err or "ok"))
         self.out = [torch.zeros((n, eng.obs_dim + 2), device=device, dtype=torch.float32) for _ in range(2)]
         self.all = [torch.zeros((n * w, eng.obs_dim + 2), device=device, dtype=torch.float32) for _ in range(2)] if sharded.rank == 0 else [None, None]
+        self.act_local = torch.zeros((n, eng.act_dim), device=device, dtype=torch.float32)
         self.gather = True
         self.k = 0
+
+    def _all_ok(self, ok):
+        """logical AND of `ok` over the ranks (a MIN all-reduce through the process group the bootstrap uses)"""
+        sh = self.sh
+        if not sh.distributed:
+            return bool(ok)
+        t = self.torch.tensor([1.0 if ok else 0.0], dtype=self.torch.float32)
+        if sh.dist.get_backend() == "nccl":
+            t = t.to(self.dev)
+        sh.dist.all_reduce(t, op=sh.dist.ReduceOp.MIN)
+        return bool(float(t.cpu()[0]) > 0.5)
 
     def step(self, actions, stream=None, timing_events=None):
         b = self.k & 1
@@ -166,9 +194,25 @@ class CtxGatherPipeline(object):
         if self.gather:
             eng.step_gather_device(actions.data_ptr(), self.out[b].data_ptr(), self.all[b].data_ptr() if self.all[b] is not None else 0, stream)
         else:
+            # (a plain step writes out[b] without the exchange bookkeeping: an exchange that may still be reading it is waited for first)
+            eng.gather_wait(stream, host=False)
             eng.step_device(actions.data_ptr(), self.out[b].data_ptr(), stream)
         if timing_events is not None:
             timing_events[1].record()
+        self.k += 1
+        return b
+
+    def closed_loop_step(self, actions_all, stream=None):
+        """One step of a CLOSED loop: rank 0's `actions_all` [total_envs, act_dim] (None elsewhere) are scattered to the ranks, every rank
+        steps its shard, the rows are gathered, and `stream` waits for that gather -- rank 0's policy can read rows(b) of THIS step on
+        `stream` to produce the next actions.  Nothing overlaps: each step needs the previous one's observations."""
+        b = self.k & 1
+        if stream is None:
+            stream = _capi.torch_stream(self.dev)
+        eng = self.sh.engine
+        eng.scatter_actions_device(actions_all.data_ptr() if actions_all is not None else 0, self.act_local.data_ptr(), stream)
+        eng.step_gather_device(self.act_local.data_ptr(), self.out[b].data_ptr(), self.all[b].data_ptr() if self.all[b] is not None else 0, stream)
+        eng.gather_wait(stream, host=False)
         self.k += 1
         return b
 

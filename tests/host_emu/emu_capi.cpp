@@ -30,6 +30,7 @@ extern "C" void pbre_ik_probe_hist(long* h, int clear) {
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_objstep.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_lane.hpp"
+#include "../../pybullet-robot-envs_amd/csrc/pbre_comm_impl.hpp"
 
 #include <type_traits>
 
@@ -320,6 +321,27 @@ static int create(const pbre_config* cfg, pbre_ctx** out) {
     return PBRE_OK;
 }
 
+// runtime policy of csrc/pbre_comm_impl.hpp for the emulation: buffers are host memory, a "stream" is the calling thread
+struct HostRuntime {
+    typedef int stream_t;
+    typedef int event_t;
+    static stream_t to_stream(void* abi, bool& own) { own = false; (void)abi; return 0; }
+    static void* raw(stream_t) { return nullptr; }
+    static std::string set_device(int) { return ""; }
+    static std::string current_device(int* d) { *d = 0; return ""; }
+    static std::string stream_create_high_priority(stream_t* s) { *s = 0; return ""; }
+    static void stream_destroy(stream_t) {}
+    static std::string stream_sync(stream_t) { return ""; }
+    static std::string event_create(event_t* e) { *e = 0; return ""; }
+    static void event_destroy(event_t) {}
+    static std::string event_record(event_t, stream_t) { return ""; }
+    static std::string stream_wait(stream_t, event_t) { return ""; }
+    static std::string event_sync(event_t) { return ""; }
+    static std::string copy_async(void* dst, const void* src, size_t bytes, stream_t) { std::memcpy(dst, src, bytes); return ""; }
+    static int step(pbre_ctx* ctx, const float* act, float* rows, void*) { return pbre_step(ctx, act, rows); }
+};
+typedef pbre_comm_detail::Comm<HostRuntime> EmuComm;
+
 extern "C" {
 
 int pbre_default_config(pbre_config* cfg, int32_t robot, int32_t task) { return default_config(cfg, robot, task); }
@@ -332,7 +354,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (cfg->robot_level && nd <= ShapeIA::NJ) return create<ShapeIA>(cfg, out);
     return nd > Shape32::NJ ? create<Shape64>(cfg, out) : (nd > Shape16::NJ ? create<Shape32>(cfg, out) : create<Shape16>(cfg, out));
 }
-void pbre_destroy(pbre_ctx* c) { delete c; }
+void pbre_destroy(pbre_ctx* c) { if (c) EmuComm::release(c); delete c; }
 const char* pbre_last_error(const pbre_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 int pbre_dims(const pbre_ctx* c, int32_t* od, int32_t* ad, int32_t* n) {
     if (!c) return PBRE_E_ARG;
@@ -447,12 +469,15 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     return PBRE_OK;
 }
 
-// the context-owned RCCL gather (pbre_comm.hip): no communicator in the CPU emulation
-int pbre_comm_unique_id(void*) { return PBRE_E_UNSUPPORTED; }
-int pbre_comm_init(pbre_ctx*, const void*, int32_t, int32_t) { return PBRE_E_UNSUPPORTED; }
-int pbre_step_gather_device(pbre_ctx*, const float*, float*, float*, void*) { return PBRE_E_UNSUPPORTED; }
-int pbre_gather_wait(pbre_ctx*, void*, int32_t) { return PBRE_E_UNSUPPORTED; }
-int pbre_comm_info(const pbre_ctx*, int32_t*, int32_t) { return PBRE_E_UNSUPPORTED; }
-const char* pbre_comm_last_error(const pbre_ctx*) { return "the CPU lane emulation has no RCCL communicator"; }
+// the context-owned exchanges of the sharded batch: the SAME source as the product's (csrc/pbre_comm_impl.hpp) on a host runtime -- host
+// buffers, no streams, everything synchronous.  With tests/fake_rccl as PBRE_RCCL_LIB the world > 1 branch of pbre_step_gather_device /
+// pbre_scatter_actions_device runs between the processes of a CPU test (tests/test_comm_fake_rccl.py).
+int pbre_comm_unique_id(void* id) { return EmuComm::unique_id(id); }
+int pbre_comm_init(pbre_ctx* c, const void* id, int32_t rank, int32_t world) { return EmuComm::init(c, id, rank, world); }
+int pbre_step_gather_device(pbre_ctx* c, const float* a, float* rl, float* ra, void* s) { return EmuComm::step_gather(c, a, rl, ra, s); }
+int pbre_gather_wait(pbre_ctx* c, void* s, int32_t h) { return EmuComm::gather_wait(c, s, h); }
+int pbre_scatter_actions_device(pbre_ctx* c, const float* all, float* local, void* s) { return EmuComm::scatter_actions(c, all, local, s); }
+int pbre_comm_info(const pbre_ctx* c, int32_t* info, int32_t n) { return EmuComm::info(c, info, n); }
+const char* pbre_comm_last_error(const pbre_ctx* c) { return EmuComm::last_error(c); }
 
 }  // extern "C"

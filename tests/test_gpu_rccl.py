@@ -154,3 +154,15 @@ def test_context_owned_rccl_gather_world_size_1(hip_lib, self_p2p, with_torch_nc
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0 and "CTX_RCCL_OK" in r.stdout, tail
     print(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["closed", "open"])
+def test_context_owned_exchanges_two_ranks_on_one_gpu(hip_lib, mode):
+    """world = 2 of csrc/pbre_comm.hip on the GPU: two processes, both on device 0, run pbre_comm_init -> pbre_scatter_actions_device ->
+    pbre_step_gather_device -> pbre_gather_wait with tests/fake_rccl as PBRE_RCCL_LIB (device buffers staged through shared memory; the real
+    RCCL refuses two ranks on one device).  What executes is the product's grouped ncclRecv x world / ncclSend branch, its event
+    ordering between the step stream and the communication stream, and the per-buffer reuse protection; rank 0 finds the stacked rows
+    bit-identical to an unsharded engine's, in a closed loop (actions computed from the gathered observations) and in the overlapped one."""
+    import test_comm_fake_rccl
+    test_comm_fake_rccl.run_world("hip", 2, 2048, 10, mode, timeout=600)
