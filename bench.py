@@ -12,7 +12,8 @@ restart inside the timed region.  The figure right after a fresh reset() (no com
 
 N > 1 (one process per GPU, RCCL over xGMI): the SAME 131072 envs are sharded over the N GPUs (strong scaling, BASELINE
 config 4: 16384 envs per GPU at N = 8) and one RCCL gather per step returns the stacked rows to rank 0, overlapped with the next
-step's kernels.  Extra keys: `weak_scaling_128k_per_gpu` (every GPU keeps a 131072-env shard) and
+step's kernels (an OPEN loop: `value`).  Extra keys: `closed_loop` (action scatter -> step -> gather -> policy on rank 0, nothing
+overlapped: what a policy that needs obs(t) for a(t + 1) gets), `weak_scaling_128k_per_gpu` (every GPU keeps a 131072-env shard) and
 `sharded_consumers_no_gather`.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1 without a launcher: starts its own N ranks
@@ -434,7 +435,8 @@ def main():
             # the ctx's communication stream; sharding.CtxGatherPipeline); should its communicator not come up on EVERY rank, all ranks
             # fall back to torch.distributed's gather (sharding.GatherPipeline).  PBRE_BENCH_CTX_COMM=0 pins the fallback.
             self.pipe, self.comm_kind, self.comm_note = None, "torch.distributed.gather", None
-            if world > 1 and backend == "nccl" and os.environ.get("PBRE_BENCH_CTX_COMM", "1") == "1":
+            # (PBRE_BENCH_CTX_COMM=force: also with a non-nccl bootstrap backend -- the single-GPU control-flow run with tests/fake_rccl as PBRE_RCCL_LIB)
+            if world > 1 and (backend == "nccl" or os.environ.get("PBRE_BENCH_CTX_COMM") == "force") and os.environ.get("PBRE_BENCH_CTX_COMM", "1") != "0":
                 ok, pipe = 1.0, None
                 try:
                     pipe = CtxGatherPipeline(self.sh, dev)
@@ -494,6 +496,31 @@ def main():
 
         def complex_frac(self):
             return self.eng.kernel_info()[5] / float(self.n_local)
+
+        def timed_closed_loop(self, steps, warmup):
+            """(side key, N > 1, context-owned communicator) the CLOSED loop: a policy on rank 0 computes a(t + 1) from the gathered
+            observations of step t, so per step: action scatter (rank 0 -> ranks) -> step kernels -> row gather (ranks -> rank 0) -> policy,
+            nothing overlapped.  The policy is a stand-in of negligible cost that really reads the gathered rows (tanh of the observed joint
+            angles + resident noise), so the data dependence is there."""
+            pipe = self.pipe
+            acts = torch.zeros((self.total, self.eng.act_dim), device=dev) if rank == 0 else None
+            noise = (torch.rand((8, self.total, self.eng.act_dim), device=dev, generator=self.gen) - 0.5) if rank == 0 else None
+            def one(k):
+                b = pipe.closed_loop_step(acts, stream)
+                if rank == 0:
+                    torch.tanh(pipe.all[b][:, 9:9 + self.eng.act_dim] * 3.0, out=acts)
+                    acts.mul_(0.6).add_(noise[k % 8])
+                self.steps_done += 1
+            for k in range(warmup):
+                one(k)
+            self.drain(); barrier()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                one(k)
+            self.drain(); barrier()
+            el = max_over_ranks([time.perf_counter() - t0])[0]
+            return {"value": self.total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3,
+                    "loop": "per step: pbre_scatter_actions_device -> step kernels -> pbre_step_gather_device's exchange -> pbre_gather_wait -> policy on rank 0 (reads the gathered rows)"}
 
         def timed_with_residual_threshold(self, steps, thr=1e-7, settle=100):
             """(side key) the same stationary batch stepped with Bullet's exit test of the sweep loop on (pbre_physics.solver_residual_threshold
@@ -571,6 +598,18 @@ def main():
             rt_side = {str(total): job.timed_with_residual_threshold(max(args.steps, 50))}
         except Exception as e:
             rt_side = {"error": repr(e)}
+
+    # extra at N>1: the closed loop (a policy that needs obs(t) to produce a(t + 1): the gather cannot hide behind the next step)
+    closed_loop = None
+    if world > 1:
+        if isinstance(job.pipe, CtxGatherPipeline):
+            try:
+                closed_loop = job.timed_closed_loop(args.steps, args.warmup)
+                comm_info = job.pipe.info()
+            except Exception as e:
+                closed_loop = {"error": repr(e)}
+        else:
+            closed_loop = {"error": "needs the context-owned communicator (pbre_scatter_actions_device); this run fell back to torch.distributed's gather"}
 
     # extra at N>1: the same steps without the gather (every rank's consumer reads its own shard's rows)
     no_gather = None
@@ -717,6 +756,7 @@ def main():
             "steady_synchronised_clocks": sync_clocks,
             "weak_scaling_128k_per_gpu": weak,
             "sharded_consumers_no_gather": no_gather,
+            "closed_loop": closed_loop,      # N > 1: `value` overlaps the gather of step t with the kernels of step t + 1 (an open loop); this is the figure a policy that needs obs(t) gets
             "host_inclusive": host,      # SURVEY 8(d) literal: upload + kernels + download through the host-buffer entry point; `value` is device-resident stepping
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
