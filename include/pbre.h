@@ -65,7 +65,11 @@ enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE co
        /* Panda, envs without robot contact: the 9 joint-motor rows (p.setJointMotorControl2, panda_env.py:305-310) are a linear
         * iteration there and their `solver_iters` sweeps are evaluated in closed form (a matrix power); this flag runs
         * them as Bullet does, row by row (validation, A/B) */
-       PBRE_F_SEQ_MOTORS = 32 };
+       PBRE_F_SEQ_MOTORS = 32,
+       /* ... and the tail of the sweeps over a resting cube's 12 object-table rows (unclamped, a sweep is one pass of
+        * Kaczmarz's method -- an affine map of the object's twist --, applied as a matrix power where a per-env bound proves that no
+        * clamp can bind); this flag runs all of them row by row (validation, A/B) */
+       PBRE_F_SEQ_OBJECT = 64 };
 
 typedef struct pbre_ctx pbre_ctx;
 

@@ -489,7 +489,7 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
         c->k_steps++;
         return hipGetLastError();
     }
-    flags |= c->cfg.flags & PBRE_F_SEQ_MOTORS;
+    flags |= c->cfg.flags & (PBRE_F_SEQ_MOTORS | PBRE_F_SEQ_OBJECT);
     const int cur = b.cur, nxt = cur ^ 1;
     const int cc = b.ccur, cn = (cc + 1) % 3, cz = (cc + 2) % 3;      // counters: current, next (zero on entry), the one after
     const int blocks = (n + FTPB - 1) / FTPB;
@@ -543,7 +543,7 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
     if (timed) (void)hipEventRecord(ek[0], s_fast);
     // the 3-waves-per-SIMD variant when the complex envs' waves would push k_fast waves of the 2-wave variant into an extra round
     bool fast3 = false;
-    if (!single && c->fast3 != 0) {
+    if (!single && c->fast3 != 0 && !RT) {      // (RT: the sweep loop of the residual-exit variant needs ~170 live registers -- at 168 it spills inside the loop)
         const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 + (hint + REPB - 1) / REPB : (hint + FTPB - 1) / FTPB * 2) + 8;
         fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
     }
@@ -558,10 +558,10 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     } else {
     if (fast3) c->launches3++;
-    if (fast3)
+    if constexpr (!RT) if (fast3)
         hipLaunchKernelGGL((k_fast<MODE, 3, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
-    else
+    if (!fast3)
         hipLaunchKernelGGL((k_fast<MODE, 2, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     }

@@ -360,6 +360,94 @@ struct Fast {
             square(G, H);
         }
     }
+    // Closed form of `n` sweeps over the object-table rows (see the simple class's solver section in step_t for the derivation and the
+    // validity bound).  rx, ry, rz: scaled lever arms of the NK slots; dinv = 1 / |J|^2 per row (0: slot unused, its rows are no-ops);
+    // rhs: the normal rows' right-hand sides (already multiplied by dinv); app: impulses applied so far; v, u: linear velocity and scaled
+    // angular velocity after the explicit sweeps.  xo: the twist after n more sweeps.  Returns whether no clamp can bind in them.
+    static PBRE_HD bool obj_closed(const float (&rx)[NC_OT], const float (&ry)[NC_OT], const float (&rz)[NC_OT], const float (&dinv)[NC_OT][3],
+                                   const float (&rhs)[NC_OT], const float (&app)[NC_OT][3], float mu, V3 v, V3 u, int n, float (&xo)[6]) {
+        constexpr int NK = NC_OT;
+        // row (c, d) as x <- x + (beta - dinv (J.x)) J with J = [dir ; r' x dir]: dir = +z, -y, +x
+        auto Jdot = [&](int c, int d, const float* x) -> float {
+            if (d == 0) return x[2] + ry[c] * x[3] - rx[c] * x[4];
+            if (d == 1) return -x[1] + rz[c] * x[3] - rx[c] * x[5];
+            return x[0] + rz[c] * x[4] - ry[c] * x[5];
+        };
+        auto Jaxpy = [&](int c, int d, float a, float* x) {
+            if (d == 0) { x[2] += a; x[3] = fmaf(a, ry[c], x[3]); x[4] = fmaf(-a, rx[c], x[4]); }
+            else if (d == 1) { x[1] -= a; x[3] = fmaf(a, rz[c], x[3]); x[5] = fmaf(-a, rx[c], x[5]); }
+            else { x[0] += a; x[4] = fmaf(a, rz[c], x[4]); x[5] = fmaf(-a, ry[c], x[5]); }
+        };
+        // one sweep as an affine map: columns 0..5 of B = S, column 6 = s (row order: the 4 normals, then the friction pairs)
+        float B[7][6];
+        PBRE_UNROLL for (int k = 0; k < 7; k++) PBRE_UNROLL for (int i = 0; i < 6; i++) B[k][i] = (i == k) ? 1.f : 0.f;
+        auto rowop = [&](int c, int d) {
+            PBRE_UNROLL for (int k = 0; k < 7; k++) {
+                const float t = Jdot(c, d, B[k]);
+                const float beta = (k == 6 && d == 0) ? rhs[c] : 0.f;
+                Jaxpy(c, d, fmaf(-dinv[c][d], t, beta), B[k]);
+            }
+        };
+        PBRE_UNROLL for (int c = 0; c < NK; c++) rowop(c, 0);
+        PBRE_UNROLL for (int c = 0; c < NK; c++) { rowop(c, 1); rowop(c, 2); }
+        float x[6] = {v.x, v.y, v.z, u.x, u.y, u.z};
+        const float xk[6] = {v.x, v.y, v.z, u.x, u.y, u.z};
+        auto apply = [&](const float (*M)[6]) {
+            float y[6];
+            PBRE_UNROLL for (int i = 0; i < 6; i++) {
+                float a = M[6][i];
+                PBRE_UNROLL for (int k = 0; k < 6; k++) a = fmaf(M[k][i], x[k], a);
+                y[i] = a;
+            }
+            PBRE_UNROLL for (int i = 0; i < 6; i++) x[i] = y[i];
+        };
+        auto square = [&](const float (*M)[6], float (*Q)[6]) {      // Q = M o M: S^2, S s + s
+            PBRE_UNROLL for (int k = 0; k < 7; k++)
+                PBRE_UNROLL for (int i = 0; i < 6; i++) {
+                    float a = k == 6 ? M[6][i] : 0.f;
+                    PBRE_UNROLL for (int j = 0; j < 6; j++) a = fmaf(M[j][i], M[k][j], a);
+                    Q[k][i] = a;
+                }
+        };
+        auto fro2 = [&](const float (*M)[6]) { float a = 0.f; PBRE_UNROLL for (int k = 0; k < 6; k++) PBRE_UNROLL for (int i = 0; i < 6; i++) a = fmaf(M[k][i], M[k][i], a); return a; };
+        float C[7][6];
+        float sig2 = 4.f;                  // |S^16|_F^2 (taken when the running power is 16; n >= 32 makes sure it is reached)
+        int r = n, pw = 1;
+        for (;;) {
+            if (r & 1) apply(B);
+            if (pw == 16) sig2 = fro2(B);
+            r >>= 1; if (!r) break;
+            square(B, C); pw <<= 1;
+            if (r & 1) apply(C);
+            if (pw == 16) sig2 = fro2(C);
+            r >>= 1; if (!r) break;
+            square(C, B); pw <<= 1;
+        }
+        PBRE_UNROLL for (int i = 0; i < 6; i++) xo[i] = x[i];
+        // ---- the bound
+        float rho2 = 0.f;
+        PBRE_UNROLL for (int i = 0; i < 6; i++) { const float e = xk[i] - x[i]; rho2 = fmaf(e, e, rho2); }
+        float eta[NK][3], E = 0.f;
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            const float jb = sqrtf(1.f + fmaf(rx[c], rx[c], fmaf(ry[c], ry[c], rz[c] * rz[c])));      // |J_r| <= jb for the three rows of the slot
+            PBRE_UNROLL for (int d = 0; d < 3; d++) {
+                eta[c][d] = fabsf(fmaf(-dinv[c][d], Jdot(c, d, x), d == 0 ? rhs[c] : 0.f));
+                E = fmaf(eta[c][d], jb, E);
+            }
+        }
+        const float sigma = sqrtf(sig2), nf = (float)n;
+        const float T = (16.f * (sqrtf(rho2) + 17.f * E) + 17.f * nf * E) / (1.f - sigma);
+        bool ok = sigma < 0.9f && T >= 0.f;          // (a NaN anywhere fails one of the comparisons below)
+        PBRE_UNROLL for (int c = 0; c < NK; c++) {
+            const bool used = dinv[c][0] != 0.f;
+            const float nmin = app[c][0] - 2.f * fmaf(nf, eta[c][0], T);
+            bool okc = nmin > 0.f;
+            PBRE_UNROLL for (int d = 1; d < 3; d++) okc = okc && (fabsf(app[c][d]) + 2.f * fmaf(nf, eta[c][d], T) <= mu * nmin);
+            ok = ok && (okc || !used);
+        }
+        return ok;
+    }
+
     // RT: pbre_physics.solver_residual_threshold > 0 (Bullet's exit test of the sweep loop, see step_t); sw: where the number of sweeps the
     // env ran goes (Params::sweeps + the env's local index), or null
     template <bool RT = false>
@@ -939,10 +1027,38 @@ struct Fast {
                 };
                 // (two sweeps per trip: a row's new applied impulse lands in a fresh register, with one sweep per trip every row pays a
                 // register move at the back edge)
-                for (int it = 0; it < P.iters; it += 2) {
+                // Closed form of the tail of the sweeps (PBRE_F_SEQ_OBJECT, flags bit 6, runs all of them row by row: validation, A/B).
+                // In the scaled coordinates of this block (unit mass, unit inertia) an object-table row has J M^-1 J^T = |J|^2 and its
+                // unclamped update  x <- x + (rhs' - (J.x) / |J|^2) J  is the ORTHOGONAL PROJECTION of the twist x onto the row's
+                // hyperplane: a sweep is one pass of Kaczmarz's method, an affine map x <- S x + s whose every factor is non-expansive
+                // in the Euclidean norm.  After OC_K explicit sweeps the remaining N = iters - OC_K are applied as (S, s)^N by binary
+                // powering (~3 k FMAs instead of N x 12 dependent rows), PROVIDED no clamp can bind in any of them.  The test, per lane:
+                // with y = x - x~ (x~: the closed form's own result, the system's solution up to rounding), a row maps y to
+                // P_r y + eta_r J_r, eta_r = the row's delta at x~ (0 for a consistent system), so |y| grows by at most E = sum |eta_r| |J_r|
+                // per sweep and contracts by sigma = |S^16|_F < 1 per 16 sweeps; a row's delta is eta_r - (J_r.y) / |J_r|^2, at most
+                // |eta_r| + |y| in size (|J_r| >= 1: its linear part is a unit vector).  Summed over the N sweeps an applied impulse
+                // therefore moves by at most  mov_r = N |eta_r| + T,  T = (16 (rho + 17 E) + 17 N E) / (1 - sigma),  rho = |x_K - x~|,
+                // from its value after the explicit sweeps.  If every normal impulse stays positive (app_n - mov_n > 0) and every friction
+                // impulse inside its cone (|app_f| + mov_f <= mu (app_n - mov_n)) under these bounds -- doubled, for the rounding of the
+                // bound itself -- no clamp binds and the closed form IS the sequence of rows up to rounding; a lane that fails (cube
+                // sliding, tipping, in flight; NaN) takes the explicit rows for the remaining sweeps.  What a lane computes does not
+                // depend on the lanes it shares a wave with.
+                constexpr int OC_K = 22;
+                const bool want_oc = !(flags & 64) && P.iters >= OC_K + 32 && !(P.iters & 1);
+                const int it_explicit = want_oc ? OC_K : P.iters;
+                for (int it = 0; it < it_explicit; it += 2) {
                     osweep();
-                    if (it + 1 >= P.iters) break;
+                    if (it + 1 >= it_explicit) break;
                     osweep();
+                }
+                if (want_oc) {
+                    float xc[6];
+                    const bool okc = obj_closed(c_rx, c_ry, c_rz, r_dinv, r_rhs, r_app, mu, ov, ow, P.iters - OC_K, xc);
+                    if (PBRE_ANY(!okc)) {
+                        for (int it = OC_K; it < P.iters; it += 2) { osweep(); osweep(); }
+                    }
+                    ov = v3(okc ? xc[0] : ov.x, okc ? xc[1] : ov.y, okc ? xc[2] : ov.z);
+                    ow = v3(okc ? xc[3] : ow.x, okc ? xc[4] : ow.y, okc ? xc[5] : ow.z);
                 }
             } else if (!no_slot) {
                 for (int it = 0; it < P.iters; it++) contacts();

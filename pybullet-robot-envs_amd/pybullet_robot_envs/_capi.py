@@ -17,7 +17,7 @@ STATE_FLOATS = 48
 ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS, ROBOT_PANDA_ARM = 0, 1, 2, 3
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
 SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
-F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES, F_SEQ_MOTORS = 1, 2, 4, 8, 16, 32
+F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES, F_SEQ_MOTORS, F_SEQ_OBJECT = 1, 2, 4, 8, 16, 32, 64
 
 
 class Physics(C.Structure):

@@ -182,7 +182,7 @@ struct Emu : pbre_ctx {
         }
     }
     void settle(int e, int cnt, int flags) {
-        flags |= cfg.flags & PBRE_F_SEQ_MOTORS;
+        flags |= cfg.flags & (PBRE_F_SEQ_MOTORS | PBRE_F_SEQ_OBJECT);
         const int mode = (P.use_ik || S::MREC) ? CoreH::M_TGT : 0;
         for (int i = 0; i < cnt; i++) step_env(&state[(size_t)e * STATE], nullptr, nullptr, mode, flags, 0, &tgt[(size_t)e * TG]);
     }
@@ -245,7 +245,7 @@ struct Emu : pbre_ctx {
             const int tail = last ? (CoreH::M_OBS | CoreH::M_TASK) : (CoreH::M_TASK | CoreH::M_INNER);
             for (int e = 0; e < n; e++) {
                 float* st = &state[(size_t)e * STATE];
-                const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET | PBRE_F_SEQ_MOTORS);
+                const int fl = cfg.flags & (PBRE_F_NO_OBJECT | PBRE_F_AUTO_RESET | PBRE_F_SEQ_MOTORS | PBRE_F_SEQ_OBJECT);
                 const unsigned long long id = P.env_id_base + (unsigned long long)e;
                 float* o = last ? out + (size_t)e * ow : nullptr;
                 if (P.use_ik) {
