@@ -47,6 +47,9 @@
 #ifndef PBRE_COUNT_BAD      // ++*p from any number of lanes (device: atomicAdd)
 #define PBRE_COUNT_BAD(p) (++*(p))
 #endif
+#ifndef PBRE_OC_PROBE       // test builds: count the lanes that pass / fail the validity bound of the object block's closed form
+#define PBRE_OC_PROBE(ok) do {} while (0)
+#endif
 #ifndef PBRE_PAIR_SYNC      // block barrier between the two waves of the pair kernel (device build; never reached on the host)
 #define PBRE_PAIR_SYNC() do {} while (0)
 #endif
@@ -1054,6 +1057,7 @@ struct Fast {
                 if (want_oc) {
                     float xc[6];
                     const bool okc = obj_closed(c_rx, c_ry, c_rz, r_dinv, r_rhs, r_app, mu, ov, ow, P.iters - OC_K, xc);
+                    PBRE_OC_PROBE(okc);
                     if (PBRE_ANY(!okc)) {
                         for (int it = OC_K; it < P.iters; it += 2) { osweep(); osweep(); }
                     }

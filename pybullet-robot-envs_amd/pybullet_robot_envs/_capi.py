@@ -155,6 +155,8 @@ class Engine:
                         getattr(self.cfg.phys, k)[i] = x
                 else:
                     setattr(self.cfg.phys, k, v)
+        if os.environ.get("PBRE_SEQ_OBJECT") == "1":      # A/B knob (tools/, bench side runs): PBRE_F_SEQ_OBJECT on every engine of the process
+            self.cfg.flags |= F_SEQ_OBJECT
         self._table = np.ascontiguousarray(robot_table, dtype=np.float64)
         self.cfg.robot_table = self._table.ctypes.data
         self.cfg.robot_table_len = self._table.size

@@ -2326,3 +2326,65 @@ def check_hands_residual_threshold(Engine, lib, n=1, steps=2, thr=1e-7, seed=9):
     assert flips <= max(1, (flips + same_n) // 4)
     assert_within(worst, TOL_HANDS, "(hands, residual threshold %g, %d env-steps, %d flips)" % (thr, same_n, flips))
     return eng
+
+
+def object_block_states(base, rng, n):
+    """States of the simple class that exercise every branch of the object block's closed form (Fast::obj_closed): cubes at rest, sliding
+    (friction on / near the cone), spinning, dropped from a few mm, tilted onto an edge, tumbling, pressed into the table.  base: one settled
+    state record."""
+    st = np.tile(np.asarray(base, np.float32), (n, 1))
+    kind = rng.integers(0, 7, n)
+    for e in range(n):
+        k = kind[e]
+        if k == 1:
+            v, a = 10 ** rng.uniform(-5, -0.3), rng.uniform(0, 2 * np.pi)
+            st[e, 25], st[e, 26] = v * np.cos(a), v * np.sin(a)
+        elif k == 2:
+            st[e, 30] = 10 ** rng.uniform(-4, 1) * rng.choice([-1, 1])
+        elif k == 3:
+            st[e, 11] += 10 ** rng.uniform(-5, -1.5)
+        elif k == 4:
+            th, ax = 10 ** rng.uniform(-4, -0.3), rng.uniform(0, 2 * np.pi)
+            st[e, 12:16] = [np.sin(th / 2) * np.cos(ax), np.sin(th / 2) * np.sin(ax), 0.0, np.cos(th / 2)]
+            st[e, 11] += 0.04 * np.sin(th)
+        elif k == 5:
+            st[e, 28:30] = rng.normal(0, 1, 2) * 10 ** rng.uniform(-3, 0.5)
+        elif k == 6:
+            st[e, 27] = -10 ** rng.uniform(-4, 0)
+    return st, kind
+
+
+def check_closed_form_object_rows(Engine, lib, table, n=256, steps=12, seed=17, stats=None):
+    """The simple class applies the tail of its sweeps over a resting cube's object-table rows in closed form where a per-env bound proves
+    that no clamp binds (Fast::obj_closed); PBRE_F_SEQ_OBJECT runs Bullet's sequential rows throughout.  Same states, one step each:
+    the robot (which these rows do not touch) bit for bit, the object's twist and pose within a quarter of the single-step bounds
+    against the oracle -- for cubes at rest (closed form taken) and for sliding / tilted / tumbling ones (explicit rows: bit for bit, then
+    closed form again once they have come to rest).  stats(): optional callable returning (failed, passed) lane counts (emulation)."""
+    rng = np.random.default_rng(seed)
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=lib)
+    from pybullet_robot_envs import _capi
+    c = Engine(table, **kw)
+    s = Engine(table, flags=_capi.F_SEQ_OBJECT, **kw)
+    c.reset()
+    st, kind = object_block_states(c.get_state()[0], rng, n)
+    c.set_state(st)
+    if stats:
+        stats(True)
+    worst, exact = {}, 0
+    for k in range(steps):
+        a = (rng.uniform(-1, 1, (n, 7)) * 0.3).astype(np.float32)      # (small moves: the arm stays away from the cube, every env in the simple class)
+        s.set_state(c.get_state())
+        (obc, rwc, dnc), (obs_, rws, dns) = c.step(a), s.step(a)
+        sc, ss = c.get_state(), s.get_state()
+        assert c.kernel_info()[5] == 0, "an env left the simple class"
+        assert np.array_equal(sc[:, :9], ss[:, :9]) and np.array_equal(sc[:, 16:25], ss[:, 16:25]) and np.array_equal(dnc, dns)
+        exact += int((sc[:, 25:31] == ss[:, 25:31]).all(axis=1).sum())
+        out_s = np.concatenate([obs_, rws[:, None], dns[:, None]], 1).astype(np.float64)
+        merge_worst(worst, panda_quantities(sc, ss.astype(np.float64), obc, out_s, rwc))
+    assert_within(worst, dict((kk, 0.25 * v) for kk, v in TOL.items()), "(closed-form object rows against the sequential rows)")
+    rep = {"worst": worst, "bitwise_equal_env_steps": exact, "env_steps": n * steps}
+    if stats:
+        failed, passed = stats(False)
+        rep.update({"lanes_failed": failed, "lanes_passed": passed})
+        assert passed > n * steps // 2 and failed > n // 8, rep       # both branches were taken
+    return rep

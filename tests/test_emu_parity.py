@@ -366,3 +366,13 @@ def test_solver_residual_threshold_is_off_by_default_and_validated(panda, emu_li
     eng.step(np.zeros((2, 7), np.float32))
     sw = eng.get_sweeps()
     assert sw.shape == (2,) and (sw >= 1).all() and (sw < 150).all()       # a hold step at rest converges in a few sweeps
+
+
+def test_closed_form_object_rows_match_the_sequential_rows(panda, emu_lib):
+    import ctypes as C
+    out = (C.c_long * 2)()
+    def stats(reset):
+        emu_lib.pbre_emu_oc_stats(out, 1 if reset else 0)
+        return out[0], out[1]
+    rep = parity.check_closed_form_object_rows(_capi.Engine, emu_lib, panda["table"], n=96, steps=10, stats=stats)
+    assert rep["bitwise_equal_env_steps"] >= rep["lanes_failed"]        # a lane that fails the bound ran the explicit rows: the same numbers

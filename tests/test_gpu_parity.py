@@ -695,3 +695,11 @@ def test_solver_residual_threshold_results_do_not_depend_on_wave_mates_or_shardi
         early += int((sw < 150).sum())
     assert np.array_equal(a.get_state(), b.get_state())
     assert a.kernel_info()[7] > 0 and early > 20 * n
+
+
+def test_closed_form_object_rows_match_the_sequential_rows(panda, hip_lib):
+    """k_fast / k_fast_pair with the object block's closed form against the same kernels with PBRE_F_SEQ_OBJECT (all 150 sweeps row by
+    row), on cubes at rest, sliding, spinning, dropped, tilted, tumbling, pressed (parity.check_closed_form_object_rows); the bound behind
+    the closed form is checked independently in tests/test_objblock_bound.py."""
+    rep = parity.check_closed_form_object_rows(_capi.Engine, hip_lib, panda["table"], n=4096, steps=12)
+    assert rep["bitwise_equal_env_steps"] > 0       # lanes that failed the bound ran the explicit rows
