@@ -1054,12 +1054,31 @@ struct Core {
             // ---- a motor row (motor_x) in 4 stages on dvr
             FR m_nt = zeroR, m_d = zeroR, m_lo = zeroR, m_hi = zeroR;
             F m_bc = zero;
-            auto mstage = [&](auto jc, auto sc) {
+            // FREE (round 5): the same row WITHOUT its clamp, in 3 stages -- delta = rhs' - dinv dv_j goes straight to the broadcast.  While no
+            // motor reaches its impulse bound (PyBullet's default force, 1e5 N, is far out of reach) this is the clamping row's delta bit for
+            // bit (a med3 whose bounds do not bind returns its first operand), at 5 instructions instead of 9 on the wave's serial chain.  The
+            // deltas of a sweep are collected in m_dsel, added to the applied impulses after the sweep's motor rows and tested against the
+            // bound there (a motor's impulse only changes in its own row: every value it takes is seen); if one ever leaves it, the solve
+            // starts over with the clamping stages -- same mechanism as the wide shapes' FREE_ROWS above.
+            FR m_dsel = zeroR;
+            auto mstage = [&](auto jc, auto sc, auto freec) {
                 constexpr int j = decltype(jc)::value, st = decltype(sc)::value;
+                constexpr bool FREE = decltype(freec)::value;
+                if constexpr (FREE) {
+                    if constexpr (st == 0) m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs);
+                    else if constexpr (st == 1) { m_dsel = LR::setlane(m_dsel, j, m_nt); m_bc = LR::bcast(m_nt, j); }
+                    else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
+                } else {
                 if constexpr (st == 0) { m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs); m_lo = nmlim - R.m_app; m_hi = R.m_lim - R.m_app; }
                 else if constexpr (st == 1) m_d = LR::med3(m_nt, m_lo, m_hi);
                 else if constexpr (st == 2) { R.m_app = LR::setlane(R.m_app, j, R.m_app + m_d); m_bc = LR::bcast(m_d, j); if constexpr (RT) m_dsw = LR::setlane(m_dsw, j, m_d); }
                 else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
+                }
+            };
+            // end of a sweep's clamp-free motor rows: false if an applied impulse has left its bound (a NaN fails the test too)
+            auto free_in_bound = [&]() {
+                R.m_app = R.m_app + m_dsel;
+                return !LR::any(LR::bnot(LR::le(LR::abs(R.m_app), R.m_lim)));
             };
             auto limit2 = [&](int j) {
                 FR t = LR::fma(R.l_j, L::lo(dvr), zeroR - R.l_rhs);
@@ -1106,13 +1125,14 @@ struct Core {
             };
             constexpr int NRT0 = NC_OT + NC_RO;
             // (RTf' M || OTn): robot stream = [2 NC_RT friction rows of the previous sweep] + NJ motor rows, object stream = NC_OT normal rows
-            auto phase_a = [&](auto rev_c, auto e_c) {
+            auto phase_a = [&](auto rev_c, auto e_c, auto freec) {
                 constexpr bool REV = decltype(rev_c)::value, WITH_E = decltype(e_c)::value;
-                constexpr int NE = WITH_E ? 2 * NC_RT * NSR : 0, NR = NE + 4 * NJ, NO = NSO * NC_OT, NZ = NR > NO ? NR : NO;
+                constexpr int MS = decltype(freec)::value ? 3 : 4;       // stages of a motor row
+                constexpr int NE = WITH_E ? 2 * NC_RT * NSR : 0, NR = NE + MS * NJ, NO = NSO * NC_OT, NZ = NR > NO ? NR : NO;
                 for_seq<NZ>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k < NE) fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{});
-                    else if constexpr (k < NR) { constexpr int r = (k - NE) / 4; mstage(std::integral_constant<int, (REV ? NJ - 1 - r : r)>{}, std::integral_constant<int, (k - NE) % 4>{}); }
+                    else if constexpr (k < NR) { constexpr int r = (k - NE) / MS; mstage(std::integral_constant<int, (REV ? NJ - 1 - r : r)>{}, std::integral_constant<int, (k - NE) % MS>{}, freec); }
                     if constexpr (k < NO) nstage(fo, dvo, std::integral_constant<int, k / NSO>{}, std::integral_constant<int, k % NSO>{});
                 });
             };
@@ -1126,9 +1146,12 @@ struct Core {
                     if constexpr (k < NO) fstage(fo, dvo, std::integral_constant<int, (k / NSO) / 2>{}, std::integral_constant<int, (k / NSO) % 2>{}, std::integral_constant<int, k % NSO>{});
                 });
             };
-            auto coupled = [&](bool fric) {       // robot-object rows on the merged vector
+            // NRO > 0: the wave uses exactly the first NRO robot-object slots (slots fill in rank order) -- no per-slot scalar test and branch
+            // between the rows (a test + branch costs a lone wave ~15 cycles, three dependent instructions' worth); 0: test every slot
+            auto coupled = [&](bool fric, auto nroc) {       // robot-object rows on the merged vector
+                constexpr int NRO = decltype(nroc)::value;
                 F dvc = L::sel(obj_lane, dvo, dvr);
-                PBRE_UNROLL for (int c = NC_OT; c < NC_OT + NC_RO; c++) if ((on_bits >> c) & 1u) {
+                PBRE_UNROLL for (int c = NC_OT; c < NC_OT + (NRO ? NRO : NC_RO); c++) if (NRO || ((on_bits >> c) & 1u)) {
                     if (!fric) res_of(c, 0, row<false>(R.rs.get(6 * c), R.rs.get(6 * c + 1), R.an[c], zero, big, dvc));
                     else {
                         F lim = R.mu[c] * R.an[c];
@@ -1145,21 +1168,29 @@ struct Core {
                 return sweep_end(it, L::sel(obj_lane, dvo, dvr));
             };
             auto rt_f = [&]() { for_seq<2 * NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{}); }); };
-            if (robot_only) {
+            // the sweeps; FREE: with the clamp-free motor stages -- returns false if a motor impulse left its bound on the way (the caller
+            // then starts over with the clamping stages)
+            auto run_chains = [&](auto freec, auto nroc) -> bool {
+                constexpr bool FREE = decltype(freec)::value;
+                constexpr int MS = FREE ? 3 : 4;
+                constexpr int NRO = decltype(nroc)::value;
+            if (NRO == 0 && robot_only) {
                 robot_only_path = true;
                 auto motors = [&](auto rev_c) {
                     constexpr bool REV = decltype(rev_c)::value;
-                    for_seq<4 * NJ>([&](auto kc) { constexpr int k = decltype(kc)::value; mstage(std::integral_constant<int, (REV ? NJ - 1 - k / 4 : k / 4)>{}, std::integral_constant<int, k % 4>{}); });
+                    for_seq<MS * NJ>([&](auto kc) { constexpr int k = decltype(kc)::value; mstage(std::integral_constant<int, (REV ? NJ - 1 - k / MS : k / MS)>{}, std::integral_constant<int, k % MS>{}, freec); });
                 };
                 auto rt_n = [&]() { for_seq<NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; nstage(fr, dvr, std::integral_constant<int, NRT0 + k / NSR>{}, std::integral_constant<int, k % NSR>{}); }); };
                 for (int it = 0; it < P.iters; it += 2) {
                     motors(std::true_type{});
+                    if constexpr (FREE) { if (!free_in_bound()) return false; }
                     if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
                     if (rt_bits) { rt_n(); rt_f(); }
                     if constexpr (RT) { if (chains_end(it)) break; }
                     if (it + 1 >= P.iters) break;
                     if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j); }
                     motors(std::false_type{});
+                    if constexpr (FREE) { if (!free_in_bound()) return false; }
                     if (rt_bits) { rt_n(); rt_f(); }
                     if constexpr (RT) { if (chains_end(it + 1)) break; }
                 }
@@ -1167,13 +1198,14 @@ struct Core {
             } else {
             const bool e_zip = !RT && rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows (RT: a sweep ends where Bullet's does)
             auto mid = [&]() {            // the rest of a sweep after its motor / limit / OT-normal rows
-                if (ro_bits) coupled(false);
+                if (NRO || ro_bits) coupled(false, nroc);
                 if (rt_bits) phase_c(std::true_type{}); else phase_c(std::false_type{});
-                if (ro_bits) coupled(true);
+                if (NRO || ro_bits) coupled(true, nroc);
                 if (rt_bits && !e_zip) rt_f();
             };
             for (int it = 0; it < P.iters; it += 2) {
-                if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}); else phase_a(std::true_type{}, std::false_type{});
+                if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}, freec); else phase_a(std::true_type{}, std::false_type{}, freec);
+                if constexpr (FREE) { if (!free_in_bound()) return false; }
                 if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
                 mid();
                 if constexpr (RT) { if (chains_end(it)) break; }
@@ -1181,13 +1213,39 @@ struct Core {
                 if (has_limit) {          // odd sweep: limits first, then the motors in forward order
                     PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
                 }
-                if (e_zip) phase_a(std::false_type{}, std::true_type{}); else phase_a(std::false_type{}, std::false_type{});
+                if (e_zip) phase_a(std::false_type{}, std::true_type{}, freec); else phase_a(std::false_type{}, std::false_type{}, freec);
+                if constexpr (FREE) { if (!free_in_bound()) return false; }
                 mid();
                 if constexpr (RT) { if (chains_end(it + 1)) break; }
             }
             if (e_zip) rt_f();            // the last sweep's
             dv = L::sel(obj_lane, dvo, dvr);
             }
+                return true;
+            };
+#ifndef PBRE_FREE_MOTOR_STAGES      // (0: A/B -- always the clamping stages)
+#define PBRE_FREE_MOTOR_STAGES 1
+#endif
+            // clamp-free first unless a motor of the wave is force-limited (those do reach their bound) or the residual exit is on
+            bool done2 = false;
+            // (the usual coupled wave: one or two robot-object slots in use)
+#ifndef PBRE_NRO_SPECIAL      // (0: A/B -- per-slot tests in every wave)
+#define PBRE_NRO_SPECIAL 1
+#endif
+            auto run_n = [&](auto freec) -> bool {
+                if (PBRE_NRO_SPECIAL && !robot_only && ro_bits == 1u) return run_chains(freec, std::integral_constant<int, 1>{});
+                if (PBRE_NRO_SPECIAL && !robot_only && ro_bits == 3u) return run_chains(freec, std::integral_constant<int, 2>{});
+                return run_chains(freec, std::integral_constant<int, 0>{});
+            };
+            if (PBRE_FREE_MOTOR_STAGES && !RT && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
+                done2 = run_n(std::true_type{});
+                if (!done2) {             // start over with clamping rows
+                    dvr = dv; dvo = dv; m_dsel = zeroR;
+                    R.m_app = zeroR; R.l_app = zeroR;
+                    PBRE_UNROLL for (int c = 0; c < NC; c++) { R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero; }
+                }
+            }
+            if (!done2) (void)run_n(std::false_type{});
         }
         }
         if (solved || solved2) {
