@@ -1223,9 +1223,9 @@ struct Core {
             }
                 return true;
             };
-#ifndef PBRE_FREE_MOTOR_STAGES      // (0: A/B -- always the clamping stages)
-#define PBRE_FREE_MOTOR_STAGES 1
-#endif
+#ifndef PBRE_FREE_MOTOR_STAGES      // 1: try the clamp-free motor stages first.  OFF: measured on MI355X (profiles/r05_chain_ab4.txt, same box, four builds)
+#define PBRE_FREE_MOTOR_STAGES 0      // the stationary step got SLOWER with them -- 16384 envs 0.133 -> 0.140 ms, 131072 envs 0.188 -> 0.192 ms -- although a
+#endif                                // row is 5 instructions instead of 9: the clamping row's bound arithmetic is what fills the DPP wait states of its broadcast
             // clamp-free first unless a motor of the wave is force-limited (those do reach their bound) or the residual exit is on
             bool done2 = false;
             // (the usual coupled wave: one or two robot-object slots in use)
