@@ -15,6 +15,8 @@
  * Per-env state record: three lane records Q[W] | V[W] | X[16] floats; W = 16 for robots with <= 9 DoF
  * (Panda: 48 floats), W = 32 for <= 20 DoF (the iCub as simulated, without its legs: 80 floats), W = 64 for <= 32 DoF, W = 128 for <= 60
  * (the iCub with hands: 272 floats); the Panda's and the iCub's robot-level engines (robot_level = 1) use W = 32 (80 floats); nd = number of DoF:
+ *   (nd below: the DoF LANES of the kernel shape -- 9, 20, 32 or 60 -- which every shipped model fills exactly except the soft-pinned
+ *   floating-base iCub, 26 DoF on the 32-lane shape: its joints are Q[0..26), lanes 26..31 are unused, the object follows at 32)
  *   Q[0..nd)  joint positions         Q[nd..nd+3)  object position   Q[nd+3..nd+7) object quaternion (x,y,z,w)
  *   V[0..nd)  joint velocities        V[nd..nd+3)  object lin. vel.  V[nd+3..nd+6) object ang. vel.
  *   X[0..2]  push target   X[3] step counter  X[4] terminated flag  X[5] episode   X[6..11] commanded hand pose (IK mode)
@@ -30,7 +32,8 @@
  *   [6..8] base position  [9..17] base rotation (row major)  [18] fixed_base  [19..23] reserved
  *   then n_links records of 40: parent, jtype(0 fixed,1 revolute,2 prismatic), axis[3], origin_xyz[3],
  *        origin_R[9], mass, com[3], inertia[9] (about COM, link axes), lower, upper, damping,
- *        dof_index(-1 fixed), lateral_friction, effort, velocity, reserved[3]
+ *        dof_index(-1 fixed), lateral_friction, effort, velocity, ik_passive (1: a joint the inverse kinematics must not move -- the
+ *        virtual joints of a soft-pinned floating base, model/table.py: float_base), reserved[2]
  *   then n_spheres records of 8: link, centre[3], radius, friction, fingertip slot + 1 (0: not a fingertip), reserved
  */
 #ifndef PBRE_H

@@ -142,7 +142,7 @@ int orc_model_from_table(const double* t, size_t n, orc_model* m) {
         for (int k = 0; k < 3; k++) { m->axis[i][k] = (real)r[2+k]; m->Xp[i][k] = (real)r[5+k]; m->com[i][k] = (real)r[18+k]; }
         for (int k = 0; k < 9; k++) { m->XR[i][k] = (real)r[8+k]; m->inertia[i][k] = (real)r[21+k]; }
         m->mass[i] = (real)r[17]; m->lower[i] = (real)r[30]; m->upper[i] = (real)r[31];
-        m->damping[i] = (real)r[32]; m->dof[i] = (int)r[33]; m->friction[i] = (real)r[34];
+        m->damping[i] = (real)r[32]; m->dof[i] = (int)r[33]; m->friction[i] = (real)r[34]; m->passive[i] = (int)r[37];
         if (m->dof[i] >= 0) m->link_of_dof[m->dof[i]] = i;
     }
     for (int k = 0; k < m->ns; k++) {
@@ -897,7 +897,7 @@ int orc_ik(const orc_model* m, const orc_task* t, const real* q_start, const rea
         /* Jacobian columns of the joints on the chain */
         real J[6][ORC_MAXD]; memset(J, 0, sizeof J);
         for (int i = ee; i >= 0; i = m->parent[i]) {
-            if (m->jtype[i] == 0) continue;
+            if (m->jtype[i] == 0 || m->passive[i]) continue;
             real aw[3], tt[3]; m3_v(R + 9*i, m->axis[i], aw);
             const int d = m->dof[i];
             if (m->jtype[i] == 1) { real rr[3] = {pe[0]-p[3*i], pe[1]-p[3*i+1], pe[2]-p[3*i+2]}; cross(aw, rr, tt); for (int k = 0; k < 3; k++) { J[k][d] = tt[k]; J[3+k][d] = aw[k]; } }

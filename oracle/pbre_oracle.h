@@ -58,6 +58,7 @@ typedef struct {
     int s_tip[ORC_MAXS];           /* fingertip slot + 1 of the sphere (0: not a fingertip) */
     int ntip;                      /* > 0: the model reports fingertip contact forces (iCub with hands) */
     int link_of_dof[ORC_MAXD];
+    int passive[ORC_MAXL];         /* 1: a joint the inverse kinematics does not move (RobotTable link record [37]: the virtual joints of a soft-pinned floating base) */
 } orc_model;
 
 /* numeric parameters of the simulated scene + task; mirrors pbre_params in include/pbre.h */

@@ -238,6 +238,8 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         for (int a = 0; a < 3; a++) T.ee_p[a] = (float)(F.p[a] + F.R[a*3] * r[18] + F.R[a*3+1] * r[19] + F.R[a*3+2] * r[20]);
         for (int a = 0; a < 3; a++) T.ee_lp[a] = (float)F.p[a];
         for (int l = 0; l < NJ; l++) T.on_chain[l] = (int)((unsigned)T.amask[l >> 5][T.ee_owner] >> (l & 31) & 1u);
+        // (link record [37]: a joint the inverse kinematics must not move -- the virtual joints of a soft-pinned floating base)
+        for (int i = 0; i < nl; i++) if (lane_of[i] >= 0 && owner[i] == i && (int)L(i)[37] != 0) T.on_chain[lane_of[i]] = 0;
     }
     for (int s = 0; s < ns; s++) {
         const double* r = t + 24 + nl * 40 + s * 8;

@@ -170,6 +170,9 @@ class Engine:
         self.state_floats = int(self.lib.pbre_state_floats(self._ctx))
         # state record layout (include/pbre.h): Q[W] | V[W] | X[16]; object pose at Q[ndof..ndof+7)
         self.ndof = int(self._table[3])
+        # where the object's pose / twist sits inside the Q / V records: behind the DoF LANES of the kernel shape the engine picked (9, 20, 32,
+        # 60; include/pbre.h) -- equal to ndof for every model but the soft-pinned floating-base iCub (26 DoF on the 32-lane shape)
+        self.obj_off = 9 if self.ndof <= 9 else (20 if self.ndof <= 20 else (32 if self.ndof <= 32 else 60))
         self.v_off = (self.state_floats - 16) // 2
         self.x_off = self.state_floats - 16
         # page-locked staging buffers of the host path (pbre_step DMAs straight from / into them): actions, and two row
@@ -425,6 +428,7 @@ class MultiEngine(object):
         e0 = self.shards[0]
         self.obs_dim, self.act_dim, self.state_floats = e0.obs_dim, e0.act_dim, e0.state_floats
         self.ndof, self.v_off, self.x_off, self.cfg, self.lib = e0.ndof, e0.v_off, e0.x_off, e0.cfg, e0.lib
+        self.obj_off = e0.obj_off
         self.num_envs = int(num_envs)
         self._pool = ThreadPoolExecutor(max_workers=g)
 

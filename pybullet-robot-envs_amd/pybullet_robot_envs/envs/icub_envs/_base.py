@@ -13,7 +13,7 @@ from pybullet_robot_envs.envs.world_envs.world_env import WorldEnv
 class ICubTaskBase(PandaTaskBase):
 
     def _setup_icub(self, action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std, tg_pose_rnd_std,
-                    renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset=False):
+                    renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset=False, floating_base=False):
         self._time_step = 1. / 240.
         self._control_arm = control_arm
         self._use_IK = use_IK
@@ -35,7 +35,7 @@ class ICubTaskBase(PandaTaskBase):
 
         # Load robot (icub_reach_gym_env.py:68-70)
         self._robot = iCubEnv(self._physics_client_id, use_IK=self._use_IK, control_arm=self._control_arm,
-                              control_orientation=self._control_orientation)
+                              control_orientation=self._control_orientation, floating_base=floating_base)
 
         # Load world environment (:73-75)
         self._world = WorldEnv(self._physics_client_id, obj_name=obj_name, obj_pose_rnd_std=obj_pose_rnd_std,
@@ -77,7 +77,7 @@ class ICubTaskBase(PandaTaskBase):
                          robot_ws=[x for lim in r.get_workspace() for x in lim])
         c.engine = _capi.make_engine(r.robot_table, devices=c.devices, task=self._TASK, num_envs=c.num_envs, lib=c.lib, robot=_capi.ROBOT_ICUB,
                                       phys=self._world.object_physics(), **overrides)
-        assert c.engine.act_dim == r.get_action_dim() and c.engine.state_floats == 80
+        assert c.engine.act_dim == r.get_action_dim() and c.engine.state_floats == (144 if r._floating_base else 80)
         self._engine = c.engine
 
     def _exact_limits(self, lim32):

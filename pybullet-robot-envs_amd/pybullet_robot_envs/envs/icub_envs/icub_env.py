@@ -38,7 +38,10 @@ class iCubEnv:
                               'r_elbow', 'r_wrist_pitch', 'r_wrist_prosup', 'r_wrist_yaw'],
                     }
 
-    def __init__(self, physicsClientId, use_IK=0, control_arm='l', control_orientation=1, control_eu_or_quat=0):
+    def __init__(self, physicsClientId, use_IK=0, control_arm='l', control_orientation=1, control_eu_or_quat=0, floating_base=False):
+        # floating_base (new, trailing; default: the base rigidly pinned at the constraint's rest pose): the reference's soft-pinned floating
+        # base as a dynamic body -- model/table.py: float_base (six virtual joints held by the constraint's equivalent motors, legs lumped)
+        self._floating_base = bool(floating_base)
 
         self._physics_client_id = physicsClientId
         self._client = _client.get(physicsClientId)
@@ -78,7 +81,7 @@ class iCubEnv:
         # the model without the legs: limbs rooted at the fixed base are independent dynamical systems, the legs carry no
         # collision geometry and no env observes them, so they cannot change any output (model/table.py prune_base_branches;
         # tests/test_golden_icub.py::test_pruned_legs_are_exact).
-        self.robot_table, self._sim_model, self._info = icub_table(self._control_arm)
+        self.robot_table, self._sim_model, self._info = icub_table(self._control_arm, floating_base=self._floating_base)
         _, self._model, self._full_info = icub_table(self._control_arm, full=True)
         self._joint_name_to_ids = {}
         for i, link in enumerate(self._model["links"]):
@@ -108,7 +111,7 @@ class iCubEnv:
 
     def sim_home(self):
         """initial_positions per DoF of the simulated model"""
-        return [self.initial_positions[n] for n in self._info["dof_names"]]
+        return [self.initial_positions.get(n, 0.0) for n in self._info["dof_names"]]
 
     def get_joint_ranges(self):
         """lower / upper limits, ranges, rest poses (= initial positions) and IK joint damping (0.1 controlled, 100 blocked) of
@@ -271,7 +274,7 @@ class iCubEnv:
     def get_object_pose(self):
         """[N, 7] position + quaternion of the scene's object."""
         eng = self._engine_or_build()
-        return eng.get_state_cols(eng.ndof, 7).astype(np.float64)
+        return eng.get_state_cols(eng.obj_off, 7).astype(np.float64)
 
     def get_joint_positions(self):
         """[N, ndof] joint positions of the simulated model, `self._info['dof_names']` order."""

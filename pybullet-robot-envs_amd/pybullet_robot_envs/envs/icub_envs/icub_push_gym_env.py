@@ -22,10 +22,10 @@ class iCubPushGymEnv(ICubTaskBase):
                  renders=False,
                  max_steps=2000,
                  reward_type=1,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None, floating_base=False):
         device_id = devices if devices is not None else device_id
         self._setup_icub(action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std, tg_pose_rnd_std,
-                         renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset)
+                         renders, max_steps, reward_type, num_envs, device_id, env_id_base, seed, _lib, auto_reset, floating_base)
 
     @property
     def _init_dist_hand_obj(self):
@@ -39,7 +39,7 @@ class iCubPushGymEnv(ICubTaskBase):
         eng = self._engine
         st = eng.get_state().astype(np.float64)
         ee = eng.observe()[:, :3].astype(np.float64)
-        ob = st[:, eng.ndof:eng.ndof + 3]
+        ob = st[:, eng.obj_off:eng.obj_off + 3]
         return goal_distance(ee, ob), goal_distance(ob, st[:, eng.x_off:eng.x_off + 3]), st
 
     def _termination(self):

@@ -20,16 +20,16 @@ class iCubReachGymEnv(ICubTaskBase):
                  obj_pose_rnd_std=0,
                  renders=False,
                  max_steps=2000,
-                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None):
+                 num_envs=1, device_id=0, env_id_base=0, seed=1234, auto_reset=False, _lib=None, devices=None, floating_base=False):
         device_id = devices if devices is not None else device_id
         self._setup_icub(action_repeat, use_IK, control_arm, control_orientation, obj_name, obj_pose_rnd_std, 0.0,
-                         renders, max_steps, 1, num_envs, device_id, env_id_base, seed, _lib, auto_reset)
+                         renders, max_steps, 1, num_envs, device_id, env_id_base, seed, _lib, auto_reset, floating_base)
 
     def _distance(self):
         eng = self._engine
         st = eng.get_state().astype(np.float64)
         ee = eng.observe()[:, :3].astype(np.float64)
-        return goal_distance(ee, st[:, eng.ndof:eng.ndof + 3]), st
+        return goal_distance(ee, st[:, eng.obj_off:eng.obj_off + 3]), st
 
     def _termination(self):
         d, st = self._distance()

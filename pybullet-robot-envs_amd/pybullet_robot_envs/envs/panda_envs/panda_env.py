@@ -277,7 +277,7 @@ class pandaEnv:
     def get_object_pose(self):
         """[N, 7] position + quaternion of the object of the demo scene (the demo reads it back through PyBullet)."""
         eng = self._engine_or_build()
-        return eng.get_state_cols(eng.ndof, 7).astype(np.float64)
+        return eng.get_state_cols(eng.obj_off, 7).astype(np.float64)
 
     def seed(self, seed=None):
         self.np_random, seed = seeding.np_random(seed)

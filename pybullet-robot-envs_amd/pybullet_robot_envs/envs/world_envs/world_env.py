@@ -111,7 +111,7 @@ class WorldEnv:
     def get_object_pose(self):
         """Batched object position [N,3] and quaternion [N,4]."""
         eng = self._client.require_engine()
-        st, o = eng.get_state(), eng.ndof
+        st, o = eng.get_state(), eng.obj_off
         return st[:, o:o + 3].astype(np.float64), st[:, o + 3:o + 7].astype(np.float64)
 
     def get_observation(self):
@@ -150,7 +150,7 @@ class WorldEnv:
         else:
             raise ValueError("check_contact: body_id %r is neither this world's table_id (%d) nor the robot's robot_id" % (body_id, self.table_id))
         no_obj = bool(eng.cfg.flags & 1)
-        f = contacts.contact_flags(robot.robot_table, eng.get_state(), eng.ndof, eng.get_physics(), no_obj)
+        f = contacts.contact_flags(robot.robot_table, eng.get_state(), eng.obj_off, eng.get_physics(), no_obj)
         hit = (f & bit) != 0
         return bool(hit[0]) if hit.shape[0] == 1 else hit
 

@@ -106,7 +106,7 @@ def contact_flags(table, state, ndof, phys, no_object=False):
     st = np.asarray(state, float)
     n = st.shape[0]
     nl, ns = int(table[2]), int(table[5])
-    R, p = link_frames(table, st[:, :ndof])
+    R, p = link_frames(table, st[:, :int(table[3])])      # (ndof: where the object sits in the record = Engine.obj_off; the joints are the table's)
     margin = float(phys.contact_margin)
     tc, th = np.array(list(phys.table_c), float), np.array(list(phys.table_h), float)
     oh = np.array(list(phys.obj_h), float)

@@ -142,3 +142,26 @@ def test_icub_solver_residual_threshold(emu_lib, task):
     eng, ora, info = parity.make_icub_pair(_capi.Engine, emu_lib, 4, task, "l", 0, 0, obj_std=0.05, tg_std=0.2)
     eng.reset(); st, _ = ora.batch_reset(4)
     parity.check_group_residual_threshold(eng, ora, st, np.random.default_rng(5), parity.TOL_ICUB, steps=3)
+
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_icub_floating_base_option(emu_lib, use_ik):
+    """Fidelity option for the reference's floating base held by createConstraint(JOINT_FIXED) (icub_env.py:95-101): the base as a dynamic
+    body -- six virtual joints held by the constraint's equivalent motors, legs lumped (model/table.py: float_base) -- on the 64-lane
+    shape: against the oracle on the same model, and its (small, measured) effect against the rigidly pinned default."""
+    rep = parity.check_icub_floating_base(_capi.Engine, emu_lib, n=2, steps=3, use_ik=use_ik)
+    assert rep["ee_pos_shift_vs_pinned_base_40_steps_m"] < 2e-3
+
+
+def test_icub_floating_base_through_the_gym_classes(emu_lib):
+    from pybullet_robot_envs.envs import iCubReachGymEnv
+    a = iCubReachGymEnv(num_envs=2, _lib=emu_lib, obj_pose_rnd_std=0.05)
+    b = iCubReachGymEnv(num_envs=2, _lib=emu_lib, obj_pose_rnd_std=0.05, floating_base=True)
+    oa, ob = a.reset(), b.reset()
+    assert oa.shape == ob.shape == (2, 31) and b._engine.ndof == 26 and b._engine.obj_off == 32
+    assert np.abs(oa - ob).max() < 1e-3
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        act = rng.uniform(-1, 1, (2, a.action_space.shape[0]))
+        (oa, ra, da, _), (ob, rb, db, _) = a.step(act), b.step(act)
+    assert np.abs(oa - ob).max() < 2e-2 and (da == db).all()

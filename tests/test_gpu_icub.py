@@ -272,3 +272,11 @@ def test_icub_solver_residual_threshold(hip_lib, task):
     parity.check_group_residual_threshold(eng, ora, st, np.random.default_rng(5), parity.TOL_ICUB, steps=3)
     eng.set_physics(solver_residual_threshold=1e-7)
     assert eng.kernel_info()[2] == 0          # with the threshold on, the lane-group kernel steps the batch (pbre_lane.hip: lane_ok)
+
+
+@pytest.mark.parametrize("use_ik", [0, 1])
+def test_icub_floating_base_option(hip_lib, use_ik):
+    """The soft-pinned floating base (model/table.py: float_base; 26 DoF, kw_step<Shape64>) on the device against the oracle, and its
+    effect on the hand's observation against the rigidly pinned default model."""
+    rep = parity.check_icub_floating_base(_capi.Engine, hip_lib, n=4, steps=3, use_ik=use_ik)
+    assert rep["ee_pos_shift_vs_pinned_base_40_steps_m"] < 2e-3
