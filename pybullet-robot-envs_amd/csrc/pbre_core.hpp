@@ -1223,9 +1223,11 @@ struct Core {
             }
                 return true;
             };
-#ifndef PBRE_FREE_MOTOR_STAGES      // 1: try the clamp-free motor stages first.  OFF: measured on MI355X (profiles/r05_chain_ab4.txt, same box, four builds)
-#define PBRE_FREE_MOTOR_STAGES 0      // the stationary step got SLOWER with them -- 16384 envs 0.133 -> 0.140 ms, 131072 envs 0.188 -> 0.192 ms -- although a
-#endif                                // row is 5 instructions instead of 9: the clamping row's bound arithmetic is what fills the DPP wait states of its broadcast
+#ifndef PBRE_FREE_MOTOR_STAGES      // 0: A/B -- always the clamping stages; 2: clamp-free first in EVERY two-chain wave
+#define PBRE_FREE_MOTOR_STAGES 1      // 1: clamp-free first in the waves with robot-object rows only (measured, profiles/r05_chain_ab4.txt and
+#endif                                // r05_phase_probe_free_motor_stages.txt: a coupled env's sweeps get 17 % shorter and 2 % of those waves start over; among the
+                                      // envs WITHOUT robot-object contact 12 % start over -- an arm pressed onto the table drives a blocked position motor
+                                      // into its bound within the 150 sweeps -- and a wave that starts over is the longest of its step: 16384 envs 0.133 -> 0.140 ms)
             // clamp-free first unless a motor of the wave is force-limited (those do reach their bound) or the residual exit is on
             bool done2 = false;
             // (the usual coupled wave: one or two robot-object slots in use)
@@ -1237,9 +1239,10 @@ struct Core {
                 if (PBRE_NRO_SPECIAL && !robot_only && ro_bits == 3u) return run_chains(freec, std::integral_constant<int, 2>{});
                 return run_chains(freec, std::integral_constant<int, 0>{});
             };
-            if (PBRE_FREE_MOTOR_STAGES && !RT && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
+            if (PBRE_FREE_MOTOR_STAGES && (PBRE_FREE_MOTOR_STAGES == 2 || (!robot_only && ro_bits != 0u)) && !RT && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
                 done2 = run_n(std::true_type{});
                 if (!done2) {             // start over with clamping rows
+                    PBRE_PROBE_PATH(11);
                     dvr = dv; dvo = dv; m_dsel = zeroR;
                     R.m_app = zeroR; R.l_app = zeroR;
                     PBRE_UNROLL for (int c = 0; c < NC; c++) { R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero; }

@@ -64,7 +64,7 @@ def main():
     v = [int(x) for x in buf]
     res = {"envs": n, "ms_per_step": round(ms, 4), "complex_envs": int(eng.kernel_info()[5]), "steps": a.steps,
            "ticks_per_step": {NAMES.get(i, str(i)): round(v[i] / a.steps, 1) for i in range(32) if v[i]}}
-    names = {12: "clamp-free", 13: "robot-only chain", 14: "two zipped chains", 15: "loops with per-slot tests"}
+    names = {11: "clamp-free motor stages left their bound: restart", 12: "clamp-free", 13: "robot-only chain", 14: "two zipped chains", 15: "loops with per-slot tests"}
     res["row_wave_paths"] = {names[k]: {"waves_per_step": round(v[32 + k] / a.steps, 3), "sweep_ticks_per_wave": round(v[48 + k] / max(1, v[32 + k]))} for k in names if v[32 + k]}
     row = sum(v[0:12]) / a.steps
     res["row_wave_ticks_per_step"] = round(row, 1)
