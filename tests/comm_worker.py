@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "pybullet-robot-envs_amd"))
 
 def main():
     kind, rank, world, rdv, total, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
-    mode = sys.argv[7] if len(sys.argv) > 7 else "closed"
+    mode = sys.argv[7] if len(sys.argv) > 7 else "closed"       # closed | open | closed-legacy | open-legacy (the latter two: GPU, torch's default stream)
     fake = os.path.join(ROOT, "tests", "fake_rccl", "build", "libfake_rccl.so")
     os.environ["PBRE_RCCL_LIB"] = fake
     from pybullet_robot_envs import _capi
@@ -29,9 +29,12 @@ def main():
         import torch
         torch.cuda.set_device(0)
         lib = _capi.load()
-        side = torch.cuda.Stream()
-        torch.cuda.set_stream(side)
-        stream = side.cuda_stream
+        if mode.endswith("-legacy"):      # torch's default stream = HIP's legacy null stream: PBRE_STREAM_LEGACY, a stream like any other for the exchanges
+            stream = _capi.STREAM_LEGACY
+        else:
+            side = torch.cuda.Stream()
+            torch.cuda.set_stream(side)
+            stream = side.cuda_stream
         def buf(shape):
             return torch.zeros(shape, device="cuda", dtype=torch.float32)
         def ptr(t):
@@ -85,7 +88,7 @@ def main():
     for k in range(steps):
         b = k & 1
         if rank == 0:
-            if mode == "closed" and prev is not None:
+            if mode.startswith("closed") and prev is not None:
                 # a policy that READS the gathered rows of the previous step: a(t + 1) = f(obs(t)) -- the closed loop
                 a_all = np.tanh(3.0 * prev[:, 9:16]).astype(np.float32) * np.float32(0.7) + rng.uniform(-0.3, 0.3, (total, eng.act_dim)).astype(np.float32)
             else:
@@ -93,12 +96,12 @@ def main():
             put(act_all, a_all)
         eng.scatter_actions_device(ptr(act_all) if rank == 0 else 0, ptr(act_local), stream)
         eng.step_gather_device(ptr(act_local), ptr(rows_local[b]), ptr(rows_all[b]) if rank == 0 else 0, stream)
-        if mode == "closed" or k == steps - 1:
+        if mode.startswith("closed") or k == steps - 1:
             eng.gather_wait(stream, host=True)
         if rank == 0:
             ob, rw, dn = ref.step(a_all)
             want = np.concatenate([ob, rw[:, None], dn[:, None]], 1)
-            if mode == "closed" or k == steps - 1:
+            if mode.startswith("closed") or k == steps - 1:
                 got = np.array(host(rows_all[b]))
                 assert got.shape == want.shape
                 assert np.array_equal(got, want), "step %d: stacked rows differ from the unsharded engine (max %g)" % (k, np.abs(got - want).max())

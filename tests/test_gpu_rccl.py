@@ -157,7 +157,7 @@ def test_context_owned_rccl_gather_world_size_1(hip_lib, self_p2p, with_torch_nc
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["closed", "open"])
+@pytest.mark.parametrize("mode", ["closed", "open", "open-legacy"])
 def test_context_owned_exchanges_two_ranks_on_one_gpu(hip_lib, mode):
     """world = 2 of csrc/pbre_comm.hip on the GPU: two processes, both on device 0, run pbre_comm_init -> pbre_scatter_actions_device ->
     pbre_step_gather_device -> pbre_gather_wait with tests/fake_rccl as PBRE_RCCL_LIB (device buffers staged through shared memory; the real
