@@ -37,9 +37,10 @@ ALG_BYTES_PER_ENV_STEP = 444.0      # read 172 B + write 272 B (Pan
 # FLOPs actually required per env-step by the sparse formulation the fast kernel uses: rounds 1-2, per PGS iteration
 # 9 motor rows x 23 + 4 normal rows x 18 + 8 friction rows x 20 = 439 flop, x150, + ~8 k for kinematics/dynamics/obs.
 # (SURVEY 8(d)'s 0.4 MFLOP assumed 33 dense rows of 70 flop; the dense figure is what the general row kernel does.)
-# Round 3: the 9 motor rows of a contact-free env are evaluated in closed form (matrix power, ~4.2 k FMA) instead of 150 sweeps, so the
-# figure counts what the kernel now has to execute: 150 x (4 x 18 + 8 x 20) for the object rows + 8.4 k + ~8 k.
-ALG_FLOP_PER_ENV_STEP = 150 * 232 + 8400.0 + 8000.0
+# Round 3: the 9 motor rows of a contact-free env are evaluated in closed form (matrix power, ~4.2 k FMA) instead of 150 sweeps.
+# Round 5: so is the tail of the object's rows -- 22 explicit sweeps x (4 x 18 + 8 x 20), then (S, s)^128 by binary powering and its
+# validity bound (~3.2 k FMA).  The figure counts what the kernel now has to execute: 22 x 232 + 6400 + 8400 + ~8000.
+ALG_FLOP_PER_ENV_STEP = 22 * 232 + 6400.0 + 8400.0 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
