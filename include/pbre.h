@@ -285,7 +285,9 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
  * for batches that leave most SIMDs without a wave), [11] its VGPRs, [12] NaN / Inf guard: env-steps since pbre_create whose state was
  * not finite (NaN or +-Inf in a joint angle / velocity or in the object's pose / twist, on input or after the step).  Such an env-step is
  * returned with reward 0 and done 1; with PBRE_F_AUTO_RESET the env restarts from the settled snapshot in the same step, without it the
- * env keeps its NaN state (and is counted again every step) until the caller resets it.  The reference has no such guard. */
+ * env keeps its NaN state (and is counted again every step) until the caller resets it.  The reference has no such guard.
+ * [13] steps since the last reset that were ONE launch (the complex envs' row blocks and the simple envs' waves in one grid, round 5: no
+ * fork / join through a second stream; [10] still says whether the simple envs' waves were the pair mapping), [14] its VGPRs. */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 /* ---- The sharded batch's per-step gather, owned by the context (no counterpart in the reference: it is one env per physics client

@@ -29,7 +29,11 @@
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
 #define PBRE_PAIR_SYNC() __syncthreads()
 #define PBRE_COUNT_BAD(p) atomicAdd((p), 1)
-#define PBRE_OBJV_SYNC() __syncthreads()
+// (Core::step, where `objv` and `P` are in scope: the side record is complete behind the block barrier -- its producer is a sibling wave of the
+// block, k_row_list -- or, P.objv_seq != 0, once its first word carries this launch's sequence number: the producer is a wave of another block,
+// k_fused's 64-thread grid.  P.objv_seq is uniform, so the barrier is not in divergent code.)
+#define PBRE_OBJV_SYNC() do { if (P.objv_seq == 0) __syncthreads(); else { const int* f_ = (const int*)objv; \
+        while (__hip_atomic_load(f_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.objv_seq) __builtin_amdgcn_s_sleep(8); } } while (0)
 #ifndef PBRE_CONST_AS        // (-DPBRE_CONST_AS= builds the A/B variant with the model constants re-read through a plain pointer)
 #define PBRE_CONST_AS __attribute__((address_space(4)))
 #endif
@@ -115,18 +119,26 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 // (131072 envs = 2048 waves = 1024 SIMDs x 2): there the displaced k_fast waves of the 2-wave variant run in a second round
 // (0.249 ms per stationary step against 0.220 ms with this variant; right after reset(), without complex envs, 0.157 against 0.187).
 // launch_step picks per step.
-template <int MODE, int WPS = PBRE_FAST_WAVES, bool RT = false>
-__global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
-                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
-    const int env = blockIdx.x * FTPB + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;   // the counter the step after this one appends to (idle now)
+// (fast_wave: one wave's work -- the 64 envs of `chunk`, lane ln; k_fast's body and, round 5, the simple envs' part of k_fused)
+template <int MODE, bool RT>
+__device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
+                                          const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                          const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                          int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count, int chunk, int ln) {
+    const int env = chunk * FTPB + ln;
+    if (chunk == 0 && ln < NB) zero_count[ln] = 0;   // the counter the step after this one appends to (idle now)
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
     const int c = FastD::step<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                                   (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                                   (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
     publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
+}
+template <int MODE, int WPS = PBRE_FAST_WAVES, bool RT = false>
+__global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
+    fast_wave<MODE, RT>(T, P, state, actions, out, n, act_dim, ow, flags, cls_cur, cls, next_list, next_count, cap, tgt, zero_count, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // Simple envs of a batch that leaves most SIMDs without a wave (a per-GPU shard of a strongly scaled batch, BASELINE configs 2 and 3):
@@ -138,16 +150,16 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
 // lone waves steps in the LONGER half + the observation instead of the sum of both.  Same operations on the same operands as k_fast:
 // bit-identical results (tests/test_gpu_parity.py), so which kernel a shard size selects is invisible in the data (sharding invariance).
 constexpr int PTPB = 2 * FTPB;
+// (pair_wave: one wave's work -- role 0 the robots, role 1 the objects of the 64 envs of `chunk`, exchange record px; k_fast_pair's body and,
+// round 5, the simple envs' part of k_fused<.., true>.  One block barrier per wave that has a simulating lane.)
 template <int MODE>
-__global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
-                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
-                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
-    __shared__ PairX px;
-    const int ln = threadIdx.x & (FTPB - 1);
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: 0 robot, 1 object
-    const int env = blockIdx.x * FTPB + ln;
-    if (blockIdx.x == 0 && threadIdx.x < NB) zero_count[threadIdx.x] = 0;
+__device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
+                                          const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                          const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                          int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count,
+                                          PairX& px, int chunk, int ln, int role) {
+    const int env = chunk * FTPB + ln;
+    if (chunk == 0 && role == 0 && ln < NB) zero_count[ln] = 0;
     const bool live = env < n && cls_cur[env] == 0;
     if (!PBRE_ANY(live)) return;              // the same decision in both waves of the block (same envs): no barrier is left waiting
     if (!live) return;
@@ -165,6 +177,16 @@ __global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict_
         if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
         __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
     }
+}
+template <int MODE>
+__global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
+                                               const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
+                                               int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
+    __shared__ PairX px;
+    // role: wave-uniform, 0 robot, 1 object
+    pair_wave<MODE>(T, P, state, actions, out, n, act_dim, ow, flags, cls_cur, cls, next_list, next_count, cap, tgt, zero_count, px, (int)blockIdx.x,
+                    (int)(threadIdx.x & (FTPB - 1)), __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 // Complex envs (robot contacts and/or limit rows), compacted per class.  Persistent blocks (the host does not know the
@@ -222,14 +244,19 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
 constexpr int REPB = 12;             // envs per block of k_row_list
 constexpr int RTPB = REPB * W + FTPB;
 // (RT: the object wave idles -- Bullet's exit test is a maximum over ALL rows of an env, so the object's rows stay in the row wave's solve)
-template <int MODE, bool RT = false>
-__global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
-                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
-                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
-                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
-                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
+// (row_list_block: the work of block `bid` of `nblk` -- k_row_list's body and, round 5, the complex envs' part of k_fused.
+// G = false: a 256-thread block, vt = threadIdx.x, the object wave hands its twists to the row waves in LDS (objv) across a block barrier.
+// G = true: the same four waves as four 64-thread blocks (vt = the thread index the wave would have had; the object wave's block first), the
+// twists travel through the per-env global records objv_g[env][W], whose first word the object wave sets to P.objv_seq last (release); no
+// barrier anywhere.  The object wave waits for nothing, and its block is dispatched before its row waves' blocks: the row waves' wait ends.)
+template <int MODE, bool RT, bool G = false>
+__device__ __forceinline__ void row_list_block(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
+                                               const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
+                                               const int* __restrict__ cur_list, const int* __restrict__ cur_count,
+                                               signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                               const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent,
+                                               float (*objv)[W], int bid, int nblk, int vt, float* __restrict__ objv_g = nullptr) {
     static_assert(NB <= 2 || MODE < 0, "the row kernel walks one complex list (PBRE_NCLASS=2) or two (3: uncoupled / coupled)");
-    __shared__ float objv[REPB][W];
     // These few waves are the tail of the step: each shares its SIMD with a k_fast wave, and a row wave is latency-bound (it leaves
     // most issue slots to its neighbour anyway), so it gets the higher wave priority and runs at its lone-wave speed.
     if (PBRE_RC_PRIO > 0) __builtin_amdgcn_s_setprio(PBRE_RC_PRIO);
@@ -238,13 +265,13 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
     // coupled sweep runs over that env's own row slots only and slows nobody else down.
     const int total0 = cur_count[0], total1 = NB > 1 ? cur_count[NB > 1 ? 1 : 0] : 0;
     const int items0 = (total0 + REPB - 1) / REPB, items1 = (total1 + REPB / 4 - 1) / (REPB / 4);
-    if (blockIdx.x == 0 && threadIdx.x == 0) report_hint(total0 + total1, recent, host_total);
+    if (bid == 0 && vt == (G ? REPB * W : 0)) report_hint(total0 + total1, recent, host_total);
     const bool obj_on = !(flags & 1) && !RT;      // (here: "the object wave solves the objects of the block's envs")
-    const bool obj_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= REPB * W)) != 0;
-    const int row = obj_wave ? (int)threadIdx.x - REPB * W : (int)(threadIdx.x >> 4);
+    const bool obj_wave = __builtin_amdgcn_readfirstlane((int)(vt >= REPB * W)) != 0;
+    const int row = obj_wave ? vt - REPB * W : (vt >> 4);
     constexpr int PHYS = MODE & (CoreD::M_ACTION | CoreD::M_TGT);
     // (the coupled envs' items come first: theirs are the longest waves of the step)
-    for (int item = blockIdx.x; item < items0 + items1; item += gridDim.x) {
+    for (int item = bid; item < items0 + items1; item += nblk) {
         const bool coupled = item < items1;
         const int* __restrict__ lst = coupled ? cur_list + cap : cur_list;
         const int total = coupled ? total1 : total0;
@@ -267,17 +294,23 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
                     // per-env object parameters (pbre_set_physics_per_env): X[12] mass, X[13] lateral friction, X[15] 1 + linear damping
                     const float o_m = st[44] > 0.f ? st[44] : P.obj_m, o_mu = st[45] > 0.f ? st[45] : P.obj_mu, o_kl = st[47] > 0.f ? st[47] - 1.f : P.kl;
                     ObjStep::run_p(P, pose, tw, o, o_m, o_mu, o_kl);
-                    PBRE_UNROLL for (int k = 0; k < 6; k++) objv[row][CoreD::LC + k] = o[k];
+                    if constexpr (G) {
+                        float* r = objv_g + (size_t)env * W;
+                        PBRE_UNROLL for (int k = 0; k < 6; k++) r[CoreD::LC + k] = o[k];
+                        __hip_atomic_store((int*)r, P.objv_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        PBRE_UNROLL for (int k = 0; k < 6; k++) objv[row][CoreD::LC + k] = o[k];
+                    }
                 }
-                __syncthreads();                                                 // pairs with PBRE_OBJV_SYNC in the row waves' Core::step
+                if constexpr (!G) __syncthreads();                               // pairs with PBRE_OBJV_SYNC in the row waves' Core::step
             }
         } else {
             CoreD::step<RT>(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
-                            (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull, obj_on ? &objv[row][0] : nullptr, st_idle,
-                            (RT && real && P.sweeps) ? P.sweeps + env : nullptr);
+                            (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull,
+                            obj_on ? (G ? objv_g + (size_t)env * W : &objv[row < REPB ? row : 0][0]) : nullptr, st_idle, (RT && real && P.sweeps) ? P.sweeps + env : nullptr);
             __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
             PBRE_PROBE_DECL
-            if (real && (threadIdx.x & 15u) == 0) {
+            if (real && (vt & 15) == 0) {
                 float q[NJ], qd[NJ];
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
                 FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
@@ -289,7 +322,77 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
             }
             PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
         }
-        if (obj_on && item + (int)gridDim.x < items0 + items1) __syncthreads();   // the side records are rewritten by the next trip
+        if constexpr (!G) if (obj_on && item + nblk < items0 + items1) __syncthreads();   // the side records are rewritten by the next trip
+    }
+}
+template <int MODE, bool RT = false>
+__global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+                                                  const float* __restrict__ actions, float* __restrict__ out, int act_dim, int ow, int flags,
+                                                  const int* __restrict__ cur_list, const int* __restrict__ cur_count,
+                                                  signed char* __restrict__ cls, int* __restrict__ next_list, int* __restrict__ next_count, int cap,
+                                                  const float* __restrict__ tgt, int* __restrict__ host_total, int dummy_base, int* __restrict__ recent) {
+    __shared__ float objv[REPB][W];
+    row_list_block<MODE, RT>(T, P, state, actions, out, act_dim, ow, flags, cur_list, cur_count, cls, next_list, next_count, cap, tgt, host_total, dummy_base, recent,
+                             objv, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x);
+}
+
+// Round 5: ONE kernel per step.  The two kernels of a step ran on two streams with a fork and a join event between them, and the step-kernel
+// timeline (profiles/r05k_step_kernels.txt) showed what that costs at 131072 envs: the second kernel starts 5.6 us after the first and the next
+// step's first kernel 12.8 us after this step's last one ends -- 13 us of a 179-us step in which nothing runs.  k_fused is both kernels in one
+// grid of 256-thread blocks: the first `rblocks` blocks are k_row_list's (dispatched first, so the step's longest waves -- the coupled envs' --
+// start first, as the rc_first order arranged before), every later block is four k_fast waves (PAIR: two robot / object wave pairs of
+// k_fast_pair, whose one barrier then spans both pairs).  Same device functions, same arithmetic: which launch form a step took is invisible
+// in the data (tests: PBRE_FUSED=0 against the default, bit for bit).  256 VGPRs like both of its parts; the 168-VGPR build of k_fast
+// (PBRE_FAST3) has no fused counterpart -- the row waves need 248 -- and is not needed: at 131072 envs k_fast<7, 2> beside the row waves
+// measured 151 us against 157 us for <7, 3> (same file), and it does not spill.
+constexpr int FUSED_WAVES = RTPB / FTPB;
+static_assert(RTPB % FTPB == 0 && FUSED_WAVES % 2 == 0, "k_fused: whole waves, whole pairs");
+// The arguments travel as ONE struct and each role reads them through its own (laundered) pointer into the kernarg segment.  As plain kernel
+// arguments all of them -- Params is ~600 bytes -- are loaded in the entry block and stay live in SGPRs through whichever role the block takes:
+// the first build of this kernel had 5.7 k more v_readlane_b32 (SGPRs spilled to VGPR lanes, re-read inside the sweep loops) than its two
+// parts together, and its row waves' sweeps ran 11-32 % slower than k_row_list's (phase probe, profiles/r05m_phase_probe.txt).
+struct FusedArgs {
+    const Tables* T; Params P; float* state; const float* actions; float* out; int n, act_dim, ow, flags;
+    const signed char* cls_cur; signed char* cls; const int* cur_list; const int* cur_count; int* next_list; int* next_count; int cap;
+    const float* tgt; int* zero_count; int* host_total; int dummy_base; int* recent; int rblocks;
+    float* objv_g;                            // (k_fused<.., false>) [cap + 32][W] the object waves' twists, first word = the launch's sequence number (P.objv_seq)
+};
+template <int MODE, bool PAIR>
+__global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs args_in_kernarg_segment) {
+    const FusedArgs PBRE_CONST_AS* a = (const FusedArgs PBRE_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr();      // (explicit arguments start at offset 0)
+    if constexpr (PAIR) {
+        // 256-thread blocks: a row block as in k_row_list / two robot-object wave pairs of k_fast_pair (whose one barrier then spans both pairs)
+        if ((int)blockIdx.x < a->rblocks) {
+            __shared__ float objv[REPB][W];
+            PBRE_LAUNDER(a);
+            row_list_block<MODE, false>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
+                                        a->next_list, a->next_count, a->cap, a->tgt, a->host_total, a->dummy_base, a->recent, objv, (int)blockIdx.x, a->rblocks,
+                                        (int)threadIdx.x);
+            return;
+        }
+        const int fb = (int)blockIdx.x - a->rblocks, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = (int)(threadIdx.x & (FTPB - 1));
+        PBRE_LAUNDER(a);
+        __shared__ PairX px[FUSED_WAVES / 2];
+        pair_wave<MODE>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count, a->cap,
+                        a->tgt, a->zero_count, px[wv >> 1], fb * (FUSED_WAVES / 2) + (wv >> 1), ln, wv & 1);
+    } else {
+        // 64-thread blocks, like k_fast's: beside a machine-filling batch (131072 envs = 2048 waves = every wave slot) the row waves displace some
+        // hundred k_fast waves into a second round, and those must be free to start wherever ONE wave slot frees up -- as whole 4-wave blocks
+        // they waited for four free slots on one CU, and the fast part of the grid ended at 173 us against 151 us (profiles/r05l_*).  So a row
+        // block is four one-wave blocks here: 4 s the object wave of slot s, 4 s + 1 .. 3 its row waves (row_list_block<.., G = true>).
+        const int rb = FUSED_WAVES * a->rblocks;
+        if ((int)blockIdx.x < rb) {
+            const int role = (int)blockIdx.x & (FUSED_WAVES - 1);
+            PBRE_LAUNDER(a);
+            row_list_block<MODE, false, true>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
+                                              a->next_list, a->next_count, a->cap, a->tgt, a->host_total, a->dummy_base, a->recent, nullptr,
+                                              (int)blockIdx.x / FUSED_WAVES, a->rblocks, (role == 0 ? REPB * W : (role - 1) * FTPB) + (int)threadIdx.x, a->objv_g);
+            return;
+        }
+        const int chunk = (int)blockIdx.x - rb;
+        PBRE_LAUNDER(a);
+        fast_wave<MODE, false>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
+                               a->cap, a->tgt, a->zero_count, chunk, (int)threadIdx.x);
     }
 }
 
@@ -370,6 +473,8 @@ struct EnvBuf {                       // a batch of state records with its class
     int* count = nullptr;             // [3][NB]: counters rotate over three buffers so that the one the step after next
                                       // appends to can be zeroed by a kernel of the current step (no memset on the hot path)
     int cur = 0, ccur = 0;            // list[cur] / count + ccur*NB: complex envs of the current state, per class
+    float* objv_g = nullptr;          // [cap + 32][W] k_fused's side records: the object waves' twists for the row waves of other blocks
+    int objv_seq = 0;                 // sequence number of the last k_fused launch (the records' "complete" mark)
     int* h_total = nullptr;           // pinned host int the device writes the complex-env count of the step it runs into
     int cap = 0;
 };
@@ -395,6 +500,10 @@ struct pbre_ctx {
     int pair = 2;                      // k_fast_pair (robot wave + object wave per 64 envs): 0 never, 1 whenever it applies, 2 while its waves fit two per SIMD (PBRE_PAIR)
     long launches_pair = 0;
     int fast3 = 2;                     // k_fast variant limited to 3 waves per SIMD: 0 never, 1 whenever complex envs are reported, 2 when they would displace k_fast waves (PBRE_FAST3)
+                                       // -- only where the step is NOT one fused launch (PBRE_FUSED=0, residual exit, action_repeat's inner steps).  (Round 5 also measured the
+                                       // spill-free build in two half-grid launches back to back, one wave per SIMD each: 0.21 ms against 0.177, profiles/r05_fast3_halves_ab.txt.)
+    int fused = 1;                     // the step as ONE launch (k_fused: row-list blocks + fast / pair blocks in one grid); 0: the two kernels on two streams (PBRE_FUSED)
+    unsigned long long launches_fused = 0;
     hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
     SidePick sp;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -452,12 +561,14 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     if ((e = hipMemset(b.cls, 0, (size_t)2 * cap)) != hipSuccess) return e;
     for (int k = 0; k < 2; k++) if ((e = hipMalloc(&b.list[k], (size_t)NB * cap * sizeof(int))) != hipSuccess) return e;
     if ((e = hipMalloc(&b.count, (3 * NB + 2) * sizeof(int))) != hipSuccess) return e;      // + the device copy of the "recent" hint
+    if ((e = hipMalloc(&b.objv_g, (size_t)(cap + 32) * W * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMemset(b.objv_g, 0, (size_t)(cap + 32) * W * sizeof(float))) != hipSuccess) return e;
     if ((e = hipHostMalloc(&b.h_total, 2 * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
     b.h_total[0] = 1; b.h_total[1] = 16;   // unknown until the first step has run
     return hipMemset(b.count, 0, (3 * NB + 2) * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
-    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count, (void*)b.objv_g}) if (p) (void)hipFree(p);
     if (b.h_total) (void)hipHostFree(b.h_total);
 }
 
@@ -504,8 +615,46 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
     //    step (613 M -> 650 M env-steps/s at 131072 envs).  Taken only when the device has reported no complex env for 16 steps in a
     //    row (a count that flickers between 0 and a few would otherwise serialise the two kernels every other step); a stale
     //    hint only serialises them for that step.
-    c->side = c->sp.pick(s);
     const int hint = b.h_total[0];
+    // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
+    bool rows = NB <= 2 && hint <= c->row_max;
+    if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB <= 2;
+    if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
+    if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB <= 2;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
+    // (the host knows the complex envs' total, not how many of them are coupled -- one env per wave: about a tenth, generously)
+    // At least 64 blocks whatever the hint says: the hint is the count of a step the DEVICE has finished, and a host that runs ahead
+    // of it (the 201 launches of a reset are enqueued in ~1 ms) sizes every launch by a count that may be a hundred steps old --
+    // 16384 envs that had all become complex meanwhile were walked by 8 blocks, 11 ms per launch.  Blocks without work exit at once.
+    const int rblocks = std::max(64, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
+    // small batches: the pair kernel (two waves per 64 envs) while all of its waves are resident at once, two per SIMD at most
+    bool pair = false;
+    if (!RT && c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
+        pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
+    if constexpr (NB <= 2 && MODE == MODE_STEP && !RT) {
+        // the whole step as one launch on the caller's stream (k_fused): no fork / join through the side stream
+        if (c->fused && rows) {
+            const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
+            hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
+            if (timed) (void)hipEventRecord(ek[0], s);
+            c->launches_fused++;
+            FusedArgs fa = {c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags, b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[cur],
+                            b.count + cc * NB, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB, b.h_total, b.cap, b.count + 3 * NB, rblocks, b.objv_g};
+            if (pair) {
+                c->launches_pair++;
+                hipLaunchKernelGGL((k_fused<MODE, true>), dim3(rblocks + (blocks + FUSED_WAVES / 2 - 1) / (FUSED_WAVES / 2)), dim3(RTPB), 0, s, fa);
+            } else {
+                if (++b.objv_seq <= 0) b.objv_seq = 1;        // (never 0: that value selects the block barrier, PBRE_OBJV_SYNC)
+                fa.P.objv_seq = b.objv_seq;
+                hipLaunchKernelGGL((k_fused<MODE, false>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa);
+            }
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }
+            b.ccur = cn;
+            b.cur = nxt;
+            return hipSuccess;
+        }
+    }
+    c->side = c->sp.pick(s);
     const bool rc_first = hint >= c->rc_first_min;
     const bool single = c->idle_single && hint == 0 && b.h_total[1] == 0;      // both kernels in order on the caller's stream
     hipStream_t s_rc = (rc_first || single) ? s : c->side, s_fast = (rc_first && !single) ? c->side : s;
@@ -514,18 +663,8 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
         if ((e = hipEventRecord(c->ev_fork, s)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(c->side, c->ev_fork, 0)) != hipSuccess) return e;
     }
-    // complex envs: row kernel while they are few (latency), lane-per-env k_fast_rc when many (throughput)
-    bool rows = NB <= 2 && hint <= c->row_max;
-    if (c->cfg.flags & PBRE_F_COMPLEX_ROWS) rows = NB <= 2;
-    if (c->cfg.flags & PBRE_F_COMPLEX_LANES) rows = false;
-    if (!c->P.obj_iso || c->P.obj_shape != 0) rows = NB <= 2;      // k_fast_rc's object rows assume a cube: other boxes and the round objects' complex envs go to the row kernel
     if constexpr (NB <= 2) {
         if (rows) {
-            // (the host knows the complex envs' total, not how many of them are coupled -- one env per wave: about a tenth, generously)
-            // At least 64 blocks whatever the hint says: the hint is the count of a step the DEVICE has finished, and a host that runs ahead
-            // of it (the 201 launches of a reset are enqueued in ~1 ms) sizes every launch by a count that may be a hundred steps old --
-            // 16384 envs that had all become complex meanwhile were walked by 8 blocks, 11 ms per launch.  Blocks without work exit at once.
-            const int rblocks = std::max(64, std::min(c->n_simd / 4, (hint + REPB - 1) / REPB + (NB > 1 ? std::min(hint, 8 + hint / 4) / (REPB / 4) : 0) + 8));
             hipLaunchKernelGGL((k_row_list<MODE, RT>), dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
@@ -547,10 +686,6 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
         const int slots2 = 2 * c->n_simd, rw = (rows ? (hint + 3) / 4 + (hint + REPB - 1) / REPB : (hint + FTPB - 1) / FTPB * 2) + 8;
         fast3 = c->fast3 == 1 || ((blocks + rw + slots2 - 1) / slots2 > (blocks + slots2 - 1) / slots2 && blocks + rw <= 3 * c->n_simd);
     }
-    // small batches: the pair kernel (two waves per 64 envs) while all of its waves are resident at once, two per SIMD at most
-    bool pair = false;
-    if (!RT && c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
-        pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
     if (pair) {
         c->launches_pair++;
         if constexpr (!(MODE & FastD::M_INNER) && !RT)      // (the inner iterations of action_repeat > 1 stay on k_fast: not instantiated; RT: one lane per env)
@@ -669,6 +804,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_IDLE_TOUCH")) c->idle_touch = atoi(ev);
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     if (const char* ev = getenv("PBRE_FAST3")) c->fast3 = atoi(ev);
+    if (const char* ev = getenv("PBRE_FUSED")) c->fused = atoi(ev);
     if (const char* ev = getenv("PBRE_PAIR")) c->pair = atoi(ev);
     if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;
@@ -839,7 +975,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_ok = nc == 0 ? 1 : 0;         // every env of the freshly reset batch is in the simple class
         }
     }
-    c->k_steps = 0; c->launches = 0; c->launches3 = 0; c->launches_pair = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
+    c->k_steps = 0; c->launches = 0; c->launches3 = 0; c->launches_pair = 0; c->launches_fused = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -1055,7 +1191,9 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
     if (!c || !info) return PBRE_E_ARG;
     if (c->wide) return wide_kernel_info(c->wide, info, n);
     hipFuncAttributes fa;
-    int rf = -1, rg = -1, rr = -1, rf3 = -1, rp = -1;
+    int rf = -1, rg = -1, rr = -1, rf3 = -1, rp = -1, ru = -1;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fused<MODE_STEP, false>) == hipSuccess) ru = fa.numRegs;
+    if (hipFuncGetAttributes(&fa, (const void*)k_fused<MODE_STEP, true>) == hipSuccess) ru = std::max(ru, (int)fa.numRegs);
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 3>) == hipSuccess) rf3 = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast_pair<MODE_STEP>) == hipSuccess) rp = fa.numRegs;
     if (hipFuncGetAttributes(&fa, (const void*)k_fast<MODE_STEP, 2>) == hipSuccess) rf = fa.numRegs;
@@ -1074,9 +1212,10 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
         (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
         (void)hipMemcpy(&bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost);
     }
-    const int v[13] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
-                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1, bad};
-    for (int i = 0; i < n; i++) info[i] = i < 13 ? v[i] : 0;
+    const int v[15] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
+                       (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1, bad,
+                       (int)(c->launches_fused & 0x7fffffff), lpe ? ru : -1};
+    for (int i = 0; i < n; i++) info[i] = i < 15 ? v[i] : 0;
     return PBRE_OK;
 }
 

@@ -114,6 +114,8 @@ struct Params {                  // float copies of pbre_physics + task constant
     float res_lim;                                  // sqrt(pbre_physics.solver_residual_threshold): an env leaves the sweep loop after the first sweep whose largest
                                                     // velocity-level row change |delta impulse / jacDiagABInv| is <= res_lim (Bullet compares the squares); 0: never
     int*  sweeps;                                   // res_lim > 0: per-env count of the sweeps run in the step ([num_envs], this ctx's local env index); may be null
+    int   objv_seq;                                 // Core::step's `objv` side record: 0 = complete behind the block barrier (its producer is a sibling wave); else complete
+                                                    // once its first word holds this number (its producer is a wave of another block: pbre_capi.hip k_fused)
 };
 
 namespace detail {

@@ -463,6 +463,7 @@ def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch
     kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40,
               use_ik=use_ik, action_repeat=action_repeat)           # (joint control, IK control, the inner iterations of action_repeat: all k_fast modes)
     monkeypatch.setenv("PBRE_PAIR", "0")            # (the two builds of k_fast: not the pair kernel, whatever the module's mapping fixture says)
+    monkeypatch.setenv("PBRE_FUSED", "0")           # (... and k_fast as a kernel of its own: the one-launch step has the 256-register build only)
     monkeypatch.setenv("PBRE_FAST3", "1")
     a = _capi.Engine(panda["table"], **kw)
     monkeypatch.setenv("PBRE_FAST3", "0")
@@ -485,6 +486,45 @@ def test_three_waves_per_simd_build_is_bit_identical(panda, hip_lib, monkeypatch
     ia, ib = a.kernel_info(), b.kernel_info()
     assert ia[8] > 0 and ib[8] == 0, (ia, ib)          # steps whose k_fast was the three-waves-per-SIMD build
     assert ia[9] <= 168 and ia[0] > 168, ia            # its register count / the default build's
+
+
+@pytest.mark.parametrize("use_ik,action_repeat", [(0, 1), (1, 1), (0, 2)])
+def test_one_launch_step_is_bit_identical_to_the_two_kernel_step(panda, hip_lib, monkeypatch, simple_env_mapping, use_ik, action_repeat):
+    """Round 5: env.step() is ONE launch (k_fused: the complex envs' row blocks and the simple envs' waves -- k_fast's or, under the pair
+    mapping, k_fast_pair's, two pairs per block -- in one grid) instead of two kernels on two streams with fork / join events.  Same
+    device functions: a full reset through each launch form, contact-rich states among the envs so that both parts of the grid have work,
+    60 steps with auto-reset -- rows, states and classes bit for bit (PBRE_FUSED=0: the two-kernel step)."""
+    n = 4096
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40,
+              use_ik=use_ik, action_repeat=action_repeat)
+    monkeypatch.setenv("PBRE_FUSED", "1")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_FUSED", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob) and np.array_equal(a.get_state(), b.get_state())
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 8, 8).astype(np.float32)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(9)
+    seen = 0
+    for _ in range(60):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+        seen = max(seen, a.kernel_info()[5])
+    assert np.array_equal(a.get_state(), b.get_state())
+    ia, ib = a.kernel_info(), b.kernel_info()
+    assert seen > 0, "no complex env: the row blocks of the fused grid had no work"
+    # steps that were one launch (IK control: while most of the batch is complex -- the home pose's IK solution lies beyond a joint limit --
+    # the lane-per-env complex kernel k_fast_rc steps them, on its own stream as before)
+    assert (ia[13] >= 60 or use_ik) and ib[13] == 0, (ia, ib)
+    assert 0 < ia[14] <= 256, ia
+    assert (ia[10] > 0) == (simple_env_mapping == "pair") and (ib[10] > 0) == (simple_env_mapping == "pair"), (ia, ib)
 
 
 def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch):

@@ -22,7 +22,10 @@ def load(name, counters):
             if m:
                 # (round 5: the step kernels carry a trailing bool, the solver-residual-threshold variant; `false` is the default build and
                 # keeps the names of the earlier rounds, `true` is marked RT)
-                name = m.group(1).replace(", false>", ">").replace(", true>", ", RT>")
+                name = m.group(1)
+                if name.startswith("k_fused"):      # (round 5: the one-launch step; its bool says which mapping the simple envs' waves have)
+                    name = name.replace(", false>", ">").replace(", true>", ", pair>")
+                name = name.replace(", false>", ">").replace(", true>", ", RT>")
                 per[name][c].append(float(r["Counter_Value"]))
     return per
 
@@ -40,7 +43,7 @@ def summarise(per):
 fs, ws = summarise(load("FETCH_SIZE", {"FETCH_SIZE"})), summarise(load("WRITE_SIZE", {"WRITE_SIZE"}))
 hbm = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r03.sh), bench.py stationary protocol, %d envs, 1 MI355X" % n_envs,
        "raw_kib": {"FETCH_SIZE": fs, "WRITE_SIZE": ws}}
-for kf in ("k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>"):
+for kf in ("k_fused<7>", "k_fused<7, pair>", "k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>"):
     if kf in fs and kf in ws:
         f_, w_ = fs[kf]["FETCH_SIZE"]["mean_stationary_third"] * 1024, ws[kf]["WRITE_SIZE"]["mean_stationary_third"] * 1024
         hbm[kf] = {"envs_per_launch": n_envs, "fetch_bytes": f_, "write_bytes": w_, "hbm_bytes": f_ + w_, "hbm_bytes_per_env_step": (f_ + w_) / n_envs,
@@ -49,8 +52,12 @@ for kf in ("k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>"):
 dom = "k_fast<7, 3>" if ("k_fast<7, 3>" in hbm and hbm["k_fast<7, 3>"]["launches"] >= hbm.get("k_fast<7, 2>", {"launches": 0})["launches"]) else "k_fast<7, 2>"
 if "k_fast_pair<7>" in hbm and dom not in hbm:
     dom = "k_fast_pair<7>"          # a batch the pair kernel steps (<= 65536 envs)
+for kf in ("k_fused<7, pair>", "k_fused<7>"):      # the step as one launch (round 5): that kernel IS the step
+    if kf in hbm and hbm[kf]["launches"] >= hbm.get(dom, {"launches": 0})["launches"]:
+        dom = kf
 if dom in hbm:
     hbm["k_fast<7>"] = dict(hbm[dom], variant=dom)
+    hbm["step_kernel"] = dict(hbm[dom], variant=dom)
 hbm["calibration"] = {"k_classify_fetch_bytes_expected": 64 * n_envs,
                       "k_classify_fetch_bytes_counter": fs.get("k_classify", {}).get("FETCH_SIZE", {"mean_all": 0})["mean_all"] * 1024,
                       "k_observe_fetch_bytes_expected": 192 * n_envs,
@@ -61,7 +68,7 @@ print(json.dumps({k: v for k, v in hbm.items() if k.startswith("k_fast")}, inden
 sq = load("SQ", {"SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"})
 out = {}
 for k, d in sq.items():
-    if not (k.startswith("k_fast<7") or k.startswith("k_fast_pair<7") or k.startswith("k_row_list<7") or k.startswith("k_fast_rc<7")):
+    if not (k.startswith("k_fast<7") or k.startswith("k_fast_pair<7") or k.startswith("k_row_list<7") or k.startswith("k_fast_rc<7") or k.startswith("k_fused<7")):
         continue
     o = {c: (sum(v[len(v) * 2 // 3:]) / max(1, len(v[len(v) * 2 // 3:]))) for c, v in d.items()}
     o["launches"] = len(next(iter(d.values())))
@@ -77,5 +84,10 @@ if "k_fast<7, 3>" not in out and "k_fast<7, 2>" not in out and "k_fast_pair<7>" 
 if "k_fast<7, 3>" in out or "k_fast<7, 2>" in out:
     d3, d2 = out.get("k_fast<7, 3>", {"launches": 0}), out.get("k_fast<7, 2>", {"launches": 0})
     out["k_fast<7>"] = dict(d3 if d3["launches"] >= d2["launches"] else d2, variant="k_fast<7, 3>" if d3["launches"] >= d2["launches"] else "k_fast<7, 2>")
+for kf in ("k_fused<7, pair>", "k_fused<7>"):
+    if kf in out and out[kf]["launches"] >= out.get("k_fast<7>", {"launches": 0})["launches"]:
+        out["k_fast<7>"] = dict(out[kf], variant=kf)
+        out["step_kernel"] = dict(out[kf], variant=kf, note="one launch per step: the complex envs' row waves (a few hundred, ~100 k instructions each, plus the idle "
+                                  "row blocks that exit at once) are in SQ_WAVES and SQ_INSTS_VALU beside the simple envs' waves; PBRE_FUSED=0 passes give k_fast's own")
 json.dump(out, open("gpurun_out/%s_pmc_sq.json" % tag, "w"), indent=1)
 print(json.dumps({k: {kk: v[kk] for kk in ("valu_insts_per_wave", "valu_active_over_wave_cycles", "wait_any_over_wave_cycles", "launches") if kk in v} for k, v in out.items()}, indent=1))
