@@ -573,7 +573,9 @@ def main():
     comm_kind, comm_note = job.comm_kind, job.comm_note
     comm_info = job.pipe.info() if hasattr(job.pipe, "info") else None
     done_frac = float(job.pipe.out[(job.pipe.k - 1) & 1][:, -1].mean())
-    kern_ms = float(eng.timing()[3])      # k_fast alone: mean of the HIP event pairs the library records around it on its stream
+    # the dominant kernel alone: mean of the HIP event pairs the library records around it on its stream -- round 5: the step IS one kernel
+    # (k_fused: the complex envs' row waves and the simple envs' waves in one grid), so this is the step's device time without launch gaps
+    kern_ms = float(eng.timing()[3])
     info = eng.kernel_info()
     episodes = float(torch.as_tensor(eng.get_state()[:, eng.x_off + 5]).mean()) if rank == 0 else 0.0
     # (side key, SURVEY section 5 "metrics": contact-count histogram) which contact kinds the envs of the stationary batch are in, from the
@@ -675,7 +677,8 @@ def main():
                 shards[str(n_sh)] = {"gpus_in_the_split": TOTAL_ENVS // n_sh, "fresh_ms_per_step": fr["ms_per_step"], "stationary_ms_per_step": stt["ms_per_step"],
                                      "fresh_env_steps_per_s": fr["value"], "stationary_env_steps_per_s": stt["value"],
                                      "complex_envs_per_step": ((inf[7] - c0) % (1 << 31)) / 205.0,
-                                     "simple_env_kernel": "k_fast_pair (robot wave + object wave per 64 envs)" if inf[10] > 0 else "k_fast"}
+                                     "simple_env_kernel": "k_fast_pair (robot wave + object wave per 64 envs)" if inf[10] > 0 else "k_fast",
+                                     "steps_that_were_one_launch": inf[13]}
                 if n_sh == 16384 and isinstance(rt_side, dict) and "error" not in rt_side:
                     rt_side[str(n_sh)] = js.timed_with_residual_threshold(200)
                 del js
@@ -706,14 +709,16 @@ def main():
         # calibrated in the profile file).  Counters cannot be read from inside this process: the figure is the committed
         # per-env summary of the counter passes over this same command, scaled to this launch's env count.
         traffic, traffic_src = None, None
-        pmc, src = _profile("pmc_hbm", "k_fast<7>")
+        fused = info[13] > 0
+        dom_kernel = "k_fused<7>" if fused else "k_fast<7>"
+        pmc, src = _profile("pmc_hbm", "step_kernel" if fused else "k_fast<7>")
         traffic_note = None
         if pmc:
             traffic, traffic_src = pmc["hbm_bytes_per_env_step"] * n_local, src
-            traffic_note = ("counters of the variant that steps the stationary batch (%s: 168 VGPRs, its setup phase spills ~380 B per lane); the "
-                            "256-VGPR variant that runs while no env is complex is spill-free and moves ~550 B per env-step (same file)" % pmc.get("variant"))
+            traffic_note = ("counters of the kernel that steps the stationary batch (%s); FETCH_SIZE + WRITE_SIZE of one launch, complex envs' rows included"
+                            % pmc.get("variant"))
         sq = None
-        d, src = _profile("pmc_sq", "k_fast<7>")
+        d, src = _profile("pmc_sq", "step_kernel" if fused else "k_fast<7>")
         if d:
             sq = {"valu_insts_per_wave": d["valu_insts_per_wave"], "valu_active_over_wave_cycles": d["valu_active_over_wave_cycles"],
                   "wait_any_over_wave_cycles": d["wait_any_over_wave_cycles"], "variant": d.get("variant"), "source": src}
@@ -747,9 +752,12 @@ def main():
             "solver_residual_threshold_1e-7": ({"stationary": rt_side,
                                                 "note": "side key: pbre_physics.solver_residual_threshold = 1e-7 (PyBullet's documented solverResidualThreshold default "
                                                         "[EXT-UNVERIFIED]); `value` is measured with the engine's default 0 = all 150 sweeps (DESIGN.md section 2)"} if rt_side else None),
-            "k_fast_variant": {"steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
+            "k_fast_variant": {"steps_that_were_one_launch_since_reset": info[13], "vgprs_one_launch_kernel": info[14],
+                               "steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
                                "steps_with_the_pair_kernel_since_reset": info[10], "vgprs_pair_kernel": info[11],
-                               "note": "launch_step picks the 168-VGPR variant for steps in which the complex envs' waves would push k_fast waves of the 256-VGPR variant into a second round (PBRE_FAST3), and the pair kernel (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
+                               "note": "round 5: a step is ONE launch (k_fused: the complex envs' row waves + the simple envs' waves in one grid; PBRE_FUSED=0: the two kernels on two streams of rounds 1-4, "
+                                       "where launch_step picks the 168-VGPR k_fast for steps in which the row waves would push waves of the 256-VGPR build into a second round, PBRE_FAST3); "
+                                       "the simple envs' waves are the pair mapping (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
             "contact_histogram_rank0": contact_hist,
             "nan_inf_guard": {"bad_env_steps_since_create": info[12], "note": "env-steps whose state was not finite (pbre_kernel_info[12]); such envs are returned with done = 1 and restarted"},
             "shards": shards,
@@ -761,7 +769,7 @@ def main():
             "host_inclusive": host,      # SURVEY 8(d) literal: upload + kernels + download through the host-buffer entry point; `value` is device-resident stepping
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
-                         "kernel": "k_fast<7>", "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
+                         "kernel": dom_kernel, "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU issue bound (%.0f FLOP per algorithmic byte against a machine balance of ~20 FLOP/B); the HBM "
                                  "fraction is small by construction, see valu" % (ALG_FLOP_PER_ENV_STEP / ALG_BYTES_PER_ENV_STEP)},

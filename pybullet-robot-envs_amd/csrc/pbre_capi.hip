@@ -120,7 +120,8 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 // (0.249 ms per stationary step against 0.220 ms with this variant; right after reset(), without complex envs, 0.157 against 0.187).
 // launch_step picks per step.
 // (fast_wave: one wave's work -- the 64 envs of `chunk`, lane ln; k_fast's body and, round 5, the simple envs' part of k_fused)
-template <int MODE, bool RT>
+// CT: read the model constants through the constant address space (k_fused; see Fast::step)
+template <int MODE, bool RT, bool CT = false>
 __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                           const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
@@ -128,9 +129,15 @@ __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Pa
     const int env = chunk * FTPB + ln;
     if (chunk == 0 && ln < NB) zero_count[ln] = 0;   // the counter the step after this one appends to (idle now)
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
-    const int c = FastD::step<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
-                                  (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
-                                  (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
+    int c;
+    if constexpr (CT)
+        c = FastD::step<RT>(*(const CTables*)T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                            (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                            (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
+    else
+        c = FastD::step<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+                            (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
+                            (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
     publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
 }
 template <int MODE, int WPS = PBRE_FAST_WAVES, bool RT = false>
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
 constexpr int PTPB = 2 * FTPB;
 // (pair_wave: one wave's work -- role 0 the robots, role 1 the objects of the 64 envs of `chunk`, exchange record px; k_fast_pair's body and,
 // round 5, the simple envs' part of k_fused<.., true>.  One block barrier per wave that has a simulating lane.)
-template <int MODE>
+template <int MODE, bool CT = false>
 __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                           const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
@@ -170,11 +177,17 @@ __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Pa
         float* o = (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr;
         const unsigned long long id = P.env_id_base + (unsigned long long)env;
         int c;
-        if (sim) c = FastD::step_t<false, 1>(*T, P, st, a, o, MODE, flags, id, (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, &px, ln);
-        else c = FastD::skipped(*T, P, st, o, MODE, flags, id);
+        if constexpr (CT) {
+            if (sim) c = FastD::step_t<false, 1>(*(const CTables*)T, P, st, a, o, MODE, flags, id, (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, &px, ln);
+            else c = FastD::skipped(*(const CTables*)T, P, st, o, MODE, flags, id);
+        } else {
+            if (sim) c = FastD::step_t<false, 1>(*T, P, st, a, o, MODE, flags, id, (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, &px, ln);
+            else c = FastD::skipped(*T, P, st, o, MODE, flags, id);
+        }
         publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
     } else {
-        if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
+        if constexpr (CT) { if (sim) (void)FastD::step_t<false, 2>(*(const CTables*)T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln); }
+        else if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
         __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
     }
 }
@@ -358,14 +371,17 @@ struct FusedArgs {
     float* objv_g;                            // (k_fused<.., false>) [cap + 32][W] the object waves' twists, first word = the launch's sequence number (P.objv_seq)
 };
 template <int MODE, bool PAIR>
-__global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs args_in_kernarg_segment) {
+__global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs args_in_kernarg_segment, const Tables* __restrict__ T) {
+    // (T -- the model constants -- is a kernel argument of its own: as a __restrict__ argument it cannot alias the pointers the roles load from the
+    // struct, so the reads through it stay scalar loads behind the roles' stores; read from the struct, 50 of k_fast's s_load_dwordx16 / x8 table
+    // reads had become per-lane global loads and the fast role spilled 488 bytes per lane)
     const FusedArgs PBRE_CONST_AS* a = (const FusedArgs PBRE_CONST_AS*)__builtin_amdgcn_kernarg_segment_ptr();      // (explicit arguments start at offset 0)
     if constexpr (PAIR) {
         // 256-thread blocks: a row block as in k_row_list / two robot-object wave pairs of k_fast_pair (whose one barrier then spans both pairs)
         if ((int)blockIdx.x < a->rblocks) {
             __shared__ float objv[REPB][W];
             PBRE_LAUNDER(a);
-            row_list_block<MODE, false>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
+            row_list_block<MODE, false>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
                                         a->next_list, a->next_count, a->cap, a->tgt, a->host_total, a->dummy_base, a->recent, objv, (int)blockIdx.x, a->rblocks,
                                         (int)threadIdx.x);
             return;
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
         const int fb = (int)blockIdx.x - a->rblocks, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), ln = (int)(threadIdx.x & (FTPB - 1));
         PBRE_LAUNDER(a);
         __shared__ PairX px[FUSED_WAVES / 2];
-        pair_wave<MODE>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count, a->cap,
+        pair_wave<MODE, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count, a->cap,
                         a->tgt, a->zero_count, px[wv >> 1], fb * (FUSED_WAVES / 2) + (wv >> 1), ln, wv & 1);
     } else {
         // 64-thread blocks, like k_fast's: beside a machine-filling batch (131072 envs = 2048 waves = every wave slot) the row waves displace some
@@ -384,14 +400,14 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
         if ((int)blockIdx.x < rb) {
             const int role = (int)blockIdx.x & (FUSED_WAVES - 1);
             PBRE_LAUNDER(a);
-            row_list_block<MODE, false, true>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
+            row_list_block<MODE, false, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
                                               a->next_list, a->next_count, a->cap, a->tgt, a->host_total, a->dummy_base, a->recent, nullptr,
                                               (int)blockIdx.x / FUSED_WAVES, a->rblocks, (role == 0 ? REPB * W : (role - 1) * FTPB) + (int)threadIdx.x, a->objv_g);
             return;
         }
         const int chunk = (int)blockIdx.x - rb;
         PBRE_LAUNDER(a);
-        fast_wave<MODE, false>(a->T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
+        fast_wave<MODE, false, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
                                a->cap, a->tgt, a->zero_count, chunk, (int)threadIdx.x);
     }
 }
@@ -641,11 +657,11 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
                             b.count + cc * NB, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB, b.h_total, b.cap, b.count + 3 * NB, rblocks, b.objv_g};
             if (pair) {
                 c->launches_pair++;
-                hipLaunchKernelGGL((k_fused<MODE, true>), dim3(rblocks + (blocks + FUSED_WAVES / 2 - 1) / (FUSED_WAVES / 2)), dim3(RTPB), 0, s, fa);
+                hipLaunchKernelGGL((k_fused<MODE, true>), dim3(rblocks + (blocks + FUSED_WAVES / 2 - 1) / (FUSED_WAVES / 2)), dim3(RTPB), 0, s, fa, (const Tables*)c->dT);
             } else {
                 if (++b.objv_seq <= 0) b.objv_seq = 1;        // (never 0: that value selects the block barrier, PBRE_OBJV_SYNC)
                 fa.P.objv_seq = b.objv_seq;
-                hipLaunchKernelGGL((k_fused<MODE, false>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa);
+                hipLaunchKernelGGL((k_fused<MODE, false>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }

@@ -213,7 +213,8 @@ struct Fast {
 
     struct Kin { M3 R[ND]; V3 p[ND]; V3 Sa[ND], Sl[ND]; };   // link frames, joint axes (world, about world origin)
 
-    static PBRE_HD void fk(const Tables& T, const float* q, Kin& K) {
+    template <class TT>
+    static PBRE_HD void fk(const TT& T, const float* q, Kin& K) {
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
             M3 R0; PBRE_UNROLL for (int k = 0; k < 9; k++) R0.m[k] = T.R0[k][j];
@@ -453,23 +454,27 @@ struct Fast {
 
     // RT: pbre_physics.solver_residual_threshold > 0 (Bullet's exit test of the sweep loop, see step_t); sw: where the number of sweeps the
     // env ran goes (Params::sweeps + the env's local index), or null
-    template <bool RT = false>
-    static PBRE_HD int step(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+    // TT: `Tables` or CTables, the same struct in the constant address space (pbre_capi.hip k_fused: there the tables pointer is not a
+    // __restrict__ kernel argument every store is known not to alias, and through a plain pointer the model constants came in as per-lane
+    // vector loads of a uniform address -- 50 x4 loads whose results were spilled, 488 B of scratch per lane -- instead of scalar loads)
+    template <bool RT = false, class TT = Tables>
+    static PBRE_HD int step(const TT& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                             unsigned long long env_id, const float* tgt, int* sw = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
         return step_t<false, 0, RT>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr, 0, sw);
     }
     // action_repeat > 1: the env left the apply_action loop in an earlier iteration of this env.step() (`if self._termination():
     // break`, panda_push_gym_env.py:239-240; flag X[14]): no simulation step, only the evaluation of the state it is in
-    static PBRE_HD int skipped(const Tables& T, const Params& P, float* st, float* out, int mode, int flags, unsigned long long env_id) {
+    template <class TT = Tables>
+    static PBRE_HD int skipped(const TT& T, const Params& P, float* st, float* out, int mode, int flags, unsigned long long env_id) {
         float q[ND], qd[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
         V3 op = v3(st[9], st[10], st[11]);
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
         return finish(T, P, st, q, qd, op, oq, out, mode, flags, env_id);
     }
-    template <bool RT = false>
-    static PBRE_HD int step_rc(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+    template <bool RT = false, class TT = Tables>
+    static PBRE_HD int step_rc(const TT& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                                unsigned long long env_id = 0, const float* tgt = nullptr, int* sw = nullptr) {
         if (st[46] != 0.f) return skipped(T, P, st, out, mode, flags, env_id);
         return step_t<true, 0, RT>(T, P, st, act, out, mode, flags, env_id, tgt, nullptr, 0, sw);
@@ -486,8 +491,8 @@ struct Fast {
     // <= P.res_lim.  The test couples the blocks of the simple class, so the motor rows run sequentially next to the object's rows (no
     // closed form, no split over two waves); a lane that has left the loop keeps a snapshot of its velocities while its wave-mates go on
     // (what an env computes does not depend on the lanes it shares a wave with).  The sweeps run are reported through `sw`.
-    template <bool RC, int ROLE = 0, bool RT = false>
-    static PBRE_HD int step_t(const Tables& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
+    template <bool RC, int ROLE = 0, bool RT = false, class TT = Tables>
+    static PBRE_HD int step_t(const TT& T, const Params& P, float* st, const float* act, float* out, int mode, int flags,
                               unsigned long long env_id, const float* tgt, PairX* px = nullptr, int ln = 0, int* sw = nullptr) {
         static_assert(ROLE == 0 || !RC, "the pair kernel steps the simple class");
         static_assert(ROLE == 0 || !RT, "the residual test is a maximum over all rows of an env: one lane steps the whole env");
@@ -1128,7 +1133,7 @@ struct Fast {
         }
         // observation / reward / termination of the new state, and its class for the next step.  The model constants
         // are re-read after the solver loop instead of keeping ~130 of them live across it.
-        const Tables* T2 = &T;
+        const TT* T2 = &T;
         PBRE_LAUNDER(T2);
         const CTables* T4 = (const CTables*)T2;
         return finish<ROLE>(*T4, P, st, q, qd, op, oq, out, mode, flags, env_id, !RC, px, ln);

@@ -28,9 +28,9 @@ echo "== rocprofv3 --kernel-trace --stats (same command, CPU baseline leg off)"
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_kernel_stats.csv && head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-60,100-
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/prof_$TAG -name "*.db" -delete
 echo "== PMC HBM / SQ of the stationary headline (separate passes, no tracing domains)"
-bash tools/profile_r05.sh $TAG 131072 2>&1 | grep -E "k_fast|valu_insts_per_wave|hbm_bytes_per_env_step|launches|valu_active" | head -40
+bash tools/profile_r05.sh $TAG 131072 2>&1 | grep -E "k_fast|k_fused|k_row|valu_insts_per_wave|hbm_bytes_per_env_step|launches|valu_active" | head -40
 echo "== the same counters for a 16384-env shard (k_fast_pair + k_row_list)"
-bash tools/profile_r05.sh ${TAG}_16384 16384 2>&1 | grep -E "k_fast|valu_insts_per_wave|hbm_bytes_per_env_step" | head -12
+bash tools/profile_r05.sh ${TAG}_16384 16384 0 2>&1 | grep -E "k_fast|k_fused|valu_insts_per_wave|hbm_bytes_per_env_step" | head -16
 echo "== kernel durations of the stationary step, distribution over 250 steps"
 rm -f gpurun_out/${TAG}_step_kernels.txt
 for N in 131072 16384; do bash tools/trace_panda_steady3.sh $N ${TAG}_trace_$N PBRE_BENCH_NO_RT=1 2>&1 | grep -E "min |span" | tee -a gpurun_out/${TAG}_step_kernels.txt; done

@@ -58,12 +58,21 @@ for kf in ("k_fused<7, pair>", "k_fused<7>"):      # the step as one launch (rou
 if dom in hbm:
     hbm["k_fast<7>"] = dict(hbm[dom], variant=dom)
     hbm["step_kernel"] = dict(hbm[dom], variant=dom)
+# the two-kernel step (PBRE_FUSED=0 passes): k_fast's own traffic
+fs0, ws0 = summarise(load("FETCH_SIZE0", {"FETCH_SIZE"})), summarise(load("WRITE_SIZE0", {"WRITE_SIZE"}))
+two = {}
+for kf in ("k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>", "k_row_list<7>"):
+    if kf in fs0 and kf in ws0:
+        f_, w_ = fs0[kf]["FETCH_SIZE"]["mean_stationary_third"] * 1024, ws0[kf]["WRITE_SIZE"]["mean_stationary_third"] * 1024
+        two[kf] = {"fetch_bytes": f_, "write_bytes": w_, "hbm_bytes_per_env_step_of_the_batch": (f_ + w_) / n_envs, "launches": fs0[kf]["FETCH_SIZE"]["calls"]}
+if two:
+    hbm["two_kernel_step_PBRE_FUSED_0"] = two
 hbm["calibration"] = {"k_classify_fetch_bytes_expected": 64 * n_envs,
                       "k_classify_fetch_bytes_counter": fs.get("k_classify", {}).get("FETCH_SIZE", {"mean_all": 0})["mean_all"] * 1024,
                       "k_observe_fetch_bytes_expected": 192 * n_envs,
                       "k_observe_fetch_bytes_counter_x2": 2 * fs.get("k_observe", {}).get("FETCH_SIZE", {"mean_all": 0})["mean_all"] * 1024}
 json.dump(hbm, open("gpurun_out/%s_pmc_hbm.json" % tag, "w"), indent=1)
-print(json.dumps({k: v for k, v in hbm.items() if k.startswith("k_fast")}, indent=1))
+print(json.dumps({k: v for k, v in hbm.items() if k.startswith("k_fast") or k.startswith("k_fused") or k.startswith("two_")}, indent=1))
 
 sq = load("SQ", {"SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"})
 out = {}
@@ -89,5 +98,20 @@ for kf in ("k_fused<7, pair>", "k_fused<7>"):
         out["k_fast<7>"] = dict(out[kf], variant=kf)
         out["step_kernel"] = dict(out[kf], variant=kf, note="one launch per step: the complex envs' row waves (a few hundred, ~100 k instructions each, plus the idle "
                                   "row blocks that exit at once) are in SQ_WAVES and SQ_INSTS_VALU beside the simple envs' waves; PBRE_FUSED=0 passes give k_fast's own")
+sq0 = load("SQ0", {"SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"})
+two = {}
+for k, d in sq0.items():
+    if not (k.startswith("k_fast<7") or k.startswith("k_fast_pair<7") or k.startswith("k_row_list<7")):
+        continue
+    o = {c: (sum(v[len(v) * 2 // 3:]) / max(1, len(v[len(v) * 2 // 3:]))) for c, v in d.items()}
+    o["launches"] = len(next(iter(d.values())))
+    if o.get("SQ_WAVE_CYCLES"):
+        o["valu_active_over_wave_cycles"] = o.get("SQ_ACTIVE_INST_VALU", 0) / o["SQ_WAVE_CYCLES"]
+    if o.get("SQ_WAVES"):
+        o["valu_insts_per_wave"] = o.get("SQ_INSTS_VALU", 0) / o["SQ_WAVES"]
+    two[k] = o
+if two:
+    out["two_kernel_step_PBRE_FUSED_0"] = two
 json.dump(out, open("gpurun_out/%s_pmc_sq.json" % tag, "w"), indent=1)
-print(json.dumps({k: {kk: v[kk] for kk in ("valu_insts_per_wave", "valu_active_over_wave_cycles", "wait_any_over_wave_cycles", "launches") if kk in v} for k, v in out.items()}, indent=1))
+print(json.dumps({k: {kk: v[kk] for kk in ("valu_insts_per_wave", "valu_active_over_wave_cycles", "wait_any_over_wave_cycles", "launches") if kk in v} for k, v in out.items() if "SQ_WAVES" in v or "launches" in v}, indent=1))
+print(json.dumps({k: {kk: v.get(kk) for kk in ("valu_insts_per_wave", "launches")} for k, v in out.get("two_kernel_step_PBRE_FUSED_0", {}).items()}))

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 counter passes of the headline command (stationary protocol: 1000-step pre-roll, then the timed steps), one --pmc pass each,
+# Round-5 counter passes of the headline command (stationary protocol: 1000-step pre-roll, then the timed steps), one --pmc pass each,
 # no tracing domains besides the kernel dispatch records rocprofv3 needs:  FETCH_SIZE, WRITE_SIZE (HBM traffic), SQ issue counters.
-#   usage: tools/profile_r04.sh <tag> [envs]      -> gpurun_out/<tag>_pmc_hbm.json, gpurun_out/<tag>_pmc_sq.json
-TAG=${1:-r05}; N=${2:-131072}
+#   usage: tools/profile_r05.sh <tag> [envs] [two-kernel passes: 1|0]      -> gpurun_out/<tag>_pmc_hbm.json, gpurun_out/<tag>_pmc_sq.json
+TAG=${1:-r05}; N=${2:-131072}; TWO=${3:-1}      # TWO=0: skip the PBRE_FUSED=0 passes
 ROOTDIR=$(pwd); export TMPDIR=/tmp
 run() {  # <name> <counters...>
   local NAME=$1; shift
@@ -11,5 +11,13 @@ run() {  # <name> <counters...>
 run FETCH_SIZE FETCH_SIZE
 run WRITE_SIZE WRITE_SIZE
 run SQ SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
+# the same issue counters with the step as two kernels (PBRE_FUSED=0): k_fast's and k_row_list's own instruction counts, comparable with rounds 1-4
+if [ "$TWO" = 1 ]; then
+export PBRE_FUSED=0
+run SQ0 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY
+run FETCH_SIZE0 FETCH_SIZE
+run WRITE_SIZE0 WRITE_SIZE
+unset PBRE_FUSED
+fi
 python tools/pmc_r05.py $TAG $N
 find gpurun_out/pmc_${TAG}_* -name "*.csv" -size +6M -delete; find gpurun_out/pmc_${TAG}_* -name "*.db" -delete
