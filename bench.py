@@ -165,7 +165,7 @@ def other_configs(torch, dev, steps=10):
                              "kernel_ms": kms, "algorithmic_bytes_per_env_step": alg_bytes,
                              "note": "fp32-VALU / dependency bound like the Panda path; see valu"}
         d, src = _profile(pmc_name)
-        if d:
+        if d and valu_key in d:      # (a counter pass that failed leaves a summary without the key: the timing must not be lost over it)
             envs_per_wave = r.pop("_envs_per_wave")
             r["valu"] = {"valu_insts_per_env_step": d[valu_key] / envs_per_wave,
                          "valu_active_over_wave_cycles": d.get("valu_active_over_wave_cycles", d.get("sq_active_inst_valu_over_wave_cycles")),

@@ -120,8 +120,9 @@ __device__ __forceinline__ void publish_class(int env, int c, signed char* __res
 // (0.249 ms per stationary step against 0.220 ms with this variant; right after reset(), without complex envs, 0.157 against 0.187).
 // launch_step picks per step.
 // (fast_wave: one wave's work -- the 64 envs of `chunk`, lane ln; k_fast's body and, round 5, the simple envs' part of k_fused)
-// CT: read the model constants through the constant address space (k_fused; see Fast::step)
-template <int MODE, bool RT, bool CT = false>
+// CT: read the model constants through the constant address space (see Fast::step; measured first in k_fused -- 131072 envs fresh 0.101 ->
+// 0.089 ms -- then made the default of every lane-per-env step kernel; false: A/B)
+template <int MODE, bool RT, bool CT = true>
 __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                           const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(FTPB, WPS) void k_fast(const Tables* __restrict__ T
 constexpr int PTPB = 2 * FTPB;
 // (pair_wave: one wave's work -- role 0 the robots, role 1 the objects of the 64 envs of `chunk`, exchange record px; k_fast_pair's body and,
 // round 5, the simple envs' part of k_fused<.., true>.  One block barrier per wave that has a simulating lane.)
-template <int MODE, bool CT = false>
+template <int MODE, bool CT = true>
 __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                           const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(FTPB) void k_fast_rc(const Tables* __restrict__ T, 
         const int i = k * FTPB + threadIdx.x;
         if (i < cur_count[b]) {
             const int env = cur_list[(size_t)b * cap + i];
-            const int c = FastD::step_rc<RT>(*T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
+            const int c = FastD::step_rc<RT>(*(const CTables*)T, P, state + (size_t)env * STATE, (MODE & FastD::M_ACTION) ? actions + (size_t)env * act_dim : nullptr,
                                              (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags, P.env_id_base + (unsigned long long)env,
                                              (MODE & FastD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, (RT && P.sweeps) ? P.sweeps + env : nullptr);
             publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);

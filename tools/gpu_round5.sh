@@ -11,6 +11,12 @@ echo "== pytest -m gpu"
 timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -vE "^/opt/amdgpu" gpurun_out/${TAG}_pytest_gpu.log | tail -4 | cut -c1-300
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -4 | tee gpurun_out/${TAG}_smoke.log
+echo "== PMC HBM / SQ of the stationary headline (separate passes, no tracing domains)"
+bash tools/profile_r05.sh $TAG 131072 2>&1 | grep -E "k_fast|k_fused|k_row|valu_insts_per_wave|hbm_bytes_per_env_step|launches|valu_active" | head -40
+echo "== the same counters for a 16384-env shard (k_fast_pair + k_row_list)"
+bash tools/profile_r05.sh ${TAG}_16384 16384 0 2>&1 | grep -E "k_fast|k_fused|valu_insts_per_wave|hbm_bytes_per_env_step" | head -16
+# (bench.py's `roofline.traffic` / `valu.sq_counters` are read from profiles/<tag>_pmc_*.json: this visit's counter summaries, copied here before the bench runs)
+cp gpurun_out/${TAG}_pmc_hbm.json profiles/${TAG}_pmc_hbm.json 2>/dev/null; cp gpurun_out/${TAG}_pmc_sq.json profiles/${TAG}_pmc_sq.json 2>/dev/null
 echo "== bench"
 timeout 900 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json; tail -2 gpurun_out/${TAG}_bench.err
 python - <<PY
@@ -27,10 +33,6 @@ echo "== rocprofv3 --kernel-trace --stats (same command, CPU baseline leg off)"
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOTDIR/gpurun_out/prof_$TAG -o run -- python $ROOTDIR/bench.py --no-cpu-baseline --no-shards > $ROOTDIR/gpurun_out/${TAG}_rocprof.log 2>&1)
 f=$(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python tools/compact_stats.py $f gpurun_out/${TAG}_kernel_stats.csv && head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-60,100-
 find gpurun_out/prof_$TAG -name "*kernel_trace.csv" -delete; find gpurun_out/prof_$TAG -name "*.db" -delete
-echo "== PMC HBM / SQ of the stationary headline (separate passes, no tracing domains)"
-bash tools/profile_r05.sh $TAG 131072 2>&1 | grep -E "k_fast|k_fused|k_row|valu_insts_per_wave|hbm_bytes_per_env_step|launches|valu_active" | head -40
-echo "== the same counters for a 16384-env shard (k_fast_pair + k_row_list)"
-bash tools/profile_r05.sh ${TAG}_16384 16384 0 2>&1 | grep -E "k_fast|k_fused|valu_insts_per_wave|hbm_bytes_per_env_step" | head -16
 echo "== kernel durations of the stationary step, distribution over 250 steps"
 rm -f gpurun_out/${TAG}_step_kernels.txt
 for N in 131072 16384; do bash tools/trace_panda_steady3.sh $N ${TAG}_trace_$N PBRE_BENCH_NO_RT=1 2>&1 | grep -E "min |span" | tee -a gpurun_out/${TAG}_step_kernels.txt; done
@@ -45,5 +47,3 @@ import json
 d=json.load(open("gpurun_out/${TAG}_bench2.json"))
 print({k: d.get(k) for k in ("value","ms_per_step","closed_loop","sharded_consumers_no_gather")}, d["config"]["rccl"])
 PY
-echo "== self-collision probe"
-timeout 600 python tools/self_collision_probe.py --envs 16384 --samples 12 2>&1 | tail -1 | tee gpurun_out/${TAG}_self_collision_probe.json | cut -c1-300

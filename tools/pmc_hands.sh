@@ -21,7 +21,7 @@ for name in ("sq", "fetch", "write"):
         continue
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "kw_step" in r["Kernel_Name"] and "14>" in r["Kernel_Name"].split("(")[0]:
+        if "kw_step" in r["Kernel_Name"] and ("14>" in r["Kernel_Name"].split("(")[0] or "14, false>" in r["Kernel_Name"].split("(")[0]):      # (round 5: trailing RT flag)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in agg.items():
         out[c] = sum(v) / len(v)
