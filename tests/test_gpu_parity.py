@@ -527,6 +527,37 @@ def test_one_launch_step_is_bit_identical_to_the_two_kernel_step(panda, hip_lib,
     assert (ia[10] > 0) == (simple_env_mapping == "pair") and (ib[10] > 0) == (simple_env_mapping == "pair"), (ia, ib)
 
 
+def test_one_launch_step_with_thousands_of_complex_envs(panda, hip_lib, monkeypatch, simple_env_mapping):
+    """The row part of k_fused when every slot makes several trips over the complex lists: 4096 envs, ALL of them in contact-rich states
+    (robot-table, robot-object, joints at limits: both complex lists), the row kernel forced (F_COMPLEX_ROWS) -- several hundred work items
+    over at most 256 slots, so each slot's object wave hands over several rounds of twists (per-env global records + sequence number in
+    the 64-thread grid, LDS + barriers in the 256-thread one).  Rows, states and classes bit for bit those of the two-kernel step."""
+    n = 4096
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(3), 24, 24).astype(np.float32)
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET | _capi.F_COMPLEX_ROWS, max_steps=40)
+    monkeypatch.setenv("PBRE_FUSED", "1")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_FUSED", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    st = a.get_state()
+    reps = (n + len(S) - 1) // len(S)
+    st[:, :S.shape[1]] = np.tile(S, (reps, 1))[:n]
+    a.set_state(st); b.set_state(st)
+    assert a.kernel_info()[5] > 3000, a.kernel_info()          # complex envs of the current state
+    rng = np.random.default_rng(11)
+    for k in range(12):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), "step %d" % k
+    assert np.array_equal(a.get_state(), b.get_state())
+    ia, ib = a.kernel_info(), b.kernel_info()
+    assert ia[13] >= 12 and ib[13] == 0, (ia, ib)
+
+
 def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch):
     """pbre_step with page-locked buffers: by default the kernels read the actions from and write the rows to host memory themselves
     (PBRE_ZERO_COPY=3); =0 stages them through device buffers with hipMemcpyAsync.  Same rows, bit for bit, complex envs included

@@ -26,6 +26,8 @@ NAMES = {0: "row: loads, motor targets", 1: "row: forward kinematics", 2: "row: 
 
 
 def main():
+    # the probes sample block 0 of the two-kernel step's kernels (in k_fused's 64-thread grid block 0 is an object wave): probe that step
+    os.environ.setdefault("PBRE_FUSED", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--envs", type=int, default=16384)
     ap.add_argument("--preroll", type=int, default=1100)
