@@ -647,7 +647,8 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
     bool pair = false;
     if (!RT && c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
         pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
-    if constexpr (NB <= 2 && MODE == MODE_STEP && !RT) {
+    // (env.step() under joint control, and the settle steps of reset(): 201 launches per reset)
+    if constexpr (NB <= 2 && (MODE == MODE_STEP || MODE == 0) && !RT) {
         // the whole step as one launch on the caller's stream (k_fused): no fork / join through the side stream
         if (c->fused && rows) {
             const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
