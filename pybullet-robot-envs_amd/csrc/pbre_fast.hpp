@@ -1051,7 +1051,10 @@ struct Fast {
                 // bound itself -- no clamp binds and the closed form IS the sequence of rows up to rounding; a lane that fails (cube
                 // sliding, tipping, in flight; NaN) takes the explicit rows for the remaining sweeps.  What a lane computes does not
                 // depend on the lanes it shares a wave with.
-                constexpr int OC_K = 22;
+#ifndef PBRE_OC_K        // explicit sweeps before the closed form (even; A/B and the acceptance probe tools/oc_accept_probe.py)
+#define PBRE_OC_K 22
+#endif
+                constexpr int OC_K = PBRE_OC_K;
                 const bool want_oc = !(flags & 64) && P.iters >= OC_K + 32 && !(P.iters & 1);
                 const int it_explicit = want_oc ? OC_K : P.iters;
                 for (int it = 0; it < it_explicit; it += 2) {
