@@ -32,8 +32,13 @@
 // (Core::step, where `objv` and `P` are in scope: the side record is complete behind the block barrier -- its producer is a sibling wave of the
 // block, k_row_list -- or, P.objv_seq != 0, once its first word carries this launch's sequence number: the producer is a wave of another block,
 // k_fused's 64-thread grid.  P.objv_seq is uniform, so the barrier is not in divergent code.)
-#define PBRE_OBJV_SYNC() do { if (P.objv_seq == 0) __syncthreads(); else { const int* f_ = (const int*)objv; \
-        while (__hip_atomic_load(f_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.objv_seq) __builtin_amdgcn_s_sleep(8); } } while (0)
+// The wait is bounded (~1 s): the producer waits for nothing and is dispatched first, so the bound is never reached -- but a wait that could
+// not end would hang the device, so a row that does reach it goes on with the record as it is and counts as a bad env-step
+// (pbre_kernel_info[12]) instead.
+#define PBRE_OBJV_SYNC() do { if (P.objv_seq == 0) __syncthreads(); else { const int* f_ = (const int*)objv; int spins_ = 0; \
+        while (__hip_atomic_load(f_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.objv_seq) { \
+            __builtin_amdgcn_s_sleep(8); \
+            if (++spins_ > (1 << 22)) { if (P.bad_count) atomicAdd(P.bad_count, 1); break; } } } } while (0)
 #ifndef PBRE_CONST_AS        // (-DPBRE_CONST_AS= builds the A/B variant with the model constants re-read through a plain pointer)
 #define PBRE_CONST_AS __attribute__((address_space(4)))
 #endif
@@ -661,7 +666,13 @@ static hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act,
                 c->launches_pair++;
                 hipLaunchKernelGGL((k_fused<MODE, true>), dim3(rblocks + (blocks + FUSED_WAVES / 2 - 1) / (FUSED_WAVES / 2)), dim3(RTPB), 0, s, fa, (const Tables*)c->dT);
             } else {
-                if (++b.objv_seq <= 0) b.objv_seq = 1;        // (never 0: that value selects the block barrier, PBRE_OBJV_SYNC)
+                // (never 0: that value selects the block barrier, PBRE_OBJV_SYNC.  After 2^31 - 1 launches -- four days of stepping -- the numbers
+                // start over, behind a clear of the records: a record last written 2^31 launches ago must not look complete)
+                if (b.objv_seq == 0x7fffffff) {
+                    if ((e = hipMemsetAsync(b.objv_g, 0, (size_t)(b.cap + 32) * W * sizeof(float), s)) != hipSuccess) return e;
+                    b.objv_seq = 0;
+                }
+                b.objv_seq++;
                 fa.P.objv_seq = b.objv_seq;
                 hipLaunchKernelGGL((k_fused<MODE, false>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
             }
@@ -823,6 +834,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_ROW_MAX")) c->row_max = atoi(ev);
     if (const char* ev = getenv("PBRE_FAST3")) c->fast3 = atoi(ev);
     if (const char* ev = getenv("PBRE_FUSED")) c->fused = atoi(ev);
+    if (const char* ev = getenv("PBRE_OBJV_SEQ0")) c->main.objv_seq = c->tmp.objv_seq = atoi(ev);      // (tests: start k_fused's sequence numbers next to their wrap)
     if (const char* ev = getenv("PBRE_PAIR")) c->pair = atoi(ev);
     if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;

@@ -558,6 +558,39 @@ def test_one_launch_step_with_thousands_of_complex_envs(panda, hip_lib, monkeypa
     assert ia[13] >= 12 and ib[13] == 0, (ia, ib)
 
 
+def test_one_launch_step_across_the_wrap_of_its_sequence_numbers(panda, hip_lib, monkeypatch):
+    """k_fused's 64-thread grid marks an object wave's side record complete with the launch's sequence number; after 2^31 - 1 launches the
+    numbers start over behind a clear of the records.  PBRE_OBJV_SEQ0 starts them eight launches before that: 20 steps across the wrap,
+    complex envs present, bit for bit the two-kernel step."""
+    n = 2048
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(5), 12, 12).astype(np.float32)
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40)
+    monkeypatch.setenv("PBRE_PAIR", "0")                     # the 64-thread grid, whatever the module's mapping fixture says
+    monkeypatch.setenv("PBRE_FUSED", "1")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_FUSED", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()                                     # (201 one-launch settle steps each: sequence numbers 1 .. 201)
+    a.close()
+    monkeypatch.setenv("PBRE_FUSED", "1")
+    monkeypatch.setenv("PBRE_OBJV_SEQ0", str(2 ** 31 - 1 - 201 - 8))
+    a = _capi.Engine(panda["table"], **kw)
+    a.reset()
+    st = b.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(13)
+    for k in range(20):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), "step %d" % k
+    assert np.array_equal(a.get_state(), b.get_state())
+    assert a.kernel_info()[13] >= 20
+
+
 def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch):
     """pbre_step with page-locked buffers: by default the kernels read the actions from and write the rows to host memory themselves
     (PBRE_ZERO_COPY=3); =0 stages them through device buffers with hipMemcpyAsync.  Same rows, bit for bit, complex envs included
