@@ -17,6 +17,21 @@
 #define PBRE_OPAQUE_I(x) asm volatile("" : "+v"(x))
 #define PBRE_OPAQUE_F(x) asm volatile("" : "+v"(x))
 #define PBRE_NOUNROLL _Pragma("nounroll")
+// Per-env hand-over of the IK targets (round 5): kw_lane_ik marks an env's targets complete with the launch's sequence number; the solve kernels
+// wait for that env's mark only.  Targets and mark are written and read with RELAXED agent-scope atomics (coherent across the XCDs' L2s by
+// themselves) around workgroup-scope fences (program order only): a release / acquire pair at agent scope is an L2 write-back / invalidate on this
+// chip, and 32768 lanes publishing and quads polling that way slowed every kernel running beside them (kw_dyn 93 -> 207 us,
+// profiles/r05u_icub_timeline_ab.txt).  The wait is bounded: a wait that cannot end would hang the device -- the IK kernel is launched first, on a
+// stream of the highest priority, and waits for nothing, so the bound is not reached; a quad that does reach it goes on and the env-step is
+// counted by the NaN / Inf guard's counter.
+#define PBRE_IK_STORE(done, p, v) do { if (done) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(p) = (v); } while (0)
+#define PBRE_IK_PUBLISH(done, seq) do { if (done) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __hip_atomic_store((done), (seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
+#define PBRE_IK_WAIT(flag, seq, bad) do { int spins_ = 0; \
+        while (__hip_atomic_load((flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (seq)) { \
+            __builtin_amdgcn_s_sleep(8); \
+            if (++spins_ > (1 << 22)) { if (bad) atomicAdd((bad), 1); break; } } \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define PBRE_LANE_MSTRIDE 64         // M^-1 in wave-private LDS, [entry][lane]
 #ifndef PBRE_LANE_MREG
 #define PBRE_LANE_MREG 50            // 160 of the 210 entries in LDS (40 KB per wave: four waves per CU), the rest in registers
@@ -37,10 +52,14 @@ __device__ __forceinline__ void wpublish(int env, int c, signed char* __restrict
 }
 // Cartesian control: hand-pose update + inverse kinematics -> joint targets, one thread per env
 __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
-                                                   const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim) {
+                                                   const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim,
+                                                   int* __restrict__ ik_done, int ik_seq) {
+    // (a higher wave priority for this kernel -- its last waves are the head of the step's critical path beside the solve kernels -- was
+    // measured: the bulk of the IK then starves kw_dyn, 95 -> 161 us, and the step gets longer; profiles/r05u_icub_timeline_ab.txt)
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (env >= n) return;
-    LaneD::ik_targets(*T, P, state + (size_t)env * Shape32::STATE, actions + (size_t)env * act_dim, tgt + (size_t)env * Shape32::TGT);
+    LaneD::ik_targets(*T, P, state + (size_t)env * Shape32::STATE, actions + (size_t)env * act_dim, tgt + (size_t)env * Shape32::TGT,
+                      ik_done ? ik_done + env : nullptr, ik_seq);
 }
 
 // ------------------------------------------------------------------ the pipeline: kw_dyn -> kw_quad (+ kw_quad_rc) -> kw_fin
@@ -129,7 +148,7 @@ __device__ __forceinline__ float qb(float x, int o) { return o == 0 ? qb_t<0>(x)
 template <bool RC>
 __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
-                                          float* __restrict__ dyn, size_t cs, int env, int r) {
+                                          float* __restrict__ dyn, size_t cs, int env, int r, const int* __restrict__ ik_done = nullptr, int ik_seq = 0) {
     constexpr int ND = LaneD::ND, W = Shape32::W, XO = 2 * Shape32::W;
     float* st = state + (size_t)env * Shape32::STATE;
     if (st[XO + 14] != 0.f) return;
@@ -177,13 +196,16 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
             const float tc = qb(tl[c % QD], c / QD);
             PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = fmaf(A[i][c], tc, acc[i]);
         }
+        // Cartesian control: this env's IK targets are read next -- wait for ITS mark (the IK kernel runs beside this one)
+        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, P.bad_count);
         PBRE_UNROLL for (int i = 0; i < QD; i++) {
             const int d = d0 + i;
             const float wj = fminf(fmaxf(fmaf(dt, acc[i], qd[i]), -vmax), vmax);
             w[i] = wj; w0[i] = wj;
             float qdes = T->home[d], kp = T->kp_hold[d], kd = T->kd_hold[d];
             const float lo = T->lower[d], up = T->upper[d];
-            if (MODE & LaneD::M_TGT) qdes = tgt[(size_t)env * Shape32::TGT + d];
+            if (MODE & LaneD::M_TGT) qdes = ik_done ? __hip_atomic_load(tgt + (size_t)env * Shape32::TGT + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                    : tgt[(size_t)env * Shape32::TGT + d];
             if (MODE & LaneD::M_ACTION) {
                 kp = T->kp_act[d]; kd = T->kd_act[d];
                 const int ai = T->act_idx[d];
@@ -414,22 +436,24 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
 // Simple envs: every env of the batch in natural order, the quads of complex envs idle.
 __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
-                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs) {
+                                                   const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs,
+                                                   const int* __restrict__ ik_done, int ik_seq) {
     const int gl = blockIdx.x * LTPB + threadIdx.x;
     const int env = gl >> 2;
     if (env >= n || cls_cur[env] != 0) return;             // (whole quads)
-    quad_step<false>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, env, gl & 3);
+    quad_step<false>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, env, gl & 3, ik_done, ik_seq);
 }
 // Complex envs (robot-object contact) over the compacted list, 16 per wave; a whole SIMD's register file per wave.  Persistent blocks
 // (the host does not know the list's length).
 __global__ __launch_bounds__(LTPB, 1) void kw_quad_rc(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                       const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
-                                                      const int* __restrict__ cur_list, const int* __restrict__ cur_count, float* __restrict__ dyn, size_t cs) {
+                                                      const int* __restrict__ cur_list, const int* __restrict__ cur_count, float* __restrict__ dyn, size_t cs,
+                                                      const int* __restrict__ ik_done, int ik_seq) {
     const int total = *cur_count;
     for (int base = blockIdx.x * (LTPB / 4); base < total; base += gridDim.x * (LTPB / 4)) {
         const int i = base + (int)(threadIdx.x >> 2);
         if (i >= total) break;                             // (whole quads)
-        quad_step<true>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, cur_list[i], (int)(threadIdx.x & 3));
+        quad_step<true>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, cur_list[i], (int)(threadIdx.x & 3), ik_done, ik_seq);
     }
 }
 
@@ -494,10 +518,17 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     hipStream_t side = nullptr;       // kw_obj, the IK kernel and kw_quad_rc run beside kw_dyn / kw_quad; picked per caller stream (pick_side)
     SidePick sp;                      // candidates + calibration (pbre_sidepick.hpp)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_dyn = nullptr;
+    // Cartesian control, round 5: the IK kernel on a stream of its own (highest priority) and per-env "targets complete" marks (ik_done[env] ==
+    // ik_seq), so that kw_quad / kw_quad_rc start right behind kw_dyn and only the quads of envs whose IK is still iterating wait
+    hipStream_t ik_stream = nullptr;
+    int* ik_done = nullptr;           // [n]
+    int ik_seq = 0;
+    int ik_overlap = 1;               // PBRE_IK_OVERLAP=0: the kernel-level dependency of rounds 2-4 (A/B)
     size_t dyn_cs = 0;
     int n_simd = 1024;
     ~WideLane() override {
-        for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)cls, (void*)list, (void*)count, (void*)dyn, (void*)ik_done}) if (p) (void)hipFree(p);
+        if (ik_stream) (void)hipStreamDestroy(ik_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_dyn) (void)hipEventDestroy(ev_dyn);
@@ -535,6 +566,12 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             if ((e = hipEventCreateWithFlags(&ev_join, efl)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_dyn, efl)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_ik, efl)) != hipSuccess) return e;
+            if (const char* ev = getenv("PBRE_IK_OVERLAP")) ik_overlap = atoi(ev);
+            if (ik_overlap) {
+                if ((e = hipStreamCreateWithPriority(&ik_stream, hipStreamNonBlocking, phi)) != hipSuccess) return e;
+                if ((e = hipMalloc(&ik_done, (size_t)n * sizeof(int))) != hipSuccess) return e;
+                if ((e = hipMemset(ik_done, 0, (size_t)n * sizeof(int))) != hipSuccess) return e;
+            }
         }
         {
             // element stride: a multiple of 16 floats (kw_quad's 64-byte segments stay aligned), but never a power of two -- with 32768 envs
@@ -554,7 +591,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     hipEvent_t ev_ik = nullptr;
     void launch_lane_ik(const float* act, hipStream_t s) override {
         if (side) { ik_pending = true; return; }
-        hipLaunchKernelGGL(kw_lane_ik, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, tgt, n, act_dim);
+        hipLaunchKernelGGL(kw_lane_ik, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, tgt, n, act_dim, (int*)nullptr, 0);
     }
     void lane_t(int MODE, const float* act, float* out, int flags, hipStream_t s, hipEvent_t* ek) {
         signed char* c_cur = cls + (size_t)cur * n; signed char* c_nxt = cls + (size_t)(cur ^ 1) * n;
@@ -582,14 +619,29 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             // side stream anyway (measured: beside the IK kernel -- right behind kw_dyn -- it stretched that kernel from 0.41 to 0.66 ms);
             // joint control: the object solve stays on the side stream, beside kw_dyn)
             const bool ik_side = ik_pending;
-            const bool obj_main = ik_side && side != nullptr;
+            // Round 5 (profiles/r05s_icub_timeline.txt: IK 1..399 us, kw_quad / kw_quad_rc 409..818, kw_fin ..887): the solve kernels waited for
+            // the WHOLE IK kernel, whose duration is that of the 0.09 % of the envs that iterate to the cap.  With per-env "targets complete"
+            // marks (kw_lane_ik publishes an env's targets in the iteration in which it converges; quad_step waits for its own env's mark
+            // right before it reads the targets) the IK kernel runs on a stream of its own beside kw_dyn AND the solve kernels.  Only while the
+            // IK kernel's, kw_dyn's and kw_obj's waves are all resident at once (3 be waves on 2 n_simd slots): the IK waves must be running
+            // before quads start to wait for them; larger batches keep the kernel-level dependency.
+            const bool ik_ovl = ik_side && side != nullptr && ik_stream != nullptr && ik_done != nullptr && 3 * be <= 2 * n_simd;
+            const bool obj_main = ik_side && side != nullptr;      // (also with the per-env hand-over: kw_obj beside the IK kernel AND kw_dyn stretched all three -- dyn 92 -> 221 us)
             if (!(flags & 1) && !obj_main) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
             mark(2, s2);
-            if (ik_side) {      // (kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
-                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim);
+            if (ik_ovl) {
+                if (ik_seq == 0x7fffffff) { (void)hipMemsetAsync(ik_done, 0, (size_t)n * sizeof(int), s); ik_seq = 0; (void)hipEventRecord(ev_fork, s); }
+                ik_seq++;
+                (void)hipStreamWaitEvent(ik_stream, ev_fork, 0);
+                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, ik_stream, dT, P, state, act, tgt, n, act_dim, ik_done, ik_seq);
+                (void)hipEventRecord(ev_ik, ik_stream);
+                ik_pending = false;
+            } else if (ik_side) {      // (kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
+                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim, (int*)nullptr, 0);
                 (void)hipEventRecord(ev_ik, side);
                 ik_pending = false;
             }
+            const int* ikd = ik_ovl ? ik_done : nullptr;
             mark(3, s2);
             if (ek) (void)hipEventRecord(ek[0], s);
             mark(4, s);
@@ -597,16 +649,17 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             mark(5, s);
             if (side) { (void)hipEventRecord(ev_dyn, s); (void)hipStreamWaitEvent(side, ev_dyn, 0); }
             mark(6, s2);
-            hipLaunchKernelGGL(kw_quad_rc, dim3(std::min((n + 15) / 16, 256)), dim3(LTPB), 0, s2, dT, P, state, act, act_dim, MODE, tgt, l_cur, k_cur, dyn, dyn_cs);
+            hipLaunchKernelGGL(kw_quad_rc, dim3(std::min((n + 15) / 16, 256)), dim3(LTPB), 0, s2, dT, P, state, act, act_dim, MODE, tgt, l_cur, k_cur, dyn, dyn_cs, ikd, ik_seq);
             mark(7, s2);
             if (side) (void)hipEventRecord(ev_join, side);
-            if (ik_side) (void)hipStreamWaitEvent(s, ev_ik, 0);
+            if (ik_side && !ik_ovl) (void)hipStreamWaitEvent(s, ev_ik, 0);
             mark(8, s);
-            hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs);
+            hipLaunchKernelGGL(kw_quad, dim3((4 * n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, n, act_dim, MODE, tgt, c_cur, dyn, dyn_cs, ikd, ik_seq);
             mark(9, s);
             if (ek) (void)hipEventRecord(ek[1], s);
             if (!(flags & 1) && obj_main) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s, P, state, objv, n);
             if (side) (void)hipStreamWaitEvent(s, ev_join, 0);
+            if (ik_ovl) (void)hipStreamWaitEvent(s, ev_ik, 0);      // (the step is complete when every kernel of it is: the IK kernel's last waves too)
             mark(10, s);
             hipLaunchKernelGGL(kw_fin, dim3(be), dim3(LTPB), 0, s, dT, P, state, out, n, ow, flags, MODE, objv, dyn, dyn_cs, c_cur, c_nxt, l_nxt, k_nxt, k_zero);
             mark(11, s);

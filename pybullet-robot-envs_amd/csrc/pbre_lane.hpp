@@ -30,6 +30,12 @@
 #include <math.h>
 #include "pbre_fast.hpp"
 #include "pbre_objstep.hpp"
+#ifndef PBRE_IK_PUBLISH      // Lane::ik_targets: mark an env's targets complete (device pipeline: release store of the sequence number; nothing on the host)
+#define PBRE_IK_PUBLISH(done, seq) do { (void)(done); (void)(seq); } while (0)
+#endif
+#ifndef PBRE_IK_STORE        // ... and write one of its targets (device pipeline with the per-env hand-over: a store that is coherent across the XCDs)
+#define PBRE_IK_STORE(done, p, v) (*(p) = (v))
+#endif
 
 #ifndef PBRE_LANE_MSTRIDE      // floats between consecutive M^-1 entries of one env (device: 64 = [entry][lane]; host: 1)
 #define PBRE_LANE_MSTRIDE 1
@@ -790,12 +796,15 @@ struct Lane {
     // hand pose (X[6..11]), clip rotation and workspace, damped-least-squares IK from the current joint angles over the joints of
     // the chain to the end effector; same algorithm and stopping rule as Core::ik_targets / oracle orc_ik.  Writes tgt[0..ND) and
     // X[6..11].  (The reset-time targets of the home hand pose are the lane-group kernel's.)
-    static PBRE_HD void ik_targets(const Tab& T, const Params& P, float* st, const float* act, float* tgt) {
-        if (T.ee_owner == Topo::ee0) ik_targets_t<Topo::ee0>(T, P, st, act, tgt); else ik_targets_t<Topo::ee1>(T, P, st, act, tgt);
+    // done / seq (device pipeline, pbre_lane.hip; null on the host): the env's "targets complete" mark.  A lane writes its targets and then
+    // `seq` to *done (release) in the iteration in which ITS env converges, not when the slowest env of its wave leaves the loop: the solve
+    // kernels wait per env (PBRE_IK_WAIT), so the 0.09 % of the envs that iterate to the cap no longer hold up everybody else's step.
+    static PBRE_HD void ik_targets(const Tab& T, const Params& P, float* st, const float* act, float* tgt, int* done = nullptr, int seq = 0) {
+        if (T.ee_owner == Topo::ee0) ik_targets_t<Topo::ee0>(T, P, st, act, tgt, done, seq); else ik_targets_t<Topo::ee1>(T, P, st, act, tgt, done, seq);
     }
     // EO: the lane that owns the end effector; the chain base -> EO is static (T.on_chain agrees with it, lane_topo_matches)
     template <int EO>
-    static PBRE_HD void ik_targets_t(const Tab& T, const Params& P, float* st, const float* act, float* tgt) {
+    static PBRE_HD void ik_targets_t(const Tab& T, const Params& P, float* st, const float* act, float* tgt, int* done = nullptr, int seq = 0) {
         float* X = st + XO;
         V3 pos = v3(fmaf(act[0], P.ik_ps, X[6]), fmaf(act[1], P.ik_ps, X[7]), fmaf(act[2], P.ik_ps, X[8]));
         V3 eul = v3(X[9], X[10], X[11]);
@@ -812,6 +821,14 @@ struct Lane {
         M3 Eo; PBRE_UNROLL for (int k = 0; k < 9; k++) Eo.m[k] = T.ee_R[k];
         float q[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
+        // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
+        // their current angle
+        bool published = false;
+        auto publish = [&]() {
+            PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_IK_STORE(done, tgt + j, Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]));
+            PBRE_IK_PUBLISH(done, seq);
+            published = true;
+        };
 #ifdef PBRE_IK_PROBE      // host emulation only (tools/ik_cycle_probe.py): at which iteration does this env's iteration become periodic?
         float q_m2[ND]; int probe_at = -1, probe_kind = 3;      // kind 0 converged (residual), 1 fixed point, 2 two-cycle, 3 neither within the cap
         PBRE_UNROLL for (int j = 0; j < ND; j++) q_m2[j] = 3.0e38f;
@@ -840,6 +857,7 @@ struct Lane {
 #ifdef PBRE_IK_PROBE
             if (!go && probe_at < 0) { probe_at = it; probe_kind = 0; }
 #endif
+            if (done && !go && !published) publish();      // (a converged env's angles no longer change: these are its final targets)
             if (!PBRE_ANY(go)) break;
             {   // orientation error as a world-frame rotation vector: axis-angle of Rt (Re Eo)^T
                 const M3 Ree = mm(Re, Eo);
@@ -904,9 +922,7 @@ struct Lane {
 #ifdef PBRE_IK_PROBE
         pbre_ik_probe_record(probe_kind, probe_at);
 #endif
-        // joints off the chain: the iCub sends those it does not control to their rest pose (icub_env.py:316-317), the others keep
-        // their current angle
-        PBRE_UNROLL for (int j = 0; j < ND; j++) tgt[j] = Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]);
+        if (!published) publish();
     }
 };
 

@@ -108,6 +108,35 @@ def test_icub_push_policy_coupled_solve(hip_lib, monkeypatch):
     print(parity.check_icub_push_policy(_capi.Engine, hip_lib, monkeypatch))
 
 
+def test_icub_ik_overlap_is_bit_identical(hip_lib, monkeypatch):
+    """Round 5: under Cartesian control the pipeline's solve kernels wait per env for the IK targets (kw_lane_ik publishes an env's targets
+    in the iteration in which it converges, on a stream of its own) instead of for the whole IK kernel.  Same arithmetic: 2048 iCub-push envs,
+    random hand actions (out-of-reach targets among them: the IK's stragglers), auto-reset -- rows and states bit for bit those of the
+    kernel-level dependency (PBRE_IK_OVERLAP=0)."""
+    from pybullet_robot_envs.model.table import icub_table
+    monkeypatch.setenv("PBRE_ICUB_LANE", "1")
+    tbl, model, info = icub_table("l")
+    ov = parity.icub_overrides(info, "l", 1, 0, 1)
+    n = 2048
+    kw = dict(task=_capi.TASK_PUSH, num_envs=n, lib=hip_lib, robot=_capi.ROBOT_ICUB, flags=_capi.F_AUTO_RESET, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2,
+              max_steps=30, **ov)
+    monkeypatch.setenv("PBRE_IK_OVERLAP", "1")
+    a = _capi.Engine(tbl, **kw)
+    monkeypatch.setenv("PBRE_IK_OVERLAP", "0")
+    b = _capi.Engine(tbl, **kw)
+    assert a.kernel_info()[2] == 1 and b.kernel_info()[2] == 1
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(17)
+    for k in range(50):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y), "step %d" % k
+    assert np.array_equal(a.get_state(), b.get_state())
+    assert a.kernel_info()[12] == 0 and b.kernel_info()[12] == 0          # (a wait that ran into its bound would have been counted here)
+
+
 def test_icub_default_path_by_batch_size(hip_lib, monkeypatch):
     """without PBRE_ICUB_LANE: the lane-group kernel below 16384 envs, the pipeline from there on"""
     from pybullet_robot_envs.model.table import icub_table

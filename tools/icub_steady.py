@@ -26,6 +26,7 @@ if args.desync:
     st[:, eng.x_off + 3] = np.random.default_rng(4321).integers(0, args.max_steps, args.envs).astype(np.float32)
     eng.set_state(st)
 dev = torch.device("cuda", 0)
+torch.manual_seed(20260928)      # (the same action sequence in every run: A/B runs compare the same trajectories)
 act = [torch.rand((args.envs, eng.act_dim), device=dev) * 2 - 1 for _ in range(8)]
 out = torch.zeros((args.envs, eng.obs_dim + 2), device=dev)
 s = torch.cuda.Stream(device=dev); torch.cuda.set_stream(s)
