@@ -49,7 +49,7 @@ struct DevLanes {
     static __device__ __forceinline__ F loadu(const float* p) { return *p; }                       // group-uniform address
     static __device__ __forceinline__ float first(F x) { return x; }                               // a group-uniform value as a scalar
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 15u) == 0; }
-    static __device__ __forceinline__ void fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }    // a lane reads what another lane of the group stored
+    static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }    // a lane reads what another lane of the group stored
     static __device__ __forceinline__ F loadx(const float* p, I idx, B m) { return m ? p[idx] : 0.f; }
     static __device__ __forceinline__ void storex(float* p, I idx, F x, B m) { if (m) p[idx] = x; }
     static __device__ __forceinline__ void store(float* p, F x) { p[threadIdx.x & 15u] = x; }
@@ -324,7 +324,7 @@ struct DevLanes128 {
     static __device__ __forceinline__ F loadu(const float* p) { const float v = *p; return F{v, v}; }
     static __device__ __forceinline__ float first(F x) { return x.a; }
     static __device__ __forceinline__ bool lane0() { return t() == 0; }
-    static __device__ __forceinline__ void fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+    static __device__ __forceinline__ void fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
     static __device__ __forceinline__ F loadx(const float* p, I idx, B m) { return F{m.a ? p[idx.a] : 0.f, m.b ? p[idx.b] : 0.f}; }
     static __device__ __forceinline__ void storex(float* p, I idx, F x, B m) { if (m.a) p[idx.a] = x.a; if (m.b) p[idx.b] = x.b; }
     static __device__ __forceinline__ void store(float* p, F x) { p[t()] = x.a; p[t() + 64] = x.b; }

@@ -327,7 +327,10 @@ __device__ __forceinline__ void row_list_block(const Tables* __restrict__ T, con
             CoreD::step<RT>(*T, P, st, (MODE & CoreD::M_ACTION) ? actions + (size_t)(real ? env : 0) * act_dim : nullptr, nullptr, PHYS, flags,
                             (MODE & CoreD::M_TGT) ? tgt + (size_t)env * NJ : nullptr, 0ull,
                             obj_on ? (G ? objv_g + (size_t)env * W : &objv[row < REPB ? row : 0][0]) : nullptr, st_idle, (RT && real && P.sweeps) ? P.sweeps + env : nullptr);
-            __atomic_thread_fence(__ATOMIC_SEQ_CST);                         // the row's stores are read back by its lane 0 below
+            // the row's stores are read back by its lane 0 below: same wave, so a WORKGROUP-scope fence (wait for the stores; the CU's L1 is
+            // write-through).  Until round 5 this was __atomic_thread_fence(SEQ_CST) = system scope: a write-back AND invalidate of the XCD's
+            // whole L2 -- full of the state records the simple envs' waves are writing -- on every row wave's critical path
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             PBRE_PROBE_DECL
             if (real && (vt & 15) == 0) {
                 float q[NJ], qd[NJ];
