@@ -241,7 +241,7 @@ def other_configs(torch, dev, steps=10):
             env._engine.step_device(zero.data_ptr(), o.data_ptr(), sh)
         r, _ = timed(env._engine, acts)
         r["workload"] = "iCubReach-v0 (IK position control of the left hand), 32768 envs, hand at its home pose (1500 zero-action steps after reset())"
-        r["pipeline"] = ("kw_dyn (1 thread / env) -> kw_quad (4 lanes / env; envs whose hand touches the object: kw_quad_rc) -> kw_fin"
+        r["pipeline"] = ("kw_lane_ik (Cartesian control; targets handed over per env, beside everything else) || kw_dyn (1 thread / env) -> kw_quad (4 lanes / env; envs whose hand touches the object: kw_quad_rc) -> kw_fin"
                          if env._engine.kernel_info()[2] else "lane-group kernel")
         r["_envs_per_wave"] = 16 if env._engine.kernel_info()[2] else 2
         # q, qd of the 20 simulated DoF each way + object 13 f each way + action 3 f + obs 31 f + reward/done + counters
