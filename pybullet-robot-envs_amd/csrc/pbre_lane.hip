@@ -448,9 +448,14 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
 __global__ __launch_bounds__(LTPB, 1) void kw_quad_rc(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                       const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
                                                       const int* __restrict__ cur_list, const int* __restrict__ cur_count, float* __restrict__ dyn, size_t cs,
-                                                      const int* __restrict__ ik_done, int ik_seq) {
+                                                      const int* __restrict__ ik_done, int ik_seq, int epw) {
+    // epw envs per wave (<= 16; PBRE_QUAD_RC_EPW).  Which limit rows and contact slots a wave sweeps is the UNION over its envs (rows of an env
+    // without them are exact no-ops), and these few lone waves are the step's critical path in both control modes -- but fewer envs per wave do
+    // not shorten them (measured, profiles/r05w_quad_rc_epw.txt: 16 / 4 / 1 envs per wave: 378 / 397 / 391 us under joint control): the
+    // kernel's duration is ONE env's coupled chain on four lanes.  What an env computes does not depend on epw.
     const int total = *cur_count;
-    for (int base = blockIdx.x * (LTPB / 4); base < total; base += gridDim.x * (LTPB / 4)) {
+    if ((int)(threadIdx.x >> 2) >= epw) return;           // (whole quads)
+    for (int base = blockIdx.x * epw; base < total; base += gridDim.x * epw) {
         const int i = base + (int)(threadIdx.x >> 2);
         if (i >= total) break;                             // (whole quads)
         quad_step<true>(T, P, state, actions, act_dim, MODE, tgt, dyn, cs, cur_list[i], (int)(threadIdx.x & 3), ik_done, ik_seq);
@@ -524,6 +529,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     int* ik_done = nullptr;           // [n]
     int ik_seq = 0;
     int ik_overlap = 1;               // PBRE_IK_OVERLAP=0: the kernel-level dependency of rounds 2-4 (A/B)
+    int rc_epw = 16;                  // envs per wave of kw_quad_rc (PBRE_QUAD_RC_EPW: A/B, measured neutral)
     size_t dyn_cs = 0;
     int n_simd = 1024;
     ~WideLane() override {
@@ -567,6 +573,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             if ((e = hipEventCreateWithFlags(&ev_dyn, efl)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_ik, efl)) != hipSuccess) return e;
             if (const char* ev = getenv("PBRE_IK_OVERLAP")) ik_overlap = atoi(ev);
+            if (const char* ev = getenv("PBRE_QUAD_RC_EPW")) rc_epw = std::min(16, std::max(1, atoi(ev)));
             if (ik_overlap) {
                 if ((e = hipStreamCreateWithPriority(&ik_stream, hipStreamNonBlocking, phi)) != hipSuccess) return e;
                 if ((e = hipMalloc(&ik_done, (size_t)n * sizeof(int))) != hipSuccess) return e;
@@ -649,7 +656,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             mark(5, s);
             if (side) { (void)hipEventRecord(ev_dyn, s); (void)hipStreamWaitEvent(side, ev_dyn, 0); }
             mark(6, s2);
-            hipLaunchKernelGGL(kw_quad_rc, dim3(std::min((n + 15) / 16, 256)), dim3(LTPB), 0, s2, dT, P, state, act, act_dim, MODE, tgt, l_cur, k_cur, dyn, dyn_cs, ikd, ik_seq);
+            hipLaunchKernelGGL(kw_quad_rc, dim3(std::min((n + rc_epw - 1) / rc_epw, 256)), dim3(LTPB), 0, s2, dT, P, state, act, act_dim, MODE, tgt, l_cur, k_cur, dyn, dyn_cs, ikd, ik_seq, rc_epw);
             mark(7, s2);
             if (side) (void)hipEventRecord(ev_join, side);
             if (ik_side && !ik_ovl) (void)hipStreamWaitEvent(s, ev_ik, 0);
