@@ -296,6 +296,8 @@ int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
  * ctx", 8(e): "gather-to-root emulated with ncclGroupStart + ncclSend / ncclRecv").  One process per GPU; the ctx of rank r was created
  * with num_envs = N / G and env_id_base = r N / G.  RCCL is loaded with dlopen on first use (PBRE_RCCL_LIB, else librccl.so.1 /
  * librccl.so): libpbre.so does not link against it.
+ *   pbre_comm_probe       any rank: does the RCCL library load and export what the exchanges need (dlopen + dlsym only; no bootstrap
+ *                         thread, no socket) -- what the ranks other than 0 call before they agree to build the communicator;
  *   pbre_comm_unique_id   rank 0: the 128-byte ncclUniqueId every rank's pbre_comm_init needs (hand it over by any out-of-band channel);
  *   pbre_comm_init        collective over the G ranks: this ctx's communicator (ncclCommInitRank on the ctx's device) and its
  *                         communication stream; released by pbre_destroy;
@@ -324,6 +326,7 @@ int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
  * An exchange that fails inside its ncclGroup closes the group and marks the communicator unusable (every later call returns the error).
  * PBRE_COMM_SELF_P2P=1 (read at pbre_comm_init): rank 0's own rows travel through ncclSend / ncclRecv too (single-GPU tests execute
  * the RCCL point-to-point path that way). */
+int pbre_comm_probe(void);
 int pbre_comm_unique_id(void* id128);
 int pbre_comm_init(pbre_ctx* ctx, const void* id128, int32_t rank, int32_t world);
 int pbre_step_gather_device(pbre_ctx* ctx, const float* d_actions, float* d_rows_local, float* d_rows_all, void* stream);

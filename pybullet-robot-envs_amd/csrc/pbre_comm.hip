@@ -40,6 +40,7 @@ typedef pbre_comm_detail::Comm<HipRuntime> CommD;
 extern "C" {
 __attribute__((visibility("hidden"))) void pbre_comm_release(const pbre_ctx* c) { CommD::release(c); }      // (pbre_destroy; not part of the C-ABI)
 const char* pbre_comm_last_error(const pbre_ctx* c) { return CommD::last_error(c); }
+int pbre_comm_probe(void) { return CommD::probe(); }
 int pbre_comm_unique_id(void* id128) { return CommD::unique_id(id128); }
 int pbre_comm_init(pbre_ctx* ctx, const void* id128, int32_t rank, int32_t world) { return CommD::init(ctx, id128, rank, world); }
 int pbre_comm_info(const pbre_ctx* ctx, int32_t* info, int32_t n) { return CommD::info(ctx, info, n); }

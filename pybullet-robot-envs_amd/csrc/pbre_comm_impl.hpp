@@ -104,6 +104,13 @@ struct Comm {
     }
     static const char* last_error(const pbre_ctx* c) { const State* m = of(c); return m ? m->err.c_str() : thread_err().c_str(); }
 
+    // load probe: dlopen + symbol resolution only -- no ncclGetUniqueId, whose bootstrap root thread and listening socket a rank
+    // other than 0 would start for nothing
+    static int probe() {
+        Rccl& R = rccl();
+        if (!R.load()) { thread_err() = R.err; return PBRE_E_UNSUPPORTED; }
+        return PBRE_OK;
+    }
     static int unique_id(void* id128) {
         if (!id128) { thread_err() = "pbre_comm_unique_id: null argument"; return PBRE_E_ARG; }
         Rccl& R = rccl();

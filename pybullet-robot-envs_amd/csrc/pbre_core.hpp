@@ -44,7 +44,7 @@
 #define PBRE_COUNT_BAD(p) (++*(p))
 #endif
 #ifndef PBRE_OBJV_SYNC       // a kernel whose `objv` side record is produced by a sibling wave of the same block (k_row_list): the block barrier
-#define PBRE_OBJV_SYNC()     // behind which it is complete; nothing where a kernel of its own produced it earlier (kw_obj) and on the host
+#define PBRE_OBJV_SYNC(poison) // behind which it is complete; nothing where a kernel of its own produced it earlier (kw_obj) and on the host
 #endif
 #ifndef PBRE_PROBE           // phase timing of one wave (tools/phase_probe.py builds with -DPBRE_PHASE_PROBE); nothing otherwise
 #define PBRE_PROBE(k)
@@ -1302,7 +1302,12 @@ struct Core {
         PBRE_PROBE(9);      // the sweeps
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
-        if (use_objv) { PBRE_OBJV_SYNC(); vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew); }
+        if (use_objv) {
+            float poison = 0.f;      // NaN when a bounded wait for the side record ran out (k_fused's 64-thread grid): the env-step goes to the NaN / Inf guard
+            PBRE_OBJV_SYNC(poison);
+            vnew = L::sel(L::band(split, obj_lane), L::load(objv), vnew);
+            if (poison != 0.f) vnew = L::c(poison);
+        }
         B dyn = obj_on ? L::bor(robot, obj_lane) : robot;
         F Vn = L::sel(dyn, vnew, Vr);
         B posl = obj_on ? L::lti(lane, LC + 3) : robot;

@@ -440,7 +440,9 @@ struct Fast {
             }
         }
         const float sigma = sqrtf(sig2), nf = (float)n;
-        const float T = (16.f * (sqrtf(rho2) + 17.f * E) + 17.f * nf * E) / (1.f - sigma);
+        // sum over the n sweeps of |y_t| (re-derived with the per-block growth term outside the 1 / (1 - sigma) factor): at block
+        // boundaries Y_m <= sigma^m rho + 16 E / (1 - sigma), inside a block |y| <= Y_m + j E (j = 0..15: 120 E per block = 7.5 E per sweep)
+        const float T = fmaf(16.f, fmaf(nf, E, sqrtf(rho2)) / (1.f - sigma), 8.f * nf * E);
         bool ok = sigma < 0.9f && T >= 0.f;          // (a NaN anywhere fails one of the comparisons below)
         PBRE_UNROLL for (int c = 0; c < NK; c++) {
             const bool used = dinv[c][0] != 0.f;
@@ -1044,8 +1046,10 @@ struct Fast {
                 // with y = x - x~ (x~: the closed form's own result, the system's solution up to rounding), a row maps y to
                 // P_r y + eta_r J_r, eta_r = the row's delta at x~ (0 for a consistent system), so |y| grows by at most E = sum |eta_r| |J_r|
                 // per sweep and contracts by sigma = |S^16|_F < 1 per 16 sweeps; a row's delta is eta_r - (J_r.y) / |J_r|^2, at most
-                // |eta_r| + |y| in size (|J_r| >= 1: its linear part is a unit vector).  Summed over the N sweeps an applied impulse
-                // therefore moves by at most  mov_r = N |eta_r| + T,  T = (16 (rho + 17 E) + 17 N E) / (1 - sigma),  rho = |x_K - x~|,
+                // |eta_r| + |y| in size (|J_r| >= 1: its linear part is a unit vector).  With rho = |x_K - x~|: at the 16-sweep block
+                // boundaries |y| <= Y_m = sigma^m rho + 16 E / (1 - sigma), inside a block |y| <= Y_m + j E (j = 0..15), so the sum of |y|
+                // over the N sweeps is at most 16 rho / (1 - sigma) + 16 N E / (1 - sigma) + 7.5 N E, and an applied impulse moves by at
+                // most  mov_r = N |eta_r| + T,  T = 16 (rho + N E) / (1 - sigma) + 8 N E,
                 // from its value after the explicit sweeps.  If every normal impulse stays positive (app_n - mov_n > 0) and every friction
                 // impulse inside its cone (|app_f| + mov_f <= mu (app_n - mov_n)) under these bounds -- doubled, for the rounding of the
                 // bound itself -- no clamp binds and the closed form IS the sequence of rows up to rounding; a lane that fails (cube

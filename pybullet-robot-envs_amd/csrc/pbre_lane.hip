@@ -25,12 +25,18 @@
 // stream of the highest priority, and waits for nothing, so the bound is not reached; a quad that does reach it goes on and the env-step is
 // counted by the NaN / Inf guard's counter.
 #define PBRE_IK_STORE(done, p, v) do { if (done) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(p) = (v); } while (0)
+// (the workgroup-scope fence alone emitted no wait, so mark and targets -- different addresses, possibly different L2 channels -- could
+// become visible to another XCD in either order.  The targets are write-through sc1 stores: vmcnt(0) returns once they have reached the
+// coherence point, and only then is the mark stored.  No L2 write-back is involved, which is what the agent-scope release cost.)
 #define PBRE_IK_PUBLISH(done, seq) do { if (done) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         __hip_atomic_store((done), (seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
-#define PBRE_IK_WAIT(flag, seq, bad) do { int spins_ = 0; \
+// A wait that reaches its bound POISONS the env: `to` becomes true, quad_step stores NaN joint positions, and the NaN / Inf guard in
+// kw_fin returns the env-step as done = 1 / reward 0, restarts the env under PBRE_F_AUTO_RESET and counts it once (pbre_kernel_info[12]).
+#define PBRE_IK_WAIT(flag, seq, to) do { int spins_ = 0; \
         while (__hip_atomic_load((flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (seq)) { \
             __builtin_amdgcn_s_sleep(8); \
-            if (++spins_ > (1 << 22)) { if (bad) atomicAdd((bad), 1); break; } } \
+            if (++spins_ > (1 << 22)) { (to) = true; break; } } \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define PBRE_LANE_MSTRIDE 64         // M^-1 in wave-private LDS, [entry][lane]
 #ifndef PBRE_LANE_MREG
@@ -188,6 +194,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     }
     // ---- unconstrained velocities v* = qd + dt M^-1 tau, motor rows against the running velocity, limit rows (see Lane::step)
     float w[QD], w0[QD], m_dinv[QD], m_rhs[QD], sabs[QD], l_dir[QD], l_rhs[QD], l_app[QD];
+    bool ik_timeout = false;            // PBRE_IK_WAIT reached its bound: the env-step goes to the NaN / Inf guard
     unsigned long long lim_b[QD];
     {
         float acc[QD];
@@ -197,7 +204,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
             PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = fmaf(A[i][c], tc, acc[i]);
         }
         // Cartesian control: this env's IK targets are read next -- wait for ITS mark (the IK kernel runs beside this one)
-        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, P.bad_count);
+        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, ik_timeout);
         PBRE_UNROLL for (int i = 0; i < QD; i++) {
             const int d = d0 + i;
             const float wj = fminf(fmaxf(fmaf(dt, acc[i], qd[i]), -vmax), vmax);
@@ -421,7 +428,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     // ---- integrate the joints (semi-implicit Euler)
     PBRE_UNROLL for (int i = 0; i < QD; i++) {
         const float v = fminf(fmaxf(w[i], -vmax), vmax);
-        st[W + d0 + i] = v; st[d0 + i] = fmaf(dt, v, q[i]);
+        st[W + d0 + i] = v; st[d0 + i] = ik_timeout ? __builtin_nanf("") : fmaf(dt, v, q[i]);
     }
     if (RC && r == 0) {      // the object's twist after the coupled solve, for kw_fin
         float o[6];

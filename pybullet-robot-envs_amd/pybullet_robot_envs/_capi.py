@@ -77,7 +77,7 @@ def load(path=None):
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
                  "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot", "pbre_get_sweeps",
-                 "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info", "pbre_scatter_actions_device"):
+                 "pbre_comm_probe", "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info", "pbre_scatter_actions_device"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_comm_last_error.restype = C.c_char_p
     lib.pbre_comm_last_error.argtypes = [C.c_void_p]
@@ -256,6 +256,16 @@ class Engine:
                                             C.c_void_p(stream or 0)))
 
     # ---- the sharded batch's gather, owned by the context (include/pbre.h: pbre_comm_*; csrc/pbre_comm.hip) ----
+    @staticmethod
+    def comm_probe(lib=None, rccl_lib=None):
+        """any rank: raises unless the RCCL library loads and exports every entry point the exchanges use (no ncclGetUniqueId: that starts
+        a bootstrap thread and a listening socket, which only rank 0 needs)"""
+        _set_rccl_lib(rccl_lib)
+        lib = lib or load()
+        rc = lib.pbre_comm_probe()
+        if rc != 0:
+            raise RuntimeError("pbre_comm_probe failed (%d): %s" % (rc, lib.pbre_comm_last_error(None).decode()))
+
     @staticmethod
     def comm_unique_id(lib=None, rccl_lib=None):
         """rank 0: the 128-byte id every rank's comm_init needs.  rccl_lib: path of the RCCL library to dlopen (default: torch's bundled

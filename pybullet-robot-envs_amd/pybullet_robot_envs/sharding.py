@@ -149,13 +149,16 @@ class CtxGatherPipeline(object):
         self.torch, self.sh, self.dev = torch, sharded, device
         eng = sharded.engine
         n, w = sharded.n_local, sharded.world
-        # Setup is failure-SYMMETRIC: every rank probes that the RCCL library loads (pbre_comm_unique_id dlopens it) and the ranks agree on
+        # Setup is failure-SYMMETRIC: every rank probes that the RCCL library loads (rank 0: pbre_comm_unique_id, the others: pbre_comm_probe) and the ranks agree on
         # the outcome before anything blocking -- a rank that failed alone (rank 0 before its broadcast, any rank before the collective
         # ncclCommInitRank) would leave the others waiting in a collective it never joins.  Either every rank has a communicator on
         # return or every rank raises (and the caller falls back to torch.distributed's gather on all of them).
         uid, err = None, None
         try:
-            uid = _capi.Engine.comm_unique_id(eng.lib, rccl_lib)       # (ranks other than 0 discard theirs)
+            if sharded.rank == 0:
+                uid = _capi.Engine.comm_unique_id(eng.lib, rccl_lib)
+            else:
+                _capi.Engine.comm_probe(eng.lib, rccl_lib)             # (load probe only: ncclGetUniqueId starts a bootstrap thread + socket)
         except Exception as e:
             err = repr(e)
         if not self._all_ok(err is None):

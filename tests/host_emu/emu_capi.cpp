@@ -475,6 +475,7 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
 // the context-owned exchanges of the sharded batch: the SAME source as the product's (csrc/pbre_comm_impl.hpp) on a host runtime -- host
 // buffers, no streams, everything synchronous.  With tests/fake_rccl as PBRE_RCCL_LIB the world > 1 branch of pbre_step_gather_device /
 // pbre_scatter_actions_device runs between the processes of a CPU test (tests/test_comm_fake_rccl.py).
+int pbre_comm_probe(void) { return EmuComm::probe(); }
 int pbre_comm_unique_id(void* id) { return EmuComm::unique_id(id); }
 int pbre_comm_init(pbre_ctx* c, const void* id, int32_t rank, int32_t world) { return EmuComm::init(c, id, rank, world); }
 int pbre_step_gather_device(pbre_ctx* c, const float* a, float* rl, float* ra, void* s) { return EmuComm::step_gather(c, a, rl, ra, s); }

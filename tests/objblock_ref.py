@@ -44,8 +44,8 @@ def sweep(J, beta, mu, x, app, active, record=None):
         x += dd * J[i]
 
 
-def bound_holds(J, beta, mu, x_k, app, active, n):
-    """Fast::obj_closed's test in fp64: (closed-form result, holds?)"""
+def bound_holds(J, beta, mu, x_k, app, active, n, details=False):
+    """Fast::obj_closed's test in fp64: (closed-form result, holds?); details: also (eta, T, sigma, E), the pieces of mov_r = n eta_r + T"""
     S = np.eye(6); s = np.zeros(6)
     for i in range(12):
         c = i if i < 4 else (i - 4) // 2
@@ -66,8 +66,8 @@ def bound_holds(J, beta, mu, x_k, app, active, n):
         eta[i] = abs(beta[i] - (J[i] @ xt) / (J[i] @ J[i]))
         E += eta[i] * np.sqrt(1.0 + J[c][3] ** 2 + J[c][4] ** 2 + J[4 + 2 * c][3] ** 2)      # |J_r| <= sqrt(1 + |r'|^2)
     if not sig < 0.9:
-        return xt, False
-    T = (16 * (rho + 17 * E) + 17 * n * E) / (1 - sig)
+        return (xt, False, None) if details else (xt, False)
+    T = 16 * (rho + n * E) / (1 - sig) + 8 * n * E
     ok = True
     for c in range(4):
         if not active[c]:
@@ -77,4 +77,6 @@ def bound_holds(J, beta, mu, x_k, app, active, n):
         for i in (4 + 2 * c, 5 + 2 * c):
             okc = okc and abs(app[i]) + 2 * (n * eta[i] + T) <= mu * nmin
         ok = ok and okc
+    if details:
+        return xt, ok, (eta, T, sig, E)
     return xt, ok

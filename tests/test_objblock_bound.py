@@ -75,3 +75,46 @@ def test_bound_implies_no_clamp_in_the_remaining_sweeps():
     assert held["rest"][1] > 200, held                       # the resting cubes take the closed form (the rest: a vertex just outside the slop)
     assert held["press"][1] > 200, held
     assert held["slide"][0] > 50 and held["slide"][1] > 20 and held["rock"][0] > 20 and held["lift"][0] > 20, held      # ... and the bound does reject
+
+
+def test_impulse_movement_bound_with_small_sigma_and_large_residuals():
+    """the inequality the test above rests on -- over n UNCLAMPED sweeps a row's applied impulse moves by at most
+    n |eta_r| + T from its value after the explicit sweeps -- checked directly where the old T = (16 (rho + 17 E) + 17 n E) / (1 - sigma)
+    was too small: well-conditioned blocks (sigma near 0) with INCONSISTENT right-hand sides (large E: the rows' deltas at the closed form's
+    result do not vanish, each sweep moves every impulse by about eta_r for ever)."""
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    for case in range(300):
+        # short lever arms make the 12 rows nearly orthogonal triples: S^16 is tiny
+        r = rng.normal(0, 1, (4, 3)) * 10 ** rng.uniform(-1.5, 0.5)
+        J = ob.rows_of(r)
+        active = np.ones(4, bool)
+        beta = rng.normal(0, 1, 12) * 10 ** rng.uniform(-3, 0)          # friction rows with a right-hand side too: as inconsistent as it gets
+        beta[4:] *= rng.choice([0.0, 1.0])
+        x = rng.normal(0, 1, 6)
+        free = lambda xx, aa: _free_sweep(J, beta, xx, aa)
+        app = np.zeros(12)
+        for _k in range(K):
+            free(x, app)
+        xt, _ok, det = ob.bound_holds(J, beta, 1.0, x.copy(), app.copy(), active, N, details=True)
+        if det is None:
+            continue
+        eta, T, sig, E = det
+        moved = np.zeros(12)
+        for _k in range(N):
+            before = app.copy()
+            free(x, app)
+            moved += np.abs(app - before)
+        bound = N * eta + T
+        assert (moved <= bound * (1 + 1e-9) + 1e-12).all(), (case, sig, E, (moved / np.maximum(bound, 1e-300)).max())
+        worst = max(worst, (moved / np.maximum(bound, 1e-300)).max())
+    print("largest moved / bound:", worst)
+    assert worst > 0.02, "the cases do exercise the bound (measured: 0.046 -- the triangle inequalities over 12 rows x 128 sweeps are not tight)"
+
+
+def _free_sweep(J, beta, x, app):
+    for i in range(12):
+        dinv = 1.0 / (J[i] @ J[i])
+        d = beta[i] - dinv * (J[i] @ x)
+        app[i] += d
+        x += d * J[i]
