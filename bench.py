@@ -485,15 +485,23 @@ def main():
             # event pairs around every EV_EVERY-th (8th) step only: an event record is a barrier packet on the stream, and a pair per step
             # costs ~10% of the 0.2 ms kernel it brackets
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if events else None
+            # one HIP event pair around the WHOLE region on the stream the step kernels are launched on (`side` is torch's current stream):
+            # a step is one launch and launches follow each other without a gap (profiles/r05_step_kernels.txt), so span / steps is the
+            # dominant kernel's average launch duration over exactly the steps `ms_per_step` is the wall time of -- the same statistic,
+            # and never longer than the step (roofline.kernel_ms must not exceed ms_per_step)
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            r0.record(side)
             for k in range(steps):
                 self.step(evs[k] if (events and k % EV_EVERY == 0) else None)
+            r1.record(side)
             self.drain()
             barrier()
             elapsed = time.perf_counter() - t0
+            torch.cuda.synchronize()
             pair = float(np.mean([a.elapsed_time(b) for a, b in evs[::EV_EVERY]])) if events else 0.0
-            el, pr = max_over_ranks([elapsed, pair])
-            return {"value": self.total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "_elapsed": el, "_pair_ms": pr}
+            el, pr, dev_ms = max_over_ranks([elapsed, pair, r0.elapsed_time(r1) / steps])
+            return {"value": self.total * steps / el, "unit": "env-steps/s", "ms_per_step": el / steps * 1e3, "_elapsed": el, "_pair_ms": pr, "_dev_ms": dev_ms}
 
         def complex_frac(self):
             return self.eng.kernel_info()[5] / float(self.n_local)
@@ -559,7 +567,9 @@ def main():
     head = job.timed(args.steps, args.warmup, events=True)
     complex_per_step = ((eng.kernel_info()[7] - csum0) % (1 << 31)) / float(args.steps + args.warmup)
     # (side key) the same timed region five more times, back to back, without event pairs: the spread of the headline on this box
-    rep = [head["ms_per_step"]] + [job.timed(args.steps, 0)["ms_per_step"] for _ in range(5)]
+    regions = [head] + [job.timed(args.steps, 0) for _ in range(5)]
+    rep = [r["ms_per_step"] for r in regions]
+    region_dev_ms = float(np.median([r["_dev_ms"] for r in regions]))      # device time per launch: median over the same six regions as `ms_per_step`
     repeats = {"ms_per_step": {"median": float(np.median(rep)), "min": float(np.min(rep)), "max": float(np.max(rep))}, "samples": len(rep),
                "value_at_median": total * 1e3 / float(np.median(rep)),
                "note": "six timed regions of exactly --steps steps each on the same stationary batch, back to back (sample 0 with HIP event pairs around every 8th step); `value` is the median's"}
@@ -575,7 +585,11 @@ def main():
     done_frac = float(job.pipe.out[(job.pipe.k - 1) & 1][:, -1].mean())
     # the dominant kernel alone: mean of the HIP event pairs the library records around it on its stream -- round 5: the step IS one kernel
     # (k_fused: the complex envs' row waves and the simple envs' waves in one grid), so this is the step's device time without launch gaps
-    kern_ms = float(eng.timing()[3])
+    kern_ms_sampled = float(eng.timing()[3])
+    fused_now = eng.kernel_info()[13] > 0
+    # one launch per step: the launch duration is the region's device span / steps (same regions, same median as `ms_per_step`); the two-kernel
+    # step (PBRE_FUSED=0) keeps the library's sampled pairs around k_fast
+    kern_ms = region_dev_ms if fused_now else kern_ms_sampled
     info = eng.kernel_info()
     episodes = float(torch.as_tensor(eng.get_state()[:, eng.x_off + 5]).mean()) if rank == 0 else 0.0
     # (side key, SURVEY section 5 "metrics": contact-count histogram) which contact kinds the envs of the stationary batch are in, from the
@@ -636,9 +650,25 @@ def main():
                 eng.step(acts[k % 4], copy=False)
             el = time.perf_counter() - t0
             ms = eng.timing()
-            host = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3,
-                    "h2d_ms": ms[0], "kernels_ms": ms[1], "d2h_ms": ms[2],
-                    "note": "SURVEY 8(d) literal metric: Engine.step(), numpy actions in, [obs|reward|done] rows out through page-locked host buffers (PCIe-bound); never `value`, which is device-resident stepping (pbre_step_device)"}
+            sync = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3, "h2d_ms": ms[0], "kernels_ms": ms[1], "d2h_ms": ms[2],
+                    "note": "Engine.step(): one step at a time, host-synchronous (zero-copy: the kernels reach over PCIe themselves)"}
+            # round 6: the same metric PIPELINED (pbre_step_async / pbre_step_wait: upload, kernels and download of consecutive steps on three
+            # streams, two steps in flight) -- an open loop, like `value`; the floor is the row download over PCIe
+            ns = 40
+            eng.step_async(acts[0])
+            for k in range(1, 4):
+                eng.step_async(acts[k % 4]); eng.step_wait()
+            t0 = time.perf_counter()
+            for k in range(ns):
+                eng.step_async(acts[k % 4]); eng.step_wait()
+            el = time.perf_counter() - t0
+            eng.step_wait()
+            row_mb = n_local * (eng.obs_dim + 2) * 4 / 1e6
+            host = {"value": n_local * ns / el, "unit": "env-steps/s", "ms_per_step": el / ns * 1e3,
+                    "rows_MB_per_step": row_mb, "d2h_GBps_if_download_bound": row_mb / (el / ns * 1e3),
+                    "synchronous": sync,
+                    "note": "SURVEY 8(d) literal metric: numpy actions in page-locked memory in, [obs|reward|done] rows out, upload + kernels + download, pipelined over "
+                            "calls (Engine.step_async / step_wait, open loop, two steps in flight); never `value`, which is device-resident stepping (pbre_step_device)"}
         except Exception as e:
             host = {"error": repr(e)}
     del job
@@ -769,14 +799,22 @@ def main():
             "host_inclusive": host,      # SURVEY 8(d) literal: upload + kernels + download through the host-buffer entry point; `value` is device-resident stepping
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
-                         "kernel": dom_kernel, "kernel_ms": kern_ms, "step_launch_pair_ms": head["_pair_ms"],
+                         "kernel": dom_kernel, "kernel_ms": kern_ms, "kernel_ms_sampled_pairs_mean": kern_ms_sampled, "step_launch_pair_ms": head["_pair_ms"],
+                         "kernel_ms_note": "HIP event pair around each timed region on the launch stream / steps, median of the six regions `ms_per_step` is the median of "
+                                           "(one launch per step, no gaps: the launch's average duration); kernel_ms_sampled_pairs_mean = the library's event pairs around every 8th launch",
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n_local,
                          "note": "path is fp32-VALU issue bound (%.0f FLOP per algorithmic byte against a machine balance of ~20 FLOP/B); the HBM "
                                  "fraction is small by construction, see valu" % (ALG_FLOP_PER_ENV_STEP / ALG_BYTES_PER_ENV_STEP)},
             "valu": {"achieved": ach_tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_VALU_PEAK_TFLOPS,
-                     # the 157.3 TF peak assumes v_pk_fma_f32 at full rate; measured on this chip (profiles/r01_ubench_pkfma.txt) a
-                     # packed FMA takes ~2 passes, so the scalar-FMA peak (78.6 TF) is the practical ceiling of fp32 FMA code
-                     "peak_scalar_fma": FP32_VALU_PEAK_TFLOPS / 2, "frac_scalar_fma": ach_tf / (FP32_VALU_PEAK_TFLOPS / 2),
+                     # round 6 (profiles/r06_ubench_valu.txt, tools/ubench/valu_rate.hip): a SIMD issues a wave64 v_fma_f32 / v_mul / v_add whose
+                     # operands are VGPRs on distinct banks every 2.2 cycles from >= 2 waves (135-138 TF measured, the spec's 157.3 TF is 2.0),
+                     # v_pk_fma_f32 every 4.2-4.4 (the same FLOP rate); an SGPR / constant operand, v_max, v_fmac or a repeated VGPR operand make it
+                     # 4.1-4.4 cycles; ONE wave issues at most one VALU instruction per 4.45-5 cycles (8.25 when it depends on the previous one).
+                     # Rounds 1-5 priced against "78.6 TF scalar-FMA peak" from a 64-thread-workgroup wall-clock benchmark of SGPR-operand FMAs.
+                     "peak_measured_fma": 138.0, "frac_measured_fma": ach_tf / 138.0,
+                     "issue_model": {"simd_cycles_per_wave_instr_best": 2.2, "simd_cycles_per_wave_instr_sgpr_operand_or_packed": 4.3,
+                                     "lone_wave_cycles_per_instr_independent": 4.45, "lone_wave_cycles_per_instr_dependent": 8.25,
+                                     "source": "profiles/r06_ubench_valu.txt"},
                      "flop_per_env_step": ALG_FLOP_PER_ENV_STEP, "sq_counters": sq, "vgprs_k_fast": info[0], "vgprs_k_fast_rc": info[6], "vgprs_k_step": info[1]},
         }
         if world == 1 and not args.no_other_configs:

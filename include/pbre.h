@@ -55,7 +55,7 @@ enum { PBRE_ROBOT_PANDA_ARM = 3,   /* pbre_default_config only: the Panda with t
        PBRE_ROBOT_ICUB_HANDS = 2 };   /* icub_model_with_hands.sdf (R/envs/icub_envs/icub_env_with_hands.py): robot-level interface --
                                      absolute joint / hand-pose commands, persistent finger motors (pbre_set_motors), fingertip
                                      contact forces appended to the observation */
-enum { PBRE_SHAPE_BOX = 0, PBRE_SHAPE_SPHERE = 1, PBRE_SHAPE_CYLINDER = 2 };   /* pbre_physics.obj_shape (reference world_env.py:18-25, 179-216: obj_name) */
+enum { PBRE_SHAPE_BOX = 0, PBRE_SHAPE_SPHERE = 1, PBRE_SHAPE_CYLINDER = 2, PBRE_SHAPE_HULL = 3 };   /* pbre_physics.obj_shape (reference world_env.py:18-25, 179-216: obj_name) */
 enum { PBRE_TASK_REACH = 0, PBRE_TASK_PUSH = 1,
        PBRE_TASK_PUSH_GOAL = 2 };   /* pandaPushGymGoalEnv termination/reward (R/envs/panda_envs/panda_push_gym_goal_env.py:89-122) */
 enum { PBRE_F_NO_OBJECT = 1,      /* object frozen and contact-free (BASELINE config 2) */
@@ -186,6 +186,17 @@ int pbre_reset_snapshot(pbre_ctx* ctx, const uint8_t* env_mask, float* obs_out);
  * out: host [num_envs][obs_dim+2] float32 = raw observation | reward | done.  Synchronous. */
 int pbre_step(pbre_ctx* ctx, const float* actions, float* out);
 
+/* The same step PIPELINED across calls (round 6; SURVEY 8(d)'s metric counts upload + kernels + download): pbre_step_async enqueues the
+ * upload of `actions`, the step and the download of its rows into `out` on three streams and returns; pbre_step_wait blocks until the
+ * rows of the OLDEST step not yet waited for are in `out`.  At most two steps may be in flight: in an open loop
+ *     pbre_step_async(a[0], out[0]);  for t = 1..: { pbre_step_async(a[t], out[t & 1]); pbre_step_wait(); consume out[(t - 1) & 1]; }
+ * the download of step t - 1 (the PCIe floor: num_envs x (obs_dim + 2) x 4 bytes) overlaps the kernels of step t and the upload of the
+ * actions of step t + 1.  Both host buffers must be page-locked (pbre_host_alloc) for the copies to be asynchronous, and stay untouched
+ * until the step's pbre_step_wait returns.  Rows are bit-equal to pbre_step's.  Any host-synchronous entry point (pbre_get_state, ...)
+ * also completes every step in flight (their pbre_step_wait calls then return at once).  Panda task envs; PBRE_E_UNSUPPORTED elsewhere. */
+int pbre_step_async(pbre_ctx* ctx, const float* actions, float* out);
+int pbre_step_wait(pbre_ctx* ctx);
+
 /* Same with device-resident buffers (HIP device pointers on ctx's GPU) enqueued on `stream`; asynchronous.  For
  * device-resident policies (replaces the stable-baselines DummyVecEnv hop, R/examples/algos/train/.../train_ddpg_reaching.py:96).
  * stream: a hipStream_t.  The step reads d_actions and writes d_out in stream order on THAT stream, so work that produced the
@@ -250,6 +261,23 @@ int pbre_set_motor_state(pbre_ctx* ctx, const float* motors);
  * episodes; batch-uniform).  The object must stay a cube (isotropic inertia) for the lane-per-env kernels. */
 int pbre_set_physics(pbre_ctx* ctx, const pbre_physics* phys);
 int pbre_get_physics(const pbre_ctx* ctx, pbre_physics* phys);
+
+/* The object as a CONVEX HULL (replaces what p.loadURDF / p.loadSDF do with the mesh objects of WorldEnv, YcbWorldEnv and
+ * SqWorldEnv -- duck_vhacd, teddy_vhacd, the YCB and superquadric models, R/envs/world_envs/world_env.py:18-25, 61-84, 179-216: Bullet
+ * collides the pieces of such a convex decomposition as btConvexHullShape).  verts: host [n_verts][3] float64, the hull's vertices in the
+ * object's frame (origin = centre of mass), 4 <= n_verts <= PBRE_HULL_MAXV; they should be the extreme points of their hull (a point
+ * inside it is accepted and is then a contact candidate like any other).  The library derives the hull's faces itself (<= PBRE_HULL_MAXF
+ * triangles; coplanar vertices form one polygonal face).  Narrow phase: against the table / ground the PBRE_NC_OT = 4 deepest vertices
+ * within the contact margin, in vertex order (the box primitive's rule over its 8 vertices: a box given as its 8 vertices in the box's
+ * vertex order v = (x > 0) + 2 (y > 0) + 4 (z > 0) reproduces PBRE_SHAPE_BOX); against a robot link's collision sphere the closest
+ * point of the hull's surface (exact: nearest face, edge or vertex), or -- centre inside -- the nearest face plane.
+ * On success pbre_physics.obj_shape becomes PBRE_SHAPE_HULL and obj_h the half extents of the hull's bounding box; mass, inertia and
+ * friction stay what pbre_physics says (obj_inertia: principal inertias about the object's axes).  A scene change like any other: the
+ * settled snapshot is stale until the next full pbre_reset.  Hull objects are stepped by the general 16-/32-/64-lane row kernels of
+ * every engine (the lane-per-env fast paths are compiled for the primitives).  pbre_set_physics with another obj_shape drops the hull;
+ * with PBRE_SHAPE_HULL it keeps it.  PBRE_E_ARG: bad count, non-finite or degenerate (flat) vertex set, more faces than PBRE_HULL_MAXF. */
+enum { PBRE_HULL_MAXV = 32, PBRE_HULL_MAXF = 64 };
+int pbre_set_object_hull(pbre_ctx* ctx, const double* verts, int32_t n_verts);
 /* pbre_physics.solver_residual_threshold > 0: the number of sweeps every env's solver ran in the most recent simulation step
  * (1..solver_iters; solver_iters when the test never fired), host [num_envs] int32.  PBRE_E_UNSUPPORTED while the threshold is 0. */
 int pbre_get_sweeps(pbre_ctx* ctx, int32_t* sweeps);

@@ -469,6 +469,109 @@ static real sphere_shape(int shape, const real* sc, real sr, const real* bc, con
     return dist;
 }
 
+/* ---- convex-hull object (obj_shape 3; SURVEY 8(f4): duck_vhacd / teddy_vhacd / the YCB meshes of world_env.py:18-25, 179-216 are convex
+ * decompositions whose pieces Bullet collides as btConvexHullShape).  The hull is given by its vertices alone.  This restatement is
+ * deliberately the brute-force definition, not the engine's face table: the closest point of the hull to an outside point is the
+ * closest point of the nearest triangle spanned by ANY three hull vertices (every such triangle lies inside the hull, and the surface
+ * is made of such triangles); a point is inside iff it is behind every SUPPORTING plane (a plane through three vertices with all other
+ * vertices on one side), and then leaves through the nearest of them -- the same inside rule as the box and the cylinder above.
+ * The supporting planes are found once per vertex set (O(n^4)) and cached per thread. */
+typedef struct { int n; double v[ORC_MAXHV][3]; int np; double (*pl)[4]; } hull_cache_t;
+static __thread hull_cache_t g_hull;
+static void hull_planes(const orc_params* prm) {
+    const int n = prm->obj_hull_n;
+    if (g_hull.n == n && g_hull.pl && memcmp(g_hull.v, prm->obj_hull, sizeof(double) * 3 * n) == 0) return;
+    free(g_hull.pl);
+    g_hull.n = n; memcpy(g_hull.v, prm->obj_hull, sizeof(double) * 3 * n);
+    g_hull.pl = (double (*)[4])malloc(sizeof(double) * 4 * (size_t)(n * n * n / 6 + 8));
+    g_hull.np = 0;
+    double scale = 0;
+    for (int i = 0; i < n; i++) for (int k = 0; k < 3; k++) if (fabs(prm->obj_hull[i][k]) > scale) scale = fabs(prm->obj_hull[i][k]);
+    const double eps = 1e-9 * (scale > 0 ? scale : 1);
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) for (int k = j + 1; k < n; k++) {
+        const double* a = prm->obj_hull[i]; const double* b = prm->obj_hull[j]; const double* c = prm->obj_hull[k];
+        const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, w[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+        double nn[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+        const double len = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        if (len < 1e-12 * (scale > 0 ? scale * scale : 1)) continue;        /* collinear */
+        for (int t = 0; t < 3; t++) nn[t] /= len;
+        int pos = 0, neg = 0;
+        for (int l = 0; l < n; l++) {
+            const double d = nn[0] * (prm->obj_hull[l][0] - a[0]) + nn[1] * (prm->obj_hull[l][1] - a[1]) + nn[2] * (prm->obj_hull[l][2] - a[2]);
+            if (d > eps) pos++; else if (d < -eps) neg++;
+        }
+        if (pos && neg) continue;                                          /* cuts through the hull */
+        const double sg = pos ? -1.0 : 1.0;                                  /* outward: every other vertex behind the plane */
+        double* q = g_hull.pl[g_hull.np++];
+        q[0] = sg * nn[0]; q[1] = sg * nn[1]; q[2] = sg * nn[2]; q[3] = q[0] * a[0] + q[1] * a[1] + q[2] * a[2];
+    }
+}
+/* closest point of triangle abc to p (Ericson, Real-Time Collision Detection 5.1.5; degenerate triangles fall through to their edges) */
+static void closest_on_triangle(const double* p, const double* a, const double* b, const double* c, double* out) {
+    double ab[3], ac[3], ap[3];
+    for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; }
+#define D3(x, y) ((x)[0] * (y)[0] + (x)[1] * (y)[1] + (x)[2] * (y)[2])
+    const double d1 = D3(ab, ap), d2 = D3(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { for (int k = 0; k < 3; k++) out[k] = a[k]; return; }
+    double bp[3]; for (int k = 0; k < 3; k++) bp[k] = p[k] - b[k];
+    const double d3 = D3(ab, bp), d4 = D3(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { for (int k = 0; k < 3; k++) out[k] = b[k]; return; }
+    const double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); for (int k = 0; k < 3; k++) out[k] = a[k] + v * ab[k]; return; }
+    double cp[3]; for (int k = 0; k < 3; k++) cp[k] = p[k] - c[k];
+    const double d5 = D3(ab, cp), d6 = D3(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { for (int k = 0; k < 3; k++) out[k] = c[k]; return; }
+    const double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); for (int k = 0; k < 3; k++) out[k] = a[k] + w * ac[k]; return; }
+    const double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int k = 0; k < 3; k++) out[k] = b[k] + w * (c[k] - b[k]);
+        return;
+    }
+    const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+    for (int k = 0; k < 3; k++) out[k] = a[k] + ab[k] * v + ac[k] * w;
+#undef D3
+}
+static real sphere_hull(const orc_params* prm, const real* sc, real sr, const real* bc, const real* Rb, real* n, real* pb) {
+    hull_planes(prm);
+    const int nv = prm->obj_hull_n;
+    real d[3], dl[3];
+    for (int k = 0; k < 3; k++) d[k] = sc[k] - bc[k];
+    m3T_v(Rb, d, dl);
+    const double p[3] = {(double)dl[0], (double)dl[1], (double)dl[2]};
+    /* inside: behind every supporting plane */
+    int inside = 1, best = -1; double depth = 1e300;
+    for (int f = 0; f < g_hull.np; f++) {
+        const double sd = g_hull.pl[f][0] * p[0] + g_hull.pl[f][1] * p[1] + g_hull.pl[f][2] * p[2] - g_hull.pl[f][3];
+        if (sd > 0) { inside = 0; break; }
+        if (-sd < depth) { depth = -sd; best = f; }
+    }
+    real nl[3], cl[3], dist;
+    if (inside && best >= 0) {
+        for (int k = 0; k < 3; k++) { nl[k] = (real)g_hull.pl[best][k]; cl[k] = (real)(p[k] + depth * g_hull.pl[best][k]); }
+        dist = (real)(-depth) - sr;
+    } else {
+        double bd2 = 1e300, bcp[3] = {0, 0, 0};
+        for (int i = 0; i < nv; i++) for (int j = i + 1; j < nv; j++) for (int k = j + 1; k < nv; k++) {
+            double cp[3];
+            closest_on_triangle(p, prm->obj_hull[i], prm->obj_hull[j], prm->obj_hull[k], cp);
+            const double e[3] = {p[0] - cp[0], p[1] - cp[1], p[2] - cp[2]};
+            const double d2 = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            if (d2 < bd2) { bd2 = d2; for (int t = 0; t < 3; t++) bcp[t] = cp[t]; }
+        }
+        const double len = sqrt(bd2);
+        if (len < 1e-12) { nl[0] = 0; nl[1] = 0; nl[2] = 1; }          /* on the surface to rounding: any normal; distance -sr */
+        else for (int k = 0; k < 3; k++) nl[k] = (real)((p[k] - bcp[k]) / len);
+        for (int k = 0; k < 3; k++) cl[k] = (real)bcp[k];
+        dist = (real)len - sr;
+    }
+    m3_v(Rb, nl, n);
+    real t[3]; m3_v(Rb, cl, t);
+    for (int k = 0; k < 3; k++) pb[k] = bc[k] + t[k];
+    return dist;
+}
+
 /* The object's candidate contact points against its support surface, as offsets from its centre in WORLD axes (8 slots; returns 0 for
  * a slot the shape does not use).  box: the 8 vertices.  sphere: the lowest point.  cylinder: per cap three rim points at 0 / 120 /
  * 240 degrees (slots 0-2 bottom cap, 4-6 top cap; an upright can stands on a tripod) and the rim's lowest point (slots 3 / 7: the
@@ -612,10 +715,15 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
         for (int k = 0; k < 3; k++) sc[s][k] = w->pw[m->s_link[s]][k] + t[k];
     }
     if (obj_on) {
-        cand_t c[8];
-        for (int v = 0; v < 8; v++) {
+        /* (hull: every vertex is a candidate; the ORC_NC_OT deepest within the margin become the contact points, in vertex order -- the
+         * box's rule over its 8 vertices) */
+        const int ncand = prm->obj_shape == 3 ? prm->obj_hull_n : 8;
+        cand_t c[ORC_MAXHV];
+        for (int v = 0; v < ncand; v++) {
             real x[3];
-            const int used = shape_candidate(prm->obj_shape, oh, Ro, v, x);
+            int used;
+            if (prm->obj_shape == 3) { real l[3] = {(real)prm->obj_hull[v][0], (real)prm->obj_hull[v][1], (real)prm->obj_hull[v][2]}; m3_v(Ro, l, x); used = 1; }
+            else used = shape_candidate(prm->obj_shape, oh, Ro, v, x);
             if (!used) { x[0] = 0; x[1] = 0; x[2] = (real)1e6; }      /* unused slot: far above any support */
             for (int k = 0; k < 3; k++) x[k] += op[k];
             real hs = support_height(prm, x);
@@ -623,11 +731,12 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
             for (int k = 0; k < 3; k++) { c[v].pA[k] = x[k]; c[v].pB[k] = x[k]; }
             c[v].pB[2] = hs; c[v].link = -1; c[v].mu = (real)(prm->obj_mu * prm->table_mu);
         }
-        n_ot = select_contacts(c, 8, ORC_NC_OT, margin, sel);
+        n_ot = select_contacts(c, ncand, ORC_NC_OT, margin, sel);
         cand_t cs[ORC_MAXS];
         for (int s = 0; s < m->ns; s++) {
             cs[s].idx = s; cs[s].link = m->s_link[s]; cs[s].mu = (real)(m->s_mu[s] * prm->obj_mu);
-            cs[s].dist = sphere_shape(prm->obj_shape, sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
+            cs[s].dist = prm->obj_shape == 3 ? sphere_hull(prm, sc[s], m->s_r[s], op, Ro, cs[s].n, cs[s].pB)
+                                             : sphere_shape(prm->obj_shape, sc[s], m->s_r[s], op, Ro, oh, cs[s].n, cs[s].pB);
             for (int k = 0; k < 3; k++) cs[s].pA[k] = cs[s].pB[k] + cs[s].n[k] * cs[s].dist;
         }
         n_ro = select_contacts(cs, m->ns, nc_ro, margin, sel + n_ot);

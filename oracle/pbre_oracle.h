@@ -40,6 +40,7 @@ typedef double real;
 #define ORC_NTIP 5       /* fingertips of the controlled hand (icub_env_with_hands.py:248) */
 #define ORC_STATE 48     /* floats per env state record of a <= 9-DoF robot (see include/pbre.h) */
 #define ORC_MAXACT 64    /* controlled joints */
+#define ORC_MAXHV 32     /* vertices of a convex-hull object (include/pbre.h: PBRE_HULL_MAXV) */
 /* State record layout (include/pbre.h): three lane records Q | V | X.  Q and V are W floats wide (W = 16 for robots
  * with <= 9 DoF, 32 for <= 20 DoF, 64 otherwise), X is 16:  Q[0..nd) q, Q[nd..nd+3) object position, Q[nd+3..nd+7) object quaternion;
  * V[0..nd) qd, V[nd..nd+6) object twist;  X[0..2] target, X[3] counter, X[4] terminated, X[5] episode,
@@ -75,11 +76,14 @@ typedef struct {
     int flags;                     /* ORC_F_* */
     int implicit_joint_damping;    /* 1: (M + dt C) dv = dt (tau - C v) instead of the explicit damping torque (include/pbre.h) */
     int obj_shape;                 /* object primitive (include/pbre.h PBRE_SHAPE_*): 0 box (half extents obj_h), 1 sphere (radius obj_h[0]),
-                                      2 cylinder about its local z axis (radius obj_h[0], half height obj_h[2]) */
+                                      2 cylinder about its local z axis (radius obj_h[0], half height obj_h[2]), 3 convex hull of obj_hull[] */
     double solver_residual_threshold;  /* Bullet's btContactSolverInfo::m_leastSquaresResidualThreshold: the sweep loop is left once the
                                       largest squared velocity-level change of a row within one sweep is <= this value.  0 (the default here,
                                       and what the engine implements): all solver_iters sweeps unless a sweep changes nothing at all.
                                       [EXT-UNVERIFIED] PyBullet documents solverResidualThreshold with default 1e-7; see orc_step_info.sweeps_* */
+    int obj_hull_n;                /* obj_shape 3 (PBRE_SHAPE_HULL): number of hull vertices (4..ORC_MAXHV) */
+    double obj_hull[ORC_MAXHV][3]; /* ... and the vertices in the object's frame (origin = centre of mass).  obj_h then holds the half extents
+                                      of the hull's bounding box (rest-height guess of the reset, as for the primitives) */
 } orc_params;
 
 #define ORC_F_NO_OBJECT 1   /* object frozen and contact-free (reset phase 1; reach config 2) */

@@ -112,6 +112,10 @@ static hipError_t quiesce(pbre_ctx* c) {
         return hipSuccess;
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
+    if (c->ap.ready) {      // the pipelined host path's copies (their rows are still delivered: pbre_step_wait finds the events complete)
+        if ((e = hipStreamSynchronize(c->ap.s_in)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(c->ap.s_out)) != hipSuccess) return e;
+    }
     return hipStreamSynchronize(c->side);
 }
 
@@ -206,9 +210,18 @@ void pbre_destroy(pbre_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
     free_buf(c->main); free_buf(c->tmp);
-    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask, (void*)c->d_bad, (void*)c->d_sweeps})
+    for (void* p : {(void*)c->dT, (void*)c->d_act, (void*)c->d_out, (void*)c->d_scratch, (void*)c->d_ids, (void*)c->d_ep, (void*)c->d_idx, (void*)c->d_mask, (void*)c->d_bad, (void*)c->d_sweeps, (void*)c->d_hull})
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->ap.ready) {
+        (void)hipStreamSynchronize(c->ap.s_in); (void)hipStreamSynchronize(c->ap.s_out);
+        for (int b = 0; b < 2; b++) {
+            if (c->ap.d_act[b]) (void)hipFree(c->ap.d_act[b]);
+            if (c->ap.d_rows[b]) (void)hipFree(c->ap.d_rows[b]);
+            for (hipEvent_t e : {c->ap.ev_in[b], c->ap.ev_step[b], c->ap.ev_out[b]}) if (e) (void)hipEventDestroy(e);
+        }
+        (void)hipStreamDestroy(c->ap.s_in); (void)hipStreamDestroy(c->ap.s_out);
+    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_join_sys) (void)hipEventDestroy(c->ev_join_sys);
@@ -480,6 +493,62 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     return PBRE_OK;
 }
 
+// ---- the pipelined host path (SURVEY 8(d)'s literal metric: action upload + kernels + row download).  pbre_step is host-synchronous: upload,
+// kernels and download of ONE step follow each other (or, zero-copy, the kernels reach over PCIe themselves and are stretched by it:
+// 0.44 ms instead of 0.15 at 131072 envs).  Here the three run on three streams with two buffer slots, so that in an open loop the DMA
+// engines download the rows of step t (18.4 MB at 131072 envs: the PCIe floor, ~0.33 ms) while the kernels of step t + 1 run and the
+// actions of step t + 2 come up.  Same kernels, same order per env: rows bit-equal to pbre_step's.
+static int async_setup(pbre_ctx* c) {
+    if (c->ap.ready) return PBRE_OK;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->ap.s_in, hipStreamNonBlocking, hi));
+    HIPCHK(hipStreamCreateWithPriority(&c->ap.s_out, hipStreamNonBlocking, hi));
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(hipMalloc(&c->ap.d_act[b], (size_t)c->n * c->act_dim * 4));
+        HIPCHK(hipMalloc(&c->ap.d_rows[b], (size_t)c->n * c->ow * 4));
+        for (hipEvent_t* e : {&c->ap.ev_in[b], &c->ap.ev_step[b], &c->ap.ev_out[b]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    c->ap.ready = true;
+    return PBRE_OK;
+}
+int pbre_step_async(pbre_ctx* c, const float* actions, float* out) {
+    if (!c || !actions || !out) return PBRE_E_ARG;
+    if (c->wide) { c->err = "pbre_step_async: implemented for the Panda task envs (the BASELINE metric's path); use pbre_step"; return PBRE_E_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->stale_snapshot && (c->cfg.flags & PBRE_F_AUTO_RESET)) { c->err = stale_snapshot_msg(); return PBRE_E_ARG; }
+    { const int rc = async_setup(c); if (rc != PBRE_OK) return rc; }
+    pbre_ctx::AsyncPath& A = c->ap;
+    if (A.issued - A.waited >= 2) { c->err = "pbre_step_async: two steps are in flight already -- pbre_step_wait first"; return PBRE_E_ARG; }
+    if (c->ext_dirty) HIPCHK(quiesce(c));
+    const int b = (int)(A.issued & 1);
+    // upload: behind the step that last read this slot's action buffer (two steps ago)
+    if (A.issued >= 2) HIPCHK(hipStreamWaitEvent(A.s_in, A.ev_step[b], 0));
+    HIPCHK(hipMemcpyAsync(A.d_act[b], actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, A.s_in));
+    HIPCHK(hipEventRecord(A.ev_in[b], A.s_in));
+    // step: behind its upload and behind the download that last read this slot's row buffer
+    HIPCHK(hipStreamWaitEvent(c->stream, A.ev_in[b], 0));
+    if (A.issued >= 2) HIPCHK(hipStreamWaitEvent(c->stream, A.ev_out[b], 0));
+    HIPCHK(full_step(c, A.d_act[b], A.d_rows[b], c->stream));
+    HIPCHK(hipEventRecord(A.ev_step[b], c->stream));
+    // download
+    HIPCHK(hipStreamWaitEvent(A.s_out, A.ev_step[b], 0));
+    HIPCHK(hipMemcpyAsync(out, A.d_rows[b], (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, A.s_out));
+    HIPCHK(hipEventRecord(A.ev_out[b], A.s_out));
+    A.issued++;
+    return PBRE_OK;
+}
+int pbre_step_wait(pbre_ctx* c) {
+    if (!c) return PBRE_E_ARG;
+    if (c->wide) { c->err = "pbre_step_wait: no pbre_step_async on this engine"; return PBRE_E_UNSUPPORTED; }
+    pbre_ctx::AsyncPath& A = c->ap;
+    if (!A.ready || A.waited >= A.issued) { c->err = "pbre_step_wait: no step in flight"; return PBRE_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(A.ev_out[A.waited & 1]));
+    A.waited++;
+    return PBRE_OK;
+}
+
 int pbre_get_state(pbre_ctx* c, float* s) {
     if (!c || !s) return PBRE_E_ARG;
     if (c->wide) return wide_get_state(c->wide, s);
@@ -573,6 +642,25 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     HIPCHK(quiesce(c));
     HIPCHK(classify(c, c->main, c->n, c->cfg.flags & PBRE_F_NO_OBJECT, c->stream));     // the contact margin may have changed
     HIPCHK(hipStreamSynchronize(c->stream));
+    return PBRE_OK;
+}
+
+int pbre_set_object_hull(pbre_ctx* c, const double* verts, int32_t n_verts) {
+    if (!c) return PBRE_E_ARG;
+    if (c->wide) return wide_set_object_hull(c->wide, verts, n_verts);
+    HullTable H;
+    const std::string e = build_hull(verts, n_verts, H);
+    if (!e.empty()) { c->err = e; return PBRE_E_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(quiesce(c));
+    if (!c->d_hull) HIPCHK(hipMalloc(&c->d_hull, sizeof H.data));
+    HIPCHK(hipMemcpy(c->d_hull, H.data, sizeof H.data, hipMemcpyHostToDevice));
+    c->P.hull = c->d_hull; c->P.hull_nv = H.nv; c->P.hull_nf = H.nf; c->P.hull_rb = H.rb; c->P.obj_shape = PBRE_SHAPE_HULL;
+    c->cfg.phys.obj_shape = PBRE_SHAPE_HULL;
+    for (int k = 0; k < 3; k++) { c->cfg.phys.obj_h[k] = H.half[k]; c->P.obj_h[k] = (float)H.half[k]; }
+    c->P.rst_objz = (float)(c->cfg.h_table + H.half[2]);
+    c->stale_snapshot = c->stale_snapshot || c->have_snapshot;      // a scene change: restarts from the old scene's settled snapshot are refused
+    c->have_snapshot = false; c->P.rst_ok = 0;
     return PBRE_OK;
 }
 

@@ -344,6 +344,73 @@ struct Core {
         return mv(Ro, v3(lx, ly, s * oh.z));
     }
 
+    // sphere vs a convex-hull object (Params::obj_shape 3, pbre_set_object_hull; oracle: sphere_hull): same contract as sphere_box.  H: the
+    // hull table (pbre_tables.hpp), read at group-uniform addresses.  A sphere whose centre is farther from the object's origin than the
+    // hull's bounding radius + its own radius + the margin cannot be a contact: its lanes get that lower bound as distance (> margin, never
+    // selected) and, when no lane of the wave is nearer, the face loop is skipped.  Otherwise per lane: the nearest face plane if the centre
+    // is behind every face (inside: the box / cylinder rule), else the closest point over the face triangles (Ericson, Real-Time Collision
+    // Detection 5.1.5, written with selects in the priority order of its early returns: vertex A, B, edge AB, vertex C, edge AC, BC, face).
+    static PBRE_HD F sphere_hull(const float* H, int nf, float rb, const V3& sc, F sr, const V3& bc, const M3& Rb, F margin, V3& n, V3& pb) {
+        const F one = L::c(1.f), zero = L::c(0.f);
+        V3 d = sub(sc, bc);
+        V3 p = mtv(Rb, d);
+        F len0 = norm(p);
+        F far = len0 - L::c(rb) - sr;
+        B near = L::lt(far, margin);
+        F il0 = one / L::max(len0, L::c(1e-30f));
+        n = v3(L::sel(L::gt(len0, zero), d.x * il0, zero), L::sel(L::gt(len0, zero), d.y * il0, zero), L::sel(L::gt(len0, zero), d.z * il0, one));
+        pb = add(bc, scl(n, L::c(rb)));
+        if (!L::any(near)) return far;
+        F best2 = L::c(3e38f), maxsd = L::c(-3e38f);
+        V3 bcp = v3(zero, zero, zero), nin = v3(zero, zero, one);
+        for (int f = 0; f < nf; f++) {
+            const float* T = H + HULL_T0 + 12 * f;
+            const V3 a = v3(L::loadu(T + 0), L::loadu(T + 1), L::loadu(T + 2)), ab = v3(L::loadu(T + 3), L::loadu(T + 4), L::loadu(T + 5));
+            const V3 ac = v3(L::loadu(T + 6), L::loadu(T + 7), L::loadu(T + 8)), nr = v3(L::loadu(T + 9), L::loadu(T + 10), L::loadu(T + 11));
+            const V3 ap = sub(p, a);
+            const F sd = dot(nr, ap);
+            const B deeper = L::gt(sd, maxsd);
+            maxsd = L::sel(deeper, sd, maxsd); nin = selv(deeper, nr, nin);
+            const F d1 = dot(ab, ap), d2 = dot(ac, ap);
+            const V3 bp = sub(ap, ab), cp = sub(ap, ac);
+            const F d3 = dot(ab, bp), d4 = dot(ac, bp), d5 = dot(ab, cp), d6 = dot(ac, cp);
+            const F vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+            const F den = one / (va + vb + vc);
+            F v = vb * den, w = vc * den;                                                   // face interior
+            const F e43 = d4 - d3, e56 = d5 - d6;
+            const B rBC = L::band(L::le(va, zero), L::band(L::ge(e43, zero), L::ge(e56, zero)));
+            const F wbc = e43 / (e43 + e56);
+            v = L::sel(rBC, one - wbc, v); w = L::sel(rBC, wbc, w);
+            const B rAC = L::band(L::le(vb, zero), L::band(L::ge(d2, zero), L::le(d6, zero)));
+            v = L::sel(rAC, zero, v); w = L::sel(rAC, d2 / (d2 - d6), w);
+            const B rC = L::band(L::ge(d6, zero), L::le(d5, d6));
+            v = L::sel(rC, zero, v); w = L::sel(rC, one, w);
+            const B rAB = L::band(L::le(vc, zero), L::band(L::ge(d1, zero), L::le(d3, zero)));
+            v = L::sel(rAB, d1 / (d1 - d3), v); w = L::sel(rAB, zero, w);
+            const B rB = L::band(L::ge(d3, zero), L::le(d4, d3));
+            v = L::sel(rB, one, v); w = L::sel(rB, zero, w);
+            const B rA = L::band(L::le(d1, zero), L::le(d2, zero));
+            v = L::sel(rA, zero, v); w = L::sel(rA, zero, w);
+            const V3 q = add(a, add(scl(ab, v), scl(ac, w)));
+            const V3 e = sub(p, q);
+            const F e2 = dot(e, e);
+            const B closer = L::lt(e2, best2);                                              // (a NaN from a degenerate triangle's 0 / 0 never wins)
+            best2 = L::sel(closer, e2, best2); bcp = selv(closer, q, bcp);
+        }
+        const B inside = L::le(maxsd, zero);
+        const F len = L::sqrt(best2);
+        const B deg = L::lt(len, L::c(1e-12f));
+        const F il = one / L::max(len, L::c(1e-30f));
+        const V3 eo = sub(p, bcp);
+        V3 n_out = v3(L::sel(deg, zero, eo.x * il), L::sel(deg, zero, eo.y * il), L::sel(deg, one, eo.z * il));
+        V3 nl = selv(inside, nin, n_out);
+        V3 cl = selv(inside, sub(p, scl(nin, maxsd)), bcp);                                  // inside: the centre's projection onto the nearest face plane
+        F dist = L::sel(inside, maxsd - sr, len - sr);
+        V3 nw = mv(Rb, nl), pw = add(bc, mv(Rb, cl));
+        n = selv(near, nw, n); pb = selv(near, pw, pb);
+        return L::sel(near, dist, far);
+    }
+
     // Select the `cap` smallest-distance candidates (dist < margin) among lanes with `valid`;
     // returns the per-lane rank (0..cap-1 in lane order) or -1.  Ties resolve to the lowest lane.
     static PBRE_HD I select_k(F dist, B valid, F margin, int cap, I lane) {
@@ -701,10 +768,43 @@ struct Core {
             V3 oh = v3(L::c(P.obj_h[0]), L::c(P.obj_h[1]), L::c(P.obj_h[2]));
             // object vertices (box) / candidate points of a round object
             B cand_used;
-            vx = add(op, shape_candidate(P.obj_shape, oh, Ro, lane, cand_used));
             F top = L::c(P.tab_c[2] + P.tab_h[2]), bot = L::c(P.tab_c[2] - P.tab_h[2]);
-            B infoot = L::band(L::le(L::abs(vx.x - L::c(P.tab_c[0])), L::c(P.tab_h[0])), L::le(L::abs(vx.y - L::c(P.tab_c[1])), L::c(P.tab_h[1])));
-            F hs = L::sel(L::band(infoot, L::gt(vx.z, bot)), top, L::c(P.ground_z));
+            auto support = [&](const V3& x) -> F {      // height of the support surface under a world point: table top inside the footprint (unless below the slab), else ground
+                B infoot = L::band(L::le(L::abs(x.x - L::c(P.tab_c[0])), L::c(P.tab_h[0])), L::le(L::abs(x.y - L::c(P.tab_c[1])), L::c(P.tab_h[1])));
+                return L::sel(L::band(infoot, L::gt(x.z, bot)), top, L::c(P.ground_z));
+            };
+            if (P.obj_shape == 3) {
+                // convex hull: every vertex is a candidate.  Lane v holds vertex v + pass * W; with more vertices than lanes each pass keeps its
+                // NC_OT deepest (select_k), their survivors are gathered onto lanes pass * NC_OT + rank -- vertex order is preserved -- and the
+                // selection below runs over those: the NC_OT deepest of all vertices, ties to the lower index, in vertex order (oracle:
+                // select_contacts over obj_hull[])
+                constexpr int PASSES = (HULL_MAXV + W - 1) / W;
+                static_assert(PASSES * NC_OT <= W, "the survivors of every pass fit one lane group");
+                auto vertex = [&](int pass, B& used) -> V3 {
+                    used = L::lti(lane, L::ci(P.hull_nv - pass * W));
+                    const I at = L::ftoi(L::itof(lane) * L::c(4.f));                 // (lane arithmetic through the float unit: the lane backends have no integer operators)
+                    const float* hv = P.hull + HULL_V0 + 4 * pass * W;
+                    return add(op, mv(Ro, v3(L::loadx(hv, at, used), L::loadx(hv + 1, at, used), L::loadx(hv + 2, at, used))));
+                };
+                if (PASSES == 1 || P.hull_nv <= W) {
+                    vx = vertex(0, cand_used);
+                } else {
+                    const F z = L::c(0.f);
+                    vx = v3(z, z, z); cand_used = L::bfalse();
+                    for (int pass = 0; pass < PASSES; pass++) {
+                        B used_p;
+                        const V3 vp = vertex(pass, used_p);
+                        const F vdp = vp.z - support(vp);
+                        const I rkp = select_k(vdp, used_p, L::c(P.margin), NC_OT, lane);
+                        for (int c = 0; c < NC_OT; c++) {
+                            const Contact cc = fetch(rkp, c, vp, vp, vp, vdp, z, L::ci(0), lane);
+                            const B here = L::band(L::eqi(lane, L::ci(pass * NC_OT + c)), cc.act);
+                            vx = selv(here, cc.pA, vx); cand_used = L::bor(cand_used, here);
+                        }
+                    }
+                }
+            } else vx = add(op, shape_candidate(P.obj_shape, oh, Ro, lane, cand_used));
+            F hs = support(vx);
             vd = vx.z - hs;
             up = v3(zero, zero, one);
             I none = L::ci(-1);
@@ -712,7 +812,8 @@ struct Core {
             d_ro = L::c(1.f);
             if (obj_on) {
                 rk_ot = select_k(vd, cand_used, margin, NC_OT, lane);
-                d_ro = P.obj_shape == 0 ? sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro) : sphere_round(P.obj_shape, sc, sr, op, Ro, oh, n_ro, pB_ro);
+                d_ro = P.obj_shape == 0 ? sphere_box(sc, sr, op, Ro, oh, n_ro, pB_ro)
+                     : (P.obj_shape == 3 ? sphere_hull(P.hull, P.hull_nf, P.hull_rb, sc, sr, op, Ro, margin, n_ro, pB_ro) : sphere_round(P.obj_shape, sc, sr, op, Ro, oh, n_ro, pB_ro));
                 pA_ro = add(pB_ro, scl(n_ro, d_ro));
                 rk_ro = select_k(d_ro, sv, margin, NC_RO, lane);
             } else { n_ro = up; pB_ro = up; pA_ro = up; }

@@ -2,7 +2,9 @@
 // configuration, pbre_config -> Tables/Params, observation limits.  Shared by
 // pbre_capi.hip (product) and tests/host_emu (lane emulation, tests only).
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <vector>
 #include <cstring>
 #include <string>
 #include "../../include/pbre.h"
@@ -154,11 +156,80 @@ inline bool apply_physics(const pbre_physics& p, Params& P2) {
     for (int k = 0; k < 3; k++) { P2.tab_c[k] = (float)p.table_c[k]; P2.tab_h[k] = (float)p.table_h[k]; P2.obj_h[k] = (float)p.obj_h[k]; P2.obj_I[k] = (float)p.obj_inertia[k]; }
     P2.tab_mu = (float)p.table_mu; P2.ground_z = (float)p.ground_z; P2.obj_m = (float)p.obj_mass; P2.obj_mu = (float)p.obj_mu;
     P2.obj_iso = (P2.obj_I[0] == P2.obj_I[1] && P2.obj_I[1] == P2.obj_I[2]) ? 1 : 0;
-    if (p.obj_shape < 0 || p.obj_shape > 2) return false;
+    if (p.obj_shape < 0 || p.obj_shape > 3 || (p.obj_shape == 3 && !P2.hull)) return false;      // (a hull needs pbre_set_object_hull first)
     P2.obj_shape = p.obj_shape;
     if (!(p.solver_residual_threshold >= 0)) return false;
     P2.res_lim = (float)std::sqrt(p.solver_residual_threshold);
     return true;
+}
+
+// The face table of a convex-hull object from its vertices (pbre_set_object_hull; layout: pbre_tables.hpp HullTable).  Supporting planes by
+// brute force over the vertex triples (n <= 32), coplanar triples merged into one polygonal face (vertices ordered by angle about the
+// face's centroid, fan-triangulated): at most 2 n - 4 triangles for vertices in general position.  Returns "" or an error text.
+inline std::string build_hull(const double* v, int n, HullTable& H) {
+    if (!v || n < 4 || n > HULL_MAXV) return "pbre_set_object_hull: n_verts must be 4..32";
+    double scale = 0;
+    for (int i = 0; i < 3 * n; i++) { if (!std::isfinite(v[i])) return "pbre_set_object_hull: non-finite vertex"; scale = std::max(scale, std::fabs(v[i])); }
+    if (!(scale > 0)) return "pbre_set_object_hull: degenerate vertex set";
+    const double eps = 1e-7 * scale;
+    struct Plane { double n[3], d; };
+    std::vector<Plane> planes;
+    auto V = [&](int i, int k) { return v[3 * i + k]; };
+    for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++) for (int k = j + 1; k < n; k++) {
+        const double u[3] = {V(j, 0) - V(i, 0), V(j, 1) - V(i, 1), V(j, 2) - V(i, 2)}, w[3] = {V(k, 0) - V(i, 0), V(k, 1) - V(i, 1), V(k, 2) - V(i, 2)};
+        double nn[3] = {u[1] * w[2] - u[2] * w[1], u[2] * w[0] - u[0] * w[2], u[0] * w[1] - u[1] * w[0]};
+        const double len = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        if (len < 1e-9 * scale * scale) continue;                      // collinear
+        for (double& x : nn) x /= len;
+        int pos = 0, neg = 0;
+        for (int l = 0; l < n; l++) {
+            const double d = nn[0] * (V(l, 0) - V(i, 0)) + nn[1] * (V(l, 1) - V(i, 1)) + nn[2] * (V(l, 2) - V(i, 2));
+            if (d > eps) pos++; else if (d < -eps) neg++;
+        }
+        if (pos && neg) continue;
+        if (!pos && !neg) return "pbre_set_object_hull: the vertices are coplanar";
+        const double sg = pos ? -1.0 : 1.0;
+        Plane pl; for (int t = 0; t < 3; t++) pl.n[t] = sg * nn[t];
+        pl.d = pl.n[0] * V(i, 0) + pl.n[1] * V(i, 1) + pl.n[2] * V(i, 2);
+        bool dup = false;
+        for (const Plane& q : planes) if (q.n[0] * pl.n[0] + q.n[1] * pl.n[1] + q.n[2] * pl.n[2] > 1.0 - 1e-10 && std::fabs(q.d - pl.d) <= eps) { dup = true; break; }
+        if (!dup) planes.push_back(pl);
+    }
+    if (planes.size() < 4) return "pbre_set_object_hull: degenerate vertex set (no volume)";
+    H.nv = n; H.nf = 0; H.rb = 0.f;
+    std::memset(H.data, 0, sizeof H.data);
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; i++) {
+        double r2 = 0;
+        for (int k = 0; k < 3; k++) { H.data[HULL_V0 + 4 * i + k] = (float)V(i, k); r2 += V(i, k) * V(i, k); lo[k] = std::min(lo[k], V(i, k)); hi[k] = std::max(hi[k], V(i, k)); }
+        H.rb = std::max(H.rb, (float)std::sqrt(r2));
+    }
+    for (int k = 0; k < 3; k++) H.half[k] = std::max(hi[k], -lo[k]);      // (about the origin = the centre of mass: what the rest-height guess of a reset needs)
+    for (const Plane& pl : planes) {
+        std::vector<int> on;
+        double c[3] = {0, 0, 0};
+        for (int l = 0; l < n; l++) if (std::fabs(pl.n[0] * V(l, 0) + pl.n[1] * V(l, 1) + pl.n[2] * V(l, 2) - pl.d) <= eps) { on.push_back(l); for (int k = 0; k < 3; k++) c[k] += V(l, k); }
+        if (on.size() < 3) continue;
+        for (double& x : c) x /= (double)on.size();
+        double u[3] = {V(on[0], 0) - c[0], V(on[0], 1) - c[1], V(on[0], 2) - c[2]};
+        const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (!(ul > 0)) continue;
+        for (double& x : u) x /= ul;
+        const double w[3] = {pl.n[1] * u[2] - pl.n[2] * u[1], pl.n[2] * u[0] - pl.n[0] * u[2], pl.n[0] * u[1] - pl.n[1] * u[0]};
+        std::vector<std::pair<double, int>> ang;
+        for (int l : on) {
+            const double r[3] = {V(l, 0) - c[0], V(l, 1) - c[1], V(l, 2) - c[2]};
+            ang.push_back({std::atan2(r[0] * w[0] + r[1] * w[1] + r[2] * w[2], r[0] * u[0] + r[1] * u[1] + r[2] * u[2]), l});
+        }
+        std::sort(ang.begin(), ang.end());                            // counter-clockwise about the outward normal
+        for (size_t t = 1; t + 1 < ang.size(); t++) {
+            if (H.nf >= HULL_MAXF) return "pbre_set_object_hull: more than 64 triangles";
+            const int a = ang[0].second, b = ang[t].second, cc = ang[t + 1].second;
+            float* T = H.data + HULL_T0 + 12 * H.nf++;
+            for (int k = 0; k < 3; k++) { T[k] = (float)V(a, k); T[3 + k] = (float)(V(b, k) - V(a, k)); T[6 + k] = (float)(V(cc, k) - V(a, k)); T[9 + k] = (float)pl.n[k]; }
+        }
+    }
+    return "";
 }
 
 // number of DoF the RobotTable declares (0 if it is not a table): selects the lane shape
@@ -195,7 +266,7 @@ inline std::string make_tables(const pbre_config& c, TablesT<S>& T, Params& P) {
     for (int k = 0; k < 3; k++) { P.tab_c[k] = (float)p.table_c[k]; P.tab_h[k] = (float)p.table_h[k]; P.obj_h[k] = (float)p.obj_h[k]; P.obj_I[k] = (float)p.obj_inertia[k]; }
     P.tab_mu = (float)p.table_mu; P.ground_z = (float)p.ground_z; P.obj_m = (float)p.obj_mass; P.obj_mu = (float)p.obj_mu;
     P.obj_iso = (P.obj_I[0] == P.obj_I[1] && P.obj_I[1] == P.obj_I[2]) ? 1 : 0;
-    if (p.obj_shape < 0 || p.obj_shape > 2) return "bad physics parameters (obj_shape)";
+    if (p.obj_shape < 0 || p.obj_shape > 2) return "bad physics parameters (obj_shape; a convex hull is set with pbre_set_object_hull after pbre_create)";
     P.obj_shape = p.obj_shape;
     if (!(p.solver_residual_threshold >= 0)) return "bad physics parameters (solver_residual_threshold)";
     P.res_lim = (float)std::sqrt(p.solver_residual_threshold);

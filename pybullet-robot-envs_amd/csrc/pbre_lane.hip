@@ -31,12 +31,16 @@
 #define PBRE_IK_PUBLISH(done, seq) do { if (done) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
         __hip_atomic_store((done), (seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
-// A wait that reaches its bound POISONS the env: `to` becomes true, quad_step stores NaN joint positions, and the NaN / Inf guard in
-// kw_fin returns the env-step as done = 1 / reward 0, restarts the env under PBRE_F_AUTO_RESET and counts it once (pbre_kernel_info[12]).
-#define PBRE_IK_WAIT(flag, seq, to) do { int spins_ = 0; \
+// A wait that reaches its bound POISONS the env: quad_step writes NaN into the env's guard element of the side buffer (element
+// 214 of quad lane 0, where kw_dyn recorded whether the incoming state was finite), and the NaN / Inf guard in kw_fin returns the env-step as
+// done = 1 / reward 0, restarts the env under PBRE_F_AUTO_RESET and counts it once (pbre_kernel_info[12]).  (A first version carried a flag
+// to the joint-position stores at the end of quad_step -- `timeout ? NaN : q` --: with that select in the kernel the envs with robot-object
+// contact came out different from run to run on the GPU (6 tests of tests/test_gpu_icub.py; the variant without the select passed); the
+// poison is now a store inside the branch that is never taken.)
+#define PBRE_IK_WAIT(flag, seq, on_timeout) do { int spins_ = 0; \
         while (__hip_atomic_load((flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (seq)) { \
             __builtin_amdgcn_s_sleep(8); \
-            if (++spins_ > (1 << 22)) { (to) = true; break; } } \
+            if (++spins_ > (1 << 22)) { on_timeout; break; } } \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define PBRE_LANE_MSTRIDE 64         // M^-1 in wave-private LDS, [entry][lane]
 #ifndef PBRE_LANE_MREG
@@ -194,7 +198,6 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     }
     // ---- unconstrained velocities v* = qd + dt M^-1 tau, motor rows against the running velocity, limit rows (see Lane::step)
     float w[QD], w0[QD], m_dinv[QD], m_rhs[QD], sabs[QD], l_dir[QD], l_rhs[QD], l_app[QD];
-    bool ik_timeout = false;            // PBRE_IK_WAIT reached its bound: the env-step goes to the NaN / Inf guard
     unsigned long long lim_b[QD];
     {
         float acc[QD];
@@ -204,7 +207,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
             PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = fmaf(A[i][c], tc, acc[i]);
         }
         // Cartesian control: this env's IK targets are read next -- wait for ITS mark (the IK kernel runs beside this one)
-        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, ik_timeout);
+        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, dyn[(size_t)214 * cs + env] = __builtin_nanf(""));
         PBRE_UNROLL for (int i = 0; i < QD; i++) {
             const int d = d0 + i;
             const float wj = fminf(fmaxf(fmaf(dt, acc[i], qd[i]), -vmax), vmax);
@@ -428,7 +431,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     // ---- integrate the joints (semi-implicit Euler)
     PBRE_UNROLL for (int i = 0; i < QD; i++) {
         const float v = fminf(fmaxf(w[i], -vmax), vmax);
-        st[W + d0 + i] = v; st[d0 + i] = ik_timeout ? __builtin_nanf("") : fmaf(dt, v, q[i]);
+        st[W + d0 + i] = v; st[d0 + i] = fmaf(dt, v, q[i]);
     }
     if (RC && r == 0) {      // the object's twist after the coupled solve, for kw_fin
         float o[6];
@@ -551,7 +554,8 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     // (round objects -- pbre_physics.obj_shape -- included: the object's own rows are ObjStep's, the robot-object test is Fast::sphere_obj)
     // (not with Bullet's residual exit, pbre_physics.solver_residual_threshold > 0: the pipeline splits an env's rows over kernels, the
     // test is a maximum over all of them -- such a batch is stepped by the lane-group kernel, Core::step<RT>)
-    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr && !(P.res_lim > 0.f); }
+    // (nor with a convex-hull object: the pipeline's narrow phase is compiled for the primitives)
+    bool lane_ok() const override { return enabled && topo_ok && cls != nullptr && objv != nullptr && !(P.res_lim > 0.f) && P.obj_shape != PBRE_SHAPE_HULL; }
     void lane_invalidate() override { cls_valid = false; }
     hipError_t lane_alloc() override {
         const char* knob = getenv("PBRE_ICUB_LANE");

@@ -187,8 +187,11 @@ __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Pa
         __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
     }
 }
+#ifndef PBRE_PAIR_WPS
+#define PBRE_PAIR_WPS 2            // waves per SIMD k_fast_pair is register-limited to (A/B: tools/build_variant.sh)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(PTPB, 2) void k_fast_pair(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
+__global__ __launch_bounds__(PTPB, PBRE_PAIR_WPS) void k_fast_pair(const Tables* __restrict__ T, const Params P, float* __restrict__ state,
                                                const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                                const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                                int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count) {
@@ -436,6 +439,7 @@ struct pbre_ctx {
     EnvBuf main, tmp;
     float *d_act = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     int* d_bad = nullptr;              // NaN / Inf guard: env-steps that met a non-finite state (Params::bad_count)
+    float* d_hull = nullptr;           // PBRE_SHAPE_HULL: the object's vertex / face table (Params::hull; pbre_set_object_hull)
     int* d_sweeps = nullptr;           // [npad] sweeps every env's solver ran in the last step (Params::sweeps; pbre_physics.solver_residual_threshold > 0)
     unsigned long long* d_ids = nullptr; unsigned* d_ep = nullptr; int* d_idx = nullptr;
     bool fast_ok = false;
@@ -455,6 +459,16 @@ struct pbre_ctx {
     hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
     SidePick sp;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // pipelined host path (pbre_step_async / pbre_step_wait, round 6): copy-in / copy-out streams, two (actions, rows) device buffer pairs and
+    // the events that order upload -> step -> download of each slot; created on first use
+    struct AsyncPath {
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        float* d_act[2] = {nullptr, nullptr};
+        float* d_rows[2] = {nullptr, nullptr};
+        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        long issued = 0, waited = 0;
+        bool ready = false;
+    } ap;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_sys = nullptr;   // ev_join_sys: with the system-scope fence (see pbre_step)
     bool rows_to_host = false;         // the step in flight writes its output rows straight into page-locked host memory
     static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
@@ -471,7 +485,8 @@ struct pbre_ctx {
     std::string err;
 };
 static inline int ceil16(int n) { return (n + EPB - 1) / EPB * EPB; }
-static inline bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL); }
+// (a convex-hull object is stepped by the general row kernel: the lane-per-env kernels are compiled for the primitives)
+static inline bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->cfg.flags & PBRE_F_FORCE_GENERAL) && c->P.obj_shape != PBRE_SHAPE_HULL; }
 
 // one batched step of the first n envs of b on stream s
 template <int MODE, bool RT>

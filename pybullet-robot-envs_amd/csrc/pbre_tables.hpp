@@ -114,9 +114,17 @@ struct Params {                  // float copies of pbre_physics + task constant
     float res_lim;                                  // sqrt(pbre_physics.solver_residual_threshold): an env leaves the sweep loop after the first sweep whose largest
                                                     // velocity-level row change |delta impulse / jacDiagABInv| is <= res_lim (Bullet compares the squares); 0: never
     int*  sweeps;                                   // res_lim > 0: per-env count of the sweeps run in the step ([num_envs], this ctx's local env index); may be null
+    // PBRE_SHAPE_HULL (obj_shape 3; pbre_set_object_hull): device table [HULL_V0 .. ) = hull_nv vertices x (x, y, z, 0), [HULL_T0 .. ) = hull_nf
+    // triangles x (a[3], ab[3], ac[3], unit outward normal[3]) in the object's frame; hull_rb = the largest vertex distance from the origin
+    const float* hull;
+    int   hull_nv, hull_nf;
+    float hull_rb;
     int   objv_seq;                                 // Core::step's `objv` side record: 0 = complete behind the block barrier (its producer is a sibling wave); else complete
                                                     // once its first word holds this number (its producer is a wave of another block: pbre_capi.hip k_fused)
 };
+
+constexpr int HULL_MAXV = 32, HULL_MAXF = 64, HULL_V0 = 0, HULL_T0 = 4 * HULL_MAXV, HULL_FLOATS = 4 * HULL_MAXV + 12 * HULL_MAXF;
+struct HullTable { int nv = 0, nf = 0; float rb = 0.f; double half[3] = {0, 0, 0}; float data[HULL_FLOATS]; };
 
 namespace detail {
 struct Xf { double R[9]; double p[3]; };

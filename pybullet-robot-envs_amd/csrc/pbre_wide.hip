@@ -101,7 +101,7 @@ void wide_destroy(WideEngine* w) {
     if (w->stream) (void)hipStreamSynchronize(w->stream);
     w->free_tables();
     for (void* p : {(void*)w->state, (void*)w->tmp, (void*)w->tgt, (void*)w->tgt_tmp, (void*)w->d_act, (void*)w->d_out,
-                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv, (void*)w->d_bad, (void*)w->d_sweeps})
+                    (void*)w->d_ids, (void*)w->d_ep, (void*)w->d_idx, (void*)w->d_mask, (void*)w->objv, (void*)w->d_bad, (void*)w->d_sweeps, (void*)w->d_hull})
         if (p) (void)hipFree(p);
     for (auto& e : w->ev) if (e) (void)hipEventDestroy(e);
     for (auto& pr : w->ev_k) for (auto& e : pr) if (e) (void)hipEventDestroy(e);
@@ -391,6 +391,22 @@ int wide_set_physics(WideEngine* w, const pbre_physics* p) {
     if (snapshot_relevant_change(w->cfg.phys, *p)) { w->stale_snapshot = w->stale_snapshot || w->have_snapshot; w->have_snapshot = false; P2.rst_ok = 0; }
     w->cfg.phys = *p; w->P = P2;
     w->lane_invalidate();          // the contact margin may have changed
+    return PBRE_OK;
+}
+int wide_set_object_hull(WideEngine* w, const double* verts, int32_t n_verts) {
+    HullTable H;
+    const std::string e = build_hull(verts, n_verts, H);
+    if (!e.empty()) { w->err = e; return PBRE_E_ARG; }
+    WCHK(hipSetDevice(w->device));
+    WCHK(wquiesce(w));
+    if (!w->d_hull) WCHK(hipMalloc(&w->d_hull, sizeof H.data));
+    WCHK(hipMemcpy(w->d_hull, H.data, sizeof H.data, hipMemcpyHostToDevice));
+    w->P.hull = w->d_hull; w->P.hull_nv = H.nv; w->P.hull_nf = H.nf; w->P.hull_rb = H.rb; w->P.obj_shape = PBRE_SHAPE_HULL;
+    w->cfg.phys.obj_shape = PBRE_SHAPE_HULL;
+    for (int k = 0; k < 3; k++) { w->cfg.phys.obj_h[k] = H.half[k]; w->P.obj_h[k] = (float)H.half[k]; }
+    w->P.rst_objz = (float)(w->cfg.h_table + H.half[2]);
+    w->stale_snapshot = w->stale_snapshot || w->have_snapshot; w->have_snapshot = false; w->P.rst_ok = 0;
+    w->lane_invalidate();
     return PBRE_OK;
 }
 int wide_get_sweeps(WideEngine* w, int32_t* sweeps) {

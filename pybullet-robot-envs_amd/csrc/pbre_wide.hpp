@@ -28,6 +28,7 @@ int  wide_apply_action(WideEngine* w, const float* actions, double max_vel);
 int  wide_motor_state(WideEngine* w, float* out, const float* in);
 int  wide_set_physics(WideEngine* w, const pbre_physics* p);
 int  wide_get_physics(const WideEngine* w, pbre_physics* p);
+int  wide_set_object_hull(WideEngine* w, const double* verts, int32_t n_verts);
 int  wide_get_sweeps(WideEngine* w, int32_t* sweeps);
 int  wide_obs_limits(const WideEngine* w, float* lo, float* hi);
 int  wide_timing(const WideEngine* w, double* ms, int32_t n);

@@ -142,6 +142,7 @@ struct WideEngine {
     float *state = nullptr, *tmp = nullptr, *tgt = nullptr, *tgt_tmp = nullptr;
     float *d_act = nullptr, *d_out = nullptr;
     int* d_bad = nullptr;                     // NaN / Inf guard counter (Params::bad_count)
+    float* d_hull = nullptr;                  // PBRE_SHAPE_HULL: the object's vertex / face table (Params::hull; pbre_set_object_hull)
     int* d_sweeps = nullptr;                  // [n] sweeps every env's solver ran in the last step (Params::sweeps; pbre_physics.solver_residual_threshold > 0)
     float* objv = nullptr;                    // [n][W] side records of kw_obj, or nullptr: object rows always solved in kw_step
     const float* obj_done = nullptr;          // state buffer whose object solve rode along with the last kw_ik launch (consumed by the next step)
@@ -206,7 +207,8 @@ struct WideImpl : WideEngine {
             hipLaunchKernelGGL((kw_step<S, L, MODE, true>), dim3(blocks_of(cnt)), dim3(WTPB), 0, s, dT, P, st, act, out, cnt, act_dim, ow, flags, tg, (const float*)nullptr);
             return;
         }
-        const float* ov = (objv && !(flags & 1)) ? objv : nullptr;
+        // (a convex-hull object's rows stay in kw_step: the per-env object solver kw_obj is compiled for the primitives)
+        const float* ov = (objv && !(flags & 1) && P.obj_shape != PBRE_SHAPE_HULL) ? objv : nullptr;
         const bool done = ov && obj_done == st;
         obj_done = nullptr;
         if (ov && !done) hipLaunchKernelGGL((kw_obj<S>), dim3((cnt + 63) / 64), dim3(64), 0, s, P, st, objv, cnt);
@@ -228,7 +230,7 @@ struct WideImpl : WideEngine {
         const int ikb = blocks_of(cnt);
         if (reset) hipLaunchKernelGGL((kw_ik<S, L, true>), dim3(ikb), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim, ikb, (float*)nullptr);
         else {
-            const bool ride = step_follows && objv != nullptr && !(cfg.flags & PBRE_F_NO_OBJECT) && !(P.res_lim > 0.f);
+            const bool ride = step_follows && objv != nullptr && !(cfg.flags & PBRE_F_NO_OBJECT) && !(P.res_lim > 0.f) && P.obj_shape != PBRE_SHAPE_HULL;
             hipLaunchKernelGGL((kw_ik<S, L, false>), dim3(ikb + (ride ? (cnt + WTPB - 1) / WTPB : 0)), dim3(WTPB), 0, s, dT, P, st, act, tg, cnt, act_dim,
                                ikb, ride ? objv : nullptr);
             obj_done = ride ? st : nullptr;

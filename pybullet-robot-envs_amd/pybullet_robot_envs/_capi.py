@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PBRE_LIB") or os.path.join(os.path.dirname(_HERE), "c
 STATE_FLOATS = 48
 ROBOT_PANDA, ROBOT_ICUB, ROBOT_ICUB_HANDS, ROBOT_PANDA_ARM = 0, 1, 2, 3
 TASK_REACH, TASK_PUSH, TASK_PUSH_GOAL = 0, 1, 2
-SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_HULL = 0, 1, 2, 3
 F_NO_OBJECT, F_AUTO_RESET, F_FORCE_GENERAL, F_COMPLEX_ROWS, F_COMPLEX_LANES, F_SEQ_MOTORS, F_SEQ_OBJECT = 1, 2, 4, 8, 16, 32, 64
 
 
@@ -76,7 +76,7 @@ def load(path=None):
     for name in ("pbre_default_config", "pbre_create", "pbre_dims", "pbre_reset", "pbre_step", "pbre_step_device",
                  "pbre_sync", "pbre_get_state", "pbre_set_state", "pbre_observe", "pbre_settle", "pbre_obs_limits",
                  "pbre_timing", "pbre_kernel_info", "pbre_set_physics", "pbre_get_physics", "pbre_state_floats", "pbre_set_motors", "pbre_apply_action", "pbre_get_motor_state", "pbre_set_motor_state",
-                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot", "pbre_get_sweeps",
+                 "pbre_get_state_cols", "pbre_set_physics_per_env", "pbre_reset_snapshot", "pbre_get_sweeps", "pbre_set_object_hull",
                  "pbre_comm_probe", "pbre_comm_unique_id", "pbre_comm_init", "pbre_step_gather_device", "pbre_gather_wait", "pbre_comm_info", "pbre_scatter_actions_device"):
         getattr(lib, name).restype = C.c_int
     lib.pbre_comm_last_error.restype = C.c_char_p
@@ -146,7 +146,12 @@ class Engine:
                         arr[i] = x
             else:
                 setattr(self.cfg, k, v)
+        hull = None
         if phys:
+            phys = dict(phys)
+            hull = phys.pop("obj_hull", None)           # a convex-hull object (model/objects.py: hull_physics): set right after pbre_create
+            if hull is not None:
+                phys["obj_shape"] = SHAPE_BOX           # (pbre_create takes a primitive; obj_h = the hull's bounding box until the hull replaces it)
             for k, v in phys.items():
                 if not hasattr(self.cfg.phys, k):
                     raise TypeError("unknown pbre_physics field %r" % k)
@@ -175,6 +180,8 @@ class Engine:
         self.obj_off = 9 if self.ndof <= 9 else (20 if self.ndof <= 20 else (32 if self.ndof <= 32 else 60))
         self.v_off = (self.state_floats - 16) // 2
         self.x_off = self.state_floats - 16
+        if hull is not None:
+            self.set_object_hull(hull)
         # page-locked staging buffers of the host path (pbre_step DMAs straight from / into them): actions, and two row
         # buffers used alternately so that the arrays step(copy=False) returned stay valid for one more step
         self._pinned = []
@@ -201,6 +208,7 @@ class Engine:
             self.lib.pbre_destroy(self._ctx)
             self._ctx = None
             self._act = self._outs = None
+            self._async = None
             for p in self._pinned:
                 self.lib.pbre_host_free(C.c_void_p(p))
             self._pinned = []
@@ -244,6 +252,30 @@ class Engine:
         o = self._outs[self._flip]
         self._flip ^= 1
         self._chk(self.lib.pbre_step(self._ctx, _fp(self._act), _fp(o)))
+        if copy:
+            return o[:, :self.obs_dim].copy(), o[:, self.obs_dim].copy(), o[:, self.obs_dim + 1].copy()
+        return o[:, :self.obs_dim], o[:, self.obs_dim], o[:, self.obs_dim + 1]
+
+    def step_async(self, actions):
+        """Pipelined host-buffer step (pbre_step_async): enqueue upload + step + download and return; `step_wait()` returns the rows of the
+        oldest step in flight.  At most two in flight -- the open loop  step_async(a0); for t: step_async(a[t]); rows = step_wait()  overlaps
+        the download of step t - 1 with the kernels of step t.  Uses three page-locked (actions, rows) slots of its own."""
+        if getattr(self, "_async", None) is None:
+            self._async = {"act": [self._pinned_array((self.num_envs, self.act_dim)) for _ in range(3)],
+                           "out": [self._pinned_array((self.num_envs, self.obs_dim + 2)) for _ in range(3)], "issued": 0, "waited": 0}
+        A = self._async
+        k = A["issued"] % 3          # (three slots: the views step_wait() returned for step t - 1 stay valid while steps t and t + 1 are in flight)
+        np.copyto(A["act"][k], np.asarray(actions).reshape(self.num_envs, self.act_dim), casting="unsafe")
+        self._chk(self.lib.pbre_step_async(self._ctx, _fp(A["act"][k]), _fp(A["out"][k])))
+        A["issued"] += 1
+
+    def step_wait(self, copy=False):
+        """(raw obs, reward, done) of the oldest step_async not yet waited for: views of a page-locked row buffer that is overwritten by
+        the third step_async from now (copy=True: copies)"""
+        A = self._async
+        self._chk(self.lib.pbre_step_wait(self._ctx))
+        o = A["out"][A["waited"] % 3]
+        A["waited"] += 1
         if copy:
             return o[:, :self.obs_dim].copy(), o[:, self.obs_dim].copy(), o[:, self.obs_dim + 1].copy()
         return o[:, :self.obs_dim], o[:, self.obs_dim], o[:, self.obs_dim + 1]
@@ -377,6 +409,10 @@ class Engine:
     def set_physics(self, **fields):
         """Update batch-uniform physics constants, e.g. set_physics(obj_mass=0.2, obj_mu=0.8, lin_damping=0.1)."""
         ph = self.get_physics()
+        fields = dict(fields)
+        hull = fields.pop("obj_hull", None)               # (model/objects.py: hull_physics) the primitive fields first, then the hull
+        if hull is not None:
+            fields["obj_shape"] = SHAPE_BOX
         for k, v in fields.items():
             if not hasattr(ph, k):
                 raise TypeError("unknown pbre_physics field %r" % k)
@@ -386,6 +422,16 @@ class Engine:
             else:
                 setattr(ph, k, v)
         self._chk(self.lib.pbre_set_physics(self._ctx, C.byref(ph)))
+        if hull is not None:
+            self.set_object_hull(hull)
+
+    def set_object_hull(self, verts):
+        """The object as the convex hull of `verts` ([n, 3], 4 <= n <= 32, object frame, origin = centre of mass): include/pbre.h
+        pbre_set_object_hull.  Mass, inertia and friction stay what set_physics / the constructor's `phys` said."""
+        v = np.ascontiguousarray(verts, dtype=np.float64)
+        if v.ndim != 2 or v.shape[1] != 3:
+            raise ValueError("verts must be [n, 3]")
+        self._chk(self.lib.pbre_set_object_hull(self._ctx, v.ctypes.data_as(C.POINTER(C.c_double)), C.c_int32(len(v))))
 
     def get_sweeps(self):
         """[N] int32: the sweeps every env's solver ran in the last simulation step -- only with set_physics(solver_residual_threshold=...)
@@ -503,6 +549,10 @@ class MultiEngine(object):
     def set_physics(self, **fields):
         for e in self.shards:
             e.set_physics(**fields)
+
+    def set_object_hull(self, verts):
+        for e in self.shards:
+            e.set_object_hull(verts)
 
     def get_sweeps(self):
         return self._cat(self._map(lambda k: self.shards[k].get_sweeps()))

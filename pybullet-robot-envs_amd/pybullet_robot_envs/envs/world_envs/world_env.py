@@ -91,7 +91,9 @@ class WorldEnv:
         GEOM_SPHERE with the radius (x3), 4 = GEOM_CYLINDER with [height, radius, 0] (pybullet's conventions)"""
         ph = self.object_physics()
         h, shape = ph["obj_h"], ph.get("obj_shape", 0)
-        if shape == 1:
+        if shape == 3:
+            geom, dims = 5, [1.0, 1.0, 1.0]          # GEOM_MESH with the mesh scale (the object is the convex hull of its mesh, model/objects.py)
+        elif shape == 1:
             geom, dims = 2, [h[0]] * 3
         elif shape == 2:
             geom, dims = 4, [2 * h[2], h[0], 0.0]

@@ -74,6 +74,42 @@ def _sphere_round_dist(shape, sc, sr, bc, Rb, h):
     return np.where(ln < 1e-9, inside - sr, ln - sr)
 
 
+def _closest_on_triangles(p, A, B, C):
+    """closest points of the triangles (A, B, C: [T, 3]) to the points p[N, 3] -> squared distances [N, T] (Ericson 5.1.5, vectorised:
+    the regions are applied from the lowest priority -- the face -- to the highest -- vertex A -- so that the last write wins)"""
+    ab, ac = (B - A)[None], (C - A)[None]
+    ap = p[:, None, :] - A[None]
+    bp, cp = ap - ab, ap - ac
+    dot = lambda x, y: np.einsum("ntk,ntk->nt", np.broadcast_to(x, ap.shape), np.broadcast_to(y, ap.shape))
+    d1, d2, d3, d4, d5, d6 = dot(ab, ap), dot(ac, ap), dot(ab, bp), dot(ac, bp), dot(ab, cp), dot(ac, cp)
+    vc, vb, va = d1 * d4 - d3 * d2, d5 * d2 - d1 * d6, d3 * d6 - d5 * d4
+    with np.errstate(divide="ignore", invalid="ignore"):
+        den = 1.0 / (va + vb + vc)
+        v, w = vb * den, vc * den
+        e43, e56 = d4 - d3, d5 - d6
+        m = (va <= 0) & (e43 >= 0) & (e56 >= 0); wbc = e43 / (e43 + e56); v = np.where(m, 1 - wbc, v); w = np.where(m, wbc, w)
+        m = (vb <= 0) & (d2 >= 0) & (d6 <= 0); v = np.where(m, 0.0, v); w = np.where(m, d2 / (d2 - d6), w)
+        m = (d6 >= 0) & (d5 <= d6); v = np.where(m, 0.0, v); w = np.where(m, 1.0, w)
+        m = (vc <= 0) & (d1 >= 0) & (d3 <= 0); v = np.where(m, d1 / (d1 - d3), v); w = np.where(m, 0.0, w)
+        m = (d3 >= 0) & (d4 <= d3); v = np.where(m, 1.0, v); w = np.where(m, 0.0, w)
+        m = (d1 <= 0) & (d2 <= 0); v = np.where(m, 0.0, v); w = np.where(m, 0.0, w)
+    e = ap - v[..., None] * ab - w[..., None] * ac
+    d2_ = np.einsum("ntk,ntk->nt", e, e)
+    return np.where(np.isfinite(d2_), d2_, np.inf)
+
+
+def _sphere_hull_dist(sc, sr, bc, Rb, hull):
+    """signed distance of spheres to the convex hull of `hull` [nv, 3] (object frame) -- csrc/pbre_core.hpp: sphere_hull.  Faces from
+    scipy's Qhull (any triangulation of the surface gives the same distances)."""
+    from scipy.spatial import ConvexHull
+    H = ConvexHull(hull)
+    dl = np.einsum("nji,nj->ni", Rb, sc - bc)
+    sd = (dl @ H.equations[:, :3].T + H.equations[:, 3][None]).max(axis=1)       # largest signed plane distance: <= 0 inside
+    tri = hull[H.simplices]
+    dist = np.sqrt(_closest_on_triangles(dl, tri[:, 0], tri[:, 1], tri[:, 2]).min(axis=1))
+    return np.where(sd <= 0, sd - sr, dist - sr)
+
+
 def _shape_candidates(shape, h, Ro):
     """[N, 8, 3] candidate contact points of the object against its support (offsets, world axes) and [N, 8] validity"""
     n = Ro.shape[0]
@@ -99,9 +135,10 @@ def _shape_candidates(shape, h, Ro):
     return r, ok
 
 
-def contact_flags(table, state, ndof, phys, no_object=False):
+def contact_flags(table, state, ndof, phys, no_object=False, hull=None):
     """[N] uint8 of OBJECT_TABLE | ROBOT_OBJECT | ROBOT_TABLE for the batch state records state[N, F] (Q | V | X layout of
-    include/pbre.h: joints at [0, ndof), object position / quaternion behind them); phys = pbre_physics (Engine.get_physics())."""
+    include/pbre.h: joints at [0, ndof), object position / quaternion behind them); phys = pbre_physics (Engine.get_physics()).
+    hull: [nv, 3] vertices of a convex-hull object (phys.obj_shape 3: the vertex set handed to Engine.set_object_hull)."""
     table = np.asarray(table, float)
     st = np.asarray(state, float)
     n = st.shape[0]
@@ -120,13 +157,21 @@ def contact_flags(table, state, ndof, phys, no_object=False):
         li, c, rad = int(s[0]), s[1:4], float(s[4])
         sc = p[:, li] + np.einsum("nij,j->ni", R[:, li], c)
         if not no_object:
-            d_ro = _sphere_box_dist(sc, rad, op, Ro, oh) if shape == 0 else _sphere_round_dist(shape, sc, rad, op, Ro, oh)
+            if shape == 3:
+                if hull is None:
+                    raise ValueError("contact_flags: a convex-hull object needs its vertices (hull=)")
+                d_ro = _sphere_hull_dist(sc, rad, op, Ro, np.asarray(hull, float))
+            else:
+                d_ro = _sphere_box_dist(sc, rad, op, Ro, oh) if shape == 0 else _sphere_round_dist(shape, sc, rad, op, Ro, oh)
             flags |= np.where(d_ro < margin, ROBOT_OBJECT, 0).astype(np.uint8)
         flags |= np.where(_sphere_box_dist(sc, rad, np.broadcast_to(tc, (n, 3)), eye, th) < margin, ROBOT_TABLE, 0).astype(np.uint8)
     if not no_object:                     # the object's candidate points (box vertices / round primitives) against the table top
         top, bot = tc[2] + th[2], tc[2] - th[2]
-        cand, ok = _shape_candidates(shape, oh, Ro)
-        for v in range(8):
+        if shape == 3:
+            cand = np.einsum("nij,vj->nvi", Ro, np.asarray(hull, float)); ok = np.ones(cand.shape[:2], bool)      # every vertex is a candidate
+        else:
+            cand, ok = _shape_candidates(shape, oh, Ro)
+        for v in range(cand.shape[1]):
             x = op + cand[:, v]
             on = (np.abs(x[:, 0] - tc[0]) <= th[0]) & (np.abs(x[:, 1] - tc[1]) <= th[1]) & (x[:, 2] > bot) & ok[:, v]
             flags |= np.where(on & (x[:, 2] - top < margin), OBJECT_TABLE, 0).astype(np.uint8)

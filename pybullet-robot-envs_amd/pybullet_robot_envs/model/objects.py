@@ -9,7 +9,13 @@ the dynamics (shape, size, mass, principal inertias, lateral friction) instead o
     Manipulation Research", 2015, object table); box axes = the published x, y, z extents;
   * pybullet_data objects: approximate extents of the meshes at the scale their URDFs load them with [EXT-UNVERIFIED: the package is
     absent; cube_small is the 5 cm / 0.1 kg cube of SURVEY Appendix B].
-Lateral friction 1.0 (cube_small.urdf) for the pybullet_data objects, PyBullet's default 0.5 for the YCB URDFs [EXT-UNVERIFIED]."""
+Lateral friction 1.0 (cube_small.urdf) for the pybullet_data objects, PyBullet's default 0.5 for the YCB URDFs [EXT-UNVERIFIED].
+
+Round 6: where the object's MESH can be read -- `pybullet_data` / `pybullet_object_models` importable, or a directory of
+`<obj_name>.obj` files named by PBRE_OBJECT_MESH_DIR -- `object_physics` returns the object as a CONVEX HULL instead (obj_shape 3, at most 32
+vertices, mass properties of the uniform solid scaled to the table's mass): `hull_physics` / `find_mesh`.  The engine's narrow phase for it
+is include/pbre.h: pbre_set_object_hull.  Bullet collides each piece of a *_vhacd decomposition as a convex hull of its own; one hull of the
+whole mesh is its convex envelope [a documented deviation; the dominant contact geometry of a duck or a can on a table is its envelope]."""
 
 # name -> (full extents x, y, z [m], mass [kg], lateral friction)
 PYBULLET_DATA_OBJECTS = {
@@ -53,7 +59,8 @@ ROUND_OBJECTS = {
     "YcbTomatoSoupCan": ("cylinder", 0.033, 0.0505),
     "duck_vhacd": ("cylinder", 0.04, 0.04),        # a rounded body on a flat base: slides on its base, rolls on its side
 }
-SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER = 0, 1, 2
+SHAPE_BOX, SHAPE_SPHERE, SHAPE_CYLINDER, SHAPE_HULL = 0, 1, 2, 3
+HULL_MAXV = 32      # include/pbre.h PBRE_HULL_MAXV
 
 
 def object_physics(obj_name):
@@ -74,3 +81,126 @@ def object_physics(obj_name):
     r, hh = rnd[1], rnd[2]
     it = mass * (3.0 * r * r + 4.0 * hh * hh) / 12.0
     return {"obj_shape": SHAPE_CYLINDER, "obj_h": [r, r, hh], "obj_mass": mass, "obj_mu": mu, "obj_inertia": [it, it, 0.5 * mass * r * r]}
+
+
+# ---------------------------------------------------------------------------------------------------------------- convex-hull objects
+def read_obj_vertices(path):
+    """the `v x y z` records of a Wavefront .obj file -> [n, 3] float64"""
+    import numpy as np
+    out = []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                t = line.split()
+                out.append([float(t[1]), float(t[2]), float(t[3])])
+    if len(out) < 4:
+        raise ValueError("%s: fewer than 4 vertices" % path)
+    return np.asarray(out, np.float64)
+
+
+def _hull_mass_properties(pts, simplices):
+    """volume, centroid and inertia tensor about the centroid (unit density) of the closed triangle surface `simplices` over `pts`,
+    by signed tetrahedra against the origin (orientation fixed per triangle so that every tetrahedron counts positive for a convex body
+    around an interior point)."""
+    import numpy as np
+    c0 = pts.mean(0)
+    P = pts - c0
+    vol, cen = 0.0, np.zeros(3)
+    C = np.zeros((3, 3))                     # covariance integral  int x x^T dV
+    canon = np.array([[2, 1, 1], [1, 2, 1], [1, 1, 2]], float) / 120.0
+    for tri in simplices:
+        a, b, c = P[tri[0]], P[tri[1]], P[tri[2]]
+        det = float(np.dot(a, np.cross(b, c)))
+        if det < 0:
+            b, c = c, b
+            det = -det
+        A = np.stack([a, b, c], 1)           # columns
+        vol += det / 6.0
+        cen += det / 24.0 * (a + b + c)
+        C += det * A @ canon @ A.T
+    cen /= vol
+    C -= vol * np.outer(cen, cen)
+    I = np.trace(C) * np.eye(3) - C
+    return vol, cen + c0, I
+
+
+def reduce_vertices(pts, max_v=HULL_MAXV):
+    """at most max_v of the hull vertices of `pts`: all of them if they are few enough, else the extreme points along the coordinate axes
+    followed by farthest-point sampling (every kept point is a vertex of the original hull, so the reduced hull lies inside it)."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    hv = pts[ConvexHull(pts).vertices]
+    if len(hv) <= max_v:
+        return hv
+    keep = []
+    for k in range(3):
+        for i in (int(np.argmin(hv[:, k])), int(np.argmax(hv[:, k]))):
+            if i not in keep:
+                keep.append(i)
+    d = np.min(np.linalg.norm(hv[:, None, :] - hv[None, keep, :], axis=2), axis=1)
+    while len(keep) < max_v:
+        i = int(np.argmax(d))
+        keep.append(i)
+        d = np.minimum(d, np.linalg.norm(hv - hv[i], axis=1))
+    return hv[sorted(keep)]
+
+
+def hull_physics(vertices, mass, mu, scale=1.0):
+    """pbre_physics fields + `obj_hull` of the convex hull of `vertices` ([n, 3]; a mesh's vertex list): vertices relative to the centre
+    of mass of the uniform solid, obj_h = half extents of their bounding box about it, obj_inertia = the diagonal of the solid's inertia
+    tensor in the mesh's own axes (the engine's object frame keeps the mesh's axes -- what the object's observed Euler angles refer to --,
+    so products of inertia are dropped: exact for the symmetric objects, an approximation otherwise)."""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    v = reduce_vertices(np.asarray(vertices, np.float64) * float(scale))
+    h = ConvexHull(v)
+    vol, cen, I = _hull_mass_properties(v, h.simplices)
+    v = v[np.sort(h.vertices)] - cen
+    dens = mass / vol
+    return {"obj_shape": SHAPE_HULL, "obj_hull": v, "obj_h": [float(np.abs(v[:, k]).max()) for k in range(3)], "obj_mass": mass, "obj_mu": mu,
+            "obj_inertia": [float(dens * I[k, k]) for k in range(3)]}
+
+
+def find_mesh(obj_name):
+    """path of the collision mesh of `obj_name`, or None: PBRE_OBJECT_MESH_DIR/<name>.obj, then the packages the reference loads its objects
+    from (world_env.py:14-15, 61-84, 179-216) when they are importable"""
+    import os
+    key = obj_name[:-5] if obj_name.endswith(".urdf") else obj_name
+    base = os.path.basename(key)
+    cands = []
+    d = os.environ.get("PBRE_OBJECT_MESH_DIR")
+    if d:
+        cands += [os.path.join(d, base + ".obj"), os.path.join(d, key + ".obj")]
+    try:
+        import pybullet_data
+        root = pybullet_data.getDataPath()
+        cands += [os.path.join(root, key + ".obj"), os.path.join(root, base + ".obj")]
+    except Exception:
+        pass
+    try:
+        from pybullet_object_models import ycb_objects
+        root = ycb_objects.getDataPath()
+        cands += [os.path.join(root, key, "collision_vhacd.obj"), os.path.join(root, key, "textured_simple_reoriented.obj")]
+    except Exception:
+        pass
+    for c in cands:
+        if os.path.isfile(c):
+            return c
+    return None
+
+
+_primitive_physics = object_physics
+
+
+def object_physics(obj_name, use_mesh=True):      # noqa: F811  (wraps the table lookup above)
+    """the object's pbre_physics fields: its mesh's convex hull where the mesh can be read (find_mesh), the primitive stand-in otherwise"""
+    prim = _primitive_physics(obj_name)
+    path = find_mesh(obj_name) if use_mesh else None
+    if path is None or prim["obj_shape"] == SHAPE_BOX and (obj_name[:-5] if obj_name.endswith(".urdf") else obj_name) == "cube_small":
+        return prim
+    try:
+        return hull_physics(read_obj_vertices(path), prim["obj_mass"], prim["obj_mu"])
+    except Exception as e:      # an unreadable mesh must not take the env down: the stand-in is the documented fallback
+        import warnings
+        warnings.warn("object %r: mesh %s not usable (%s); using the primitive stand-in" % (obj_name, path, e))
+        return prim

@@ -5,6 +5,7 @@
 // loads this library; it is neither shipped nor a fallback.
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 #include "lanes_host.hpp"
@@ -79,7 +80,7 @@ struct Emu : pbre_ctx {
     void step_env(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id = 0, const float* tg = nullptr) {
         if (P.res_lim > 0.f) { step_env_rt(st, act, out, mode, flags, env_id, tg); return; }
         if constexpr (PANDA) {
-            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
+            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL) && P.obj_shape != PBRE_SHAPE_HULL) {
                 // the class is recomputed here instead of being carried from the previous step
                 if (FastH::classify_state(T, P, st, flags) == 0) {
                     n_fast++;
@@ -120,7 +121,7 @@ struct Emu : pbre_ctx {
         }
         if constexpr (std::is_same<S, Shape32>::value) {
             // the device's kw_lane / kw_list pair (pbre_wide.hip): task-env steps of the whole batch; settle steps stay on the lane-group kernel
-            if (lane_ok && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
+            if (lane_ok && P.obj_shape != PBRE_SHAPE_HULL && (mode & (CoreH::M_OBS | CoreH::M_TASK))) {
                 if (LaneH::classify_state(T, P, st, flags) == 0) {
                     n_fast++;
                     float mi[LaneH::NM];
@@ -141,7 +142,7 @@ struct Emu : pbre_ctx {
         if constexpr (!PANDA) {
             // the device's kw_obj + kw_step pair (pbre_wide_impl.hpp): the object's half of the step per env, used by Core::step
             // when the group has no robot-object contact
-            if (obj_split && !(flags & 1)) {
+            if (obj_split && !(flags & 1) && P.obj_shape != PBRE_SHAPE_HULL) {
                 float side[W] = {0.f}, pose[7], tw[6], o[6];
                 for (int k = 0; k < 7; k++) pose[k] = st[S::LC + k];
                 for (int k = 0; k < 6; k++) tw[k] = st[W + S::LC + k];
@@ -158,7 +159,7 @@ struct Emu : pbre_ctx {
     void step_env_rt(float* st, const float* act, float* out, int mode, int flags, unsigned long long env_id, const float* tg) {
         int* sw = &sweeps[(size_t)(st - state.data()) / STATE];
         if constexpr (PANDA) {
-            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL)) {
+            if (fast_ok && !(cfg.flags & PBRE_F_FORCE_GENERAL) && P.obj_shape != PBRE_SHAPE_HULL) {
                 if (FastH::classify_state(T, P, st, flags) == 0) { n_fast++; count_bad(FastH::template step<true>(T, P, st, act, out, mode, flags, env_id, tg, sw)); }
                 else if ((cfg.flags & PBRE_F_COMPLEX_ROWS) || !P.obj_iso || P.obj_shape != 0) {
                     n_rc++;
@@ -384,6 +385,23 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
     c->step(actions, out);
     return PBRE_OK;
 }
+// (the pipelined host path: on the host runtime a step is done when the call returns; the bookkeeping -- at most two in flight, wait needs
+// one -- is the device library's)
+static thread_local long g_async_in_flight = 0;
+int pbre_step_async(pbre_ctx* c, const float* actions, float* out) {
+    if (!c || !actions || !out) return PBRE_E_ARG;
+    if (c->sf != 48) { c->err = "pbre_step_async: implemented for the Panda task envs"; return PBRE_E_UNSUPPORTED; }
+    if (g_async_in_flight >= 2) { c->err = "pbre_step_async: two steps are in flight already -- pbre_step_wait first"; return PBRE_E_ARG; }
+    const int rc = pbre_step(c, actions, out);
+    if (rc == PBRE_OK) g_async_in_flight++;
+    return rc;
+}
+int pbre_step_wait(pbre_ctx* c) {
+    if (!c) return PBRE_E_ARG;
+    if (g_async_in_flight <= 0) { c->err = "pbre_step_wait: no step in flight"; return PBRE_E_ARG; }
+    g_async_in_flight--;
+    return PBRE_OK;
+}
 int pbre_step_device(pbre_ctx* c, const float* a, float* o, void*) { return pbre_step(c, a, o); }
 int pbre_sync(pbre_ctx*) { return PBRE_OK; }
 
@@ -448,6 +466,20 @@ int pbre_set_physics(pbre_ctx* c, const pbre_physics* phys) {
     if (c->fast_ok && !fast_scene_ok(P2)) { c->err = "the lane-per-env kernels need explicit joint damping"; return PBRE_E_UNSUPPORTED; }
     if (snapshot_relevant_change(c->cfg.phys, *phys)) { c->stale_snapshot = c->stale_snapshot || c->have_snapshot; c->have_snapshot = false; P2.rst_ok = 0; }
     c->cfg = cfg; c->P = P2;
+    return PBRE_OK;
+}
+int pbre_set_object_hull(pbre_ctx* c, const double* verts, int32_t n_verts) {      // same host code as the device library (csrc/pbre_host.hpp: build_hull); the table stays in host memory
+    if (!c) return PBRE_E_ARG;
+    static thread_local std::vector<std::unique_ptr<HullTable>> keep;      // (tables live as long as the process: a ctx's Params points into one)
+    std::unique_ptr<HullTable> H(new HullTable);
+    const std::string e = build_hull(verts, n_verts, *H);
+    if (!e.empty()) { c->err = e; return PBRE_E_ARG; }
+    c->P.hull = H->data; c->P.hull_nv = H->nv; c->P.hull_nf = H->nf; c->P.hull_rb = H->rb; c->P.obj_shape = PBRE_SHAPE_HULL;
+    c->cfg.phys.obj_shape = PBRE_SHAPE_HULL;
+    for (int k = 0; k < 3; k++) { c->cfg.phys.obj_h[k] = H->half[k]; c->P.obj_h[k] = (float)H->half[k]; }
+    c->P.rst_objz = (float)(c->cfg.h_table + H->half[2]);
+    c->stale_snapshot = c->stale_snapshot || c->have_snapshot; c->have_snapshot = false; c->P.rst_ok = 0;
+    keep.push_back(std::move(H));
     return PBRE_OK;
 }
 int pbre_set_physics_per_env(pbre_ctx* c, const uint8_t* mask, const float* obj_mass, const float* obj_mu, const float* obj_lin_damping,

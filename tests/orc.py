@@ -44,7 +44,8 @@ class Params(C.Structure):
                 ("table_c", C.c_double * 3), ("table_h", C.c_double * 3), ("table_mu", C.c_double),
                 ("ground_z", C.c_double), ("obj_h", C.c_double * 3), ("obj_mass", C.c_double),
                 ("obj_inertia", C.c_double * 3), ("obj_mu", C.c_double), ("flags", C.c_int), ("implicit_joint_damping", C.c_int),
-                ("obj_shape", C.c_int), ("solver_residual_threshold", C.c_double)]
+                ("obj_shape", C.c_int), ("solver_residual_threshold", C.c_double),
+                ("obj_hull_n", C.c_int), ("obj_hull", (C.c_double * 3) * 32)]      # obj_shape 3: vertices of the convex hull (oracle/pbre_oracle.h ORC_MAXHV)
 
 
 class Task(C.Structure):
@@ -272,6 +273,15 @@ def set_object(o, ph):
         o.params.obj_inertia[k] = ph["obj_inertia"][k]
     o.params.obj_mass, o.params.obj_mu = ph["obj_mass"], ph["obj_mu"]
     o.params.obj_shape = int(ph.get("obj_shape", 0))
+    hull = ph.get("obj_hull")
+    o.params.obj_hull_n = 0
+    if hull is not None:
+        hull = np.asarray(hull, np.float64)
+        assert hull.ndim == 2 and hull.shape[1] == 3 and 4 <= len(hull) <= 32
+        o.params.obj_hull_n = len(hull)
+        for i, v in enumerate(hull):
+            for k in range(3):
+                o.params.obj_hull[i][k] = float(v[k])
 
 
 def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, floating_base=False, **kw):

@@ -34,7 +34,7 @@ def run_world(kind, world, total, steps, mode="closed", timeout=300):
     return outs
 
 
-@pytest.mark.parametrize("world,mode", [(2, "closed"), (4, "closed"), (2, "open")])
+@pytest.mark.parametrize("world,mode", [(2, "closed"), (4, "closed"), (2, "open"), (8, "closed"), (8, "open")])      # (8: the driver's SCALE run is --gpus 8)
 def test_context_owned_gather_and_scatter_world_gt_1(emu_lib, world, mode):
     run_world("emu", world, 8 * world, 8, mode)
 

@@ -248,6 +248,29 @@ def test_round_objects(panda, emu_lib, flags):
     assert rep["YcbTennisBall"]["travel_cm"] > 5 and rep["YcbTomatoSoupCan"]["travel_cm"] > 5
 
 
+def test_convex_hull_objects(panda, emu_lib):
+    """the object as a convex hull (pbre_set_object_hull) -- the cube as its 8 vertices (must reproduce the box primitive), a
+    tetrahedron, a 20-vertex blob and a 32-vertex one (two candidate passes on the 16-lane shape) -- against the oracle's brute-force hull"""
+    rep = parity.check_hull_objects(_capi.Engine, emu_lib, panda["table"], n=4)
+    print("hull objects:", {k: {kk: v[kk] for kk in ("reset_rel", "rest_height", "obj_w", "skipped", "compared", "robot_contact_compared") if kk in v} for k, v in rep.items()})
+    assert all(v["robot_contact_compared"] >= 2 for v in rep.values())
+
+
+def test_hull_entry_point_rejects_bad_vertex_sets(panda, emu_lib):
+    eng = _capi.Engine(panda["table"], task=1, num_envs=1, lib=emu_lib)
+    for bad in (np.zeros((3, 3)), np.zeros((33, 3)), np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0.0]]), np.full((5, 3), np.nan)):
+        with pytest.raises(RuntimeError):
+            eng.set_object_hull(bad)
+    assert eng.get_physics().obj_shape == 0                      # a refused hull leaves the object as it was
+    eng.set_object_hull(0.03 * np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1.0]]))
+    assert eng.get_physics().obj_shape == 3 and abs(eng.get_physics().obj_h[2] - 0.03) < 1e-12
+    eng.set_physics(obj_mass=0.2)                                # keeps the hull
+    assert eng.get_physics().obj_shape == 3
+    eng.set_physics(obj_shape=0)                                 # back to the box primitive
+    assert eng.get_physics().obj_shape == 0
+    eng.close()
+
+
 def test_closed_form_motor_rows_match_the_sequential_rows(panda, emu_lib):
     """The simple class applies its 150 sweeps over the clamp-free motor rows in closed form (a matrix power, Fast::motor_closed);
     PBRE_F_SEQ_MOTORS runs Bullet's sequential rows instead.  Same states, one step each: the object (which the motor rows do not

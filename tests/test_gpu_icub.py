@@ -309,3 +309,36 @@ def test_icub_floating_base_option(hip_lib, use_ik):
     effect on the hand's observation against the rigidly pinned default model."""
     rep = parity.check_icub_floating_base(_capi.Engine, hip_lib, n=4, steps=3, use_ik=use_ik)
     assert rep["ee_pos_shift_vs_pinned_base_40_steps_m"] < 2e-3
+
+
+def _write_chamfered_box_obj(path, full=(0.09, 0.07, 0.08), b=0.012):
+    """a synthetic "duck_vhacd.obj": a box of the duck stand-in's extents with its corners cut off (24 hull vertices) plus a few interior
+    vertices a real mesh would have -- no mesh of the reference's objects exists on any box"""
+    hx, hy, hz = (0.5 * x for x in full)
+    vs = []
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                vs += [(sx * (hx - b), sy * hy, sz * hz), (sx * hx, sy * (hy - b), sz * hz), (sx * hx, sy * hy, sz * (hz - b))]
+    vs += [(0.0, 0.0, 0.0), (0.01, -0.01, 0.02), (-0.02, 0.01, -0.01)]
+    with open(path, "w") as f:
+        f.write("# synthetic test mesh\n")
+        for v in vs:
+            f.write("v %.6f %.6f %.6f\n" % (v[0] + 0.003, v[1] - 0.002, v[2] + 0.001))      # (mesh origin off the centre of mass)
+        f.write("f 1 2 3\n")
+
+
+@pytest.mark.gpu
+def test_icub_hull_object_from_a_mesh_file(hip_lib, tmp_path, monkeypatch):
+    """SURVEY 8(f4) end to end: `obj_name` -> mesh file (PBRE_OBJECT_MESH_DIR; pybullet_data / pybullet_object_models where importable) ->
+    convex hull (model/objects.py: hull_physics: <= 32 vertices about the centre of mass, mass properties of the solid) ->
+    pbre_set_object_hull -> the iCub engine's lane-group kernel (W = 32: one candidate pass), crafted contact states against the oracle"""
+    from pybullet_robot_envs.model import objects
+    _write_chamfered_box_obj(str(tmp_path / "duck_vhacd.obj"))
+    assert objects.object_physics("duck_vhacd")["obj_shape"] == 2            # no mesh anywhere: the cylinder stand-in
+    monkeypatch.setenv("PBRE_OBJECT_MESH_DIR", str(tmp_path))
+    ph = objects.object_physics("duck_vhacd")
+    assert ph["obj_shape"] == 3 and len(ph["obj_hull"]) == 24 and abs(ph["obj_h"][0] - 0.045) < 1e-9 and abs(ph["obj_h"][2] - 0.04) < 1e-9
+    assert np.abs(np.asarray(ph["obj_hull"]).mean(0)).max() < 1e-9           # about the centre of mass (a symmetric solid: its centroid)
+    rep = parity.check_icub_contact_states(_capi.Engine, hip_lib, n_each=12, obj_name="duck_vhacd")
+    assert rep["states"] == 4 * 12 and rep["complex_envs_stepped"] >= 0

@@ -432,6 +432,15 @@ def test_round_objects(panda, hip_lib, flags):
     print("round objects:", {k: {kk: v[kk] for kk in ("travel_cm", "free_run_obj_pos_diff", "obj_w", "skipped", "compared", "robot_contact_compared") if kk in v} for k, v in rep.items()})
 
 
+def test_convex_hull_objects(panda, hip_lib):
+    """the object as a convex hull (pbre_set_object_hull; k_step: Core's hull candidates + sphere_hull) -- the cube as its 8
+    vertices (reproduces the box primitive: object-table rows bit for bit), a tetrahedron, a 20- and a 32-vertex blob -- reset, sliding /
+    spinning single steps and robot-object contacts at faces and vertices against the oracle's brute-force hull"""
+    rep = parity.check_hull_objects(_capi.Engine, hip_lib, panda["table"], n=24)
+    print("hull objects:", {k: {kk: v[kk] for kk in ("reset_rel", "rest_height", "obj_w", "skipped", "compared", "robot_contact_compared") if kk in v} for k, v in rep.items()})
+    assert all(v["robot_contact_compared"] >= 12 for v in rep.values())
+
+
 def test_closed_form_motor_rows_match_the_sequential_rows(panda, hip_lib):
     """The simple class applies its 150 sweeps over the clamp-free motor rows in closed form (a matrix power, Fast::motor_closed);
     PBRE_F_SEQ_MOTORS runs Bullet's sequential rows instead.  Same states, one step each: the object (which the motor rows do not
@@ -614,6 +623,44 @@ def test_staged_copies_match_zero_copy_host_buffers(panda, hip_lib, monkeypatch)
         for x, y in zip(a.step(act), b.step(act)):
             assert np.array_equal(x, y)
     assert a.kernel_info()[7] > 0          # complex env-steps were among them
+
+
+def test_pipelined_host_path_is_bit_equal_to_the_synchronous_one(panda, hip_lib):
+    """pbre_step_async / pbre_step_wait (round 6: upload, kernels and download of consecutive steps overlap on three streams, two steps in
+    flight) against pbre_step: the same rows, bit for bit, over 40 steps with auto-reset and contact-rich envs; the bookkeeping errors
+    (a third step in flight, a wait without a step) are refused; a host-synchronous call in between does not lose rows."""
+    n = 4096
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=30)
+    a = _capi.Engine(panda["table"], **kw)
+    b = _capi.Engine(panda["table"], **kw)
+    a.reset(); b.reset()
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(2), 6, 6).astype(np.float32)
+    st = a.get_state()
+    st[:len(S), :S.shape[1]] = S
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(12)
+    acts = rng.uniform(-1, 1, (40, n, 7)).astype(np.float32)
+    ref = [a.step(acts[t]) for t in range(40)]
+    with pytest.raises(RuntimeError):
+        b.step_async(acts[0]); b.step_async(acts[1]); b.step_async(acts[2])      # the third is refused (nothing was enqueued for it)
+    got = [b.step_wait(copy=True), b.step_wait(copy=True)]
+    with pytest.raises(RuntimeError):
+        b.step_wait()
+    b.step_async(acts[2])
+    for t in range(3, 40):
+        b.step_async(acts[t])
+        if t == 20:
+            assert np.isfinite(b.get_state()).all()           # a host-synchronous entry point with two steps in flight
+        got.append(b.step_wait(copy=True))
+    got.append(b.step_wait(copy=True))
+    assert len(got) == 40
+    for t in range(40):
+        for x, y in zip(ref[t], got[t]):
+            assert np.array_equal(x, y), t
+    assert np.array_equal(a.get_state(), b.get_state()) and a.kernel_info()[7] > 0
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("use_ik", [0, 1])
