@@ -655,17 +655,20 @@ def main():
             # round 6: the same metric PIPELINED (pbre_step_async / pbre_step_wait: upload, kernels and download of consecutive steps on three
             # streams, two steps in flight) -- an open loop, like `value`; the floor is the row download over PCIe
             ns = 40
-            eng.step_async(acts[0])
-            for k in range(1, 4):
-                eng.step_async(acts[k % 4]); eng.step_wait()
+            for k in range(4):
+                eng.step_pipelined(acts[k % 4])
+            calls = []
             t0 = time.perf_counter()
             for k in range(ns):
-                eng.step_async(acts[k % 4]); eng.step_wait()
+                tc = time.perf_counter()
+                eng.step_pipelined(acts[k % 4])      # (copy the actions into the page-locked slot, wait for the rows of the step before last, enqueue)
+                calls.append(time.perf_counter() - tc)
             el = time.perf_counter() - t0
-            eng.step_wait()
+            eng.step_wait(); eng.step_wait()
             row_mb = n_local * (eng.obs_dim + 2) * 4 / 1e6
             host = {"value": n_local * ns / el, "unit": "env-steps/s", "ms_per_step": el / ns * 1e3,
                     "rows_MB_per_step": row_mb, "d2h_GBps_if_download_bound": row_mb / (el / ns * 1e3),
+                    "ms_per_call_last_8": [round(x * 1e3, 3) for x in calls[-8:]],
                     "synchronous": sync,
                     "note": "SURVEY 8(d) literal metric: numpy actions in page-locked memory in, [obs|reward|done] rows out, upload + kernels + download, pipelined over "
                             "calls (Engine.step_async / step_wait, open loop, two steps in flight); never `value`, which is device-resident stepping (pbre_step_device)"}

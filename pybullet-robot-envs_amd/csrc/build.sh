@@ -21,7 +21,10 @@ for u in $UNITS; do
     OBJS="$OBJS obj/$name.o"; LOGS="$LOGS obj/$name.log"
     stale=0
     [ -f obj/$name.o ] || stale=1
-    for f in $src $HDRS; do [ $stale = 1 ] || [ obj/$name.o -nt $f ] || stale=1; done
+    # the unit's own headers (host-side preprocessor pass, < 0.1 s), not the whole list: a change to pbre_lane.hpp rebuilds pbre_lane.hip only
+    deps=$($HIPCC --offload-arch=gfx950 -std=c++17 --cuda-host-only -MM $extra $src 2>/dev/null | tr ' \\' '\n\n' | grep -E "^[A-Za-z_./]+\.(hpp|h|hip)$" | grep -v "^/" | sort -u | tr '\n' ' ')
+    [ -n "$deps" ] || deps="$src $HDRS"
+    for f in $deps build.sh; do [ $stale = 1 ] || [ obj/$name.o -nt $f ] || stale=1; done
     if [ $stale = 1 ]; then
         while [ $running -ge $JOBS ]; do wait -n || rc=1; running=$((running - 1)); done
         ( $HIPCC $FLAGS $extra -c -o obj/$name.o.tmp $src 2> obj/$name.log && mv obj/$name.o.tmp obj/$name.o ) &

@@ -114,7 +114,7 @@ static hipError_t quiesce(pbre_ctx* c) {
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
     if (c->ap.ready) {      // the pipelined host path's copies (their rows are still delivered: pbre_step_wait finds the events complete)
         if ((e = hipStreamSynchronize(c->ap.s_in)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(c->ap.s_out)) != hipSuccess) return e;
+        for (int b = 0; b < 2; b++) if ((e = hipStreamSynchronize(c->ap.s_out[b])) != hipSuccess) return e;
     }
     return hipStreamSynchronize(c->side);
 }
@@ -214,13 +214,13 @@ void pbre_destroy(pbre_ctx* c) {
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ap.ready) {
-        (void)hipStreamSynchronize(c->ap.s_in); (void)hipStreamSynchronize(c->ap.s_out);
+        (void)hipStreamSynchronize(c->ap.s_in); (void)hipStreamSynchronize(c->ap.s_out[0]); (void)hipStreamSynchronize(c->ap.s_out[1]);
         for (int b = 0; b < 2; b++) {
             if (c->ap.d_act[b]) (void)hipFree(c->ap.d_act[b]);
             if (c->ap.d_rows[b]) (void)hipFree(c->ap.d_rows[b]);
             for (hipEvent_t e : {c->ap.ev_in[b], c->ap.ev_step[b], c->ap.ev_out[b]}) if (e) (void)hipEventDestroy(e);
         }
-        (void)hipStreamDestroy(c->ap.s_in); (void)hipStreamDestroy(c->ap.s_out);
+        (void)hipStreamDestroy(c->ap.s_in); (void)hipStreamDestroy(c->ap.s_out[0]); (void)hipStreamDestroy(c->ap.s_out[1]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -498,17 +498,24 @@ int pbre_step(pbre_ctx* c, const float* actions, float* out) {
 // 0.44 ms instead of 0.15 at 131072 envs).  Here the three run on three streams with two buffer slots, so that in an open loop the DMA
 // engines download the rows of step t (18.4 MB at 131072 envs: the PCIe floor, ~0.33 ms) while the kernels of step t + 1 run and the
 // actions of step t + 2 come up.  Same kernels, same order per env: rows bit-equal to pbre_step's.
+// rows out by a copy KERNEL (PBRE_ASYNC_D2H=1; A/B): coalesced 16-byte stores into the page-locked host buffer from a few waves on the
+// download stream.  Measured (profiles/r06k_host_async_probe.txt): 54 GB/s alone, but beside k_fused -- which holds every wave slot -- the
+// pipelined step is 0.56 ms against 0.47 with the DMA engine (hipMemcpyAsync, the default: 55 GB/s and no wave slots)
+__global__ __launch_bounds__(256) void k_rows_out(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 static int async_setup(pbre_ctx* c) {
     if (c->ap.ready) return PBRE_OK;
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(hipStreamCreateWithPriority(&c->ap.s_in, hipStreamNonBlocking, hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->ap.s_out, hipStreamNonBlocking, hi));
+    for (int b = 0; b < 2; b++) HIPCHK(hipStreamCreateWithPriority(&c->ap.s_out[b], hipStreamNonBlocking, hi));
     for (int b = 0; b < 2; b++) {
         HIPCHK(hipMalloc(&c->ap.d_act[b], (size_t)c->n * c->act_dim * 4));
         HIPCHK(hipMalloc(&c->ap.d_rows[b], (size_t)c->n * c->ow * 4));
         for (hipEvent_t* e : {&c->ap.ev_in[b], &c->ap.ev_step[b], &c->ap.ev_out[b]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
+    if (const char* e = getenv("PBRE_ASYNC_BLOCKS")) c->async_blocks = std::max(1, atoi(e));
     c->ap.ready = true;
     return PBRE_OK;
 }
@@ -529,12 +536,32 @@ int pbre_step_async(pbre_ctx* c, const float* actions, float* out) {
     // step: behind its upload and behind the download that last read this slot's row buffer
     HIPCHK(hipStreamWaitEvent(c->stream, A.ev_in[b], 0));
     if (A.issued >= 2) HIPCHK(hipStreamWaitEvent(c->stream, A.ev_out[b], 0));
-    HIPCHK(full_step(c, A.d_act[b], A.d_rows[b], c->stream));
+    // PBRE_ASYNC_D2H: how the rows reach the host buffer -- 0 the DMA engine (hipMemcpyAsync), 1 a copy kernel on the download stream, 2 the
+    // step kernels write them into the page-locked buffer themselves (pbre_step's zero-copy, minus its host synchronisation)
+    static const int d2h_mode = [] { const char* e = getenv("PBRE_ASYNC_D2H"); return e ? atoi(e) : 0; }();
+    const size_t bytes = (size_t)c->n * c->ow * 4;
+    bool host_mapped = false;
+    if (d2h_mode != 0) {
+        hipPointerAttribute_t pa;
+        host_mapped = hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+    }
+    const bool direct = d2h_mode == 2 && host_mapped;
+    c->rows_to_host = direct;
+    const hipError_t fe = full_step(c, A.d_act[b], direct ? out : A.d_rows[b], c->stream);
+    c->rows_to_host = false;
+    HIPCHK(fe);
     HIPCHK(hipEventRecord(A.ev_step[b], c->stream));
     // download
-    HIPCHK(hipStreamWaitEvent(A.s_out, A.ev_step[b], 0));
-    HIPCHK(hipMemcpyAsync(out, A.d_rows[b], (size_t)c->n * c->ow * 4, hipMemcpyDeviceToHost, A.s_out));
-    HIPCHK(hipEventRecord(A.ev_out[b], A.s_out));
+    HIPCHK(hipStreamWaitEvent(A.s_out[b], A.ev_step[b], 0));
+    if (!direct) {
+        const bool mapped = d2h_mode == 1 && (bytes % 16) == 0 && ((uintptr_t)out % 16) == 0 && host_mapped;
+        if (mapped) {
+            hipLaunchKernelGGL(k_rows_out, dim3(c->async_blocks), dim3(256), 0, A.s_out[b], (const float4*)A.d_rows[b], (float4*)out, bytes / 16);
+            HIPCHK(hipGetLastError());
+        } else HIPCHK(hipMemcpyAsync(out, A.d_rows[b], bytes, hipMemcpyDeviceToHost, A.s_out[b]));
+    }
+    HIPCHK(hipEventRecord(A.ev_out[b], A.s_out[b]));
     A.issued++;
     return PBRE_OK;
 }
@@ -544,7 +571,7 @@ int pbre_step_wait(pbre_ctx* c) {
     pbre_ctx::AsyncPath& A = c->ap;
     if (!A.ready || A.waited >= A.issued) { c->err = "pbre_step_wait: no step in flight"; return PBRE_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventSynchronize(A.ev_out[A.waited & 1]));
+    HIPCHK(hipStreamSynchronize(A.s_out[A.waited & 1]));
     A.waited++;
     return PBRE_OK;
 }

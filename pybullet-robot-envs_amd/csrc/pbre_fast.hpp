@@ -364,10 +364,115 @@ struct Fast {
             square(G, H);
         }
     }
+    // Bullet's residual exit over the clamp-free motor rows WITHOUT running every sweep (round 6; step_t<false, 0, true>).  In: e = w0 - t.
+    // A motor row's velocity-level change |delta impulse / jacDiagABInv| is |e_j| at its turn, so the exit test of sweep `it` is
+    // max_j |e_j at row j's turn| <= tau (the object's rows pass or fail by `opass`: bit it for it < OK, pass from OK on).  The sweeps
+    // alternate direction (rows ND-1..0, then 0..ND-1); after the first pair e_{ND-1} = 0 at every pair boundary and a pair is the
+    // NH x NH map H of motor_closed.  Scan: the first pair explicitly; then COARSE steps of eight pairs with H^8 (three squarings), each
+    // followed by a trial pair from the state it reaches -- a lane advances while that trial pair does not pass; then explicit pairs
+    // from where the lane stopped until one passes (at most eight + the tail).  At most 1 + 9 + 9 explicit pairs instead of 75.
+    // The scan finds the first passing sweep among those it visits: every sweep from the lane's last coarse stop on, and the trial
+    // pairs before it.  It would miss a sweep that passes INSIDE an earlier coarse block while the block's end does not (a residual
+    // that is not decreasing in the sweep index); `mono` is cleared when the trial pairs' residuals do not decrease, and such a lane
+    // takes the explicit rows.  Out: e = the error after the exit sweep (or after sweep iters - 1); returns the sweeps used.
+    static PBRE_HD int motor_scan(const float* A, const float* dinv, float* e, int iters, float tau, unsigned opass, int OK, bool& mono) {
+        auto row = [&](float* v, int j, float& r) {
+            r = fmaxf(r, fabsf(v[j]));
+            const float s = v[j] * dinv[j];
+            PBRE_UNROLL for (int k = 0; k < ND; k++) if (k != j) v[k] = fmaf(-s, A[sym(k, j)], v[k]);
+            v[j] = 0.f;
+        };
+        int used = iters;
+        bool found = false;
+        float ex[ND];
+        PBRE_UNROLL for (int k = 0; k < ND; k++) ex[k] = 0.f;
+        auto passes = [&](int it, float r) -> bool { const bool po = it >= OK || ((opass >> (it & 31)) & 1u) != 0u; return r <= tau && po && it < iters; };
+        auto commit = [&](int it, float r, const float* v, bool live = true) {
+            const bool hit = live && !found && passes(it, r);
+            PBRE_UNROLL for (int k = 0; k < ND; k++) ex[k] = hit ? v[k] : ex[k];
+            used = hit ? it + 1 : used;
+            found = found || hit;
+        };
+        {   // sweeps 0 and 1
+            float r = 0.f;
+            PBRE_UNROLL for (int j = ND - 1; j >= 0; j--) row(e, j, r);
+            commit(0, r, e);
+            r = 0.f;
+            PBRE_UNROLL for (int j = 1; j < ND; j++) row(e, j, r);
+            commit(1, r, e);
+        }
+        mono = true;
+        const int mlast = (iters >> 1) - 1;           // index of the last pair
+        int m = 1;                                      // the pair the lane's state `e` is the start of
+        if (mlast >= 1) {
+            float H[NH][NH], G[NH][NH];
+            PBRE_UNROLL for (int c = 0; c < NH; c++) {
+                float v[ND], rr = 0.f;
+                PBRE_UNROLL for (int k = 0; k < ND; k++) v[k] = k == c ? 1.f : 0.f;
+                PBRE_UNROLL for (int j = NH - 1; j >= 0; j--) if (j <= c) row(v, j, rr);
+                PBRE_UNROLL for (int j = 1; j < ND; j++) row(v, j, rr);
+                PBRE_UNROLL for (int k = 0; k < NH; k++) H[k][c] = v[k];
+            }
+            auto square = [&](const float (*X)[NH], float (*Y)[NH]) {
+                PBRE_UNROLL for (int i = 0; i < NH; i++)
+                    PBRE_UNROLL for (int c = 0; c < NH; c++) {
+                        float a = 0.f;
+                        PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(X[i][k], X[k][c], a);
+                        Y[i][c] = a;
+                    }
+            };
+            square(H, G); square(G, H); square(H, G);           // G = H^8
+            bool stop = false;
+            float r_last = 3e38f;
+            for (int c = 0; c < 9; c++) {
+                float v[ND], rR = 0.f, rF = 0.f;
+                PBRE_UNROLL for (int i = 0; i < NH; i++) {
+                    float a = 0.f;
+                    PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(G[i][k], e[k], a);
+                    v[i] = a;
+                }
+                v[NH] = 0.f;
+                float cand[NH];
+                PBRE_UNROLL for (int i = 0; i < NH; i++) cand[i] = v[i];
+                PBRE_UNROLL for (int j = NH - 1; j >= 0; j--) row(v, j, rR);
+                PBRE_UNROLL for (int j = 1; j < ND; j++) row(v, j, rF);
+                const int mt = m + 8;
+                const bool exit_here = passes(2 * mt, rR) || passes(2 * mt + 1, rF);
+                const bool adv = !found && !stop && !exit_here && mt <= mlast;
+                mono = mono && !(adv && !(rF <= r_last));
+                r_last = adv ? rF : r_last;
+                PBRE_UNROLL for (int i = 0; i < NH; i++) e[i] = adv ? cand[i] : e[i];
+                m = adv ? mt : m;
+                stop = stop || !adv;
+                if (!PBRE_ANY(!stop && !found)) break;
+            }
+            for (int f = 0; f < 10; f++) {
+                const bool live = !found && m <= mlast;
+                if (!PBRE_ANY(live)) break;
+                float v[ND], r = 0.f;
+                PBRE_UNROLL for (int i = 0; i < NH; i++) v[i] = e[i];
+                v[NH] = 0.f;
+                PBRE_UNROLL for (int j = NH - 1; j >= 0; j--) row(v, j, r);
+                commit(2 * m, r, v, live);
+                r = 0.f;
+                PBRE_UNROLL for (int j = 1; j < ND; j++) row(v, j, r);
+                commit(2 * m + 1, r, v, live);
+                PBRE_UNROLL for (int i = 0; i < NH; i++) e[i] = live ? v[i] : e[i];
+                m = live ? m + 1 : m;
+            }
+            e[NH] = 0.f;
+        }
+        PBRE_UNROLL for (int k = 0; k < ND; k++) e[k] = found ? ex[k] : e[k];
+        return used;
+    }
     // Closed form of `n` sweeps over the object-table rows (see the simple class's solver section in step_t for the derivation and the
     // validity bound).  rx, ry, rz: scaled lever arms of the NK slots; dinv = 1 / |J|^2 per row (0: slot unused, its rows are no-ops);
     // rhs: the normal rows' right-hand sides (already multiplied by dinv); app: impulses applied so far; v, u: linear velocity and scaled
     // angular velocity after the explicit sweeps.  xo: the twist after n more sweeps.  Returns whether no clamp can bind in them.
+    // PERLANE (round 6, Bullet's residual exit): `n` differs from lane to lane (0 .. iters - OC_K: the sweeps between the explicit ones and the
+    // lane's exit sweep) -- the squarings run until every lane's exponent is used up and the 16th power (the bound's contraction factor) has
+    // been seen, a lane applies a power when its bit is set.
+    template <bool PERLANE = false>
     static PBRE_HD bool obj_closed(const float (&rx)[NC_OT], const float (&ry)[NC_OT], const float (&rz)[NC_OT], const float (&dinv)[NC_OT][3],
                                    const float (&rhs)[NC_OT], const float (&app)[NC_OT][3], float mu, V3 v, V3 u, int n, float (&xo)[6]) {
         constexpr int NK = NC_OT;
@@ -417,6 +522,27 @@ struct Fast {
         float C[7][6];
         float sig2 = 4.f;                  // |S^16|_F^2 (taken when the running power is 16; n >= 32 makes sure it is reached)
         int r = n, pw = 1;
+        if constexpr (PERLANE) {
+            auto apply_if = [&](const float (*M)[6], bool on) {
+                float y[6];
+                PBRE_UNROLL for (int i = 0; i < 6; i++) {
+                    float a = M[6][i];
+                    PBRE_UNROLL for (int k = 0; k < 6; k++) a = fmaf(M[k][i], x[k], a);
+                    y[i] = a;
+                }
+                PBRE_UNROLL for (int i = 0; i < 6; i++) x[i] = on ? y[i] : x[i];
+            };
+            for (;;) {
+                apply_if(B, (r & 1) != 0);
+                if (pw == 16) sig2 = fro2(B);
+                r >>= 1; if (!PBRE_ANY(r != 0) && pw >= 16) break;
+                square(B, C); pw <<= 1;
+                apply_if(C, (r & 1) != 0);
+                if (pw == 16) sig2 = fro2(C);
+                r >>= 1; if (!PBRE_ANY(r != 0) && pw >= 16) break;
+                square(C, B); pw <<= 1;
+            }
+        } else
         for (;;) {
             if (r & 1) apply(B);
             if (pw == 16) sig2 = fro2(B);
@@ -626,8 +752,8 @@ struct Fast {
             }
         }
         // (simple class: M itself is needed once more, for the impulse bound of the motor rows' closed form)
-        float M0[(RC || RT) ? 1 : ND * (ND + 1) / 2];
-        if (!RC && !RT && ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
+        float M0[ND * (ND + 1) / 2];      // (dead, and never materialised, in the complex class)
+        if (!RC && ROBOT) { PBRE_UNROLL for (int i = 0; i < ND * (ND + 1) / 2; i++) M0[i] = Mi[i]; }
         // ---- M^-1 by the symmetric sweep operator (A -> -A^-1), Gauss-Jordan arithmetic on the triangle
         if (ROBOT) PBRE_UNROLL for (int k = 0; k < ND; k++) {
             const float pv = 1.f / Mi[sym(k, k)];
@@ -684,6 +810,24 @@ struct Fast {
             if constexpr (RT) lsr = fmaxf(lsr, fabsf(d * Mi[sym(j, j)]));
             PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, fmaf(d, Mi[sym(k, j)], wget(w, k)));
         };
+        // can a motor reach its impulse bound within the sweeps (see the solver section below)?  False: the motor rows are clamp-free.
+        auto motor_may_clamp = [&](const float* e) -> bool {
+            float en = 0.f, lam[ND];
+            PBRE_UNROLL for (int j = 0; j < ND; j++) {
+                float l = 0.f;
+                PBRE_UNROLL for (int k = 0; k < ND; k++) l = fmaf(M0[sym(j, k)], e[k], l);
+                lam[j] = l; en = fmaf(l, e[j], en);
+            }
+            bool ov_ = !(en >= 0.f);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) ov_ = ov_ || !(fabsf(lam[j]) + sqrtf(en * M0[sym(j, j)]) <= mlim);
+            return ov_;
+        };
+        bool rt_over = true;      // RT, simple class: the same test, for the closed form of Bullet's residual exit in the solver section
+        if (!RC && RT && ROBOT) {
+            float e[ND];
+            PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
+            rt_over = motor_may_clamp(e);
+        }
         if (!RC && !RT && ROBOT) {
             // ---- simple class, motor block (see the solver section below for the why and the validity bound)
             const bool want_closed = !(flags & 32) && P.iters >= 4 && !(P.iters & 1);
@@ -692,15 +836,7 @@ struct Fast {
             if (want_closed) {
                 float e[ND];
                 PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
-                float en = 0.f, lam[ND];
-                PBRE_UNROLL for (int j = 0; j < ND; j++) {
-                    float l = 0.f;
-                    PBRE_UNROLL for (int k = 0; k < ND; k++) l = fmaf(M0[sym(j, k)], e[k], l);
-                    lam[j] = l; en = fmaf(l, e[j], en);
-                }
-                bool ov_ = !(en >= 0.f);
-                PBRE_UNROLL for (int j = 0; j < ND; j++) ov_ = ov_ || !(fabsf(lam[j]) + sqrtf(en * M0[sym(j, j)]) <= mlim);
-                over = ov_;
+                over = motor_may_clamp(e);
                 motor_closed(Mi, m_dinv, e, P.iters >> 1);
                 PBRE_UNROLL for (int j = 0; j < ND; j++) wc[j] = m_t[j] + e[j];
             }
@@ -994,6 +1130,75 @@ struct Fast {
             };
             bool all_slots = true;
             PBRE_UNROLL for (int c = 0; c < NK; c++) all_slots = all_slots && any_c[c];
+            // ---- Round 6: the exit sweep and the state at it WITHOUT running every sweep (simple class, cube resting on all four slots).
+            // The blocks share no unknown, so sweep `it` passes Bullet's test iff the motor rows' largest change and the object rows' largest
+            // change both are <= res_lim.  (a) Object: the OC_K explicit sweeps of the step without the exit test, with the test of each
+            // recorded (bit `it` of opass); from OC_K on the rows are the clamp-free Kaczmarz passes of obj_closed, whose changes only shrink:
+            // a lane qualifies when sweep OC_K - 1 passes and obj_closed's bound holds.  (b) Motors: motor_scan finds the first sweep that
+            // passes in both blocks and the error there.  (c) Object at that sweep: the matrix power with a per-lane exponent, or -- a lane
+            // that leaves within the explicit sweeps -- those sweeps again up to its exit.  A lane that does not qualify (a motor may reach
+            // its impulse bound, the cube slides / rocks, a residual that does not decrease) takes the explicit rows below: the wave
+            // runs them if any of its lanes needs them, a qualifying lane still takes its closed form, so what a lane computes does not depend
+            // on its wave-mates.  PBRE_F_SEQ_MOTORS / PBRE_F_SEQ_OBJECT (either): explicit rows for every lane (validation, A/B).
+            bool cl_ok = false;
+            float cl_w[RC ? 1 : ND];
+            V3 cl_ov = ov, cl_ow = ow;
+            int cl_used = P.iters;
+            if constexpr (!RC && ROLE == 0) {
+#ifndef PBRE_OC_K
+#define PBRE_OC_K 22
+#endif
+                constexpr int OC_K = PBRE_OC_K;
+#ifndef PBRE_RT_CLOSED       // (build knob, tools/build_variant.sh: 0 = Bullet's residual exit by explicit rows only, as in round 5)
+#define PBRE_RT_CLOSED 1
+#endif
+                const bool want = PBRE_RT_CLOSED && ROBOT && OBJECT && obj_on && obj_inline && all_slots && !(flags & (32 | 64)) && P.iters >= OC_K + 32 && !(P.iters & 1) && OC_K <= 32;
+                if (want) {
+                    auto osweep = [&]() {
+                        PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
+                        PBRE_UNROLL for (int c = 0; c < NK; c++) { orow(c, 1); orow(c, 2); }
+                    };
+                    const V3 ov0 = ov, ow0 = ow;
+                    unsigned opass = 0u;
+                    for (int it = 0; it < OC_K; it++) {
+                        lsr = 0.f;
+                        osweep();
+                        opass |= (lsr <= P.res_lim) ? (1u << it) : 0u;
+                    }
+                    bool ok = ((opass >> (OC_K - 1)) & 1u) != 0u && !rt_over;
+                    float e[ND];
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) e[j] = wget(w, j) - m_t[j];
+                    bool mono = true;
+                    cl_used = motor_scan(Mi, m_dinv, e, P.iters, P.res_lim, opass, OC_K, mono);
+                    ok = ok && mono;
+                    PBRE_UNROLL for (int j = 0; j < ND; j++) cl_w[j] = m_t[j] + e[j];
+                    const int n_tail = cl_used - OC_K;
+                    float xc[6];
+                    const bool okc = obj_closed<true>(c_rx, c_ry, c_rz, r_dinv, r_rhs, r_app, mu, ov, ow, n_tail > 0 ? n_tail : 0, xc);
+                    ok = ok && (okc || n_tail < 0);
+                    cl_ov = v3(xc[0], xc[1], xc[2]); cl_ow = v3(xc[3], xc[4], xc[5]);
+                    // the rows start over: for the lanes that left within the explicit sweeps (their twist after `cl_used` sweeps), and for
+                    // the explicit path below
+                    ov = ov0; ow = ow0;
+                    PBRE_UNROLL for (int c = 0; c < NK; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
+                    if (PBRE_ANY(ok && n_tail < 0)) {
+                        for (int it = 0; it < OC_K - 1; it++) {
+                            osweep();
+                            const bool at = n_tail < 0 && it + 1 == cl_used;
+                            cl_ov = v3(at ? ov.x : cl_ov.x, at ? ov.y : cl_ov.y, at ? ov.z : cl_ov.z);
+                            cl_ow = v3(at ? ow.x : cl_ow.x, at ? ow.y : cl_ow.y, at ? ow.z : cl_ow.z);
+                        }
+                        ov = ov0; ow = ow0;
+                        PBRE_UNROLL for (int c = 0; c < NK; c++) PBRE_UNROLL for (int d = 0; d < 3; d++) r_app[c][d] = 0.f;
+                    }
+                    cl_ok = ok;
+                    PBRE_OC_PROBE(ok);
+                }
+            }
+            // (RC || ...: in the complex-class kernel the test is constant -- and must be WRITTEN as one: with `if (PBRE_ANY(!cl_ok))` alone,
+            // cl_ok never set, k_fast_rc<., RT> left the sweep loop early on the GPU, sweep counts 55 / 1 where the emulation and the oracle say
+            // 69 / 48; found by tools/rt_rc_probe.py, variant builds B / C of round 6)
+            if (RC || ROLE != 0 || PBRE_ANY(!cl_ok)) {
             if (obj_sep) run([&]() { lsr = fmaxf(lsr, os.sweep_res()); });
             else if (!RC && all_slots) run([&]() {
                 PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
@@ -1007,6 +1212,13 @@ struct Fast {
                 os.vx = done ? os_k[0] : os.vx; os.vy = done ? os_k[1] : os.vy; os.vz = done ? os_k[2] : os.vz;
                 os.wx = done ? os_k[3] : os.wx; os.wy = done ? os_k[4] : os.wy; os.wz = done ? os_k[5] : os.wz;
                 os.result(P, o_tw);
+            }
+            }
+            if constexpr (!RC && ROLE == 0) {
+                PBRE_UNROLL for (int k = 0; k < ND; k++) wset(w, k, cl_ok ? cl_w[k] : wget(w, k));
+                ov = v3(cl_ok ? cl_ov.x : ov.x, cl_ok ? cl_ov.y : ov.y, cl_ok ? cl_ov.z : ov.z);
+                ow = v3(cl_ok ? cl_ow.x : ow.x, cl_ok ? cl_ow.y : ow.y, cl_ok ? cl_ow.z : ow.z);
+                used = cl_ok ? cl_used : used;
             }
             if (sw) *sw = used;
         } else

@@ -17,31 +17,24 @@
 #define PBRE_OPAQUE_I(x) asm volatile("" : "+v"(x))
 #define PBRE_OPAQUE_F(x) asm volatile("" : "+v"(x))
 #define PBRE_NOUNROLL _Pragma("nounroll")
-// Per-env hand-over of the IK targets (round 5): kw_lane_ik marks an env's targets complete with the launch's sequence number; the solve kernels
-// wait for that env's mark only.  Targets and mark are written and read with RELAXED agent-scope atomics (coherent across the XCDs' L2s by
-// themselves) around workgroup-scope fences (program order only): a release / acquire pair at agent scope is an L2 write-back / invalidate on this
-// chip, and 32768 lanes publishing and quads polling that way slowed every kernel running beside them (kw_dyn 93 -> 207 us,
-// profiles/r05u_icub_timeline_ab.txt).  The wait is bounded: a wait that cannot end would hang the device -- the IK kernel is launched first, on a
-// stream of the highest priority, and waits for nothing, so the bound is not reached; a quad that does reach it goes on and the env-step is
-// counted by the NaN / Inf guard's counter.
-#define PBRE_IK_STORE(done, p, v) do { if (done) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *(p) = (v); } while (0)
-// (the workgroup-scope fence alone emitted no wait, so mark and targets -- different addresses, possibly different L2 channels -- could
-// become visible to another XCD in either order.  The targets are write-through sc1 stores: vmcnt(0) returns once they have reached the
-// coherence point, and only then is the mark stored.  No L2 write-back is involved, which is what the agent-scope release cost.)
-#define PBRE_IK_PUBLISH(done, seq) do { if (done) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
-        __hip_atomic_store((done), (seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } } while (0)
-// A wait that reaches its bound POISONS the env: quad_step writes NaN into the env's guard element of the side buffer (element
-// 214 of quad lane 0, where kw_dyn recorded whether the incoming state was finite), and the NaN / Inf guard in kw_fin returns the env-step as
-// done = 1 / reward 0, restarts the env under PBRE_F_AUTO_RESET and counts it once (pbre_kernel_info[12]).  (A first version carried a flag
-// to the joint-position stores at the end of quad_step -- `timeout ? NaN : q` --: with that select in the kernel the envs with robot-object
-// contact came out different from run to run on the GPU (6 tests of tests/test_gpu_icub.py; the variant without the select passed); the
-// poison is now a store inside the branch that is never taken.)
-#define PBRE_IK_WAIT(flag, seq, on_timeout) do { int spins_ = 0; \
-        while (__hip_atomic_load((flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (seq)) { \
-            __builtin_amdgcn_s_sleep(8); \
-            if (++spins_ > (1 << 22)) { on_timeout; break; } } \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+// Per-env hand-over of the IK targets (round 5; re-done in round 6): kw_lane_ik hands an env's joint targets to the solve kernels in the
+// iteration in which THAT env converges; the quads wait for their own env's targets only.
+// Round 5 wrote the 20 targets and then a per-env "done" mark (relaxed agent-scope stores around a workgroup-scope fence).  Nothing ordered
+// the mark behind the targets across XCDs, an s_waitcnt vmcnt(0) between them was not enough either -- a write-through store is
+// acknowledged before it is visible to another XCD's loads -- and round 6's contention test (tests/test_gpu_contention.py: a second context
+// keeps the GPU busy, so the quads really do spin and read the moment the mark appears) produced rows that differed from the solo run's.
+// A release / acquire pair at agent scope would order them, but is an L2 write-back / invalidate per publishing lane on this chip (measured
+// in round 5: kw_dyn 93 -> 207 us).  So no ordering between addresses is needed any more: every target travels as ONE 64-bit word
+// (value | sequence number << 32) written and read with 64-bit relaxed agent-scope atomics -- single-copy atomic, coherent across the XCDs --
+// and a quad lane polls its own five words until all of them carry this launch's number.  The plain target array is still written (plain
+// stores: the kernels of later steps read it after the IK kernel has ended).
+// The wait is bounded (~1 s): the IK kernel is launched first, on a stream of the highest priority, and waits for nothing; a quad that
+// does reach the bound POISONS its env: it writes NaN into the env's guard element of the side buffer (element 214 of quad
+// lane 0, where kw_dyn recorded whether the incoming state was finite), and the NaN / Inf guard in kw_fin returns the env-step as done = 1 /
+// reward 0, restarts the env under PBRE_F_AUTO_RESET and counts it once (pbre_kernel_info[12]).
+#define PBRE_IK_STORE(done, seq, j, p, v) do { const float v_ = (v); *(p) = v_; \
+        if (done) __hip_atomic_store((unsigned long long*)(done) + (j), ((unsigned long long)(unsigned)(seq) << 32) | (unsigned long long)__float_as_uint(v_), \
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #define PBRE_LANE_MSTRIDE 64         // M^-1 in wave-private LDS, [entry][lane]
 #ifndef PBRE_LANE_MREG
 #define PBRE_LANE_MREG 50            // 160 of the 210 entries in LDS (40 KB per wave: four waves per CU), the rest in registers
@@ -63,13 +56,13 @@ __device__ __forceinline__ void wpublish(int env, int c, signed char* __restrict
 // Cartesian control: hand-pose update + inverse kinematics -> joint targets, one thread per env
 __global__ __launch_bounds__(LTPB, 2) void kw_lane_ik(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, float* __restrict__ tgt, int n, int act_dim,
-                                                   int* __restrict__ ik_done, int ik_seq) {
+                                                   unsigned long long* __restrict__ ik_done, int ik_seq) {
     // (a higher wave priority for this kernel -- its last waves are the head of the step's critical path beside the solve kernels -- was
     // measured: the bulk of the IK then starves kw_dyn, 95 -> 161 us, and the step gets longer; profiles/r05u_icub_timeline_ab.txt)
     const int env = blockIdx.x * LTPB + threadIdx.x;
     if (env >= n) return;
     LaneD::ik_targets(*T, P, state + (size_t)env * Shape32::STATE, actions + (size_t)env * act_dim, tgt + (size_t)env * Shape32::TGT,
-                      ik_done ? ik_done + env : nullptr, ik_seq);
+                      ik_done ? (int*)(ik_done + (size_t)env * LaneD::ND) : nullptr, ik_seq);      // (the env's box: ND words)
 }
 
 // ------------------------------------------------------------------ the pipeline: kw_dyn -> kw_quad (+ kw_quad_rc) -> kw_fin
@@ -158,7 +151,7 @@ __device__ __forceinline__ float qb(float x, int o) { return o == 0 ? qb_t<0>(x)
 template <bool RC>
 __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T, const Params& P, float* __restrict__ state,
                                           const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
-                                          float* __restrict__ dyn, size_t cs, int env, int r, const int* __restrict__ ik_done = nullptr, int ik_seq = 0) {
+                                          float* __restrict__ dyn, size_t cs, int env, int r, const unsigned long long* __restrict__ ik_done = nullptr, int ik_seq = 0) {
     constexpr int ND = LaneD::ND, W = Shape32::W, XO = 2 * Shape32::W;
     float* st = state + (size_t)env * Shape32::STATE;
     if (st[XO + 14] != 0.f) return;
@@ -198,6 +191,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
     }
     // ---- unconstrained velocities v* = qd + dt M^-1 tau, motor rows against the running velocity, limit rows (see Lane::step)
     float w[QD], w0[QD], m_dinv[QD], m_rhs[QD], sabs[QD], l_dir[QD], l_rhs[QD], l_app[QD];
+    float ik_t[QD] = {0.f, 0.f, 0.f, 0.f, 0.f};      // Cartesian control with the per-env hand-over: this lane's targets out of the env's box
     unsigned long long lim_b[QD];
     {
         float acc[QD];
@@ -207,15 +201,34 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
             PBRE_UNROLL for (int i = 0; i < QD; i++) acc[i] = fmaf(A[i][c], tc, acc[i]);
         }
         // Cartesian control: this env's IK targets are read next -- wait for ITS mark (the IK kernel runs beside this one)
-        if ((MODE & LaneD::M_TGT) && ik_done) PBRE_IK_WAIT(ik_done + env, ik_seq, dyn[(size_t)214 * cs + env] = __builtin_nanf(""));
+        if ((MODE & LaneD::M_TGT) && ik_done) {
+            const unsigned long long* box = ik_done + (size_t)env * ND + d0;      // this quad lane's five (value, sequence) words
+            // (poll ONE word -- the last one the IK lane writes -- and read the other four only once it carries this launch's number: five
+            // loads per poll from 131072 waiting lanes slowed every kernel beside them, iCub reach 0.38 -> 0.62 ms per step at 32768 envs)
+            int spins = 0;
+            for (;;) {
+                const unsigned long long x4 = __hip_atomic_load(box + (QD - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool all = (int)(x4 >> 32) == ik_seq;
+                ik_t[QD - 1] = __uint_as_float((unsigned)x4);
+                if (all) {
+                    PBRE_UNROLL for (int i = 0; i < QD - 1; i++) {
+                        const unsigned long long x = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        all = all && (int)(x >> 32) == ik_seq;
+                        ik_t[i] = __uint_as_float((unsigned)x);
+                    }
+                }
+                if (all) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { dyn[(size_t)214 * cs + env] = __builtin_nanf(""); break; }
+            }
+        }
         PBRE_UNROLL for (int i = 0; i < QD; i++) {
             const int d = d0 + i;
             const float wj = fminf(fmaxf(fmaf(dt, acc[i], qd[i]), -vmax), vmax);
             w[i] = wj; w0[i] = wj;
             float qdes = T->home[d], kp = T->kp_hold[d], kd = T->kd_hold[d];
             const float lo = T->lower[d], up = T->upper[d];
-            if (MODE & LaneD::M_TGT) qdes = ik_done ? __hip_atomic_load(tgt + (size_t)env * Shape32::TGT + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                    : tgt[(size_t)env * Shape32::TGT + d];
+            if (MODE & LaneD::M_TGT) qdes = ik_done ? ik_t[i] : tgt[(size_t)env * Shape32::TGT + d];
             if (MODE & LaneD::M_ACTION) {
                 kp = T->kp_act[d]; kd = T->kd_act[d];
                 const int ai = T->act_idx[d];
@@ -447,7 +460,7 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
 __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                    const float* __restrict__ actions, int n, int act_dim, int MODE, const float* __restrict__ tgt,
                                                    const signed char* __restrict__ cls_cur, float* __restrict__ dyn, size_t cs,
-                                                   const int* __restrict__ ik_done, int ik_seq) {
+                                                   const unsigned long long* __restrict__ ik_done, int ik_seq) {
     const int gl = blockIdx.x * LTPB + threadIdx.x;
     const int env = gl >> 2;
     if (env >= n || cls_cur[env] != 0) return;             // (whole quads)
@@ -458,7 +471,7 @@ __global__ __launch_bounds__(LTPB, PBRE_QUAD_WAVES) void kw_quad(const TablesT<S
 __global__ __launch_bounds__(LTPB, 1) void kw_quad_rc(const TablesT<Shape32>* __restrict__ T, const Params P, float* __restrict__ state,
                                                       const float* __restrict__ actions, int act_dim, int MODE, const float* __restrict__ tgt,
                                                       const int* __restrict__ cur_list, const int* __restrict__ cur_count, float* __restrict__ dyn, size_t cs,
-                                                      const int* __restrict__ ik_done, int ik_seq, int epw) {
+                                                      const unsigned long long* __restrict__ ik_done, int ik_seq, int epw) {
     // epw envs per wave (<= 16; PBRE_QUAD_RC_EPW).  Which limit rows and contact slots a wave sweeps is the UNION over its envs (rows of an env
     // without them are exact no-ops), and these few lone waves are the step's critical path in both control modes -- but fewer envs per wave do
     // not shorten them (measured, profiles/r05w_quad_rc_epw.txt: 16 / 4 / 1 envs per wave: 378 / 397 / 391 us under joint control): the
@@ -536,7 +549,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     // Cartesian control, round 5: the IK kernel on a stream of its own (highest priority) and per-env "targets complete" marks (ik_done[env] ==
     // ik_seq), so that kw_quad / kw_quad_rc start right behind kw_dyn and only the quads of envs whose IK is still iterating wait
     hipStream_t ik_stream = nullptr;
-    int* ik_done = nullptr;           // [n]
+    unsigned long long* ik_done = nullptr;      // [n][ND] the hand-over boxes: (target | sequence number << 32) per DoF
     int ik_seq = 0;
     int ik_overlap = 1;               // PBRE_IK_OVERLAP=0: the kernel-level dependency of rounds 2-4 (A/B)
     int rc_epw = 16;                  // envs per wave of kw_quad_rc (PBRE_QUAD_RC_EPW: A/B, measured neutral)
@@ -587,8 +600,8 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             if (const char* ev = getenv("PBRE_QUAD_RC_EPW")) rc_epw = std::min(16, std::max(1, atoi(ev)));
             if (ik_overlap) {
                 if ((e = hipStreamCreateWithPriority(&ik_stream, hipStreamNonBlocking, phi)) != hipSuccess) return e;
-                if ((e = hipMalloc(&ik_done, (size_t)n * sizeof(int))) != hipSuccess) return e;
-                if ((e = hipMemset(ik_done, 0, (size_t)n * sizeof(int))) != hipSuccess) return e;
+                if ((e = hipMalloc(&ik_done, (size_t)n * LaneD::ND * sizeof(unsigned long long))) != hipSuccess) return e;
+                if ((e = hipMemset(ik_done, 0, (size_t)n * LaneD::ND * sizeof(unsigned long long))) != hipSuccess) return e;
             }
         }
         {
@@ -609,7 +622,7 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
     hipEvent_t ev_ik = nullptr;
     void launch_lane_ik(const float* act, hipStream_t s) override {
         if (side) { ik_pending = true; return; }
-        hipLaunchKernelGGL(kw_lane_ik, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, tgt, n, act_dim, (int*)nullptr, 0);
+        hipLaunchKernelGGL(kw_lane_ik, dim3((n + LTPB - 1) / LTPB), dim3(LTPB), 0, s, dT, P, state, act, tgt, n, act_dim, (unsigned long long*)nullptr, 0);
     }
     void lane_t(int MODE, const float* act, float* out, int flags, hipStream_t s, hipEvent_t* ek) {
         signed char* c_cur = cls + (size_t)cur * n; signed char* c_nxt = cls + (size_t)(cur ^ 1) * n;
@@ -648,18 +661,18 @@ struct WideLane : WideImpl<Shape32, DevLanes32> {
             if (!(flags & 1) && !obj_main) hipLaunchKernelGGL((kw_obj<Shape32>), dim3(be), dim3(64), 0, s2, P, state, objv, n);
             mark(2, s2);
             if (ik_ovl) {
-                if (ik_seq == 0x7fffffff) { (void)hipMemsetAsync(ik_done, 0, (size_t)n * sizeof(int), s); ik_seq = 0; (void)hipEventRecord(ev_fork, s); }
+                if (ik_seq == 0x7fffffff) { (void)hipMemsetAsync(ik_done, 0, (size_t)n * LaneD::ND * sizeof(unsigned long long), s); ik_seq = 0; (void)hipEventRecord(ev_fork, s); }
                 ik_seq++;
                 (void)hipStreamWaitEvent(ik_stream, ev_fork, 0);
                 hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, ik_stream, dT, P, state, act, tgt, n, act_dim, ik_done, ik_seq);
                 (void)hipEventRecord(ev_ik, ik_stream);
                 ik_pending = false;
             } else if (ik_side) {      // (kw_quad_rc must be the next thing in this stream when the targets are ready, see lane_alloc)
-                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim, (int*)nullptr, 0);
+                hipLaunchKernelGGL(kw_lane_ik, dim3(be), dim3(LTPB), 0, side, dT, P, state, act, tgt, n, act_dim, (unsigned long long*)nullptr, 0);
                 (void)hipEventRecord(ev_ik, side);
                 ik_pending = false;
             }
-            const int* ikd = ik_ovl ? ik_done : nullptr;
+            const unsigned long long* ikd = ik_ovl ? ik_done : nullptr;
             mark(3, s2);
             if (ek) (void)hipEventRecord(ek[0], s);
             mark(4, s);

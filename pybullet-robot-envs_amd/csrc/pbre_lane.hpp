@@ -30,11 +30,8 @@
 #include <math.h>
 #include "pbre_fast.hpp"
 #include "pbre_objstep.hpp"
-#ifndef PBRE_IK_PUBLISH      // Lane::ik_targets: mark an env's targets complete (device pipeline: release store of the sequence number; nothing on the host)
-#define PBRE_IK_PUBLISH(done, seq) do { (void)(done); (void)(seq); } while (0)
-#endif
-#ifndef PBRE_IK_STORE        // ... and write one of its targets (device pipeline with the per-env hand-over: a store that is coherent across the XCDs)
-#define PBRE_IK_STORE(done, p, v) (*(p) = (v))
+#ifndef PBRE_IK_STORE        // Lane::ik_targets writes target j of its env (device pipeline with the per-env hand-over, pbre_lane.hip: also as a
+#define PBRE_IK_STORE(done, seq, j, p, v) (*(p) = (v))      // (value, sequence number) pair into the env's hand-over box `done`; host: the plain store)
 #endif
 
 #ifndef PBRE_LANE_MSTRIDE      // floats between consecutive M^-1 entries of one env (device: 64 = [entry][lane]; host: 1)
@@ -796,9 +793,9 @@ struct Lane {
     // hand pose (X[6..11]), clip rotation and workspace, damped-least-squares IK from the current joint angles over the joints of
     // the chain to the end effector; same algorithm and stopping rule as Core::ik_targets / oracle orc_ik.  Writes tgt[0..ND) and
     // X[6..11].  (The reset-time targets of the home hand pose are the lane-group kernel's.)
-    // done / seq (device pipeline, pbre_lane.hip; null on the host): the env's "targets complete" mark.  A lane writes its targets and then
-    // `seq` to *done (release) in the iteration in which ITS env converges, not when the slowest env of its wave leaves the loop: the solve
-    // kernels wait per env (PBRE_IK_WAIT), so the 0.09 % of the envs that iterate to the cap no longer hold up everybody else's step.
+    // done / seq (device pipeline, pbre_lane.hip; null on the host): the env's hand-over box.  A lane writes its targets -- each with the
+    // launch's sequence number beside it -- in the iteration in which ITS env converges, not when the slowest env of its wave leaves the
+    // loop: the solve kernels wait per env (quad_step), so the 0.09 % of the envs that iterate to the cap no longer hold up everybody else.
     static PBRE_HD void ik_targets(const Tab& T, const Params& P, float* st, const float* act, float* tgt, int* done = nullptr, int seq = 0) {
         if (T.ee_owner == Topo::ee0) ik_targets_t<Topo::ee0>(T, P, st, act, tgt, done, seq); else ik_targets_t<Topo::ee1>(T, P, st, act, tgt, done, seq);
     }
@@ -825,8 +822,7 @@ struct Lane {
         // their current angle
         bool published = false;
         auto publish = [&]() {
-            PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_IK_STORE(done, tgt + j, Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]));
-            PBRE_IK_PUBLISH(done, seq);
+            PBRE_UNROLL for (int j = 0; j < ND; j++) PBRE_IK_STORE(done, seq, j, tgt + j, Topo::is_anc(j, EO) ? q[j] : (T.blocked[j] ? T.home[j] : st[j]));
             published = true;
         };
 #ifdef PBRE_IK_PROBE      // host emulation only (tools/ik_cycle_probe.py): at which iteration does this env's iteration become periodic?

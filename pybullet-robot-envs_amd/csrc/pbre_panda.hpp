@@ -372,8 +372,11 @@ struct FusedArgs {
     const float* tgt; int* zero_count; int* host_total; int dummy_base; int* recent; int rblocks;
     float* objv_g;                            // (k_fused<.., false>) [cap + 32][W] the object waves' twists, first word = the launch's sequence number (P.objv_seq)
 };
-template <int MODE, bool PAIR>
+// RT (round 6): Bullet's residual exit -- the 64-thread grid only (the pair mapping splits an env over two waves, the exit test is a maximum
+// over all of its rows); the row blocks' object waves idle (Core::step<RT> sweeps the object's rows itself).
+template <int MODE, bool PAIR, bool RT = false>
 __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs args_in_kernarg_segment, const Tables* __restrict__ T) {
+    static_assert(!(PAIR && RT), "the residual exit steps an env on one lane");
     // (T -- the model constants -- is a kernel argument of its own: as a __restrict__ argument it cannot alias the pointers the roles load from the
     // struct, so the reads through it stay scalar loads behind the roles' stores; read from the struct, 50 of k_fast's s_load_dwordx16 / x8 table
     // reads had become per-lane global loads and the fast role spilled 488 bytes per lane)
@@ -402,14 +405,14 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
         if ((int)blockIdx.x < rb) {
             const int role = (int)blockIdx.x & (FUSED_WAVES - 1);
             PBRE_LAUNDER(a);
-            row_list_block<MODE, false, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
+            row_list_block<MODE, RT, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->act_dim, a->ow, a->flags, a->cur_list, a->cur_count, a->cls,
                                               a->next_list, a->next_count, a->cap, a->tgt, a->host_total, a->dummy_base, a->recent, nullptr,
                                               (int)blockIdx.x / FUSED_WAVES, a->rblocks, (role == 0 ? REPB * W : (role - 1) * FTPB) + (int)threadIdx.x, a->objv_g);
             return;
         }
         const int chunk = (int)blockIdx.x - rb;
         PBRE_LAUNDER(a);
-        fast_wave<MODE, false, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
+        fast_wave<MODE, RT, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
                                a->cap, a->tgt, a->zero_count, chunk, (int)threadIdx.x);
     }
 }
@@ -462,13 +465,15 @@ struct pbre_ctx {
     // pipelined host path (pbre_step_async / pbre_step_wait, round 6): copy-in / copy-out streams, two (actions, rows) device buffer pairs and
     // the events that order upload -> step -> download of each slot; created on first use
     struct AsyncPath {
-        hipStream_t s_in = nullptr, s_out = nullptr;
+        hipStream_t s_in = nullptr, s_out[2] = {nullptr, nullptr};      // (one download stream per slot: pbre_step_wait drains THAT stream -- measured: hipEventSynchronize
+                                                                        // on the older slot's event returned only when the newer download on the same stream was done too)
         float* d_act[2] = {nullptr, nullptr};
         float* d_rows[2] = {nullptr, nullptr};
         hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
         long issued = 0, waited = 0;
         bool ready = false;
     } ap;
+    int async_blocks = 128;            // PBRE_ASYNC_BLOCKS: 256-thread blocks of the row-download kernel (k_rows_out)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_sys = nullptr;   // ev_join_sys: with the system-scope fence (see pbre_step)
     bool rows_to_host = false;         // the step in flight writes its output rows straight into page-locked host memory
     static constexpr int KRING = 64;           // HIP event pairs around the dominant kernel of the last KRING sampled steps,
@@ -491,10 +496,14 @@ static inline bool lane_per_env(const pbre_ctx* c) { return c->fast_ok && !(c->c
 // one batched step of the first n envs of b on stream s
 template <int MODE, bool RT>
 hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float* out, int flags, hipStream_t s) {
+    // (the per-env sweep counts -- pbre_get_sweeps, residual exit -- are indexed by the env's place in the MAIN buffer; settle and
+    // partial-reset steps of the compacted tmp buffer must not write theirs over other envs' counts)
+    Params Pk = c->P;
+    if (&b != &c->main) Pk.sweeps = nullptr;
     if (!lane_per_env(c)) {
         hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
         (void)hipEventRecord(ek[0], s);
-        hipLaunchKernelGGL((k_step<MODE, RT>), dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, c->P, b.state, act, out, c->d_scratch, n, ceil16(n),
+        hipLaunchKernelGGL((k_step<MODE, RT>), dim3(ceil16(n) / EPB), dim3(TPB), 0, s, c->dT, Pk, b.state, act, out, c->d_scratch, n, ceil16(n),
                            c->act_dim, c->ow, flags, b.tgt);
         (void)hipEventRecord(ek[1], s);
         c->k_steps++;
@@ -531,17 +540,18 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
     if (!RT && c->pair != 0 && !(flags & PBRE_F_NO_OBJECT) && !(MODE & FastD::M_INNER))
         pair = c->pair == 1 || 2 * blocks <= 2 * c->n_simd;
     // (env.step() under joint control, and the settle steps of reset(): 201 launches per reset)
-    if constexpr (NB <= 2 && (MODE == MODE_STEP || MODE == 0) && !RT) {
+    if constexpr (NB <= 2 && (MODE == MODE_STEP || MODE == 0)) {
         // the whole step as one launch on the caller's stream (k_fused): no fork / join through the side stream
         if (c->fused && rows) {
             const bool timed = (c->launches++ % c->ksample) == c->ksample - 1;
             hipEvent_t* ek = c->ev_k[c->k_steps % pbre_ctx::KRING];
             if (timed) (void)hipEventRecord(ek[0], s);
             c->launches_fused++;
-            FusedArgs fa = {c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags, b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[cur],
+            FusedArgs fa = {c->dT, Pk, b.state, act, out, n, c->act_dim, c->ow, flags, b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[cur],
                             b.count + cc * NB, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB, b.h_total, b.cap, b.count + 3 * NB, rblocks, b.objv_g};
             if (pair) {
                 c->launches_pair++;
+                if constexpr (!RT)      // (`pair` is never set with the residual exit)
                 hipLaunchKernelGGL((k_fused<MODE, true>), dim3(rblocks + (blocks + FUSED_WAVES / 2 - 1) / (FUSED_WAVES / 2)), dim3(RTPB), 0, s, fa, (const Tables*)c->dT);
             } else {
                 // (never 0: that value selects the block barrier, PBRE_OBJV_SYNC.  After 2^31 - 1 launches -- four days of stepping -- the numbers
@@ -552,7 +562,7 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
                 }
                 b.objv_seq++;
                 fa.P.objv_seq = b.objv_seq;
-                hipLaunchKernelGGL((k_fused<MODE, false>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
+                hipLaunchKernelGGL((k_fused<MODE, false, RT>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }
@@ -572,12 +582,12 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
     }
     if constexpr (NB <= 2) {
         if (rows) {
-            hipLaunchKernelGGL((k_row_list<MODE, RT>), dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+            hipLaunchKernelGGL((k_row_list<MODE, RT>), dim3(rblocks), dim3(RTPB), 0, s_rc, c->dT, Pk, b.state, act, out, c->act_dim, c->ow, flags,
                                b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.cap, b.count + 3 * NB);
         }
     }
     if (!rows)
-        hipLaunchKernelGGL((k_fast_rc<MODE, RT>), dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, c->P, b.state, act, out, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast_rc<MODE, RT>), dim3(std::min(c->n_simd, blocks + NB)), dim3(FTPB), 0, s_rc, c->dT, Pk, b.state, act, out, c->act_dim, c->ow, flags,
                            b.list[cur], b.count + cc * NB, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.h_total, b.count + 3 * NB);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // HIP event pair around the dominant kernel on the stream it runs on, for pbre_timing[3]; sampled (every KSAMPLE-th step):
@@ -596,15 +606,15 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
     if (pair) {
         c->launches_pair++;
         if constexpr (!(MODE & FastD::M_INNER) && !RT)      // (the inner iterations of action_repeat > 1 stay on k_fast: not instantiated; RT: one lane per env)
-        hipLaunchKernelGGL((k_fast_pair<MODE>), dim3(blocks), dim3(PTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast_pair<MODE>), dim3(blocks), dim3(PTPB), 0, s_fast, c->dT, Pk, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     } else {
     if (fast3) c->launches3++;
     if constexpr (!RT) if (fast3)
-        hipLaunchKernelGGL((k_fast<MODE, 3, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast<MODE, 3, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, Pk, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     if (!fast3)
-        hipLaunchKernelGGL((k_fast<MODE, 2, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, c->P, b.state, act, out, n, c->act_dim, c->ow, flags,
+        hipLaunchKernelGGL((k_fast<MODE, 2, RT>), dim3(blocks), dim3(FTPB), 0, s_fast, c->dT, Pk, b.state, act, out, n, c->act_dim, c->ow, flags,
                            b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB);
     }
     if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -269,6 +269,21 @@ class Engine:
         self._chk(self.lib.pbre_step_async(self._ctx, _fp(A["act"][k]), _fp(A["out"][k])))
         A["issued"] += 1
 
+    def step_pipelined(self, actions):
+        """The open-loop pipeline in the order that keeps the host off the critical path: copy `actions` into the next page-locked slot (while
+        the GPU works), THEN wait for the rows of the step before last, THEN enqueue this step.  Returns (obs, reward, done) views of the step
+        two calls back, None for the first two calls; drain with step_wait() twice at the end."""
+        if getattr(self, "_async", None) is None:
+            self.step_async(actions)                      # (first call: creates the slots)
+            return None
+        A = self._async
+        k = A["issued"] % 3
+        np.copyto(A["act"][k], np.asarray(actions).reshape(self.num_envs, self.act_dim), casting="unsafe")
+        rows = self.step_wait() if A["issued"] - A["waited"] >= 2 else None
+        self._chk(self.lib.pbre_step_async(self._ctx, _fp(A["act"][k]), _fp(A["out"][k])))
+        A["issued"] += 1
+        return rows
+
     def step_wait(self, copy=False):
         """(raw obs, reward, done) of the oldest step_async not yet waited for: views of a page-locked row buffer that is overwritten by
         the third step_async from now (copy=True: copies)"""

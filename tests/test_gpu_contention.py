@@ -33,6 +33,7 @@ def _run(eng, torch, dev, steps, acts, stream, desync_state=None):
     if desync_state is not None:
         eng.set_state(desync_state)
     out = torch.zeros((steps, eng.num_envs, eng.obs_dim + 2), device=dev)
+    torch.cuda.synchronize()          # (the fill runs on torch's current stream, the steps on `stream`: under contention the fill came LAST and wiped step 0's rows)
     for k in range(steps):
         eng.step_device(acts[k].data_ptr(), out[k].data_ptr(), stream.cuda_stream)
     return out
