@@ -642,12 +642,30 @@ def main():
     host = None
     if world == 1 and not args.no_host_path:
         try:
-            acts = [job.pool[k].cpu().numpy() for k in range(4)]
+            # (64 i.i.d. action batches on the host: a pool of four, recycled, pushes thousands of envs into joint limits within a few hundred steps)
+            g_h = torch.Generator(device=dev); g_h.manual_seed(4242 + rank)
+            acts = [(torch.rand((n_local, job.pool.shape[2]), device=dev, generator=g_h) * 2 - 1).cpu().numpy() for _ in range(64)]
+            # An engine of its own, stepped through the host-buffer entry points only (its batch: reset, de-synchronised episode clocks, 300
+            # host-path steps with i.i.d. actions).  On the job's engine -- which has taken thousands of pbre_step_device launches on torch's
+            # stream -- the same pipelined loop measures 0.93 ms per step instead of 0.39 (wait for the rows 0.78 ms instead of 0.26;
+            # profiles/r06_host_path.txt): unexplained so far, PBRE_BENCH_HOST_JOB_ENGINE=1 measures it there.
+            host_engine = "own"
+            if os.environ.get("PBRE_BENCH_HOST_JOB_ENGINE") == "1":
+                host_engine = "job"
+            else:
+                eng = _capi.Engine(tbl, task=_capi.TASK_PUSH, num_envs=n_local, device_id=local_rank, env_id_base=rank * n_local, seed=1234,
+                                   obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, flags=_capi.F_AUTO_RESET)
+                eng.reset()
+                st_h = eng.get_state()
+                st_h[:, eng.x_off + 3] = np.random.default_rng(4321).integers(0, 1000, n_local).astype(np.float32)
+                eng.set_state(st_h)
+                for k in range(300):
+                    eng.step(acts[(7 * k) % 64], copy=False)
             for k in range(2):
                 eng.step(acts[k], copy=False)
             t0 = time.perf_counter()
             for k in range(10):
-                eng.step(acts[k % 4], copy=False)
+                eng.step(acts[(5 * k + 1) % 64], copy=False)
             el = time.perf_counter() - t0
             ms = eng.timing()
             sync = {"value": n_local * 10 / el, "unit": "env-steps/s", "ms_per_step": el / 10 * 1e3, "h2d_ms": ms[0], "kernels_ms": ms[1], "d2h_ms": ms[2],
@@ -656,12 +674,12 @@ def main():
             # streams, two steps in flight) -- an open loop, like `value`; the floor is the row download over PCIe
             ns = 40
             for k in range(4):
-                eng.step_pipelined(acts[k % 4])
+                eng.step_pipelined(acts[(3 * k + 2) % 64])
             calls = []
             t0 = time.perf_counter()
             for k in range(ns):
                 tc = time.perf_counter()
-                eng.step_pipelined(acts[k % 4])      # (copy the actions into the page-locked slot, wait for the rows of the step before last, enqueue)
+                eng.step_pipelined(acts[(11 * k + 5) % 64])      # (copy the actions into the page-locked slot, wait for the rows of the step before last, enqueue)
                 calls.append(time.perf_counter() - tc)
             el = time.perf_counter() - t0
             eng.step_wait(); eng.step_wait()
@@ -669,7 +687,8 @@ def main():
             host = {"value": n_local * ns / el, "unit": "env-steps/s", "ms_per_step": el / ns * 1e3,
                     "rows_MB_per_step": row_mb, "d2h_GBps_if_download_bound": row_mb / (el / ns * 1e3),
                     "ms_per_call_last_8": [round(x * 1e3, 3) for x in calls[-8:]],
-                    "synchronous": sync,
+                    "host_phase_ms_per_call": dict(zip(("copy_actions", "wait_rows", "enqueue"), [round(x / max(1, eng._async["phase_s"][3]) * 1e3, 4) for x in eng._async["phase_s"][:3]])),
+                    "synchronous": sync, "engine": host_engine, "complex_envs_at_the_end": int(eng.kernel_info()[5]), "one_launch_steps": int(eng.kernel_info()[13]),
                     "note": "SURVEY 8(d) literal metric: numpy actions in page-locked memory in, [obs|reward|done] rows out, upload + kernels + download, pipelined over "
                             "calls (Engine.step_async / step_wait, open loop, two steps in flight); never `value`, which is device-resident stepping (pbre_step_device)"}
         except Exception as e:

@@ -112,11 +112,7 @@ static hipError_t quiesce(pbre_ctx* c) {
         return hipSuccess;
     }
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e;
-    if (c->ap.ready) {      // the pipelined host path's copies (their rows are still delivered: pbre_step_wait finds the events complete)
-        if ((e = hipStreamSynchronize(c->ap.s_in)) != hipSuccess) return e;
-        for (int b = 0; b < 2; b++) if ((e = hipStreamSynchronize(c->ap.s_out[b])) != hipSuccess) return e;
-    }
-    return hipStreamSynchronize(c->side);
+    return hipStreamSynchronize(c->side);      // (also the pipelined host path's downloads: pbre_step_wait then finds their events complete)
 }
 
 static hipError_t alloc_buf(EnvBuf& b, int cap) {
@@ -214,13 +210,11 @@ void pbre_destroy(pbre_ctx* c) {
         if (p) (void)hipFree(p);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->ap.ready) {
-        (void)hipStreamSynchronize(c->ap.s_in); (void)hipStreamSynchronize(c->ap.s_out[0]); (void)hipStreamSynchronize(c->ap.s_out[1]);
         for (int b = 0; b < 2; b++) {
             if (c->ap.d_act[b]) (void)hipFree(c->ap.d_act[b]);
             if (c->ap.d_rows[b]) (void)hipFree(c->ap.d_rows[b]);
-            for (hipEvent_t e : {c->ap.ev_in[b], c->ap.ev_step[b], c->ap.ev_out[b]}) if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : {c->ap.ev_step[b], c->ap.ev_out[b]}) if (e) (void)hipEventDestroy(e);
         }
-        (void)hipStreamDestroy(c->ap.s_in); (void)hipStreamDestroy(c->ap.s_out[0]); (void)hipStreamDestroy(c->ap.s_out[1]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -506,14 +500,10 @@ __global__ __launch_bounds__(256) void k_rows_out(const float4* __restrict__ src
 }
 static int async_setup(pbre_ctx* c) {
     if (c->ap.ready) return PBRE_OK;
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->ap.s_in, hipStreamNonBlocking, hi));
-    for (int b = 0; b < 2; b++) HIPCHK(hipStreamCreateWithPriority(&c->ap.s_out[b], hipStreamNonBlocking, hi));
     for (int b = 0; b < 2; b++) {
         HIPCHK(hipMalloc(&c->ap.d_act[b], (size_t)c->n * c->act_dim * 4));
         HIPCHK(hipMalloc(&c->ap.d_rows[b], (size_t)c->n * c->ow * 4));
-        for (hipEvent_t* e : {&c->ap.ev_in[b], &c->ap.ev_step[b], &c->ap.ev_out[b]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t* e : {&c->ap.ev_step[b], &c->ap.ev_out[b]}) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     if (const char* e = getenv("PBRE_ASYNC_BLOCKS")) c->async_blocks = std::max(1, atoi(e));
     c->ap.ready = true;
@@ -529,12 +519,10 @@ int pbre_step_async(pbre_ctx* c, const float* actions, float* out) {
     if (A.issued - A.waited >= 2) { c->err = "pbre_step_async: two steps are in flight already -- pbre_step_wait first"; return PBRE_E_ARG; }
     if (c->ext_dirty) HIPCHK(quiesce(c));
     const int b = (int)(A.issued & 1);
-    // upload: behind the step that last read this slot's action buffer (two steps ago)
-    if (A.issued >= 2) HIPCHK(hipStreamWaitEvent(A.s_in, A.ev_step[b], 0));
-    HIPCHK(hipMemcpyAsync(A.d_act[b], actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, A.s_in));
-    HIPCHK(hipEventRecord(A.ev_in[b], A.s_in));
-    // step: behind its upload and behind the download that last read this slot's row buffer
-    HIPCHK(hipStreamWaitEvent(c->stream, A.ev_in[b], 0));
+    hipStream_t dl = c->sp.pick(c->stream);      // the stream that really runs beside c->stream
+    // upload (in stream order: the step that last read this slot's action buffer is two steps back on the same stream), then the step --
+    // behind the download that last read this slot's row buffer
+    HIPCHK(hipMemcpyAsync(A.d_act[b], actions, (size_t)c->n * c->act_dim * 4, hipMemcpyHostToDevice, c->stream));
     if (A.issued >= 2) HIPCHK(hipStreamWaitEvent(c->stream, A.ev_out[b], 0));
     // PBRE_ASYNC_D2H: how the rows reach the host buffer -- 0 the DMA engine (hipMemcpyAsync), 1 a copy kernel on the download stream, 2 the
     // step kernels write them into the page-locked buffer themselves (pbre_step's zero-copy, minus its host synchronisation)
@@ -553,15 +541,15 @@ int pbre_step_async(pbre_ctx* c, const float* actions, float* out) {
     HIPCHK(fe);
     HIPCHK(hipEventRecord(A.ev_step[b], c->stream));
     // download
-    HIPCHK(hipStreamWaitEvent(A.s_out[b], A.ev_step[b], 0));
+    HIPCHK(hipStreamWaitEvent(dl, A.ev_step[b], 0));
     if (!direct) {
         const bool mapped = d2h_mode == 1 && (bytes % 16) == 0 && ((uintptr_t)out % 16) == 0 && host_mapped;
         if (mapped) {
-            hipLaunchKernelGGL(k_rows_out, dim3(c->async_blocks), dim3(256), 0, A.s_out[b], (const float4*)A.d_rows[b], (float4*)out, bytes / 16);
+            hipLaunchKernelGGL(k_rows_out, dim3(c->async_blocks), dim3(256), 0, dl, (const float4*)A.d_rows[b], (float4*)out, bytes / 16);
             HIPCHK(hipGetLastError());
-        } else HIPCHK(hipMemcpyAsync(out, A.d_rows[b], bytes, hipMemcpyDeviceToHost, A.s_out[b]));
+        } else HIPCHK(hipMemcpyAsync(out, A.d_rows[b], bytes, hipMemcpyDeviceToHost, dl));
     }
-    HIPCHK(hipEventRecord(A.ev_out[b], A.s_out[b]));
+    HIPCHK(hipEventRecord(A.ev_out[b], dl));
     A.issued++;
     return PBRE_OK;
 }
@@ -571,7 +559,15 @@ int pbre_step_wait(pbre_ctx* c) {
     pbre_ctx::AsyncPath& A = c->ap;
     if (!A.ready || A.waited >= A.issued) { c->err = "pbre_step_wait: no step in flight"; return PBRE_E_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(A.s_out[A.waited & 1]));
+    // (poll the slot's event: hipEventSynchronize returned only once the NEWER download enqueued on the same stream was done too -- the
+    // pipeline then runs one step deep)
+    for (;;) {
+        const hipError_t q = hipEventQuery(A.ev_out[A.waited & 1]);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { c->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return PBRE_E_DEVICE; }
+        for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+    }
+    (void)hipGetLastError();
     A.waited++;
     return PBRE_OK;
 }

@@ -203,23 +203,25 @@ __device__ __forceinline__ void quad_step(const TablesT<Shape32>* __restrict__ T
         // Cartesian control: this env's IK targets are read next -- wait for ITS mark (the IK kernel runs beside this one)
         if ((MODE & LaneD::M_TGT) && ik_done) {
             const unsigned long long* box = ik_done + (size_t)env * ND + d0;      // this quad lane's five (value, sequence) words
-            // (poll ONE word -- the last one the IK lane writes -- and read the other four only once it carries this launch's number: five
-            // loads per poll from 131072 waiting lanes slowed every kernel beside them, iCub reach 0.38 -> 0.62 ms per step at 32768 envs)
+            // Poll ONE word per ENV -- the last one the IK lane writes, the same address for the four lanes of the quad -- and read this lane's
+            // own five only once that one carries the launch's number (and go on polling if one of them does not yet: nothing orders the
+            // words).  Per-lane polling (five words, then one) cost 10 x the memory transactions of round 5's per-env mark and slowed the IK
+            // kernel everybody waits for: iCub reach 0.38 -> 0.62 ms per step at 32768 envs (profiles/r06_icub_handover.txt).
+            const unsigned long long* last = ik_done + (size_t)env * ND + (ND - 1);
             int spins = 0;
             for (;;) {
-                const unsigned long long x4 = __hip_atomic_load(box + (QD - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool all = (int)(x4 >> 32) == ik_seq;
-                ik_t[QD - 1] = __uint_as_float((unsigned)x4);
+                const unsigned long long xl = __hip_atomic_load(last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bool all = (int)(xl >> 32) == ik_seq;
                 if (all) {
-                    PBRE_UNROLL for (int i = 0; i < QD - 1; i++) {
+                    PBRE_UNROLL for (int i = 0; i < QD; i++) {
                         const unsigned long long x = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         all = all && (int)(x >> 32) == ik_seq;
                         ik_t[i] = __uint_as_float((unsigned)x);
                     }
                 }
                 if (all) break;
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 22)) { dyn[(size_t)214 * cs + env] = __builtin_nanf(""); break; }
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1 << 21)) { dyn[(size_t)214 * cs + env] = __builtin_nanf(""); break; }
             }
         }
         PBRE_UNROLL for (int i = 0; i < QD; i++) {

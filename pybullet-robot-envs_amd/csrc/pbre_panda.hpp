@@ -462,14 +462,14 @@ struct pbre_ctx {
     hipStream_t stream = nullptr, side = nullptr;      // side: the candidate of `sp` that overlaps with the caller's stream
     SidePick sp;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // pipelined host path (pbre_step_async / pbre_step_wait, round 6): copy-in / copy-out streams, two (actions, rows) device buffer pairs and
-    // the events that order upload -> step -> download of each slot; created on first use
+    // pipelined host path (pbre_step_async / pbre_step_wait, round 6): two (actions, rows) device buffer pairs and the events that order upload
+    // -> step -> download of each slot; created on first use.  The upload rides on the ctx's stream ahead of the step, the download on the side
+    // stream the overlap probe picked (pbre_sidepick.hpp: HIP multiplexes streams onto a few hardware queues, and streams that share one do
+    // not overlap -- three more streams of their own measured 0.42 ms per step in a small process and 0.95 ms in bench.py's)
     struct AsyncPath {
-        hipStream_t s_in = nullptr, s_out[2] = {nullptr, nullptr};      // (one download stream per slot: pbre_step_wait drains THAT stream -- measured: hipEventSynchronize
-                                                                        // on the older slot's event returned only when the newer download on the same stream was done too)
         float* d_act[2] = {nullptr, nullptr};
         float* d_rows[2] = {nullptr, nullptr};
-        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_step[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        hipEvent_t ev_step[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
         long issued = 0, waited = 0;
         bool ready = false;
     } ap;

@@ -7,6 +7,7 @@ loudly with RuntimeError.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -278,10 +279,15 @@ class Engine:
             return None
         A = self._async
         k = A["issued"] % 3
+        t0 = time.perf_counter()
         np.copyto(A["act"][k], np.asarray(actions).reshape(self.num_envs, self.act_dim), casting="unsafe")
+        t1 = time.perf_counter()
         rows = self.step_wait() if A["issued"] - A["waited"] >= 2 else None
+        t2 = time.perf_counter()
         self._chk(self.lib.pbre_step_async(self._ctx, _fp(A["act"][k]), _fp(A["out"][k])))
         A["issued"] += 1
+        ph = A.setdefault("phase_s", [0.0, 0.0, 0.0, 0])      # host seconds spent copying the actions / waiting for rows / enqueueing, calls
+        ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += time.perf_counter() - t2; ph[3] += 1
         return rows
 
     def step_wait(self, copy=False):
