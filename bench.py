@@ -44,7 +44,7 @@ ALG_FLOP_PER_ENV_STEP = 22 * 232 + 6400.0 + 8400.0 + 8000.0
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 TOTAL_ENVS = 131072                 # BASELINE.json: "Panda-push 128k envs"
-PROFILE_TAG = "r05"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
+PROFILE_TAG = "r06"                 # profiles/<tag>_pmc_*.json: counter summaries of this command (tools/pmc.sh, tools/pmc_sq.sh)
 
 
 def _profile(name, key=None):

@@ -47,6 +47,22 @@
 #ifndef PBRE_COUNT_BAD      // ++*p from any number of lanes (device: atomicAdd)
 #define PBRE_COUNT_BAD(p) (++*(p))
 #endif
+// y0 += s * x0, y1 += s * x1: with -DPBRE_PK_SQUARE=1 ONE v_pk_fma_f32 on the device (two fmaf otherwise and on the host: the same IEEE
+// operations, the same bits).  Round 6 measured that a packed fp32 FMA issues like a scalar one (profiles/r06_ubench_valu.txt; rounds 1-5
+// believed 7.2 cycles), so the matrix squarings of the closed forms were rewritten to need half the instructions -- 1900 fewer per k_fast
+// wave -- and the step did not get faster: 0.1868 against 0.1870 ms stationary at 131072 envs, 0.1249 / 0.1253 at 16384, rows bit-identical
+// (profiles/r06w_pk_square_ab.txt).  The wave is bound by dependent-issue latency, not by its instruction count; the packed build also
+// spills more (k_fused 100 -> 196 B of scratch per lane).  Off by default.
+#ifndef PBRE_PK_SQUARE
+#define PBRE_PK_SQUARE 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && PBRE_PK_SQUARE
+typedef float pbre_f2 __attribute__((ext_vector_type(2)));
+#define PBRE_FMA2(s, x0, x1, y0, y1) do { const pbre_f2 r_ = __builtin_elementwise_fma((pbre_f2){(s), (s)}, (pbre_f2){(x0), (x1)}, (pbre_f2){(y0), (y1)}); \
+        (y0) = r_.x; (y1) = r_.y; } while (0)
+#else
+#define PBRE_FMA2(s, x0, x1, y0, y1) do { (y0) = fmaf((s), (x0), (y0)); (y1) = fmaf((s), (x1), (y1)); } while (0)
+#endif
 #ifndef PBRE_OC_PROBE       // test builds: count the lanes that pass / fail the validity bound of the object block's closed form
 #define PBRE_OC_PROBE(ok) do {} while (0)
 #endif
@@ -348,11 +364,12 @@ struct Fast {
             PBRE_UNROLL for (int i = 0; i < NH; i++) e[i] = y[i];
         };
         auto square = [&](const float (*X)[NH], float (*Y)[NH]) {
+            static_assert(NH % 2 == 0, "columns in pairs");
             PBRE_UNROLL for (int i = 0; i < NH; i++)
-                PBRE_UNROLL for (int c = 0; c < NH; c++) {
-                    float a = 0.f;
-                    PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(X[i][k], X[k][c], a);
-                    Y[i][c] = a;
+                PBRE_UNROLL for (int c = 0; c < NH; c += 2) {
+                    float a0 = 0.f, a1 = 0.f;
+                    PBRE_UNROLL for (int k = 0; k < NH; k++) PBRE_FMA2(X[i][k], X[k][c], X[k][c + 1], a0, a1);
+                    Y[i][c] = a0; Y[i][c + 1] = a1;
                 }
         };
         for (;;) {
@@ -415,10 +432,10 @@ struct Fast {
             }
             auto square = [&](const float (*X)[NH], float (*Y)[NH]) {
                 PBRE_UNROLL for (int i = 0; i < NH; i++)
-                    PBRE_UNROLL for (int c = 0; c < NH; c++) {
-                        float a = 0.f;
-                        PBRE_UNROLL for (int k = 0; k < NH; k++) a = fmaf(X[i][k], X[k][c], a);
-                        Y[i][c] = a;
+                    PBRE_UNROLL for (int c = 0; c < NH; c += 2) {
+                        float a0 = 0.f, a1 = 0.f;
+                        PBRE_UNROLL for (int k = 0; k < NH; k++) PBRE_FMA2(X[i][k], X[k][c], X[k][c + 1], a0, a1);
+                        Y[i][c] = a0; Y[i][c + 1] = a1;
                     }
             };
             square(H, G); square(G, H); square(H, G);           // G = H^8
@@ -512,10 +529,10 @@ struct Fast {
         };
         auto square = [&](const float (*M)[6], float (*Q)[6]) {      // Q = M o M: S^2, S s + s
             PBRE_UNROLL for (int k = 0; k < 7; k++)
-                PBRE_UNROLL for (int i = 0; i < 6; i++) {
-                    float a = k == 6 ? M[6][i] : 0.f;
-                    PBRE_UNROLL for (int j = 0; j < 6; j++) a = fmaf(M[j][i], M[k][j], a);
-                    Q[k][i] = a;
+                PBRE_UNROLL for (int i = 0; i < 6; i += 2) {
+                    float a0 = k == 6 ? M[6][i] : 0.f, a1 = k == 6 ? M[6][i + 1] : 0.f;
+                    PBRE_UNROLL for (int j = 0; j < 6; j++) PBRE_FMA2(M[k][j], M[j][i], M[j][i + 1], a0, a1);
+                    Q[k][i] = a0; Q[k][i + 1] = a1;
                 }
         };
         auto fro2 = [&](const float (*M)[6]) { float a = 0.f; PBRE_UNROLL for (int k = 0; k < 6; k++) PBRE_UNROLL for (int i = 0; i < 6; i++) a = fmaf(M[k][i], M[k][i], a); return a; };

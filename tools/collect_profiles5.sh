@@ -24,4 +24,5 @@ c gpurun_out/pmc_icub_hbm_${TAG}.json profiles/${TAG}_pmc_icub_hbm.json
 c gpurun_out/pmc_hands_${TAG}.json profiles/${TAG}_pmc_hands.json
 c gpurun_out/${TAG}_hands_bench.json profiles/${TAG}_hands_bench.json
 c gpurun_out/${TAG}_bench2.json profiles/${TAG}_bench_2ranks_one_device.json
+c gpurun_out/${TAG}_bench8.json profiles/${TAG}_bench_8ranks_one_device.json
 ls -la profiles | grep ${TAG}
