@@ -691,6 +691,8 @@ def main():
                     "synchronous": sync, "engine": host_engine, "complex_envs_at_the_end": int(eng.kernel_info()[5]), "one_launch_steps": int(eng.kernel_info()[13]),
                     "note": "SURVEY 8(d) literal metric: numpy actions in page-locked memory in, [obs|reward|done] rows out, upload + kernels + download, pipelined over "
                             "calls (Engine.step_async / step_wait, open loop, two steps in flight); never `value`, which is device-resident stepping (pbre_step_device)"}
+            if host_engine == "own":
+                eng.close()
         except Exception as e:
             host = {"error": repr(e)}
     del job
