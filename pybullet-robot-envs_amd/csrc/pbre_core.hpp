@@ -1182,6 +1182,7 @@ struct Core {
             };
             // end of a sweep's clamp-free motor rows: false if an applied impulse has left its bound (a NaN fails the test too)
             auto free_in_bound = [&]() {
+                if constexpr (RT) m_dsw = m_dsel;      // (the sweep's motor deltas, for the residual test at its end)
                 R.m_app = R.m_app + m_dsel;
                 return !LR::any(LR::bnot(LR::le(LR::abs(R.m_app), R.m_lim)));
             };
@@ -1328,6 +1329,9 @@ struct Core {
             }
                 return true;
             };
+#ifndef PBRE_RT_FREE_STAGES          // 1: the clamp-free motor stages under the residual exit too.  Bit-identical (checksums of 300 steps at 16384 and
+#define PBRE_RT_FREE_STAGES 0        // 131072 envs) and no faster: 0.2207 against 0.2169 ms per step at 131072 envs, 0.1913 / 0.1910 at 16384
+#endif                               // (profiles/r06zc_rt_ab.txt) -- the RT row waves' time is not their motor rows.  Off.
 #ifndef PBRE_FREE_MOTOR_STAGES      // 0: A/B -- always the clamping stages; 2: clamp-free first in EVERY two-chain wave
 #define PBRE_FREE_MOTOR_STAGES 1      // 1: clamp-free first in the waves with robot-object rows only (measured, profiles/r05_chain_ab4.txt and
 #endif                                // r05_phase_probe_free_motor_stages.txt: a coupled env's sweeps get 17 % shorter and 2 % of those waves start over; among the
@@ -1344,13 +1348,20 @@ struct Core {
                 if (PBRE_NRO_SPECIAL && !robot_only && ro_bits == 3u) return run_chains(freec, std::integral_constant<int, 2>{});
                 return run_chains(freec, std::integral_constant<int, 0>{});
             };
-            if (PBRE_FREE_MOTOR_STAGES && (PBRE_FREE_MOTOR_STAGES == 2 || (!robot_only && ro_bits != 0u)) && !RT && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
+            // (round 6, PBRE_RT_FREE_STAGES: also under the residual exit -- a group's snapshot is taken from rows that returned the clamping rows'
+            // deltas bit for bit, and a wave that starts over forgets its snapshots: what a group computes does not depend on the path its wave took)
+            if (PBRE_FREE_MOTOR_STAGES && (PBRE_FREE_MOTOR_STAGES == 2 || (!robot_only && ro_bits != 0u)) && (!RT || PBRE_RT_FREE_STAGES) && !LR::any(LR::lt(R.m_lim, LR::c(P.motor_imp)))) {
                 done2 = run_n(std::true_type{});
                 if (!done2) {             // start over with clamping rows
                     PBRE_PROBE_PATH(11);
                     dvr = dv; dvo = dv; m_dsel = zeroR;
                     R.m_app = zeroR; R.l_app = zeroR;
                     PBRE_UNROLL for (int c = 0; c < NC; c++) { R.an[c] = zero; R.a1[c] = zero; R.a2[c] = zero; }
+                    if constexpr (RT) {
+                        rt_done = L::bfalse(); rt_dv = zero; rt_used = L::c((float)P.iters);
+                        PBRE_UNROLL for (int c = 0; c < NC_RO; c++) rt_an[c] = zero;
+                        m_dsw = zeroR; l_dsw = zeroR; lsr = zero; fr.res = zero; fo.res = zero;
+                    }
                 }
             }
             if (!done2) (void)run_n(std::false_type{});

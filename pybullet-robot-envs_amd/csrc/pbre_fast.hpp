@@ -66,6 +66,9 @@ typedef float pbre_f2 __attribute__((ext_vector_type(2)));
 #ifndef PBRE_OC_PROBE       // test builds: count the lanes that pass / fail the validity bound of the object block's closed form
 #define PBRE_OC_PROBE(ok) do {} while (0)
 #endif
+#ifndef PBRE_RT_PROBE       // test builds: why a lane did not take the closed form of the residual exit (bit mask) and its state record
+#define PBRE_RT_PROBE(why, st) do {} while (0)
+#endif
 #ifndef PBRE_PAIR_SYNC      // block barrier between the two waves of the pair kernel (device build; never reached on the host)
 #define PBRE_PAIR_SYNC() do {} while (0)
 #endif
@@ -1210,12 +1213,16 @@ struct Fast {
                     }
                     cl_ok = ok;
                     PBRE_OC_PROBE(ok);
+                    PBRE_RT_PROBE((((opass >> (OC_K - 1)) & 1u) != 0u ? 0 : 1) | (rt_over ? 2 : 0) | (mono ? 0 : 4) | ((okc || n_tail < 0) ? 0 : 8), st);
                 }
             }
             // (RC || ...: in the complex-class kernel the test is constant -- and must be WRITTEN as one: with `if (PBRE_ANY(!cl_ok))` alone,
             // cl_ok never set, k_fast_rc<., RT> left the sweep loop early on the GPU, sweep counts 55 / 1 where the emulation and the oracle say
             // 69 / 48; found by tools/rt_rc_probe.py, variant builds B / C of round 6)
-            if (RC || ROLE != 0 || PBRE_ANY(!cl_ok)) {
+#ifndef PBRE_RT_NO_FALLBACK      // (diagnostic build knob: 1 = the explicit rows are never run beside the closed form -- timing A/B only)
+#define PBRE_RT_NO_FALLBACK 0
+#endif
+            if (RC || ROLE != 0 || (!PBRE_RT_NO_FALLBACK && PBRE_ANY(!cl_ok))) {
             if (obj_sep) run([&]() { lsr = fmaxf(lsr, os.sweep_res()); });
             else if (!RC && all_slots) run([&]() {
                 PBRE_UNROLL for (int c = 0; c < NK; c++) orow(c, 0);
@@ -1299,7 +1306,10 @@ struct Fast {
                     float xc[6];
                     const bool okc = obj_closed(c_rx, c_ry, c_rz, r_dinv, r_rhs, r_app, mu, ov, ow, P.iters - OC_K, xc);
                     PBRE_OC_PROBE(okc);
-                    if (PBRE_ANY(!okc)) {
+#ifndef PBRE_OC_NO_FALLBACK      // (diagnostic build knob: 1 = a lane that fails the bound keeps its 22-sweep state -- timing A/B only)
+#define PBRE_OC_NO_FALLBACK 0
+#endif
+                    if (!PBRE_OC_NO_FALLBACK && PBRE_ANY(!okc)) {
                         for (int it = OC_K; it < P.iters; it += 2) { osweep(); osweep(); }
                     }
                     ov = v3(okc ? xc[0] : ov.x, okc ? xc[1] : ov.y, okc ? xc[2] : ov.z);
@@ -1489,7 +1499,18 @@ struct Fast {
         float q[ND];
         PBRE_UNROLL for (int j = 0; j < ND; j++) q[j] = st[j];
         Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
-        return sweep(T, P, q, nullptr, v3(st[9], st[10], st[11]), oq, flags).cls;
+        return rt_class(P, st, flags, sweep(T, P, q, nullptr, v3(st[9], st[10], st[11]), oq, flags).cls);
+    }
+    // Residual exit (round 6): in the simple class the exit sweep comes from closed forms whose object part needs a cube AT REST on the table.  A
+    // cube that moves -- sliding after a push, rocking, in flight -- fails that bound, and on the GPU the lane's whole wave then runs the 150
+    // explicit sweeps: one such lane per ~150 k env-steps (tools/rt_why_probe.py) = about one wave per step at 131072 envs, which is the step's
+    // tail (0.237 -> 0.20 ms without it, profiles/r06z_rt_ab.txt).  With the exit test on, a state whose object moves is therefore a complex
+    // one (class 1: the row kernel's 16 lanes sweep its rows explicitly) -- a function of the env's own state, like every class.  The fallback
+    // inside the simple-class kernel stays for what the speed test does not foresee.
+    static PBRE_HD int rt_class(const Params& P, const float* st, int flags, int cls) {
+        if (!(P.res_lim > 0.f) || cls != 0 || (flags & 1)) return cls;
+        const float v2 = fmaf(st[25], st[25], fmaf(st[26], st[26], st[27] * st[27])), w2 = fmaf(st[28], st[28], fmaf(st[29], st[29], st[30] * st[30]));
+        return (v2 > 1e-6f || w2 > 1e-4f) ? 1 : 0;       // |v| > 1 mm/s or |w| > 0.01 rad/s (a resting cube: < 1e-5 either)
     }
 
     // ---------------------------------------------------------------- inverse kinematics (use_IK = 1)
@@ -1760,6 +1781,7 @@ struct Fast {
             out[o++] = reward; out[o++] = done;
         }
         if (ROLE == 1) PBRE_PROBE(20);      // robot wave: object tests, observation, reward, row
+        if constexpr (ROLE != 1) cls = rt_class(P, st, flags, cls);
         return cls | (bad ? BAD_BIT : 0);
     }
 };

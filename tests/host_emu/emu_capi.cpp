@@ -30,6 +30,10 @@ extern "C" void pbre_ik_probe_hist(long* h, int clear) {
 #include "../../pybullet-robot-envs_amd/csrc/pbre_core.hpp"
 static long g_oc_stats[2] = {0, 0};      // lanes that failed / passed the validity bound of the object block's closed form (Fast::obj_closed)
 #define PBRE_OC_PROBE(ok) (g_oc_stats[(ok) ? 1 : 0]++)
+static long g_rt_why[16] = {0};           // residual exit, closed form: lanes by reason mask (1 object rows not through after OC_K sweeps, 2 a motor may clamp, 4 trial residuals not decreasing, 8 object bound)
+static float g_rt_speed[16][2] = {{0}};   // ... and the smallest object speed |v|, |w| seen among the lanes of each mask (is "the cube moves" a predictor?)
+#define PBRE_RT_PROBE(why, st) do { int w_ = (why); g_rt_why[w_]++; float v_ = sqrtf((st)[25]*(st)[25] + (st)[26]*(st)[26] + (st)[27]*(st)[27]), o_ = sqrtf((st)[28]*(st)[28] + (st)[29]*(st)[29] + (st)[30]*(st)[30]); \
+    if (g_rt_why[w_] == 1 || v_ + o_ < g_rt_speed[w_][0] + g_rt_speed[w_][1]) { g_rt_speed[w_][0] = v_; g_rt_speed[w_][1] = o_; } } while (0)
 #include "../../pybullet-robot-envs_amd/csrc/pbre_fast.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_objstep.hpp"
 #include "../../pybullet-robot-envs_amd/csrc/pbre_lane.hpp"
@@ -450,6 +454,7 @@ int pbre_get_physics(const pbre_ctx* c, pbre_physics* phys) {
     *phys = c->cfg.phys;
     return PBRE_OK;
 }
+void pbre_emu_rt_why(long* out, float* speed, int reset) { for (int i = 0; i < 16; i++) { out[i] = g_rt_why[i]; speed[2 * i] = g_rt_speed[i][0]; speed[2 * i + 1] = g_rt_speed[i][1]; if (reset) g_rt_why[i] = 0; } }
 void pbre_emu_oc_stats(long* out, int reset) { out[0] = g_oc_stats[0]; out[1] = g_oc_stats[1]; if (reset) g_oc_stats[0] = g_oc_stats[1] = 0; }
 int pbre_get_sweeps(pbre_ctx* c, int32_t* sweeps) {
     if (!c || !sweeps) return PBRE_E_ARG;

@@ -2421,6 +2421,48 @@ def check_residual_threshold(Engine, lib, table, states=None, n=48, steps=3, thr
     return rep
 
 
+def check_residual_threshold_moving_cubes(Engine, lib, table, n=32, seed=43):
+    """Residual exit, round 6: a state whose cube MOVES (sliding / spinning on the table, no robot contact) is a complex-class state while the
+    threshold is on (Fast::rt_class: the closed form of the exit sweep needs a cube at rest; one such lane sent its whole k_fast wave onto the
+    explicit rows) -- stepped by the row kernel's explicit rows -- and a simple one with the threshold off.  Checks the class counts
+    (pbre_kernel_info[3..5]) and, through check_residual_threshold, the step itself against the oracle."""
+    rng = np.random.default_rng(seed)
+    eng, ora = make_pair(Engine, lib, table, n)
+    st = check_reset(eng, ora, n)
+    X = 25                                    # object twist: st[25..30]
+    moving = np.zeros(n, bool); moving[1::3] = True
+    S = st.copy()
+    k = int(moving.sum())
+    S[moving, X:X + 2] = rng.uniform(-0.08, 0.08, (k, 2))                 # sliding at up to 8 cm/s
+    S[moving, X + 5] = rng.uniform(-0.6, 0.6, k)                          # ... and spinning about the vertical
+    a = np.zeros((n, eng.act_dim), np.float32)
+    s32 = S.astype(np.float32)
+    def one_step():
+        """envs the simple-class kernel / the complex-class kernels stepped in one step (the HIP library reports the most recent step, the CPU
+        emulation running sums)"""
+        b = eng.kernel_info()
+        eng.step(a)
+        i = eng.kernel_info()
+        if i[3] + i[4] + i[5] != n:
+            i = [x - y for x, y in zip(i, b)]
+        return i[3], i[4] + i[5]
+    eng.set_state(s32)
+    assert one_step() == (n, 0), "threshold off: a moving cube without contact is a simple-class state"
+    eng.set_physics(solver_residual_threshold=1e-7)
+    try:
+        eng.set_state(s32)
+        got = one_step()
+        assert got == (n - k, k), "threshold on: the %d moving cubes are complex-class states (%r)" % (k, got)
+        # a cube that has come to rest is a simple-class state again: 400 hold steps (friction stops an 8 cm/s slide within ~0.1 s)
+        for _ in range(400):
+            eng.step(a)
+        got = one_step()
+        assert got == (n, 0), "the cubes came to rest, every env is a simple-class one again (%r)" % (got,)
+    finally:
+        eng.set_physics(solver_residual_threshold=0.0)
+    return check_residual_threshold(Engine, lib, table, states=S, steps=2, tol=TOL_CONTACT, expect_early=True, seed=seed)
+
+
 TOL_RT_FLIP_GROUP = {"q": 5e-6, "qd": 1.2e-3, "obj_pos": 2e-6, "obj_quat": 3e-6, "obj_v": 5e-3, "obj_w": 4e-3,
                      "obs_ee_pos": 5e-6, "obs_ee_eul": 1e-5, "obs_ee_vel": 8e-4, "obs_rest": 2e-5}
 

@@ -377,6 +377,11 @@ def test_solver_residual_threshold_contact_rich_states(panda, emu_lib, flags):
     parity.check_residual_threshold(_capi.Engine, emu_lib, panda["table"], states=S, steps=1, flags=flags, tol=parity.TOL_CONTACT, skip_ambiguous=True)
 
 
+def test_solver_residual_threshold_moving_cubes_are_complex_class_states(panda, emu_lib):
+    rep = parity.check_residual_threshold_moving_cubes(_capi.Engine, emu_lib, panda["table"])
+    print({k: v for k, v in rep.items() if k not in ("worst", "worst_flip")})
+
+
 def test_solver_residual_threshold_is_off_by_default_and_validated(panda, emu_lib):
     eng = _capi.Engine(panda["table"], task=1, num_envs=2, lib=emu_lib)
     assert eng.get_physics().solver_residual_threshold == 0.0

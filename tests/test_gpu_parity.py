@@ -816,6 +816,11 @@ def test_solver_residual_threshold_contact_rich_states(panda, hip_lib, flags):
     parity.check_residual_threshold(_capi.Engine, hip_lib, panda["table"], states=S, steps=1, flags=flags, tol=parity.TOL_CONTACT, skip_ambiguous=True)
 
 
+def test_solver_residual_threshold_moving_cubes_are_complex_class_states(panda, hip_lib):
+    rep = parity.check_residual_threshold_moving_cubes(_capi.Engine, hip_lib, panda["table"], n=96)
+    print({k: v for k, v in rep.items() if k not in ("worst", "worst_flip")})
+
+
 def test_solver_residual_threshold_results_do_not_depend_on_wave_mates_or_sharding(panda, hip_lib):
     """With the threshold on an env leaves the sweep loop on its own while its wave goes on: two engines side by side (complex envs land in
     different row-kernel waves from run to run) and a 2-shard split of the same batch are bit-identical over 40 steps with auto-reset."""

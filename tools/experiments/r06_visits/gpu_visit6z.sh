@@ -1,0 +1,5 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+C=pybullet-robot-envs_amd/csrc
+for N in 16384 131072; do timeout 600 python tools/rt_ab.py $N $C/libpbre.so $C/libpbre_nofb.so 2>&1 | grep -vE "amdgpu.ids"; done | tee gpurun_out/r06z_rt_ab.txt
