@@ -2433,7 +2433,8 @@ def check_residual_threshold_moving_cubes(Engine, lib, table, n=32, seed=43):
     moving = np.zeros(n, bool); moving[1::3] = True
     S = st.copy()
     k = int(moving.sum())
-    S[moving, X:X + 2] = rng.uniform(-0.08, 0.08, (k, 2))                 # sliding at up to 8 cm/s
+    ang, spd = rng.uniform(0, 2 * np.pi, k), rng.uniform(0.05, 0.08, k)   # sliding at 5..8 cm/s (friction takes 2 cm/s per step: none stops within the
+    S[moving, X], S[moving, X + 1] = spd * np.cos(ang), spd * np.sin(ang)  # step the class counts are read after)
     S[moving, X + 5] = rng.uniform(-0.6, 0.6, k)                          # ... and spinning about the vertical
     a = np.zeros((n, eng.act_dim), np.float32)
     s32 = S.astype(np.float32)
