@@ -143,6 +143,7 @@ int orc_model_from_table(const double* t, size_t n, orc_model* m) {
         for (int k = 0; k < 9; k++) { m->XR[i][k] = (real)r[8+k]; m->inertia[i][k] = (real)r[21+k]; }
         m->mass[i] = (real)r[17]; m->lower[i] = (real)r[30]; m->upper[i] = (real)r[31];
         m->damping[i] = (real)r[32]; m->dof[i] = (int)r[33]; m->friction[i] = (real)r[34]; m->passive[i] = (int)r[37];
+        m->max_force[i] = (m->passive[i] && r[35] > 0) ? (real)r[35] : (real)0;
         if (m->dof[i] >= 0) m->link_of_dof[m->dof[i]] = i;
     }
     for (int k = 0; k < m->ns; k++) {
@@ -828,7 +829,9 @@ static void sim_step_fv(const orc_model* m, const orc_params* prm_in, real* st, 
             verr = vt - vs[j];
         }
         r->rhs = verr * r->dinv;
-        r->hi = (real)prm->max_motor_impulse * (fscale ? fscale[j] : (real)1); r->lo = -r->hi;
+        r->hi = (real)prm->max_motor_impulse * (fscale ? fscale[j] : (real)1);
+        if (m->max_force[m->link_of_dof[j]] > 0) r->hi = m->max_force[m->link_of_dof[j]] * dt;      /* the base constraint's rows: its own maxForce */
+        r->lo = -r->hi;
     }
     /* contacts: normal row + 2 friction rows (btPlaneSpace1 directions) */
     for (int c = 0; c < nsel; c++) {

@@ -60,6 +60,8 @@ typedef struct {
     int ntip;                      /* > 0: the model reports fingertip contact forces (iCub with hands) */
     int link_of_dof[ORC_MAXD];
     int passive[ORC_MAXL];         /* 1: a joint the inverse kinematics does not move (RobotTable link record [37]: the virtual joints of a soft-pinned floating base) */
+    real max_force[ORC_MAXL];      /* > 0: force bound (N) of the joint's motor row instead of max_motor_impulse / dt -- the base constraint's maxForce on the virtual
+                                    * joints of a soft-pinned floating base (link record [35] of a joint with [37] set; reference icub_env.py:95-101, PyBullet default 500) */
 } orc_model;
 
 /* numeric parameters of the simulated scene + task; mirrors pbre_params in include/pbre.h */

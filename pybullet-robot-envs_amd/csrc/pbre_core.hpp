@@ -873,6 +873,12 @@ struct Core {
             R.l_rhs = L::lo(L::sel(L::bor(lo_v, up_v), (zero - pen * L::c(P.erp) * inv_dt - dir * vstar) * dinv, zero));
             R.m_app = zeroR; R.l_app = zeroR;
             R.m_lim = LR::c(P.motor_imp) * fscale;         // setJointMotorControl `force` (default for every joint but grasping fingers)
+            if constexpr (SH::W >= 64) {                   // (the floating-base model is a 26-DoF one: the 64-lane shapes)
+                // the base constraint's rows (createConstraint(JOINT_FIXED), icub_env.py:95-101) are bounded by ITS maxForce, not by a motor's:
+                // the virtual joints' hold motors carry it in the table (Tables::mforce)
+                const FR mf = L::lo(L::load(T.mforce));
+                R.m_lim = LR::sel(LR::gt(mf, zeroR), mf * LR::c(P.dt), R.m_lim);
+            }
         }
         const BR any_limit = LR::ne(R.l_dir, zeroR);
         // contacts

@@ -82,6 +82,8 @@ struct TablesT {
     int   on_chain[W];           // 1: this lane's joint is on the chain base -> end effector (joints the IK moves)
     int   blocked[W];            // 1: a joint the robot env does not control: the IK branch sends it to its rest pose (icub_env.py:316-317)
     int   tip_of[W];             // fingertip slot (0..NTIP-1) of the link this lane owns, -1 otherwise
+    float mforce[W];             // > 0: force bound (N) of this lane's hold motor instead of the default -- the virtual joints of a soft-pinned floating base
+                                 //      carry the base constraint's maxForce (link record [35] of a joint with [37] set; PyBullet's createConstraint default: 500 N)
     int   ndof, n_act, n_obs_j, nspheres;
 };
 using Tables = TablesT<Shape16>;
@@ -250,6 +252,7 @@ inline std::string build_tables(const double* t, size_t n, const double* home, c
         for (int l = 0; l < NJ; l++) T.on_chain[l] = (int)((unsigned)T.amask[l >> 5][T.ee_owner] >> (l & 31) & 1u);
         // (link record [37]: a joint the inverse kinematics must not move -- the virtual joints of a soft-pinned floating base)
         for (int i = 0; i < nl; i++) if (lane_of[i] >= 0 && owner[i] == i && (int)L(i)[37] != 0) T.on_chain[lane_of[i]] = 0;
+        for (int i = 0; i < nl; i++) if (lane_of[i] >= 0 && owner[i] == i && (int)L(i)[37] != 0 && L(i)[35] > 0) T.mforce[lane_of[i]] = (float)L(i)[35];
     }
     for (int s = 0; s < ns; s++) {
         const double* r = t + 24 + nl * 40 + s * 8;

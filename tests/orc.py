@@ -25,7 +25,7 @@ def _mk(real):
                     ("mass", real * MAXL), ("com", real * 3 * MAXL), ("inertia", real * 9 * MAXL),
                     ("lower", real * MAXL), ("upper", real * MAXL), ("damping", real * MAXL), ("friction", real * MAXL),
                     ("s_link", C.c_int * MAXS), ("s_c", real * 3 * MAXS), ("s_r", real * MAXS), ("s_mu", real * MAXS),
-                    ("s_tip", C.c_int * MAXS), ("ntip", C.c_int), ("link_of_dof", C.c_int * MAXD), ("passive", C.c_int * MAXL)]
+                    ("s_tip", C.c_int * MAXS), ("ntip", C.c_int), ("link_of_dof", C.c_int * MAXD), ("passive", C.c_int * MAXL), ("max_force", real * MAXL)]
 
     class StepInfo(C.Structure):
         _fields_ = [("ncontacts", C.c_int), ("type", C.c_int * NC), ("link", C.c_int * NC), ("idx", C.c_int * NC),
@@ -284,9 +284,9 @@ def set_object(o, ph):
                 o.params.obj_hull[i][k] = float(v[k])
 
 
-def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, floating_base=False, **kw):
+def icub_oracle(control_arm="l", task=0, use_ik=1, control_orientation=0, floating_base=False, base_force=500.0, **kw):
     from pybullet_robot_envs.model.table import icub_table
-    tbl, model, info = icub_table(control_arm, floating_base=floating_base)
+    tbl, model, info = icub_table(control_arm, floating_base=floating_base, base_force=base_force)
     o = Oracle(tbl, task=task, **kw)
     o.set_icub(info, task, control_arm, use_ik, control_orientation)
     return o, tbl, info

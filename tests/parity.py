@@ -2611,6 +2611,62 @@ def check_closed_form_object_rows(Engine, lib, table, n=256, steps=12, seed=17, 
 TOL_ICUB_FLOAT = dict(TOL_ICUB, q=1.5e-6, qd=2e-4, obs_ee_pos=1.5e-6, obs_ee_vel=2e-4)
 
 
+def check_icub_base_force_bound(Engine, lib, n=2, steps=3, seed=10, base_force=200.0):
+    """The base constraint's force bound (icub_env.py:95-101: createConstraint leaves maxForce at PyBullet's default, 500 N; VERDICT r5 "missing"
+    item 4): the rows of the floating base's constraint are bounded by `base_force` N.  With 500 N the robot's weight (324 N) stays inside the
+    bound -- check_icub_floating_base; HERE the bound is set BELOW the weight (a model parameter: table.float_base(base_force=...)), so the vertical
+    row saturates and the robot sinks: single steps from identical states, engine against oracle within TOL_ICUB_FLOAT, and the base's
+    vertical velocity after one step from rest is the free-fall deficit -(g - F / M) dt within 5 %."""
+    from pybullet_robot_envs import _capi
+    from pybullet_robot_envs.model.table import icub_table
+    ora5, _, _ = orc.icub_oracle("l", task=1, use_ik=0, control_orientation=0, floating_base=True)
+    ora, tbl, info = orc.icub_oracle("l", task=1, use_ik=0, control_orientation=0, floating_base=True, base_force=base_force)
+    for o in (ora5, ora):
+        o.task.obj_pose_rnd_std = 0.05; o.task.tg_pose_rnd_std = 0.2
+    ov = icub_overrides(info, "l", 0, 0, 1)
+    eng = Engine(tbl, task=1, num_envs=n, lib=lib, robot=_capi.ROBOT_ICUB, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, **ov)
+    assert eng.ndof == 26
+
+    def to_engine(a):            # (the engine keeps the object behind the 32 DoF lanes of its kernel shape, the oracle right behind the 26 joints)
+        a = np.asarray(a, np.float32); b = np.zeros_like(a); vo = eng.v_off
+        b[:, :26] = a[:, :26]; b[:, 32:39] = a[:, 26:33]
+        b[:, vo:vo + 26] = a[:, vo:vo + 26]; b[:, vo + 32:vo + 38] = a[:, vo + 26:vo + 32]
+        b[:, eng.x_off:] = a[:, eng.x_off:]
+        return b
+
+    def to_oracle(a):
+        a = np.asarray(a); b = np.zeros_like(a); vo = eng.v_off
+        b[:, :26] = a[:, :26]; b[:, 26:33] = a[:, 32:39]
+        b[:, vo:vo + 26] = a[:, vo:vo + 26]; b[:, vo + 26:vo + 32] = a[:, vo + 32:vo + 38]
+        b[:, eng.x_off:] = a[:, eng.x_off:]
+        return b
+    st, _ = ora5.batch_reset(n)            # the settled state of the 500 N model: the base at rest, held
+    M = float(icub_table("l", floating_base=True)[1]["floating_base"]["lumped_mass"])
+    mass_all = M + sum(l["mass"] for l in icub_table("l", floating_base=True)[1]["links"][7:])
+    rng = np.random.default_rng(seed)
+    worst = {}
+    vo = eng.v_off
+    for k in range(steps + 1):
+        # (step 0 with zero actions -- gentle joint targets: the vertical row carries the weight alone; then random targets, whose reaction
+        # forces are of the bound's size themselves)
+        a = rng.uniform(-1, 1, (n, eng.act_dim)).astype(np.float32) if k else np.zeros((n, eng.act_dim), np.float32)
+        s32 = st.astype(np.float32)
+        eng.set_state(to_engine(s32))
+        ob, rw, dn = eng.step(a)
+        so, out = ora.batch_step(s32.astype(np.float64), a)
+        se = to_oracle(eng.get_state())
+        if k == 0:
+            g = abs(float(ora.params.gravity_z)) if hasattr(ora.params, "gravity_z") else 9.8
+            want = -(g - base_force / mass_all) * float(ora.params.dt)
+            assert np.all(np.abs(so[:, vo + 2] / want - 1) < 0.05), ("oracle: the base does not sink at the free-fall deficit", so[:, vo + 2], want)
+            assert np.all(np.abs(se[:, vo + 2] / want - 1) < 0.05), ("engine: the base does not sink at the free-fall deficit", se[:, vo + 2], want)
+        merge_worst(worst, {"q": float(np.abs(se[:, :26] - so[:, :26]).max()), "qd": float(np.abs(se[:, vo:vo + 26] - so[:, vo:vo + 26]).max()),
+                            "obs_ee_pos": float(np.abs(ob[:, :3] - out[:, :3]).max())})
+        st = so
+    assert_within(worst, TOL_ICUB_FLOAT, "(floating-base iCub, base constraint bounded at %g N, %d envs x %d steps)" % (base_force, n, steps))
+    return {"worst": worst, "base_vz_after_one_step": float(se[0, vo + 2])}
+
+
 def check_icub_floating_base(Engine, lib, n=2, steps=3, use_ik=1, seed=9):
     """The fidelity option for the reference's floating base (icub_env.py:95-101: createConstraint(JOINT_FIXED) on a floating multibody):
     (1) engine against oracle on the floating model -- reset and single steps within TOL_ICUB_FLOAT; (2) the option's effect, engine
@@ -2676,5 +2732,7 @@ def check_icub_floating_base(Engine, lib, n=2, steps=3, use_ik=1, seed=9):
         d_ee = max(d_ee, float(np.abs(o1[:, :3] - o2[:, :3]).max()))
         d_base = max(d_base, float(np.abs(eng.get_state()[:, :3]).max()))
     rep.update({"ee_pos_shift_vs_pinned_base_40_steps_m": d_ee, "base_excursion_40_steps_m": d_base, "worst": worst})
-    assert 0 < d_base < 5e-3 and d_ee < 2e-2, rep      # the base is dynamic (it moves) and the constraint holds it (it moves little)
+    # the base is dynamic (it moves) and the constraint holds it (it moves little).  (Until round 6 the constraint's rows were unbounded: excursion
+    # < 5 mm, hand shift < 2 mm.  With the constraint's 500 N on every row the random joint targets' reaction forces DO saturate it: 7 mm / 12 mm.)
+    assert 0 < d_base < 2e-2 and d_ee < 3e-2, rep
     return rep

@@ -308,7 +308,14 @@ def test_icub_floating_base_option(hip_lib, use_ik):
     """The soft-pinned floating base (model/table.py: float_base; 26 DoF, kw_step<Shape64>) on the device against the oracle, and its
     effect on the hand's observation against the rigidly pinned default model."""
     rep = parity.check_icub_floating_base(_capi.Engine, hip_lib, n=4, steps=3, use_ik=use_ik)
-    assert rep["ee_pos_shift_vs_pinned_base_40_steps_m"] < 2e-3
+    assert rep["ee_pos_shift_vs_pinned_base_40_steps_m"] < 3e-2      # (12 mm with the constraint's 500 N bound on its rows, round 6; 2 mm unbounded)
+
+
+def test_icub_base_constraint_force_bound(hip_lib):
+    """the base constraint's maxForce as a bound on its rows, set below the robot's weight: the robot sinks at the free-fall deficit, device
+    against oracle"""
+    rep = parity.check_icub_base_force_bound(_capi.Engine, hip_lib, n=4)
+    print(rep)
 
 
 def _write_chamfered_box_obj(path, full=(0.09, 0.07, 0.08), b=0.012):
