@@ -50,6 +50,12 @@
 #define PBRE_PROBE(k)
 #define PBRE_PROBE_DECL
 #endif
+#ifndef PBRE_FREE_SWITCH_FRAC        // the fraction of its bound an applied impulse may reach on the clamp-free stages (see free_far_inside)
+#define PBRE_FREE_SWITCH_FRAC 0.5f
+#endif
+#ifndef PBRE_FREE_SWITCH             // 1: a wave on the clamp-free motor stages goes on with the clamping ones once an impulse is past PBRE_FREE_SWITCH_FRAC of its
+#define PBRE_FREE_SWITCH 0           // bound, instead of starting over when one leaves it (see free_far_inside).  Bit-identical rows; k_fused at 131072 envs max 292 ->
+#endif                               // 240 us, mean 165.5 -> 163.2, but median 149.5 -> 156.1, and at 16384 envs mean 123.9 -> 125.5 (profiles/r06zj_switch_ab.txt): off.
 #ifndef PBRE_PROBE_PATH      // (probe builds: which solver path a wave took)
 #define PBRE_PROBE_PATH(k)
 #endif
@@ -1192,6 +1198,13 @@ struct Core {
                 R.m_app = R.m_app + m_dsel;
                 return !LR::any(LR::bnot(LR::le(LR::abs(R.m_app), R.m_lim)));
             };
+            // ... and (round 6, PBRE_FREE_SWITCH) true while every applied impulse is still far inside it.  A wave that starts over is the longest of
+            // its step at TWICE the chain, and 27 % of the stationary steps at 131072 envs have one (tools/wave_trace.py, profiles/r06zf_wave_trace.txt;
+            // r06ze_tail_ab.txt: k_fused max 290 us against 238, mean 166.1 against 161.9, with the clamp-free stages off altogether).  With the switch
+            // a wave leaves the clamp-free stages for the clamping ones at the next boundary between sweep pairs once an impulse is past
+            // PBRE_FREE_SWITCH_FRAC of its bound -- nothing has been clamped yet, so the clamp-free rows so far ARE the clamping rows bit for bit and
+            // the sweeps simply go on; starting over is left for an impulse that jumps past the bound within one pair.  Measured, the two cancel.
+            auto free_far_inside = [&]() { return !LR::any(LR::bnot(LR::le(LR::abs(R.m_app), R.m_lim * LR::c(PBRE_FREE_SWITCH_FRAC)))); };
             auto limit2 = [&](int j) {
                 FR t = LR::fma(R.l_j, L::lo(dvr), zeroR - R.l_rhs);
                 FR s_ = LR::med3(R.l_app - t, zeroR, llim);
@@ -1315,21 +1328,37 @@ struct Core {
                 if (NRO || ro_bits) coupled(true, nroc);
                 if (rt_bits && !e_zip) rt_f();
             };
-            for (int it = 0; it < P.iters; it += 2) {
-                if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}, freec); else phase_a(std::true_type{}, std::false_type{}, freec);
-                if constexpr (FREE) { if (!free_in_bound()) return false; }
-                if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
-                mid();
-                if constexpr (RT) { if (chains_end(it)) break; }
-                if (it + 1 >= P.iters) break;
-                if (has_limit) {          // odd sweep: limits first, then the motors in forward order
-                    PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
+            // the sweeps from `it0` (even) on, in pairs, with the clamp-free (fc = true) or the clamping motor stages.  Returns 0: done (all sweeps, or
+            // the residual exit), 1: clamp-free stages only -- an applied impulse is past PBRE_FREE_SWITCH_FRAC of its bound: go on from `it0` (updated)
+            // with the clamping stages, 2: clamp-free stages only -- an impulse has left its bound: start over.  (Two loops, one per kind of stage,
+            // and NOT one loop with a test per phase: a branch between the phases splits the basic block the two chains' stages are interleaved in --
+            // measured, a coupled wave's sweeps 173 -> 197 us, profiles/r06zi_wave_trace_switch.txt.)
+            auto pairs = [&](auto fc, int& it0) -> int {
+                constexpr bool FC = decltype(fc)::value;
+                for (int it = it0; it < P.iters; it += 2) {
+                    if (e_zip && it > 0) phase_a(std::true_type{}, std::true_type{}, fc); else phase_a(std::true_type{}, std::false_type{}, fc);
+                    if constexpr (FC) { if (!free_in_bound()) return 2; }
+                    if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
+                    mid();
+                    if constexpr (RT) { if (chains_end(it)) return 0; }
+                    if (it + 1 >= P.iters) return 0;
+                    if (has_limit) {          // odd sweep: limits first, then the motors in forward order
+                        PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j);
+                    }
+                    if (e_zip) phase_a(std::false_type{}, std::true_type{}, fc); else phase_a(std::false_type{}, std::false_type{}, fc);
+                    if constexpr (FC) { if (!free_in_bound()) return 2; }
+                    mid();
+                    if constexpr (RT) { if (chains_end(it + 1)) return 0; }
+                    if constexpr (FC) { if (PBRE_FREE_SWITCH && !free_far_inside()) { it0 = it + 2; PBRE_PROBE_PATH(10); return 1; } }
                 }
-                if (e_zip) phase_a(std::false_type{}, std::true_type{}, freec); else phase_a(std::false_type{}, std::false_type{}, freec);
-                if constexpr (FREE) { if (!free_in_bound()) return false; }
-                mid();
-                if constexpr (RT) { if (chains_end(it + 1)) break; }
-            }
+                return 0;
+            };
+            int it0 = 0;
+            if constexpr (FREE) {
+                const int r = pairs(std::true_type{}, it0);
+                if (r == 2) return false;
+                if (r == 1) (void)pairs(std::false_type{}, it0);
+            } else (void)pairs(std::false_type{}, it0);
             if (e_zip) rt_f();            // the last sweep's
             dv = L::sel(obj_lane, dvo, dvr);
             }
@@ -1417,6 +1446,9 @@ struct Core {
         }
 
         PBRE_PROBE_PATH(solved ? 12 : (solved2 ? (robot_only_path ? 13 : 14) : 15));      // clamp-free / robot-only chain / two zipped chains / loops with per-slot tests
+#ifdef PBRE_TRACE_ROWS
+        PBRE_TRACE_ROWS(on_bits, has_limit);      // (tools/wave_trace.py builds: what the wave's sweeps were made of)
+#endif
         PBRE_PROBE(9);      // the sweeps
         // ---- velocity + position update (semi-implicit Euler; quaternion exponential map for the object)
         F vnew = clampf(vstar + L::sel(L::eqi(lane, L1), zero, dv), zero - vmax, vmax);
