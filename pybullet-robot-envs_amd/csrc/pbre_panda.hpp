@@ -44,13 +44,13 @@ __device__ unsigned long long g_probe[64];
 #ifdef PBRE_WAVE_TRACE       // tools/wave_trace.py (variant build of ONE step unit): every row wave records the ticks from the start of Core::step to the end
 // of its sweeps and what its sweeps were made of -- bits 0..15: solver paths taken (11 = started over with clamping motor rows, 12..15 see
 // PBRE_PROBE_PATH in pbre_core.hpp), 16..19 robot-object slots, 20..23 object-table slots, 24..25 robot-table slots, 30 a joint-limit row -- to find the step's longest wave
-__device__ unsigned long long g_wtrace[16384][2];
+__device__ unsigned long long g_wtrace[16384][3];      // ticks, bits, address of the wave's (first group's) state record
 __device__ unsigned int g_wtrace_n;
 #define PBRE_PROBE_DECL unsigned wt_bits_ = 0u; unsigned long long wt_t0_ = __builtin_readcyclecounter(); (void)wt_bits_; (void)wt_t0_;
 #define PBRE_PROBE_PATH(k) (wt_bits_ |= 1u << (k))
 #define PBRE_TRACE_ROWS(ob, hl) (wt_bits_ |= ((((unsigned)(ob) >> 4) & 15u) << 16) | (((unsigned)(ob) & 15u) << 20) | ((((unsigned)(ob) >> 8) & 3u) << 24) | ((hl) ? 1u << 30 : 0u))
 #define PBRE_PROBE(k) do { if ((k) == 9 && (threadIdx.x & 63) == 0) { const unsigned i_ = atomicAdd(&g_wtrace_n, 1u); \
-        if (i_ < 16384u) { g_wtrace[i_][0] = __builtin_readcyclecounter() - wt_t0_; g_wtrace[i_][1] = wt_bits_; } } } while (0)
+        if (i_ < 16384u) { g_wtrace[i_][0] = __builtin_readcyclecounter() - wt_t0_; g_wtrace[i_][1] = wt_bits_; g_wtrace[i_][2] = (unsigned long long)st; } } } while (0)
 #endif
 #include "pbre_host.hpp"
 #include "lanes_device.hpp"

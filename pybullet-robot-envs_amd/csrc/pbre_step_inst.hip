@@ -11,7 +11,7 @@ extern "C" int pbre_debug_wave_trace(unsigned long long* out, int max_records, i
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wtrace_n), sizeof n) != hipSuccess) return -1;
     if (n > 16384u) n = 16384u;
     if ((int)n > max_records) n = (unsigned)max_records;
-    if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), (size_t)n * 2 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wtrace), (size_t)n * 3 * sizeof(unsigned long long)) != hipSuccess) return -1;
     const unsigned int z = 0;
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace_n), &z, sizeof z) != hipSuccess) return -1;
     return (int)n;

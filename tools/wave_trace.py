@@ -46,9 +46,10 @@ def main():
         act.uniform_(-1, 1, generator=gen)
         eng.step_device(act.data_ptr(), out.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (2 * 16384))()
+    buf = (C.c_ulonglong * (3 * 16384))()
     lib.pbre_debug_wave_trace(buf, 16384, 1)
     rec = []
+    persist, prev_so = [0, 0], set()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for k in range(a.steps):
         act.uniform_(-1, 1, generator=gen)
@@ -60,7 +61,11 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         m = lib.pbre_debug_wave_trace(buf, 16384, 1)
-        r = np.frombuffer(buf, dtype=np.uint64, count=2 * max(m, 0)).reshape(-1, 2).copy()
+        r = np.frombuffer(buf, dtype=np.uint64, count=3 * max(m, 0)).reshape(-1, 3).copy()
+        so_set = set(int(x) for x in r[((r[:, 1] >> np.uint64(11)) & np.uint64(1)) != 0, 2]) if m > 0 else set()
+        if k > 0:
+            persist[0] += len(so_set & prev_so); persist[1] += len(so_set)
+        prev_so = so_set
         if m <= 0:
             rec.append((ms, 0, 0, 0, 0, 0)); continue
         i = int(np.argmax(r[:, 0]))
@@ -81,6 +86,7 @@ def main():
     for g, v in sorted(groups.items(), key=lambda kv: -len(kv[1])):
         v = np.array(v)
         print("  %4d steps  step time mean %6.1f us (min %6.1f max %6.1f)  longest wave mean %6.1f us   %s" % (len(v), v[:, 0].mean(), v[:, 0].min(), v[:, 0].max(), v[:, 1].mean(), g))
+    print("waves that started over: %d in all; %d of them (%.0f %%) step an env whose wave also started over in the step before" % (persist[1], persist[0], 100.0 * persist[0] / max(1, persist[1])))
     so = np.array([x[4] for x in rec])
     print("row waves that left the clamp-free stages for the clamping ones (bit 10), per step: mean %.2f" % np.mean([x[5] for x in rec]))
     print("steps with a wave that started over: %d of %d (their step time mean %.1f us; the others %.1f us)" % ((so > 0).sum(), len(so), ms[so > 0].mean() * 1e3 if (so > 0).any() else 0.0, ms[so == 0].mean() * 1e3))
