@@ -809,9 +809,11 @@ def main():
             "k_fast_variant": {"steps_that_were_one_launch_since_reset": info[13], "vgprs_one_launch_kernel": info[14],
                                "steps_with_3_waves_per_simd_variant_since_reset": info[8], "vgprs_2_wave_variant": info[0], "vgprs_3_wave_variant": info[9],
                                "steps_with_the_pair_kernel_since_reset": info[10], "vgprs_pair_kernel": info[11],
+                               "steps_with_tail_pairs_since_reset": info[15] if len(info) > 15 else None,
                                "note": "round 5: a step is ONE launch (k_fused: the complex envs' row waves + the simple envs' waves in one grid; PBRE_FUSED=0: the two kernels on two streams of rounds 1-4, "
                                        "where launch_step picks the 168-VGPR k_fast for steps in which the row waves would push waves of the 256-VGPR build into a second round, PBRE_FAST3); "
-                                       "the simple envs' waves are the pair mapping (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR)"},
+                                       "the simple envs' waves are the pair mapping (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR); "
+                                       "round 6: in a machine-filling batch the last chunks -- as many as the row waves keep out of the first round -- are stepped as such pairs too (tail pairs, PBRE_TAIL_PAIR)"},
             "contact_histogram_rank0": contact_hist,
             "nan_inf_guard": {"bad_env_steps_since_create": info[12], "note": "env-steps whose state was not finite (pbre_kernel_info[12]); such envs are returned with done = 1 and restarted"},
             "shards": shards,

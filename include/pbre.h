@@ -315,7 +315,9 @@ int pbre_timing(const pbre_ctx* ctx, double* ms, int32_t n);
  * returned with reward 0 and done 1; with PBRE_F_AUTO_RESET the env restarts from the settled snapshot in the same step, without it the
  * env keeps its NaN state (and is counted again every step) until the caller resets it.  The reference has no such guard.
  * [13] steps since the last reset that were ONE launch (the complex envs' row blocks and the simple envs' waves in one grid, round 5: no
- * fork / join through a second stream; [10] still says whether the simple envs' waves were the pair mapping), [14] its VGPRs. */
+ * fork / join through a second stream; [10] still says whether the simple envs' waves were the pair mapping), [14] its VGPRs, [15] those
+ * of [13] in which the last chunks of a machine-filling batch -- the ones the complex envs' waves keep out of the first round -- were
+ * stepped as robot wave + object wave pairs (round 6: "tail pairs"). */
 int pbre_kernel_info(const pbre_ctx* ctx, int32_t* info, int32_t n);
 
 /* ---- The sharded batch's per-step gather, owned by the context (no counterpart in the reference: it is one env per physics client

@@ -29,6 +29,19 @@ struct DevLanes {
         return x;
     }
     static __device__ __forceinline__ F setlane(F x, int j, F src) { return setlane_l(x, j, src, (int)(threadIdx.x & 15u)); }
+    // The tail of a one-DoF row (motor / limit row of joint J) as ONE block of three instructions:
+    //     rec lane J <- recval          (v_cmp_eq_u32 + v_cndmask_b32, as setlane)
+    //     acc += (lane J of bval) * m   (v_fmac_f32 with a DPP row_newbcast source operand: no v_mov_b32_dpp, no register for the broadcast)
+    // Round 6 measured that a lone wave issues one instruction per ~4.5 cycles whether or not it depends on its predecessor
+    // (profiles/r06_ubench_valu.txt): every instruction of the row waves' sweeps is on the step's critical path, the ones "off the chain"
+    // too.  The compiler does not fold update_dpp into the fma (VOP3 at that point), hence the asm.  The DPP operand needs two wait
+    // states behind the VALU write of bval: the compare and the select are those two (one block: the order is fixed).
+    template <int J>
+    static __device__ __forceinline__ F row_tail(F& rec, F recval, F bval, F m, F acc) {
+        asm("v_cmp_eq_u32_e32 vcc, %3, %2\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_fmac_f32_dpp %1, %5, %6 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(rec), "+v"(acc) : "v"((int)(threadIdx.x & 15u)), "n"(J), "v"(recval), "v"(bval), "v"(m) : "vcc");
+        return acc;
+    }
     static __device__ __forceinline__ unsigned long long lanebits(B b) {      // bit j: b holds on lane j of some group of the wave
         unsigned long long m = __ballot((int)b);
         m |= m >> 32; m |= m >> 16;
@@ -152,6 +165,8 @@ struct DevLanes32 : DevLanes {
     // select, as in DevLanes64::setlane, -6 % although it removes the v_readlane pairs that restore the compiler's spilled SGPR masks
     // -- the half-wave solver loop is bound by its per-wave serial chain, not by VALU issue)
     static __device__ __forceinline__ F setlane(F x, int j, F src) { return (int)(threadIdx.x & 31u) == j ? src : x; }
+    template <int J>
+    static __device__ __forceinline__ F row_tail(F& rec, F recval, F bval, F m, F acc) { rec = setlane(rec, J, recval); return __builtin_fmaf(bcast(bval, J), m, acc); }
     static __device__ __forceinline__ unsigned long long lanebits(B b) { unsigned long long m = __ballot((int)b); return (m | (m >> 32)) & 0xFFFFFFFFull; }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 31u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 31u) == 0; }
@@ -225,6 +240,8 @@ struct DevLanes64 : DevLanes {
             : "+v"(x) : "v"(src), "n"(j < 32 ? 1u << (j & 31) : 0u), "n"(j >= 32 ? 1u << (j & 31) : 0u) : "vcc");
         return x;
     }
+    template <int J>
+    static __device__ __forceinline__ F row_tail(F& rec, F recval, F bval, F m, F acc) { rec = setlane(rec, J, recval); return __builtin_fmaf(bcast(bval, J), m, acc); }
     static __device__ __forceinline__ I lane() { return (int)(threadIdx.x & 63u); }
     static __device__ __forceinline__ bool lane0() { return (threadIdx.x & 63u) == 0; }
     static __device__ __forceinline__ F load(const float* p) { return p[threadIdx.x & 63u]; }

@@ -129,12 +129,14 @@ static hipError_t alloc_buf(EnvBuf& b, int cap) {
     if ((e = hipMalloc(&b.count, (3 * NB + 2) * sizeof(int))) != hipSuccess) return e;      // + the device copy of the "recent" hint
     if ((e = hipMalloc(&b.objv_g, (size_t)(cap + 32) * W * sizeof(float))) != hipSuccess) return e;
     if ((e = hipMemset(b.objv_g, 0, (size_t)(cap + 32) * W * sizeof(float))) != hipSuccess) return e;
+    if ((e = hipMalloc(&b.pair_g, (size_t)((cap + FTPB - 1) / FTPB) * PBRE_PAIR_G_BYTES)) != hipSuccess) return e;
+    if ((e = hipMemset(b.pair_g, 0, (size_t)((cap + FTPB - 1) / FTPB) * PBRE_PAIR_G_BYTES)) != hipSuccess) return e;
     if ((e = hipHostMalloc(&b.h_total, 2 * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
     b.h_total[0] = 1; b.h_total[1] = 16;   // unknown until the first step has run
     return hipMemset(b.count, 0, (3 * NB + 2) * sizeof(int));
 }
 static void free_buf(EnvBuf& b) {
-    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count, (void*)b.objv_g}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)b.state, (void*)b.cls, (void*)b.tgt, (void*)b.list[0], (void*)b.list[1], (void*)b.count, (void*)b.objv_g, (void*)b.pair_g}) if (p) (void)hipFree(p);
     if (b.h_total) (void)hipHostFree(b.h_total);
 }
 
@@ -254,6 +256,7 @@ int pbre_create(const pbre_config* cfg, pbre_ctx** out) {
     if (const char* ev = getenv("PBRE_FUSED")) c->fused = atoi(ev);
     if (const char* ev = getenv("PBRE_OBJV_SEQ0")) c->main.objv_seq = c->tmp.objv_seq = atoi(ev);      // (tests: start k_fused's sequence numbers next to their wrap)
     if (const char* ev = getenv("PBRE_PAIR")) c->pair = atoi(ev);
+    if (const char* ev = getenv("PBRE_TAIL_PAIR")) c->tail_pair = atoi(ev);      // (0: A/B; n > 1: tests -- always the last n chunks)
     if (const char* ev = getenv("PBRE_ZERO_COPY")) c->zero_copy = atoi(ev);
     int ndev = 0;
     hipError_t he = hipGetDeviceCount(&ndev);
@@ -423,7 +426,7 @@ int pbre_reset(pbre_ctx* c, const uint8_t* mask, float* obs) {
             c->P.rst_ok = nc == 0 ? 1 : 0;         // every env of the freshly reset batch is in the simple class
         }
     }
-    c->k_steps = 0; c->launches = 0; c->launches3 = 0; c->launches_pair = 0; c->launches_fused = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
+    c->k_steps = 0; c->launches = 0; c->launches3 = 0; c->launches_pair = 0; c->launches_fused = 0; c->launches_tail = 0;      // pbre_timing[3] averages env steps only, not the settle launches above
     if (obs) return pbre_observe(c, obs);
     return PBRE_OK;
 }
@@ -764,10 +767,10 @@ int pbre_kernel_info(const pbre_ctx* c, int32_t* info, int32_t n) {
         (void)hipSetDevice(c->device); (void)hipDeviceSynchronize();
         (void)hipMemcpy(&bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost);
     }
-    const int v[15] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
+    const int v[16] = {lpe ? rf : -1, rg, lpe ? 1 : 0, lpe ? c->n - complex_now : 0, lpe ? 0 : c->n, complex_now, lpe ? rr : -1, complex_sum,
                        (int)(c->launches3 & 0x7fffffff), lpe ? rf3 : -1, (int)(c->launches_pair & 0x7fffffff), lpe ? rp : -1, bad,
-                       (int)(c->launches_fused & 0x7fffffff), lpe ? ru : -1};
-    for (int i = 0; i < n; i++) info[i] = i < 15 ? v[i] : 0;
+                       (int)(c->launches_fused & 0x7fffffff), lpe ? ru : -1, (int)(c->launches_tail & 0x7fffffff)};
+    for (int i = 0; i < n; i++) info[i] = i < 16 ? v[i] : 0;
     return PBRE_OK;
 }
 

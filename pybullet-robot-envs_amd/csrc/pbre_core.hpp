@@ -56,6 +56,12 @@
 #ifndef PBRE_FREE_SWITCH             // 1: a wave on the clamp-free motor stages goes on with the clamping ones once an impulse is past PBRE_FREE_SWITCH_FRAC of its
 #define PBRE_FREE_SWITCH 0           // bound, instead of starting over when one leaves it (see free_far_inside).  Bit-identical rows; k_fused at 131072 envs max 292 ->
 #endif                               // 240 us, mean 165.5 -> 163.2, but median 149.5 -> 156.1, and at 16384 envs mean 123.9 -> 125.5 (profiles/r06zj_switch_ab.txt): off.
+#ifndef PBRE_FRIC_FOLD               // 1: the staged friction rows of the two-chain sweeps take their "normal impulse is 0: skip" from the bounds (see cstage)
+#define PBRE_FRIC_FOLD 1
+#endif
+#ifndef PBRE_RO_LIMIT_SPECIAL        // 1: a robot-only wave with exactly ONE joint at a limit runs a copy of its sweeps with that joint's limit row inlined -- no
+#define PBRE_RO_LIMIT_SPECIAL 1      // per-joint scalar test + branch between the rows (9 x ~15 cycles per sweep for a lone wave)
+#endif
 #ifndef PBRE_PROBE_PATH      // (probe builds: which solver path a wave took)
 #define PBRE_PROBE_PATH(k)
 #endif
@@ -1168,12 +1174,17 @@ struct Core {
             PBRE_TWO_CHAIN_TRACE(ro_bits, rt_bits, has_limit);      // (host test builds: which row patterns took this path)
 #endif
             F dvr = dv, dvo = dv;         // 1 on the constant-one lane, 0 elsewhere
-            // ---- a motor row (motor_x) in 4 stages on dvr
+            // ---- a motor row (motor_x) in 3 stages on dvr
+            // Round 6, last session: the row as few INSTRUCTIONS as it can be -- a lone wave issues one per ~4.5 cycles whether or not it depends
+            // on its predecessor (profiles/r06_ubench_valu.txt), so the bookkeeping "off the chain" cost as much as the chain.  The two clamp
+            // bounds are taken once per sweep (motors_begin: a motor's applied impulse only changes in its own row, once per sweep), the
+            // deltas are collected in m_dsel and added to the applied impulses once per sweep (motors_end), and the row's tail -- record the
+            // delta, broadcast it, update the vector -- is L::row_tail's three instructions (v_fmac with a DPP row broadcast as its source).
+            // Same operations on the same operands as before: bit-identical rows (GPU tests: the plain loops against these paths).
             FR m_nt = zeroR, m_d = zeroR, m_lo = zeroR, m_hi = zeroR;
-            F m_bc = zero;
-            // FREE (round 5): the same row WITHOUT its clamp, in 3 stages -- delta = rhs' - dinv dv_j goes straight to the broadcast.  While no
+            // FREE (round 5): the same row WITHOUT its clamp, in 2 stages -- delta = rhs' - dinv dv_j goes straight to the broadcast.  While no
             // motor reaches its impulse bound (PyBullet's default force, 1e5 N, is far out of reach) this is the clamping row's delta bit for
-            // bit (a med3 whose bounds do not bind returns its first operand), at 5 instructions instead of 9 on the wave's serial chain.  The
+            // bit (a med3 whose bounds do not bind returns its first operand), at 4 instructions instead of 6 on the wave's serial chain.  The
             // deltas of a sweep are collected in m_dsel, added to the applied impulses after the sweep's motor rows and tested against the
             // bound there (a motor's impulse only changes in its own row: every value it takes is seen); if one ever leaves it, the solve
             // starts over with the clamping stages -- same mechanism as the wide shapes' FREE_ROWS above.
@@ -1183,14 +1194,18 @@ struct Core {
                 constexpr bool FREE = decltype(freec)::value;
                 if constexpr (FREE) {
                     if constexpr (st == 0) m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs);
-                    else if constexpr (st == 1) { m_dsel = LR::setlane(m_dsel, j, m_nt); m_bc = LR::bcast(m_nt, j); }
-                    else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
+                    else dvr = L::template row_tail<j>(m_dsel, m_nt, m_nt, R.Mi[j], dvr);
                 } else {
-                if constexpr (st == 0) { m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs); m_lo = nmlim - R.m_app; m_hi = R.m_lim - R.m_app; }
+                if constexpr (st == 0) m_nt = LR::fma(m_ndinv_x, L::lo(dvr), R.m_rhs);
                 else if constexpr (st == 1) m_d = LR::med3(m_nt, m_lo, m_hi);
-                else if constexpr (st == 2) { R.m_app = LR::setlane(R.m_app, j, R.m_app + m_d); m_bc = LR::bcast(m_d, j); if constexpr (RT) m_dsw = LR::setlane(m_dsw, j, m_d); }
-                else dvr = L::fma_lo(m_bc, R.Mi[j], dvr);
+                else dvr = L::template row_tail<j>(m_dsel, m_d, m_d, R.Mi[j], dvr);
                 }
+            };
+            // before / after the motor rows of a sweep on the clamping stages (the clamp-free ones: free_in_bound)
+            auto motors_begin = [&]() { m_lo = nmlim - R.m_app; m_hi = R.m_lim - R.m_app; };
+            auto motors_end = [&]() {
+                R.m_app = R.m_app + m_dsel;
+                if constexpr (RT) m_dsw = m_dsel;      // (the sweep's motor deltas, for the residual test at its end)
             };
             // end of a sweep's clamp-free motor rows: false if an applied impulse has left its bound (a NaN fails the test too)
             auto free_in_bound = [&]() {
@@ -1226,12 +1241,18 @@ struct Core {
                 constexpr bool FRIC = decltype(fricc)::value, OBJ = decltype(objc)::value;
                 constexpr int st = (OBJ && st0 >= 4) ? st0 + 1 : st0;         // OBJ rows skip stage 4 (row_mirror)
                 if constexpr (st == 0) {
-                    if (FRIC) { f.lo = zero - lim; f.hi = lim; } else { f.lo = zero; f.hi = big; }
+                    if (FRIC) {
+                        // PBRE_FRIC_FOLD: "skipped while the normal impulse is 0" as the row's BOUNDS -- med3(x, app, app) = app, the value the select
+                        // behind the clamp returned -- taken here, off the row's chain of dependent instructions (one link less per friction row:
+                        // a lone wave's dependent instruction costs 8.25 cycles, profiles/r06_ubench_valu.txt)
+                        if (PBRE_FRIC_FOLD) { const B on_ = L::gt(lim, zero); f.lo = L::sel(on_, zero - lim, app); f.hi = L::sel(on_, lim, app); }
+                        else { f.lo = zero - lim; f.hi = lim; }
+                    } else { f.lo = zero; f.hi = big; }
                     f.p = R.rs.get(ROW) * vec;
                 }
                 else if constexpr (st <= 4) f.p = L::sum_step(f.p, st - 1);
                 else if constexpr (st == 5) f.s = app - f.p;
-                else if constexpr (st == 6) { f.s = L::med3(f.s, f.lo, f.hi); if (FRIC) f.s = L::sel(L::gt(f.hi, zero), f.s, app); }
+                else if constexpr (st == 6) { f.s = L::med3(f.s, f.lo, f.hi); if (FRIC && !PBRE_FRIC_FOLD) f.s = L::sel(L::gt(f.hi, zero), f.s, app); }
                 else if constexpr (st == 7) { f.p = f.s - app; app = f.s; if constexpr (RT) f.res = L::max(f.res, L::abs(f.p * r_den[ROW / 6][(ROW % 6) / 2])); }
                 else vec = L::fma(f.p, R.rs.get(ROW + 1), vec);
             };
@@ -1252,14 +1273,16 @@ struct Core {
             // (RTf' M || OTn): robot stream = [2 NC_RT friction rows of the previous sweep] + NJ motor rows, object stream = NC_OT normal rows
             auto phase_a = [&](auto rev_c, auto e_c, auto freec) {
                 constexpr bool REV = decltype(rev_c)::value, WITH_E = decltype(e_c)::value;
-                constexpr int MS = decltype(freec)::value ? 3 : 4;       // stages of a motor row
+                constexpr int MS = decltype(freec)::value ? 2 : 3;       // stages of a motor row
                 constexpr int NE = WITH_E ? 2 * NC_RT * NSR : 0, NR = NE + MS * NJ, NO = NSO * NC_OT, NZ = NR > NO ? NR : NO;
+                if constexpr (!decltype(freec)::value) motors_begin();
                 for_seq<NZ>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k < NE) fstage(fr, dvr, std::integral_constant<int, NRT0 + (k / NSR) / 2>{}, std::integral_constant<int, (k / NSR) % 2>{}, std::integral_constant<int, k % NSR>{});
                     else if constexpr (k < NR) { constexpr int r = (k - NE) / MS; mstage(std::integral_constant<int, (REV ? NJ - 1 - r : r)>{}, std::integral_constant<int, (k - NE) % MS>{}, freec); }
                     if constexpr (k < NO) nstage(fo, dvo, std::integral_constant<int, k / NSO>{}, std::integral_constant<int, k % NSO>{});
                 });
+                if constexpr (!decltype(freec)::value) motors_end();
             };
             // (RTn || OTf)
             auto phase_c = [&](auto rt_c) {
@@ -1297,28 +1320,44 @@ struct Core {
             // then starts over with the clamping stages)
             auto run_chains = [&](auto freec, auto nroc) -> bool {
                 constexpr bool FREE = decltype(freec)::value;
-                constexpr int MS = FREE ? 3 : 4;
+                constexpr int MS = FREE ? 2 : 3;
                 constexpr int NRO = decltype(nroc)::value;
             if (NRO == 0 && robot_only) {
                 robot_only_path = true;
                 auto motors = [&](auto rev_c) {
                     constexpr bool REV = decltype(rev_c)::value;
+                    if constexpr (!FREE) motors_begin();
                     for_seq<MS * NJ>([&](auto kc) { constexpr int k = decltype(kc)::value; mstage(std::integral_constant<int, (REV ? NJ - 1 - k / MS : k / MS)>{}, std::integral_constant<int, k % MS>{}, freec); });
+                    if constexpr (!FREE) motors_end();
                 };
                 auto rt_n = [&]() { for_seq<NC_RT * NSR>([&](auto kc) { constexpr int k = decltype(kc)::value; nstage(fr, dvr, std::integral_constant<int, NRT0 + k / NSR>{}, std::integral_constant<int, k % NSR>{}); }); };
-                for (int it = 0; it < P.iters; it += 2) {
-                    motors(std::true_type{});
-                    if constexpr (FREE) { if (!free_in_bound()) return false; }
-                    if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
-                    if (rt_bits) { rt_n(); rt_f(); }
-                    if constexpr (RT) { if (chains_end(it)) break; }
-                    if (it + 1 >= P.iters) break;
-                    if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j); }
-                    motors(std::false_type{});
-                    if constexpr (FREE) { if (!free_in_bound()) return false; }
-                    if (rt_bits) { rt_n(); rt_f(); }
-                    if constexpr (RT) { if (chains_end(it + 1)) break; }
+                // LJ >= 0: joint LJ is the only joint of the wave at a limit (PBRE_RO_LIMIT_SPECIAL) -- its row inlined, no per-joint tests; -1: test every joint
+                auto ro_sweeps = [&](auto ljc) -> bool {
+                    constexpr int LJ = decltype(ljc)::value;
+                    for (int it = 0; it < P.iters; it += 2) {
+                        motors(std::true_type{});
+                        if constexpr (FREE) { if (!free_in_bound()) return false; }
+                        if constexpr (LJ >= 0) limit2(LJ);
+                        else if (has_limit) { PBRE_UNROLL for (int j = NJ - 1; j >= 0; j--) if ((lim_bits >> j) & 1ull) limit2(j); }
+                        if (rt_bits) { rt_n(); rt_f(); }
+                        if constexpr (RT) { if (chains_end(it)) break; }
+                        if (it + 1 >= P.iters) break;
+                        if constexpr (LJ >= 0) limit2(LJ);
+                        else if (has_limit) { PBRE_UNROLL for (int j = 0; j < NJ; j++) if ((lim_bits >> j) & 1ull) limit2(j); }
+                        motors(std::false_type{});
+                        if constexpr (FREE) { if (!free_in_bound()) return false; }
+                        if (rt_bits) { rt_n(); rt_f(); }
+                        if constexpr (RT) { if (chains_end(it + 1)) break; }
+                    }
+                    return true;
+                };
+                bool ran = false, ok = true;
+                if constexpr (PBRE_RO_LIMIT_SPECIAL && !FREE) {
+                    const int lj = __builtin_popcountll(lim_bits) == 1 ? __builtin_ctzll(lim_bits) : -1;
+                    for_seq<NJ>([&](auto jc) { if (!ran && lj == decltype(jc)::value) { ok = ro_sweeps(jc); ran = true; } });
                 }
+                if (!ran) ok = ro_sweeps(std::integral_constant<int, -1>{});
+                if (!ok) return false;
                 dv = dvr;
             } else {
             const bool e_zip = !RT && rt_bits != 0u && !has_limit;       // the RTf rows ride along with the next sweep's motor rows (RT: a sweep ends where Bullet's does)

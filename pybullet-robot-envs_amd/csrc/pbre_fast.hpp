@@ -69,8 +69,8 @@ typedef float pbre_f2 __attribute__((ext_vector_type(2)));
 #ifndef PBRE_RT_PROBE       // test builds: why a lane did not take the closed form of the residual exit (bit mask) and its state record
 #define PBRE_RT_PROBE(why, st) do {} while (0)
 #endif
-#ifndef PBRE_PAIR_SYNC      // block barrier between the two waves of the pair kernel (device build; never reached on the host)
-#define PBRE_PAIR_SYNC() do {} while (0)
+#ifndef PBRE_PAIR_SYNC      // the robot wave of a pair waits for its object wave (device build: pbre_panda.hpp; never reached on the host)
+#define PBRE_PAIR_SYNC(px, ln) do {} while (0)
 #endif
 #include "pbre_objstep.hpp"
 
@@ -86,6 +86,11 @@ struct PairX {
     float o[7][64];          // object wave -> robot wave: the object's new position (3) and quaternion (4)
     float sc[3 * W][64];     // robot wave, for itself: collision-sphere centres of the new state (tested against the new object pose
                              // once the object wave has delivered it)
+    // the robot wave's own note of where its object wave is (written and read by the robot wave only).  g == nullptr: a sibling wave of the
+    // block -- `o` is complete behind the block barrier; else a wave of ANOTHER block (k_fused's tail pairs, pbre_panda.hpp): the pair's
+    // global record -- this PairX itself, then one word per lane that carries the launch's sequence number `seq` once `o` is complete
+    const float* g;
+    int seq;
 };
 
 // Franka Panda as flattened by build_tables(): 7-revolute chain, two prismatic fingers on lane 6,
@@ -1656,7 +1661,7 @@ struct Fast {
                 // which the object wave's new pose is in LDS, then the sphere-object tests
                 tl = sweep<1>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds, px, ln);
                 if (ROLE == 1) PBRE_PROBE(22);      // robot wave: kinematics of the new state
-                PBRE_PAIR_SYNC();
+                PBRE_PAIR_SYNC(px, ln);
                 if (ROLE == 1) PBRE_PROBE(23);      // robot wave: waiting for the object wave
                 if (!(flags & 1)) {
                     op = v3(px->o[0][ln], px->o[1][ln], px->o[2][ln]);

@@ -16,7 +16,20 @@
 #define PBRE_ANY(x) (__any((int)(x)) != 0)
 #define PBRE_REG_BARRIER() asm volatile("" ::: "memory")
 #define PBRE_LAUNDER(p) asm volatile("" : "+s"(p))
-#define PBRE_PAIR_SYNC() __syncthreads()
+#define PBRE_PAIR_G_FLAGS (55 * 64 * 4 + 64)       /* byte offset of the 64 sequence words in a tail pair's global record: behind a whole PairX */
+#define PBRE_PAIR_G_BYTES (PBRE_PAIR_G_FLAGS + 64 * 4)
+// (Fast::finish, robot wave of a pair: the object wave's seven values in px->o.  px->g == nullptr: the object wave is a sibling wave of the block --
+// block barrier.  Else it is a wave of another block (k_fused's tail pairs) that writes the seven values into the pair's GLOBAL record -- a PairX
+// both waves use (px == px->g there: the k_fused grid's 64-thread blocks keep no LDS, measured: 13.8 KB of static LDS per block cost every k_fast
+// wave of the grid 9 %) -- and then, per lane, the launch's sequence number behind it (release): the lane waits for ITS word (acquire), bounded
+// like PBRE_OBJV_SYNC -- the object wave waits for nothing and its block is dispatched before the robot wave's; a wait that runs out hands NaNs over: the NaN / Inf guard returns the env-step
+// as done = 1, counts it once and restarts the env.)
+#define PBRE_PAIR_SYNC(px, ln) do { if ((px)->g == nullptr) __syncthreads(); else { \
+        const int* f_ = (const int*)((const char*)((px)->g) + PBRE_PAIR_G_FLAGS) + (ln); const int want_ = (px)->seq; int spins_ = 0; bool ok_ = true; \
+        while (__hip_atomic_load(f_, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want_) { \
+            __builtin_amdgcn_s_sleep(8); \
+            if (++spins_ > (1 << 22)) { ok_ = false; break; } } \
+        PBRE_UNROLL for (int k_ = 0; k_ < 7; k_++) (px)->o[k_][ln] = ok_ ? (px)->g[k_ * 64 + (ln)] : __builtin_nanf(""); } } while (0)
 #define PBRE_COUNT_BAD(p) atomicAdd((p), 1)
 // (Core::step, where `objv` and `P` are in scope: the side record is complete behind the block barrier -- its producer is a sibling wave of the
 // block, k_row_list -- or, P.objv_seq != 0, once its first word carries this launch's sequence number: the producer is a wave of another block,
@@ -171,7 +184,11 @@ __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Pa
                                           const float* __restrict__ actions, float* __restrict__ out, int n, int act_dim, int ow, int flags,
                                           const signed char* __restrict__ cls_cur, signed char* __restrict__ cls, int* __restrict__ next_list,
                                           int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count,
-                                          PairX& px, int chunk, int ln, int role) {
+                                          PairX& px_lds, int chunk, int ln, int role, float* __restrict__ pg = nullptr, int seq = 0) {
+    // pg != nullptr (k_fused's tail pairs): the two waves are two one-wave BLOCKS and the pair's record is the chunk's GLOBAL one (a PairX + 64
+    // sequence words, PBRE_PAIR_SYNC): the object wave only ever touches px.o, the robot wave px.sc / px.g / px.seq
+    PairX& px = pg ? *(PairX*)pg : px_lds;
+    if (role == 0) { px.g = pg; px.seq = seq; }                // (every lane the same values; read back by this wave alone)
     const int env = chunk * FTPB + ln;
     if (chunk == 0 && role == 0 && ln < NB) zero_count[ln] = 0;
     const bool live = env < n && cls_cur[env] == 0;
@@ -195,7 +212,8 @@ __device__ __forceinline__ void pair_wave(const Tables* __restrict__ T, const Pa
     } else {
         if constexpr (CT) { if (sim) (void)FastD::step_t<false, 2>(*(const CTables*)T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln); }
         else if (sim) (void)FastD::step_t<false, 2>(*T, P, st, nullptr, nullptr, MODE, flags, 0ull, nullptr, &px, ln);
-        __syncthreads();                      // its stores (state record, LDS) are complete before the robot wave goes on
+        if (pg) { if (sim) __hip_atomic_store((int*)((char*)pg + PBRE_PAIR_G_FLAGS) + ln, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }     // its stores (state record, pg) first
+        else __syncthreads();                 // its stores (state record, LDS) are complete before the robot wave goes on
     }
 }
 #ifndef PBRE_PAIR_WPS
@@ -373,6 +391,7 @@ __global__ __launch_bounds__(RTPB, 2) void k_row_list(const Tables* __restrict__
 // measured 151 us against 157 us for <7, 3> (same file), and it does not spill.
 constexpr int FUSED_WAVES = RTPB / FTPB;
 static_assert(RTPB % FTPB == 0 && FUSED_WAVES % 2 == 0, "k_fused: whole waves, whole pairs");
+static_assert(sizeof(PairX) <= PBRE_PAIR_G_FLAGS, "a tail pair's global record: the sequence words behind the PairX");
 // The arguments travel as ONE struct and each role reads them through its own (laundered) pointer into the kernarg segment.  As plain kernel
 // arguments all of them -- Params is ~600 bytes -- are loaded in the entry block and stay live in SGPRs through whichever role the block takes:
 // the first build of this kernel had 5.7 k more v_readlane_b32 (SGPRs spilled to VGPR lanes, re-read inside the sweep loops) than its two
@@ -382,6 +401,8 @@ struct FusedArgs {
     const signed char* cls_cur; signed char* cls; const int* cur_list; const int* cur_count; int* next_list; int* next_count; int cap;
     const float* tgt; int* zero_count; int* host_total; int dummy_base; int* recent; int rblocks;
     float* objv_g;                            // (k_fused<.., false>) [cap + 32][W] the object waves' twists, first word = the launch's sequence number (P.objv_seq)
+    float* pair_g;                            // (k_fused<.., false>) [chunks] the tail pairs' global records (a PairX + 64 sequence words, PBRE_PAIR_SYNC), sequence number P.objv_seq
+    int ntail;                                // the last `ntail` 64-env chunks are stepped by a robot wave + an object wave (two blocks each) instead of one k_fast wave
 };
 // RT (round 6): Bullet's residual exit -- the 64-thread grid only (the pair mapping splits an env over two waves, the exit test is a maximum
 // over all of its rows); the row blocks' object waves idle (Core::step<RT> sweeps the object's rows itself).
@@ -422,6 +443,24 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
             return;
         }
         const int chunk = (int)blockIdx.x - rb;
+        if constexpr (!RT) {
+            // Tail pairs (round 6, last session).  A batch that fills every wave slot (131072 envs = 2048 k_fast waves on 2048 slots) runs as many
+            // k_fast waves in a SECOND round as the row / object waves hold slots, and those start when the first k_fast waves end: the step was
+            // first round + one lone k_fast wave (~90 + ~60 us) whatever the chain did.  The chunks that will be displaced -- the last ones of the
+            // grid, `ntail` of them by the host's hint -- are split like k_fast_pair's: an object wave (its block first) and a robot wave, which
+            // in the second round find free SIMDs and take the LONGER half instead of the sum.  Same operations on the same operands as k_fast
+            // (step_t<false, 1 / 2>): which mapping a chunk took is invisible in the data.
+            const int nfast = (a->n + FTPB - 1) / FTPB - a->ntail;
+            if (chunk >= nfast) {
+                const int t = chunk - nfast, tchunk = nfast + (t >> 1), role = (t & 1) ^ 1;      // even t: the object wave (dispatched first)
+                float* pg = (float*)((char*)a->pair_g + (size_t)tchunk * PBRE_PAIR_G_BYTES);
+                const int seq = a->P.objv_seq;
+                PBRE_LAUNDER(a);
+                pair_wave<MODE, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
+                                      a->cap, a->tgt, a->zero_count, *(PairX*)pg, tchunk, (int)threadIdx.x, role, pg, seq);
+                return;
+            }
+        }
         PBRE_LAUNDER(a);
         fast_wave<MODE, RT, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
                                a->cap, a->tgt, a->zero_count, chunk, (int)threadIdx.x);
@@ -440,6 +479,7 @@ struct EnvBuf {                       // a batch of state records with its class
     int cur = 0, ccur = 0;            // list[cur] / count + ccur*NB: complex envs of the current state, per class
     float* objv_g = nullptr;          // [cap + 32][W] k_fused's side records: the object waves' twists for the row waves of other blocks
     int objv_seq = 0;                 // sequence number of the last k_fused launch (the records' "complete" mark)
+    float* pair_g = nullptr;          // [(cap + 63) / 64] records of PBRE_PAIR_G_BYTES: k_fused's tail pairs (a PairX + per-lane sequence words)
     int* h_total = nullptr;           // pinned host int the device writes the complex-env count of the step it runs into
     int cap = 0;
 };
@@ -465,6 +505,9 @@ struct pbre_ctx {
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
     int pair = 2;                      // k_fast_pair (robot wave + object wave per 64 envs): 0 never, 1 whenever it applies, 2 while its waves fit two per SIMD (PBRE_PAIR)
     long launches_pair = 0;
+    int tail_pair = 1;                 // k_fused's 64-thread grid: the chunks the row waves displace into a second round as robot / object wave pairs (PBRE_TAIL_PAIR: 0 never,
+                                       // 1 by the hint, n > 1: always the last n chunks -- tests)
+    long launches_tail = 0;
     int fast3 = 2;                     // k_fast variant limited to 3 waves per SIMD: 0 never, 1 whenever complex envs are reported, 2 when they would displace k_fast waves (PBRE_FAST3)
                                        // -- only where the step is NOT one fused launch (PBRE_FUSED=0, residual exit, action_repeat's inner steps).  (Round 5 also measured the
                                        // spill-free build in two half-grid launches back to back, one wave per SIMD each: 0.21 ms against 0.177, profiles/r05_fast3_halves_ab.txt.)
@@ -559,7 +602,7 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
             if (timed) (void)hipEventRecord(ek[0], s);
             c->launches_fused++;
             FusedArgs fa = {c->dT, Pk, b.state, act, out, n, c->act_dim, c->ow, flags, b.cls + (size_t)cur * b.cap, b.cls + (size_t)nxt * b.cap, b.list[cur],
-                            b.count + cc * NB, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB, b.h_total, b.cap, b.count + 3 * NB, rblocks, b.objv_g};
+                            b.count + cc * NB, b.list[nxt], b.count + cn * NB, b.cap, b.tgt, b.count + cz * NB, b.h_total, b.cap, b.count + 3 * NB, rblocks, b.objv_g, b.pair_g, 0};
             if (pair) {
                 c->launches_pair++;
                 if constexpr (!RT)      // (`pair` is never set with the residual exit)
@@ -569,11 +612,23 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
                 // start over, behind a clear of the records: a record last written 2^31 launches ago must not look complete)
                 if (b.objv_seq == 0x7fffffff) {
                     if ((e = hipMemsetAsync(b.objv_g, 0, (size_t)(b.cap + 32) * W * sizeof(float), s)) != hipSuccess) return e;
+                    if ((e = hipMemsetAsync(b.pair_g, 0, (size_t)((b.cap + FTPB - 1) / FTPB) * PBRE_PAIR_G_BYTES, s)) != hipSuccess) return e;
                     b.objv_seq = 0;
                 }
                 b.objv_seq++;
                 fa.P.objv_seq = b.objv_seq;
-                hipLaunchKernelGGL((k_fused<MODE, false, RT>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
+                // tail pairs: as many of the last chunks as the row blocks' waves (the hint's complex envs: the coupled ones -- about a quarter,
+                // generously -- one per wave, the others four, an object wave per 12) will keep k_fast waves out of the first round
+                int ntail = 0;
+                if (!RT && c->tail_pair != 0 && c->cfg.action_repeat <= 1 && !(flags & PBRE_F_NO_OBJECT) && b.pair_g) {
+                    const int coupled = NB > 1 ? std::min(hint, 8 + hint / 4) : 0;
+                    const int rw = coupled + (hint - coupled + 3) / 4 + (hint + REPB - 1) / REPB;
+                    ntail = c->tail_pair > 1 ? c->tail_pair : (hint > 0 ? blocks + rw - 2 * c->n_simd : 0);
+                    ntail = std::max(0, std::min(ntail, blocks - 1));
+                }
+                fa.ntail = ntail;
+                if (ntail) c->launches_tail++;
+                hipLaunchKernelGGL((k_fused<MODE, false, RT>), dim3(FUSED_WAVES * rblocks + blocks + ntail), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }

@@ -27,6 +27,9 @@ struct HostLanesT {
     static F uni(const F& x) { return x; }
     static unsigned long long lanebits(const B& b) { unsigned long long m = 0; for (int i = 0; i < W && i < 64; i++) if (b.v[i]) m |= 1ull << i; return m; }
     static F setlane(const F& x, int j, const F& src) { F r = x; r.v[j] = src.v[j]; return r; }
+    // (device: one asm block -- compare, select, v_fmac with a DPP row broadcast; the same operations)
+    template <int J>
+    static F row_tail(F& rec, const F& recval, const F& bval, const F& m, const F& acc) { rec = setlane(rec, J, recval); return fma(bcast(bval, J), m, acc); }
     template <int N> struct RowStore {
         F v[N];
         void init() {}

@@ -1,6 +1,6 @@
-"""The cross-block spin-wait paths under contention.  Two hot paths wait, inside a kernel, for data another wave of the
+"""The cross-block spin-wait paths under contention.  Three hot paths wait, inside a kernel, for data another wave of the
 same or of another kernel publishes: k_fused<., false>'s row waves for the object wave's global side record (csrc/pbre_panda.hpp:
-PBRE_OBJV_SYNC) and the iCub pipeline's quads for kw_lane_ik's per-env marks (csrc/pbre_lane.hip: PBRE_IK_WAIT).  Both rest on "the producer
+PBRE_OBJV_SYNC), its tail pairs' robot waves for their object waves' records (PBRE_PAIR_SYNC; the first test covers both) and the iCub pipeline's quads for kw_lane_ik's per-env marks (csrc/pbre_lane.hip: PBRE_IK_WAIT).  Both rest on "the producer
 waits for nothing and is dispatched first"; both are bounded, and a wait that runs out poisons the env-step, which the NaN / Inf guard counts
 (pbre_kernel_info[12]).  Here the engine under test steps while a SECOND context keeps the GPU busy from another stream -- a 131072-env Panda
 batch, one launch of 2300 one-wave blocks after the other: every wave slot of the chip is contended for -- and must (a) never reach a bound
@@ -45,6 +45,8 @@ def test_one_launch_panda_step_beside_a_second_context(panda, hip_lib, monkeypat
     import torch
     dev = torch.device("cuda", 0)
     monkeypatch.setenv("PBRE_FUSED", "1")
+    # (tail pairs in every launch: by the hint they start once the device has REPORTED complex envs -- and these 320 launches are all enqueued before the first has run)
+    monkeypatch.setenv("PBRE_TAIL_PAIR", "236")
     n, warm, steps = 131072, 260, 60
     gen = torch.Generator(device=dev); gen.manual_seed(11)
     acts = torch.rand((warm + steps, n, 7), device=dev, generator=gen) * 2 - 1
@@ -63,6 +65,7 @@ def test_one_launch_panda_step_beside_a_second_context(panda, hip_lib, monkeypat
     torch.cuda.synchronize()
     assert solo.kernel_info()[13] >= warm + steps and solo.kernel_info()[10] == 0, "the solo run was not the 64-thread one-launch step"
     assert solo.kernel_info()[5] > 0, "no complex env: the row waves had nothing to wait for"
+    assert solo.kernel_info()[15] > 0, "no step had tail pairs: the robot waves' wait for their object waves' global records was not exercised"
     assert solo.kernel_info()[12] == 0
     busy, enqueue, s_b = _busy_engine(panda, hip_lib, torch, dev)
     test = fresh()

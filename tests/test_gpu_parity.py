@@ -536,6 +536,40 @@ def test_one_launch_step_is_bit_identical_to_the_two_kernel_step(panda, hip_lib,
     assert (ia[10] > 0) == (simple_env_mapping == "pair") and (ib[10] > 0) == (simple_env_mapping == "pair"), (ia, ib)
 
 
+def test_tail_pairs_of_the_one_launch_step_are_bit_identical(panda, hip_lib, monkeypatch):
+    """Round 6: in k_fused's 64-thread grid the last chunks of a machine-filling batch -- the ones the row waves keep out of the first round --
+    are stepped by a robot wave and an object wave (two one-wave blocks, the object's new pose through a global record + per-lane sequence
+    words) instead of one k_fast wave.  Forced here at a small size (PBRE_TAIL_PAIR=n: always the last n chunks; PBRE_PAIR=0: the 64-thread
+    grid): a full reset through each form, contact-rich states among the envs, 60 steps with auto-reset -- rows, states and classes bit for
+    bit those without tail pairs, no env-step lost to a wait (guard counter 0), and the sequence numbers' wrap in between."""
+    n = 4096
+    kw = dict(task=1, num_envs=n, obj_pose_rnd_std=0.05, tg_pose_rnd_std=0.2, lib=hip_lib, flags=_capi.F_AUTO_RESET, max_steps=40)
+    monkeypatch.setenv("PBRE_PAIR", "0")
+    monkeypatch.setenv("PBRE_OBJV_SEQ0", str(0x7fffffff - 230))       # (201 settle launches of the reset, then the wrap within the 60 steps)
+    monkeypatch.setenv("PBRE_TAIL_PAIR", "40")
+    a = _capi.Engine(panda["table"], **kw)
+    monkeypatch.setenv("PBRE_TAIL_PAIR", "0")
+    b = _capi.Engine(panda["table"], **kw)
+    oa, ob = a.reset(), b.reset()
+    assert np.array_equal(oa, ob) and np.array_equal(a.get_state(), b.get_state())
+    _, ora = parity.make_pair(_capi.Engine, hip_lib, panda["table"], 1)
+    base, _ = ora.batch_reset(1)
+    S = parity.contact_states(ora, panda, base[0], np.random.default_rng(1), 8, 8).astype(np.float32)
+    st = a.get_state()
+    st[n - len(S):, :S.shape[1]] = S              # (among the tail chunks' envs: lanes of complex envs idle in either mapping)
+    a.set_state(st); b.set_state(st)
+    rng = np.random.default_rng(9)
+    for _ in range(60):
+        act = rng.uniform(-1, 1, (n, a.act_dim)).astype(np.float32)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    assert np.array_equal(a.get_state(), b.get_state())
+    ia, ib = a.kernel_info(), b.kernel_info()
+    assert ia[15] >= 60 and ib[15] == 0, (ia, ib)      # steps (since the reset) that had tail pairs
+    assert ia[12] == 0 and ib[12] == 0, (ia, ib)       # NaN / Inf guard: no env-step lost to a wait that ran out
+
+
 def test_one_launch_step_with_thousands_of_complex_envs(panda, hip_lib, monkeypatch, simple_env_mapping):
     """The row part of k_fused when every slot makes several trips over the complex lists: 4096 envs, ALL of them in contact-rich states
     (robot-table, robot-object, joints at limits: both complex lists), the row kernel forced (F_COMPLEX_ROWS) -- several hundred work items
