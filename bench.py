@@ -764,7 +764,7 @@ def main():
         # per-env summary of the counter passes over this same command, scaled to this launch's env count.
         traffic, traffic_src = None, None
         fused = info[13] > 0
-        dom_kernel = "k_fused<7>" if fused else "k_fast<7>"
+        dom_kernel = ("k_fused<7, tail>" if (len(info) > 15 and info[15] > 0) else "k_fused<7>") if fused else "k_fast<7>"      # (tail: the instantiation with tail pairs)
         pmc, src = _profile("pmc_hbm", "step_kernel" if fused else "k_fast<7>")
         traffic_note = None
         if pmc:

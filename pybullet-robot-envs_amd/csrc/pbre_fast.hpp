@@ -69,6 +69,9 @@ typedef float pbre_f2 __attribute__((ext_vector_type(2)));
 #ifndef PBRE_RT_PROBE       // test builds: why a lane did not take the closed form of the residual exit (bit mask) and its state record
 #define PBRE_RT_PROBE(why, st) do {} while (0)
 #endif
+#ifndef PBRE_ROW_SUM_I      // sum of an int over the 16 lanes of a row wave's group (device build: pbre_panda.hpp; sweep<3> is never instantiated on the host)
+#define PBRE_ROW_SUM_I(x) (x)
+#endif
 #ifndef PBRE_PAIR_SYNC      // the robot wave of a pair waits for its object wave (device build: pbre_panda.hpp; never reached on the host)
 #define PBRE_PAIR_SYNC(px, ln) do {} while (0)
 #endif
@@ -1438,6 +1441,8 @@ struct Fast {
         t.Va = v3(0.f, 0.f, 0.f); t.Vl = v3(0.f, 0.f, 0.f); t.pe = v3(0.f, 0.f, 0.f);
         PBRE_UNROLL for (int k = 0; k < 9; k++) t.Re.m[k] = 0.f;
         M3 R[ND]; V3 p[ND];
+        V3 pk0 = v3(0.f, 0.f, 0.f), pk1 = pk0;      // ROLE 3: this lane's sphere(s) of the new state (<= 32 spheres: s and s + 16)
+        float pr0 = 0.f, pr1 = 0.f;
         PBRE_UNROLL for (int j = 0; j < ND; j++) {
             const int pj = Topo::parent(j) < 0 ? 0 : Topo::parent(j);
             V3 ax = v3(T.axis[0][j], T.axis[1][j], T.axis[2][j]);
@@ -1462,6 +1467,11 @@ struct Fast {
                 // exact sphere-box tests (a square root each) only run if some lane of the wave is not clearly far
                 const float sr = T.s_r[s];
                 if (ROLE == 1) { px->sc[3 * s][ln] = sc.x; px->sc[3 * s + 1][ln] = sc.y; px->sc[3 * s + 2][ln] = sc.z; }
+                else if (ROLE == 3) {      // row wave: lane s mod 16 of the group keeps sphere s, the tests follow the loop -- one pass for all spheres
+                    const bool mine = (s & 15) == ln;
+                    if (s < 16) { if (mine) { pk0 = sc; pr0 = sr; } } else if (mine) { pk1 = sc; pr1 = sr; }
+                    continue;
+                }
                 else if (obj_on) {
                     const V3 dd = sub(sc, op);
                     const float reach = sr + P.margin + orad;
@@ -1479,6 +1489,19 @@ struct Fast {
                 }
                 if (eo == j) { t.Re = R[j]; t.pe = p[j]; }
             }
+        }
+        if (ROLE == 3) {
+            // the 16 lanes of the group ran the same kinematics on the same inputs; each now tests the sphere(s) it kept -- the same two tests on
+            // the same operands as lane-per-env, one pass instead of `nspheres` -- and the counts are summed over the group: the same class
+            PBRE_UNROLL for (int k = 0; k < 2; k++) {
+                const int s = ln + 16 * k;
+                if (s < T.nspheres) {
+                    const V3 sc = k ? pk1 : pk0; const float sr = k ? pr1 : pr0;
+                    if (obj_on && sphere_obj_dist(P, sc, sr, op, Ro, oh) < P.margin) nO++;
+                    if (sphere_box_dist(sc, sr, tc, Id, th) < P.margin) nT++;
+                }
+            }
+            nO = PBRE_ROW_SUM_I(nO); nT = PBRE_ROW_SUM_I(nT);
         }
         t.cls = cls_of(nO, nT, lim); t.nT = nT; t.lim = lim;
         return t;
@@ -1668,7 +1691,8 @@ struct Fast {
                     oq.x = px->o[3][ln]; oq.y = px->o[4][ln]; oq.z = px->o[5][ln]; oq.w = px->o[6][ln];
                     tl.cls = cls_of(sweep_object(T, P, op, oq, bounds, px, ln), tl.nT, tl.lim);
                 }
-            } else tl = sweep<0>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds);
+            } else if (ROLE == 3) tl = sweep<3>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, false, nullptr, ln);      // (all 16 lanes of a row wave's group)
+            else tl = sweep<0>(T, P, q, want_obs ? qd : nullptr, op, oq, flags, bounds);
             first = false;
             cls = tl.cls;
             if (!want_obs) return;

@@ -31,6 +31,18 @@
             if (++spins_ > (1 << 22)) { ok_ = false; break; } } \
         PBRE_UNROLL for (int k_ = 0; k_ < 7; k_++) (px)->o[k_][ln] = ok_ ? (px)->g[k_ * 64 + (ln)] : __builtin_nanf(""); } } while (0)
 #define PBRE_COUNT_BAD(p) atomicAdd((p), 1)
+// (Fast::sweep<3>: an int summed over the 16 lanes of a row -- the DPP butterfly of DevLanes::sum on integers)
+static __device__ __forceinline__ int pbre_row_sum_i(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);     // row_mirror
+    return x;
+}
+#define PBRE_ROW_SUM_I(x) pbre_row_sum_i(x)
+#ifndef PBRE_ROW_FINISH16      // 1: Fast::finish of a row wave's env on all 16 lanes of its group (the collision spheres' tests of the new state's class
+#define PBRE_ROW_FINISH16 1    // one per lane, in one pass); 0: on lane 0 alone, as until round 6 (A/B)
+#endif
 // (Core::step, where `objv` and `P` are in scope: the side record is complete behind the block barrier -- its producer is a sibling wave of the
 // block, k_row_list -- or, P.objv_seq != 0, once its first word carries this launch's sequence number: the producer is a wave of another block,
 // k_fused's 64-thread grid.  P.objv_seq is uniform, so the barrier is not in divergent code.)
@@ -354,15 +366,17 @@ __device__ __forceinline__ void row_list_block(const Tables* __restrict__ T, con
             // whole L2 -- full of the state records the simple envs' waves are writing -- on every row wave's critical path
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             PBRE_PROBE_DECL
-            if (real && (vt & 15) == 0) {
+            // (PBRE_ROW_FINISH16: every lane of the group runs the same scalar code on the same inputs -- and stores the same values to the same
+            // addresses --, the sphere tests are dealt out one per lane (Fast::sweep<3>); lane 0 publishes the class)
+            if (real && (PBRE_ROW_FINISH16 || (vt & 15) == 0)) {
                 float q[NJ], qd[NJ];
                 PBRE_UNROLL for (int j = 0; j < NJ; j++) { q[j] = st[j]; qd[j] = st[16 + j]; }
                 FastD::V3 op; op.x = st[9]; op.y = st[10]; op.z = st[11];
                 FastD::Q4 oq; oq.x = st[12]; oq.y = st[13]; oq.z = st[14]; oq.w = st[15];
                 // (the tables through the constant address space: scalar loads although the row's stores precede them -- Fast::finish)
-                const int c = FastD::finish(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
-                                            P.env_id_base + (unsigned long long)env);
-                publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
+                const int c = FastD::finish<PBRE_ROW_FINISH16 ? 3 : 0>(*(const CTables*)T, P, st, q, qd, op, oq, (MODE & FastD::M_OBS) ? out + (size_t)env * ow : nullptr, MODE, flags,
+                                            P.env_id_base + (unsigned long long)env, false, nullptr, vt & 15);
+                if ((vt & 15) == 0) publish_class(env, c, cls, next_list, next_count, cap, P.bad_count);
             }
             PBRE_PROBE(11);     // Fast::finish on lane 0 of each row
         }
@@ -404,11 +418,26 @@ struct FusedArgs {
     float* pair_g;                            // (k_fused<.., false>) [chunks] the tail pairs' global records (a PairX + 64 sequence words, PBRE_PAIR_SYNC), sequence number P.objv_seq
     int ntail;                                // the last `ntail` 64-env chunks are stepped by a robot wave + an object wave (two blocks each) instead of one k_fast wave
 };
+// A tail pair's wave (k_fused<.., false, false, TAIL = true>): role 0 the robots, 1 the objects of the 64 envs of chunk `tchunk`.
+// (Measured, profiles/r06q / r06r: the two roles inlined beside the row roles and the k_fast role change the kernel's ONE register allocation -- the k_fast role came out
+// with 50 % more SGPR spills re-read in its loops, v_readlane 972 -> ~1500, and the FRESH step at 131072 envs went 0.0905 -> 0.097 ms -- so the kernel WITH tail pairs is an
+// instantiation of its own, launched only for steps that will have displaced chunks; a step without complex envs runs the kernel of before.  As a non-inlined FUNCTION
+// the pair's wave cost the kernel 656 B of scratch per lane for the call ABI and crashed on the device: dropped.)
+template <int MODE>
+__device__ __forceinline__ void tail_pair_role(const FusedArgs PBRE_CONST_AS* a, const Tables* __restrict__ T, int tchunk, int role, int ln) {
+    float* pg = (float*)((char*)a->pair_g + (size_t)tchunk * PBRE_PAIR_G_BYTES);
+    const int seq = a->P.objv_seq;
+    PBRE_LAUNDER(a);
+    pair_wave<MODE, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
+                          a->cap, a->tgt, a->zero_count, *(PairX*)pg, tchunk, ln, role, pg, seq);
+}
 // RT (round 6): Bullet's residual exit -- the 64-thread grid only (the pair mapping splits an env over two waves, the exit test is a maximum
 // over all of its rows); the row blocks' object waves idle (Core::step<RT> sweeps the object's rows itself).
-template <int MODE, bool PAIR, bool RT = false>
+// TAIL: the instantiation with tail pairs (64-thread grid, no residual exit), see tail_pair_role
+template <int MODE, bool PAIR, bool RT = false, bool TAIL = false>
 __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs args_in_kernarg_segment, const Tables* __restrict__ T) {
     static_assert(!(PAIR && RT), "the residual exit steps an env on one lane");
+    static_assert(!TAIL || (!PAIR && !RT), "tail pairs: the 64-thread grid of the default step");
     // (T -- the model constants -- is a kernel argument of its own: as a __restrict__ argument it cannot alias the pointers the roles load from the
     // struct, so the reads through it stay scalar loads behind the roles' stores; read from the struct, 50 of k_fast's s_load_dwordx16 / x8 table
     // reads had become per-lane global loads and the fast role spilled 488 bytes per lane)
@@ -443,7 +472,7 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
             return;
         }
         const int chunk = (int)blockIdx.x - rb;
-        if constexpr (!RT) {
+        if constexpr (TAIL) {
             // Tail pairs (round 6, last session).  A batch that fills every wave slot (131072 envs = 2048 k_fast waves on 2048 slots) runs as many
             // k_fast waves in a SECOND round as the row / object waves hold slots, and those start when the first k_fast waves end: the step was
             // first round + one lone k_fast wave (~90 + ~60 us) whatever the chain did.  The chunks that will be displaced -- the last ones of the
@@ -452,12 +481,8 @@ __global__ __launch_bounds__(PAIR ? RTPB : FTPB, 2) void k_fused(const FusedArgs
             // (step_t<false, 1 / 2>): which mapping a chunk took is invisible in the data.
             const int nfast = (a->n + FTPB - 1) / FTPB - a->ntail;
             if (chunk >= nfast) {
-                const int t = chunk - nfast, tchunk = nfast + (t >> 1), role = (t & 1) ^ 1;      // even t: the object wave (dispatched first)
-                float* pg = (float*)((char*)a->pair_g + (size_t)tchunk * PBRE_PAIR_G_BYTES);
-                const int seq = a->P.objv_seq;
-                PBRE_LAUNDER(a);
-                pair_wave<MODE, true>(T, *(const Params*)&a->P, a->state, a->actions, a->out, a->n, a->act_dim, a->ow, a->flags, a->cls_cur, a->cls, a->next_list, a->next_count,
-                                      a->cap, a->tgt, a->zero_count, *(PairX*)pg, tchunk, (int)threadIdx.x, role, pg, seq);
+                const int t = chunk - nfast;
+                tail_pair_role<MODE>(a, T, nfast + (t >> 1), (t & 1) ^ 1, (int)threadIdx.x);      // even t: the object wave (dispatched first)
                 return;
             }
         }
@@ -628,7 +653,12 @@ hipError_t launch_step_t(pbre_ctx* c, EnvBuf& b, int n, const float* act, float*
                 }
                 fa.ntail = ntail;
                 if (ntail) c->launches_tail++;
-                hipLaunchKernelGGL((k_fused<MODE, false, RT>), dim3(FUSED_WAVES * rblocks + blocks + ntail), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
+                bool launched = false;
+                if constexpr (!RT) if (ntail) {
+                    hipLaunchKernelGGL((k_fused<MODE, false, false, true>), dim3(FUSED_WAVES * rblocks + blocks + ntail), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
+                    launched = true;
+                }
+                if (!launched) hipLaunchKernelGGL((k_fused<MODE, false, RT>), dim3(FUSED_WAVES * rblocks + blocks), dim3(FTPB), 0, s, fa, (const Tables*)c->dT);
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (timed) { (void)hipEventRecord(ek[1], s); c->k_steps++; }

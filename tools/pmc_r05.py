@@ -23,8 +23,9 @@ def load(name, counters):
                 # (round 5: the step kernels carry a trailing bool, the solver-residual-threshold variant; `false` is the default build and
                 # keeps the names of the earlier rounds, `true` is marked RT)
                 name = m.group(1)
-                if name.startswith("k_fused"):      # (round 5: the one-launch step; its bool says which mapping the simple envs' waves have)
-                    name = name.replace(", false>", ">").replace(", true>", ", pair>")
+                if name.startswith("k_fused<"):      # k_fused<MODE, PAIR, RT, TAIL> (round 5: PAIR -- the simple envs' waves' mapping; round 6: RT, TAIL -- the instantiation with tail pairs)
+                    a = [x.strip() for x in name[len("k_fused<"):-1].split(",")] + ["false"] * 3
+                    name = "k_fused<" + a[0] + (", pair" if a[1] == "true" else "") + (", RT" if a[2] == "true" else "") + (", tail" if a[3] == "true" else "") + ">"
                 name = name.replace(", false>", ">").replace(", true>", ", RT>")
                 per[name][c].append(float(r["Counter_Value"]))
     return per
@@ -43,7 +44,7 @@ def summarise(per):
 fs, ws = summarise(load("FETCH_SIZE", {"FETCH_SIZE"})), summarise(load("WRITE_SIZE", {"WRITE_SIZE"}))
 hbm = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_r03.sh), bench.py stationary protocol, %d envs, 1 MI355X" % n_envs,
        "raw_kib": {"FETCH_SIZE": fs, "WRITE_SIZE": ws}}
-for kf in ("k_fused<7>", "k_fused<7, pair>", "k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>"):
+for kf in ("k_fused<7>", "k_fused<7, tail>", "k_fused<7, pair>", "k_fast<7, 3>", "k_fast<7, 2>", "k_fast_pair<7>"):
     if kf in fs and kf in ws:
         f_, w_ = fs[kf]["FETCH_SIZE"]["mean_stationary_third"] * 1024, ws[kf]["WRITE_SIZE"]["mean_stationary_third"] * 1024
         hbm[kf] = {"envs_per_launch": n_envs, "fetch_bytes": f_, "write_bytes": w_, "hbm_bytes": f_ + w_, "hbm_bytes_per_env_step": (f_ + w_) / n_envs,
@@ -52,7 +53,7 @@ for kf in ("k_fused<7>", "k_fused<7, pair>", "k_fast<7, 3>", "k_fast<7, 2>", "k_
 dom = "k_fast<7, 3>" if ("k_fast<7, 3>" in hbm and hbm["k_fast<7, 3>"]["launches"] >= hbm.get("k_fast<7, 2>", {"launches": 0})["launches"]) else "k_fast<7, 2>"
 if "k_fast_pair<7>" in hbm and dom not in hbm:
     dom = "k_fast_pair<7>"          # a batch the pair kernel steps (<= 65536 envs)
-for kf in ("k_fused<7, pair>", "k_fused<7>"):      # the step as one launch (round 5): that kernel IS the step
+for kf in ("k_fused<7, pair>", "k_fused<7>", "k_fused<7, tail>"):      # the step as one launch (round 5): that kernel IS the step
     if kf in hbm and hbm[kf]["launches"] >= hbm.get(dom, {"launches": 0})["launches"]:
         dom = kf
 if dom in hbm:
@@ -93,7 +94,7 @@ if "k_fast<7, 3>" not in out and "k_fast<7, 2>" not in out and "k_fast_pair<7>" 
 if "k_fast<7, 3>" in out or "k_fast<7, 2>" in out:
     d3, d2 = out.get("k_fast<7, 3>", {"launches": 0}), out.get("k_fast<7, 2>", {"launches": 0})
     out["k_fast<7>"] = dict(d3 if d3["launches"] >= d2["launches"] else d2, variant="k_fast<7, 3>" if d3["launches"] >= d2["launches"] else "k_fast<7, 2>")
-for kf in ("k_fused<7, pair>", "k_fused<7>"):
+for kf in ("k_fused<7, pair>", "k_fused<7>", "k_fused<7, tail>"):
     if kf in out and out[kf]["launches"] >= out.get("k_fast<7>", {"launches": 0})["launches"]:
         out["k_fast<7>"] = dict(out[kf], variant=kf)
         out["step_kernel"] = dict(out[kf], variant=kf, note="one launch per step: the complex envs' row waves (a few hundred, ~100 k instructions each, plus the idle "
