@@ -813,7 +813,7 @@ def main():
                                "note": "round 5: a step is ONE launch (k_fused: the complex envs' row waves + the simple envs' waves in one grid; PBRE_FUSED=0: the two kernels on two streams of rounds 1-4, "
                                        "where launch_step picks the 168-VGPR k_fast for steps in which the row waves would push waves of the 256-VGPR build into a second round, PBRE_FAST3); "
                                        "the simple envs' waves are the pair mapping (robot wave + object wave per 64 envs) for batches of up to 65536 envs per GPU (PBRE_PAIR); "
-                                       "round 6: in a machine-filling batch the last chunks -- as many as the row waves keep out of the first round -- are stepped as such pairs too (tail pairs, PBRE_TAIL_PAIR)"},
+                                       "round 6: PBRE_TAIL_PAIR=1 steps the last chunks of a machine-filling batch -- as many as the row waves keep out of the first round -- as such pairs too (tail pairs; measured +1.3 % here, -34 % with few complex envs: off by default)"},
             "contact_histogram_rank0": contact_hist,
             "nan_inf_guard": {"bad_env_steps_since_create": info[12], "note": "env-steps whose state was not finite (pbre_kernel_info[12]); such envs are returned with done = 1 and restarted"},
             "shards": shards,

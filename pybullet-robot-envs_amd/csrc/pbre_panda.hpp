@@ -530,8 +530,10 @@ struct pbre_ctx {
     int row_max = 4096;                // up to this many complex envs they are stepped by the row kernel (1 wave per 4 envs)
     int pair = 2;                      // k_fast_pair (robot wave + object wave per 64 envs): 0 never, 1 whenever it applies, 2 while its waves fit two per SIMD (PBRE_PAIR)
     long launches_pair = 0;
-    int tail_pair = 1;                 // k_fused's 64-thread grid: the chunks the row waves displace into a second round as robot / object wave pairs (PBRE_TAIL_PAIR: 0 never,
-                                       // 1 by the hint, n > 1: always the last n chunks -- tests)
+    int tail_pair = 0;                 // k_fused's 64-thread grid: the chunks the row waves displace into a second round as robot / object wave pairs (PBRE_TAIL_PAIR: 0 never,
+                                       // 1 by the hint, n > 1: always the last n chunks -- tests).  Measured (profiles/r06s_final_structure_ab.txt, r06t_bench_tail_pairs_by_hint.json):
+                                       // by the hint the stationary mix at 131072 envs gains 1.3 % (0.1494 -> 0.1476 ms) and a batch with FEW complex envs -- synchronised
+                                       // episode clocks, ~30 per step -- loses 34 % (0.091 -> 0.122: two dozen pairs at the end of the grid start when the first round ends): off
     long launches_tail = 0;
     int fast3 = 2;                     // k_fast variant limited to 3 waves per SIMD: 0 never, 1 whenever complex envs are reported, 2 when they would displace k_fast waves (PBRE_FAST3)
                                        // -- only where the step is NOT one fused launch (PBRE_FUSED=0, residual exit, action_repeat's inner steps).  (Round 5 also measured the
