@@ -1406,9 +1406,11 @@ struct Core {
 #ifndef PBRE_RT_FREE_STAGES          // 1: the clamp-free motor stages under the residual exit too.  Bit-identical (checksums of 300 steps at 16384 and
 #define PBRE_RT_FREE_STAGES 0        // 131072 envs) and no faster: 0.2207 against 0.2169 ms per step at 131072 envs, 0.1913 / 0.1910 at 16384
 #endif                               // (profiles/r06zc_rt_ab.txt) -- the RT row waves' time is not their motor rows.  Off.
-#ifndef PBRE_FREE_MOTOR_STAGES      // 0: A/B -- always the clamping stages; 2: clamp-free first in EVERY two-chain wave
-#define PBRE_FREE_MOTOR_STAGES 1      // 1: clamp-free first in the waves with robot-object rows only (measured, profiles/r05_chain_ab4.txt and
-#endif                                // r05_phase_probe_free_motor_stages.txt: a coupled env's sweeps get 17 % shorter and 2 % of those waves start over; among the
+#ifndef PBRE_FREE_MOTOR_STAGES      // 0: always the clamping stages (the default since the round-6 diet of the clamping row: 5 instructions on a 3-link chain against the
+#define PBRE_FREE_MOTOR_STAGES 0      // clamp-free row's 4 on 2 -- what is left to gain no longer pays for the waves that start over: 131072 envs stationary 0.1490 -> 0.1447 ms,
+#endif                                // 16384 envs 0.0987 -> 0.0983, three interleaved runs, profiles/r06u_free_stages_ab.txt); 2: clamp-free first in EVERY two-chain wave;
+                                      // 1 (rounds 5-6): clamp-free first in the waves with robot-object rows only (measured then, profiles/r05_chain_ab4.txt and
+                                      // r05_phase_probe_free_motor_stages.txt: a coupled env's sweeps get 17 % shorter and 2 % of those waves start over; among the
                                       // envs WITHOUT robot-object contact 12 % start over -- an arm pressed onto the table drives a blocked position motor
                                       // into its bound within the 150 sweeps -- and a wave that starts over is the longest of its step: 16384 envs 0.133 -> 0.140 ms)
             // clamp-free first unless a motor of the wave is force-limited (those do reach their bound) or the residual exit is on
