@@ -71,6 +71,10 @@ __device__ unsigned long long g_probe[64];
 // PBRE_PROBE_PATH in pbre_core.hpp), 16..19 robot-object slots, 20..23 object-table slots, 24..25 robot-table slots, 30 a joint-limit row -- to find the step's longest wave
 __device__ unsigned long long g_wtrace[16384][3];      // ticks, bits, address of the wave's (first group's) state record
 __device__ unsigned int g_wtrace_n;
+// (diagnosis of what a k_fast wave costs the row wave it shares a SIMD with, DESIGN 5.3: pbre_debug_wave_diag(mode) makes every k_fast wave of k_fused<., false>
+// hold its slot for ~90 us WITHOUT stepping its envs -- 1: asleep (no vector instruction, no code streamed), 2: a dependent v_fma chain in a 16-instruction loop (the vector
+// unit as busy as a latency-bound wave keeps it, no instruction-cache footprint), 3: the same chain as 128 KB of straight-line code; 0: the step as it is.  Trace builds only: the rows of the simple envs are garbage then.)
+__device__ int g_wave_diag;
 #define PBRE_PROBE_DECL unsigned wt_bits_ = 0u; unsigned long long wt_t0_ = __builtin_readcyclecounter(); (void)wt_bits_; (void)wt_t0_;
 #define PBRE_PROBE_PATH(k) (wt_bits_ |= 1u << (k))
 #define PBRE_TRACE_ROWS(ob, hl) (wt_bits_ |= ((((unsigned)(ob) >> 4) & 15u) << 16) | (((unsigned)(ob) & 15u) << 20) | ((((unsigned)(ob) >> 8) & 3u) << 24) | ((hl) ? 1u << 30 : 0u))
@@ -160,6 +164,41 @@ __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Pa
                                           int* __restrict__ next_count, int cap, const float* __restrict__ tgt, int* __restrict__ zero_count, int chunk, int ln) {
     const int env = chunk * FTPB + ln;
     if (chunk == 0 && ln < NB) zero_count[ln] = 0;   // the counter the step after this one appends to (idle now)
+#ifdef PBRE_WAVE_TRACE
+    if (g_wave_diag >= 6) {      // 6, 7, 8: the step as it is, but every k_fast wave starts ~3 / 6 / 12 us late (does the row waves' setup -- dependent loads -- get through before the herd?)
+        const unsigned long long t0 = __builtin_readcyclecounter(), wait = 6300ull << (g_wave_diag - 6);
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    } else
+    if (const int diag = g_wave_diag) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        float x = (float)ln;
+        while (__builtin_readcyclecounter() - t0 < 190000ull) {      // ~90 us at 2.1 GHz
+            if (diag == 1) __builtin_amdgcn_s_sleep(32);
+            else if (diag == 2) { PBRE_UNROLL for (int k = 0; k < 16; k++) x = __builtin_fmaf(x, 1.0000001f, 1e-9f); }
+            else if (diag == 4) {      // 4: EIGHT independent v_fma chains in a 64-instruction loop: the vector unit saturated (a k_fast wave's matrix squarings)
+                float y0 = x, y1 = x + 1.f, y2 = x + 2.f, y3 = x + 3.f, y4 = x + 4.f, y5 = x + 5.f, y6 = x + 6.f, y7 = x + 7.f;
+                PBRE_UNROLL for (int k = 0; k < 8; k++) {
+                    y0 = __builtin_fmaf(y0, 1.0000001f, 1e-9f); y1 = __builtin_fmaf(y1, 1.0000001f, 1e-9f); y2 = __builtin_fmaf(y2, 1.0000001f, 1e-9f); y3 = __builtin_fmaf(y3, 1.0000001f, 1e-9f);
+                    y4 = __builtin_fmaf(y4, 1.0000001f, 1e-9f); y5 = __builtin_fmaf(y5, 1.0000001f, 1e-9f); y6 = __builtin_fmaf(y6, 1.0000001f, 1e-9f); y7 = __builtin_fmaf(y7, 1.0000001f, 1e-9f);
+                }
+                x = ((y0 + y1) + (y2 + y3)) + ((y4 + y5) + (y6 + y7));
+            } else if (diag == 5) {    // 5: memory traffic: a simple env's lane reads its state record and writes it back (what k_fast moves per env, over and over)
+                if (env < n && cls_cur[env] == 0) {
+                    float* st_ = state + (size_t)env * STATE;
+                    PBRE_UNROLL for (int k = 0; k < STATE; k++) { const float v_ = __builtin_nontemporal_load(st_ + k); x += v_; __builtin_nontemporal_store(v_, st_ + k); }
+                }
+            } else {
+                // 3: the same dependent chain as 16384 instructions of straight-line code (128 KB: twice the instruction cache), streamed again and again
+#define PBRE_DIAG_R4(s) s s s s
+#define PBRE_DIAG_R16(s) PBRE_DIAG_R4(PBRE_DIAG_R4(s))
+#define PBRE_DIAG_R256(s) PBRE_DIAG_R16(PBRE_DIAG_R16(s))
+                PBRE_DIAG_R256(PBRE_DIAG_R16(PBRE_DIAG_R4(asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(1.0000001f), "v"(1e-9f));)))
+            }
+        }
+        if (x == 12345.678f) zero_count[0] = 1;      // (keeps the chain alive)
+        return;
+    }
+#endif
     if (env >= n || cls_cur[env] != 0) return;      // classes of the state this step starts from (the kernels of the step write the next array)
     int c;
     if constexpr (CT)

@@ -16,4 +16,8 @@ extern "C" int pbre_debug_wave_trace(unsigned long long* out, int max_records, i
     if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_wtrace_n), &z, sizeof z) != hipSuccess) return -1;
     return (int)n;
 }
+extern "C" int pbre_debug_wave_diag(int mode) {      // (see g_wave_diag)
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wave_diag), &mode, sizeof mode) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--envs", type=int, default=131072)
     ap.add_argument("--preroll", type=int, default=1100)
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--diag", type=int, default=0, help="after the pre-roll: 1 = the k_fast waves hold their slots asleep, 2 = busy with a dependent v_fma chain, "
+                    "instead of stepping their envs (pbre_debug_wave_diag; what sharing a SIMD costs the row waves, DESIGN 5.3) -- use a few steps only")
     ap.add_argument("--lib", default=os.path.join(ROOT, "pybullet-robot-envs_amd", "csrc", "libpbre_wtrace.so"))
     a = ap.parse_args()
     lib = _capi.load(a.lib)
@@ -48,6 +50,9 @@ def main():
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (3 * 16384))()
     lib.pbre_debug_wave_trace(buf, 16384, 1)
+    if a.diag:
+        assert lib.pbre_debug_wave_diag(C.c_int(a.diag)) == 0
+        print("diag mode %d: the k_fast waves do not step their envs from here on" % a.diag)
     rec = []
     persist, prev_so = [0, 0], set()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,11 +86,11 @@ def main():
           % (n, a.steps, np.median(ms) * 1e3, ms.mean() * 1e3, np.percentile(ms, 75) * 1e3, ms.max() * 1e3, int(np.median([x[1] for x in rec])), scale))
     groups = collections.defaultdict(list)
     for (m_, cnt, t, b, so, sw_) in rec:
-        groups[describe(b)].append((m_ * 1e3, t * scale))
+        groups[describe(b)].append((m_ * 1e3, t * scale, t))
     print("steps grouped by their longest row wave (Core::step start .. end of sweeps):")
     for g, v in sorted(groups.items(), key=lambda kv: -len(kv[1])):
         v = np.array(v)
-        print("  %4d steps  step time mean %6.1f us (min %6.1f max %6.1f)  longest wave mean %6.1f us   %s" % (len(v), v[:, 0].mean(), v[:, 0].min(), v[:, 0].max(), v[:, 1].mean(), g))
+        print("  %4d steps  step time mean %6.1f us (min %6.1f max %6.1f)  longest wave mean %6.1f us = %6.1f k ticks   %s" % (len(v), v[:, 0].mean(), v[:, 0].min(), v[:, 0].max(), v[:, 1].mean(), v[:, 2].mean() / 1e3, g))
     print("waves that started over: %d in all; %d of them (%.0f %%) step an env whose wave also started over in the step before" % (persist[1], persist[0], 100.0 * persist[0] / max(1, persist[1])))
     so = np.array([x[4] for x in rec])
     print("row waves that left the clamp-free stages for the clamping ones (bit 10), per step: mean %.2f" % np.mean([x[5] for x in rec]))
