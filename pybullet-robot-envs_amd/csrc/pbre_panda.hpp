@@ -73,7 +73,7 @@ __device__ unsigned long long g_wtrace[16384][3];      // ticks, bits, address o
 __device__ unsigned int g_wtrace_n;
 // (diagnosis of what a k_fast wave costs the row wave it shares a SIMD with, DESIGN 5.3: pbre_debug_wave_diag(mode) makes every k_fast wave of k_fused<., false>
 // hold its slot for ~90 us WITHOUT stepping its envs -- 1: asleep (no vector instruction, no code streamed), 2: a dependent v_fma chain in a 16-instruction loop (the vector
-// unit as busy as a latency-bound wave keeps it, no instruction-cache footprint), 3: the same chain as 128 KB of straight-line code; 0: the step as it is.  Trace builds only: the rows of the simple envs are garbage then.)
+// unit as busy as a latency-bound wave keeps it, no instruction-cache footprint), 3: the same chain as 128 KB of straight-line code, 4: eight independent chains, 5: state-record streaming, 9: 3 and 5 in turn; 0: the step as it is.  Trace builds only: the rows of the simple envs are garbage then.)
 __device__ int g_wave_diag;
 #define PBRE_PROBE_DECL unsigned wt_bits_ = 0u; unsigned long long wt_t0_ = __builtin_readcyclecounter(); (void)wt_bits_; (void)wt_t0_;
 #define PBRE_PROBE_PATH(k) (wt_bits_ |= 1u << (k))
@@ -165,7 +165,7 @@ __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Pa
     const int env = chunk * FTPB + ln;
     if (chunk == 0 && ln < NB) zero_count[ln] = 0;   // the counter the step after this one appends to (idle now)
 #ifdef PBRE_WAVE_TRACE
-    if (g_wave_diag >= 6) {      // 6, 7, 8: the step as it is, but every k_fast wave starts ~3 / 6 / 12 us late (does the row waves' setup -- dependent loads -- get through before the herd?)
+    if (g_wave_diag >= 6 && g_wave_diag <= 8) {      // 6, 7, 8: the step as it is, but every k_fast wave starts ~3 / 6 / 12 us late (does the row waves' setup -- dependent loads -- get through before the herd?)
         const unsigned long long t0 = __builtin_readcyclecounter(), wait = 6300ull << (g_wave_diag - 6);
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(16);
     } else
@@ -189,6 +189,11 @@ __device__ __forceinline__ void fast_wave(const Tables* __restrict__ T, const Pa
                 }
             } else {
                 // 3: the same dependent chain as 16384 instructions of straight-line code (128 KB: twice the instruction cache), streamed again and again
+                // 9: 3 and 5 in turn -- code streaming AND memory traffic (an evicted row loop is re-fetched through a busy L2?)
+                if (diag == 9 && env < n && cls_cur[env] == 0) {
+                    float* st_ = state + (size_t)env * STATE;
+                    PBRE_UNROLL for (int k = 0; k < STATE; k++) { const float v_ = __builtin_nontemporal_load(st_ + k); x += v_ * 0.f; __builtin_nontemporal_store(v_, st_ + k); }
+                }
 #define PBRE_DIAG_R4(s) s s s s
 #define PBRE_DIAG_R16(s) PBRE_DIAG_R4(PBRE_DIAG_R4(s))
 #define PBRE_DIAG_R256(s) PBRE_DIAG_R16(PBRE_DIAG_R16(s))
